@@ -1,0 +1,157 @@
+/* TEST INFRASTRUCTURE ONLY -- defined-order CPU restatement of the cluster scan arithmetic.
+ *
+ * Part of oracle/: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.  The product path (vamb_amd/) never links or calls it.
+ *
+ * Restates, with a FIXED floating-point evaluation order that the HIP kernels reproduce bit-for-bit:
+ *   - vamb/cluster.py:653-669  _normalize          -> vo_normalize
+ *   - vamb/cluster.py:672-676  _calc_distances     -> vo_distances
+ *   - vamb/cluster.py:606-637  sample_medoid       -> vo_scan (within list, local density)
+ *   - vamb/cluster.py:452-481  find_threshold head -> vo_scan (loner count, weighted histogram)
+ *   - vamb/cluster.py:640-650  _smaller_indices    -> vo_select
+ *
+ * Defined order (the contract shared with vamb_amd/csrc/cluster.hip):
+ *   dot(i)   = fmaf chain over k = 0..L-1 starting from +0.0f          (one rounding per step)
+ *   d(i)     = 0.5f - dot(i);  d(medoid) = 0
+ *   density  = sum_i llrint( (double)( len_i * (0.05f - d_i) ) * 2^16 )   exact int64, order-free
+ *   hist[b]  = sum_i llrint( (double) len_i * 2^8 )                      exact int64, order-free
+ *   bin b    : edge[b] <= d < edge[b+1] (last bin closed), edge = float32 linspace(0, 0.3, 61) as
+ *              torch.linspace produces it (== torch.histogram's searchsorted-right-minus-one rule)
+ * The reference sums density / histogram in fp32 in an unspecified (MKL / vectorised) order; the
+ * integer accumulation here is the correctly rounded version of the same sum.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define VO_NBINS 60
+#define VO_DENSITY_SCALE 65536.0
+#define VO_HIST_SCALE 256.0
+
+/* torch.linspace(0.0, 0.3, 61) in float32, bit patterns as ATen's (vectorised) linspace kernel
+ * produces them; these are also the edges torch.histogram(range=(0,0.3), bins=60) writes
+ * (cluster.py:288,475-481).  tests/test_oracle_cluster.py asserts table == torch.linspace. */
+static const uint32_t g_edge_bits[VO_NBINS + 1] = {
+    0x00000000u, 0x3ba3d70bu, 0x3c23d70bu, 0x3c75c290u, 0x3ca3d70bu, 0x3cccccceu,
+    0x3cf5c290u, 0x3d0f5c2au, 0x3d23d70bu, 0x3d3851ecu, 0x3d4cccceu, 0x3d6147afu,
+    0x3d75c290u, 0x3d851eb9u, 0x3d8f5c2au, 0x3d99999au, 0x3da3d70bu, 0x3dae147cu,
+    0x3db851ecu, 0x3dc28f5du, 0x3dccccceu, 0x3dd70a3eu, 0x3de147afu, 0x3deb8520u,
+    0x3df5c290u, 0x3e000001u, 0x3e051eb9u, 0x3e0a3d71u, 0x3e0f5c2au, 0x3e147ae2u,
+    0x3e19999au, 0x3e1eb852u, 0x3e23d70au, 0x3e28f5c3u, 0x3e2e147bu, 0x3e333333u,
+    0x3e3851ecu, 0x3e3d70a4u, 0x3e428f5cu, 0x3e47ae15u, 0x3e4ccccdu, 0x3e51eb85u,
+    0x3e570a3eu, 0x3e5c28f6u, 0x3e6147aeu, 0x3e666667u, 0x3e6b851fu, 0x3e70a3d8u,
+    0x3e75c290u, 0x3e7ae148u, 0x3e800000u, 0x3e828f5cu, 0x3e851eb9u, 0x3e87ae15u,
+    0x3e8a3d71u, 0x3e8ccccdu, 0x3e8f5c29u, 0x3e91eb85u, 0x3e947ae2u, 0x3e970a3eu,
+    0x3e99999au};
+static float g_edges[VO_NBINS + 1];
+static int g_edges_ready = 0;
+
+static void make_edges(void) {
+    memcpy(g_edges, g_edge_bits, sizeof(g_edges));
+    g_edges_ready = 1;
+}
+
+void vo_edges(float* out) {
+    if (!g_edges_ready) make_edges();
+    memcpy(out, g_edges, sizeof(g_edges));
+}
+
+/* bin index or -1 when d is outside [edge[0], edge[60]] (torch.histogram skips those) */
+int vo_bin(float d) {
+    if (!g_edges_ready) make_edges();
+    if (!(d >= g_edges[0]) || !(d <= g_edges[VO_NBINS])) return -1;
+    int b = (int)(d * 200.0f);
+    if (b < 0) b = 0;
+    if (b > VO_NBINS - 1) b = VO_NBINS - 1;
+    while (b > 0 && d < g_edges[b]) --b;
+    while (b < VO_NBINS - 1 && d >= g_edges[b + 1]) ++b;
+    return b;
+}
+
+/* cluster.py:653-669.  Row-major [n][L], in place. */
+void vo_normalize(float* m, int64_t n, int L) {
+    const float inv_l = (float)(1.0 / (double)L);
+    const float sqrt2 = (float)1.4142135623730951; /* tensor * (2**0.5): python double cast to f32 */
+    for (int64_t i = 0; i < n; ++i) {
+        float* row = m + i * (int64_t)L;
+        int allzero = 1;
+        for (int k = 0; k < L; ++k) if (row[k] != 0.0f) { allzero = 0; break; }
+        if (allzero) for (int k = 0; k < L; ++k) row[k] = inv_l;
+        float ss = 0.0f;
+        for (int k = 0; k < L; ++k) ss = fmaf(row[k], row[k], ss);
+        const float denom = sqrtf(ss) * sqrt2;
+        for (int k = 0; k < L; ++k) row[k] = row[k] / denom;
+    }
+}
+
+static inline float dist_to(const float* row, const float* q, int L) {
+    float acc = 0.0f;
+    for (int k = 0; k < L; ++k) acc = fmaf(row[k], q[k], acc);
+    return 0.5f - acc;
+}
+
+/* cluster.py:672-676 */
+void vo_distances(const float* m, int64_t n, int L, int64_t medoid, float* dist) {
+    const float* q = m + medoid * (int64_t)L;
+    for (int64_t i = 0; i < n; ++i) dist[i] = dist_to(m + i * (int64_t)L, q, L);
+    dist[medoid] = 0.0f;
+}
+
+/* One sample_medoid + the head of find_threshold, restricted to rows with kept[i] != 0
+ * (kept == NULL means all rows live, i.e. the reference's packed CPU path).
+ * within_idx receives the ascending row indices with d <= 0.05f (at most cap written; the true
+ * count is returned in *n_within).  dist (optional) receives every distance. */
+void vo_scan(const float* m, const float* lengths, const uint8_t* kept, int64_t n, int L,
+             int64_t medoid, float* dist, int64_t* hist_fx, int64_t* density_fx,
+             int64_t* n_within, int64_t* n_lt, int64_t* within_idx, int64_t cap) {
+    if (!g_edges_ready) make_edges();
+    const float* q = m + medoid * (int64_t)L;
+    int64_t dens = 0, nw = 0, nlt = 0;
+    for (int b = 0; b < VO_NBINS; ++b) hist_fx[b] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        float d = dist_to(m + i * (int64_t)L, q, L);
+        if (i == medoid) d = 0.0f;
+        if (dist) dist[i] = d;
+        if (kept && !kept[i]) continue;
+        if (d < 0.05f) ++nlt;
+        if (d <= 0.05f) {
+            const float p = lengths[i] * (0.05f - d);
+            dens += llrint((double)p * VO_DENSITY_SCALE);
+            if (within_idx && nw < cap) within_idx[nw] = i;
+            ++nw;
+        }
+        const int b = vo_bin(d);
+        if (b >= 0) hist_fx[b] += llrint((double)lengths[i] * VO_HIST_SCALE);
+    }
+    *density_fx = dens;
+    *n_within = nw;
+    *n_lt = nlt;
+}
+
+/* cluster.py:640-650: ascending indices of live rows with d <= threshold (float32 compare) */
+int64_t vo_select(const float* m, const uint8_t* kept, int64_t n, int L, int64_t medoid,
+                  float threshold, int64_t* out_idx, int64_t cap) {
+    const float* q = m + medoid * (int64_t)L;
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (kept && !kept[i]) continue;
+        float d = dist_to(m + i * (int64_t)L, q, L);
+        if (i == medoid) d = 0.0f;
+        if (d <= threshold) {
+            if (cnt < cap) out_idx[cnt] = i;
+            ++cnt;
+        }
+    }
+    return cnt;
+}
+
+/* vambcore.overwrite_matrix contract (vambtools.py:291-321): order-preserving row compaction */
+int64_t vo_compact_rows(float* m, const uint8_t* mask, int64_t n, int L) {
+    int64_t w = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!mask[i]) continue;
+        if (w != i) memmove(m + w * (int64_t)L, m + i * (int64_t)L, sizeof(float) * (size_t)L);
+        ++w;
+    }
+    return w;
+}
