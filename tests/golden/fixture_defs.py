@@ -1,0 +1,169 @@
+"""Shared definitions of the golden-vector cases (inputs are regenerated from seeds; only the
+reference's OUTPUTS are stored in the .npz files next to this module).
+
+Used by ``make_golden.py`` (which runs the real reference, build container only) and by the tests
+(which never touch /root/reference).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from vamb_amd import synth  # noqa: E402
+
+GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
+
+# ------------------------------------------------------------------------------------------------
+# Cluster cases: name -> (matrix, lengths, kwargs)
+# ------------------------------------------------------------------------------------------------
+CLUSTER_CASES = {
+    # reference test/test_cluster.py:11-13 (almost all "loner")
+    "test_cluster_py": dict(kind="uniform", seed=5, n=1024, L=40),
+    # reference test/test_results.py:131-132 latent (3-d), lengths from the VAE fixture seed
+    "test_results_py": dict(kind="results", seed=15, n=1000, L=3),
+    "blob_s008_n2000": dict(kind="blob", seed=1, n=2000, L=32, sigma=0.08, k=20),
+    "blob_s050_n3000": dict(kind="blob", seed=2, n=3000, L=32, sigma=0.5, k=30),
+    "blob_s025_n1500_L64": dict(kind="blob", seed=3, n=1500, L=64, sigma=0.25, k=15),
+    "blob_s008_n10000": dict(kind="blob", seed=4, n=10000, L=32, sigma=0.08, k=None),
+    # degenerate rows: all-zero rows (cluster.py:664-666) and exact duplicates
+    "blob_zero_dup": dict(kind="zerodup", seed=6, n=600, L=16, sigma=0.1, k=6),
+    # small window so that the PVR relaxation / restart-from-best-seed path runs often
+    "blob_s050_window": dict(kind="blob", seed=8, n=1200, L=32, sigma=0.5, k=12,
+                             kwargs=dict(windowsize=20, minsuccesses=5, maxsteps=10)),
+}
+
+
+def cluster_inputs(name):
+    c = CLUSTER_CASES[name]
+    kw = dict(c.get("kwargs", {}))
+    if c["kind"] == "uniform":
+        rng = np.random.RandomState(c["seed"])
+        mat = rng.random_sample((c["n"], c["L"])).astype(np.float32)
+        lens = rng.randint(500, 1000, size=c["n"])
+    elif c["kind"] == "results":
+        rng = np.random.RandomState(c["seed"])
+        mat = rng.random_sample((c["n"], c["L"])).astype(np.float32) - np.float32(0.5)
+        lens = np.random.RandomState(c["seed"]).randint(2000, 5000, c["n"])
+    elif c["kind"] == "blob":
+        mat, _ = synth.blob_latent(c["n"], c["L"], c["sigma"], c["seed"], c["k"])
+        lens = synth.lengths(c["n"], c["seed"])
+        kw.setdefault("rng_seed", c["seed"])
+    elif c["kind"] == "zerodup":
+        mat, _ = synth.blob_latent(c["n"], c["L"], c["sigma"], c["seed"], c["k"])
+        lens = synth.lengths(c["n"], c["seed"])
+        mat[[3, 77, 401]] = 0.0
+        mat[100:110] = mat[100]
+        mat[500] = mat[20]
+        kw.setdefault("rng_seed", c["seed"])
+    else:
+        raise KeyError(c["kind"])
+    return np.ascontiguousarray(mat), lens, kw
+
+
+KIND_CODE = {"normal": 0, "loner": 1, "fallback": 2}
+
+
+def pack_stream(clusters):
+    """list of Cluster-like objects -> dict of flat arrays (compact, exact)."""
+    med = np.array([int(c.medoid) for c in clusters], np.int64)
+    seed = np.array([int(c.seed) for c in clusters], np.int64)
+    kind = np.array([KIND_CODE[c.kind_str] for c in clusters], np.uint8)
+    radius = np.array([np.nan if c.radius is None else float(c.radius) for c in clusters], np.float64)
+    opvr = np.array([np.nan if c.observed_pvr is None else float(c.observed_pvr) for c in clusters], np.float64)
+    mpvr = np.array([float(c.maximal_pvr) for c in clusters], np.float64)
+    succ = np.array([int(c.successes) for c in clusters], np.int64)
+    att = np.array([int(c.attempts) for c in clusters], np.int64)
+    sizes = np.array([len(c.members) for c in clusters], np.int64)
+    if len(clusters):
+        members = np.concatenate([np.sort(np.asarray(c.members, dtype=np.int64)) for c in clusters])
+    else:
+        members = np.zeros(0, np.int64)
+    return dict(medoid=med, seed=seed, kind=kind, radius=radius, observed_pvr=opvr, maximal_pvr=mpvr,
+                successes=succ, attempts=att, sizes=sizes, members=members.astype(np.int32))
+
+
+def streams_equal(a, b):
+    """Exact comparison of two packed streams; returns (ok, message)."""
+    for key in ("medoid", "seed", "kind", "successes", "attempts", "sizes", "members"):
+        if a[key].shape != b[key].shape or not np.array_equal(a[key], b[key]):
+            n = min(len(a[key]), len(b[key]))
+            bad = np.flatnonzero(a[key][:n] != b[key][:n])
+            first = int(bad[0]) if len(bad) else n
+            return False, f"{key} differs (first at {first}; lens {len(a[key])} vs {len(b[key])})"
+    for key in ("radius", "observed_pvr", "maximal_pvr"):
+        if not np.array_equal(a[key], b[key], equal_nan=True):
+            return False, f"{key} differs"
+    return True, "identical"
+
+
+# ------------------------------------------------------------------------------------------------
+# make_dataloader cases
+# ------------------------------------------------------------------------------------------------
+PREP_CASES = {
+    "prep_s6": dict(n=64, nsamples=6, seed=11),
+    "prep_s1": dict(n=40, nsamples=1, seed=12),
+    "prep_zero_rows": dict(n=50, nsamples=4, seed=13, zero_rows=[0, 7, 33]),
+}
+
+
+def prep_inputs(name):
+    c = PREP_CASES[name]
+    ab, tnf, lens, _ = synth.features(c["n"], c["nsamples"], c["seed"], k=4)
+    for r in c.get("zero_rows", []):
+        ab[r] = 0.0
+    return ab, tnf, lens
+
+
+# ------------------------------------------------------------------------------------------------
+# VAE cases
+# ------------------------------------------------------------------------------------------------
+VAE_CASES = {
+    # small architecture, dropout on (injected masks), 3 optimizer steps
+    "vae_small_drop": dict(n=48, batch=24, nsamples=6, nhiddens=[48, 40], nlatent=8, dropout=0.2,
+                           alpha=None, beta=200.0, seed=21, steps=3, store="full"),
+    # no dropout, different widths, ragged batch (not a multiple of anything)
+    "vae_small_nodrop": dict(n=37, batch=37, nsamples=5, nhiddens=[33, 17], nlatent=5, dropout=0.0,
+                             alpha=0.3, beta=50.0, seed=22, steps=3, store="full"),
+    # single sample: ce weight 0, softmax over one column (encode.py:334-335)
+    "vae_single_sample": dict(n=30, batch=16, nsamples=1, nhiddens=[24, 24], nlatent=4, dropout=0.0,
+                              alpha=None, beta=200.0, seed=23, steps=4, store="full"),
+    # three hidden layers
+    "vae_three_layers": dict(n=40, batch=20, nsamples=7, nhiddens=[32, 24, 16], nlatent=6, dropout=0.2,
+                             alpha=None, beta=200.0, seed=24, steps=4, store="full"),
+    # the default architecture (512, 512, latent 32) -- outputs summarised, weights never stored
+    "vae_default_arch": dict(n=96, batch=64, nsamples=14, nhiddens=[512, 512], nlatent=32, dropout=0.2,
+                             alpha=None, beta=200.0, seed=25, steps=3, store="summary"),
+}
+
+
+def vae_inputs(name):
+    """Raw features for a VAE case (normalised by the *reference's* make_dataloader in make_golden;
+    the normalised tensors are stored in the fixture so VAE tests do not depend on our prep)."""
+    c = VAE_CASES[name]
+    ab, tnf, lens, _ = synth.features(c["n"], c["nsamples"], c["seed"], k=4)
+    return ab, tnf, lens
+
+
+def vae_randomness(name):
+    """Injected dropout keep-masks and reparameterisation noise for every step of a case.
+
+    masks[step] is a list of 2*len(nhiddens) boolean arrays in application order (encoder hidden
+    layers, then decoder hidden layers); eps[step] is float32 [batch, nlatent]."""
+    c = VAE_CASES[name]
+    rng = np.random.RandomState(c["seed"] + 1000)
+    widths = list(c["nhiddens"]) + list(c["nhiddens"][::-1])
+    masks, eps = [], []
+    for _ in range(c["steps"]):
+        masks.append([rng.random_sample((c["batch"], w)) >= c["dropout"] for w in widths])
+        eps.append(rng.standard_normal((c["batch"], c["nlatent"])).astype(np.float32))
+    return masks, eps
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))

@@ -1,0 +1,152 @@
+#!/usr/bin/env python
+"""Generate the golden vectors in this directory by running the REAL reference code.
+
+Build-container only: needs /root/reference (read-only) and loads
+``vamb/{vambtools,cluster,encode}.py`` through ``oracle/ref_harness.py`` (stubs only for loguru,
+vambcore.overwrite_matrix and dadaptation.DAdaptAdam -- the latter restated, PARITY UNPINNED).
+The GPU box never runs this; tests read the committed .npz files.
+
+    python tests/golden/make_golden.py            # regenerate everything
+    python tests/golden/make_golden.py cluster    # only one family (cluster | prep | vae)
+
+Environment recorded in golden_manifest.json (torch / numpy versions, thread count).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, HERE)
+
+import fixture_defs as fd  # noqa: E402
+import ref_harness  # noqa: E402
+import vae_oracle  # noqa: E402
+
+
+def gen_cluster(cl):
+    out = {}
+    for name in fd.CLUSTER_CASES:
+        mat, lens, kw = fd.cluster_inputs(name)
+        clusters = list(cl.ClusterGenerator(mat.copy(), lens, **kw))
+        packed = fd.pack_stream(clusters)
+        np.savez_compressed(os.path.join(HERE, f"cluster_{name}.npz"), **packed)
+        kinds = np.bincount(packed["kind"], minlength=3)
+        out[name] = dict(n_clusters=len(clusters), normal=int(kinds[0]), loner=int(kinds[1]),
+                         fallback=int(kinds[2]))
+        print("cluster", name, out[name])
+    return out
+
+
+def gen_prep(en):
+    out = {}
+    for name in fd.PREP_CASES:
+        ab, tnf, lens = fd.prep_inputs(name)
+        dl = en.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=16)
+        d, t, a, w = (x.numpy().copy() for x in dl.dataset.tensors)
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), depths=d, tnf=t, total_abundance=a, weights=w)
+        out[name] = dict(n=len(d))
+        print("prep", name, d.shape)
+    return out
+
+
+def gen_vae(en):
+    import torch
+    import dadaptation  # the stub installed by ref_harness (oracle/dadapt_restated.py)
+
+    out = {}
+    for name, c in fd.VAE_CASES.items():
+        ab, tnf, lens = fd.vae_inputs(name)
+        dl = en.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=c["batch"])
+        depths, tnfz, totab, weights = dl.dataset.tensors
+        B = c["batch"]
+        vae = en.VAE(c["nsamples"], nhiddens=list(c["nhiddens"]), nlatent=c["nlatent"], alpha=c["alpha"],
+                     beta=c["beta"], dropout=c["dropout"], seed=0)
+        st0 = vae_oracle.init_state(c["nsamples"], c["nhiddens"], c["nlatent"], c["seed"])
+        vae.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st0.items()})
+        masks, eps = fd.vae_randomness(name)
+        mask_q, eps_q = [], []
+
+        class InjectedDropout(torch.nn.Module):
+            def forward(self, x):
+                if not self.training or c["dropout"] == 0:
+                    return x
+                m = mask_q.pop(0)
+                scale = np.float32(1.0) / (np.float32(1.0) - np.float32(c["dropout"]))
+                return x * torch.from_numpy(m.astype(np.float32) * scale)
+
+        vae.dropoutlayer = InjectedDropout()
+        vae.reparameterize = lambda mu: (mu + torch.from_numpy(eps_q.pop(0))) if eps_q else mu
+        opt = dadaptation.DAdaptAdam(vae.parameters(), decouple=True)
+        rec = dict(depths=depths.numpy().copy(), tnf=tnfz.numpy().copy(), total_abundance=totab.numpy().copy(),
+                   weights=weights.numpy().copy())
+        losses, ds = [], []
+        vae.train()
+        for step in range(c["steps"]):
+            mask_q[:] = list(masks[step])
+            eps_q[:] = [eps[step]]
+            d_in, t_in, a_in, w_in = depths[:B], tnfz[:B], totab[:B], weights[:B]
+            opt.zero_grad()
+            do, to, ao, mu = vae(d_in, t_in, a_in)
+            ls = vae.calc_loss(d_in, do, t_in, to, a_in, ao, mu, w_in)
+            ls[0].backward()
+            if step == 0:
+                rec["step0_depths_out"] = do.detach().numpy().copy()
+                rec["step0_tnf_out"] = to.detach().numpy().copy()
+                rec["step0_ab_out"] = ao.detach().numpy().copy()
+                rec["step0_mu"] = mu.detach().numpy().copy()
+                for pname, p in vae.named_parameters():
+                    g = p.grad.detach().numpy()
+                    if c["store"] == "full":
+                        rec["grad0/" + pname] = g.copy()
+                    else:
+                        rec["grad0_norm/" + pname] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                        rec["grad0_head/" + pname] = g.reshape(-1)[:64].copy()
+            opt.step()
+            losses.append([float(x.item()) for x in ls])
+            ds.append(opt.param_groups[0]["d"])
+        rec["losses"] = np.array(losses, np.float64)
+        rec["d_after"] = np.array(ds, np.float64)
+        rec["numerator_weighted"] = np.array(opt.param_groups[0]["numerator_weighted"], np.float64)
+        for k, v in vae.state_dict().items():
+            v = v.numpy()
+            if c["store"] == "full" or v.size <= 4096:
+                rec["final/" + k] = v.copy()
+            else:
+                rec["final_norm/" + k] = np.array(np.sqrt((v.astype(np.float64) ** 2).sum()))
+                rec["final_head/" + k] = v.reshape(-1)[:64].copy()
+        vae.eval()
+        rec["latent"] = vae.encode(dl)
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+        out[name] = dict(loss0=losses[0][0], loss_last=losses[-1][0], d_last=ds[-1])
+        print("vae", name, out[name])
+    return out
+
+
+def main():
+    which = sys.argv[1:] or ["cluster", "prep", "vae"]
+    import torch
+
+    torch.set_num_threads(1)  # deterministic MKL reductions for the stored vectors
+    vt, cl, en = ref_harness.load_reference()
+    manifest_path = os.path.join(HERE, "golden_manifest.json")
+    manifest = json.load(open(manifest_path)) if os.path.exists(manifest_path) else {}
+    manifest["environment"] = dict(torch=torch.__version__, numpy=np.__version__, threads=1,
+                                   reference="RasmussenLab/vamb @ /root/reference (v5.0.x)")
+    if "cluster" in which:
+        manifest["cluster"] = gen_cluster(cl)
+    if "prep" in which:
+        manifest["prep"] = gen_prep(en)
+    if "vae" in which:
+        manifest["vae"] = gen_vae(en)
+    json.dump(manifest, open(manifest_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

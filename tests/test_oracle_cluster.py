@@ -1,0 +1,80 @@
+"""The cluster oracle (oracle/cluster_oracle.py + oracle/cluster_scan.c) against the golden cluster
+streams produced by the REAL reference ClusterGenerator (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+import fixture_defs as fd
+import cluster_oracle as co
+
+
+def test_edge_table_is_torch_linspace(oracle_lib):
+    import torch
+
+    e = np.zeros(61, np.float32)
+    oracle_lib.vo_edges(e.ctypes.data)
+    assert np.array_equal(e, torch.linspace(0.0, 0.3, 61).numpy())
+
+
+def test_binning_matches_torch_histogram(oracle_lib):
+    import torch
+
+    edges = torch.linspace(0.0, 0.3, 61).numpy()
+    rng = np.random.RandomState(0)
+    v = np.concatenate([rng.random_sample(3000).astype(np.float32) * 0.32 - 0.01, edges,
+                        np.nextafter(edges, np.float32(1)), np.nextafter(edges, np.float32(-1))]).astype(np.float32)
+    for x in v:
+        h = torch.histogram(torch.tensor([x]), bins=60, range=(0.0, 0.3))[0].numpy()
+        nz = np.flatnonzero(h)
+        ref = int(nz[0]) if len(nz) else -1
+        assert oracle_lib.vo_bin(float(x)) == ref, float(x)
+
+
+def test_normalize_matches_torch(oracle_lib):
+    import torch
+
+    rng = np.random.RandomState(3)
+    m = rng.standard_normal((500, 32)).astype(np.float32)
+    m[7] = 0
+    ours = co.normalize(m.copy())
+    t = torch.from_numpy(m.copy())
+    zero = (t == 0).all(dim=1)
+    t[zero] = 1 / t.shape[1]
+    t /= t.norm(dim=1).reshape(-1, 1) * (2 ** 0.5)
+    # same formula, different summation order inside norm(): a few ulp
+    assert np.abs(ours - t.numpy()).max() < 2e-7
+    assert np.allclose((ours.astype(np.float64) ** 2).sum(axis=1), 0.5, atol=1e-6)
+
+
+def test_smoothing_table_matches_reference_constant():
+    # value of vamb/cluster.py:39-73 _NORMALPDF (float32 tensor * python 0.005)
+    assert co.NORMALPDF.dtype == np.float32 and len(co.NORMALPDF) == 31
+    assert abs(float(co.NORMALPDF.sum()) - 1.0) < 1e-3
+    assert co.NORMALPDF[15] == np.float32(0.005) * np.float32(3.98942280e01)
+
+
+@pytest.mark.parametrize("name", list(fd.CLUSTER_CASES))
+def test_oracle_reproduces_reference_stream(oracle_lib, name):
+    mat, lens, kw = fd.cluster_inputs(name)
+    got = fd.pack_stream(list(co.OracleClusterGenerator(mat.copy(), lens, **kw)))
+    want = fd.load("cluster_" + name)
+    ok, msg = fd.streams_equal(got, want)
+    assert ok, msg
+
+
+def test_every_point_clustered_once(oracle_lib):
+    mat, lens, kw = fd.cluster_inputs("blob_s008_n2000")
+    seen = np.zeros(len(mat), int)
+    for c in co.OracleClusterGenerator(mat, lens, **kw):
+        seen[c.members] += 1
+    assert (seen == 1).all()
+
+
+def test_bad_params(oracle_lib):
+    mat, lens, _ = fd.cluster_inputs("blob_zero_dup")
+    for kw in (dict(maxsteps=0), dict(windowsize=0), dict(minsuccesses=0), dict(minsuccesses=5, windowsize=4)):
+        with pytest.raises(ValueError):
+            co.OracleClusterGenerator(mat, lens, **kw)
+    with pytest.raises(ValueError):
+        co.OracleClusterGenerator(mat.astype(np.float64), lens)
+    with pytest.raises(ValueError):
+        co.OracleClusterGenerator(mat[:0], lens[:0])

@@ -1,0 +1,72 @@
+"""The numpy VAE oracle (oracle/vae_oracle.py, explicit backward + restated D-Adapt-Adam) against
+golden vectors recorded from the REAL reference ``vamb.encode.VAE`` under torch autograd
+(tests/golden/make_golden.py).  Tolerances are float32-roundoff class."""
+import numpy as np
+import pytest
+
+import fixture_defs as fd
+import vae_oracle as vo
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("name", list(fd.VAE_CASES))
+def test_oracle_matches_reference(name):
+    c = fd.VAE_CASES[name]
+    g = fd.load(name)
+    masks, eps = fd.vae_randomness(name)
+    B = c["batch"]
+    st0 = vo.init_state(c["nsamples"], c["nhiddens"], c["nlatent"], c["seed"])
+    m = vo.OracleVAE(c["nsamples"], c["nhiddens"], c["nlatent"], c["alpha"], c["beta"], c["dropout"], state=st0)
+    d, t, a, w = g["depths"], g["tnf"], g["total_abundance"], g["weights"]
+    for step in range(c["steps"]):
+        do, to, ao, mu = m.forward(d[:B], t[:B], a[:B], eps=eps[step], masks=masks[step], train=True)
+        ls = m.calc_loss(d[:B], do, t[:B], to, a[:B], ao, mu, w[:B])
+        grads = m.backward()
+        if step == 0:
+            assert rel(mu, g["step0_mu"]) < 5e-6
+            assert rel(do, g["step0_depths_out"]) < 5e-6
+            assert rel(to, g["step0_tnf_out"]) < 5e-6
+            assert rel(ao, g["step0_ab_out"]) < 5e-6
+            for n in m.names:
+                if c["store"] == "full":
+                    assert rel(grads[n], g["grad0/" + n]) < 2e-5, n
+                else:
+                    nrm = np.sqrt((grads[n] ** 2).sum())
+                    assert abs(nrm - g["grad0_norm/" + n]) / g["grad0_norm/" + n] < 2e-5, n
+                    assert rel(grads[n].reshape(-1)[:64], g["grad0_head/" + n]) < 2e-4, n
+        m.dadapt_step()
+        assert rel(np.array(ls), g["losses"][step]) < 2e-6
+        assert abs(m.d - g["d_after"][step]) / g["d_after"][step] < 2e-5
+    assert abs(m.numerator_weighted - g["numerator_weighted"]) <= 2e-5 * abs(g["numerator_weighted"]) + 1e-30
+    for k, v in m.state.items():
+        if v.dtype.kind != "f":
+            assert int(v) == int(g["final/" + k])
+        elif "final/" + k in g:
+            assert rel(v, g["final/" + k]) < 5e-6, k
+        else:
+            nrm = np.sqrt((v ** 2).sum())
+            assert abs(nrm - g["final_norm/" + k]) / g["final_norm/" + k] < 5e-6, k
+    lat = m.encode(d, t, a)
+    assert lat.dtype == np.float32 and lat.shape == (c["n"], c["nlatent"])
+    assert (lat.view(np.uint32) & 0xFFF == 0).all()
+    # 12 cleared mantissa bits: one unit of the kept mantissa is 2^-11 relative
+    assert np.abs(lat - g["latent"]).max() <= np.abs(g["latent"]).max() * 2.0 ** -10
+
+
+def test_loss_weight_broadcast_quirk():
+    """encode.py:347: [B] * [B,1] broadcasts; loss.mean() == mean(rows) * mean(weights)."""
+    c = fd.VAE_CASES["vae_small_nodrop"]
+    g = fd.load("vae_small_nodrop")
+    st0 = vo.init_state(c["nsamples"], c["nhiddens"], c["nlatent"], c["seed"])
+    m = vo.OracleVAE(c["nsamples"], c["nhiddens"], c["nlatent"], c["alpha"], c["beta"], c["dropout"], state=st0)
+    masks, eps = fd.vae_randomness("vae_small_nodrop")
+    B = c["batch"]
+    d, t, a, w = (g[k][:B] for k in ("depths", "tnf", "total_abundance", "weights"))
+    do, to, ao, mu = m.forward(d, t, a, eps=eps[0], masks=masks[0])
+    loss, ab, ce, sse, kld = m.calc_loss(d, do, t, to, a, ao, mu, w)
+    assert abs(loss - (ab + ce + sse + kld) * w.astype(np.float64).mean()) < 1e-12
