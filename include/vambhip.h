@@ -1,0 +1,177 @@
+/* vambhip.h -- C ABI of libvambhip.so, the MI355X (gfx950) hot path of Vamb's
+ * VAE-train -> encode -> cluster pipeline.
+ *
+ * The reference (RasmussenLab/vamb v5.0.x) has no FFI for this path: its boundary is the Python class
+ * surface `vamb.encode.VAE` / `vamb.encode.make_dataloader` / `vamb.cluster.ClusterGenerator`, whose
+ * native arithmetic lives in torch, `dadaptation` and the Rust wheel `vambcore`.  This header is the
+ * C boundary a maintainer binds instead (ctypes stub: vamb_amd/_lib.py).  Each entry
+ * point names the reference code it replaces (file:line into /root/reference).
+ *
+ * Conventions
+ *   - every function returns 0 (VH_OK) or a negative vh_status; vh_last_error() gives the message of
+ *     the last failure on the calling thread.  No C++ exception crosses the boundary.
+ *   - host pointers passed in are owned by the caller and only read/written during the call;
+ *     all device memory is owned by the handle and released by *_destroy.
+ *   - one host thread per handle; the library serialises its work on one HIP stream per handle.
+ *   - float means IEEE binary32, row-major, C-contiguous.
+ */
+#ifndef VAMBHIP_H
+#define VAMBHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    VH_OK = 0,
+    VH_ERR_INVALID = -1,  /* bad argument (the Python layer raises ValueError)        */
+    VH_ERR_HIP = -2,      /* HIP runtime error (message carries hipGetErrorString)    */
+    VH_ERR_NOMEM = -3,    /* device allocation failed                                 */
+    VH_ERR_STATE = -4     /* call not valid in the handle's current state             */
+} vh_status;
+
+const char* vh_last_error(void);
+const char* vh_version(void);
+/* number of visible HIP devices (0 with an error message when there is no GPU) */
+int vh_device_count(int* n);
+/* bind the calling process to a device (LOCAL_RANK under torch.distributed.run) */
+int vh_set_device(int device);
+
+/* =============================================================================================
+ * Cluster scan  (replaces the torch/MKL + vambcore arithmetic inside vamb/cluster.py)
+ * ============================================================================================= */
+#define VH_NBINS 60
+/* fixed-point scales of the exact integer accumulators (see DESIGN.md "defined-order arithmetic") */
+#define VH_DENSITY_SCALE 65536.0
+#define VH_HIST_SCALE 256.0
+
+typedef struct vh_clu vh_clu;
+
+/* Raw accumulators of one medoid scan.  density = density_fx / VH_DENSITY_SCALE rounded to float;
+ * histogram[b] = hist_fx[b] / VH_HIST_SCALE rounded to float. */
+typedef struct {
+    int64_t density_fx;       /* sum len_i * (0.05f - d_i) over live rows with d_i <= 0.05f   (cluster.py:628-629) */
+    int64_t hist_fx[VH_NBINS];/* length-weighted histogram of live d_i in [0, 0.3], torch.histogram edge rule (cluster.py:467-481) */
+    int64_t n_within;         /* live rows with d_i <= 0.05f                                   (cluster.py:621-626) */
+    int64_t n_lt;             /* live rows with d_i <  0.05f  -> loner test                    (cluster.py:457)     */
+} vh_scan_result;
+
+/* ClusterGenerator.__init__ (cluster.py:234-292): upload [n][L] latent rows + float32 lengths,
+ * normalise on device unless `normalized` (cluster.py:653-669), keep the matrix resident in HBM in
+ * column-major (SoA) form.  If normalized_out != NULL it receives the normalised row-major matrix
+ * (the reference normalises the caller's array in place when destroy=True). */
+int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, int normalized,
+                  float* normalized_out, vh_clu** out);
+int vh_clu_destroy(vh_clu* h);
+/* current number of physical rows (live + masked-out) */
+int vh_clu_rows(vh_clu* h, int64_t* n_rows, int64_t* n_live);
+
+/* sample_medoid (cluster.py:606-637) + head of find_threshold (cluster.py:452-481) for k medoids in
+ * ONE pass over the matrix.  medoid_rows[j] is the physical row whose distance is forced to 0
+ * (cluster.py:675), or -1 when that row lives in another shard.  queries == NULL: the query vectors
+ * are the rows medoid_rows[j] of this handle; otherwise queries is a host [k][L] array. 1 <= k <= 32. */
+int vh_clu_scan(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries, vh_scan_result* out);
+
+/* _smaller_indices (cluster.py:640-650) / the `within` list of sample_medoid (cluster.py:621-626):
+ * ascending physical rows that are live and have d <= threshold (float32 compare).  Writes at most
+ * cap indices, returns the true count in *n_out.  remove != 0 also clears their live flag
+ * (kept_mask[point] = 0, cluster.py:308-309). */
+int vh_clu_select(vh_clu* h, int64_t medoid_row, const float* query, float threshold, int remove,
+                  int64_t* out_rows, int64_t cap, int64_t* n_out);
+/* kept_mask[point] = 0 for explicit rows (cluster.py:308-309) */
+int vh_clu_remove(vh_clu* h, const int64_t* rows, int64_t n);
+/* pack (cluster.py:318-335; vambcore.overwrite_matrix, vambtools.py:291-321): order-preserving
+ * compaction of matrix / lengths by the live mask; afterwards every row is live. */
+int vh_clu_pack(vh_clu* h, int64_t* new_rows);
+/* copy rows out (row-major [k][L]); rows == NULL: the whole physical matrix [n_rows][L] */
+int vh_clu_get_rows(vh_clu* h, const int64_t* rows, int64_t k, float* out);
+int vh_clu_get_kept(vh_clu* h, uint8_t* out /* [n_rows] */);
+/* bytes of matrix + lengths + mask one scan pass reads (for roofline accounting) and the duration in
+ * milliseconds of the last scan/select kernel measured with HIP events on the handle's stream */
+int vh_clu_last_kernel_ms(vh_clu* h, float* ms);
+int vh_clu_set_timing(vh_clu* h, int enable);
+
+
+/* =============================================================================================
+ * VAE  (replaces the torch / dadaptation arithmetic inside vamb/encode.py)
+ * ============================================================================================= */
+#define VH_MAX_HIDDEN_LAYERS 8
+#define VH_NTNF 103
+
+typedef struct vh_vae vh_vae;
+
+/* VAE.__init__ arguments after defaulting (encode.py:171-223).  Validation (ValueError cases of
+ * encode.py:182-208) is repeated by the library and reported as VH_ERR_INVALID. */
+typedef struct {
+    int32_t nsamples;
+    int32_t nlatent;
+    int32_t nlayers;                          /* len(nhiddens) */
+    int32_t nhiddens[VH_MAX_HIDDEN_LAYERS];
+    float alpha;
+    float beta;
+    float dropout;
+    uint64_t seed;                            /* seeds parameter init, dropout and reparameterisation noise */
+} vh_vae_config;
+
+int vh_vae_create(const vh_vae_config* cfg, vh_vae** out);
+int vh_vae_destroy(vh_vae* h);
+
+/* Parameters and buffers by their torch state_dict names (encode.py:226-249): e.g.
+ * "encoderlayers.0.weight" [nh0][D], "encodernorms.1.running_var" [nh1], "mu.bias" [L],
+ * "outputlayer.weight" [D][nh0], "...num_batches_tracked" [1] (as float).  n is the logical element
+ * count (row-major); VH_ERR_INVALID if name or n does not match.  VAE.save / VAE.load (encode.py:486-541). */
+int vh_vae_param_size(vh_vae* h, const char* name, int64_t* n);
+int vh_vae_set_param(vh_vae* h, const char* name, const float* data, int64_t n);
+int vh_vae_get_param(vh_vae* h, const char* name, float* data, int64_t n);
+/* gradient of the last training step for a parameter (autograd's p.grad after loss.backward(), encode.py:418) */
+int vh_vae_get_grad(vh_vae* h, const char* name, float* data, int64_t n);
+
+/* The four tensors of make_dataloader's TensorDataset (encode.py:129-137), uploaded once and kept
+ * resident: depths [n][nsamples], tnf [n][103], abundance [n][1], weights [n][1]. */
+int vh_vae_set_dataset(vh_vae* h, const float* depths, const float* tnf, const float* abundance,
+                       const float* weights, int64_t n);
+
+/* One optimisation step = the body of trainepoch's batch loop (encode.py:390-425): forward, loss,
+ * backward, DAdaptAdam.step (dadaptation==3.2, encode.py:578), on dataset rows `rows[0..batch)`.
+ * eps   : NULL (device generator) or host [batch][nlatent] reparameterisation noise (encode.py:277)
+ * masks : NULL (device generator) or host keep-masks, for every hidden layer in application order
+ *         (encoder then decoder) a [batch][nhidden] uint8 block, concatenated
+ * losses: out, the five means calc_loss returns (loss, ab_sse, ce, sse, kld) (encode.py:350-356) */
+int vh_vae_train_step(vh_vae* h, const int64_t* rows, int64_t batch, const float* eps, const uint8_t* masks,
+                      double losses[5]);
+/* A whole epoch (encode.py:390-437): perm holds n_batches*batch dataset rows; the five per-batch means
+ * are averaged over the batches exactly like the epoch log line.  One host sync per epoch. */
+int vh_vae_train_epoch(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, double loss_means[5]);
+
+/* VAE.forward on explicit host inputs (encode.py:306-314); training != 0 uses batch statistics,
+ * dropout and noise like a torch module in train() mode (and updates the BatchNorm running stats).
+ * Outputs are host arrays [batch][nsamples], [batch][103], [batch][1], [batch][nlatent]; any may be NULL. */
+int vh_vae_forward(vh_vae* h, const float* depths, const float* tnf, const float* abundance, int64_t batch,
+                   int training, const float* eps, const uint8_t* masks, float* depths_out, float* tnf_out,
+                   float* abundance_out, float* mu_out);
+
+/* VAE.encode (encode.py:442-484): eval-mode encoder over the resident dataset, low 12 mantissa bits
+ * cleared (vambtools.py:324-330); latent is a host [n][nlatent] array. */
+int vh_vae_encode(vh_vae* h, float* latent);
+
+/* D-Adapt-Adam group state (d, numerator_weighted, k) */
+int vh_vae_opt_state(vh_vae* h, double* d, double* numerator_weighted, int64_t* k);
+
+/* Optional HIP-event probe around the forward GEMM of encoder layer `layer` (bench.py roofline):
+ * after vh_vae_train_epoch, *ms_total is the summed duration of the probed launches and *launches
+ * their number; *flops_per_launch = 2*batch*K*N of that GEMM. */
+int vh_vae_set_probe(vh_vae* h, int enable, int layer);
+int vh_vae_probe_result(vh_vae* h, double* ms_total, int64_t* launches, double* flops_per_launch);
+
+/* Diagnostic: run one GEMM instantiation on host data.  C[M][N] = sum_k A(m,k) B(n,k) (+bias[n] if
+ * bias != NULL).  a_kc / b_kc: operand stored [rows][K] (1) or [K][rows] (0).  tile: 0 = 64x128,
+ * 1 = 128x128, 2 = 128x32.  splits > 1 exercises the split-K slabs (summed on the host side of the call). */
+int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, const float* bias, float* C,
+                  int M, int N, int K, int splits, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAMBHIP_H */

@@ -13,6 +13,7 @@ Environment recorded in golden_manifest.json (torch / numpy versions, thread cou
 """
 from __future__ import annotations
 
+import hashlib
 import json
 import os
 import sys
@@ -36,6 +37,9 @@ def gen_cluster(cl):
         mat, lens, kw = fd.cluster_inputs(name)
         clusters = list(cl.ClusterGenerator(mat.copy(), lens, **kw))
         packed = fd.pack_stream(clusters)
+        # np.argsort is unstable (cluster.py:275): record the seed order this CPU produced
+        packed["order_sha256"] = np.array(hashlib.sha256(
+            np.argsort(lens)[::-1].astype(np.int64).tobytes()).hexdigest())
         np.savez_compressed(os.path.join(HERE, f"cluster_{name}.npz"), **packed)
         kinds = np.bincount(packed["kind"], minlength=3)
         out[name] = dict(n_clusters=len(clusters), normal=int(kinds[0]), loner=int(kinds[1]),

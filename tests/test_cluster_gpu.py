@@ -1,0 +1,154 @@
+"""GPU parity tests of the cluster path: libvambhip (HIP kernels through the C ABI) against the
+oracle on the same seeded inputs -- bit-exact for every integer accumulator and for the emitted
+cluster stream -- and against the reference's golden streams."""
+import ctypes
+import hashlib
+
+import numpy as np
+import pytest
+
+import cluster_oracle as co
+import fixture_defs as fd
+from vamb_amd import _lib, cluster as vc, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(mat, lens, normalized=False, out=None):
+    return vc.HipScanBackend(np.ascontiguousarray(mat), np.asarray(lens).astype(np.float32), normalized, out)
+
+
+@pytest.mark.parametrize("n,L", [(1, 32), (5, 3), (1023, 32), (1025, 40), (4096, 64), (3000, 15), (777, 130)])
+def test_normalize_bit_exact(oracle_lib, n, L):
+    rng = np.random.RandomState(n + L)
+    m = rng.standard_normal((n, L)).astype(np.float32)
+    if n > 3:
+        m[2] = 0
+    want = co.normalize(m.copy())
+    got = m.copy()
+    b = _mk(m, np.ones(n), False, got)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(b.matrix().view(np.uint32), want.view(np.uint32))
+    b.close()
+
+
+@pytest.mark.parametrize("n,L,k", [(1, 8, 1), (700, 32, 1), (5000, 32, 3), (5000, 40, 8), (20000, 32, 12),
+                                   (20000, 64, 25), (3000, 3, 32), (2049, 15, 17)])
+def test_scan_accumulators_bit_exact(oracle_lib, n, L, k):
+    lat, _ = synth.blob_latent(n, L, 0.2, seed=n + k, k=max(2, n // 300))
+    lens = synth.lengths(n, 3)
+    m = co.normalize(lat.copy())
+    lf = lens.astype(np.float32)
+    kept = np.ones(n, np.uint8)
+    rng = np.random.RandomState(1)
+    dead = rng.choice(n, size=n // 5, replace=False) if n > 10 else np.array([], int)
+    kept[dead] = 0
+    b = _mk(m, lens, True)
+    b.remove(dead)
+    live = np.flatnonzero(kept)
+    meds = [int(x) for x in rng.choice(live, size=min(k, len(live)), replace=False)]
+    got = b.scan(meds)
+    for med, g in zip(meds, got):
+        w = co.scan(m, lf, kept, med, want_dist=False)
+        assert g.n_within == w["n_within"] and g.n_lt == w["n_lt"], med
+        assert np.array_equal(g.hist_fx, w["hist_fx"]), med
+        assert g.density == co.density_value(w["density_fx"]), med
+        for thr in (0.05, 0.06, 0.123456, 0.3):
+            rows = b.select(med, thr, remove=False)
+            assert np.array_equal(rows, co.select(m, kept, med, thr)), (med, thr)
+    b.close()
+
+
+def test_select_remove_and_pack(oracle_lib):
+    n, L = 9000, 32
+    lat, _ = synth.blob_latent(n, L, 0.1, seed=9, k=9)
+    lens = synth.lengths(n, 9)
+    m = co.normalize(lat.copy())
+    kept = np.ones(n, np.uint8)
+    b = _mk(m, lens, True)
+    ref_m, ref_len = m.copy(), lens.astype(np.float32)
+    for med in (10, 4000, 8999):
+        if not kept[med]:
+            continue
+        rows = b.select(med, 0.1, remove=True)
+        want = co.select(ref_m, kept, med, 0.1)
+        assert np.array_equal(rows, want)
+        kept[want] = 0
+    got_kept = np.empty(n, np.uint8)
+    _lib.check(b.lib.vh_clu_get_kept(b.h, _lib.ptr(got_kept)))
+    assert np.array_equal(got_kept, kept)
+    new_n = b.pack()
+    keepb = kept.astype(bool)
+    assert new_n == keepb.sum()
+    assert np.array_equal(b.matrix().view(np.uint32), ref_m[keepb].view(np.uint32))
+    # scans after packing see the compacted rows and lengths
+    m2, l2 = np.ascontiguousarray(ref_m[keepb]), np.ascontiguousarray(ref_len[keepb])
+    g = b.scan([5])[0]
+    w = co.scan(m2, l2, None, 5, want_dist=False)
+    assert g.n_within == w["n_within"] and np.array_equal(g.hist_fx, w["hist_fx"])
+    assert g.density == co.density_value(w["density_fx"])
+    b.close()
+
+
+@pytest.mark.parametrize("name", list(fd.CLUSTER_CASES))
+def test_stream_matches_oracle_and_reference(oracle_lib, name):
+    mat, lens, kw = fd.cluster_inputs(name)
+    got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
+    want = fd.pack_stream(list(co.OracleClusterGenerator(mat.copy(), lens, **kw)))
+    ok, msg = fd.streams_equal(got, want)
+    assert ok, "vs oracle: " + msg
+    golden = fd.load("cluster_" + name)
+    order_hash = hashlib.sha256(np.argsort(lens)[::-1].astype(np.int64).tobytes()).hexdigest()
+    if "order_sha256" in golden and str(golden["order_sha256"]) != order_hash:
+        pytest.skip("np.argsort tie order differs on this CPU (unstable sort, cluster.py:275); "
+                    "oracle comparison passed")
+    ok, msg = fd.streams_equal(got, golden)
+    assert ok, "vs reference golden: " + msg
+
+
+def test_forced_packing_same_stream(oracle_lib, monkeypatch):
+    monkeypatch.setattr(vc.ClusterGenerator, "PACK_MIN_ROWS", 64)
+    mat, lens, kw = fd.cluster_inputs("blob_s050_window")
+    got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
+    ok, msg = fd.streams_equal(got, fd.pack_stream(list(co.OracleClusterGenerator(mat.copy(), lens, **kw))))
+    assert ok, msg
+
+
+def test_reference_unit_test_semantics():
+    # reference test/test_cluster.py:38-91 against the GPU path
+    rng = np.random.RandomState(5)
+    data = rng.random_sample((1024, 40)).astype(np.float32)
+    lens = rng.randint(500, 1000, size=1024)
+    with pytest.raises(ValueError):
+        vc.ClusterGenerator(data.astype(np.float64), lens)
+    g = vc.ClusterGenerator(data, lens)
+    assert g is iter(g)
+    first = next(g)
+    assert isinstance(first, vc.Cluster) and isinstance(first.members, np.ndarray)
+    clusters = list(g) + [first]
+    assert sum(len(c.members) for c in clusters) == len(data)
+    assert set(int(i) for c in clusters for i in c.members) == set(range(len(data)))
+    cp = data.copy()
+    g2 = vc.ClusterGenerator(cp, lens, destroy=True)
+    assert np.all(np.abs(cp - g2.matrix.numpy()) < 1e-6)
+    assert np.any(np.abs(data - cp) > 0.001)
+
+
+def test_large_sweep_properties(oracle_lib):
+    """BASELINE-sized shard (200k x 32): size-independent properties instead of an oracle run."""
+    n = 200_000
+    lat, labels = synth.blob_latent(n, 32, 0.08, seed=1)
+    lens = synth.lengths(n, 1)
+    seen = np.zeros(n, np.int32)
+    purity_ok = 0
+    clusters = 0
+    for c in vc.ClusterGenerator(lat, lens, destroy=True, rng_seed=1):
+        seen[c.members] += 1
+        assert np.all(np.diff(c.members) > 0)           # ascending, unique
+        assert int(c.medoid) in set(c.members.tolist()) or c.kind_str != "loner"
+        lab = labels[c.members]
+        purity_ok += np.bincount(lab).max() == len(lab)
+        clusters += 1
+    assert (seen == 1).all()                              # every contig emitted exactly once
+    assert clusters >= synth.n_genomes(n) * 0.9
+    assert purity_ok >= 0.95 * clusters

@@ -1,0 +1,76 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/vambhip.h declares;
+the ctypes table in vamb_amd/_lib.py lists exactly the same names.  No compute calls here."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    so = os.path.join(ROOT, "vamb_amd", "libvambhip.so")
+    if not os.path.exists(so):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "vamb_amd", "csrc", "build.py")])
+    from vamb_amd import _lib
+
+    return _lib.load()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "vambhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vh_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_matches_ctypes_table(built_lib):
+    from vamb_amd import _lib
+
+    assert header_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_every_symbol_is_exported(built_lib):
+    for name in header_symbols():
+        assert hasattr(built_lib, name), name
+    assert built_lib.vh_version().startswith(b"vambhip")
+
+
+def test_invalid_arguments_become_valueerror(built_lib):
+    import ctypes
+
+    from vamb_amd import _lib
+
+    # argument validation happens before any device work, so this runs without a GPU
+    with pytest.raises(ValueError):
+        _lib.check(built_lib.vh_clu_create(None, None, 0, 0, 0, None, ctypes.byref(ctypes.c_void_p())))
+    assert b"NULL" in built_lib.vh_last_error() or b"observation" in built_lib.vh_last_error()
+
+
+def test_edge_table_in_library_source_is_torch_linspace():
+    import torch
+
+    src = open(os.path.join(ROOT, "vamb_amd", "csrc", "cluster.hip")).read()
+    block = src[src.index("c_edge_bits[VH_NBINS + 1] = {"):]
+    block = block[: block.index("};")]
+    bits = np.array([int(x, 16) for x in re.findall(r"0x([0-9a-f]{8})u", block)], dtype=np.uint32)
+    assert len(bits) == 61
+    assert np.array_equal(bits.view(np.float32), torch.linspace(0.0, 0.3, 61).numpy())
+
+
+def test_no_gpu_fails_loudly(built_lib):
+    from vamb_amd import _lib
+
+    try:
+        n = _lib.device_count()
+    except _lib.VambHipError:
+        n = 0
+    if n > 0:
+        pytest.skip("a GPU is visible")
+    from vamb_amd import cluster as vc
+
+    with pytest.raises(_lib.VambHipError):
+        vc.ClusterGenerator(np.ones((4, 3), np.float32), np.ones(4))

@@ -1,0 +1,76 @@
+"""vamb_amd.encode.make_dataloader / set_batchsize (host numpy, reference encode.py:33-146) against
+tensors produced by the REAL reference (tests/golden/prep_*.npz) and the reference's own unit-test
+properties (test/test_encode.py:8-119)."""
+import numpy as np
+import pytest
+import torch
+
+import fixture_defs as fd
+from vamb_amd import encode as ve
+
+
+@pytest.mark.parametrize("name", list(fd.PREP_CASES))
+def test_matches_reference_tensors(name):
+    ab, tnf, lens = fd.prep_inputs(name)
+    dl = ve.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=16)
+    g = fd.load(name)
+    got = [t.numpy() for t in dl.dataset.tensors]
+    for arr, key in zip(got, ("depths", "tnf", "total_abundance", "weights")):
+        assert arr.dtype == np.float32 and arr.shape == g[key].shape
+        assert np.array_equal(arr, g[key]), key   # same numpy calls in the same order: bit-exact
+
+
+def test_bad_args():
+    tnfs = np.random.random((111, 103)).astype(np.float32)
+    rpkm = np.random.random((111, 14)).astype(np.float32)
+    lens = np.random.randint(2000, 5000, size=111)
+    with pytest.raises(ValueError):
+        ve.make_dataloader([[1, 2, 3]], tnfs, lens, batchsize=32)
+    with pytest.raises(ValueError):
+        ve.make_dataloader(rpkm, [[1, 2, 3]], lens, batchsize=32)
+    with pytest.raises(ValueError):
+        ve.make_dataloader(rpkm, tnfs, lens, batchsize=0)
+    with pytest.raises(ValueError):
+        ve.make_dataloader(np.random.random((110,)).astype(np.float32), tnfs, lens, batchsize=32)
+    with pytest.raises(ValueError):
+        ve.make_dataloader(rpkm.astype(np.float64), tnfs, lens, batchsize=32)
+    z = rpkm.copy()
+    z[:, 3] = 0
+    with pytest.raises(ValueError):
+        ve.make_dataloader(z, tnfs, lens, batchsize=32)
+
+
+def test_destroy_normalisation_and_iteration():
+    rng = np.random.RandomState(0)
+    tnfs = rng.random_sample((111, 103)).astype(np.float32)
+    rpkm = rng.random_sample((111, 14)).astype(np.float32)
+    lens = rng.randint(2000, 5000, size=111)
+    c_r, c_t = rpkm.copy(), tnfs.copy()
+    ve.make_dataloader(rpkm, tnfs, lens, batchsize=32)
+    assert np.array_equal(rpkm, c_r) and np.array_equal(tnfs, c_t)
+    dl = ve.make_dataloader(c_r, c_t, lens, batchsize=32, destroy=True)
+    assert np.any(np.abs(rpkm - c_r) > 1e-4) and np.any(np.abs(tnfs - c_t) > 1e-4)
+    assert np.all(np.abs(c_t.mean(axis=0)) < 1e-5) and np.all(np.abs(c_t.std(axis=0) - 1) < 1e-5)
+    assert np.all(np.abs(c_r.sum(axis=1) - 1) < 1e-5) and np.all(c_r >= 0)
+    batch = next(iter(dl))
+    assert len(batch) == 4
+    for m in batch:
+        assert m.dtype == torch.float32 and m.shape[0] == 32
+    assert len(dl) == 111 // 32 and dl.batch_size == 32
+    enc = ve.set_batchsize(dl, 64, 111, encode=True)
+    assert len(enc) == 2 and enc.batch_size == 64
+    first = next(iter(enc))[1].numpy()
+    assert np.array_equal(first, c_t[:64])          # ordered, not shuffled
+    dbl = ve.set_batchsize(dl, 64, 111)
+    assert len(dbl) == 1                             # drop_last
+
+
+def test_single_sample():
+    rng = np.random.RandomState(1)
+    tnfs = rng.random_sample((111, 103)).astype(np.float32)
+    single = rng.random_sample((111, 1)).astype(np.float32)
+    cp = single.copy()
+    dl = ve.make_dataloader(single, tnfs, rng.randint(2000, 5000, size=111), batchsize=32, destroy=True)
+    assert abs(abs(single.mean()) - 1.0) < 1e-6 and abs(single.std()) < 1e-6
+    assert (torch.argsort(dl.dataset.tensors[2], dim=0, stable=True)
+            == torch.argsort(torch.from_numpy(cp), dim=0, stable=True)).all().item()

@@ -1,0 +1,124 @@
+"""ctypes binding of ``libvambhip.so`` (C ABI declared in ``include/vambhip.h``).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` / ``vamb_amd/csrc/build.py``.
+There is NO fallback: if the library is missing or a call fails, the caller gets an exception.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvambhip.so")
+NBINS = 60
+DENSITY_SCALE = 65536.0
+HIST_SCALE = 256.0
+
+VH_OK = 0
+VH_ERR_INVALID = -1
+
+
+class VambHipError(RuntimeError):
+    pass
+
+
+class ScanResult(ctypes.Structure):
+    _fields_ = [("density_fx", ctypes.c_int64), ("hist_fx", ctypes.c_int64 * NBINS),
+                ("n_within", ctypes.c_int64), ("n_lt", ctypes.c_int64)]
+
+
+_lib = None
+
+_i64 = ctypes.c_int64
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes).  Must list every symbol declared in include/vambhip.h
+# (tests/test_lib_abi.py cross-checks the header against this table and the .so).
+SIGNATURES = {
+    "vh_last_error": (ctypes.c_char_p, []),
+    "vh_version": (ctypes.c_char_p, []),
+    "vh_device_count": (_int, [ctypes.POINTER(_int)]),
+    "vh_set_device": (_int, [_int]),
+    "vh_clu_create": (_int, [_vp, _vp, _i64, _int, _int, _vp, _pp]),
+    "vh_clu_destroy": (_int, [_vp]),
+    "vh_clu_rows": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "vh_clu_scan": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "vh_clu_select": (_int, [_vp, _i64, _vp, _f32, _int, _vp, _i64, ctypes.POINTER(_i64)]),
+    "vh_clu_remove": (_int, [_vp, _vp, _i64]),
+    "vh_clu_pack": (_int, [_vp, ctypes.POINTER(_i64)]),
+    "vh_clu_get_rows": (_int, [_vp, _vp, _i64, _vp]),
+    "vh_clu_get_kept": (_int, [_vp, _vp]),
+    "vh_clu_last_kernel_ms": (_int, [_vp, ctypes.POINTER(_f32)]),
+    "vh_clu_set_timing": (_int, [_vp, _int]),
+    "vh_vae_create": (_int, [_vp, _pp]),
+    "vh_vae_destroy": (_int, [_vp]),
+    "vh_vae_param_size": (_int, [_vp, ctypes.c_char_p, ctypes.POINTER(_i64)]),
+    "vh_vae_set_param": (_int, [_vp, ctypes.c_char_p, _vp, _i64]),
+    "vh_vae_get_param": (_int, [_vp, ctypes.c_char_p, _vp, _i64]),
+    "vh_vae_get_grad": (_int, [_vp, ctypes.c_char_p, _vp, _i64]),
+    "vh_vae_set_dataset": (_int, [_vp, _vp, _vp, _vp, _vp, _i64]),
+    "vh_vae_train_step": (_int, [_vp, _vp, _i64, _vp, _vp, ctypes.POINTER(ctypes.c_double)]),
+    "vh_vae_train_epoch": (_int, [_vp, _vp, _i64, _i64, ctypes.POINTER(ctypes.c_double)]),
+    "vh_vae_forward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vh_vae_encode": (_int, [_vp, _vp]),
+    "vh_vae_opt_state": (_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                ctypes.POINTER(_i64)]),
+    "vh_vae_set_probe": (_int, [_vp, _int, _int]),
+    "vh_vae_probe_result": (_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
+                                   ctypes.POINTER(ctypes.c_double)]),
+    "vh_debug_gemm": (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _int, _int, _int, _int,
+                             ctypes.POINTER(_f32)]),
+}
+
+
+def load():
+    """Load libvambhip.so and type every entry point.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VambHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ "
+            "as g; g.build()'` (or `python vamb_amd/csrc/build.py`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    if status == VH_OK:
+        return
+    msg = load().vh_last_error().decode("utf-8", "replace")
+    if status == VH_ERR_INVALID:
+        raise ValueError(msg)
+    raise VambHipError(f"libvambhip status {status}: {msg}")
+
+
+def device_count() -> int:
+    n = _int(0)
+    check(load().vh_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def require_gpu():
+    """Fail loudly when no MI355X is visible (never silently fall back)."""
+    n = device_count()
+    if n < 1:
+        raise VambHipError("no HIP device visible")
+    return n
+
+
+def ptr(a):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.flags.c_contiguous
+    return a.ctypes.data_as(ctypes.c_void_p)

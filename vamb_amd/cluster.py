@@ -1,0 +1,470 @@
+"""Iterative medoid clustering on MI355X -- drop-in for ``vamb.cluster``.
+
+``ClusterGenerator`` keeps the reference's constructor signature, iterator protocol, ``Cluster``
+objects and ``ValueError`` behaviour (``/root/reference/vamb/cluster.py:122-292``), so
+``vamb.__main__.cluster_and_write_files`` (``__main__.py:1277-1289``) can use it unchanged.
+
+Division of labour
+  * host (this file): the sequential decision logic, kept literally equivalent to the reference --
+    length-ordered seed walk (cluster.py:342-384), ``random.Random`` candidate sampling
+    (415-450), 31-tap smoothing + peak/valley walk (483-543), success window / PVR relaxation
+    (386-413), cluster emission (545-604).
+  * device (``csrc/cluster.hip`` through the C ABI): every pass over the latent matrix -- distance
+    scan with density / loner count / length-weighted histogram (606-637, 452-481), threshold
+    selection (640-650), row removal (304-309) and order-preserving compaction (318-335).
+
+Differences from the reference that do not change results
+  * the <= ``maxsteps`` candidates of one ``wander_medoid`` round are scanned speculatively in ONE
+    pass over the matrix (``sample_medoid`` is a pure, cached function in the reference, so looking
+    ahead is unobservable); the RNG stream and the order in which candidates are judged are identical.
+  * rows of emitted clusters are masked on the device and physically compacted only when fewer than
+    half of the resident rows are live (the reference's CPU path compacts after every cluster); all
+    decisions use live rows only, i.e. the CPU-path semantics (hard part 5).
+  * distances are never materialised: the scan returns exact integer accumulators.
+"""
+from __future__ import annotations
+
+import ctypes
+import random as _random
+from collections import deque as _deque
+from typing import Optional
+
+import numpy as _np
+
+from . import _lib
+
+_DEFAULT_RADIUS = 0.06
+_MEDOID_RADIUS = 0.05
+_DELTA_X = 0.005
+_XMAX = 0.3
+_NBINS = 60
+_MAX_MEDOIDS_PER_PASS = 32
+
+# N(0, 0.01) pdf on [-0.075, 0.075] in steps of 0.005, scaled by 0.005 in float32 -- the constant of
+# vamb/cluster.py:39-73 (float32 tensor times python float => float32 * float32).
+_NORMALPDF = (_np.float32(_DELTA_X) * _np.array(
+    [2.43432053e-11, 9.13472041e-10, 2.66955661e-08, 6.07588285e-07, 1.07697600e-05, 1.48671951e-04,
+     1.59837411e-03, 1.33830226e-02, 8.72682695e-02, 4.43184841e-01, 1.75283005e00, 5.39909665e00,
+     1.29517596e01, 2.41970725e01, 3.52065327e01, 3.98942280e01, 3.52065327e01, 2.41970725e01,
+     1.29517596e01, 5.39909665e00, 1.75283005e00, 4.43184841e-01, 8.72682695e-02, 1.33830226e-02,
+     1.59837411e-03, 1.48671951e-04, 1.07697600e-05, 6.07588285e-07, 2.66955661e-08, 9.13472041e-10,
+     2.43432053e-11], dtype=_np.float32)).astype(_np.float32)
+
+
+class Loner:
+    __slots__ = []
+
+
+class NoThreshold:
+    __slots__ = []
+
+
+class Cluster:
+    """Same attribute surface as the reference's ``Cluster`` (cluster.py:76-119)."""
+
+    __slots__ = ["medoid", "seed", "members", "maximal_pvr", "observed_pvr", "radius", "isdefault",
+                 "successes", "attempts"]
+
+    def __init__(self, medoid: int, seed: int, members: _np.ndarray, maximal_pvr: float,
+                 observed_pvr: Optional[float], radius: Optional[float], successes: int, attempts: int):
+        self.medoid = medoid
+        self.seed = seed
+        self.members = members
+        self.maximal_pvr = maximal_pvr
+        self.observed_pvr = observed_pvr
+        self.radius = radius
+        self.successes = successes
+        self.attempts = attempts
+
+    @property
+    def kind_str(self) -> str:
+        if self.observed_pvr is not None:
+            return "normal"
+        return "loner" if self.radius is None else "fallback"
+
+
+class ScanStats:
+    """What one medoid scan returns to the host (all exact)."""
+
+    __slots__ = ("density", "n_within", "n_lt", "hist_fx")
+
+    def __init__(self, density_fx: int, n_within: int, n_lt: int, hist_fx: _np.ndarray):
+        # the python float the reference gets from `.sum().item()` on a float32 tensor (cluster.py:629)
+        self.density = float(_np.float32(density_fx / _lib.DENSITY_SCALE))
+        self.n_within = n_within
+        self.n_lt = n_lt
+        self.hist_fx = hist_fx
+
+
+class HipScanBackend:
+    """Single-GPU backend: one ``vh_clu`` handle holding the whole matrix."""
+
+    def __init__(self, matrix: _np.ndarray, lengths_f32: _np.ndarray, normalized: bool,
+                 normalized_out: Optional[_np.ndarray]):
+        self.lib = _lib.load()
+        _lib.require_gpu()
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.vh_clu_create(_lib.ptr(matrix), _lib.ptr(lengths_f32), matrix.shape[0],
+                                          matrix.shape[1], int(bool(normalized)), _lib.ptr(normalized_out),
+                                          ctypes.byref(handle)))
+        self.h = handle
+        self.L = matrix.shape[1]
+        self.n_rows = matrix.shape[0]
+        self._res = (_lib.ScanResult * _MAX_MEDOIDS_PER_PASS)()
+        self._sel = _np.empty(max(1, self.n_rows), _np.int64)
+        # accounting for bench.py / DESIGN.md roofline: rows streamed by scan and select passes
+        self.scan_passes = 0
+        self.scan_medoids = 0
+        self.rows_streamed = 0
+        self.kernel_ms = 0.0
+        self.timing = False
+
+    def close(self):
+        if self.h is not None and self.h.value:
+            self.lib.vh_clu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_timing(self, on: bool):
+        self.timing = bool(on)
+        _lib.check(self.lib.vh_clu_set_timing(self.h, int(on)))
+
+    def _collect_ms(self):
+        if self.timing:
+            ms = ctypes.c_float(0)
+            _lib.check(self.lib.vh_clu_last_kernel_ms(self.h, ctypes.byref(ms)))
+            self.kernel_ms += ms.value
+
+    def scan(self, medoids):
+        """List of physical rows -> list of ScanStats (one pass per <= 32 medoids)."""
+        out = []
+        for lo in range(0, len(medoids), _MAX_MEDOIDS_PER_PASS):
+            chunk = medoids[lo:lo + _MAX_MEDOIDS_PER_PASS]
+            rows = _np.asarray(chunk, dtype=_np.int64)
+            _lib.check(self.lib.vh_clu_scan(self.h, len(chunk), _lib.ptr(rows), None, self._res))
+            self.scan_passes += 1
+            self.scan_medoids += len(chunk)
+            self.rows_streamed += self.n_rows
+            self._collect_ms()
+            for j in range(len(chunk)):
+                r = self._res[j]
+                out.append(ScanStats(r.density_fx, r.n_within, r.n_lt,
+                                     _np.frombuffer(r.hist_fx, dtype=_np.int64).copy()))
+        return out
+
+    def select(self, medoid: int, threshold: float, remove: bool) -> _np.ndarray:
+        n = ctypes.c_int64(0)
+        thr = float(_np.float32(threshold))  # torch compares in float32 (cluster.py:640-650)
+        _lib.check(self.lib.vh_clu_select(self.h, int(medoid), None, thr, int(remove), _lib.ptr(self._sel),
+                                          len(self._sel), ctypes.byref(n)))
+        self.rows_streamed += self.n_rows
+        self.scan_passes += 1
+        self._collect_ms()
+        return self._sel[: n.value].copy()
+
+    def remove(self, rows: _np.ndarray):
+        rows = _np.ascontiguousarray(rows, dtype=_np.int64)
+        _lib.check(self.lib.vh_clu_remove(self.h, _lib.ptr(rows), len(rows)))
+
+    def pack(self) -> int:
+        n = ctypes.c_int64(0)
+        _lib.check(self.lib.vh_clu_pack(self.h, ctypes.byref(n)))
+        self.n_rows = n.value
+        return n.value
+
+    def matrix(self) -> _np.ndarray:
+        out = _np.empty((self.n_rows, self.L), _np.float32)
+        _lib.check(self.lib.vh_clu_get_rows(self.h, None, 0, _lib.ptr(out)))
+        return out
+
+
+class _MatrixView:
+    """``ClusterGenerator.matrix`` -- supports ``.numpy()`` and ``len()`` like the reference's tensor."""
+
+    def __init__(self, backend):
+        self._backend = backend
+
+    def numpy(self) -> _np.ndarray:
+        return self._backend.matrix()
+
+    def __len__(self):
+        return self._backend.n_rows
+
+
+def smooth_histogram(histogram: _np.ndarray) -> _np.ndarray:
+    """31-tap smoothing of the 60-bin histogram, float32 multiply then float32 add in ascending bin
+    order (cluster.py:495-500); returns the 60 densities of cluster.py:500."""
+    pdf_len = len(_NORMALPDF)
+    densities = _np.zeros(len(histogram) + pdf_len - 1, dtype=_np.float32)
+    for i in range(len(histogram)):
+        densities[i:i + pdf_len] += _NORMALPDF * histogram[i]
+    return densities[15:-15]
+
+
+def threshold_from_densities(densities: _np.ndarray, peak_valley_ratio: float):
+    """Peak / valley walk of cluster.py:483-543.  NoThreshold() or (threshold, observed_pvr)."""
+    peak_density = 0.0
+    peak_over = False
+    minimum_x = 0.0
+    threshold = None
+    delta_x = _XMAX / len(densities)
+    x = 0
+    density_at_minimum = 0.0
+    for value in densities.tolist():  # float32 -> python float, as `.item()` does
+        density = value
+        if not peak_over and density > peak_density:
+            if x > 0.1:  # first peak must not lie beyond 0.1
+                return NoThreshold()
+            peak_density = density
+        if not peak_over and density < 0.6 * peak_density:
+            peak_over = True
+            density_at_minimum = density
+        if peak_over and density > 1.5 * density_at_minimum:
+            break
+        if peak_over and density < density_at_minimum:
+            minimum_x, density_at_minimum = x, density
+            if density < peak_valley_ratio * peak_density:
+                threshold = minimum_x
+        x += delta_x
+    if threshold is None or threshold > 0.2 + peak_valley_ratio:
+        return NoThreshold()
+    return (threshold, density_at_minimum / peak_density)
+
+
+class ClusterGenerator:
+    """Iterative medoid cluster generator running its matrix passes on an MI355X.
+
+    Inputs (identical to the reference, cluster.py:122-135, 234-245):
+        matrix: (obs x features) numpy float32
+        lengths: contig lengths
+        maxsteps, windowsize, minsuccesses: search parameters
+        destroy: normalise ``matrix`` in place instead of copying
+        normalized: matrix is already preprocessed
+        cuda: accepted for signature compatibility; the matrix passes always run on the GPU
+        rng_seed: seed of the candidate sampler
+    """
+
+    PACK_FRACTION = 0.5   # compact the resident matrix when fewer than this fraction of rows are live
+    PACK_MIN_ROWS = 8192
+
+    def __repr__(self) -> str:
+        return f"ClusterGenerator({len(self.matrix)} points, {self.n_emitted_clusters} clusters)"
+
+    def __str__(self) -> str:
+        return (f"ClusterGenerator({len(self.matrix)} points, {self.n_emitted_clusters} clusters)\n"
+                f"  CUDA:         {self.cuda}\n  maxsteps:     {self.maxsteps}\n"
+                f"  minsuccesses: {self.minsuccesses}\n  pvr:          {self.peak_valley_ratio}\n"
+                f"  successes:    {self.successes}/{len(self.attempts)}\n")
+
+    @staticmethod
+    def _check_params(matrix, lengths, maxsteps, windowsize, minsuccesses) -> None:
+        if matrix.dtype != _np.float32:
+            raise ValueError("Matrix must be of dtype float32")
+        if maxsteps < 1:
+            raise ValueError(f"maxsteps must be a positive integer, not {maxsteps}")
+        if windowsize < 1:
+            raise ValueError(f"windowsize must be at least 1, not {windowsize}")
+        if minsuccesses < 1 or minsuccesses > windowsize:
+            raise ValueError(f"minsuccesses must be between 1 and windowsize, not {minsuccesses}")
+        if len(matrix) < 1:
+            raise ValueError("Matrix must have at least 1 observation.")
+        if len(lengths) != len(matrix):
+            raise ValueError("N sequences in lengths and matrix do not match")
+
+    def __init__(self, matrix: _np.ndarray, lengths: _np.ndarray, maxsteps: int = 25, windowsize: int = 300,
+                 minsuccesses: int = 15, destroy: bool = False, normalized: bool = False, cuda: bool = False,
+                 rng_seed: int = 0, _backend_factory=None):
+        self._check_params(matrix, lengths, maxsteps, windowsize, minsuccesses)
+        if matrix.ndim != 2:
+            raise ValueError("Matrix must be 2-dimensional")
+        lengths = _np.asarray(lengths)
+        lengths_f32 = _np.ascontiguousarray(lengths, dtype=_np.float32)  # torch.Tensor(lengths), cluster.py:277
+
+        inplace_target = None
+        upload = matrix
+        if not matrix.flags.c_contiguous:
+            upload = _np.ascontiguousarray(matrix)
+            if destroy:
+                inplace_target = matrix
+        # destroy=True: the caller's array receives the normalised rows (cluster.py:253-258)
+        normalized_out = upload if (destroy and not normalized) else None
+
+        factory = HipScanBackend if _backend_factory is None else _backend_factory
+        self._backend = factory(upload, lengths_f32, normalized, normalized_out)
+        if inplace_target is not None and normalized_out is not None:
+            inplace_target[...] = normalized_out
+
+        self.maxsteps: int = maxsteps
+        self.minsuccesses: int = minsuccesses
+        self.cuda: bool = True
+        self.rng = _random.Random(rng_seed)
+        self.matrix = _MatrixView(self._backend)
+        n = len(matrix)
+        self.indices = _np.arange(n)                       # original row of every resident row
+        self._kept = _np.ones(n, dtype=bool)               # host mirror of the device live mask
+        self.order = _np.argsort(lengths)[::-1].copy()     # same call as cluster.py:275
+        self.order_index = 0
+        self.n_emitted_clusters = 0
+        self.n_remaining_points = n
+        self.peak_valley_ratio = 0.1
+        self.attempts: _deque = _deque(maxlen=windowsize)
+        self.successes = 0
+        self._stats_cache: dict[int, ScanStats] = {}
+        self._within_cache: dict[int, _np.ndarray] = {}
+
+    def __iter__(self):
+        return self
+
+    # cluster.py:298-316
+    def __next__(self) -> Cluster:
+        if self.n_remaining_points == 0:
+            raise StopIteration
+        assert self.n_remaining_points > 0
+        cluster, points = self._find_cluster()
+        self._stats_cache.clear()
+        self._within_cache.clear()
+        self.n_emitted_clusters += 1
+        self.n_remaining_points -= len(points)
+        self._kept[points] = False
+        n_rows = len(self._kept)
+        if (self.n_remaining_points > 0 and n_rows >= self.PACK_MIN_ROWS
+                and self.n_remaining_points < self.PACK_FRACTION * n_rows):
+            self.pack()
+        return cluster
+
+    # cluster.py:318-335
+    def pack(self):
+        "Remove all used points from the resident matrix and indices."
+        new_n = self._backend.pack()
+        self.indices = self.indices[self._kept]
+        assert new_n == len(self.indices)
+        self._kept = _np.ones(new_n, dtype=bool)
+        self._stats_cache.clear()
+        self._within_cache.clear()
+
+    def pack_order(self):
+        self.order = self.order[self.order > -1]
+        assert len(self.order) > 0
+
+    # cluster.py:342-384
+    def get_next_seed(self) -> int:
+        n_order = len(self.order)
+        i = self.order_index - 1
+        while True:
+            i = (i + 1) % n_order
+            if i == 0 and self.n_emitted_clusters > 0:
+                self.pack_order()
+                n_order = len(self.order)
+            order = self.order[i]
+            if order == -1:
+                continue
+            row = int(_np.searchsorted(self.indices, order))
+            if row >= len(self.indices) or self.indices[row] != order or not self._kept[row]:
+                self.order[i] = -1
+                continue
+            self.order_index = i + 1
+            return row
+
+    # cluster.py:386-413
+    def update_successes(self, success: bool):
+        if len(self.attempts) == self.attempts.maxlen:
+            self.successes -= self.attempts.popleft()
+        self.successes += success
+        self.attempts.append(success)
+        if len(self.attempts) == self.attempts.maxlen and self.successes < self.minsuccesses:
+            self.peak_valley_ratio += 0.1
+            self.attempts.clear()
+            self.successes = 0
+            self.order_index = 0
+
+    # ---- device-backed pieces of sample_medoid (cluster.py:606-637) ----------------------------
+    def _ensure_stats(self, medoids):
+        missing = [m for m in dict.fromkeys(medoids) if m not in self._stats_cache]
+        if missing:
+            for m, st in zip(missing, self._backend.scan(missing)):
+                self._stats_cache[m] = st
+
+    def _within(self, medoid: int) -> _np.ndarray:
+        hit = self._within_cache.get(medoid)
+        if hit is None:
+            hit = self._backend.select(medoid, _MEDOID_RADIUS, remove=False)
+            self._within_cache[medoid] = hit
+        return hit
+
+    def sample_medoid(self, medoid: int):
+        """(rows within 0.05 of `medoid`, its ScanStats, local density) -- cluster.py:606-637."""
+        self._ensure_stats([medoid])
+        st = self._stats_cache[medoid]
+        return self._within(medoid), st, st.density
+
+    # cluster.py:415-450
+    def wander_medoid(self, seed: int):
+        medoid = seed
+        tried = {medoid}
+        self._ensure_stats([seed])
+        stats = self._stats_cache[seed]
+        local_density = stats.density
+        candidates = [i for i in self._within(seed).tolist() if i not in tried]
+        candidates = self.rng.sample(candidates, k=min(len(candidates), self.maxsteps))
+        i = 0
+        while i < len(candidates):
+            # look ahead: every not-yet-scanned candidate of this round shares one matrix pass
+            self._ensure_stats(candidates[i:])
+            sampled = candidates[i]
+            tried.add(sampled)
+            sampled_stats = self._stats_cache[sampled]
+            if sampled_stats.density > local_density:
+                medoid, stats, local_density = sampled, sampled_stats, sampled_stats.density
+                candidates = [j for j in self._within(sampled).tolist() if j not in tried]
+                candidates = self.rng.sample(candidates, k=min(len(candidates), self.maxsteps))
+                i = 0
+            else:
+                i += 1
+        return medoid, stats
+
+    # cluster.py:452-543
+    def find_threshold(self, stats: ScanStats):
+        if stats.n_lt == 1:
+            return Loner()
+        histogram = (stats.hist_fx.astype(_np.float64) / _lib.HIST_SCALE).astype(_np.float32)
+        return threshold_from_densities(smooth_histogram(histogram), self.peak_valley_ratio)
+
+    def _logical_index(self, row: int) -> int:
+        """Index the row would have in the reference's packed matrix (reported as Cluster.seed)."""
+        return int(_np.count_nonzero(self._kept[:row]))
+
+    # cluster.py:545-604
+    def _find_cluster(self):
+        while True:
+            seed = self.get_next_seed()
+            medoid, stats = self.wander_medoid(seed)
+            threshold = self.find_threshold(stats)
+            original = int(self.indices[medoid])
+            if isinstance(threshold, Loner):
+                cluster = Cluster(original, self._logical_index(seed), _np.array([original]),
+                                  self.peak_valley_ratio, None, None, self.successes, len(self.attempts))
+                points = _np.array([medoid], dtype=_np.int64)
+                self._backend.remove(points)
+                return cluster, points
+            if isinstance(threshold, NoThreshold):
+                if self.peak_valley_ratio > 0.55:
+                    seed_logical = self._logical_index(seed)
+                    points = self._backend.select(medoid, _DEFAULT_RADIUS, remove=True)
+                    cluster = Cluster(original, seed_logical, self.indices[points], self.peak_valley_ratio,
+                                      None, _DEFAULT_RADIUS, self.successes, len(self.attempts))
+                    return cluster, points
+                self.update_successes(False)
+                continue
+            radius, observed_pvr = threshold
+            seed_logical = self._logical_index(seed)
+            points = self._backend.select(medoid, radius, remove=True)
+            cluster = Cluster(original, seed_logical, self.indices[points], self.peak_valley_ratio,
+                              observed_pvr, radius, self.successes, len(self.attempts))
+            if self.peak_valley_ratio < 0.55:
+                self.update_successes(True)
+            return cluster, points

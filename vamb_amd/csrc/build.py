@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Build libvambhip.so (gfx950 only) in-tree with hipcc.  No cmake, no torch extension machinery:
+the product is a plain C-ABI shared library (include/vambhip.h).
+
+    python vamb_amd/csrc/build.py [--force]
+
+cluster.hip is compiled with -ffp-contract=off (its arithmetic is bit-exact against the oracle);
+the VAE kernels use the default (fast) contraction.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, "libvambhip.so")
+OBJ_DIR = os.path.join(HERE, "build")
+
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt",
+          "-Wall", "-Wno-unused-function"]
+SOURCES = {
+    "cluster.hip": ["-ffp-contract=off"],
+    "vae.hip": [],
+}
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found")
+    return exe
+
+
+def newer(a: str, b: str) -> bool:
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".hpp", ".h"))]
+    headers.append(os.path.join(os.path.dirname(PKG), "include", "vambhip.h"))
+    jobs = []
+    objs = []
+    for src, extra in SOURCES.items():
+        spath = os.path.join(HERE, src)
+        if not os.path.exists(spath):
+            continue
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        stale = force or newer(spath, obj) or any(newer(h, obj) for h in headers) or newer(__file__, obj)
+        if stale:
+            jobs.append([hipcc(), *COMMON, *extra, "-c", spath, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or not os.path.exists(OUT):
+        run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,747 @@
+// cluster.hip -- MI355X (gfx950) kernels + C ABI for the medoid-scan side of vamb/cluster.py.
+//
+// Data layout in HBM (per handle):
+//   Mt      float [L4][ld]   the L2-normalised latent matrix, COLUMN-major (SoA): column c of every
+//                            row is contiguous, so a wavefront reading 4 rows per lane issues fully
+//                            coalesced 1 KiB global_load_dwordx4 per column.  ld = round_up(n, 1024),
+//                            L4 = round_up(L, 4) (zero columns: fmaf(0,0,acc) == acc, exact).
+//   lengths float [ld]       contig lengths as float32 (torch.Tensor(lengths), cluster.py:277)
+//   kept    u8    [ld]       live mask (kept_mask, cluster.py:227); padding rows are 0
+// One scan pass reads n*(4*L4 + 4 + 1) bytes and is HBM-bound (0.5 flop/B per medoid); up to 32
+// medoids share one pass (the <=25 candidates of a wander_medoid round, cluster.py:415-450).
+//
+// Arithmetic contract (bit-exact with oracle/cluster_scan.c):
+//   dot = fmaf chain over columns ascending from +0.0f; d = 0.5f - dot; d(medoid) = 0
+//   density / histogram accumulate exactly in int64 fixed point (order-free => atomics are legal)
+// This file is compiled with -ffp-contract=off so that nothing but the explicit fmaf is fused.
+#include "common.hpp"
+
+#include <algorithm>
+#include <memory>
+
+namespace vh {
+thread_local std::string g_last_error;
+}
+
+using namespace vh;
+
+namespace {
+
+constexpr int kRowsPerThread = 4;
+constexpr int kBlock = 256;
+constexpr int kRowsPerBlock = kBlock * kRowsPerThread;  // 1024
+constexpr int kResultWords = VH_NBINS + 3;              // density, hist[60], n_within, n_lt
+constexpr int kMaxMedoids = 32;
+
+// torch.linspace(0.0, 0.3, 61) float32 bit patterns (== edges torch.histogram writes, cluster.py:288,
+// 475-481).  tests/test_lib_abi.py asserts the table equals torch.linspace.
+__constant__ uint32_t c_edge_bits[VH_NBINS + 1] = {
+    0x00000000u, 0x3ba3d70bu, 0x3c23d70bu, 0x3c75c290u, 0x3ca3d70bu, 0x3cccccceu,
+    0x3cf5c290u, 0x3d0f5c2au, 0x3d23d70bu, 0x3d3851ecu, 0x3d4cccceu, 0x3d6147afu,
+    0x3d75c290u, 0x3d851eb9u, 0x3d8f5c2au, 0x3d99999au, 0x3da3d70bu, 0x3dae147cu,
+    0x3db851ecu, 0x3dc28f5du, 0x3dccccceu, 0x3dd70a3eu, 0x3de147afu, 0x3deb8520u,
+    0x3df5c290u, 0x3e000001u, 0x3e051eb9u, 0x3e0a3d71u, 0x3e0f5c2au, 0x3e147ae2u,
+    0x3e19999au, 0x3e1eb852u, 0x3e23d70au, 0x3e28f5c3u, 0x3e2e147bu, 0x3e333333u,
+    0x3e3851ecu, 0x3e3d70a4u, 0x3e428f5cu, 0x3e47ae15u, 0x3e4ccccdu, 0x3e51eb85u,
+    0x3e570a3eu, 0x3e5c28f6u, 0x3e6147aeu, 0x3e666667u, 0x3e6b851fu, 0x3e70a3d8u,
+    0x3e75c290u, 0x3e7ae148u, 0x3e800000u, 0x3e828f5cu, 0x3e851eb9u, 0x3e87ae15u,
+    0x3e8a3d71u, 0x3e8ccccdu, 0x3e8f5c29u, 0x3e91eb85u, 0x3e947ae2u, 0x3e970a3eu,
+    0x3e99999au};
+
+// ---------------------------------------------------------------------------------------------
+// K9: normalise rows (cluster.py:653-669) and transpose to the SoA layout.  One thread per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void clu_normalize_transpose_kernel(float* __restrict__ rowmajor, int64_t n, int L,
+                                                                     int do_normalize, float* __restrict__ Mt,
+                                                                     int64_t ld) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    float* r = rowmajor + row * (int64_t)L;
+    if (!do_normalize) {
+        for (int k = 0; k < L; ++k) Mt[(int64_t)k * ld + row] = r[k];
+        return;
+    }
+    bool allzero = true;
+    float ss = 0.0f;
+    for (int k = 0; k < L; ++k) {
+        const float x = r[k];
+        allzero = allzero && (x == 0.0f);
+        ss = __builtin_fmaf(x, x, ss);
+    }
+    const float inv_l = (float)(1.0 / (double)L);
+    if (allzero) {
+        ss = 0.0f;
+        for (int k = 0; k < L; ++k) ss = __builtin_fmaf(inv_l, inv_l, ss);
+    }
+    const float sqrt2 = (float)1.4142135623730951;
+    const float denom = __builtin_sqrtf(ss) * sqrt2;  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+    for (int k = 0; k < L; ++k) {
+        const float x = allzero ? inv_l : r[k];
+        const float y = x / denom;
+        r[k] = y;
+        Mt[(int64_t)k * ld + row] = y;
+    }
+}
+
+// gather query rows from the SoA matrix: q[j][c] = Mt[c][rows[j]]   (zero for the pad columns)
+__global__ void clu_gather_queries_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
+                                          const int64_t* __restrict__ rows, int k, float* __restrict__ q) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= k * L4) return;
+    const int j = idx / L4, c = idx - j * L4;
+    q[idx] = Mt[(int64_t)c * ld + rows[j]];
+}
+
+// row-major gather of arbitrary rows (get_rows): out[i][c] = Mt[c][rows ? rows[i] : i]
+__global__ void clu_rows_to_rowmajor_kernel(const float* __restrict__ Mt, int64_t ld, int L,
+                                            const int64_t* __restrict__ rows, int64_t k, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= k * L) return;
+    const int64_t i = idx / L;
+    const int c = (int)(idx - i * L);
+    const int64_t r = rows ? rows[i] : i;
+    out[idx] = Mt[(int64_t)c * ld + r];
+}
+
+// torch.histogram bin rule: edge[b] <= d < edge[b+1], last bin closed; -1 outside [edge0, edge60]
+__device__ __forceinline__ int bin_of(float d, const float* edges) {
+    if (!(d >= edges[0]) || !(d <= edges[VH_NBINS])) return -1;
+    int b = (int)(d * 200.0f);
+    b = b < 0 ? 0 : (b > VH_NBINS - 1 ? VH_NBINS - 1 : b);
+    while (b > 0 && d < edges[b]) --b;
+    while (b < VH_NBINS - 1 && d >= edges[b + 1]) ++b;
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6: multi-medoid scan.  Each thread owns RPT consecutive rows (4 for few medoids: 1 KiB coalesced
+// loads per wave-instruction; 2 when KM >= 12 so that KM*RPT accumulators stay within ~128 VGPRs).
+// ---------------------------------------------------------------------------------------------
+template <int RPT>
+__device__ __forceinline__ void load_rows(const float* __restrict__ p, float (&x)[RPT]) {
+    if constexpr (RPT == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else {
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        x[0] = v.x; x[1] = v.y;
+    }
+}
+
+template <int RPT>
+__device__ __forceinline__ void load_live(const uint8_t* __restrict__ p, unsigned char (&x)[RPT]) {
+    if constexpr (RPT == 4) {
+        const uchar4 v = *reinterpret_cast<const uchar4*>(p);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else {
+        const uchar2 v = *reinterpret_cast<const uchar2*>(p);
+        x[0] = v.x; x[1] = v.y;
+    }
+}
+
+template <int KM, int RPT>
+__global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
+                                                          const float* __restrict__ lengths,
+                                                          const uint8_t* __restrict__ kept, int64_t n,
+                                                          const float* __restrict__ q,
+                                                          const int64_t* __restrict__ medoid,
+                                                          unsigned long long* __restrict__ results) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(smem_raw);       // [KM][kResultWords]
+    long long* med_s = reinterpret_cast<long long*>(acc_s + KM * kResultWords);         // [KM]
+    float* edges_s = reinterpret_cast<float*>(med_s + KM);                              // [64]
+    float* q_s = edges_s + 64;                                                          // [KM][L4]
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
+    for (int i = tid; i < KM; i += kBlock) med_s[i] = medoid[i];
+    for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
+    for (int i = tid; i < KM * L4; i += kBlock) q_s[i] = q[i];
+    __syncthreads();
+
+    const float radius = 0.05f;
+
+    for (int64_t base = ((int64_t)blockIdx.x * kBlock + tid) * RPT; base < n;
+         base += (int64_t)gridDim.x * kBlock * RPT) {
+        unsigned char live[RPT];
+        load_live<RPT>(kept + base, live);
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) any = any || (live[r] != 0);
+        // whole wavefront dead (already emitted rows): skip the column loads
+        if (__ballot(any) == 0ull) continue;
+
+        float acc[KM][RPT];
+#pragma unroll
+        for (int j = 0; j < KM; ++j)
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) acc[j][r] = 0.0f;
+
+        const float* col = Mt + base;
+        for (int c = 0; c < L4; c += 4) {
+            float x[4][RPT];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) load_rows<RPT>(col + (int64_t)(c + i) * ld, x[i]);
+#pragma unroll
+            for (int j = 0; j < KM; ++j) {
+                const float4 qq = *reinterpret_cast<const float4*>(q_s + j * L4 + c);
+                const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)   // columns ascending: the defined fmaf order
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) acc[j][r] = __builtin_fmaf(x[i][r], qv[i], acc[j][r]);
+            }
+        }
+
+        float len[RPT];
+        load_rows<RPT>(lengths + base, len);
+#pragma unroll
+        for (int j = 0; j < KM; ++j) {
+            const long long med = med_s[j];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                if (!live[r]) continue;
+                float d = 0.5f - acc[j][r];
+                if (base + r == med) d = 0.0f;
+                // rows inside the medoid radius are rare: accumulate straight into LDS (exact integers)
+                if (d <= radius) {
+                    const float p = len[r] * (radius - d);
+                    const long long pf = __double2ll_rn((double)p * VH_DENSITY_SCALE);
+                    atomicAdd(&acc_s[j * kResultWords + 0], (unsigned long long)pf);
+                    atomicAdd(&acc_s[j * kResultWords + 1 + VH_NBINS], 1ull);
+                    if (d < radius) atomicAdd(&acc_s[j * kResultWords + 2 + VH_NBINS], 1ull);
+                }
+                const int b = bin_of(d, edges_s);
+                if (b >= 0) {
+                    const long long w = __double2ll_rn((double)len[r] * VH_HIST_SCALE);
+                    atomicAdd(&acc_s[j * kResultWords + 1 + b], (unsigned long long)w);
+                }
+            }
+        }
+    }
+
+    __syncthreads();
+    for (int i = tid; i < KM * kResultWords; i += kBlock) {
+        const unsigned long long v = acc_s[i];
+        if (v != 0ull) atomicAdd(&results[i], v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7a: select -- unordered append of live rows with d <= threshold (host sorts; lists are short),
+// optionally clearing their live flag.  Same fmaf chain as the scan => identical distances.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void clu_select_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
+                                                            uint8_t* __restrict__ kept, int64_t n,
+                                                            const float* __restrict__ q, int64_t medoid,
+                                                            float threshold, int remove,
+                                                            int32_t* __restrict__ out_rows,
+                                                            unsigned int* __restrict__ out_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* q_s = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L4; i += kBlock) q_s[i] = q[i];
+    __syncthreads();
+    const int lane = tid & 63;
+
+    for (int64_t base = ((int64_t)blockIdx.x * kBlock + tid) * kRowsPerThread; base < n;
+         base += (int64_t)gridDim.x * kRowsPerBlock) {
+        uchar4 kp = *reinterpret_cast<const uchar4*>(kept + base);
+        if (__ballot((kp.x | kp.y | kp.z | kp.w) != 0) == 0ull) continue;
+        float acc[kRowsPerThread] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* col = Mt + base;
+        for (int c = 0; c < L4; c += 4) {
+            const float4 x0 = *reinterpret_cast<const float4*>(col + (int64_t)(c + 0) * ld);
+            const float4 x1 = *reinterpret_cast<const float4*>(col + (int64_t)(c + 1) * ld);
+            const float4 x2 = *reinterpret_cast<const float4*>(col + (int64_t)(c + 2) * ld);
+            const float4 x3 = *reinterpret_cast<const float4*>(col + (int64_t)(c + 3) * ld);
+            const float4 qq = *reinterpret_cast<const float4*>(q_s + c);
+            acc[0] = __builtin_fmaf(x0.x, qq.x, acc[0]);
+            acc[1] = __builtin_fmaf(x0.y, qq.x, acc[1]);
+            acc[2] = __builtin_fmaf(x0.z, qq.x, acc[2]);
+            acc[3] = __builtin_fmaf(x0.w, qq.x, acc[3]);
+            acc[0] = __builtin_fmaf(x1.x, qq.y, acc[0]);
+            acc[1] = __builtin_fmaf(x1.y, qq.y, acc[1]);
+            acc[2] = __builtin_fmaf(x1.z, qq.y, acc[2]);
+            acc[3] = __builtin_fmaf(x1.w, qq.y, acc[3]);
+            acc[0] = __builtin_fmaf(x2.x, qq.z, acc[0]);
+            acc[1] = __builtin_fmaf(x2.y, qq.z, acc[1]);
+            acc[2] = __builtin_fmaf(x2.z, qq.z, acc[2]);
+            acc[3] = __builtin_fmaf(x2.w, qq.z, acc[3]);
+            acc[0] = __builtin_fmaf(x3.x, qq.w, acc[0]);
+            acc[1] = __builtin_fmaf(x3.y, qq.w, acc[1]);
+            acc[2] = __builtin_fmaf(x3.z, qq.w, acc[2]);
+            acc[3] = __builtin_fmaf(x3.w, qq.w, acc[3]);
+        }
+        const unsigned char live[4] = {kp.x, kp.y, kp.z, kp.w};
+        unsigned char newlive[4] = {kp.x, kp.y, kp.z, kp.w};
+        bool any_removed = false;
+#pragma unroll
+        for (int r = 0; r < kRowsPerThread; ++r) {
+            float d = 0.5f - acc[r];
+            if (base + r == medoid) d = 0.0f;
+            const bool hit = live[r] && (d <= threshold);
+            const unsigned long long ball = __ballot(hit);
+            if (ball != 0ull) {
+                const int leader = __ffsll((long long)ball) - 1;
+                unsigned int start = 0;
+                if (lane == leader) start = atomicAdd(out_count, (unsigned int)__popcll(ball));
+                start = __shfl(start, leader);
+                if (hit) {
+                    const unsigned long long below = ball & ((1ull << lane) - 1ull);
+                    out_rows[start + (unsigned int)__popcll(below)] = (int32_t)(base + r);
+                    if (remove) { newlive[r] = 0; any_removed = true; }
+                }
+            }
+        }
+        if (any_removed) {
+            uchar4 w;
+            w.x = newlive[0]; w.y = newlive[1]; w.z = newlive[2]; w.w = newlive[3];
+            *reinterpret_cast<uchar4*>(kept + base) = w;
+        }
+    }
+}
+
+__global__ void clu_remove_kernel(uint8_t* __restrict__ kept, const int64_t* __restrict__ rows, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) kept[rows[i]] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7b: order-preserving compaction (pack).  count -> single-block exclusive scan -> source list
+// -> column gather.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void clu_count_kept_kernel(const uint8_t* __restrict__ kept, int64_t n_pad,
+                                                                unsigned int* __restrict__ block_counts) {
+    __shared__ unsigned int s;
+    if (threadIdx.x == 0) s = 0;
+    __syncthreads();
+    const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kRowsPerThread;
+    unsigned int c = 0;
+    if (base < n_pad) {
+        const uchar4 kp = *reinterpret_cast<const uchar4*>(kept + base);
+        c = (kp.x != 0) + (kp.y != 0) + (kp.z != 0) + (kp.w != 0);
+    }
+    // wave reduce then one LDS atomic per wave
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s, c);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s;
+}
+
+// single block: exclusive scan of nb counts in place; total written to *total
+__global__ __launch_bounds__(1024) void clu_exclusive_scan_kernel(unsigned int* __restrict__ counts, int nb,
+                                                                  unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long part[1024];
+    const int t = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int lo = t * per, hi = min(nb, lo + per);
+    unsigned long long s = 0;
+    for (int i = lo; i < hi; ++i) s += counts[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[t];
+    for (int i = lo; i < hi; ++i) { const unsigned int v = counts[i]; counts[i] = (unsigned int)run; run += v; }
+}
+
+// src[new] = old physical row, ascending.  Block b owns rows [b*1024, b*1024+1024).
+__global__ __launch_bounds__(kBlock) void clu_build_src_kernel(const uint8_t* __restrict__ kept, int64_t n_pad,
+                                                               const unsigned int* __restrict__ block_offsets,
+                                                               int32_t* __restrict__ src) {
+    __shared__ unsigned int wave_tot[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = ((int64_t)blockIdx.x * kBlock + tid) * kRowsPerThread;
+    uchar4 kp = make_uchar4(0, 0, 0, 0);
+    if (base < n_pad) kp = *reinterpret_cast<const uchar4*>(kept + base);
+    const unsigned int c = (kp.x != 0) + (kp.y != 0) + (kp.z != 0) + (kp.w != 0);
+    // inclusive wave prefix
+    unsigned int inc = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int v = __shfl_up(inc, off);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    unsigned int wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += wave_tot[w];
+    unsigned int pos = block_offsets[blockIdx.x] + wave_base + inc - c;
+    if (kp.x) src[pos++] = (int32_t)(base + 0);
+    if (kp.y) src[pos++] = (int32_t)(base + 1);
+    if (kp.z) src[pos++] = (int32_t)(base + 2);
+    if (kp.w) src[pos++] = (int32_t)(base + 3);
+}
+
+// out[c][i] = in[c][src[i]] for i < n_new, 0 for the padding; blockIdx.y = column (L4 = matrix, +1 = lengths)
+__global__ __launch_bounds__(kBlock) void clu_gather_columns_kernel(const float* __restrict__ in, int64_t ld_in,
+                                                                    float* __restrict__ out, int64_t ld_out,
+                                                                    const int32_t* __restrict__ src, int64_t n_new,
+                                                                    const float* __restrict__ len_in,
+                                                                    float* __restrict__ len_out, int L4) {
+    const int c = blockIdx.y;
+    const float* pin = (c < L4) ? in + (int64_t)c * ld_in : len_in;
+    float* pout = (c < L4) ? out + (int64_t)c * ld_out : len_out;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ld_out; i += (int64_t)gridDim.x * kBlock)
+        pout[i] = (i < n_new) ? pin[src[i]] : 0.0f;
+}
+
+__global__ void clu_fill_kept_kernel(uint8_t* __restrict__ kept, int64_t n_live, int64_t n_pad) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x)
+        kept[i] = (i < n_live) ? 1 : 0;
+}
+
+int pick_km(int k) {
+    static const int sizes[] = {1, 2, 4, 8, 12, 16, 24, 32};
+    for (int s : sizes)
+        if (k <= s) return s;
+    return -1;
+}
+
+int scan_grid(int64_t n) {
+    const int64_t blocks = ceil_div(n, kRowsPerBlock);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
+}
+
+}  // namespace
+
+struct vh_clu {
+    int L = 0, L4 = 0;
+    int64_t n_rows = 0;   // physical rows
+    int64_t n_live = 0;
+    int64_t ld = 0;       // leading dimension (>= n_rows, multiple of 1024)
+    hipStream_t stream = nullptr;
+    DevBuf<float> Mt, Mt_alt, lengths, lengths_alt, q;
+    DevBuf<uint8_t> kept;
+    DevBuf<int64_t> medoids;
+    DevBuf<unsigned long long> results;
+    DevBuf<int32_t> sel_rows;   // select output / pack source list
+    DevBuf<unsigned int> counts;  // [0]: select counter; [1..]: pack block counts
+    DevBuf<unsigned long long> total;
+    DevBuf<int64_t> row_idx;
+    PinnedBuf<unsigned long long> h_results;
+    PinnedBuf<int64_t> h_medoids;
+    PinnedBuf<float> h_q;
+    std::vector<int32_t> h_sel;
+    EventTimer timer;
+
+    ~vh_clu() {
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+template <int KM>
+void launch_scan(vh_clu* h) {
+    constexpr int RPT = (KM >= 12) ? 2 : 4;
+    const size_t smem = (size_t)KM * kResultWords * 8 + (size_t)KM * 8 + 64 * 4 + (size_t)KM * h->L4 * 4;
+    const int64_t blocks = ceil_div(h->ld, (int64_t)kBlock * RPT);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
+    hipLaunchKernelGGL((clu_scan_kernel<KM, RPT>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
+                       h->lengths.p, h->kept.p, h->ld, h->q.p, h->medoids.p, h->results.p);
+}
+
+void dispatch_scan(vh_clu* h, int km) {
+    switch (km) {
+        case 1: launch_scan<1>(h); break;
+        case 2: launch_scan<2>(h); break;
+        case 4: launch_scan<4>(h); break;
+        case 8: launch_scan<8>(h); break;
+        case 12: launch_scan<12>(h); break;
+        case 16: launch_scan<16>(h); break;
+        case 24: launch_scan<24>(h); break;
+        default: launch_scan<32>(h); break;
+    }
+    VH_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vh_last_error(void) { return g_last_error.c_str(); }
+const char* vh_version(void) { return "vambhip 0.1 (gfx950)"; }
+
+int vh_device_count(int* n) {
+    return guarded([&] {
+        VH_REQUIRE(n != nullptr, "n is NULL");
+        *n = 0;
+        int c = 0;
+        hipError_t e = hipGetDeviceCount(&c);
+        if (e != hipSuccess) throw HipError{e, "hipGetDeviceCount", __FILE__, __LINE__};
+        *n = c;
+    });
+}
+
+int vh_set_device(int device) {
+    return guarded([&] { VH_HIP(hipSetDevice(device)); });
+}
+
+int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, int normalized, float* normalized_out,
+                  vh_clu** out) {
+    return guarded([&] {
+        VH_REQUIRE(out != nullptr, "out is NULL");
+        *out = nullptr;
+        VH_REQUIRE(matrix != nullptr && lengths != nullptr, "matrix/lengths is NULL");
+        VH_REQUIRE(n >= 1, "Matrix must have at least 1 observation.");
+        VH_REQUIRE(L >= 1 && L <= 4096, "latent width %d outside [1, 4096]", L);
+        VH_REQUIRE(n < (int64_t)2147483647 - 2048, "more than 2^31 rows per shard are not supported");
+        std::unique_ptr<vh_clu> h(new vh_clu());
+        h->L = L;
+        h->L4 = (int)round_up(L, 4);
+        h->n_rows = h->n_live = n;
+        h->ld = round_up(n, kRowsPerBlock);
+        VH_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->Mt.alloc((size_t)h->L4 * h->ld);
+        h->lengths.alloc((size_t)h->ld);
+        h->kept.alloc((size_t)h->ld);
+        h->q.alloc((size_t)kMaxMedoids * h->L4);
+        h->medoids.alloc(kMaxMedoids);
+        h->results.alloc((size_t)kMaxMedoids * kResultWords);
+        h->counts.alloc((size_t)(1 + h->ld / kRowsPerBlock));
+        h->total.alloc(1);
+        h->h_results.ensure((size_t)kMaxMedoids * kResultWords);
+        h->h_medoids.ensure(kMaxMedoids);
+        h->h_q.ensure((size_t)kMaxMedoids * h->L4);
+
+        DevBuf<float> staging;
+        staging.alloc((size_t)n * L);
+        VH_HIP(hipMemsetAsync(h->Mt.p, 0, h->Mt.bytes(), h->stream));
+        VH_HIP(hipMemsetAsync(h->lengths.p, 0, h->lengths.bytes(), h->stream));
+        VH_HIP(hipMemcpyAsync(staging.p, matrix, (size_t)n * L * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        VH_HIP(hipMemcpyAsync(h->lengths.p, lengths, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(clu_normalize_transpose_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64), 0, h->stream,
+                           staging.p, n, L, normalized ? 0 : 1, h->Mt.p, h->ld);
+        VH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(clu_fill_kept_kernel, dim3(1024), dim3(256), 0, h->stream, h->kept.p, n, h->ld);
+        VH_HIP(hipGetLastError());
+        if (normalized_out)
+            VH_HIP(hipMemcpyAsync(normalized_out, staging.p, (size_t)n * L * sizeof(float), hipMemcpyDeviceToHost,
+                                  h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+        *out = h.release();
+    });
+}
+
+int vh_clu_destroy(vh_clu* h) {
+    return guarded([&] { delete h; });
+}
+
+int vh_clu_rows(vh_clu* h, int64_t* n_rows, int64_t* n_live) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "handle is NULL");
+        if (n_rows) *n_rows = h->n_rows;
+        if (n_live) *n_live = h->n_live;
+    });
+}
+
+int vh_clu_set_timing(vh_clu* h, int enable) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "handle is NULL");
+        h->timer.enable(enable != 0);
+    });
+}
+
+int vh_clu_last_kernel_ms(vh_clu* h, float* ms) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && ms != nullptr, "NULL argument");
+        *ms = h->timer.last_ms;
+    });
+}
+
+int vh_clu_scan(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries, vh_scan_result* out) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && medoid_rows != nullptr && out != nullptr, "NULL argument");
+        VH_REQUIRE(k >= 1 && k <= kMaxMedoids, "k=%d outside [1, %d]", k, kMaxMedoids);
+        const int km = pick_km(k);
+        for (int j = 0; j < km; ++j) {
+            const int64_t m = medoid_rows[j < k ? j : 0];
+            VH_REQUIRE(m >= -1 && m < h->n_rows, "medoid row %lld out of range", (long long)m);
+            VH_REQUIRE(queries != nullptr || m >= 0, "medoid row -1 needs an explicit query vector");
+            h->h_medoids.p[j] = m;
+        }
+        VH_HIP(hipMemcpyAsync(h->medoids.p, h->h_medoids.p, (size_t)km * sizeof(int64_t), hipMemcpyHostToDevice,
+                              h->stream));
+        if (queries) {
+            for (int j = 0; j < km; ++j) {
+                const float* src = queries + (size_t)(j < k ? j : 0) * h->L;
+                float* dst = h->h_q.p + (size_t)j * h->L4;
+                for (int c = 0; c < h->L4; ++c) dst[c] = c < h->L ? src[c] : 0.0f;
+            }
+            VH_HIP(hipMemcpyAsync(h->q.p, h->h_q.p, (size_t)km * h->L4 * sizeof(float), hipMemcpyHostToDevice,
+                                  h->stream));
+        } else {
+            const int tot = km * h->L4;
+            hipLaunchKernelGGL(clu_gather_queries_kernel, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->Mt.p,
+                               h->ld, h->L4, h->medoids.p, km, h->q.p);
+            VH_HIP(hipGetLastError());
+        }
+        VH_HIP(hipMemsetAsync(h->results.p, 0, (size_t)km * kResultWords * 8, h->stream));
+        h->timer.start(h->stream);
+        dispatch_scan(h, km);
+        h->timer.stop(h->stream);
+        VH_HIP(hipMemcpyAsync(h->h_results.p, h->results.p, (size_t)k * kResultWords * 8, hipMemcpyDeviceToHost,
+                              h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+        h->timer.collect();
+        for (int j = 0; j < k; ++j) {
+            const unsigned long long* r = h->h_results.p + (size_t)j * kResultWords;
+            out[j].density_fx = (int64_t)r[0];
+            for (int b = 0; b < VH_NBINS; ++b) out[j].hist_fx[b] = (int64_t)r[1 + b];
+            out[j].n_within = (int64_t)r[1 + VH_NBINS];
+            out[j].n_lt = (int64_t)r[2 + VH_NBINS];
+        }
+    });
+}
+
+int vh_clu_select(vh_clu* h, int64_t medoid_row, const float* query, float threshold, int remove, int64_t* out_rows,
+                  int64_t cap, int64_t* n_out) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && n_out != nullptr, "NULL argument");
+        VH_REQUIRE(medoid_row >= -1 && medoid_row < h->n_rows, "medoid row out of range");
+        VH_REQUIRE(query != nullptr || medoid_row >= 0, "medoid row -1 needs an explicit query vector");
+        VH_REQUIRE(cap >= 0 && (cap == 0 || out_rows != nullptr), "bad output buffer");
+        h->sel_rows.ensure((size_t)h->ld);
+        if (query) {
+            for (int c = 0; c < h->L4; ++c) h->h_q.p[c] = c < h->L ? query[c] : 0.0f;
+            VH_HIP(hipMemcpyAsync(h->q.p, h->h_q.p, (size_t)h->L4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        } else {
+            h->h_medoids.p[0] = medoid_row;
+            VH_HIP(hipMemcpyAsync(h->medoids.p, h->h_medoids.p, sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(clu_gather_queries_kernel, dim3((h->L4 + 255) / 256), dim3(256), 0, h->stream, h->Mt.p,
+                               h->ld, h->L4, h->medoids.p, 1, h->q.p);
+            VH_HIP(hipGetLastError());
+        }
+        VH_HIP(hipMemsetAsync(h->counts.p, 0, sizeof(unsigned int), h->stream));
+        h->timer.start(h->stream);
+        hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
+                           h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, h->q.p, medoid_row, threshold, remove,
+                           h->sel_rows.p, h->counts.p);
+        VH_HIP(hipGetLastError());
+        h->timer.stop(h->stream);
+        unsigned int cnt = 0;
+        VH_HIP(hipMemcpyAsync(&cnt, h->counts.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+        h->timer.collect();
+        h->h_sel.resize(cnt);
+        if (cnt) {
+            VH_HIP(hipMemcpyAsync(h->h_sel.data(), h->sel_rows.p, (size_t)cnt * sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, h->stream));
+            VH_HIP(hipStreamSynchronize(h->stream));
+            std::sort(h->h_sel.begin(), h->h_sel.end());
+        }
+        const int64_t w = std::min<int64_t>(cap, cnt);
+        for (int64_t i = 0; i < w; ++i) out_rows[i] = h->h_sel[i];
+        *n_out = cnt;
+        if (remove) h->n_live -= cnt;
+    });
+}
+
+int vh_clu_remove(vh_clu* h, const int64_t* rows, int64_t n) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && (n == 0 || rows != nullptr), "NULL argument");
+        VH_REQUIRE(n >= 0, "negative count");
+        if (n == 0) return;
+        for (int64_t i = 0; i < n; ++i)
+            VH_REQUIRE(rows[i] >= 0 && rows[i] < h->n_rows, "row %lld out of range", (long long)rows[i]);
+        // count rows that are still live so that n_live stays exact
+        std::vector<uint8_t> flags;
+        h->row_idx.ensure((size_t)n);
+        VH_HIP(hipMemcpyAsync(h->row_idx.p, rows, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        // read back current flags of these rows (small lists) to keep the live count exact
+        std::vector<int64_t> uniq(rows, rows + n);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        int64_t live = 0;
+        for (int64_t r : uniq) {
+            uint8_t f = 0;
+            VH_HIP(hipMemcpyAsync(&f, h->kept.p + r, 1, hipMemcpyDeviceToHost, h->stream));
+            VH_HIP(hipStreamSynchronize(h->stream));
+            live += f != 0;
+        }
+        hipLaunchKernelGGL(clu_remove_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, h->stream, h->kept.p,
+                           h->row_idx.p, n);
+        VH_HIP(hipGetLastError());
+        VH_HIP(hipStreamSynchronize(h->stream));
+        h->n_live -= live;
+    });
+}
+
+int vh_clu_pack(vh_clu* h, int64_t* new_rows) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "handle is NULL");
+        const int nb = (int)(h->ld / kRowsPerBlock);
+        unsigned int* block_counts = h->counts.p + 1;
+        hipLaunchKernelGGL(clu_count_kept_kernel, dim3(nb), dim3(kBlock), 0, h->stream, h->kept.p, h->ld, block_counts);
+        VH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(clu_exclusive_scan_kernel, dim3(1), dim3(1024), 0, h->stream, block_counts, nb, h->total.p);
+        VH_HIP(hipGetLastError());
+        unsigned long long total = 0;
+        VH_HIP(hipMemcpyAsync(&total, h->total.p, sizeof(total), hipMemcpyDeviceToHost, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+        const int64_t n_new = (int64_t)total;
+        VH_REQUIRE(n_new == h->n_live, "internal: live count mismatch (%lld vs %lld)", (long long)n_new,
+                   (long long)h->n_live);
+        if (n_new == h->n_rows) {
+            if (new_rows) *new_rows = n_new;
+            return;
+        }
+        h->sel_rows.ensure((size_t)h->ld);
+        hipLaunchKernelGGL(clu_build_src_kernel, dim3(nb), dim3(kBlock), 0, h->stream, h->kept.p, h->ld, block_counts,
+                           h->sel_rows.p);
+        VH_HIP(hipGetLastError());
+        const int64_t ld_new = round_up(std::max<int64_t>(n_new, 1), kRowsPerBlock);
+        h->Mt_alt.ensure((size_t)h->L4 * ld_new);
+        h->lengths_alt.ensure((size_t)ld_new);
+        const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(ld_new, kBlock), 2048));
+        hipLaunchKernelGGL(clu_gather_columns_kernel, dim3(gx, h->L4 + 1), dim3(kBlock), 0, h->stream, h->Mt.p, h->ld,
+                           h->Mt_alt.p, ld_new, h->sel_rows.p, n_new, h->lengths.p, h->lengths_alt.p, h->L4);
+        VH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(clu_fill_kept_kernel, dim3(1024), dim3(256), 0, h->stream, h->kept.p, n_new, h->ld);
+        VH_HIP(hipGetLastError());
+        VH_HIP(hipStreamSynchronize(h->stream));
+        std::swap(h->Mt, h->Mt_alt);
+        std::swap(h->lengths, h->lengths_alt);
+        h->ld = ld_new;
+        h->n_rows = n_new;
+        if (new_rows) *new_rows = n_new;
+    });
+}
+
+int vh_clu_get_rows(vh_clu* h, const int64_t* rows, int64_t k, float* out) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && out != nullptr, "NULL argument");
+        if (rows == nullptr) k = h->n_rows;
+        VH_REQUIRE(k >= 0, "negative count");
+        if (k == 0) return;
+        if (rows) {
+            for (int64_t i = 0; i < k; ++i)
+                VH_REQUIRE(rows[i] >= 0 && rows[i] < h->n_rows, "row %lld out of range", (long long)rows[i]);
+            h->row_idx.ensure((size_t)k);
+            VH_HIP(hipMemcpyAsync(h->row_idx.p, rows, (size_t)k * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        }
+        DevBuf<float> tmp;
+        tmp.alloc((size_t)k * h->L);
+        const int64_t tot = k * h->L;
+        hipLaunchKernelGGL(clu_rows_to_rowmajor_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, h->stream,
+                           h->Mt.p, h->ld, h->L, rows ? h->row_idx.p : nullptr, k, tmp.p);
+        VH_HIP(hipGetLastError());
+        VH_HIP(hipMemcpyAsync(out, tmp.p, (size_t)tot * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+    });
+}
+
+int vh_clu_get_kept(vh_clu* h, uint8_t* out) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && out != nullptr, "NULL argument");
+        VH_HIP(hipMemcpyAsync(out, h->kept.p, (size_t)h->n_rows, hipMemcpyDeviceToHost, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+// Shared host-side plumbing for libvambhip.so: error reporting across the C ABI, RAII device
+// buffers, stream + event timing.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/vambhip.h"
+
+namespace vh {
+
+extern thread_local std::string g_last_error;
+
+inline int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+struct HipError {
+    hipError_t err;
+    const char* what;
+    const char* file;
+    int line;
+};
+
+#define VH_HIP(expr)                                                              \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) throw ::vh::HipError{_e, #expr, __FILE__, __LINE__}; \
+    } while (0)
+
+struct InvalidArg {
+    std::string msg;
+};
+#define VH_REQUIRE(cond, ...)                                        \
+    do {                                                             \
+        if (!(cond)) {                                               \
+            char _b[512];                                            \
+            snprintf(_b, sizeof(_b), __VA_ARGS__);                   \
+            throw ::vh::InvalidArg{std::string(_b)};                 \
+        }                                                            \
+    } while (0)
+
+// Run `body` and translate C++ exceptions into status codes (nothing crosses the C boundary).
+template <class F>
+int guarded(F&& body) {
+    try {
+        body();
+        return VH_OK;
+    } catch (const HipError& e) {
+        int code = (e.err == hipErrorOutOfMemory) ? VH_ERR_NOMEM : VH_ERR_HIP;
+        return fail(code, "HIP error %d (%s) in `%s` at %s:%d", (int)e.err, hipGetErrorString(e.err), e.what,
+                    e.file, e.line);
+    } catch (const InvalidArg& e) {
+        return fail(VH_ERR_INVALID, "%s", e.msg.c_str());
+    } catch (const std::bad_alloc&) {
+        return fail(VH_ERR_NOMEM, "host allocation failed");
+    } catch (...) {
+        return fail(VH_ERR_HIP, "unknown C++ exception");
+    }
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        VH_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+    }
+    void ensure(size_t count) {
+        if (count > n) alloc(count);
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// Pinned host staging buffer (D2H of small results without an extra pageable bounce).
+template <class T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    void ensure(size_t count) {
+        if (count <= n) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        VH_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+        n = count;
+    }
+};
+
+struct EventTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool enabled = false;
+    float last_ms = 0.f;
+    ~EventTimer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+    void enable(bool on) {
+        if (on && !a) {
+            VH_HIP(hipEventCreate(&a));
+            VH_HIP(hipEventCreate(&b));
+        }
+        enabled = on;
+    }
+    void start(hipStream_t s) { if (enabled) VH_HIP(hipEventRecord(a, s)); }
+    void stop(hipStream_t s) { if (enabled) VH_HIP(hipEventRecord(b, s)); }
+    // call after the stream has been synchronised
+    void collect() { if (enabled) VH_HIP(hipEventElapsedTime(&last_ms, a, b)); }
+};
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
+
+}  // namespace vh

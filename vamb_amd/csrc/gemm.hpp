@@ -1,0 +1,284 @@
+// gemm.hpp -- fp32-input MFMA GEMM for the VAE's dense contractions (gfx950).
+//
+//   C[m][n] = sum_k A(m,k) * B(n,k)        m < M, n < N, k < K (K multiple of 32)
+//
+// built on v_mfma_f32_32x32x2_f32: exact fp32 products accumulated as a k-ordered fmaf chain (the
+// guide's "SGEMM class": 64 FLOP/clk/SIMD, 157 TF/s chip peak), which is what BASELINE config C1
+// ("fp32") asks for.  Each operand can be stored either "K-contiguous" (row-major [rows][K]: the
+// forward activations and weights) or "row-contiguous" ([K][rows]: what the backward passes need,
+// dX = dY*W reads W as [contraction n][k], dW = dY^T*X reads both operands as [contraction m][..]),
+// so no transposed copies of weights or activations are ever materialised.
+//
+// Tile: BM x BN x 32 per workgroup of 4 wavefronts (WM x WN), each wave TM x TN MFMA tiles of 32x32.
+// Global -> registers (float4, coalesced along the contiguous dimension) -> LDS [k][row] (stride
+// BM+1 for transposing ds_write_b32 of K-contiguous operands, BM+4 for ds_write_b128 of
+// row-contiguous ones; both conflict-free) -> ds_read_b32 fragments (lane l: row l&31, k l>>5).
+// Double-buffered LDS, next tile's global loads in flight during the current tile's MFMAs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace vh {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+enum EpiKind : int {
+    EPI_STORE = 0,         // C = acc
+    EPI_BIAS = 1,          // C = acc + bias[n]
+    EPI_HIDDEN_TRAIN = 2,  // h = dropout(leaky_relu(acc + bias)); C = h; column sums of h, h^2 (encode.py:264,292)
+    EPI_HIDDEN_EVAL = 3,   // C = leaky_relu(acc + bias) * scale[n] + shift[n]   (eval-mode BatchNorm folded)
+    EPI_SPLITK = 4,        // C[blockIdx.z] = acc   (partial slabs, summed by the consumer)
+    EPI_LATENT_MASK = 5    // C = bits(acc + bias) & ~0xFFF   (encode.py:483, vambtools.py:324-330)
+};
+
+struct GemmArgs {
+    const float* A;
+    int64_t lda;
+    const float* B;
+    int64_t ldb;
+    float* C;
+    int64_t ldc;
+    int M, N, K;
+    int k_per_split;      // contraction elements per blockIdx.z (multiple of 32)
+    int64_t slab_stride;  // elements between split-K slabs
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    int m_real;           // rows that belong to the batch (statistics / dropout rows)
+    float* stat_partial;  // [gridDim.y][2][ld_stat]
+    int ld_stat;
+    float drop_scale;     // 1/(1-p); p == 0 disables dropout
+    uint32_t drop_thresh; // keep iff hash32 >= drop_thresh  (p * 2^32)
+    uint64_t drop_key;    // seed ^ step ^ layer
+    const uint8_t* drop_mask;  // injected keep-mask [m_real][ld_mask] (parity mode) or nullptr
+    int64_t ld_mask;
+};
+
+// counter-based uniform 32-bit hash (splitmix64 finaliser); also used by the backward kernels so the
+// dropout mask is regenerated instead of stored
+__host__ __device__ __forceinline__ uint32_t hash32(uint64_t key, uint64_t idx) {
+    uint64_t z = key + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+__device__ __forceinline__ bool dropout_keep(const GemmArgs& g, int row, int col) {
+    if (g.drop_mask) return g.drop_mask[(int64_t)row * g.ld_mask + col] != 0;
+    return hash32(g.drop_key, (uint64_t)row * (uint64_t)g.N + (uint64_t)col) >= g.drop_thresh;
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+    constexpr int BK = 32;
+    constexpr int SA = BM + (A_KC ? 1 : 4);
+    constexpr int SB = BN + (B_KC ? 1 : 4);
+    constexpr int TM = BM / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    constexpr int UA = BM * 8 / 256;  // float4 units per thread per tile
+    constexpr int UB = BN * 8 / 256;
+    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    static_assert(TM >= 1 && TN >= 1 && UA >= 1 && UB >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+    float* As = gemm_smem;                 // [2][BK][SA]
+    float* Bs = gemm_smem + 2 * BK * SA;   // [2][BK][SB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nchunks = (kend - kbeg) / BK;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra[UA], rb[UB];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < UA; ++r) {
+            const int u = tid + 256 * r;
+            if constexpr (A_KC) {
+                const int row = u >> 3, kq = u & 7, gm = m0 + row;
+                ra[r] = zero4;
+                if (gm < g.M) ra[r] = *reinterpret_cast<const float4*>(g.A + (int64_t)gm * g.lda + k0 + 4 * kq);
+            } else {
+                const int k = u / (BM / 4), mq = u % (BM / 4), gm = m0 + 4 * mq;
+                ra[r] = zero4;
+                if (gm < g.M) ra[r] = *reinterpret_cast<const float4*>(g.A + (int64_t)(k0 + k) * g.lda + gm);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < UB; ++r) {
+            const int u = tid + 256 * r;
+            if constexpr (B_KC) {
+                const int row = u >> 3, kq = u & 7, gn = n0 + row;
+                rb[r] = zero4;
+                if (gn < g.N) rb[r] = *reinterpret_cast<const float4*>(g.B + (int64_t)gn * g.ldb + k0 + 4 * kq);
+            } else {
+                const int k = u / (BN / 4), nq = u % (BN / 4), gn = n0 + 4 * nq;
+                rb[r] = zero4;
+                if (gn < g.N) rb[r] = *reinterpret_cast<const float4*>(g.B + (int64_t)(k0 + k) * g.ldb + gn);
+            }
+        }
+    };
+
+    auto sstore = [&](int buf) {
+        float* as = As + buf * BK * SA;
+        float* bs = Bs + buf * BK * SB;
+#pragma unroll
+        for (int r = 0; r < UA; ++r) {
+            const int u = tid + 256 * r;
+            if constexpr (A_KC) {
+                const int row = u >> 3, kq = u & 7;
+                as[(4 * kq + 0) * SA + row] = ra[r].x;
+                as[(4 * kq + 1) * SA + row] = ra[r].y;
+                as[(4 * kq + 2) * SA + row] = ra[r].z;
+                as[(4 * kq + 3) * SA + row] = ra[r].w;
+            } else {
+                const int k = u / (BM / 4), mq = u % (BM / 4);
+                *reinterpret_cast<float4*>(as + k * SA + 4 * mq) = ra[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < UB; ++r) {
+            const int u = tid + 256 * r;
+            if constexpr (B_KC) {
+                const int row = u >> 3, kq = u & 7;
+                bs[(4 * kq + 0) * SB + row] = rb[r].x;
+                bs[(4 * kq + 1) * SB + row] = rb[r].y;
+                bs[(4 * kq + 2) * SB + row] = rb[r].z;
+                bs[(4 * kq + 3) * SB + row] = rb[r].w;
+            } else {
+                const int k = u / (BN / 4), nq = u % (BN / 4);
+                *reinterpret_cast<float4*>(bs + k * SB + 4 * nq) = rb[r];
+            }
+        }
+    };
+
+    if (nchunks > 0) {
+        gload(kbeg);
+        sstore(0);
+    }
+    __syncthreads();
+
+    const int frag_k = lane >> 5;   // which of the 2 k's of an MFMA step this lane feeds
+    const int frag_r = lane & 31;   // row (A) / column (B) within the 32x32 tile
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) gload(kbeg + (c + 1) * BK);
+        const float* as = As + buf * BK * SA + (wm * TM * 32 + frag_r);
+        const float* bs = Bs + buf * BK * SB + (wn * TN * 32 + frag_r);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[(kk + frag_k) * SA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[(kk + frag_k) * SB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // epilogue.  acc[i][j][reg] is C[row][col] with
+    //   row = m0 + (wm*TM + i)*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5),  col = n0 + (wn*TN + j)*32 + (lane&31)
+    // ---------------------------------------------------------------------------------------
+    float* Cout = g.C;
+    if constexpr (EPI == EPI_SPLITK) Cout += (int64_t)blockIdx.z * g.slab_stride;
+
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + frag_r;
+        const bool col_ok = col < g.N;
+        float bias = 0.f, sc = 1.f, sh = 0.f;
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_HIDDEN_TRAIN || EPI == EPI_HIDDEN_EVAL || EPI == EPI_LATENT_MASK)
+            bias = col_ok ? g.bias[col] : 0.f;
+        if constexpr (EPI == EPI_HIDDEN_EVAL) {
+            sc = col_ok ? g.scale[col] : 0.f;
+            sh = col_ok ? g.shift[col] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * frag_k;
+                if (!col_ok || row >= g.M) continue;
+                float v = acc[i][j][reg];
+                if constexpr (EPI == EPI_BIAS) {
+                    v += bias;
+                } else if constexpr (EPI == EPI_HIDDEN_TRAIN) {
+                    v += bias;
+                    v = v > 0.f ? v : 0.01f * v;
+                    if (g.drop_scale != 1.0f || g.drop_mask) {
+                        const bool keep = (row < g.m_real) && dropout_keep(g, row, col);
+                        v = keep ? v * g.drop_scale : 0.f;
+                    }
+                    if (row < g.m_real) { s1[j] += v; s2[j] += v * v; }
+                } else if constexpr (EPI == EPI_HIDDEN_EVAL) {
+                    v += bias;
+                    v = v > 0.f ? v : 0.01f * v;
+                    v = v * sc + sh;
+                } else if constexpr (EPI == EPI_LATENT_MASK) {
+                    v += bias;
+                    v = __uint_as_float(__float_as_uint(v) & 0xFFFFF000u);
+                }
+                Cout[(int64_t)row * g.ldc + col] = v;
+            }
+        }
+    }
+
+    if constexpr (EPI == EPI_HIDDEN_TRAIN) {
+        // per-column partial sums of this workgroup's BM rows -> stat_partial[blockIdx.y][{0,1}][col]
+        float* red = gemm_smem;  // [2][WM][BN], reuses the operand tiles (all waves are past the last barrier)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 32);
+            if (lane < 32) {
+                const int cb = (wn * TN + j) * 32 + lane;
+                red[(0 * WM + wm) * BN + cb] = s1[j];
+                red[(1 * WM + wm) * BN + cb] = s2[j];
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += 256) {
+            const int stat = t / BN, cb = t % BN;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) s += red[(stat * WM + w) * BN + cb];
+            const int col = n0 + cb;
+            if (col < g.N) g.stat_partial[((int64_t)blockIdx.y * 2 + stat) * g.ld_stat + col] = s;
+        }
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+constexpr size_t gemm_smem_bytes() {
+    return sizeof(float) * 2 * 32 * ((BM + (A_KC ? 1 : 4)) + (BN + (B_KC ? 1 : 4)));
+}
+
+}  // namespace vh

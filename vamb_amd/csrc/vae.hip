@@ -1,0 +1,1023 @@
+// vae.hip -- MI355X (gfx950) implementation of vamb.encode.VAE's numerics behind the C ABI:
+// forward (encode.py:259-314), loss (316-357), backward (autograd of the same), BatchNorm1d,
+// dropout, D-Adapt-Adam (dadaptation 3.2, encode.py:578) and the eval-mode encode pass (442-484).
+//
+// HBM layout (per handle)
+//   X      [n][D_p]    the normalised feature matrix depths|tnf|abundance, rows padded to D_p = ru32(D)
+//   w      [n]         contig weights
+//   P/M1/M2/S  flat    parameters and D-Adapt-Adam moments; every tensor stored padded
+//                      ([rows_p][cols_p], multiples of 32, zero padding) in a 1024-element aligned slot
+//   per-batch workspaces sized for the current batch (bs_p = ru128(bs))
+// All dense contractions run on the fp32-input MFMA kernel of gemm.hpp; everything else is a small
+// bandwidth-bound kernel from vae_kernels.hpp.  One stream, no host synchronisation inside an epoch.
+#include "common.hpp"
+#include "gemm.hpp"
+#include "vae_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <map>
+#include <memory>
+#include <random>
+
+using namespace vh;
+
+namespace {
+
+constexpr int kColPad = 32;
+constexpr int kRowPad = 128;
+constexpr int kProbeRing = 512;
+
+struct Tensor {
+    std::string name;
+    int rows = 1, cols = 1;      // logical shape ([cols] vectors have rows == 1)
+    int rows_p = 1, cols_p = 1;  // padded shape
+    size_t off = 0;              // offset in the flat buffers (optimised tensors) or in bnbuf
+    size_t slot = 0;             // allocated elements (multiple of 1024)
+    bool optimised = true;
+    // gradient slabs for the current batch size
+    float* slab = nullptr;
+    int nslab = 0;
+    int64_t stride = 0;
+    int64_t logical() const { return (int64_t)rows * cols; }
+    int64_t padded() const { return (int64_t)rows_p * cols_p; }
+};
+
+struct Hidden {
+    int nin = 0, nout = 0, nin_p = 0, nout_p = 0;
+    int tW = -1, tb = -1, tG = -1, tB = -1, tRM = -1, tRV = -1;
+    DevBuf<float> H, A;                 // post-dropout activations, post-BN activations
+    DevBuf<float> mean, invstd, scale, shift;
+    DevBuf<uint8_t> mask;               // injected dropout keep-mask (parity mode)
+    long long batches_tracked = 0;
+};
+
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI>
+void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
+    static bool attr_set = false;
+    constexpr size_t smem = gemm_smem_bytes<BM, BN, AKC, BKC>();
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AKC, BKC, EPI>;
+    if (!attr_set) {
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, g);
+    VH_HIP(hipGetLastError());
+}
+
+// tile: 0 = 64x128 (2x2 waves), 1 = 128x128 (2x2), 2 = 128x32 (4x1)
+template <bool AKC, bool BKC, int EPI>
+void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
+    switch (tile) {
+        case 0: launch_gemm<64, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
+        case 1: launch_gemm<128, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
+        default: launch_gemm<128, 32, 4, 1, AKC, BKC, EPI>(s, g, splits); break;
+    }
+}
+
+int fwd_tile(int N) { return N <= 32 ? 2 : 0; }
+int stat_rows_per_block(int tile) { return tile == 0 ? 64 : 128; }
+
+GemmArgs base_args() {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.drop_scale = 1.0f;
+    return g;
+}
+
+}  // namespace
+
+struct vh_vae {
+    vh_vae_config cfg;
+    int nl = 0;       // hidden layers per side
+    int S = 0, D = 0, D_p = 0, L = 0, L_p = 0;
+    float ce_w = 0, ab_w = 0, sse_w = 0, kld_w = 0;
+    hipStream_t stream = nullptr;
+
+    std::vector<Tensor> tensors;
+    std::map<std::string, int> tindex;
+    std::vector<Hidden> hidden;   // encoder layers then decoder layers
+    int tWmu = -1, tbmu = -1, tWo = -1, tbo = -1;
+    size_t flat_elems = 0, bn_elems = 0;
+    DevBuf<float> P, M1, M2, Sv, bnbuf;
+
+    // dataset
+    int64_t n = 0;
+    DevBuf<float> X, w;
+    DevBuf<int64_t> perm;
+
+    // per-batch workspaces
+    int bs = 0, bs_p = 0;
+    DevBuf<float> Xb, Wb, MU, Z, EPS, R, dR, dMUk, DA, DZ, wsum, stat_part, bwd_part, S12, loss_part, slabs, out_sm;
+    DevBuf<TensorDesc> descs;
+    DevBuf<int> blk_tensor, blk_local;
+    DevBuf<double> opt_part;
+    DevBuf<StepState> state;
+    int opt_blocks = 0;
+    int loss_blocks = 0;
+    uint64_t step_counter = 0;
+
+    // probe
+    bool probe_on = false;
+    int probe_layer = 0;
+    std::vector<hipEvent_t> ev_a, ev_b;
+    int probe_used = 0;
+    double probe_ms = 0.0;
+    int64_t probe_launches = 0;
+    double probe_flops = 0.0;
+
+    ~vh_vae() {
+        for (auto e : ev_a) (void)hipEventDestroy(e);
+        for (auto e : ev_b) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    int add_tensor(const std::string& name, int rows, int cols, bool optimised) {
+        Tensor t;
+        t.name = name;
+        t.rows = rows;
+        t.cols = cols;
+        t.rows_p = rows == 1 ? 1 : (int)round_up(rows, kColPad);
+        t.cols_p = (int)round_up(cols, kColPad);
+        t.optimised = optimised;
+        t.slot = (size_t)round_up(t.padded(), 1024);
+        if (optimised) { t.off = flat_elems; flat_elems += t.slot; }
+        else { t.off = bn_elems; bn_elems += t.slot; }
+        tensors.push_back(t);
+        tindex[name] = (int)tensors.size() - 1;
+        return (int)tensors.size() - 1;
+    }
+    float* pptr(int t) { return (tensors[t].optimised ? P.p : bnbuf.p) + tensors[t].off; }
+};
+
+namespace {
+
+// ---- host <-> padded device layout ---------------------------------------------------------------
+void upload_tensor(vh_vae* h, int ti, const float* data) {
+    Tensor& t = h->tensors[ti];
+    std::vector<float> buf((size_t)t.slot, 0.0f);
+    for (int r = 0; r < t.rows; ++r)
+        memcpy(buf.data() + (size_t)r * t.cols_p, data + (size_t)r * t.cols, sizeof(float) * t.cols);
+    VH_HIP(hipMemcpyAsync(h->pptr(ti), buf.data(), sizeof(float) * t.slot, hipMemcpyHostToDevice, h->stream));
+    VH_HIP(hipStreamSynchronize(h->stream));
+}
+
+void download_padded(vh_vae* h, const Tensor& t, const float* dev, float* out) {
+    std::vector<float> buf((size_t)t.padded());
+    VH_HIP(hipMemcpyAsync(buf.data(), dev, sizeof(float) * buf.size(), hipMemcpyDeviceToHost, h->stream));
+    VH_HIP(hipStreamSynchronize(h->stream));
+    for (int r = 0; r < t.rows; ++r)
+        memcpy(out + (size_t)r * t.cols, buf.data() + (size_t)r * t.cols_p, sizeof(float) * t.cols);
+}
+
+void init_parameters(vh_vae* h) {
+    std::mt19937_64 rng(h->cfg.seed * 0x9E3779B97F4A7C15ull + 12345);
+    auto uniform_fill = [&](int ti, double bound) {
+        Tensor& t = h->tensors[ti];
+        std::uniform_real_distribution<double> dist(-bound, bound);
+        std::vector<float> v((size_t)t.logical());
+        for (auto& x : v) x = (float)dist(rng);
+        upload_tensor(h, ti, v.data());
+    };
+    auto const_fill = [&](int ti, float value) {
+        std::vector<float> v((size_t)h->tensors[ti].logical(), value);
+        upload_tensor(h, ti, v.data());
+    };
+    // torch.nn.Linear default: kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in)) for weight and bias
+    for (auto& hl : h->hidden) {
+        const double b = 1.0 / std::sqrt((double)hl.nin);
+        uniform_fill(hl.tW, b);
+        uniform_fill(hl.tb, b);
+        const_fill(hl.tG, 1.0f);
+        const_fill(hl.tB, 0.0f);
+        const_fill(hl.tRM, 0.0f);
+        const_fill(hl.tRV, 1.0f);
+    }
+    const double bmu = 1.0 / std::sqrt((double)h->hidden[h->nl - 1].nout);
+    uniform_fill(h->tWmu, bmu);
+    uniform_fill(h->tbmu, bmu);
+    const double bo = 1.0 / std::sqrt((double)h->hidden[2 * h->nl - 1].nout);
+    uniform_fill(h->tWo, bo);
+    uniform_fill(h->tbo, bo);
+}
+
+int dw_splits(int M, int N, int K, int tile) {
+    const int bm = tile == 0 ? 64 : 128, bn = tile == 2 ? 32 : 128;
+    const int tiles = (int)(ceil_div(M, bm) * ceil_div(N, bn));
+    int want = (int)std::max<int64_t>(1, ceil_div(512, tiles));
+    want = std::min(want, K / 32);
+    return std::max(1, want);
+}
+int dw_tile(int M, int N) {
+    if (N <= 32) return 2;
+    if (M >= 128) return 1;
+    return 0;
+}
+
+// (re)allocate everything that depends on the batch size
+void prepare_batch(vh_vae* h, int bs) {
+    if (bs == h->bs) return;
+    VH_HIP(hipStreamSynchronize(h->stream));
+    const int bs_p = (int)round_up(bs, kRowPad);
+    h->bs = bs;
+    h->bs_p = bs_p;
+    int maxw = std::max(h->D_p, h->L_p);
+    for (auto& hl : h->hidden) maxw = std::max(maxw, hl.nout_p);
+    h->Xb.ensure((size_t)bs_p * h->D_p);
+    h->Wb.ensure(bs_p);
+    h->MU.ensure((size_t)bs_p * h->L_p);
+    h->Z.ensure((size_t)bs_p * h->L_p);
+    h->EPS.ensure((size_t)bs_p * h->L_p);
+    h->R.ensure((size_t)bs_p * h->D_p);
+    h->dR.ensure((size_t)bs_p * h->D_p);
+    h->dMUk.ensure((size_t)bs_p * h->L_p);
+    h->DA.ensure((size_t)bs_p * maxw);
+    h->DZ.ensure((size_t)bs_p * maxw);
+    h->wsum.ensure(4);
+    h->stat_part.ensure((size_t)(bs_p / 64) * 2 * maxw);
+    const int nrb = bs_p / kRB;
+    h->bwd_part.ensure((size_t)nrb * 2 * maxw);
+    h->S12.ensure((size_t)2 * maxw);
+    h->loss_blocks = bs_p / 4;
+    h->loss_part.ensure((size_t)h->loss_blocks * 4);
+    h->out_sm.ensure((size_t)bs_p * std::max(1, h->S));
+    for (auto& hl : h->hidden) {
+        hl.H.ensure((size_t)bs_p * hl.nout_p);
+        hl.A.ensure((size_t)bs_p * hl.nout_p);
+    }
+    // gradient slabs: weights get split-K slabs, biases row-block partials, BN affine a single slab
+    size_t total = 0;
+    auto plan = [&](int ti, int nslab, int64_t stride) {
+        Tensor& t = h->tensors[ti];
+        t.nslab = nslab;
+        t.stride = stride;
+        t.slab = reinterpret_cast<float*>(total);  // offset for now
+        total += (size_t)round_up((int64_t)nslab * stride, 256);
+    };
+    for (auto& hl : h->hidden) {
+        const int tile = dw_tile(hl.nout_p, hl.nin_p);
+        plan(hl.tW, dw_splits(hl.nout_p, hl.nin_p, bs_p, tile), (int64_t)hl.nout_p * hl.nin_p);
+        plan(hl.tb, nrb, hl.nout_p);
+        plan(hl.tG, 1, hl.nout_p);
+        plan(hl.tB, 1, hl.nout_p);
+    }
+    {
+        const int hlast = h->hidden[h->nl - 1].nout_p;
+        plan(h->tWmu, dw_splits(h->L_p, hlast, bs_p, dw_tile(h->L_p, hlast)), (int64_t)h->L_p * hlast);
+        plan(h->tbmu, nrb, h->L_p);
+        const int hdec = h->hidden[2 * h->nl - 1].nout_p;
+        plan(h->tWo, dw_splits(h->D_p, hdec, bs_p, dw_tile(h->D_p, hdec)), (int64_t)h->D_p * hdec);
+        plan(h->tbo, nrb, h->D_p);
+    }
+    h->slabs.ensure(total);
+    std::vector<TensorDesc> descs;
+    std::vector<int> blk_tensor, blk_local;
+    for (auto& t : h->tensors) {
+        if (!t.optimised) continue;
+        t.slab = h->slabs.p + reinterpret_cast<size_t>(t.slab);
+        TensorDesc d;
+        d.slab = t.slab;
+        d.nslab = t.nslab;
+        d.stride = t.stride;
+        d.p_off = (int64_t)t.off;
+        d.size = t.padded();
+        const int id = (int)descs.size();
+        descs.push_back(d);
+        for (int b = 0; b < (int)ceil_div(t.padded(), 1024); ++b) {
+            blk_tensor.push_back(id);
+            blk_local.push_back(b);
+        }
+    }
+    h->opt_blocks = (int)blk_tensor.size();
+    h->descs.ensure(descs.size());
+    h->blk_tensor.ensure(blk_tensor.size());
+    h->blk_local.ensure(blk_local.size());
+    h->opt_part.ensure((size_t)h->opt_blocks * 2);
+    VH_HIP(hipMemcpy(h->descs.p, descs.data(), sizeof(TensorDesc) * descs.size(), hipMemcpyHostToDevice));
+    VH_HIP(hipMemcpy(h->blk_tensor.p, blk_tensor.data(), sizeof(int) * blk_tensor.size(), hipMemcpyHostToDevice));
+    VH_HIP(hipMemcpy(h->blk_local.p, blk_local.data(), sizeof(int) * blk_local.size(), hipMemcpyHostToDevice));
+}
+
+struct DropCfg {
+    float scale = 1.0f;
+    uint32_t thresh = 0;
+    bool injected = false;
+};
+
+DropCfg drop_cfg(vh_vae* h, bool training, bool injected) {
+    DropCfg d;
+    if (!training || h->cfg.dropout <= 0.0f) return d;
+    d.scale = 1.0f / (1.0f - h->cfg.dropout);
+    d.thresh = (uint32_t)std::min<double>(4294967295.0, (double)h->cfg.dropout * 4294967296.0);
+    d.injected = injected;
+    return d;
+}
+
+uint64_t layer_key(vh_vae* h, int layer) {
+    return (h->cfg.seed * 0xD1342543DE82EF95ull) ^ (h->step_counter << 8) ^ (uint64_t)layer;
+}
+
+void upload_masks(vh_vae* h, const uint8_t* masks, int bs) {
+    size_t off = 0;
+    for (auto& hl : h->hidden) {
+        std::vector<uint8_t> buf((size_t)h->bs_p * hl.nout_p, 0);
+        for (int r = 0; r < bs; ++r)
+            memcpy(buf.data() + (size_t)r * hl.nout_p, masks + off + (size_t)r * hl.nout, hl.nout);
+        off += (size_t)bs * hl.nout;
+        hl.mask.ensure(buf.size());
+        VH_HIP(hipMemcpyAsync(hl.mask.p, buf.data(), buf.size(), hipMemcpyHostToDevice, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+    }
+}
+
+void probe_record(vh_vae* h, bool start) {
+    if (!h->probe_on || h->probe_used >= kProbeRing) return;
+    if ((int)h->ev_a.size() <= h->probe_used) {
+        hipEvent_t a, b;
+        VH_HIP(hipEventCreate(&a));
+        VH_HIP(hipEventCreate(&b));
+        h->ev_a.push_back(a);
+        h->ev_b.push_back(b);
+    }
+    if (start) VH_HIP(hipEventRecord(h->ev_a[h->probe_used], h->stream));
+    else { VH_HIP(hipEventRecord(h->ev_b[h->probe_used], h->stream)); h->probe_used++; }
+}
+
+void probe_collect(vh_vae* h) {
+    for (int i = 0; i < h->probe_used; ++i) {
+        float ms = 0.f;
+        VH_HIP(hipEventElapsedTime(&ms, h->ev_a[i], h->ev_b[i]));
+        h->probe_ms += ms;
+        h->probe_launches++;
+    }
+    h->probe_used = 0;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------
+// Xb/Wb must hold the batch.  training: batch statistics + dropout + noise; else running statistics.
+void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, bool add_noise) {
+    const int bs = h->bs, bs_p = h->bs_p;
+    hipStream_t s = h->stream;
+    const DropCfg dc = drop_cfg(h, training, masks_injected);
+    const float* in = h->Xb.p;
+    int in_w = h->D_p;
+    auto hidden_layer = [&](int li) {
+        Hidden& hl = h->hidden[li];
+        const int tile = fwd_tile(hl.nout_p);
+        GemmArgs g = base_args();
+        g.A = in; g.lda = in_w;
+        g.B = h->pptr(hl.tW); g.ldb = hl.nin_p;
+        g.M = bs_p; g.N = hl.nout_p; g.K = hl.nin_p; g.k_per_split = g.K;
+        g.bias = h->pptr(hl.tb);
+        g.m_real = bs;
+        const bool probed = h->probe_on && training && li == h->probe_layer;
+        if (training) {
+            g.C = hl.H.p; g.ldc = hl.nout_p;
+            g.stat_partial = h->stat_part.p; g.ld_stat = hl.nout_p;
+            g.drop_scale = dc.scale; g.drop_thresh = dc.thresh; g.drop_key = layer_key(h, li);
+            g.drop_mask = dc.injected ? hl.mask.p : nullptr; g.ld_mask = hl.nout_p;
+            if (probed) { probe_record(h, true); h->probe_flops = 2.0 * bs * (double)hl.nin * hl.nout; }
+            gemm_tile<true, true, EPI_HIDDEN_TRAIN>(s, tile, g, 1);
+            if (probed) probe_record(h, false);
+            const int nb = bs_p / stat_rows_per_block(tile);
+            hipLaunchKernelGGL(vae_bn_finalize_kernel, dim3((unsigned)ceil_div(hl.nout_p, 256)), dim3(256), 0, s,
+                               h->stat_part.p, nb, hl.nout_p, hl.nout_p, bs, h->pptr(hl.tG), h->pptr(hl.tB),
+                               h->pptr(hl.tRM), h->pptr(hl.tRV), hl.mean.p, hl.invstd.p, hl.scale.p, hl.shift.p);
+            VH_HIP(hipGetLastError());
+            hl.batches_tracked++;
+            const int64_t total4 = (int64_t)bs_p * hl.nout_p / 4;
+            hipLaunchKernelGGL(vae_bn_apply_kernel, dim3((unsigned)std::min<int64_t>(2048, ceil_div(total4, 256))),
+                               dim3(256), 0, s, hl.H.p, hl.A.p, total4, hl.nout_p, hl.scale.p, hl.shift.p);
+            VH_HIP(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(vae_bn_eval_coeff_kernel, dim3((unsigned)ceil_div(hl.nout_p, 256)), dim3(256), 0, s,
+                               hl.nout_p, h->pptr(hl.tG), h->pptr(hl.tB), h->pptr(hl.tRM), h->pptr(hl.tRV),
+                               hl.scale.p, hl.shift.p);
+            VH_HIP(hipGetLastError());
+            g.C = hl.A.p; g.ldc = hl.nout_p;
+            g.scale = hl.scale.p; g.shift = hl.shift.p;
+            gemm_tile<true, true, EPI_HIDDEN_EVAL>(s, tile, g, 1);
+        }
+        in = hl.A.p;
+        in_w = hl.nout_p;
+    };
+    for (int li = 0; li < h->nl; ++li) hidden_layer(li);
+    {   // mu = a * Wmu^T + bmu  (encode.py:268)
+        GemmArgs g = base_args();
+        g.A = in; g.lda = in_w;
+        g.B = h->pptr(h->tWmu); g.ldb = in_w;
+        g.C = h->MU.p; g.ldc = h->L_p;
+        g.M = bs_p; g.N = h->L_p; g.K = in_w; g.k_per_split = g.K;
+        g.bias = h->pptr(h->tbmu);
+        gemm_tile<true, true, EPI_BIAS>(s, fwd_tile(h->L_p), g, 1);
+    }
+    {   // latent = mu + eps  (encode.py:276-286; sigma == 1)
+        const int64_t tot = (int64_t)bs_p * h->L_p;
+        if (!eps_injected) {
+            if (add_noise)
+                hipLaunchKernelGGL(vae_randn_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s, h->EPS.p, bs,
+                                   h->L, h->L_p, bs_p, layer_key(h, 0xEE));
+            else
+                VH_HIP(hipMemsetAsync(h->EPS.p, 0, sizeof(float) * tot, s));
+            VH_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(vae_reparam_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s, h->MU.p, h->EPS.p,
+                           h->Z.p, bs, h->L, h->L_p, bs_p);
+        VH_HIP(hipGetLastError());
+    }
+    in = h->Z.p;
+    in_w = h->L_p;
+    for (int li = h->nl; li < 2 * h->nl; ++li) hidden_layer(li);
+    {   // reconstruction = a * Wo^T + bo  (encode.py:294)
+        GemmArgs g = base_args();
+        g.A = in; g.lda = in_w;
+        g.B = h->pptr(h->tWo); g.ldb = in_w;
+        g.C = h->R.p; g.ldc = h->D_p;
+        g.M = bs_p; g.N = h->D_p; g.K = in_w; g.k_per_split = g.K;
+        g.bias = h->pptr(h->tbo);
+        gemm_tile<true, true, EPI_BIAS>(s, fwd_tile(h->D_p), g, 1);
+    }
+}
+
+void loss_and_seed(vh_vae* h) {
+    hipStream_t s = h->stream;
+    hipLaunchKernelGGL(vae_sum_kernel, dim3(1), dim3(256), 0, s, h->Wb.p, h->bs, h->wsum.p);
+    VH_HIP(hipGetLastError());
+    LossArgs a;
+    a.R = h->R.p; a.X = h->Xb.p; a.ld = h->D_p;
+    a.MU = h->MU.p; a.ldl = h->L_p;
+    a.wsum = h->wsum.p;
+    a.bs = h->bs; a.bs_p = h->bs_p; a.S = h->S; a.L = h->L;
+    a.ce_w = h->ce_w; a.ab_w = h->ab_w; a.sse_w = h->sse_w; a.kld_w = h->kld_w;
+    a.dR = h->dR.p; a.dMUk = h->dMUk.p; a.part = h->loss_part.p;
+    hipLaunchKernelGGL(vae_loss_kernel, dim3(h->loss_blocks), dim3(256), 0, s, a);
+    VH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, h->loss_part.p, h->loss_blocks, h->wsum.p,
+                       h->bs, h->state.p);
+    VH_HIP(hipGetLastError());
+}
+
+// dW slabs = dZ^T * In  (both operands row-contiguous along the batch)
+void grad_weight(vh_vae* h, int tW, const float* dZ, int out_p, const float* In, int in_p) {
+    Tensor& t = h->tensors[tW];
+    const int tile = dw_tile(out_p, in_p);
+    GemmArgs g = base_args();
+    g.A = dZ; g.lda = out_p;
+    g.B = In; g.ldb = in_p;
+    g.C = t.slab; g.ldc = in_p;
+    g.M = out_p; g.N = in_p; g.K = h->bs_p;
+    g.k_per_split = (int)round_up(ceil_div(h->bs_p, t.nslab), 32);
+    g.slab_stride = t.stride;
+    const int splits = (int)ceil_div(h->bs_p, g.k_per_split);
+    if (splits < t.nslab)  // unused slabs must read as zero
+        VH_HIP(hipMemsetAsync(t.slab + (int64_t)splits * t.stride, 0, sizeof(float) * (t.nslab - splits) * t.stride,
+                              h->stream));
+    gemm_tile<false, false, EPI_SPLITK>(h->stream, tile, g, splits);
+}
+
+// dIn = dZ * W   (dZ K-contiguous over the layer's outputs, W row-contiguous [out][in])
+void grad_input(vh_vae* h, const float* dZ, int out_p, int tW, int in_p, float* dIn) {
+    GemmArgs g = base_args();
+    g.A = dZ; g.lda = out_p;
+    g.B = h->pptr(tW); g.ldb = in_p;
+    g.C = dIn; g.ldc = in_p;
+    g.M = h->bs_p; g.N = in_p; g.K = out_p; g.k_per_split = g.K;
+    gemm_tile<true, false, EPI_STORE>(h->stream, fwd_tile(in_p), g, 1);
+}
+
+void backward(vh_vae* h, bool masks_injected) {
+    hipStream_t s = h->stream;
+    const int bs = h->bs, bs_p = h->bs_p, nrb = bs_p / kRB;
+    const DropCfg dc = drop_cfg(h, true, masks_injected);
+    // output layer
+    {
+        Hidden& last = h->hidden[2 * h->nl - 1];
+        grad_weight(h, h->tWo, h->dR.p, h->D_p, last.A.p, last.nout_p);
+        hipLaunchKernelGGL(vae_colsum_partial_kernel, dim3((unsigned)ceil_div(h->D_p, 256), nrb), dim3(256), 0, s,
+                           h->dR.p, (int64_t)h->D_p, h->D_p, bs_p, h->tensors[h->tbo].slab);
+        VH_HIP(hipGetLastError());
+        grad_input(h, h->dR.p, h->D_p, h->tWo, last.nout_p, h->DA.p);
+    }
+    auto hidden_bwd = [&](int li, const float* In, int in_p, bool need_dinput) {
+        Hidden& hl = h->hidden[li];
+        const dim3 grid((unsigned)ceil_div(hl.nout_p, 256), nrb);
+        hipLaunchKernelGGL(vae_bn_bwd_reduce_kernel, grid, dim3(256), 0, s, h->DA.p, hl.H.p, hl.nout_p, bs, hl.mean.p,
+                           hl.invstd.p, h->bwd_part.p);
+        VH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(vae_bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(hl.nout_p, 256)), dim3(256), 0, s,
+                           h->bwd_part.p, nrb, hl.nout_p, h->S12.p, h->tensors[hl.tG].slab, h->tensors[hl.tB].slab);
+        VH_HIP(hipGetLastError());
+        BnBwdArgs a;
+        a.DA = h->DA.p; a.H = hl.H.p; a.DZ = h->DZ.p;
+        a.n_p = hl.nout_p; a.bs = bs; a.bs_p = bs_p;
+        a.mean = hl.mean.p; a.invstd = hl.invstd.p; a.gamma = h->pptr(hl.tG); a.S12 = h->S12.p;
+        a.drop_scale = dc.scale; a.drop_thresh = dc.thresh; a.drop_key = layer_key(h, li);
+        a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
+        a.dbias_part = h->tensors[hl.tb].slab;
+        hipLaunchKernelGGL(vae_bn_bwd_apply_kernel, grid, dim3(256), 0, s, a);
+        VH_HIP(hipGetLastError());
+        grad_weight(h, hl.tW, h->DZ.p, hl.nout_p, In, in_p);
+        if (need_dinput) grad_input(h, h->DZ.p, hl.nout_p, hl.tW, in_p, h->DA.p);
+    };
+    for (int li = 2 * h->nl - 1; li >= h->nl; --li) {
+        const bool first_dec = li == h->nl;
+        const float* In = first_dec ? h->Z.p : h->hidden[li - 1].A.p;
+        const int in_p = first_dec ? h->L_p : h->hidden[li - 1].nout_p;
+        hidden_bwd(li, In, in_p, true);
+    }
+    {   // latent: dMU = dZlat + d(KLD)/dmu; mu layer
+        Hidden& enc_last = h->hidden[h->nl - 1];
+        hipLaunchKernelGGL(vae_latent_bwd_kernel, dim3((unsigned)ceil_div(h->L_p, 256), nrb), dim3(256), 0, s, h->DA.p,
+                           h->dMUk.p, h->DZ.p, h->L_p, bs, bs_p, h->tensors[h->tbmu].slab);
+        VH_HIP(hipGetLastError());
+        grad_weight(h, h->tWmu, h->DZ.p, h->L_p, enc_last.A.p, enc_last.nout_p);
+        grad_input(h, h->DZ.p, h->L_p, h->tWmu, enc_last.nout_p, h->DA.p);
+    }
+    for (int li = h->nl - 1; li >= 0; --li) {
+        const float* In = li == 0 ? h->Xb.p : h->hidden[li - 1].A.p;
+        const int in_p = li == 0 ? h->D_p : h->hidden[li - 1].nout_p;
+        hidden_bwd(li, In, in_p, li > 0);  // the input gradient of layer 0 is never needed
+    }
+}
+
+void optimizer_step(vh_vae* h) {
+    hipLaunchKernelGGL(vae_dadapt_kernel, dim3(h->opt_blocks), dim3(256), 0, h->stream, h->descs.p, h->blk_tensor.p,
+                       h->blk_local.p, h->P.p, h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p);
+    VH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(vae_dadapt_finalize_kernel, dim3(1), dim3(256), 0, h->stream, h->opt_part.p, h->opt_blocks,
+                       h->state.p);
+    VH_HIP(hipGetLastError());
+}
+
+void gather_rows(vh_vae* h, const int64_t* dev_idx) {
+    hipLaunchKernelGGL(vae_gather_kernel, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, h->stream, h->X.p,
+                       (int64_t)h->D_p, h->w.p, dev_idx, h->bs, h->bs_p, h->Xb.p, h->Wb.p);
+    VH_HIP(hipGetLastError());
+}
+
+void train_step_device(vh_vae* h, const int64_t* dev_idx, bool eps_injected, bool masks_injected) {
+    gather_rows(h, dev_idx);
+    forward(h, true, eps_injected, masks_injected, true);
+    loss_and_seed(h);
+    backward(h, masks_injected);
+    optimizer_step(h);
+    h->step_counter++;
+}
+
+void read_state(vh_vae* h, StepState* out) {
+    VH_HIP(hipMemcpyAsync(out, h->state.p, sizeof(StepState), hipMemcpyDeviceToHost, h->stream));
+    VH_HIP(hipStreamSynchronize(h->stream));
+}
+
+void reset_epoch_sums(vh_vae* h) {
+    const size_t off = offsetof(StepState, epoch_loss);
+    VH_HIP(hipMemsetAsync(reinterpret_cast<char*>(h->state.p) + off, 0, sizeof(StepState) - off, h->stream));
+}
+
+int find_tensor(vh_vae* h, const char* name) {
+    VH_REQUIRE(name != nullptr, "name is NULL");
+    auto it = h->tindex.find(name);
+    VH_REQUIRE(it != h->tindex.end(), "unknown parameter name '%s'", name);
+    return it->second;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
+    return guarded([&] {
+        VH_REQUIRE(cfg != nullptr && out != nullptr, "NULL argument");
+        *out = nullptr;
+        // encode.py:182-208
+        VH_REQUIRE(cfg->nlatent >= 1, "Minimum 1 latent neuron, not %d", cfg->nlatent);
+        VH_REQUIRE(cfg->nsamples >= 1, "nsamples must be > 0, not %d", cfg->nsamples);
+        VH_REQUIRE(cfg->nlayers >= 1 && cfg->nlayers <= VH_MAX_HIDDEN_LAYERS, "between 1 and %d hidden layers",
+                   VH_MAX_HIDDEN_LAYERS);
+        for (int i = 0; i < cfg->nlayers; ++i)
+            VH_REQUIRE(cfg->nhiddens[i] >= 1, "Minimum 1 neuron per layer, not %d", cfg->nhiddens[i]);
+        VH_REQUIRE(cfg->beta > 0, "beta must be > 0, not %g", (double)cfg->beta);
+        VH_REQUIRE(cfg->alpha > 0 && cfg->alpha < 1, "alpha must be 0 < alpha < 1, not %g", (double)cfg->alpha);
+        VH_REQUIRE(cfg->dropout >= 0 && cfg->dropout < 1, "dropout must be 0 <= dropout < 1, not %g",
+                   (double)cfg->dropout);
+        std::unique_ptr<vh_vae> h(new vh_vae());
+        h->cfg = *cfg;
+        h->nl = cfg->nlayers;
+        h->S = cfg->nsamples;
+        h->D = cfg->nsamples + VH_NTNF + 1;
+        h->D_p = (int)round_up(h->D, kColPad);
+        h->L = cfg->nlatent;
+        h->L_p = (int)round_up(h->L, kColPad);
+        // encode.py:333-343
+        const double a = cfg->alpha, S = cfg->nsamples;
+        h->ce_w = cfg->nsamples == 1 ? 0.0f : (float)(((1 - a) * (S - 1)) / (S * std::log(S)));
+        h->ab_w = (float)((1 - a) * (1 / S));
+        h->sse_w = (float)(a / VH_NTNF);
+        h->kld_w = (float)(1.0 / ((double)cfg->nlatent * cfg->beta));
+        VH_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+
+        h->hidden.resize(2 * h->nl);
+        auto make_hidden = [&](int li, const std::string& lin, const std::string& norm, int nin, int nout) {
+            Hidden& hl = h->hidden[li];
+            hl.nin = nin; hl.nout = nout;
+            hl.nin_p = (int)round_up(nin, kColPad);
+            hl.nout_p = (int)round_up(nout, kColPad);
+            hl.tW = h->add_tensor(lin + ".weight", nout, nin, true);
+            hl.tb = h->add_tensor(lin + ".bias", 1, nout, true);
+            hl.tG = h->add_tensor(norm + ".weight", 1, nout, true);
+            hl.tB = h->add_tensor(norm + ".bias", 1, nout, true);
+            hl.tRM = h->add_tensor(norm + ".running_mean", 1, nout, false);
+            hl.tRV = h->add_tensor(norm + ".running_var", 1, nout, false);
+            hl.mean.alloc(hl.nout_p); hl.invstd.alloc(hl.nout_p); hl.scale.alloc(hl.nout_p); hl.shift.alloc(hl.nout_p);
+        };
+        int nin = h->D;
+        for (int i = 0; i < h->nl; ++i) {
+            make_hidden(i, "encoderlayers." + std::to_string(i), "encodernorms." + std::to_string(i), nin,
+                        cfg->nhiddens[i]);
+            nin = cfg->nhiddens[i];
+        }
+        h->tWmu = h->add_tensor("mu.weight", h->L, nin, true);
+        h->tbmu = h->add_tensor("mu.bias", 1, h->L, true);
+        nin = h->L;
+        for (int i = 0; i < h->nl; ++i) {
+            const int nout = cfg->nhiddens[h->nl - 1 - i];
+            make_hidden(h->nl + i, "decoderlayers." + std::to_string(i), "decodernorms." + std::to_string(i), nin, nout);
+            nin = nout;
+        }
+        h->tWo = h->add_tensor("outputlayer.weight", h->D, nin, true);
+        h->tbo = h->add_tensor("outputlayer.bias", 1, h->D, true);
+
+        h->P.alloc(h->flat_elems); h->M1.alloc(h->flat_elems); h->M2.alloc(h->flat_elems); h->Sv.alloc(h->flat_elems);
+        h->bnbuf.alloc(h->bn_elems);
+        VH_HIP(hipMemsetAsync(h->P.p, 0, h->P.bytes(), h->stream));
+        VH_HIP(hipMemsetAsync(h->M1.p, 0, h->M1.bytes(), h->stream));
+        VH_HIP(hipMemsetAsync(h->M2.p, 0, h->M2.bytes(), h->stream));
+        VH_HIP(hipMemsetAsync(h->Sv.p, 0, h->Sv.bytes(), h->stream));
+        VH_HIP(hipMemsetAsync(h->bnbuf.p, 0, h->bnbuf.bytes(), h->stream));
+        h->state.alloc(1);
+        StepState st;
+        memset(&st, 0, sizeof(st));
+        st.d = 1e-6;  // DAdaptAdam d0
+        VH_HIP(hipMemcpyAsync(h->state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+        init_parameters(h.get());
+        *out = h.release();
+    });
+}
+
+int vh_vae_destroy(vh_vae* h) {
+    return guarded([&] { delete h; });
+}
+
+int vh_vae_param_size(vh_vae* h, const char* name, int64_t* n) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && n != nullptr, "NULL argument");
+        std::string s(name ? name : "");
+        const std::string suffix = ".num_batches_tracked";
+        if (s.size() > suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0) {
+            find_tensor(h, (s.substr(0, s.size() - suffix.size()) + ".running_mean").c_str());
+            *n = 1;
+            return;
+        }
+        *n = h->tensors[find_tensor(h, name)].logical();
+    });
+}
+
+int vh_vae_set_param(vh_vae* h, const char* name, const float* data, int64_t n) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && data != nullptr, "NULL argument");
+        std::string s(name ? name : "");
+        const std::string suffix = ".num_batches_tracked";
+        if (s.size() > suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0) {
+            const int ti = find_tensor(h, (s.substr(0, s.size() - suffix.size()) + ".running_mean").c_str());
+            VH_REQUIRE(n == 1, "num_batches_tracked has one element");
+            for (auto& hl : h->hidden)
+                if (hl.tRM == ti) hl.batches_tracked = (long long)data[0];
+            return;
+        }
+        const int ti = find_tensor(h, name);
+        VH_REQUIRE(n == h->tensors[ti].logical(), "parameter '%s' has %lld elements, got %lld", name,
+                   (long long)h->tensors[ti].logical(), (long long)n);
+        upload_tensor(h, ti, data);
+    });
+}
+
+int vh_vae_get_param(vh_vae* h, const char* name, float* data, int64_t n) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && data != nullptr, "NULL argument");
+        std::string s(name ? name : "");
+        const std::string suffix = ".num_batches_tracked";
+        if (s.size() > suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0) {
+            const int ti = find_tensor(h, (s.substr(0, s.size() - suffix.size()) + ".running_mean").c_str());
+            VH_REQUIRE(n == 1, "num_batches_tracked has one element");
+            for (auto& hl : h->hidden)
+                if (hl.tRM == ti) data[0] = (float)hl.batches_tracked;
+            return;
+        }
+        const int ti = find_tensor(h, name);
+        const Tensor& t = h->tensors[ti];
+        VH_REQUIRE(n == t.logical(), "parameter '%s' has %lld elements, got %lld", name, (long long)t.logical(),
+                   (long long)n);
+        download_padded(h, t, h->pptr(ti), data);
+    });
+}
+
+int vh_vae_get_grad(vh_vae* h, const char* name, float* data, int64_t n) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && data != nullptr, "NULL argument");
+        const int ti = find_tensor(h, name);
+        const Tensor& t = h->tensors[ti];
+        VH_REQUIRE(t.optimised, "'%s' is a buffer, not a parameter", name);
+        VH_REQUIRE(t.slab != nullptr, "no training step has run yet");
+        VH_REQUIRE(n == t.logical(), "parameter '%s' has %lld elements, got %lld", name, (long long)t.logical(),
+                   (long long)n);
+        std::vector<float> slab((size_t)t.nslab * t.stride);
+        VH_HIP(hipMemcpyAsync(slab.data(), t.slab, sizeof(float) * slab.size(), hipMemcpyDeviceToHost, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+        for (int r = 0; r < t.rows; ++r)
+            for (int c = 0; c < t.cols; ++c) {
+                float g = 0.f;  // same slab order as the optimiser kernel
+                for (int s = 0; s < t.nslab; ++s) g += slab[(size_t)s * t.stride + (size_t)r * t.cols_p + c];
+                data[(size_t)r * t.cols + c] = g;
+            }
+    });
+}
+
+int vh_vae_set_dataset(vh_vae* h, const float* depths, const float* tnf, const float* abundance, const float* weights,
+                       int64_t n) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && depths && tnf && abundance && weights, "NULL argument");
+        VH_REQUIRE(n >= 1, "empty dataset");
+        h->n = n;
+        h->X.alloc((size_t)n * h->D_p);
+        h->w.alloc((size_t)n);
+        // assemble padded rows on the host in chunks (one H2D per chunk)
+        const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / (h->D_p * 4));
+        std::vector<float> buf((size_t)std::min(chunk, n) * h->D_p);
+        for (int64_t lo = 0; lo < n; lo += chunk) {
+            const int64_t hi = std::min(n, lo + chunk);
+            std::fill(buf.begin(), buf.end(), 0.0f);
+            for (int64_t r = lo; r < hi; ++r) {
+                float* dst = buf.data() + (size_t)(r - lo) * h->D_p;
+                memcpy(dst, depths + (size_t)r * h->S, sizeof(float) * h->S);
+                memcpy(dst + h->S, tnf + (size_t)r * VH_NTNF, sizeof(float) * VH_NTNF);
+                dst[h->S + VH_NTNF] = abundance[r];
+            }
+            VH_HIP(hipMemcpy(h->X.p + (size_t)lo * h->D_p, buf.data(), sizeof(float) * (size_t)(hi - lo) * h->D_p,
+                             hipMemcpyHostToDevice));
+        }
+        VH_HIP(hipMemcpy(h->w.p, weights, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    });
+}
+
+int vh_vae_train_step(vh_vae* h, const int64_t* rows, int64_t batch, const float* eps, const uint8_t* masks,
+                      double losses[5]) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && rows != nullptr, "NULL argument");
+        VH_REQUIRE(h->n > 0, "no dataset: call vh_vae_set_dataset first");
+        VH_REQUIRE(batch >= 2, "BatchNorm1d needs more than 1 value per channel when training (batch=%lld)",
+                   (long long)batch);
+        VH_REQUIRE(batch <= (1 << 24), "batch too large");
+        for (int64_t i = 0; i < batch; ++i)
+            VH_REQUIRE(rows[i] >= 0 && rows[i] < h->n, "row %lld out of range", (long long)rows[i]);
+        prepare_batch(h, (int)batch);
+        h->perm.ensure((size_t)batch);
+        VH_HIP(hipMemcpyAsync(h->perm.p, rows, sizeof(int64_t) * batch, hipMemcpyHostToDevice, h->stream));
+        if (eps) {
+            std::vector<float> e((size_t)h->bs_p * h->L_p, 0.f);
+            for (int r = 0; r < batch; ++r) memcpy(e.data() + (size_t)r * h->L_p, eps + (size_t)r * h->L, sizeof(float) * h->L);
+            VH_HIP(hipMemcpyAsync(h->EPS.p, e.data(), sizeof(float) * e.size(), hipMemcpyHostToDevice, h->stream));
+            VH_HIP(hipStreamSynchronize(h->stream));
+        }
+        if (masks && h->cfg.dropout > 0) upload_masks(h, masks, (int)batch);
+        reset_epoch_sums(h);
+        train_step_device(h, h->perm.p, eps != nullptr, masks != nullptr && h->cfg.dropout > 0);
+        StepState st;
+        read_state(h, &st);
+        probe_collect(h);
+        if (losses)
+            for (int i = 0; i < 5; ++i) losses[i] = st.step_loss[i];
+    });
+}
+
+int vh_vae_train_epoch(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, double loss_means[5]) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && perm != nullptr, "NULL argument");
+        VH_REQUIRE(h->n > 0, "no dataset: call vh_vae_set_dataset first");
+        VH_REQUIRE(n_batches >= 1, "no batches");
+        VH_REQUIRE(batch >= 2, "BatchNorm1d needs more than 1 value per channel when training (batch=%lld)",
+                   (long long)batch);
+        VH_REQUIRE(batch <= (1 << 24), "batch too large");
+        const int64_t total = n_batches * batch;
+        for (int64_t i = 0; i < total; ++i)
+            VH_REQUIRE(perm[i] >= 0 && perm[i] < h->n, "row %lld out of range", (long long)perm[i]);
+        prepare_batch(h, (int)batch);
+        h->perm.ensure((size_t)total);
+        VH_HIP(hipMemcpyAsync(h->perm.p, perm, sizeof(int64_t) * total, hipMemcpyHostToDevice, h->stream));
+        reset_epoch_sums(h);
+        for (int64_t b = 0; b < n_batches; ++b) train_step_device(h, h->perm.p + b * batch, false, false);
+        StepState st;
+        read_state(h, &st);
+        probe_collect(h);
+        if (loss_means)
+            for (int i = 0; i < 5; ++i) loss_means[i] = st.epoch_loss[i] / (double)n_batches;
+    });
+}
+
+int vh_vae_forward(vh_vae* h, const float* depths, const float* tnf, const float* abundance, int64_t batch,
+                   int training, const float* eps, const uint8_t* masks, float* depths_out, float* tnf_out,
+                   float* abundance_out, float* mu_out) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && depths && tnf && abundance, "NULL argument");
+        VH_REQUIRE(batch >= 1 && batch <= (1 << 24), "bad batch size");
+        VH_REQUIRE(!training || batch >= 2, "Expected more than 1 value per channel when training");
+        prepare_batch(h, (int)batch);
+        std::vector<float> xb((size_t)h->bs_p * h->D_p, 0.f);
+        for (int64_t r = 0; r < batch; ++r) {
+            float* dst = xb.data() + (size_t)r * h->D_p;
+            memcpy(dst, depths + (size_t)r * h->S, sizeof(float) * h->S);
+            memcpy(dst + h->S, tnf + (size_t)r * VH_NTNF, sizeof(float) * VH_NTNF);
+            dst[h->S + VH_NTNF] = abundance[r];
+        }
+        VH_HIP(hipMemcpyAsync(h->Xb.p, xb.data(), sizeof(float) * xb.size(), hipMemcpyHostToDevice, h->stream));
+        std::vector<float> e;
+        if (eps) {
+            e.assign((size_t)h->bs_p * h->L_p, 0.f);
+            for (int r = 0; r < batch; ++r) memcpy(e.data() + (size_t)r * h->L_p, eps + (size_t)r * h->L, sizeof(float) * h->L);
+            VH_HIP(hipMemcpyAsync(h->EPS.p, e.data(), sizeof(float) * e.size(), hipMemcpyHostToDevice, h->stream));
+        }
+        VH_HIP(hipStreamSynchronize(h->stream));
+        const bool inj_masks = training && masks != nullptr && h->cfg.dropout > 0;
+        if (inj_masks) upload_masks(h, masks, (int)batch);
+        forward(h, training != 0, eps != nullptr, inj_masks, true);
+        h->step_counter++;
+        // outputs
+        std::vector<float> r((size_t)batch * h->D_p);
+        VH_HIP(hipMemcpyAsync(r.data(), h->R.p, sizeof(float) * r.size(), hipMemcpyDeviceToHost, h->stream));
+        if (depths_out) {
+            hipLaunchKernelGGL(vae_softmax_out_kernel, dim3((unsigned)ceil_div(batch, 4)), dim3(256), 0, h->stream,
+                               h->R.p, (int64_t)h->D_p, (int)batch, h->S, h->out_sm.p);
+            VH_HIP(hipGetLastError());
+            VH_HIP(hipMemcpyAsync(depths_out, h->out_sm.p, sizeof(float) * (size_t)batch * h->S, hipMemcpyDeviceToHost,
+                                  h->stream));
+        }
+        std::vector<float> mu;
+        if (mu_out) {
+            mu.resize((size_t)batch * h->L_p);
+            VH_HIP(hipMemcpyAsync(mu.data(), h->MU.p, sizeof(float) * mu.size(), hipMemcpyDeviceToHost, h->stream));
+        }
+        VH_HIP(hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < batch; ++i) {
+            if (tnf_out) memcpy(tnf_out + (size_t)i * VH_NTNF, r.data() + (size_t)i * h->D_p + h->S, sizeof(float) * VH_NTNF);
+            if (abundance_out) abundance_out[i] = r[(size_t)i * h->D_p + h->S + VH_NTNF];
+            if (mu_out) memcpy(mu_out + (size_t)i * h->L, mu.data() + (size_t)i * h->L_p, sizeof(float) * h->L);
+        }
+    });
+}
+
+int vh_vae_encode(vh_vae* h, float* latent) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && latent != nullptr, "NULL argument");
+        VH_REQUIRE(h->n > 0, "no dataset: call vh_vae_set_dataset first");
+        hipStream_t s = h->stream;
+        const int64_t chunk = 16384;
+        int maxw = 0;
+        for (int li = 0; li < h->nl; ++li) maxw = std::max(maxw, h->hidden[li].nout_p);
+        DevBuf<float> a0, a1, lat;
+        a0.alloc((size_t)chunk * maxw);
+        a1.alloc((size_t)chunk * maxw);
+        lat.alloc((size_t)chunk * h->L);
+        for (int li = 0; li < h->nl; ++li) {
+            Hidden& hl = h->hidden[li];
+            hipLaunchKernelGGL(vae_bn_eval_coeff_kernel, dim3((unsigned)ceil_div(hl.nout_p, 256)), dim3(256), 0, s,
+                               hl.nout_p, h->pptr(hl.tG), h->pptr(hl.tB), h->pptr(hl.tRM), h->pptr(hl.tRV),
+                               hl.scale.p, hl.shift.p);
+            VH_HIP(hipGetLastError());
+        }
+        for (int64_t lo = 0; lo < h->n; lo += chunk) {
+            const int m = (int)std::min<int64_t>(chunk, h->n - lo);
+            const float* in = h->X.p + (size_t)lo * h->D_p;
+            int in_w = h->D_p;
+            float* bufs[2] = {a0.p, a1.p};
+            for (int li = 0; li < h->nl; ++li) {
+                Hidden& hl = h->hidden[li];
+                GemmArgs g = base_args();
+                g.A = in; g.lda = in_w;
+                g.B = h->pptr(hl.tW); g.ldb = hl.nin_p;
+                g.C = bufs[li & 1]; g.ldc = hl.nout_p;
+                g.M = m; g.N = hl.nout_p; g.K = hl.nin_p; g.k_per_split = g.K;
+                g.bias = h->pptr(hl.tb); g.scale = hl.scale.p; g.shift = hl.shift.p; g.m_real = m;
+                gemm_tile<true, true, EPI_HIDDEN_EVAL>(s, fwd_tile(hl.nout_p), g, 1);
+                in = bufs[li & 1];
+                in_w = hl.nout_p;
+            }
+            GemmArgs g = base_args();
+            g.A = in; g.lda = in_w;
+            g.B = h->pptr(h->tWmu); g.ldb = in_w;
+            g.C = lat.p; g.ldc = h->L;          // compact [m][L]: only the logical columns are stored
+            g.M = m; g.N = h->L; g.K = in_w; g.k_per_split = g.K;
+            g.bias = h->pptr(h->tbmu);
+            gemm_tile<true, true, EPI_LATENT_MASK>(s, fwd_tile(h->L_p), g, 1);
+            VH_HIP(hipMemcpyAsync(latent + (size_t)lo * h->L, lat.p, sizeof(float) * (size_t)m * h->L,
+                                  hipMemcpyDeviceToHost, s));
+            VH_HIP(hipStreamSynchronize(s));
+        }
+    });
+}
+
+int vh_vae_opt_state(vh_vae* h, double* d, double* numerator_weighted, int64_t* k) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "NULL argument");
+        StepState st;
+        read_state(h, &st);
+        if (d) *d = st.d;
+        if (numerator_weighted) *numerator_weighted = st.numerator_weighted;
+        if (k) *k = st.k;
+    });
+}
+
+int vh_vae_set_probe(vh_vae* h, int enable, int layer) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "NULL argument");
+        VH_REQUIRE(layer >= 0 && layer < 2 * h->nl, "layer out of range");
+        h->probe_on = enable != 0;
+        h->probe_layer = layer;
+        h->probe_ms = 0.0;
+        h->probe_launches = 0;
+        h->probe_used = 0;
+    });
+}
+
+int vh_vae_probe_result(vh_vae* h, double* ms_total, int64_t* launches, double* flops_per_launch) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "NULL argument");
+        if (ms_total) *ms_total = h->probe_ms;
+        if (launches) *launches = h->probe_launches;
+        if (flops_per_launch) *flops_per_launch = h->probe_flops;
+    });
+}
+
+int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, const float* bias, float* C, int M,
+                  int N, int K, int splits, float* ms) {
+    return guarded([&] {
+        VH_REQUIRE(A && B && C, "NULL argument");
+        VH_REQUIRE(tile >= 0 && tile <= 2, "tile in {0,1,2}");
+        VH_REQUIRE(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && M % 4 == 0 && N % 4 == 0,
+                   "need K multiple of 32 and M, N multiples of 4");
+        VH_REQUIRE(splits >= 1 && (K / 32) >= splits, "bad split count");
+        VH_REQUIRE(!(bias && (splits > 1 || !a_kc || !b_kc)), "bias only with K-contiguous operands and one split");
+        VH_REQUIRE(!(a_kc == 0 && b_kc == 1), "layout (row-contiguous A, K-contiguous B) is not instantiated");
+        hipStream_t s;
+        VH_HIP(hipStreamCreate(&s));
+        DevBuf<float> dA, dB, dC, dbias;
+        dA.alloc((size_t)M * K); dB.alloc((size_t)N * K);
+        const int k_per = (int)round_up(ceil_div(K, splits), 32);
+        const int nsplit = (int)ceil_div(K, k_per);
+        dC.alloc((size_t)nsplit * M * N);
+        VH_HIP(hipMemcpy(dA.p, A, sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
+        VH_HIP(hipMemcpy(dB.p, B, sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice));
+        if (bias) { dbias.alloc(N); VH_HIP(hipMemcpy(dbias.p, bias, sizeof(float) * N, hipMemcpyHostToDevice)); }
+        GemmArgs g = base_args();
+        g.A = dA.p; g.lda = a_kc ? K : M;
+        g.B = dB.p; g.ldb = b_kc ? K : N;
+        g.C = dC.p; g.ldc = N;
+        g.M = M; g.N = N; g.K = K; g.k_per_split = k_per; g.slab_stride = (int64_t)M * N;
+        g.bias = dbias.p; g.m_real = M;
+        hipEvent_t e0, e1;
+        VH_HIP(hipEventCreate(&e0));
+        VH_HIP(hipEventCreate(&e1));
+        auto run = [&] {
+            if (a_kc && b_kc) {
+                if (bias) gemm_tile<true, true, EPI_BIAS>(s, tile, g, 1);
+                else gemm_tile<true, true, EPI_SPLITK>(s, tile, g, nsplit);
+            } else if (a_kc && !b_kc) {
+                gemm_tile<true, false, EPI_SPLITK>(s, tile, g, nsplit);
+            } else {
+                gemm_tile<false, false, EPI_SPLITK>(s, tile, g, nsplit);
+            }
+        };
+        run();  // warm-up (also sets the LDS attribute)
+        VH_HIP(hipEventRecord(e0, s));
+        run();
+        VH_HIP(hipEventRecord(e1, s));
+        VH_HIP(hipStreamSynchronize(s));
+        float t = 0.f;
+        VH_HIP(hipEventElapsedTime(&t, e0, e1));
+        if (ms) *ms = t;
+        std::vector<float> hc((size_t)nsplit * M * N);
+        VH_HIP(hipMemcpy(hc.data(), dC.p, sizeof(float) * hc.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < (size_t)M * N; ++i) {
+            float acc = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) acc += hc[(size_t)sp * M * N + i];
+            C[i] = acc;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(s);
+    });
+}
+
+}  // extern "C"

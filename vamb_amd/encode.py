@@ -1,0 +1,442 @@
+"""VAE training / encoding on MI355X -- drop-in for ``vamb.encode``.
+
+``make_dataloader``, ``set_batchsize`` and ``VAE`` keep the reference's signatures, argument meaning
+and ``ValueError`` behaviour (``/root/reference/vamb/encode.py:33-610``) so that
+``vamb.__main__.trainvae`` (``__main__.py:1065-1107``) runs unchanged on top of them.
+
+Division of labour
+  * host (this file): feature normalisation with numpy exactly as the reference does it
+    (encode.py:98-126; the DataLoader object is the reference's own boundary type), the epoch /
+    batch-size schedule (359-440, 543-610), shuffling, logging, ``model.pt`` (486-541).
+  * device (``csrc/vae.hip`` through the C ABI): everything inside the batch loop -- forward, loss,
+    backward, D-Adapt-Adam -- and the eval-mode encode pass.  The normalised feature matrix is
+    uploaded once and stays resident in HBM; there is one host synchronisation per epoch.
+"""
+from __future__ import annotations
+
+import ctypes
+import logging
+from collections import OrderedDict
+from math import log as _log
+from pathlib import Path
+from typing import IO, Optional, Union
+
+import numpy as _np
+import torch as _torch
+from torch.utils.data import DataLoader as _DataLoader
+from torch.utils.data.dataset import TensorDataset as _TensorDataset
+
+from . import _lib
+
+logger = logging.getLogger("vamb_amd.encode")
+NTNF = 103
+
+
+def _zscore_inplace(array: _np.ndarray, axis: Optional[int] = None) -> None:
+    """In-place z-score with the reference's conventions (vambtools.py:250-288): population std,
+    zero std replaced by 1."""
+    mean = array.mean(axis=axis)
+    std = array.std(axis=axis)
+    if axis is None:
+        if std == 0:
+            std = 1
+    else:
+        std[std == 0.0] = 1
+        shape = tuple(dim if ax != axis else 1 for ax, dim in enumerate(array.shape))
+        mean.shape, std.shape = shape, shape
+    array -= mean
+    array /= std
+
+
+def set_batchsize(data_loader: _DataLoader, batch_size: int, n_obs: int, encode=False) -> _DataLoader:
+    """Copy of the data loader with another batch size (encode.py:33-50).  ``encode=True`` gives the
+    ordered, keep-everything loader used before encoding."""
+    return _DataLoader(
+        dataset=data_loader.dataset,
+        batch_size=batch_size,
+        shuffle=not encode,
+        drop_last=not encode and (n_obs > batch_size),
+        num_workers=0,
+        pin_memory=data_loader.pin_memory,
+        collate_fn=data_loader.collate_fn,
+    )
+
+
+def make_dataloader(abundance: _np.ndarray, tnf: _np.ndarray, lengths: _np.ndarray, batchsize: int = 256,
+                    destroy: bool = False, cuda: bool = False) -> _DataLoader:
+    """Normalise abundance / TNF / lengths and wrap them as the reference's DataLoader
+    (encode.py:53-146): tensors are (depths [N,S], tnf [N,103], total_abundance [N,1], weights [N,1])."""
+    if not isinstance(abundance, _np.ndarray) or not isinstance(tnf, _np.ndarray):
+        raise ValueError("TNF and abundance must be Numpy arrays")
+    if batchsize < 1:
+        raise ValueError(f"Batch size must be minimum 1, not {batchsize}")
+    if len(abundance) != len(tnf) or len(tnf) != len(lengths):
+        raise ValueError("Lengths of abundance, TNF and lengths arrays must be the same")
+    if not (abundance.dtype == tnf.dtype == _np.float32):
+        raise ValueError("TNF and abundance must be Numpy arrays of dtype float32")
+    if not destroy:
+        abundance = abundance.copy()
+        tnf = tnf.copy()
+
+    # equal sequencing depth per sample, then per-contig total and relative abundance (98-113)
+    sample_depths_sum = abundance.sum(axis=0)
+    if _np.any(sample_depths_sum == 0):
+        raise ValueError("One or more samples have zero depth in all sequences, so cannot be depth normalized")
+    abundance *= 1_000_000 / sample_depths_sum
+    total_abundance = abundance.sum(axis=1)
+    n_samples = abundance.shape[1]
+    zero_total = total_abundance == 0
+    abundance[zero_total] = 1 / n_samples
+    divisor = total_abundance.copy()
+    divisor[zero_total] = 1.0
+    abundance /= divisor.reshape((-1, 1))
+
+    # log total abundance and TNF are z-scored (116-119)
+    total_abundance = _np.log(total_abundance.clip(min=0.001))
+    _zscore_inplace(total_abundance)
+    _zscore_inplace(tnf, axis=0)
+    total_abundance.shape = (len(total_abundance), 1)
+
+    # contig weights from lengths (122-126)
+    lengths = lengths.astype(_np.float32)
+    weights = _np.log(lengths).astype(_np.float32) - 5.0
+    weights[weights < 2.0] = 2.0
+    weights *= len(weights) / weights.sum()
+    weights.shape = (len(weights), 1)
+
+    dataset = _TensorDataset(_torch.from_numpy(abundance), _torch.from_numpy(tnf),
+                             _torch.from_numpy(total_abundance), _torch.from_numpy(weights))
+    # The loader is only a container here (the batch loop runs on the GPU over the resident matrix),
+    # so no worker processes are spawned.
+    return _DataLoader(dataset=dataset, batch_size=batchsize, drop_last=(len(abundance) > batchsize),
+                       shuffle=True, num_workers=0, pin_memory=False)
+
+
+class _Config(ctypes.Structure):
+    _fields_ = [("nsamples", ctypes.c_int32), ("nlatent", ctypes.c_int32), ("nlayers", ctypes.c_int32),
+                ("nhiddens", ctypes.c_int32 * 8), ("alpha", ctypes.c_float), ("beta", ctypes.c_float),
+                ("dropout", ctypes.c_float), ("seed", ctypes.c_uint64)]
+
+
+def _as_f32(x) -> _np.ndarray:
+    if isinstance(x, _torch.Tensor):
+        x = x.detach().cpu().numpy()
+    return _np.ascontiguousarray(x, dtype=_np.float32)
+
+
+class VAE:
+    """Variational autoencoder with the reference's interface (encode.py:149-257); the network lives
+    on the GPU behind ``libvambhip``.
+
+    Instantiate with:
+        nsamples: Number of samples in abundance matrix
+        nhiddens: list of n_neurons in the hidden layers [None=Auto]
+        nlatent: Number of neurons in the latent layer [32]
+        alpha: Approximate starting TNF/(CE+TNF) ratio in loss. [None = Auto]
+        beta: Multiply KLD by the inverse of this value [200]
+        dropout: Probability of dropout on forward pass [0.2]
+        cuda: accepted for compatibility; the model always runs on the GPU
+        seed: seeds parameter initialisation, shuffling, dropout and noise
+    """
+
+    def __init__(self, nsamples: int, nhiddens: Optional[list[int]] = None, nlatent: int = 32,
+                 alpha: Optional[float] = None, beta: float = 200.0, dropout: Optional[float] = 0.2,
+                 cuda: bool = False, seed: int = 0):
+        if nlatent < 1:
+            raise ValueError(f"Minimum 1 latent neuron, not {nlatent}")
+        if nsamples < 1:
+            raise ValueError(f"nsamples must be > 0, not {nsamples}")
+        if alpha is None:
+            alpha = 0.15 if nsamples > 1 else 0.50
+        if nhiddens is None:
+            nhiddens = [512, 512] if nsamples > 1 else [256, 256]
+        if dropout is None:
+            dropout = 0.2 if nsamples > 1 else 0.0
+        if any(i < 1 for i in nhiddens):
+            raise ValueError(f"Minimum 1 neuron per layer, not {min(nhiddens)}")
+        if beta <= 0:
+            raise ValueError(f"beta must be > 0, not {beta}")
+        if not (0 < alpha < 1):
+            raise ValueError(f"alpha must be 0 < alpha < 1, not {alpha}")
+        if not (0 <= dropout < 1):
+            raise ValueError(f"dropout must be 0 <= dropout < 1, not {dropout}")
+        if len(nhiddens) > 8:
+            raise ValueError("at most 8 hidden layers are supported")
+
+        _torch.manual_seed(seed)
+        self.usecuda = True
+        self.nsamples = nsamples
+        self.ntnf = NTNF
+        self.alpha = alpha
+        self.beta = beta
+        self.nhiddens = list(nhiddens)
+        self.nlatent = nlatent
+        self.dropout = dropout
+        self.training = True  # a fresh torch module is in train() mode
+
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        cfg = _Config()
+        cfg.nsamples, cfg.nlatent, cfg.nlayers = nsamples, nlatent, len(nhiddens)
+        for i, n in enumerate(nhiddens):
+            cfg.nhiddens[i] = n
+        cfg.alpha, cfg.beta, cfg.dropout, cfg.seed = alpha, beta, dropout, seed & 0xFFFFFFFFFFFFFFFF
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.vh_vae_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        self._dataset_key = None
+        self._n_rows = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self._lib.vh_vae_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- torch.nn.Module look-alikes ------------------------------------------------------------
+    def train(self, mode: bool = True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def cuda(self):
+        return self
+
+    def _state_names(self):
+        names = []
+        nl = len(self.nhiddens)
+        for kind in ("encoder", "decoder"):
+            for i in range(nl):
+                names += [f"{kind}layers.{i}.weight", f"{kind}layers.{i}.bias"]
+            for i in range(nl):
+                names += [f"{kind}norms.{i}.{s}" for s in
+                          ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")]
+        names += ["mu.weight", "mu.bias", "outputlayer.weight", "outputlayer.bias"]
+        return names
+
+    def _shape_of(self, name: str):
+        d = self.nsamples + NTNF + 1
+        enc_in = [d] + self.nhiddens[:-1]
+        dec_w = self.nhiddens[::-1]
+        dec_in = [self.nlatent] + dec_w[:-1]
+        part, rest = name.split(".", 1)
+        if part in ("mu", "outputlayer"):
+            nout, nin = (self.nlatent, self.nhiddens[-1]) if part == "mu" else (d, self.nhiddens[0])
+            return (nout, nin) if rest == "weight" else (nout,)
+        idx, field = rest.split(".", 1)
+        idx = int(idx)
+        if part == "encoderlayers":
+            return (self.nhiddens[idx], enc_in[idx]) if field == "weight" else (self.nhiddens[idx],)
+        if part == "decoderlayers":
+            return (dec_w[idx], dec_in[idx]) if field == "weight" else (dec_w[idx],)
+        width = self.nhiddens[idx] if part == "encodernorms" else dec_w[idx]
+        return () if field == "num_batches_tracked" else (width,)
+
+    def state_dict(self) -> "OrderedDict[str, _torch.Tensor]":
+        out = OrderedDict()
+        for name in self._state_names():
+            shape = self._shape_of(name)
+            n = int(_np.prod(shape)) if shape else 1
+            buf = _np.empty(n, _np.float32)
+            _lib.check(self._lib.vh_vae_get_param(self._h, name.encode(), _lib.ptr(buf), n))
+            if name.endswith("num_batches_tracked"):
+                out[name] = _torch.tensor(int(buf[0]), dtype=_torch.int64)
+            else:
+                out[name] = _torch.from_numpy(buf.reshape(shape).copy())
+        return out
+
+    def load_state_dict(self, state) -> None:
+        expected = set(self._state_names())
+        got = set(state.keys())
+        if expected != got:
+            raise RuntimeError(f"state_dict mismatch: missing {sorted(expected - got)}, "
+                               f"unexpected {sorted(got - expected)}")
+        for name in self._state_names():
+            value = state[name]
+            arr = _as_f32(value).reshape(-1)
+            shape = self._shape_of(name)
+            n = int(_np.prod(shape)) if shape else 1
+            if arr.size != n:
+                raise RuntimeError(f"size mismatch for {name}: expected {shape}, got {tuple(_np.shape(value))}")
+            _lib.check(self._lib.vh_vae_set_param(self._h, name.encode(), _lib.ptr(arr), n))
+
+    def parameters_gradient(self, name: str) -> _np.ndarray:
+        """Gradient of the last training step for one parameter (what ``p.grad`` holds after
+        ``loss.backward()`` in the reference, encode.py:418)."""
+        shape = self._shape_of(name)
+        n = int(_np.prod(shape))
+        buf = _np.empty(n, _np.float32)
+        _lib.check(self._lib.vh_vae_get_grad(self._h, name.encode(), _lib.ptr(buf), n))
+        return buf.reshape(shape)
+
+    def optimizer_state(self):
+        d, nw, k = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(self._lib.vh_vae_opt_state(self._h, ctypes.byref(d), ctypes.byref(nw), ctypes.byref(k)))
+        return dict(d=d.value, numerator_weighted=nw.value, k=k.value)
+
+    # ---- forward / loss (encode.py:306-357) -------------------------------------------------------
+    def forward(self, depths, tnf, abundance, _eps=None, _masks=None):
+        d, t, a = _as_f32(depths), _as_f32(tnf), _as_f32(abundance)
+        if d.ndim != 2 or d.shape[1] != self.nsamples or t.shape != (len(d), NTNF) or a.shape != (len(d), 1):
+            raise ValueError("expected depths [B, nsamples], tnf [B, 103], abundance [B, 1]")
+        b = len(d)
+        do = _np.empty((b, self.nsamples), _np.float32)
+        to = _np.empty((b, NTNF), _np.float32)
+        ao = _np.empty((b, 1), _np.float32)
+        mu = _np.empty((b, self.nlatent), _np.float32)
+        eps = None if _eps is None else _as_f32(_eps)
+        masks = None if _masks is None else _np.ascontiguousarray(
+            _np.concatenate([_np.asarray(m, dtype=_np.uint8).reshape(-1) for m in _masks]))
+        _lib.check(self._lib.vh_vae_forward(self._h, _lib.ptr(d), _lib.ptr(t), _lib.ptr(a), b, int(self.training),
+                                            _lib.ptr(eps), _lib.ptr(masks), _lib.ptr(do), _lib.ptr(to),
+                                            _lib.ptr(ao), _lib.ptr(mu)))
+        return (_torch.from_numpy(do), _torch.from_numpy(to), _torch.from_numpy(ao), _torch.from_numpy(mu))
+
+    __call__ = forward
+
+    def calc_loss(self, depths_in, depths_out, tnf_in, tnf_out, abundance_in, abundance_out, mu, weights):
+        """The reference's loss on host tensors (encode.py:316-357), for callers that evaluate
+        ``vae(...)`` outputs themselves (test_encode.py:159-167).  Training computes the same
+        quantities on the device.  Note ``weights`` is [B,1] while the row terms are [B]: like the
+        reference this broadcasts to [B,B] before ``.mean()``."""
+        t = lambda x: x if isinstance(x, _torch.Tensor) else _torch.as_tensor(x)  # noqa: E731
+        depths_in, depths_out, tnf_in, tnf_out = t(depths_in), t(depths_out), t(tnf_in), t(tnf_out)
+        abundance_in, abundance_out, mu, weights = t(abundance_in), t(abundance_out), t(mu), t(weights)
+        ab_sse = (abundance_out - abundance_in).pow(2).sum(dim=1)
+        ce = -((depths_out + 1e-9).log() * depths_in).sum(dim=1)
+        sse = (tnf_out - tnf_in).pow(2).sum(dim=1)
+        kld = 0.5 * (mu.pow(2)).sum(dim=1)
+        if self.nsamples == 1:
+            ce_weight = 0.0
+        else:
+            ce_weight = ((1 - self.alpha) * (self.nsamples - 1)) / (self.nsamples * _log(self.nsamples))
+        ab_sse_weight = (1 - self.alpha) * (1 / self.nsamples)
+        sse_weight = self.alpha / self.ntnf
+        kld_weight = 1 / (self.nlatent * self.beta)
+        weighed_ab, weighed_ce = ab_sse * ab_sse_weight, ce * ce_weight
+        weighed_sse, weighed_kld = sse * sse_weight, kld * kld_weight
+        loss = ((weighed_ce + weighed_ab + weighed_sse) + weighed_kld) * weights
+        return (loss.mean(), weighed_ab.mean(), weighed_ce.mean(), weighed_sse.mean(), weighed_kld.mean())
+
+    # ---- dataset residency --------------------------------------------------------------------------
+    def _ensure_dataset(self, data_loader) -> int:
+        tensors = data_loader.dataset.tensors
+        if len(tensors) != 4:
+            raise ValueError("expected a DataLoader made by make_dataloader (4 tensors)")
+        key = tuple((t.data_ptr(), tuple(t.shape)) for t in tensors)
+        n = len(tensors[0])
+        if key != self._dataset_key:
+            d, t, a, w = (_as_f32(x) for x in tensors)
+            if d.shape != (n, self.nsamples) or t.shape != (n, NTNF) or a.shape != (n, 1) or w.shape != (n, 1):
+                raise ValueError("dataset tensors do not match this VAE (nsamples / 103 TNF / 1 / 1 columns)")
+            _lib.check(self._lib.vh_vae_set_dataset(self._h, _lib.ptr(d), _lib.ptr(t), _lib.ptr(a), _lib.ptr(w), n))
+            self._dataset_key = key
+            self._n_rows = n
+        return n
+
+    def train_batch(self, rows, eps=None, masks=None):
+        """One optimisation step on explicit dataset rows with optionally injected randomness
+        (parity tests).  Returns the five means of calc_loss: (loss, ab_sse, ce, sse, kld)."""
+        rows = _np.ascontiguousarray(rows, dtype=_np.int64)
+        e = None if eps is None else _as_f32(eps)
+        m = None if masks is None else _np.ascontiguousarray(
+            _np.concatenate([_np.asarray(x, dtype=_np.uint8).reshape(-1) for x in masks]))
+        out = (ctypes.c_double * 5)()
+        _lib.check(self._lib.vh_vae_train_step(self._h, _lib.ptr(rows), len(rows), _lib.ptr(e), _lib.ptr(m), out))
+        return tuple(out)
+
+    # ---- training (encode.py:359-440, 543-610) ------------------------------------------------------
+    def trainepoch(self, data_loader, epoch: int, optimizer, batchsteps: list[int]):
+        n_seq = self._ensure_dataset(data_loader)
+        if n_seq < 2:
+            raise ValueError(
+                f"Cannot train on a dataset with fewer than 2 sequences, but got {n_seq} sequences. "
+                "If you are trying to fit a DL model to this few sequences, "
+                "something probably went wrong in your pipeline.")
+        self.train()
+        if epoch in batchsteps:
+            data_loader = set_batchsize(data_loader, data_loader.batch_size * 2, n_seq)
+        bs = data_loader.batch_size
+        # RandomSampler semantics: a fresh permutation per epoch; drop the ragged tail iff n > batch
+        perm = _torch.randperm(n_seq).numpy()
+        if n_seq > bs:
+            n_batches = n_seq // bs
+            batch = bs
+        else:
+            n_batches, batch = 1, n_seq
+        perm = _np.ascontiguousarray(perm[: n_batches * batch], dtype=_np.int64)
+        means = (ctypes.c_double * 5)()
+        _lib.check(self._lib.vh_vae_train_epoch(self._h, _lib.ptr(perm), n_batches, batch, means))
+        loss, ab, ce, sse, kld = tuple(means)
+        logger.info(
+            "\t\tEpoch: {:>3}  Loss: {:.5e}  CE: {:.5e}  AB: {:.5e}  SSE: {:.5e}  KLD: {:.5e}  Batchsize: {:>4}".format(
+                epoch + 1, loss, ce, ab, sse, kld, bs))
+        self.last_epoch_losses = dict(loss=loss, ce=ce, ab=ab, sse=sse, kld=kld, batchsize=bs)
+        self.eval()
+        return data_loader
+
+    def trainmodel(self, dataloader, nepochs: int = 500, batchsteps: Optional[list[int]] = [25, 75, 150, 300],
+                   modelfile: Union[None, str, Path, IO[bytes]] = None):
+        """Train the autoencoder (encode.py:543-610).  Output: None"""
+        if nepochs < 1:
+            raise ValueError(f"Minimum 1 epoch, not {nepochs}")
+        if batchsteps is None:
+            batchsteps_set: set[int] = set()
+        else:
+            batchsteps = list(batchsteps)
+            if not all(isinstance(i, int) for i in batchsteps):
+                raise ValueError("All elements of batchsteps must be integers")
+            if max(batchsteps, default=0) >= nepochs:
+                raise ValueError("Max batchsteps must not equal or exceed nepochs")
+            batchsteps_set = set(batchsteps)
+        ncontigs, nsamples = dataloader.dataset.tensors[0].shape
+        logger.info("\tNetwork properties:")
+        logger.info(f"\t    CUDA: {self.usecuda}")
+        logger.info(f"\t    Alpha: {self.alpha}")
+        logger.info(f"\t    Beta: {self.beta}")
+        logger.info(f"\t    Dropout: {self.dropout}")
+        logger.info(f"\t    N hidden: {', '.join(map(str, self.nhiddens))}")
+        logger.info(f"\t    N latent: {self.nlatent}")
+        logger.info("\tTraining properties:")
+        logger.info(f"\t    N epochs: {nepochs}")
+        logger.info(f"\t    Starting batch size: {dataloader.batch_size}")
+        steps = ", ".join(map(str, sorted(batchsteps_set))) if batchsteps_set else "None"
+        logger.info(f"\t    Batchsteps: {steps}")
+        logger.info(f"\t    N sequences: {ncontigs}")
+        logger.info(f"\t    N samples: {nsamples}")
+        for epoch in range(nepochs):
+            dataloader = self.trainepoch(dataloader, epoch, None, sorted(batchsteps_set))
+        if modelfile is not None:
+            try:
+                self.save(modelfile)
+            except Exception:
+                pass
+        return None
+
+    # ---- encode (encode.py:442-484) -----------------------------------------------------------------
+    def encode(self, data_loader) -> _np.ndarray:
+        self.eval()
+        n = self._ensure_dataset(data_loader)
+        latent = _np.empty((n, self.nlatent), dtype=_np.float32)
+        _lib.check(self._lib.vh_vae_encode(self._h, _lib.ptr(latent)))
+        return latent
+
+    # ---- model.pt (encode.py:486-541) ---------------------------------------------------------------
+    def save(self, filehandle):
+        state = {"nsamples": self.nsamples, "alpha": self.alpha, "beta": self.beta, "dropout": self.dropout,
+                 "nhiddens": self.nhiddens, "nlatent": self.nlatent, "state": self.state_dict()}
+        _torch.save(state, filehandle)
+
+    @classmethod
+    def load(cls, path: Union[IO[bytes], str], cuda: bool = False, evaluate: bool = True):
+        dictionary = _torch.load(path, map_location=lambda storage, loc: storage, weights_only=True)
+        vae = cls(dictionary["nsamples"], dictionary["nhiddens"], dictionary["nlatent"], dictionary["alpha"],
+                  dictionary["beta"], dictionary["dropout"], cuda)
+        vae.load_state_dict(dictionary["state"])
+        if evaluate:
+            vae.eval()
+        return vae
