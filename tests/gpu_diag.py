@@ -23,11 +23,14 @@ print("devices:", _lib.device_count(), lib.vh_version())
 def gemm_bench():
     res = []
     rng = np.random.RandomState(0)
-    for (tile, a_kc, b_kc, M, N, K, splits) in [
-            (0, 1, 1, 4096, 512, 160, 1), (0, 1, 1, 4096, 512, 512, 1), (1, 1, 1, 4096, 512, 512, 1),
-            (0, 1, 1, 8192, 512, 1120, 1), (1, 1, 1, 8192, 512, 1120, 1), (2, 1, 1, 4096, 32, 512, 1),
-            (0, 1, 0, 4096, 512, 512, 1), (1, 1, 0, 4096, 512, 512, 1),
-            (1, 0, 0, 512, 512, 4096, 16), (0, 0, 0, 512, 160, 4096, 32), (1, 0, 0, 512, 512, 4096, 32)]:
+    shapes = []
+    for tile in (0, 1, 2, 3):
+        shapes += [(tile, 1, 1, 4096, 512, 160, 1), (tile, 1, 1, 4096, 512, 512, 1), (tile, 1, 1, 4096, 160, 512, 1),
+                   (tile, 1, 0, 4096, 512, 512, 1), (tile, 1, 0, 4096, 512, 160, 1),
+                   (tile, 0, 0, 512, 512, 4096, 8), (tile, 0, 0, 512, 512, 4096, 16), (tile, 0, 0, 512, 160, 4096, 16),
+                   (tile, 1, 1, 8192, 512, 1120, 1)]
+    shapes += [(2, 1, 1, 4096, 32, 512, 1), (2, 1, 1, 4096, 32, 512, 8), (2, 1, 0, 4096, 32, 512, 8)]
+    for (tile, a_kc, b_kc, M, N, K, splits) in shapes:
         A = rng.standard_normal((M, K)).astype(np.float32)
         B = rng.standard_normal((N, K)).astype(np.float32)
         Ad = np.ascontiguousarray(A if a_kc else A.T)
@@ -117,7 +120,10 @@ def vae_bench():
     return res
 
 
+which = sys.argv[1:] or ["gemm", "scan", "cluster", "vae"]
 for name, fn in (("gemm", gemm_bench), ("scan", scan_bench), ("cluster", cluster_e2e), ("vae", vae_bench)):
+    if name not in which:
+        continue
     try:
         out[name] = fn()
     except Exception as e:  # keep going: we want as much information per GPU call as possible

@@ -28,6 +28,7 @@ namespace {
 constexpr int kColPad = 32;
 constexpr int kRowPad = 128;
 constexpr int kProbeRing = 512;
+constexpr int kSkinnySplits = 8;   // split-K slabs for the GEMMs whose output is only nlatent wide
 
 struct Tensor {
     std::string name;
@@ -68,18 +69,21 @@ void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
     VH_HIP(hipGetLastError());
 }
 
-// tile: 0 = 64x128 (2x2 waves), 1 = 128x128 (2x2), 2 = 128x32 (4x1)
+// tile: 0 = 64x128 (2x2 waves), 1 = 128x128 (2x2), 2 = 128x32 (4x1), 3 = 64x64 (2x2)
 template <bool AKC, bool BKC, int EPI>
 void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
     switch (tile) {
         case 0: launch_gemm<64, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
         case 1: launch_gemm<128, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
+        case 3: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
         default: launch_gemm<128, 32, 4, 1, AKC, BKC, EPI>(s, g, splits); break;
     }
 }
 
-int fwd_tile(int N) { return N <= 32 ? 2 : 0; }
-int stat_rows_per_block(int tile) { return tile == 0 ? 64 : 128; }
+// measured on MI355X (profiles/r01_diag_gemm_tiles.json): the 64x64 tile (2 workgroups per CU) wins or ties
+// for every fp32 shape of the 512-wide network; skinny outputs use 128x32.
+int fwd_tile(int N) { return N <= 32 ? 2 : 3; }
+int stat_rows_per_block(int tile) { return (tile == 0 || tile == 3) ? 64 : 128; }
 
 GemmArgs base_args() {
     GemmArgs g;
@@ -111,7 +115,7 @@ struct vh_vae {
 
     // per-batch workspaces
     int bs = 0, bs_p = 0;
-    DevBuf<float> Xb, Wb, MU, Z, EPS, R, dR, dMUk, DA, DZ, wsum, stat_part, bwd_part, S12, loss_part, slabs, out_sm;
+    DevBuf<float> Xb, Wb, MU, Z, EPS, R, dR, dMUk, DA, DZ, wsum, stat_part, bwd_part, S12, loss_part, slabs, out_sm, skinny;
     DevBuf<TensorDesc> descs;
     DevBuf<int> blk_tensor, blk_local;
     DevBuf<double> opt_part;
@@ -205,16 +209,15 @@ void init_parameters(vh_vae* h) {
 }
 
 int dw_splits(int M, int N, int K, int tile) {
-    const int bm = tile == 0 ? 64 : 128, bn = tile == 2 ? 32 : 128;
+    const int bm = (tile == 0 || tile == 3) ? 64 : 128, bn = tile == 2 ? 32 : (tile == 3 ? 64 : 128);
     const int tiles = (int)(ceil_div(M, bm) * ceil_div(N, bn));
-    int want = (int)std::max<int64_t>(1, ceil_div(512, tiles));
+    int want = (int)std::max<int64_t>(1, ceil_div(256, tiles));
     want = std::min(want, K / 32);
     return std::max(1, want);
 }
 int dw_tile(int M, int N) {
     if (N <= 32) return 2;
-    if (M >= 128) return 1;
-    return 0;
+    return 3;
 }
 
 // (re)allocate everything that depends on the batch size
@@ -244,6 +247,7 @@ void prepare_batch(vh_vae* h, int bs) {
     h->loss_blocks = bs_p / 4;
     h->loss_part.ensure((size_t)h->loss_blocks * 4);
     h->out_sm.ensure((size_t)bs_p * std::max(1, h->S));
+    h->skinny.ensure((size_t)kSkinnySplits * bs_p * h->L_p);
     for (auto& hl : h->hidden) {
         hl.H.ensure((size_t)bs_p * hl.nout_p);
         hl.A.ensure((size_t)bs_p * hl.nout_p);
@@ -383,7 +387,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
             gemm_tile<true, true, EPI_HIDDEN_TRAIN>(s, tile, g, 1);
             if (probed) probe_record(h, false);
             const int nb = bs_p / stat_rows_per_block(tile);
-            hipLaunchKernelGGL(vae_bn_finalize_kernel, dim3((unsigned)ceil_div(hl.nout_p, 256)), dim3(256), 0, s,
+            hipLaunchKernelGGL(vae_bn_finalize_kernel, dim3((unsigned)ceil_div(hl.nout_p, 16)), dim3(16, 16), 0, s,
                                h->stat_part.p, nb, hl.nout_p, hl.nout_p, bs, h->pptr(hl.tG), h->pptr(hl.tB),
                                h->pptr(hl.tRM), h->pptr(hl.tRV), hl.mean.p, hl.invstd.p, hl.scale.p, hl.shift.p);
             VH_HIP(hipGetLastError());
@@ -405,14 +409,20 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
         in_w = hl.nout_p;
     };
     for (int li = 0; li < h->nl; ++li) hidden_layer(li);
-    {   // mu = a * Wmu^T + bmu  (encode.py:268)
+    int mu_slabs = 1;
+    {   // mu = a * Wmu^T + bmu  (encode.py:268).  The output is only nlatent wide, so the contraction is
+        // split over up to 8 workgroup slices (slabs); bias and the slab sum are folded into the
+        // reparameterisation kernel below.
         GemmArgs g = base_args();
         g.A = in; g.lda = in_w;
         g.B = h->pptr(h->tWmu); g.ldb = in_w;
-        g.C = h->MU.p; g.ldc = h->L_p;
-        g.M = bs_p; g.N = h->L_p; g.K = in_w; g.k_per_split = g.K;
-        g.bias = h->pptr(h->tbmu);
-        gemm_tile<true, true, EPI_BIAS>(s, fwd_tile(h->L_p), g, 1);
+        g.C = h->skinny.p; g.ldc = h->L_p;
+        g.M = bs_p; g.N = h->L_p; g.K = in_w;
+        const int want = std::max(1, std::min(kSkinnySplits, in_w / 64));
+        g.k_per_split = (int)round_up(ceil_div(in_w, want), 32);
+        mu_slabs = (int)ceil_div(in_w, g.k_per_split);
+        g.slab_stride = (int64_t)bs_p * h->L_p;
+        gemm_tile<true, true, EPI_SPLITK>(s, fwd_tile(h->L_p), g, mu_slabs);
     }
     {   // latent = mu + eps  (encode.py:276-286; sigma == 1)
         const int64_t tot = (int64_t)bs_p * h->L_p;
@@ -424,8 +434,9 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
                 VH_HIP(hipMemsetAsync(h->EPS.p, 0, sizeof(float) * tot, s));
             VH_HIP(hipGetLastError());
         }
-        hipLaunchKernelGGL(vae_reparam_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s, h->MU.p, h->EPS.p,
-                           h->Z.p, bs, h->L, h->L_p, bs_p);
+        hipLaunchKernelGGL(vae_reparam_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s, h->skinny.p,
+                           mu_slabs, (int64_t)bs_p * h->L_p, h->pptr(h->tbmu), h->EPS.p, h->MU.p, h->Z.p, bs, h->L,
+                           h->L_p, bs_p);
         VH_HIP(hipGetLastError());
     }
     in = h->Z.p;
@@ -478,14 +489,27 @@ void grad_weight(vh_vae* h, int tW, const float* dZ, int out_p, const float* In,
     gemm_tile<false, false, EPI_SPLITK>(h->stream, tile, g, splits);
 }
 
-// dIn = dZ * W   (dZ K-contiguous over the layer's outputs, W row-contiguous [out][in])
-void grad_input(vh_vae* h, const float* dZ, int out_p, int tW, int in_p, float* dIn) {
+// dIn = dZ * W   (dZ K-contiguous over the layer's outputs, W row-contiguous [out][in]).
+// Returns the number of slabs written: 1 (dIn itself) or, when the input is only nlatent wide, the
+// split-K slabs in h->skinny that the consumer sums.
+int grad_input(vh_vae* h, const float* dZ, int out_p, int tW, int in_p, float* dIn, bool to_latent = false) {
     GemmArgs g = base_args();
     g.A = dZ; g.lda = out_p;
     g.B = h->pptr(tW); g.ldb = in_p;
+    g.M = h->bs_p; g.N = in_p; g.K = out_p;
+    if (to_latent && in_p <= 32 && out_p >= 128) {
+        const int want = std::max(1, std::min(kSkinnySplits, out_p / 64));
+        g.k_per_split = (int)round_up(ceil_div(out_p, want), 32);
+        const int splits = (int)ceil_div(out_p, g.k_per_split);
+        g.C = h->skinny.p; g.ldc = in_p;
+        g.slab_stride = (int64_t)h->bs_p * in_p;
+        gemm_tile<true, false, EPI_SPLITK>(h->stream, fwd_tile(in_p), g, splits);
+        return splits;
+    }
     g.C = dIn; g.ldc = in_p;
-    g.M = h->bs_p; g.N = in_p; g.K = out_p; g.k_per_split = g.K;
+    g.k_per_split = g.K;
     gemm_tile<true, false, EPI_STORE>(h->stream, fwd_tile(in_p), g, 1);
+    return 1;
 }
 
 void backward(vh_vae* h, bool masks_injected) {
@@ -496,18 +520,20 @@ void backward(vh_vae* h, bool masks_injected) {
     {
         Hidden& last = h->hidden[2 * h->nl - 1];
         grad_weight(h, h->tWo, h->dR.p, h->D_p, last.A.p, last.nout_p);
-        hipLaunchKernelGGL(vae_colsum_partial_kernel, dim3((unsigned)ceil_div(h->D_p, 256), nrb), dim3(256), 0, s,
+        hipLaunchKernelGGL(vae_colsum_partial_kernel, dim3((unsigned)ceil_div(h->D_p, kCT), nrb), dim3(kCT, kRL), 0, s,
                            h->dR.p, (int64_t)h->D_p, h->D_p, bs_p, h->tensors[h->tbo].slab);
         VH_HIP(hipGetLastError());
         grad_input(h, h->dR.p, h->D_p, h->tWo, last.nout_p, h->DA.p);
     }
+    int latent_slabs = 1;
     auto hidden_bwd = [&](int li, const float* In, int in_p, bool need_dinput) {
         Hidden& hl = h->hidden[li];
-        const dim3 grid((unsigned)ceil_div(hl.nout_p, 256), nrb);
-        hipLaunchKernelGGL(vae_bn_bwd_reduce_kernel, grid, dim3(256), 0, s, h->DA.p, hl.H.p, hl.nout_p, bs, hl.mean.p,
+        const dim3 grid((unsigned)ceil_div(hl.nout_p, kCT), nrb);
+        const dim3 block(kCT, kRL);
+        hipLaunchKernelGGL(vae_bn_bwd_reduce_kernel, grid, block, 0, s, h->DA.p, hl.H.p, hl.nout_p, bs, hl.mean.p,
                            hl.invstd.p, h->bwd_part.p);
         VH_HIP(hipGetLastError());
-        hipLaunchKernelGGL(vae_bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(hl.nout_p, 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL(vae_bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(hl.nout_p, 16)), dim3(16, 16), 0, s,
                            h->bwd_part.p, nrb, hl.nout_p, h->S12.p, h->tensors[hl.tG].slab, h->tensors[hl.tB].slab);
         VH_HIP(hipGetLastError());
         BnBwdArgs a;
@@ -517,10 +543,13 @@ void backward(vh_vae* h, bool masks_injected) {
         a.drop_scale = dc.scale; a.drop_thresh = dc.thresh; a.drop_key = layer_key(h, li);
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
         a.dbias_part = h->tensors[hl.tb].slab;
-        hipLaunchKernelGGL(vae_bn_bwd_apply_kernel, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(vae_bn_bwd_apply_kernel, grid, block, 0, s, a);
         VH_HIP(hipGetLastError());
         grad_weight(h, hl.tW, h->DZ.p, hl.nout_p, In, in_p);
-        if (need_dinput) grad_input(h, h->DZ.p, hl.nout_p, hl.tW, in_p, h->DA.p);
+        if (need_dinput) {
+            const int n = grad_input(h, h->DZ.p, hl.nout_p, hl.tW, in_p, h->DA.p, li == h->nl);
+            if (li == h->nl) latent_slabs = n;
+        }
     };
     for (int li = 2 * h->nl - 1; li >= h->nl; --li) {
         const bool first_dec = li == h->nl;
@@ -530,8 +559,11 @@ void backward(vh_vae* h, bool masks_injected) {
     }
     {   // latent: dMU = dZlat + d(KLD)/dmu; mu layer
         Hidden& enc_last = h->hidden[h->nl - 1];
-        hipLaunchKernelGGL(vae_latent_bwd_kernel, dim3((unsigned)ceil_div(h->L_p, 256), nrb), dim3(256), 0, s, h->DA.p,
-                           h->dMUk.p, h->DZ.p, h->L_p, bs, bs_p, h->tensors[h->tbmu].slab);
+        // latent_slabs == 1: the first decoder layer wrote dZlat into DA; otherwise split-K slabs in skinny
+        const float* src = latent_slabs == 1 ? h->DA.p : h->skinny.p;
+        hipLaunchKernelGGL(vae_latent_bwd_kernel, dim3((unsigned)ceil_div(h->L_p, kCT), nrb), dim3(kCT, kRL), 0, s, src,
+                           latent_slabs, (int64_t)bs_p * h->L_p, h->dMUk.p, h->DZ.p, h->L_p, bs, bs_p,
+                           h->tensors[h->tbmu].slab);
         VH_HIP(hipGetLastError());
         grad_weight(h, h->tWmu, h->DZ.p, h->L_p, enc_last.A.p, enc_last.nout_p);
         grad_input(h, h->DZ.p, h->L_p, h->tWmu, enc_last.nout_p, h->DA.p);
@@ -964,7 +996,7 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
                   int N, int K, int splits, float* ms) {
     return guarded([&] {
         VH_REQUIRE(A && B && C, "NULL argument");
-        VH_REQUIRE(tile >= 0 && tile <= 2, "tile in {0,1,2}");
+        VH_REQUIRE(tile >= 0 && tile <= 3, "tile in {0,1,2,3}");
         VH_REQUIRE(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && M % 4 == 0 && N % 4 == 0,
                    "need K multiple of 32 and M, N multiples of 4");
         VH_REQUIRE(splits >= 1 && (K / 32) >= splits, "bad split count");

@@ -67,18 +67,27 @@ __global__ __launch_bounds__(256) void vae_sum_kernel(const float* __restrict__ 
 }
 
 // ---- BatchNorm1d forward (training): finalise statistics from the GEMM epilogue's partial sums --
-__global__ void vae_bn_finalize_kernel(const float* __restrict__ part, int nb, int ld, int n_p, int bs,
-                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       float* __restrict__ rm, float* __restrict__ rv, float* __restrict__ mean,
-                                       float* __restrict__ invstd, float* __restrict__ scale,
-                                       float* __restrict__ shift) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= n_p) return;
+// blockDim (16, 16): 16 columns per workgroup, 16 lanes share the nb partials of each column
+// (fixed assignment and fixed combination order => deterministic).
+__global__ __launch_bounds__(256) void vae_bn_finalize_kernel(
+    const float* __restrict__ part, int nb, int ld, int n_p, int bs, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv, float* __restrict__ mean,
+    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double r1[16][17], r2[16][17];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int col = blockIdx.x * 16 + tx;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nb; ++b) {
-        s1 += (double)part[((int64_t)b * 2 + 0) * ld + col];
-        s2 += (double)part[((int64_t)b * 2 + 1) * ld + col];
-    }
+    if (col < n_p)
+        for (int b = ty; b < nb; b += 16) {
+            s1 += (double)part[((int64_t)b * 2 + 0) * ld + col];
+            s2 += (double)part[((int64_t)b * 2 + 1) * ld + col];
+        }
+    r1[ty][tx] = s1;
+    r2[ty][tx] = s2;
+    __syncthreads();
+    if (ty != 0 || col >= n_p) return;
+    s1 = 0.0; s2 = 0.0;
+    for (int i = 0; i < 16; ++i) { s1 += r1[i][tx]; s2 += r2[i][tx]; }
     const double m = s1 / bs;
     double var = s2 / bs - m * m;  // biased variance (normalisation)
     if (var < 0.0) var = 0.0;
@@ -139,13 +148,17 @@ __global__ void vae_randn_kernel(float* __restrict__ E, int bs, int L, int L_p, 
     E[i] = v;
 }
 
-// Z = MU + E on the real rows / columns, 0 on the padding
-__global__ void vae_reparam_kernel(const float* __restrict__ MU, const float* __restrict__ E, float* __restrict__ Z,
-                                   int bs, int L, int L_p, int bs_p) {
+// MU = sum of the split-K slabs + bias;  Z = MU + E on the real rows / columns, 0 on the padding
+__global__ void vae_reparam_kernel(const float* __restrict__ slabs, int nslab, int64_t stride,
+                                   const float* __restrict__ bias, const float* __restrict__ E,
+                                   float* __restrict__ MU, float* __restrict__ Z, int bs, int L, int L_p, int bs_p) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)bs_p * L_p) return;
     const int r = (int)(i / L_p), c = (int)(i % L_p);
-    Z[i] = (r < bs && c < L) ? MU[i] + E[i] : 0.f;
+    float m = bias[c];
+    for (int s = 0; s < nslab; ++s) m += slabs[(int64_t)s * stride + i];
+    MU[i] = m;
+    Z[i] = (r < bs && c < L) ? m + E[i] : 0.f;
 }
 
 // ---- loss (encode.py:316-357) + backward seed ------------------------------------------------------
@@ -300,47 +313,83 @@ __global__ __launch_bounds__(256) void vae_softmax_out_kernel(const float* __res
     for (int c = lane; c < S; c += 64) out[(int64_t)row * S + c] = expf(r[c] - mx) / se;
 }
 
-// ---- column-parallel backward helpers (one thread per column, kRB rows per workgroup) ------------
+// ---- column-parallel backward helpers -----------------------------------------------------------------
+// blockDim (32, 8): a workgroup owns 32 columns x kRB rows; thread (tx, ty) walks rows r0+ty, r0+ty+8, ...
+// and the 8 row-lanes are combined through LDS in a fixed order.
+constexpr int kCT = 32;
+constexpr int kRL = 8;
+
+__device__ __forceinline__ float column_block_sum(float v, float (*red)[kCT + 1]) {
+    red[threadIdx.y][threadIdx.x] = v;
+    __syncthreads();
+    float s = 0.f;
+    if (threadIdx.y == 0)
+#pragma unroll
+        for (int i = 0; i < kRL; ++i) s += red[i][threadIdx.x];
+    __syncthreads();
+    return s;  // valid on threadIdx.y == 0
+}
+
 // part[rb][col] = sum over the workgroup's rows of G[row][col]
-__global__ void vae_colsum_partial_kernel(const float* __restrict__ G, int64_t ld, int n_p, int rows,
-                                          float* __restrict__ part) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= n_p) return;
+__global__ __launch_bounds__(256) void vae_colsum_partial_kernel(const float* __restrict__ G, int64_t ld, int n_p,
+                                                                 int rows, float* __restrict__ part) {
+    __shared__ float red[kRL][kCT + 1];
+    const int col = blockIdx.x * kCT + threadIdx.x;
     const int r0 = blockIdx.y * kRB, r1 = min(rows, r0 + kRB);
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += G[(int64_t)r * ld + col];
-    part[(int64_t)blockIdx.y * n_p + col] = s;
+    if (col < n_p)
+        for (int r = r0 + threadIdx.y; r < r1; r += kRL) s += G[(int64_t)r * ld + col];
+    s = column_block_sum(s, red);
+    if (threadIdx.y == 0 && col < n_p) part[(int64_t)blockIdx.y * n_p + col] = s;
 }
 
 // BatchNorm backward, pass 1: partial sums of dA and dA * xhat
-__global__ void vae_bn_bwd_reduce_kernel(const float* __restrict__ DA, const float* __restrict__ H, int n_p, int bs,
-                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                         float* __restrict__ part /*[nrb][2][n_p]*/) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= n_p) return;
+__global__ __launch_bounds__(256) void vae_bn_bwd_reduce_kernel(const float* __restrict__ DA,
+                                                                const float* __restrict__ H, int n_p, int bs,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                float* __restrict__ part /*[nrb][2][n_p]*/) {
+    __shared__ float red[kRL][kCT + 1];
+    const int col = blockIdx.x * kCT + threadIdx.x;
     const int r0 = blockIdx.y * kRB, r1 = min(bs, r0 + kRB);
-    const float m = mean[col], is = invstd[col];
     float s1 = 0.f, s2 = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        const float da = DA[(int64_t)r * n_p + col];
-        const float xh = (H[(int64_t)r * n_p + col] - m) * is;
-        s1 += da;
-        s2 += da * xh;
+    if (col < n_p) {
+        const float m = mean[col], is = invstd[col];
+        for (int r = r0 + threadIdx.y; r < r1; r += kRL) {
+            const float da = DA[(int64_t)r * n_p + col];
+            const float xh = (H[(int64_t)r * n_p + col] - m) * is;
+            s1 += da;
+            s2 += da * xh;
+        }
     }
-    part[((int64_t)blockIdx.y * 2 + 0) * n_p + col] = s1;
-    part[((int64_t)blockIdx.y * 2 + 1) * n_p + col] = s2;
+    s1 = column_block_sum(s1, red);
+    s2 = column_block_sum(s2, red);
+    if (threadIdx.y == 0 && col < n_p) {
+        part[((int64_t)blockIdx.y * 2 + 0) * n_p + col] = s1;
+        part[((int64_t)blockIdx.y * 2 + 1) * n_p + col] = s2;
+    }
 }
 
-// pass 2: totals; these are also the gradients of beta (S1) and gamma (S2)
-__global__ void vae_bn_bwd_finalize_kernel(const float* __restrict__ part, int nrb, int n_p, float* __restrict__ S12,
-                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= n_p) return;
+// pass 2: totals; these are also the gradients of beta (S1) and gamma (S2).  blockDim (16, 16).
+__global__ __launch_bounds__(256) void vae_bn_bwd_finalize_kernel(const float* __restrict__ part, int nrb, int n_p,
+                                                                  float* __restrict__ S12,
+                                                                  float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta) {
+    __shared__ double r1[16][17], r2[16][17];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int col = blockIdx.x * 16 + tx;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nrb; ++b) {
-        s1 += (double)part[((int64_t)b * 2 + 0) * n_p + col];
-        s2 += (double)part[((int64_t)b * 2 + 1) * n_p + col];
-    }
+    if (col < n_p)
+        for (int b = ty; b < nrb; b += 16) {
+            s1 += (double)part[((int64_t)b * 2 + 0) * n_p + col];
+            s2 += (double)part[((int64_t)b * 2 + 1) * n_p + col];
+        }
+    r1[ty][tx] = s1;
+    r2[ty][tx] = s2;
+    __syncthreads();
+    if (ty != 0 || col >= n_p) return;
+    s1 = 0.0; s2 = 0.0;
+    for (int i = 0; i < 16; ++i) { s1 += r1[i][tx]; s2 += r2[i][tx]; }
     S12[col] = (float)s1;
     S12[n_p + col] = (float)s2;
     dbeta[col] = (float)s1;
@@ -365,49 +414,62 @@ struct BnBwdArgs {
 };
 
 // pass 3: dZ = BN'(dA) * dropout' * leaky_relu'  and the per-workgroup column sums of dZ (bias grads)
-__global__ void vae_bn_bwd_apply_kernel(const BnBwdArgs a) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= a.n_p) return;
+__global__ __launch_bounds__(256) void vae_bn_bwd_apply_kernel(const BnBwdArgs a) {
+    __shared__ float red[kRL][kCT + 1];
+    const int col = blockIdx.x * kCT + threadIdx.x;
     const int r0 = blockIdx.y * kRB, r1 = min(a.bs_p, r0 + kRB);
-    const float m = a.mean[col], is = a.invstd[col], gm = a.gamma[col];
-    const float c1 = a.S12[col] / (float)a.bs, c2 = a.S12[a.n_p + col] / (float)a.bs;
-    const bool use_drop = (a.drop_scale != 1.0f) || (a.drop_mask != nullptr);
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        const int64_t i = (int64_t)r * a.n_p + col;
-        float dz = 0.f;
-        if (r < a.bs) {
-            const float h = a.H[i];
-            const float xh = (h - m) * is;
-            float dh = is * gm * (a.DA[i] - c1 - xh * c2);
-            bool keep = true;
-            if (use_drop) {
-                keep = a.drop_mask ? (a.drop_mask[(int64_t)r * a.ld_mask + col] != 0)
-                                   : (hash32(a.drop_key, (uint64_t)r * (uint64_t)a.n_p + (uint64_t)col) >= a.drop_thresh);
-                dh *= a.drop_scale;
+    if (col < a.n_p) {
+        const float m = a.mean[col], is = a.invstd[col], gm = a.gamma[col];
+        const float c1 = a.S12[col] / (float)a.bs, c2 = a.S12[a.n_p + col] / (float)a.bs;
+        const bool use_drop = (a.drop_scale != 1.0f) || (a.drop_mask != nullptr);
+        for (int r = r0 + threadIdx.y; r < r1; r += kRL) {
+            const int64_t i = (int64_t)r * a.n_p + col;
+            float dz = 0.f;
+            if (r < a.bs) {
+                const float h = a.H[i];
+                const float xh = (h - m) * is;
+                float dh = is * gm * (a.DA[i] - c1 - xh * c2);
+                bool keep = true;
+                if (use_drop) {
+                    keep = a.drop_mask
+                               ? (a.drop_mask[(int64_t)r * a.ld_mask + col] != 0)
+                               : (hash32(a.drop_key, (uint64_t)r * (uint64_t)a.n_p + (uint64_t)col) >= a.drop_thresh);
+                    dh *= a.drop_scale;
+                }
+                dz = keep ? dh * (h > 0.f ? 1.0f : kLeakySlope) : 0.f;
             }
-            dz = keep ? dh * (h > 0.f ? 1.0f : kLeakySlope) : 0.f;
+            a.DZ[i] = dz;
+            s += dz;
         }
-        a.DZ[i] = dz;
-        s += dz;
     }
-    a.dbias_part[(int64_t)blockIdx.y * a.n_p + col] = s;
+    s = column_block_sum(s, red);
+    if (threadIdx.y == 0 && col < a.n_p) a.dbias_part[(int64_t)blockIdx.y * a.n_p + col] = s;
 }
 
-// latent: dMU = dZlat + KLD part (zero on padding rows); column partial sums for the mu bias
-__global__ void vae_latent_bwd_kernel(const float* __restrict__ DA, const float* __restrict__ dMUk,
-                                      float* __restrict__ DZ, int L_p, int bs, int bs_p, float* __restrict__ part) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= L_p) return;
+// latent: dMU = (sum of the split-K slabs of dZlat) + KLD part (zero on padding rows); column partial
+// sums for the mu bias
+__global__ __launch_bounds__(256) void vae_latent_bwd_kernel(const float* __restrict__ slabs, int nslab,
+                                                             int64_t stride, const float* __restrict__ dMUk,
+                                                             float* __restrict__ DZ, int L_p, int bs, int bs_p,
+                                                             float* __restrict__ part) {
+    __shared__ float red[kRL][kCT + 1];
+    const int col = blockIdx.x * kCT + threadIdx.x;
     const int r0 = blockIdx.y * kRB, r1 = min(bs_p, r0 + kRB);
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        const int64_t i = (int64_t)r * L_p + col;
-        const float v = r < bs ? DA[i] + dMUk[i] : 0.f;
-        DZ[i] = v;
-        s += v;
-    }
-    part[(int64_t)blockIdx.y * L_p + col] = s;
+    if (col < L_p)
+        for (int r = r0 + threadIdx.y; r < r1; r += kRL) {
+            const int64_t i = (int64_t)r * L_p + col;
+            float v = 0.f;
+            if (r < bs) {
+                v = dMUk[i];
+                for (int k = 0; k < nslab; ++k) v += slabs[(int64_t)k * stride + i];
+            }
+            DZ[i] = v;
+            s += v;
+        }
+    s = column_block_sum(s, red);
+    if (threadIdx.y == 0 && col < L_p) part[(int64_t)blockIdx.y * L_p + col] = s;
 }
 
 // ---- D-Adapt-Adam (dadaptation==3.2 DAdaptAdam.step as Vamb configures it, encode.py:578) ----------
