@@ -51,6 +51,8 @@ def parse():
     p.add_argument("--latent", type=int, default=32)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=20_000)
+    p.add_argument("--force-dist", action="store_true",
+                   help="take the multi-GPU code path (process group + RCCL communicator) even with one rank")
     return p.parse_args()
 
 
@@ -155,28 +157,42 @@ def main():
     _lib.check(lib.vh_set_device(local))
     comm = None
     dist = None
-    if world > 1:
-        import torch
+    if world > 1 or args.force_dist:
+        # Control plane: gloo (bootstrap, barriers, the max-over-ranks of the timing).  Data plane: RCCL
+        # called inside libvambhip on its own HIP stream (vamb_amd/parallel.py).  torch.cuda is never
+        # touched: PyTorch-ROCm bundles a private HIP runtime that must not be mixed with the library's.
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-        from vamb_amd import parallel
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        # gloo / RCCL print banners on stdout; the contract is ONE JSON line there -> send them to stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo")
+            from vamb_amd import parallel
 
-        comm = parallel.Communicator.from_torch_distributed(dist)
+            comm = parallel.Communicator.from_torch_distributed(dist)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     # synthetic inputs of the named shape (per-rank shard under weak scaling), normalised on the host
     # exactly as `vamb bin default` does, then uploaded once: resident in HBM before the clock starts
     ab, tnf, lens, _ = synth.features(args.contigs, args.samples, seed=1 + rank)
-    dl = ve.make_dataloader(ab, tnf, lens, batchsize=args.batch, destroy=True)
+    # under data parallelism the loader's batch size is the ALL-RANK batch: --batch rows per GPU
+    dl = ve.make_dataloader(ab, tnf, lens, batchsize=args.batch * world, destroy=True)
 
     def barrier():
+        _lib.check(lib.vh_device_synchronize())
         if dist is not None:
-            import torch
-
             dist.barrier()
-            torch.cuda.synchronize()
+            _lib.check(lib.vh_device_synchronize())
 
     for i in range(args.warmup):
         run_step(ve, vc, lib, _lib, dl, lens, args, seed=1000 + i, comm=comm)
@@ -190,7 +206,7 @@ def main():
     if dist is not None:
         import torch
 
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -250,6 +266,8 @@ def main():
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None
         print(json.dumps(line))
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

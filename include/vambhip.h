@@ -165,6 +165,29 @@ int vh_vae_opt_state(vh_vae* h, double* d, double* numerator_weighted, int64_t* 
 int vh_vae_set_probe(vh_vae* h, int enable, int layer);
 int vh_vae_probe_result(vh_vae* h, double* ms_total, int64_t* launches, double* flops_per_launch);
 
+/* =============================================================================================
+ * Data-parallel training (one process per GPU, RCCL over xGMI).  The reference has no distributed
+ * path; these entry points are what a multi-GPU host (vamb_amd/parallel.py) binds.
+ * ============================================================================================= */
+typedef struct vh_comm vh_comm;
+/* rank 0: 128 opaque bytes (ncclUniqueId) to hand to every rank out of band */
+int vh_comm_unique_id(unsigned char* out128);
+/* collective over all ranks: ncclCommInitRank on the calling process' current device */
+int vh_comm_create(int rank, int world, const unsigned char* id128, vh_comm** out);
+int vh_comm_destroy(vh_comm* c);
+/* hipDeviceSynchronize of the library's HIP runtime (the timing fence used by bench.py) */
+int vh_device_synchronize(void);
+/* From now on every optimisation step all-reduces (sum) the flat gradient over `comm` before the
+ * D-Adapt-Adam update; comm == NULL detaches.  All ranks must hold identical parameters. */
+int vh_vae_attach_comm(vh_vae* h, vh_comm* comm);
+/* Epoch over this rank's shard: perm holds n_batches*batch LOCAL dataset rows; the loss of every
+ * step is normalised by the all-rank batch (global_batch rows, global_wsum[b] = sum of the weights
+ * of global batch b) so that the summed gradients equal the single-GPU gradient of the global batch
+ * (BatchNorm statistics stay per-rank).  loss_means are the all-rank epoch means.
+ * global_batch <= 0 / global_wsum == NULL: plain single-GPU epoch. */
+int vh_vae_train_epoch_dp(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, int64_t global_batch,
+                          const float* global_wsum, double loss_means[5]);
+
 /* Diagnostic: run one GEMM instantiation on host data.  C[M][N] = sum_k A(m,k) B(n,k) (+bias[n] if
  * bias != NULL).  a_kc / b_kc: operand stored [rows][K] (1) or [K][rows] (0).  tile: 0 = 64x128,
  * 1 = 128x128, 2 = 128x32.  splits > 1 exercises the split-K slabs (summed on the host side of the call). */

@@ -58,6 +58,9 @@ def lib():
         L.vo_scan.argtypes = [vp, vp, vp, i64, ctypes.c_int, i64, vp, vp, vp, vp, vp, vp, i64]
         L.vo_select.argtypes = [vp, vp, i64, ctypes.c_int, i64, f32, vp, i64]
         L.vo_select.restype = i64
+        L.vo_scan_q.argtypes = [vp, vp, vp, i64, ctypes.c_int, i64, vp, vp, vp, vp, vp, vp, vp, i64]
+        L.vo_select_q.argtypes = [vp, vp, i64, ctypes.c_int, i64, vp, f32, vp, i64]
+        L.vo_select_q.restype = i64
         L.vo_compact_rows.argtypes = [vp, vp, i64, ctypes.c_int]
         L.vo_compact_rows.restype = i64
         L.vo_bin.argtypes = [f32]
@@ -92,6 +95,27 @@ def scan(matrix, lengths_f32, kept, medoid, want_dist=True):
                   _p(dens), _p(nw), _p(nlt), _p(within), n)
     return dict(dist=dist, hist_fx=hist, density_fx=int(dens[0]), n_within=int(nw[0]),
                 n_lt=int(nlt[0]), within=within[: int(nw[0])].copy())
+
+
+def scan_query(matrix, lengths_f32, kept, medoid, query):
+    """scan() against an explicit query vector; medoid = -1 when the medoid row is in another shard."""
+    n, L = matrix.shape
+    hist = np.zeros(NBINS, np.int64)
+    dens = np.zeros(1, np.int64)
+    nw = np.zeros(1, np.int64)
+    nlt = np.zeros(1, np.int64)
+    q = np.ascontiguousarray(query, dtype=np.float32)
+    lib().vo_scan_q(_p(matrix), _p(lengths_f32), _p(kept), n, L, int(medoid), _p(q), None, _p(hist), _p(dens),
+                    _p(nw), _p(nlt), None, 0)
+    return dict(hist_fx=hist, density_fx=int(dens[0]), n_within=int(nw[0]), n_lt=int(nlt[0]))
+
+
+def select_query(matrix, kept, medoid, query, threshold):
+    n, L = matrix.shape
+    out = np.empty(max(n, 1), np.int64)
+    q = np.ascontiguousarray(query, dtype=np.float32)
+    cnt = lib().vo_select_q(_p(matrix), _p(kept), n, L, int(medoid), _p(q), float(np.float32(threshold)), _p(out), n)
+    return out[:cnt].copy()
 
 
 def select(matrix, kept, medoid, threshold):

@@ -99,13 +99,15 @@ void vo_distances(const float* m, int64_t n, int L, int64_t medoid, float* dist)
 
 /* One sample_medoid + the head of find_threshold, restricted to rows with kept[i] != 0
  * (kept == NULL means all rows live, i.e. the reference's packed CPU path).
+ * q: the query vector (NULL: row `medoid` of m); medoid: the row whose distance is forced to 0, or -1
+ * when the medoid is not part of this matrix (row-sharded execution).
  * within_idx receives the ascending row indices with d <= 0.05f (at most cap written; the true
  * count is returned in *n_within).  dist (optional) receives every distance. */
-void vo_scan(const float* m, const float* lengths, const uint8_t* kept, int64_t n, int L,
-             int64_t medoid, float* dist, int64_t* hist_fx, int64_t* density_fx,
-             int64_t* n_within, int64_t* n_lt, int64_t* within_idx, int64_t cap) {
+void vo_scan_q(const float* m, const float* lengths, const uint8_t* kept, int64_t n, int L,
+               int64_t medoid, const float* q, float* dist, int64_t* hist_fx, int64_t* density_fx,
+               int64_t* n_within, int64_t* n_lt, int64_t* within_idx, int64_t cap) {
     if (!g_edges_ready) make_edges();
-    const float* q = m + medoid * (int64_t)L;
+    if (!q) q = m + medoid * (int64_t)L;
     int64_t dens = 0, nw = 0, nlt = 0;
     for (int b = 0; b < VO_NBINS; ++b) hist_fx[b] = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -128,10 +130,16 @@ void vo_scan(const float* m, const float* lengths, const uint8_t* kept, int64_t 
     *n_lt = nlt;
 }
 
+void vo_scan(const float* m, const float* lengths, const uint8_t* kept, int64_t n, int L,
+             int64_t medoid, float* dist, int64_t* hist_fx, int64_t* density_fx,
+             int64_t* n_within, int64_t* n_lt, int64_t* within_idx, int64_t cap) {
+    vo_scan_q(m, lengths, kept, n, L, medoid, 0, dist, hist_fx, density_fx, n_within, n_lt, within_idx, cap);
+}
+
 /* cluster.py:640-650: ascending indices of live rows with d <= threshold (float32 compare) */
-int64_t vo_select(const float* m, const uint8_t* kept, int64_t n, int L, int64_t medoid,
-                  float threshold, int64_t* out_idx, int64_t cap) {
-    const float* q = m + medoid * (int64_t)L;
+int64_t vo_select_q(const float* m, const uint8_t* kept, int64_t n, int L, int64_t medoid, const float* q,
+                    float threshold, int64_t* out_idx, int64_t cap) {
+    if (!q) q = m + medoid * (int64_t)L;
     int64_t cnt = 0;
     for (int64_t i = 0; i < n; ++i) {
         if (kept && !kept[i]) continue;
@@ -143,6 +151,11 @@ int64_t vo_select(const float* m, const uint8_t* kept, int64_t n, int L, int64_t
         }
     }
     return cnt;
+}
+
+int64_t vo_select(const float* m, const uint8_t* kept, int64_t n, int L, int64_t medoid,
+                  float threshold, int64_t* out_idx, int64_t cap) {
+    return vo_select_q(m, kept, n, L, medoid, 0, threshold, out_idx, cap);
 }
 
 /* vambcore.overwrite_matrix contract (vambtools.py:291-321): order-preserving row compaction */

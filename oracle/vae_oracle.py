@@ -172,7 +172,8 @@ class OracleVAE:
         self._tape = dict(hidden=tape, mu=tape_mu, a_last=a, x=x)
         return depths_out, tnf_out, ab_out, mu
 
-    def calc_loss(self, depths_in, depths_out, tnf_in, tnf_out, ab_in, ab_out, mu, weights):
+    def calc_loss(self, depths_in, depths_out, tnf_in, tnf_out, ab_in, ab_out, mu, weights,
+                  global_wsum=None, global_batch=None):
         """encode.py:316-357.  Returns the 5 scalars and stashes what backward needs."""
         ce_w, ab_w, sse_w, kld_w = loss_weights(self.nsamples, self.nlatent, self.alpha, self.beta)
         dt = self.dtype
@@ -187,6 +188,9 @@ class OracleVAE:
         w = weights.reshape(-1)
         rows = (ce * ce_w + ab_sse * ab_w + sse * sse_w) + kld * kld_w
         loss_row = rows * w.mean()
+        # data-parallel shard of a larger batch: normalise by the all-rank batch instead
+        # (d loss / d rows_i = wsum_global / B_global^2; see vamb_amd/parallel.py)
+        self._row_grad = None if global_wsum is None else float(global_wsum) / float(global_batch) ** 2
         self._loss_in = dict(depths_in=depths_in, depths_out=depths_out, tnf_in=tnf_in, tnf_out=tnf_out,
                              ab_in=ab_in, ab_out=ab_out, mu=mu, w=w)
         return (loss_row.mean(), (ab_sse * ab_w).mean(), (ce * ce_w).mean(), (sse * sse_w).mean(),
@@ -199,6 +203,8 @@ class OracleVAE:
         ce_w, ab_w, sse_w, kld_w = loss_weights(self.nsamples, self.nlatent, self.alpha, self.beta)
         B = L["w"].shape[0]
         g = np.full((B, 1), L["w"].mean() / B, dtype=self.dtype)  # d mean(outer(rows, w)) / d rows_i
+        if getattr(self, "_row_grad", None) is not None:
+            g = np.full((B, 1), self._row_grad, dtype=self.dtype)
         S = self.nsamples
         p = L["depths_out"]
         dp = g * ce_w * (-L["depths_in"] / (p + 1e-9))

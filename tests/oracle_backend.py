@@ -35,6 +35,29 @@ class OracleScanBackend:
             out.append(ScanStats(r["density_fx"], r["n_within"], r["n_lt"], r["hist_fx"]))
         return out
 
+    # ---- pieces the row-sharded backend (vamb_amd.parallel.ShardedScanBackend) needs -------------
+    def get_rows(self, rows):
+        return self.m[np.asarray(rows, dtype=np.int64)].copy()
+
+    def scan_raw(self, rows, queries=None):
+        self.scan_passes += 1
+        out = np.zeros((len(rows), 63), np.int64)
+        for j, med in enumerate(rows):
+            q = self.m[med] if queries is None else queries[j]
+            r = co.scan_query(self.m, self.lengths, self.kept, int(med), q)
+            out[j, 0] = r["density_fx"]
+            out[j, 1:61] = r["hist_fx"]
+            out[j, 61] = r["n_within"]
+            out[j, 62] = r["n_lt"]
+        return out
+
+    def select_query(self, row, query, threshold, remove):
+        q = self.m[row] if query is None else query
+        rows = co.select_query(self.m, self.kept, int(row), q, threshold)
+        if remove:
+            self.kept[rows] = 0
+        return rows
+
     def select(self, medoid, threshold, remove):
         rows = co.select(self.m, self.kept, medoid, threshold)
         if remove:

@@ -1,0 +1,87 @@
+"""GPU test of the data-parallel plumbing with a 1-rank RCCL communicator (the GPU box has one GPU):
+ncclCommInitRank / in-stream ncclAllReduce / the flat-gradient path must reproduce the plain
+single-GPU epoch exactly (the all-reduce over one rank is the identity and the slab sum order is the
+same), and the all-rank loss normalisation must be honoured."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from vamb_amd import _lib, encode as ve, parallel, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def comm():
+    import torch.distributed as dist
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    c = parallel.Communicator(dist, rccl=True)
+    yield c
+    c.close()
+    dist.destroy_process_group()
+
+
+def _setup(seed=5):
+    n, S = 3000, 6
+    ab, tnf, lens, _ = synth.features(n, S, seed=seed)
+    dl = ve.make_dataloader(ab, tnf, lens, batchsize=256, destroy=True)
+    return n, S, dl
+
+
+def test_rccl_epoch_equals_plain_epoch(comm):
+    n, S, dl = _setup()
+    lib = _lib.load()
+    perm = np.random.RandomState(0).permutation(n)[: (n // 256) * 256].astype(np.int64)
+    outs = []
+    for use_comm in (False, True):
+        vae = ve.VAE(S, nhiddens=[64, 48], nlatent=8, seed=3)
+        vae._ensure_dataset(dl)
+        if use_comm:
+            vae.attach_communicator(comm)
+        means = (ctypes.c_double * 5)()
+        for _ in range(2):
+            if use_comm:
+                w = dl.dataset.tensors[3].numpy().reshape(-1).astype(np.float64)
+                gw = w[perm].reshape(-1, 256).sum(axis=1).astype(np.float32)
+                _lib.check(lib.vh_vae_train_epoch_dp(vae._h, _lib.ptr(perm), n // 256, 256, 256, _lib.ptr(gw), means))
+            else:
+                _lib.check(lib.vh_vae_train_epoch(vae._h, _lib.ptr(perm), n // 256, 256, means))
+        outs.append((vae.state_dict(), list(means), vae.optimizer_state()))
+    (sd0, m0, o0), (sd1, m1, o1) = outs
+    # dropout masks differ only through the rank key (rank 0 in both) -> identical streams
+    for k in sd0:
+        a, b = sd0[k].numpy(), sd1[k].numpy()
+        assert np.allclose(a, b, rtol=2e-5, atol=1e-7), k
+    assert np.allclose(m0, m1, rtol=1e-5)
+    assert abs(o0["d"] - o1["d"]) <= 1e-5 * o0["d"]
+
+
+def test_global_batch_normalisation(comm):
+    """Half of a batch with global_batch = 2*local and the global weight sum gives exactly half the
+    gradient contribution: loss means scale by 1/2 relative to a self-contained batch with the same
+    weight mean."""
+    n, S, dl = _setup(seed=6)
+    lib = _lib.load()
+    rows = np.arange(256, dtype=np.int64)
+    w = dl.dataset.tensors[3].numpy().reshape(-1).astype(np.float64)
+    res = []
+    for gb in (256, 512):
+        vae = ve.VAE(S, nhiddens=[64, 48], nlatent=8, dropout=0.0, seed=3)
+        vae._ensure_dataset(dl)
+        vae.attach_communicator(comm)
+        gw = np.array([w[rows].sum() * (gb // 256)], np.float32)
+        means = (ctypes.c_double * 5)()
+        _lib.check(lib.vh_vae_train_epoch_dp(vae._h, _lib.ptr(rows), 1, 256, gb, _lib.ptr(gw), means))
+        res.append(list(means))
+    # the reported local share of the all-rank mean halves when the batch is twice as large
+    assert np.allclose(np.array(res[1][1:]), np.array(res[0][1:]) / 2, rtol=1e-3)

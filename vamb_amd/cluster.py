@@ -140,32 +140,51 @@ class HipScanBackend:
             _lib.check(self.lib.vh_clu_last_kernel_ms(self.h, ctypes.byref(ms)))
             self.kernel_ms += ms.value
 
+    def scan_raw(self, rows, queries=None) -> _np.ndarray:
+        """One pass for <= 32 medoids.  rows[j] = physical row whose distance is forced to 0 (or -1 when
+        the medoid lives in another shard, then ``queries`` [k, L] must be given).  Returns the raw
+        int64 accumulators [k, 63] = (density_fx, hist_fx[60], n_within, n_lt)."""
+        rows = _np.ascontiguousarray(rows, dtype=_np.int64)
+        k = len(rows)
+        q = None if queries is None else _np.ascontiguousarray(queries, dtype=_np.float32)
+        _lib.check(self.lib.vh_clu_scan(self.h, k, _lib.ptr(rows), _lib.ptr(q), self._res))
+        self.scan_passes += 1
+        self.scan_medoids += k
+        self.rows_streamed += self.n_rows
+        self._collect_ms()
+        return _np.frombuffer(self._res, dtype=_np.int64, count=k * (_NBINS + 3)).reshape(k, _NBINS + 3).copy()
+
     def scan(self, medoids):
         """List of physical rows -> list of ScanStats (one pass per <= 32 medoids)."""
         out = []
         for lo in range(0, len(medoids), _MAX_MEDOIDS_PER_PASS):
-            chunk = medoids[lo:lo + _MAX_MEDOIDS_PER_PASS]
-            rows = _np.asarray(chunk, dtype=_np.int64)
-            _lib.check(self.lib.vh_clu_scan(self.h, len(chunk), _lib.ptr(rows), None, self._res))
-            self.scan_passes += 1
-            self.scan_medoids += len(chunk)
-            self.rows_streamed += self.n_rows
-            self._collect_ms()
-            for j in range(len(chunk)):
-                r = self._res[j]
-                out.append(ScanStats(r.density_fx, r.n_within, r.n_lt,
-                                     _np.frombuffer(r.hist_fx, dtype=_np.int64).copy()))
+            raw = self.scan_raw(medoids[lo:lo + _MAX_MEDOIDS_PER_PASS])
+            for r in raw:
+                out.append(ScanStats(int(r[0]), int(r[_NBINS + 1]), int(r[_NBINS + 2]), r[1:_NBINS + 1]))
         return out
 
-    def select(self, medoid: int, threshold: float, remove: bool) -> _np.ndarray:
+    def get_rows(self, rows) -> _np.ndarray:
+        rows = _np.ascontiguousarray(rows, dtype=_np.int64)
+        out = _np.empty((len(rows), self.L), _np.float32)
+        if len(rows):
+            _lib.check(self.lib.vh_clu_get_rows(self.h, _lib.ptr(rows), len(rows), _lib.ptr(out)))
+        return out
+
+    def select_query(self, row: int, query, threshold: float, remove: bool) -> _np.ndarray:
+        """select() against an explicit query vector (row = -1 when the medoid is not in this shard)."""
         n = ctypes.c_int64(0)
-        thr = float(_np.float32(threshold))  # torch compares in float32 (cluster.py:640-650)
-        _lib.check(self.lib.vh_clu_select(self.h, int(medoid), None, thr, int(remove), _lib.ptr(self._sel),
+        thr = float(_np.float32(threshold))
+        q = None if query is None else _np.ascontiguousarray(query, dtype=_np.float32)
+        _lib.check(self.lib.vh_clu_select(self.h, int(row), _lib.ptr(q), thr, int(remove), _lib.ptr(self._sel),
                                           len(self._sel), ctypes.byref(n)))
         self.rows_streamed += self.n_rows
         self.scan_passes += 1
         self._collect_ms()
         return self._sel[: n.value].copy()
+
+    def select(self, medoid: int, threshold: float, remove: bool) -> _np.ndarray:
+        # torch compares in float32 (cluster.py:640-650): select_query casts the threshold
+        return self.select_query(int(medoid), None, threshold, remove)
 
     def remove(self, rows: _np.ndarray):
         rows = _np.ascontiguousarray(rows, dtype=_np.int64)
@@ -299,12 +318,36 @@ class ClusterGenerator:
         if inplace_target is not None and normalized_out is not None:
             inplace_target[...] = normalized_out
 
+        self._setup(lengths, maxsteps, windowsize, minsuccesses, rng_seed)
+
+    @classmethod
+    def from_backend(cls, backend, lengths: _np.ndarray, maxsteps: int = 25, windowsize: int = 300,
+                     minsuccesses: int = 15, rng_seed: int = 0):
+        """Build the host state machine on top of an existing scan backend (the row-sharded multi-GPU
+        backend of ``vamb_amd.parallel``).  ``lengths`` are the GLOBAL contig lengths."""
+        lengths = _np.asarray(lengths)
+        if maxsteps < 1:
+            raise ValueError(f"maxsteps must be a positive integer, not {maxsteps}")
+        if windowsize < 1:
+            raise ValueError(f"windowsize must be at least 1, not {windowsize}")
+        if minsuccesses < 1 or minsuccesses > windowsize:
+            raise ValueError(f"minsuccesses must be between 1 and windowsize, not {minsuccesses}")
+        if backend.n_rows < 1:
+            raise ValueError("Matrix must have at least 1 observation.")
+        if len(lengths) != backend.n_rows:
+            raise ValueError("N sequences in lengths and matrix do not match")
+        self = cls.__new__(cls)
+        self._backend = backend
+        self._setup(lengths, maxsteps, windowsize, minsuccesses, rng_seed)
+        return self
+
+    def _setup(self, lengths, maxsteps, windowsize, minsuccesses, rng_seed):
         self.maxsteps: int = maxsteps
         self.minsuccesses: int = minsuccesses
         self.cuda: bool = True
         self.rng = _random.Random(rng_seed)
         self.matrix = _MatrixView(self._backend)
-        n = len(matrix)
+        n = self._backend.n_rows
         self.indices = _np.arange(n)                       # original row of every resident row
         self._kept = _np.ones(n, dtype=bool)               # host mirror of the device live mask
         self.order = _np.argsort(lengths)[::-1].copy()     # same call as cluster.py:275

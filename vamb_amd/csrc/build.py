@@ -25,6 +25,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-cor
 SOURCES = {
     "cluster.hip": ["-ffp-contract=off"],
     "vae.hip": [],
+    "comm.hip": [],
 }
 
 
@@ -63,7 +64,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if jobs or force or not os.path.exists(OUT):
-        run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
+        run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs, "-ldl"])
     return OUT
 
 

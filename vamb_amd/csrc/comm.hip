@@ -1,0 +1,136 @@
+// comm.hip -- dlopen-bound RCCL wrappers + C ABI of the communicator (see comm.hpp).
+#include "comm.hpp"
+
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <string>
+
+#include "common.hpp"
+
+using namespace vh;
+
+namespace {
+
+// the few RCCL entry points we need, with their rccl.h prototypes spelled out so that the header
+// (and a link-time dependency) is not required
+typedef struct { char internal[128]; } UniqueId;
+typedef int (*fn_get_unique_id)(UniqueId*);
+typedef int (*fn_comm_init_rank)(void**, int, UniqueId, int);
+typedef int (*fn_comm_destroy)(void*);
+typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*fn_error_string)(int);
+
+constexpr int kNcclFloat32 = 7;  // ncclFloat32 / ncclFloat
+constexpr int kNcclFloat64 = 8;  // ncclFloat64 / ncclDouble
+constexpr int kNcclSum = 0;      // ncclSum
+
+struct Rccl {
+    void* handle = nullptr;
+    fn_get_unique_id get_unique_id = nullptr;
+    fn_comm_init_rank comm_init_rank = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_all_reduce all_reduce = nullptr;
+    fn_error_string error_string = nullptr;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    if (r.handle) return r;
+    std::string tried;
+    const char* env = getenv("VAMBHIP_RCCL");
+    std::string rocm = getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "/opt/rocm";
+    const std::string candidates[] = {env ? env : "", rocm + "/lib/librccl.so.1", rocm + "/lib/librccl.so",
+                                      "/opt/rocm/lib/librccl.so.1"};
+    for (const auto& c : candidates) {
+        if (c.empty()) continue;
+        r.handle = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+        tried += c + " ";
+    }
+    if (!r.handle) throw InvalidArg{"cannot load RCCL (tried: " + tried + ")"};
+    r.get_unique_id = (fn_get_unique_id)dlsym(r.handle, "ncclGetUniqueId");
+    r.comm_init_rank = (fn_comm_init_rank)dlsym(r.handle, "ncclCommInitRank");
+    r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
+    r.all_reduce = (fn_all_reduce)dlsym(r.handle, "ncclAllReduce");
+    r.error_string = (fn_error_string)dlsym(r.handle, "ncclGetErrorString");
+    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce)
+        throw InvalidArg{"RCCL library lacks a required symbol"};
+    return r;
+}
+
+void check_nccl(int rc, const char* what) {
+    if (rc == 0) return;
+    Rccl& r = rccl();
+    const char* msg = r.error_string ? r.error_string(rc) : "?";
+    char buf[256];
+    snprintf(buf, sizeof(buf), "RCCL error %d (%s) in %s", rc, msg, what);
+    throw InvalidArg{std::string(buf)};
+}
+
+}  // namespace
+
+namespace vh {
+
+void rccl_unique_id(unsigned char out[128]) {
+    UniqueId id;
+    check_nccl(rccl().get_unique_id(&id), "ncclGetUniqueId");
+    memcpy(out, id.internal, 128);
+}
+
+vh_comm* rccl_comm_create(int rank, int world, const unsigned char idbytes[128]) {
+    UniqueId id;
+    memcpy(id.internal, idbytes, 128);
+    vh_comm* c = new vh_comm();
+    c->rank = rank;
+    c->world = world;
+    int rc = rccl().comm_init_rank(&c->nccl_comm, world, id, rank);
+    if (rc != 0) {
+        delete c;
+        check_nccl(rc, "ncclCommInitRank");
+    }
+    return c;
+}
+
+void rccl_comm_destroy(vh_comm* c) {
+    if (!c) return;
+    if (c->nccl_comm) (void)rccl().comm_destroy(c->nccl_comm);
+    delete c;
+}
+
+void rccl_allreduce_sum_f32(vh_comm* c, float* buf, size_t count, hipStream_t stream) {
+    check_nccl(rccl().all_reduce(buf, buf, count, kNcclFloat32, kNcclSum, c->nccl_comm, stream), "ncclAllReduce(f32)");
+}
+
+void rccl_allreduce_sum_f64(vh_comm* c, double* buf, size_t count, hipStream_t stream) {
+    check_nccl(rccl().all_reduce(buf, buf, count, kNcclFloat64, kNcclSum, c->nccl_comm, stream), "ncclAllReduce(f64)");
+}
+
+}  // namespace vh
+
+extern "C" {
+
+int vh_comm_unique_id(unsigned char* out128) {
+    return guarded([&] {
+        VH_REQUIRE(out128 != nullptr, "NULL argument");
+        rccl_unique_id(out128);
+    });
+}
+
+int vh_comm_create(int rank, int world, const unsigned char* id128, vh_comm** out) {
+    return guarded([&] {
+        VH_REQUIRE(out != nullptr && id128 != nullptr, "NULL argument");
+        VH_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
+        *out = rccl_comm_create(rank, world, id128);
+    });
+}
+
+int vh_comm_destroy(vh_comm* c) {
+    return guarded([&] { rccl_comm_destroy(c); });
+}
+
+int vh_device_synchronize(void) {
+    return guarded([&] { VH_HIP(hipDeviceSynchronize()); });
+}
+
+}  // extern "C"

@@ -10,6 +10,7 @@
 //   per-batch workspaces sized for the current batch (bs_p = ru128(bs))
 // All dense contractions run on the fp32-input MFMA kernel of gemm.hpp; everything else is a small
 // bandwidth-bound kernel from vae_kernels.hpp.  One stream, no host synchronisation inside an epoch.
+#include "comm.hpp"
 #include "common.hpp"
 #include "gemm.hpp"
 #include "vae_kernels.hpp"
@@ -123,6 +124,13 @@ struct vh_vae {
     int opt_blocks = 0;
     int loss_blocks = 0;
     uint64_t step_counter = 0;
+
+    // data parallelism (one process per GPU; gradients all-reduced over RCCL on `stream`)
+    vh_comm* comm = nullptr;
+    DevBuf<float> G, gwsum;          // flat gradient buffer; per-batch global weight sums
+    DevBuf<TensorDesc> descs_flat;   // descriptors that read G instead of the slabs
+    const float* wsum_src = nullptr; // weight sum used by the loss of the current step
+    int global_bs = 0;               // rows of the all-rank batch (== bs without a communicator)
 
     // probe
     bool probe_on = false;
@@ -295,6 +303,11 @@ void prepare_batch(vh_vae* h, int bs) {
             blk_local.push_back(b);
         }
     }
+    std::vector<TensorDesc> descs_flat = descs;
+    h->G.ensure(h->flat_elems);
+    for (auto& d : descs_flat) { d.slab = h->G.p + d.p_off; d.nslab = 1; d.stride = 0; }
+    h->descs_flat.ensure(descs_flat.size());
+    VH_HIP(hipMemcpy(h->descs_flat.p, descs_flat.data(), sizeof(TensorDesc) * descs_flat.size(), hipMemcpyHostToDevice));
     h->opt_blocks = (int)blk_tensor.size();
     h->descs.ensure(descs.size());
     h->blk_tensor.ensure(blk_tensor.size());
@@ -321,7 +334,8 @@ DropCfg drop_cfg(vh_vae* h, bool training, bool injected) {
 }
 
 uint64_t layer_key(vh_vae* h, int layer) {
-    return (h->cfg.seed * 0xD1342543DE82EF95ull) ^ (h->step_counter << 8) ^ (uint64_t)layer;
+    const uint64_t rank = h->comm ? (uint64_t)h->comm->rank : 0ull;
+    return (h->cfg.seed * 0xD1342543DE82EF95ull) ^ (h->step_counter << 8) ^ (uint64_t)layer ^ (rank << 52);
 }
 
 void upload_masks(vh_vae* h, const uint8_t* masks, int bs) {
@@ -455,19 +469,25 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
 
 void loss_and_seed(vh_vae* h) {
     hipStream_t s = h->stream;
-    hipLaunchKernelGGL(vae_sum_kernel, dim3(1), dim3(256), 0, s, h->Wb.p, h->bs, h->wsum.p);
-    VH_HIP(hipGetLastError());
+    const float* wsum = h->wsum_src;
+    if (!wsum) {   // single GPU: sum of this batch's weights
+        hipLaunchKernelGGL(vae_sum_kernel, dim3(1), dim3(256), 0, s, h->Wb.p, h->bs, h->wsum.p);
+        VH_HIP(hipGetLastError());
+        wsum = h->wsum.p;
+    }
+    const int bs_global = h->global_bs > 0 ? h->global_bs : h->bs;
     LossArgs a;
     a.R = h->R.p; a.X = h->Xb.p; a.ld = h->D_p;
     a.MU = h->MU.p; a.ldl = h->L_p;
-    a.wsum = h->wsum.p;
+    a.wsum = wsum;
+    a.inv_b2 = (float)(1.0 / ((double)bs_global * (double)bs_global));
     a.bs = h->bs; a.bs_p = h->bs_p; a.S = h->S; a.L = h->L;
     a.ce_w = h->ce_w; a.ab_w = h->ab_w; a.sse_w = h->sse_w; a.kld_w = h->kld_w;
     a.dR = h->dR.p; a.dMUk = h->dMUk.p; a.part = h->loss_part.p;
     hipLaunchKernelGGL(vae_loss_kernel, dim3(h->loss_blocks), dim3(256), 0, s, a);
     VH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, h->loss_part.p, h->loss_blocks, h->wsum.p,
-                       h->bs, h->state.p);
+    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, h->loss_part.p, h->loss_blocks, wsum,
+                       bs_global, h->state.p);
     VH_HIP(hipGetLastError());
 }
 
@@ -576,7 +596,17 @@ void backward(vh_vae* h, bool masks_injected) {
 }
 
 void optimizer_step(vh_vae* h) {
-    hipLaunchKernelGGL(vae_dadapt_kernel, dim3(h->opt_blocks), dim3(256), 0, h->stream, h->descs.p, h->blk_tensor.p,
+    const TensorDesc* descs = h->descs.p;
+    if (h->comm) {
+        // sum this rank's slabs into the flat buffer, all-reduce it over the ranks (RCCL, same stream,
+        // no host synchronisation), then every rank applies the identical update
+        hipLaunchKernelGGL(vae_reduce_slabs_kernel, dim3(h->opt_blocks), dim3(256), 0, h->stream, h->descs.p,
+                           h->blk_tensor.p, h->blk_local.p, h->G.p);
+        VH_HIP(hipGetLastError());
+        rccl_allreduce_sum_f32(h->comm, h->G.p, h->flat_elems, h->stream);
+        descs = h->descs_flat.p;
+    }
+    hipLaunchKernelGGL(vae_dadapt_kernel, dim3(h->opt_blocks), dim3(256), 0, h->stream, descs, h->blk_tensor.p,
                        h->blk_local.p, h->P.p, h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p);
     VH_HIP(hipGetLastError());
     hipLaunchKernelGGL(vae_dadapt_finalize_kernel, dim3(1), dim3(256), 0, h->stream, h->opt_part.p, h->opt_blocks,
@@ -835,7 +865,8 @@ int vh_vae_train_step(vh_vae* h, const int64_t* rows, int64_t batch, const float
     });
 }
 
-int vh_vae_train_epoch(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, double loss_means[5]) {
+int vh_vae_train_epoch_dp(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, int64_t global_batch,
+                          const float* global_wsum, double loss_means[5]) {
     return guarded([&] {
         VH_REQUIRE(h != nullptr && perm != nullptr, "NULL argument");
         VH_REQUIRE(h->n > 0, "no dataset: call vh_vae_set_dataset first");
@@ -843,19 +874,57 @@ int vh_vae_train_epoch(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_
         VH_REQUIRE(batch >= 2, "BatchNorm1d needs more than 1 value per channel when training (batch=%lld)",
                    (long long)batch);
         VH_REQUIRE(batch <= (1 << 24), "batch too large");
+        const bool dp = h->comm != nullptr && h->comm->world > 1;
+        if (global_batch <= 0) global_batch = batch;
+        VH_REQUIRE(global_batch >= batch, "global batch smaller than the local batch");
+        VH_REQUIRE(!(global_batch != batch && global_wsum == nullptr),
+                   "a global batch needs the per-batch global weight sums");
+        VH_REQUIRE(!(global_batch != batch && h->comm == nullptr), "a global batch needs a communicator");
         const int64_t total = n_batches * batch;
         for (int64_t i = 0; i < total; ++i)
             VH_REQUIRE(perm[i] >= 0 && perm[i] < h->n, "row %lld out of range", (long long)perm[i]);
         prepare_batch(h, (int)batch);
         h->perm.ensure((size_t)total);
         VH_HIP(hipMemcpyAsync(h->perm.p, perm, sizeof(int64_t) * total, hipMemcpyHostToDevice, h->stream));
+        if (global_wsum) {
+            h->gwsum.ensure((size_t)n_batches);
+            VH_HIP(hipMemcpyAsync(h->gwsum.p, global_wsum, sizeof(float) * n_batches, hipMemcpyHostToDevice, h->stream));
+        }
+        h->global_bs = (int)global_batch;
         reset_epoch_sums(h);
-        for (int64_t b = 0; b < n_batches; ++b) train_step_device(h, h->perm.p + b * batch, false, false);
+        for (int64_t b = 0; b < n_batches; ++b) {
+            h->wsum_src = global_wsum ? h->gwsum.p + b : nullptr;
+            train_step_device(h, h->perm.p + b * batch, false, false);
+        }
+        h->wsum_src = nullptr;
+        h->global_bs = 0;
+        if (dp) {
+            // epoch log line: every rank holds local_sum / B_global, the sum over ranks is the global mean
+            StepState* st = h->state.p;
+            rccl_allreduce_sum_f64(h->comm, st->epoch_loss, 5, h->stream);
+            // BatchNorm running statistics are per-rank (local batch statistics): average them so that
+            // every rank encodes with the same eval-mode network
+            rccl_allreduce_sum_f32(h->comm, h->bnbuf.p, h->bn_elems, h->stream);
+            hipLaunchKernelGGL(vae_scale_kernel, dim3(64), dim3(256), 0, h->stream, h->bnbuf.p, (int64_t)h->bn_elems,
+                               1.0f / (float)h->comm->world);
+            VH_HIP(hipGetLastError());
+        }
         StepState st;
         read_state(h, &st);
         probe_collect(h);
         if (loss_means)
             for (int i = 0; i < 5; ++i) loss_means[i] = st.epoch_loss[i] / (double)n_batches;
+    });
+}
+
+int vh_vae_train_epoch(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, double loss_means[5]) {
+    return vh_vae_train_epoch_dp(h, perm, n_batches, batch, 0, nullptr, loss_means);
+}
+
+int vh_vae_attach_comm(vh_vae* h, vh_comm* comm) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "NULL argument");
+        h->comm = comm;
     });
 }
 

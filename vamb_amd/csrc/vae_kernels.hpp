@@ -172,7 +172,8 @@ struct LossArgs {
     int64_t ld;
     const float* MU;     // [bs_p][ldl]
     int64_t ldl;
-    const float* wsum;   // sum of the batch weights
+    const float* wsum;   // sum of the (global) batch weights
+    float inv_b2;        // 1 / B_global^2
     int bs, bs_p, S, L;
     float ce_w, ab_w, sse_w, kld_w;
     float* dR;           // [bs_p][ld]
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const LossArgs a) {
         } else {
             const float* r = a.R + (int64_t)row * a.ld;
             const float* x = a.X + (int64_t)row * a.ld;
-            const float g = a.wsum[0] / ((float)a.bs * (float)a.bs);
+            const float g = a.wsum[0] * a.inv_b2;
             const int S = a.S;
             // softmax over the S abundance logits
             float mx = -3.0e38f;
@@ -273,8 +274,10 @@ struct StepState {
 };
 
 // reduce the loss partials, produce the five means (encode.py:350-356) and add them to the epoch sums
+// bs_global: rows of the whole (all-rank) batch; under data parallelism every rank adds its own share
+// local_sum / bs_global and the epoch sums are all-reduced once per epoch.
 __global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const float* __restrict__ part, int nblocks,
-                                                                const float* __restrict__ wsum, int bs,
+                                                                const float* __restrict__ wsum, int bs_global,
                                                                 StepState* __restrict__ st) {
     __shared__ double red[4][256];
     double s[4] = {0, 0, 0, 0};
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const float* __r
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        const double bs = (double)bs_global;
         const double ab = red[0][0] / bs, ce = red[1][0] / bs, sse = red[2][0] / bs, kld = red[3][0] / bs;
         const double wmean = (double)wsum[0] / bs;
         const double loss = ((ce + ab + sse) + kld) * wmean;
@@ -480,6 +484,27 @@ struct TensorDesc {
     int64_t p_off;        // offset of the tensor in the flat parameter / moment buffers
     int64_t size;         // padded element count actually used
 };
+
+// data-parallel path: G[flat] = sum of this rank's gradient slabs (then all-reduced over the ranks)
+__global__ __launch_bounds__(256) void vae_reduce_slabs_kernel(const TensorDesc* __restrict__ descs,
+                                                               const int* __restrict__ blk_tensor,
+                                                               const int* __restrict__ blk_local,
+                                                               float* __restrict__ G) {
+    const TensorDesc td = descs[blk_tensor[blockIdx.x]];
+    const int64_t local = (int64_t)blk_local[blockIdx.x] * 1024 + threadIdx.x * 4;
+    if (local >= td.size) return;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < td.nslab; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(td.slab + (int64_t)s * td.stride + local);
+        g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+    }
+    *reinterpret_cast<float4*>(G + td.p_off + local) = g;
+}
+
+__global__ void vae_scale_kernel(float* __restrict__ v, int64_t n, float f) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        v[i] *= f;
+}
 
 // One pass over every parameter: moments, s, parameter update, and the two global reductions
 // (numerator dot and |s|_1) as per-workgroup partials.  Each workgroup covers 1024 elements of ONE tensor.

@@ -186,6 +186,13 @@ class VAE:
         self._h = h
         self._dataset_key = None
         self._n_rows = 0
+        self._comm = None
+
+    def attach_communicator(self, comm) -> None:
+        """Data-parallel training over ``comm`` (``vamb_amd.parallel.Communicator``): this process holds
+        one row shard of the dataset; every step all-reduces the gradient over RCCL inside the library."""
+        self._comm = comm
+        _lib.check(self._lib.vh_vae_attach_comm(self._h, comm.handle if comm is not None else None))
 
     def __del__(self):
         try:
@@ -361,16 +368,25 @@ class VAE:
         if epoch in batchsteps:
             data_loader = set_batchsize(data_loader, data_loader.batch_size * 2, n_seq)
         bs = data_loader.batch_size
+        means = (ctypes.c_double * 5)()
         # RandomSampler semantics: a fresh permutation per epoch; drop the ragged tail iff n > batch
         perm = _torch.randperm(n_seq).numpy()
-        if n_seq > bs:
-            n_batches = n_seq // bs
-            batch = bs
+        if self._comm is not None:
+            # data parallel: `bs` is the ALL-RANK batch; this rank contributes bs / world local rows
+            from . import parallel as _parallel
+
+            weights = data_loader.dataset.tensors[3].numpy()
+            rows, n_batches, batch, gwsum = _parallel.plan_epoch(self._comm, n_seq, bs, weights, perm)
+            _lib.check(self._lib.vh_vae_train_epoch_dp(self._h, _lib.ptr(rows), n_batches, batch, bs,
+                                                       _lib.ptr(gwsum), means))
         else:
-            n_batches, batch = 1, n_seq
-        perm = _np.ascontiguousarray(perm[: n_batches * batch], dtype=_np.int64)
-        means = (ctypes.c_double * 5)()
-        _lib.check(self._lib.vh_vae_train_epoch(self._h, _lib.ptr(perm), n_batches, batch, means))
+            if n_seq > bs:
+                n_batches = n_seq // bs
+                batch = bs
+            else:
+                n_batches, batch = 1, n_seq
+            perm = _np.ascontiguousarray(perm[: n_batches * batch], dtype=_np.int64)
+            _lib.check(self._lib.vh_vae_train_epoch(self._h, _lib.ptr(perm), n_batches, batch, means))
         loss, ab, ce, sse, kld = tuple(means)
         logger.info(
             "\t\tEpoch: {:>3}  Loss: {:.5e}  CE: {:.5e}  AB: {:.5e}  SSE: {:.5e}  KLD: {:.5e}  Batchsize: {:>4}".format(

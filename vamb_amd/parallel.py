@@ -1,0 +1,228 @@
+"""Multi-GPU execution of the hot path: one process per GPU, contigs sharded by row.
+
+The reference has no distributed path (no NCCL/MPI call site), so nothing here
+mirrors reference code; it is the host side of BASELINE.json's north star ("training mini-batches and
+the cluster seed search partition across the 8 GPUs ... RCCL all-reduce of gradients and all-gather of
+per-shard neighbour histograms").
+
+Two planes
+  * bulk data plane: RCCL called from inside libvambhip on the library's own HIP stream
+    (``vh_comm_*`` / ``vh_vae_train_epoch_dp``): the flat gradient all-reduce of every optimisation
+    step, the per-epoch BatchNorm-buffer and loss reductions.  No host synchronisation per step.
+  * control plane: a ``torch.distributed`` process group (gloo is enough: a few hundred bytes per
+    message) for bootstrap (the ncclUniqueId), per-epoch batch planning and the cluster scan's
+    scalar/histogram reductions and candidate-list gathers.
+
+Training semantics under data parallelism: every rank holds a contiguous row shard and contributes
+``global_batch / world`` rows to each step; the loss of a step is normalised by the ALL-RANK batch so
+the summed gradients equal the single-GPU gradient of the same global batch.  BatchNorm batch
+statistics are per-rank (as in torch DDP without SyncBatchNorm); running statistics are averaged over
+ranks after every epoch so that all ranks encode with the same network.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as _np
+
+from . import _lib
+from .cluster import _MAX_MEDOIDS_PER_PASS, ScanStats
+
+
+class Communicator:
+    """A torch.distributed group (control plane) plus, optionally, an RCCL communicator owned by
+    libvambhip (data plane)."""
+
+    def __init__(self, dist, group=None, rccl: bool = True):
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.handle = None
+        self._lib = None
+        if rccl:
+            self._lib = _lib.load()
+            ident = (ctypes.c_ubyte * 128)()
+            if self.rank == 0:
+                _lib.check(self._lib.vh_comm_unique_id(ident))
+            payload = [bytes(ident)]
+            dist.broadcast_object_list(payload, src=0, group=group)
+            ident = (ctypes.c_ubyte * 128).from_buffer_copy(payload[0])
+            h = ctypes.c_void_p()
+            _lib.check(self._lib.vh_comm_create(self.rank, self.world, ident, ctypes.byref(h)))
+            self.handle = h
+
+    @classmethod
+    def from_torch_distributed(cls, dist, group=None, rccl: bool = True) -> "Communicator":
+        return cls(dist, group, rccl)
+
+    def close(self):
+        if self.handle is not None and self._lib is not None:
+            self._lib.vh_comm_destroy(self.handle)
+            self.handle = None
+
+    # ---- control-plane helpers (numpy in, numpy out) ------------------------------------------
+    def _tensor(self, a: _np.ndarray):
+        import torch
+
+        return torch.from_numpy(a)
+
+    def all_reduce_sum(self, a: _np.ndarray) -> _np.ndarray:
+        a = _np.ascontiguousarray(a).copy()
+        self.dist.all_reduce(self._tensor(a), op=self.dist.ReduceOp.SUM, group=self.group)
+        return a
+
+    def all_reduce_min(self, a: _np.ndarray) -> _np.ndarray:
+        a = _np.ascontiguousarray(a).copy()
+        self.dist.all_reduce(self._tensor(a), op=self.dist.ReduceOp.MIN, group=self.group)
+        return a
+
+    def all_gather_arrays(self, a: _np.ndarray) -> list:
+        """Variable-length gather of 1-d / 2-d arrays (same dtype and trailing shape on every rank)."""
+        out = [None] * self.world
+        self.dist.all_gather_object(out, _np.ascontiguousarray(a), group=self.group)
+        return out
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+# -------------------------------------------------------------------------------------------------
+# training: per-epoch plan of a data-parallel epoch
+# -------------------------------------------------------------------------------------------------
+def plan_epoch(comm: Communicator, n_local: int, global_batch: int, weights_local: _np.ndarray, perm: _np.ndarray):
+    """Split one epoch over the ranks.
+
+    perm is this rank's permutation of its LOCAL rows.  Returns (rows, n_batches, local_batch,
+    global_wsum): rows = perm truncated to n_batches*local_batch, n_batches = the minimum over ranks
+    of full local batches (every rank must run the same number of collective steps), and
+    global_wsum[b] = sum over ALL ranks of the weights of batch b (the loss normaliser).
+    """
+    if global_batch % comm.world != 0:
+        raise ValueError(f"global batch {global_batch} is not divisible by the number of GPUs {comm.world}")
+    local_batch = global_batch // comm.world
+    if local_batch < 2:
+        raise ValueError("every GPU needs at least 2 rows per step (BatchNorm)")
+    if n_local < local_batch:
+        raise ValueError(f"shard of {n_local} rows is smaller than the per-GPU batch {local_batch}")
+    n_batches = int(comm.all_reduce_min(_np.array([n_local // local_batch], dtype=_np.int64))[0])
+    rows = _np.ascontiguousarray(perm[: n_batches * local_batch], dtype=_np.int64)
+    w = _np.asarray(weights_local, dtype=_np.float64).reshape(-1)
+    local_wsum = w[rows].reshape(n_batches, local_batch).sum(axis=1)
+    global_wsum = comm.all_reduce_sum(local_wsum).astype(_np.float32)
+    return rows, n_batches, local_batch, global_wsum
+
+
+# -------------------------------------------------------------------------------------------------
+# clustering: the scan backend over row shards
+# -------------------------------------------------------------------------------------------------
+class ShardedScanBackend:
+    """Scan backend for ``ClusterGenerator`` whose matrix is row-sharded over the ranks of ``comm``.
+
+    Rank r holds the contiguous global rows [offset[r], offset[r+1]).  Every rank runs the same host
+    logic (same RNG seed) and calls the same methods in the same order; each call is
+      local device pass  +  one small reduction / gather on the control plane.
+    Integer accumulators make the reduced results independent of the number of shards: the cluster
+    stream is bit-identical to the single-GPU one.
+    """
+
+    def __init__(self, comm: Communicator, local_backend):
+        self.comm = comm
+        self.local = local_backend
+        self.L = local_backend.L
+        self._refresh_offsets()
+        self.scan_passes = 0
+        self.scan_medoids = 0
+        self.rows_streamed = 0
+        self.kernel_ms = 0.0
+
+    def _refresh_offsets(self):
+        counts = _np.zeros(self.comm.world, dtype=_np.int64)
+        counts[self.comm.rank] = self.local.n_rows
+        counts = self.comm.all_reduce_sum(counts)
+        self.offsets = _np.concatenate([[0], _np.cumsum(counts)])
+        self.n_rows = int(self.offsets[-1])
+
+    def _owner_local(self, rows):
+        """global rows -> (local row or -1 per entry) for this rank"""
+        rows = _np.asarray(rows, dtype=_np.int64)
+        lo, hi = self.offsets[self.comm.rank], self.offsets[self.comm.rank + 1]
+        mine = (rows >= lo) & (rows < hi)
+        return _np.where(mine, rows - lo, -1), mine
+
+    def _queries(self, rows):
+        """[k, L] query vectors of global rows: owners contribute their rows, the rest zeros; a sum
+        all-reduce distributes them exactly (x + 0 == x)."""
+        local_rows, mine = self._owner_local(rows)
+        q = _np.zeros((len(local_rows), self.L), dtype=_np.float32)
+        if mine.any():
+            q[mine] = self.local.get_rows(local_rows[mine])
+        return self.comm.all_reduce_sum(q), local_rows
+
+    def scan(self, medoids):
+        out = []
+        for lo in range(0, len(medoids), _MAX_MEDOIDS_PER_PASS):
+            chunk = medoids[lo:lo + _MAX_MEDOIDS_PER_PASS]
+            q, local_rows = self._queries(chunk)
+            raw = self.local.scan_raw(local_rows, q)          # int64 [k, 63]
+            raw = self.comm.all_reduce_sum(raw)
+            self.scan_passes += 1
+            self.scan_medoids += len(chunk)
+            self.rows_streamed += self.local.n_rows
+            for j in range(len(chunk)):
+                out.append(ScanStats(int(raw[j, 0]), int(raw[j, 61]), int(raw[j, 62]), raw[j, 1:61].copy()))
+        return out
+
+    def select(self, medoid: int, threshold: float, remove: bool) -> _np.ndarray:
+        q, local_rows = self._queries([medoid])
+        rows = self.local.select_query(int(local_rows[0]), q[0], threshold, remove)
+        self.scan_passes += 1
+        self.rows_streamed += self.local.n_rows
+        parts = self.comm.all_gather_arrays(rows + self.offsets[self.comm.rank])
+        return _np.concatenate(parts).astype(_np.int64)
+
+    def remove(self, rows):
+        local_rows, mine = self._owner_local(rows)
+        if mine.any():
+            self.local.remove(local_rows[mine])
+
+    def pack(self) -> int:
+        self.local.pack()
+        self._refresh_offsets()
+        return self.n_rows
+
+    def matrix(self) -> _np.ndarray:
+        return _np.concatenate(self.comm.all_gather_arrays(self.local.matrix()), axis=0)
+
+    def set_timing(self, on: bool):
+        if hasattr(self.local, "set_timing"):
+            self.local.set_timing(on)
+
+    def close(self):
+        if hasattr(self.local, "close"):
+            self.local.close()
+
+
+def sharded_cluster_generator(comm: Communicator, local_matrix: _np.ndarray, local_lengths: _np.ndarray,
+                              maxsteps: int = 25, windowsize: int = 300, minsuccesses: int = 15,
+                              destroy: bool = False, normalized: bool = False, rng_seed: int = 0,
+                              _local_backend_factory=None):
+    """``ClusterGenerator`` over a row-sharded latent matrix.  Every rank passes its own shard (rank
+    order == global row order) and iterates the returned generator in lock step; all ranks receive the
+    same stream of clusters with GLOBAL row indices."""
+    from .cluster import ClusterGenerator, HipScanBackend
+
+    local_matrix = _np.ascontiguousarray(local_matrix)
+    if local_matrix.dtype != _np.float32:
+        raise ValueError("Matrix must be of dtype float32")
+    if len(local_lengths) != len(local_matrix):
+        raise ValueError("N sequences in lengths and matrix do not match")
+    lengths_global = _np.concatenate(comm.all_gather_arrays(_np.asarray(local_lengths)))
+    lf = _np.ascontiguousarray(local_lengths, dtype=_np.float32)
+    factory = HipScanBackend if _local_backend_factory is None else _local_backend_factory
+    out = local_matrix if (destroy and not normalized) else None
+    local = factory(local_matrix, lf, normalized, out)
+    backend = ShardedScanBackend(comm, local)
+    return ClusterGenerator.from_backend(backend, lengths_global, maxsteps=maxsteps, windowsize=windowsize,
+                                         minsuccesses=minsuccesses, rng_seed=rng_seed)
