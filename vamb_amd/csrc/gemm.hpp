@@ -51,7 +51,8 @@ struct GemmArgs {
     int ld_stat;
     float drop_scale;     // 1/(1-p); p == 0 disables dropout
     uint32_t drop_thresh; // keep iff hash32 >= drop_thresh  (p * 2^32)
-    uint64_t drop_key;    // seed ^ step ^ layer
+    uint64_t drop_key;    // seed ^ layer (^ step, read from *step_ptr so that a captured graph stays valid)
+    const unsigned long long* step_ptr;  // device-resident global step counter (may be nullptr)
     const uint8_t* drop_mask;  // injected keep-mask [m_real][ld_mask] (parity mode) or nullptr
     int64_t ld_mask;
 };
@@ -66,21 +67,26 @@ __host__ __device__ __forceinline__ uint32_t hash32(uint64_t key, uint64_t idx) 
     return (uint32_t)(z >> 32);
 }
 
-__device__ __forceinline__ bool dropout_keep(const GemmArgs& g, int row, int col) {
-    if (g.drop_mask) return g.drop_mask[(int64_t)row * g.ld_mask + col] != 0;
-    return hash32(g.drop_key, (uint64_t)row * (uint64_t)g.N + (uint64_t)col) >= g.drop_thresh;
+__device__ __forceinline__ uint64_t step_key(uint64_t base, const unsigned long long* step_ptr) {
+    return step_ptr ? (base ^ ((uint64_t)(*step_ptr) << 8)) : base;
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
-    constexpr int BK = 32;
+__device__ __forceinline__ bool dropout_keep(const GemmArgs& g, uint64_t key, int row, int col) {
+    if (g.drop_mask) return g.drop_mask[(int64_t)row * g.ld_mask + col] != 0;
+    return hash32(key, (uint64_t)row * (uint64_t)g.N + (uint64_t)col) >= g.drop_thresh;
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, int BK = 32>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g) {
+    constexpr int NT = WM * WN * 64;       // threads per workgroup (1 wavefront per 32x32-tile group)
     constexpr int SA = BM + (A_KC ? 1 : 4);
     constexpr int SB = BN + (B_KC ? 1 : 4);
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
-    constexpr int UA = BM * 8 / 256;  // float4 units per thread per tile
-    constexpr int UB = BN * 8 / 256;
-    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    constexpr int KQ = BK / 4;             // float4 units along K of a K-contiguous operand row
+    constexpr int UA = BM * KQ / NT;       // float4 units per thread per tile
+    constexpr int UB = BN * KQ / NT;
+    static_assert(WM * WN == 4 || WM * WN == 1, "4 wavefronts per workgroup, or a single free-running one");
     static_assert(TM >= 1 && TN >= 1 && UA >= 1 && UB >= 1, "tile too small");
 
     extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
@@ -110,9 +116,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     auto gload = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < UA; ++r) {
-            const int u = tid + 256 * r;
+            const int u = tid + NT * r;
             if constexpr (A_KC) {
-                const int row = u >> 3, kq = u & 7, gm = m0 + row;
+                const int row = u / KQ, kq = u % KQ, gm = m0 + row;
                 ra[r] = zero4;
                 if (gm < g.M) ra[r] = *reinterpret_cast<const float4*>(g.A + (int64_t)gm * g.lda + k0 + 4 * kq);
             } else {
@@ -123,9 +129,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int r = 0; r < UB; ++r) {
-            const int u = tid + 256 * r;
+            const int u = tid + NT * r;
             if constexpr (B_KC) {
-                const int row = u >> 3, kq = u & 7, gn = n0 + row;
+                const int row = u / KQ, kq = u % KQ, gn = n0 + row;
                 rb[r] = zero4;
                 if (gn < g.N) rb[r] = *reinterpret_cast<const float4*>(g.B + (int64_t)gn * g.ldb + k0 + 4 * kq);
             } else {
@@ -141,9 +147,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         float* bs = Bs + buf * BK * SB;
 #pragma unroll
         for (int r = 0; r < UA; ++r) {
-            const int u = tid + 256 * r;
+            const int u = tid + NT * r;
             if constexpr (A_KC) {
-                const int row = u >> 3, kq = u & 7;
+                const int row = u / KQ, kq = u % KQ;
                 as[(4 * kq + 0) * SA + row] = ra[r].x;
                 as[(4 * kq + 1) * SA + row] = ra[r].y;
                 as[(4 * kq + 2) * SA + row] = ra[r].z;
@@ -155,9 +161,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int r = 0; r < UB; ++r) {
-            const int u = tid + 256 * r;
+            const int u = tid + NT * r;
             if constexpr (B_KC) {
-                const int row = u >> 3, kq = u & 7;
+                const int row = u / KQ, kq = u % KQ;
                 bs[(4 * kq + 0) * SB + row] = rb[r].x;
                 bs[(4 * kq + 1) * SB + row] = rb[r].y;
                 bs[(4 * kq + 2) * SB + row] = rb[r].z;
@@ -182,18 +188,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         if (c + 1 < nchunks) gload(kbeg + (c + 1) * BK);
         const float* as = As + buf * BK * SA + (wm * TM * 32 + frag_r);
         const float* bs = Bs + buf * BK * SB + (wn * TN * 32 + frag_r);
+        // all fragments of this K-tile first (ds_read_b32 burst), then an uninterrupted MFMA chain
+        float af[BK / 2][TM], bf[BK / 2][TN];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[(kk + frag_k) * SA + i * 32];
+            for (int i = 0; i < TM; ++i) af[kk / 2][i] = as[(kk + frag_k) * SA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[(kk + frag_k) * SB + j * 32];
+            for (int j = 0; j < TN; ++j) bf[kk / 2][j] = bs[(kk + frag_k) * SB + j * 32];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk / 2][i], bf[kk / 2][j], acc[i][j], 0, 0, 0);
         }
         if (c + 1 < nchunks) sstore(buf ^ 1);
         __syncthreads();
@@ -209,6 +219,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     float s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    uint64_t drop_key = 0;
+    if constexpr (EPI == EPI_HIDDEN_TRAIN) drop_key = step_key(g.drop_key, g.step_ptr);
 
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
                     v += bias;
                     v = v > 0.f ? v : 0.01f * v;
                     if (g.drop_scale != 1.0f || g.drop_mask) {
-                        const bool keep = (row < g.m_real) && dropout_keep(g, row, col);
+                        const bool keep = (row < g.m_real) && dropout_keep(g, drop_key, row, col);
                         v = keep ? v * g.drop_scale : 0.f;
                     }
                     if (row < g.m_real) { s1[j] += v; s2[j] += v * v; }
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
             }
         }
         __syncthreads();
-        for (int t = tid; t < 2 * BN; t += 256) {
+        for (int t = tid; t < 2 * BN; t += NT) {
             const int stat = t / BN, cb = t % BN;
             float s = 0.f;
 #pragma unroll
@@ -276,9 +288,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, bool A_KC, bool B_KC, int BK = 32>
 constexpr size_t gemm_smem_bytes() {
-    return sizeof(float) * 2 * 32 * ((BM + (A_KC ? 1 : 4)) + (BN + (B_KC ? 1 : 4)));
+    return sizeof(float) * 2 * BK * ((BM + (A_KC ? 1 : 4)) + (BN + (B_KC ? 1 : 4)));
 }
 
 }  // namespace vh

@@ -49,24 +49,24 @@ struct Tensor {
 struct Hidden {
     int nin = 0, nout = 0, nin_p = 0, nout_p = 0;
     int tW = -1, tb = -1, tG = -1, tB = -1, tRM = -1, tRV = -1;
-    DevBuf<float> H, A;                 // post-dropout activations, post-BN activations
+    DevBuf<float> H, A, DZ;             // post-dropout activations, post-BN activations, grad wrt pre-activation
     DevBuf<float> mean, invstd, scale, shift;
     DevBuf<uint8_t> mask;               // injected dropout keep-mask (parity mode)
     long long batches_tracked = 0;
 };
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI>
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, int BK = 32>
 void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
     static bool attr_set = false;
-    constexpr size_t smem = gemm_smem_bytes<BM, BN, AKC, BKC>();
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AKC, BKC, EPI>;
+    constexpr size_t smem = gemm_smem_bytes<BM, BN, AKC, BKC, BK>();
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AKC, BKC, EPI, BK>;
     if (!attr_set) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)smem));
         attr_set = true;
     }
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, g);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g);
     VH_HIP(hipGetLastError());
 }
 
@@ -77,6 +77,8 @@ void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
         case 0: launch_gemm<64, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
         case 1: launch_gemm<128, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
         case 3: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
+        case 4: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, 64>(s, g, splits); break;   // BK = 64: half the barriers
+        case 5: launch_gemm<32, 32, 1, 1, AKC, BKC, EPI>(s, g, splits); break;       // one free-running wave per tile
         default: launch_gemm<128, 32, 4, 1, AKC, BKC, EPI>(s, g, splits); break;
     }
 }
@@ -84,7 +86,7 @@ void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
 // measured on MI355X (profiles/r01_diag_gemm_tiles.json): the 64x64 tile (2 workgroups per CU) wins or ties
 // for every fp32 shape of the 512-wide network; skinny outputs use 128x32.
 int fwd_tile(int N) { return N <= 32 ? 2 : 3; }
-int stat_rows_per_block(int tile) { return (tile == 0 || tile == 3) ? 64 : 128; }
+int stat_rows_per_block(int tile) { return tile == 5 ? 32 : ((tile == 0 || tile == 3 || tile == 4) ? 64 : 128); }
 
 GemmArgs base_args() {
     GemmArgs g;
@@ -101,6 +103,10 @@ struct vh_vae {
     int S = 0, D = 0, D_p = 0, L = 0, L_p = 0;
     float ce_w = 0, ab_w = 0, sse_w = 0, kld_w = 0;
     hipStream_t stream = nullptr;
+    // weight-gradient GEMMs are off the critical path of backward (only the optimiser needs them): they
+    // run on a second stream, forked after each layer's dZ is ready and joined before the update
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     std::vector<Tensor> tensors;
     std::map<std::string, int> tindex;
@@ -116,20 +122,31 @@ struct vh_vae {
 
     // per-batch workspaces
     int bs = 0, bs_p = 0;
-    DevBuf<float> Xb, Wb, MU, Z, EPS, R, dR, dMUk, DA, DZ, wsum, stat_part, bwd_part, S12, loss_part, slabs, out_sm, skinny;
+    DevBuf<float> Xb, Wb, MU, Z, EPS, R, dR, dMUk, DA, dMU, stat_part, bwd_part, S12, loss_part, slabs, out_sm, skinny;
     DevBuf<TensorDesc> descs;
     DevBuf<int> blk_tensor, blk_local;
     DevBuf<double> opt_part;
     DevBuf<StepState> state;
     int opt_blocks = 0;
     int loss_blocks = 0;
-    uint64_t step_counter = 0;
+
+    // the whole optimisation step as one replayable hipGraph (everything that changes from step to
+    // step -- batch index, RNG step, d, wsum -- lives in device memory)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_bs = -1;
+    bool graph_dp = false;
+    const int64_t* graph_idx = nullptr;
+    const float* graph_gwsum = nullptr;
+    int graph_global_bs = 0;
+    bool use_graph = true;
+    bool warmed_up = false;   // one eager step has run (kernel attributes set, workspaces touched)
 
     // data parallelism (one process per GPU; gradients all-reduced over RCCL on `stream`)
     vh_comm* comm = nullptr;
     DevBuf<float> G, gwsum;          // flat gradient buffer; per-batch global weight sums
     DevBuf<TensorDesc> descs_flat;   // descriptors that read G instead of the slabs
-    const float* wsum_src = nullptr; // weight sum used by the loss of the current step
+    const float* gwsum_src = nullptr; // per-batch all-rank weight sums of the running epoch (or nullptr)
     int global_bs = 0;               // rows of the all-rank batch (== bs without a communicator)
 
     // probe
@@ -141,9 +158,21 @@ struct vh_vae {
     int64_t probe_launches = 0;
     double probe_flops = 0.0;
 
+    void drop_graph() {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        graph_exec = nullptr;
+        graph = nullptr;
+        graph_bs = -1;
+    }
+
     ~vh_vae() {
+        drop_graph();
         for (auto e : ev_a) (void)hipEventDestroy(e);
         for (auto e : ev_b) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -232,6 +261,7 @@ int dw_tile(int M, int N) {
 void prepare_batch(vh_vae* h, int bs) {
     if (bs == h->bs) return;
     VH_HIP(hipStreamSynchronize(h->stream));
+    h->drop_graph();
     const int bs_p = (int)round_up(bs, kRowPad);
     h->bs = bs;
     h->bs_p = bs_p;
@@ -246,8 +276,7 @@ void prepare_batch(vh_vae* h, int bs) {
     h->dR.ensure((size_t)bs_p * h->D_p);
     h->dMUk.ensure((size_t)bs_p * h->L_p);
     h->DA.ensure((size_t)bs_p * maxw);
-    h->DZ.ensure((size_t)bs_p * maxw);
-    h->wsum.ensure(4);
+    h->dMU.ensure((size_t)bs_p * h->L_p);
     h->stat_part.ensure((size_t)(bs_p / 64) * 2 * maxw);
     const int nrb = bs_p / kRB;
     h->bwd_part.ensure((size_t)nrb * 2 * maxw);
@@ -259,6 +288,7 @@ void prepare_batch(vh_vae* h, int bs) {
     for (auto& hl : h->hidden) {
         hl.H.ensure((size_t)bs_p * hl.nout_p);
         hl.A.ensure((size_t)bs_p * hl.nout_p);
+        hl.DZ.ensure((size_t)bs_p * hl.nout_p);
     }
     // gradient slabs: weights get split-K slabs, biases row-block partials, BN affine a single slab
     size_t total = 0;
@@ -335,8 +365,10 @@ DropCfg drop_cfg(vh_vae* h, bool training, bool injected) {
 
 uint64_t layer_key(vh_vae* h, int layer) {
     const uint64_t rank = h->comm ? (uint64_t)h->comm->rank : 0ull;
-    return (h->cfg.seed * 0xD1342543DE82EF95ull) ^ (h->step_counter << 8) ^ (uint64_t)layer ^ (rank << 52);
+    return (h->cfg.seed * 0xD1342543DE82EF95ull) ^ (uint64_t)layer ^ (rank << 52);
 }
+
+const unsigned long long* step_ptr(vh_vae* h) { return &h->state.p->step; }
 
 void upload_masks(vh_vae* h, const uint8_t* masks, int bs) {
     size_t off = 0;
@@ -396,6 +428,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
             g.C = hl.H.p; g.ldc = hl.nout_p;
             g.stat_partial = h->stat_part.p; g.ld_stat = hl.nout_p;
             g.drop_scale = dc.scale; g.drop_thresh = dc.thresh; g.drop_key = layer_key(h, li);
+            g.step_ptr = step_ptr(h);
             g.drop_mask = dc.injected ? hl.mask.p : nullptr; g.ld_mask = hl.nout_p;
             if (probed) { probe_record(h, true); h->probe_flops = 2.0 * bs * (double)hl.nin * hl.nout; }
             gemm_tile<true, true, EPI_HIDDEN_TRAIN>(s, tile, g, 1);
@@ -405,7 +438,6 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
                                h->stat_part.p, nb, hl.nout_p, hl.nout_p, bs, h->pptr(hl.tG), h->pptr(hl.tB),
                                h->pptr(hl.tRM), h->pptr(hl.tRV), hl.mean.p, hl.invstd.p, hl.scale.p, hl.shift.p);
             VH_HIP(hipGetLastError());
-            hl.batches_tracked++;
             const int64_t total4 = (int64_t)bs_p * hl.nout_p / 4;
             hipLaunchKernelGGL(vae_bn_apply_kernel, dim3((unsigned)std::min<int64_t>(2048, ceil_div(total4, 256))),
                                dim3(256), 0, s, hl.H.p, hl.A.p, total4, hl.nout_p, hl.scale.p, hl.shift.p);
@@ -438,19 +470,12 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
         g.slab_stride = (int64_t)bs_p * h->L_p;
         gemm_tile<true, true, EPI_SPLITK>(s, fwd_tile(h->L_p), g, mu_slabs);
     }
-    {   // latent = mu + eps  (encode.py:276-286; sigma == 1)
+    {   // latent = mu + eps  (encode.py:276-286; sigma == 1); eps injected (parity) or generated in place
         const int64_t tot = (int64_t)bs_p * h->L_p;
-        if (!eps_injected) {
-            if (add_noise)
-                hipLaunchKernelGGL(vae_randn_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s, h->EPS.p, bs,
-                                   h->L, h->L_p, bs_p, layer_key(h, 0xEE));
-            else
-                VH_HIP(hipMemsetAsync(h->EPS.p, 0, sizeof(float) * tot, s));
-            VH_HIP(hipGetLastError());
-        }
         hipLaunchKernelGGL(vae_reparam_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s, h->skinny.p,
-                           mu_slabs, (int64_t)bs_p * h->L_p, h->pptr(h->tbmu), h->EPS.p, h->MU.p, h->Z.p, bs, h->L,
-                           h->L_p, bs_p);
+                           mu_slabs, (int64_t)bs_p * h->L_p, h->pptr(h->tbmu), eps_injected ? h->EPS.p : nullptr,
+                           layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z.p, bs, h->L, h->L_p,
+                           bs_p);
         VH_HIP(hipGetLastError());
     }
     in = h->Z.p;
@@ -469,29 +494,32 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
 
 void loss_and_seed(vh_vae* h) {
     hipStream_t s = h->stream;
-    const float* wsum = h->wsum_src;
-    if (!wsum) {   // single GPU: sum of this batch's weights
-        hipLaunchKernelGGL(vae_sum_kernel, dim3(1), dim3(256), 0, s, h->Wb.p, h->bs, h->wsum.p);
-        VH_HIP(hipGetLastError());
-        wsum = h->wsum.p;
-    }
     const int bs_global = h->global_bs > 0 ? h->global_bs : h->bs;
     LossArgs a;
     a.R = h->R.p; a.X = h->Xb.p; a.ld = h->D_p;
     a.MU = h->MU.p; a.ldl = h->L_p;
-    a.wsum = wsum;
     a.inv_b2 = (float)(1.0 / ((double)bs_global * (double)bs_global));
     a.bs = h->bs; a.bs_p = h->bs_p; a.S = h->S; a.L = h->L;
     a.ce_w = h->ce_w; a.ab_w = h->ab_w; a.sse_w = h->sse_w; a.kld_w = h->kld_w;
     a.dR = h->dR.p; a.dMUk = h->dMUk.p; a.part = h->loss_part.p;
     hipLaunchKernelGGL(vae_loss_kernel, dim3(h->loss_blocks), dim3(256), 0, s, a);
     VH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, h->loss_part.p, h->loss_blocks, wsum,
-                       bs_global, h->state.p);
+    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, h->loss_part.p, h->loss_blocks, h->Wb.p,
+                       h->bs, h->gwsum_src, bs_global, h->state.p);
     VH_HIP(hipGetLastError());
 }
 
-// dW slabs = dZ^T * In  (both operands row-contiguous along the batch)
+// dW slabs = dZ^T * In  (both operands row-contiguous along the batch).  Runs on the side stream once the
+// main stream has produced dZ (fork event), concurrently with the rest of the backward chain.
+void fork_side(vh_vae* h) {
+    VH_HIP(hipEventRecord(h->ev_fork, h->stream));
+    VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+}
+void join_side(vh_vae* h) {
+    VH_HIP(hipEventRecord(h->ev_join, h->side));
+    VH_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+}
+
 void grad_weight(vh_vae* h, int tW, const float* dZ, int out_p, const float* In, int in_p) {
     Tensor& t = h->tensors[tW];
     const int tile = dw_tile(out_p, in_p);
@@ -505,8 +533,8 @@ void grad_weight(vh_vae* h, int tW, const float* dZ, int out_p, const float* In,
     const int splits = (int)ceil_div(h->bs_p, g.k_per_split);
     if (splits < t.nslab)  // unused slabs must read as zero
         VH_HIP(hipMemsetAsync(t.slab + (int64_t)splits * t.stride, 0, sizeof(float) * (t.nslab - splits) * t.stride,
-                              h->stream));
-    gemm_tile<false, false, EPI_SPLITK>(h->stream, tile, g, splits);
+                              h->side));
+    gemm_tile<false, false, EPI_SPLITK>(h->side, tile, g, splits);
 }
 
 // dIn = dZ * W   (dZ K-contiguous over the layer's outputs, W row-contiguous [out][in]).
@@ -536,12 +564,13 @@ void backward(vh_vae* h, bool masks_injected) {
     hipStream_t s = h->stream;
     const int bs = h->bs, bs_p = h->bs_p, nrb = bs_p / kRB;
     const DropCfg dc = drop_cfg(h, true, masks_injected);
-    // output layer
+    // output layer: dR is ready (loss kernel) -> weight / bias gradients on the side stream
     {
         Hidden& last = h->hidden[2 * h->nl - 1];
+        fork_side(h);
         grad_weight(h, h->tWo, h->dR.p, h->D_p, last.A.p, last.nout_p);
-        hipLaunchKernelGGL(vae_colsum_partial_kernel, dim3((unsigned)ceil_div(h->D_p, kCT), nrb), dim3(kCT, kRL), 0, s,
-                           h->dR.p, (int64_t)h->D_p, h->D_p, bs_p, h->tensors[h->tbo].slab);
+        hipLaunchKernelGGL(vae_colsum_partial_kernel, dim3((unsigned)ceil_div(h->D_p, kCT), nrb), dim3(kCT, kRL), 0,
+                           h->side, h->dR.p, (int64_t)h->D_p, h->D_p, bs_p, h->tensors[h->tbo].slab);
         VH_HIP(hipGetLastError());
         grad_input(h, h->dR.p, h->D_p, h->tWo, last.nout_p, h->DA.p);
     }
@@ -557,17 +586,19 @@ void backward(vh_vae* h, bool masks_injected) {
                            h->bwd_part.p, nrb, hl.nout_p, h->S12.p, h->tensors[hl.tG].slab, h->tensors[hl.tB].slab);
         VH_HIP(hipGetLastError());
         BnBwdArgs a;
-        a.DA = h->DA.p; a.H = hl.H.p; a.DZ = h->DZ.p;
+        a.DA = h->DA.p; a.H = hl.H.p; a.DZ = hl.DZ.p;
         a.n_p = hl.nout_p; a.bs = bs; a.bs_p = bs_p;
         a.mean = hl.mean.p; a.invstd = hl.invstd.p; a.gamma = h->pptr(hl.tG); a.S12 = h->S12.p;
         a.drop_scale = dc.scale; a.drop_thresh = dc.thresh; a.drop_key = layer_key(h, li);
+        a.step_ptr = step_ptr(h);
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
         a.dbias_part = h->tensors[hl.tb].slab;
         hipLaunchKernelGGL(vae_bn_bwd_apply_kernel, grid, block, 0, s, a);
         VH_HIP(hipGetLastError());
-        grad_weight(h, hl.tW, h->DZ.p, hl.nout_p, In, in_p);
+        fork_side(h);
+        grad_weight(h, hl.tW, hl.DZ.p, hl.nout_p, In, in_p);
         if (need_dinput) {
-            const int n = grad_input(h, h->DZ.p, hl.nout_p, hl.tW, in_p, h->DA.p, li == h->nl);
+            const int n = grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, h->DA.p, li == h->nl);
             if (li == h->nl) latent_slabs = n;
         }
     };
@@ -582,17 +613,19 @@ void backward(vh_vae* h, bool masks_injected) {
         // latent_slabs == 1: the first decoder layer wrote dZlat into DA; otherwise split-K slabs in skinny
         const float* src = latent_slabs == 1 ? h->DA.p : h->skinny.p;
         hipLaunchKernelGGL(vae_latent_bwd_kernel, dim3((unsigned)ceil_div(h->L_p, kCT), nrb), dim3(kCT, kRL), 0, s, src,
-                           latent_slabs, (int64_t)bs_p * h->L_p, h->dMUk.p, h->DZ.p, h->L_p, bs, bs_p,
+                           latent_slabs, (int64_t)bs_p * h->L_p, h->dMUk.p, h->dMU.p, h->L_p, bs, bs_p,
                            h->tensors[h->tbmu].slab);
         VH_HIP(hipGetLastError());
-        grad_weight(h, h->tWmu, h->DZ.p, h->L_p, enc_last.A.p, enc_last.nout_p);
-        grad_input(h, h->DZ.p, h->L_p, h->tWmu, enc_last.nout_p, h->DA.p);
+        fork_side(h);
+        grad_weight(h, h->tWmu, h->dMU.p, h->L_p, enc_last.A.p, enc_last.nout_p);
+        grad_input(h, h->dMU.p, h->L_p, h->tWmu, enc_last.nout_p, h->DA.p);
     }
     for (int li = h->nl - 1; li >= 0; --li) {
         const float* In = li == 0 ? h->Xb.p : h->hidden[li - 1].A.p;
         const int in_p = li == 0 ? h->D_p : h->hidden[li - 1].nout_p;
         hidden_bwd(li, In, in_p, li > 0);  // the input gradient of layer 0 is never needed
     }
+    join_side(h);  // every weight gradient is complete before the optimiser reads the slabs
 }
 
 void optimizer_step(vh_vae* h) {
@@ -616,17 +649,74 @@ void optimizer_step(vh_vae* h) {
 
 void gather_rows(vh_vae* h, const int64_t* dev_idx) {
     hipLaunchKernelGGL(vae_gather_kernel, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, h->stream, h->X.p,
-                       (int64_t)h->D_p, h->w.p, dev_idx, h->bs, h->bs_p, h->Xb.p, h->Wb.p);
+                       (int64_t)h->D_p, h->w.p, dev_idx, &h->state.p->batch, h->bs, h->bs_p, h->Xb.p, h->Wb.p);
     VH_HIP(hipGetLastError());
 }
 
+// One optimisation step on the batch `state->batch` of the row list dev_idx.  Every launch argument
+// is identical from step to step, so the same sequence can be captured once and replayed.
 void train_step_device(vh_vae* h, const int64_t* dev_idx, bool eps_injected, bool masks_injected) {
     gather_rows(h, dev_idx);
     forward(h, true, eps_injected, masks_injected, true);
     loss_and_seed(h);
     backward(h, masks_injected);
     optimizer_step(h);
-    h->step_counter++;
+}
+
+// BatchNorm1d.num_batches_tracked: one per training-mode forward
+void count_batches(vh_vae* h, long long n) {
+    for (auto& hl : h->hidden) hl.batches_tracked += n;
+}
+
+void set_batch_index(vh_vae* h, long long b) {
+    VH_HIP(hipMemcpyAsync(&h->state.p->batch, &b, sizeof(b), hipMemcpyHostToDevice, h->stream));
+    VH_HIP(hipStreamSynchronize(h->stream));
+}
+
+// Run batches [first, n_batches) of the epoch whose row list is dev_idx.  The first step after a
+// (re)allocation runs eagerly (it sets kernel attributes and carries the optional HIP-event probe); the
+// remaining steps replay one captured graph.
+void run_epoch_steps(vh_vae* h, const int64_t* dev_idx, int64_t n_batches) {
+    const bool dp = h->comm != nullptr;
+    // hipGraph replay of the 56-launch step measured 16 % SLOWER than eager launches on MI355X / ROCm 7.2
+    // (36.3 vs 31.3 ms per C1 epoch, profiles/README.md), so it is opt-in.
+    const bool graphs = h->use_graph && getenv("VAMBHIP_GRAPH") != nullptr &&
+                        !(dp && getenv("VAMBHIP_DP_GRAPH") == nullptr);
+    count_batches(h, n_batches);
+    int64_t b = 0;
+    if (!graphs) {
+        for (; b < n_batches; ++b) train_step_device(h, dev_idx, false, false);
+        return;
+    }
+    // step 0 of every epoch is eager: warm-up for a fresh configuration and the probe's measurement point
+    train_step_device(h, dev_idx, false, false);
+    b = 1;
+    if (b >= n_batches) return;
+    if (!h->graph_exec || h->graph_bs != h->bs || h->graph_dp != dp || h->graph_idx != dev_idx ||
+        h->graph_gwsum != h->gwsum_src || h->graph_global_bs != h->global_bs) {
+        h->drop_graph();
+        const bool probe = h->probe_on;
+        h->probe_on = false;  // no event records inside the captured sequence
+        VH_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        try {
+            train_step_device(h, dev_idx, false, false);
+        } catch (...) {
+            hipGraph_t g = nullptr;
+            (void)hipStreamEndCapture(h->stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+            h->probe_on = probe;
+            throw;
+        }
+        VH_HIP(hipStreamEndCapture(h->stream, &h->graph));
+        h->probe_on = probe;
+        VH_HIP(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+        h->graph_bs = h->bs;
+        h->graph_dp = dp;
+        h->graph_idx = dev_idx;
+        h->graph_gwsum = h->gwsum_src;
+        h->graph_global_bs = h->global_bs;
+    }
+    for (; b < n_batches; ++b) VH_HIP(hipGraphLaunch(h->graph_exec, h->stream));
 }
 
 void read_state(vh_vae* h, StepState* out) {
@@ -680,6 +770,9 @@ int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
         h->sse_w = (float)(a / VH_NTNF);
         h->kld_w = (float)(1.0 / ((double)cfg->nlatent * cfg->beta));
         VH_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        VH_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        VH_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        VH_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
 
         h->hidden.resize(2 * h->nl);
         auto make_hidden = [&](int li, const std::string& lin, const std::string& norm, int nin, int nout) {
@@ -798,12 +891,14 @@ int vh_vae_get_grad(vh_vae* h, const char* name, float* data, int64_t n) {
                    (long long)n);
         std::vector<float> slab((size_t)t.nslab * t.stride);
         VH_HIP(hipMemcpyAsync(slab.data(), t.slab, sizeof(float) * slab.size(), hipMemcpyDeviceToHost, h->stream));
-        VH_HIP(hipStreamSynchronize(h->stream));
+        StepState st;
+        read_state(h, &st);
+        const float gscale = (float)st.wsum;  // the loss' sum(w) factor is applied by the optimiser kernel
         for (int r = 0; r < t.rows; ++r)
             for (int c = 0; c < t.cols; ++c) {
                 float g = 0.f;  // same slab order as the optimiser kernel
                 for (int s = 0; s < t.nslab; ++s) g += slab[(size_t)s * t.stride + (size_t)r * t.cols_p + c];
-                data[(size_t)r * t.cols + c] = g;
+                data[(size_t)r * t.cols + c] = g * gscale;
             }
     });
 }
@@ -856,7 +951,11 @@ int vh_vae_train_step(vh_vae* h, const int64_t* rows, int64_t batch, const float
         }
         if (masks && h->cfg.dropout > 0) upload_masks(h, masks, (int)batch);
         reset_epoch_sums(h);
+        set_batch_index(h, 0);
+        h->gwsum_src = nullptr;
+        h->global_bs = 0;
         train_step_device(h, h->perm.p, eps != nullptr, masks != nullptr && h->cfg.dropout > 0);
+        count_batches(h, 1);
         StepState st;
         read_state(h, &st);
         probe_collect(h);
@@ -890,13 +989,12 @@ int vh_vae_train_epoch_dp(vh_vae* h, const int64_t* perm, int64_t n_batches, int
             h->gwsum.ensure((size_t)n_batches);
             VH_HIP(hipMemcpyAsync(h->gwsum.p, global_wsum, sizeof(float) * n_batches, hipMemcpyHostToDevice, h->stream));
         }
-        h->global_bs = (int)global_batch;
+        h->global_bs = (global_wsum != nullptr) ? (int)global_batch : 0;
+        h->gwsum_src = global_wsum ? h->gwsum.p : nullptr;
         reset_epoch_sums(h);
-        for (int64_t b = 0; b < n_batches; ++b) {
-            h->wsum_src = global_wsum ? h->gwsum.p + b : nullptr;
-            train_step_device(h, h->perm.p + b * batch, false, false);
-        }
-        h->wsum_src = nullptr;
+        set_batch_index(h, 0);
+        run_epoch_steps(h, h->perm.p, n_batches);
+        h->gwsum_src = nullptr;
         h->global_bs = 0;
         if (dp) {
             // epoch log line: every rank holds local_sum / B_global, the sum over ranks is the global mean
@@ -954,7 +1052,9 @@ int vh_vae_forward(vh_vae* h, const float* depths, const float* tnf, const float
         const bool inj_masks = training && masks != nullptr && h->cfg.dropout > 0;
         if (inj_masks) upload_masks(h, masks, (int)batch);
         forward(h, training != 0, eps != nullptr, inj_masks, true);
-        h->step_counter++;
+        if (training) count_batches(h, 1);
+        hipLaunchKernelGGL(vae_advance_step_kernel, dim3(1), dim3(1), 0, h->stream, h->state.p);
+        VH_HIP(hipGetLastError());
         // outputs
         std::vector<float> r((size_t)batch * h->D_p);
         VH_HIP(hipMemcpyAsync(r.data(), h->R.p, sizeof(float) * r.size(), hipMemcpyDeviceToHost, h->stream));
@@ -1065,7 +1165,8 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
                   int N, int K, int splits, float* ms) {
     return guarded([&] {
         VH_REQUIRE(A && B && C, "NULL argument");
-        VH_REQUIRE(tile >= 0 && tile <= 3, "tile in {0,1,2,3}");
+        VH_REQUIRE(tile >= 0 && tile <= 5, "tile in {0..5}");
+        VH_REQUIRE(tile != 4 || (K % 64 == 0 && (K / std::max(1, splits)) % 64 == 0), "tile 4 needs K multiple of 64");
         VH_REQUIRE(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && M % 4 == 0 && N % 4 == 0,
                    "need K multiple of 32 and M, N multiples of 4");
         VH_REQUIRE(splits >= 1 && (K / 32) >= splits, "bad split count");

@@ -33,13 +33,16 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- batch assembly ----------------------------------------------------------------------------
 // Xb[r][:] = X[idx[r]][:], Wb[r] = w[idx[r]] for r < bs; zero rows for the padding.  blockDim (64,4).
+// idx (if given) is the epoch's row list; the batch to use is *batch_ptr (device resident, advanced by
+// the optimiser's finalize kernel, so that one captured graph serves every step of the epoch).
 __global__ void vae_gather_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ w_all,
-                                  const int64_t* __restrict__ idx, int bs, int bs_p, float* __restrict__ Xb,
-                                  float* __restrict__ Wb) {
+                                  const int64_t* __restrict__ idx, const long long* __restrict__ batch_ptr, int bs,
+                                  int bs_p, float* __restrict__ Xb, float* __restrict__ Wb) {
     const int r = blockIdx.x * 4 + threadIdx.y;
     if (r >= bs_p) return;
     const bool real = r < bs;
-    const int64_t src = real ? (idx ? idx[r] : (int64_t)r) : 0;
+    const int64_t first = batch_ptr ? (int64_t)(*batch_ptr) * bs : 0;
+    const int64_t src = real ? (idx ? idx[first + r] : (int64_t)r) : 0;
     const float4* s = reinterpret_cast<const float4*>(X + src * ldx);
     float4* d = reinterpret_cast<float4*>(Xb + (int64_t)r * ldx);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -133,24 +136,18 @@ __global__ void vae_bn_apply_kernel(const float* __restrict__ H, float* __restri
 }
 
 // ---- reparameterisation (encode.py:276-286) ------------------------------------------------------
-// standard-normal noise, Box-Muller over the counter-based hash (free-running mode)
-__global__ void vae_randn_kernel(float* __restrict__ E, int bs, int L, int L_p, int bs_p, uint64_t key) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)bs_p * L_p) return;
-    const int r = (int)(i / L_p), c = (int)(i % L_p);
-    float v = 0.f;
-    if (r < bs && c < L) {
-        const uint64_t id = (uint64_t)r * (uint64_t)L_p + (uint64_t)c;
-        const float u1 = ((float)hash32(key, 2 * id) + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
-        const float u2 = (float)hash32(key, 2 * id + 1) * 2.3283064365386963e-10f;
-        v = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
-    }
-    E[i] = v;
+// standard-normal noise: Box-Muller over the counter-based hash (free-running mode)
+__device__ __forceinline__ float hash_randn(uint64_t key, uint64_t id) {
+    const float u1 = ((float)hash32(key, 2 * id) + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
+    const float u2 = (float)hash32(key, 2 * id + 1) * 2.3283064365386963e-10f;
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
-// MU = sum of the split-K slabs + bias;  Z = MU + E on the real rows / columns, 0 on the padding
+// MU = sum of the split-K slabs + bias;  Z = MU + eps on the real rows / columns, 0 on the padding.
+// eps comes from E (injected, parity mode) or is generated in place (E == nullptr); noise == 0 disables it.
 __global__ void vae_reparam_kernel(const float* __restrict__ slabs, int nslab, int64_t stride,
-                                   const float* __restrict__ bias, const float* __restrict__ E,
+                                   const float* __restrict__ bias, const float* __restrict__ E, uint64_t key,
+                                   const unsigned long long* __restrict__ step_ptr, int noise,
                                    float* __restrict__ MU, float* __restrict__ Z, int bs, int L, int L_p, int bs_p) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)bs_p * L_p) return;
@@ -158,7 +155,14 @@ __global__ void vae_reparam_kernel(const float* __restrict__ slabs, int nslab, i
     float m = bias[c];
     for (int s = 0; s < nslab; ++s) m += slabs[(int64_t)s * stride + i];
     MU[i] = m;
-    Z[i] = (r < bs && c < L) ? m + E[i] : 0.f;
+    float z = 0.f;
+    if (r < bs && c < L) {
+        float e = 0.f;
+        if (E) e = E[i];
+        else if (noise) e = hash_randn(step_key(key, step_ptr), (uint64_t)i);
+        z = m + e;
+    }
+    Z[i] = z;
 }
 
 // ---- loss (encode.py:316-357) + backward seed ------------------------------------------------------
@@ -172,8 +176,8 @@ struct LossArgs {
     int64_t ld;
     const float* MU;     // [bs_p][ldl]
     int64_t ldl;
-    const float* wsum;   // sum of the (global) batch weights
-    float inv_b2;        // 1 / B_global^2
+    float inv_b2;        // 1 / B_global^2 ; the factor sum(w) is applied by the optimiser (gradients are
+                         // linear in it), so the backward pass does not wait for a reduction over the weights
     int bs, bs_p, S, L;
     float ce_w, ab_w, sse_w, kld_w;
     float* dR;           // [bs_p][ld]
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const LossArgs a) {
         } else {
             const float* r = a.R + (int64_t)row * a.ld;
             const float* x = a.X + (int64_t)row * a.ld;
-            const float g = a.wsum[0] * a.inv_b2;
+            const float g = a.inv_b2;
             const int S = a.S;
             // softmax over the S abundance logits
             float mx = -3.0e38f;
@@ -268,36 +272,45 @@ struct StepState {
     double d;                  // D-Adapt estimate
     double numerator_weighted;
     long long k;
+    unsigned long long step;   // global step counter (seeds dropout / noise)
+    long long batch;           // index of the current batch inside the epoch's row list
+    double wsum;               // sum of the (all-rank) batch weights of the current step
     double step_loss[5];       // loss, ab, ce, sse, kld of the last step (calc_loss order)
     double epoch_loss[5];      // running sums over the epoch's batches
     long long epoch_batches;
 };
 
-// reduce the loss partials, produce the five means (encode.py:350-356) and add them to the epoch sums
-// bs_global: rows of the whole (all-rank) batch; under data parallelism every rank adds its own share
+// reduce the loss partials, produce the five means (encode.py:350-356), add them to the epoch sums and
+// publish the batch weight sum: sum(Wb) on one GPU, gwsum[batch] (planned on the host) under data
+// parallelism.  bs_global: rows of the whole (all-rank) batch; every rank adds its own share
 // local_sum / bs_global and the epoch sums are all-reduced once per epoch.
 __global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const float* __restrict__ part, int nblocks,
-                                                                const float* __restrict__ wsum, int bs_global,
+                                                                const float* __restrict__ Wb, int bs,
+                                                                const float* __restrict__ gwsum, int bs_global,
                                                                 StepState* __restrict__ st) {
-    __shared__ double red[4][256];
-    double s[4] = {0, 0, 0, 0};
+    __shared__ double red[5][256];
+    double s[5] = {0, 0, 0, 0, 0};
     for (int b = threadIdx.x; b < nblocks; b += 256)
         for (int t = 0; t < 4; ++t) s[t] += (double)part[(int64_t)b * 4 + t];
-    for (int t = 0; t < 4; ++t) red[t][threadIdx.x] = s[t];
+    if (!gwsum)
+        for (int i = threadIdx.x; i < bs; i += 256) s[4] += (double)Wb[i];
+    for (int t = 0; t < 5; ++t) red[t][threadIdx.x] = s[t];
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if (threadIdx.x < off)
-            for (int t = 0; t < 4; ++t) red[t][threadIdx.x] += red[t][threadIdx.x + off];
+            for (int t = 0; t < 5; ++t) red[t][threadIdx.x] += red[t][threadIdx.x + off];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const double bs = (double)bs_global;
-        const double ab = red[0][0] / bs, ce = red[1][0] / bs, sse = red[2][0] / bs, kld = red[3][0] / bs;
-        const double wmean = (double)wsum[0] / bs;
+        const double bsg = (double)bs_global;
+        const double wsum = gwsum ? (double)gwsum[st->batch] : (double)(float)red[4][0];
+        const double ab = red[0][0] / bsg, ce = red[1][0] / bsg, sse = red[2][0] / bsg, kld = red[3][0] / bsg;
+        const double wmean = wsum / bsg;
         const double loss = ((ce + ab + sse) + kld) * wmean;
         const double v[5] = {loss, ab, ce, sse, kld};
         for (int t = 0; t < 5; ++t) { st->step_loss[t] = v[t]; st->epoch_loss[t] += v[t]; }
         st->epoch_batches += 1;
+        st->wsum = wsum;
     }
 }
 
@@ -412,6 +425,7 @@ struct BnBwdArgs {
     float drop_scale;
     uint32_t drop_thresh;
     uint64_t drop_key;
+    const unsigned long long* step_ptr;
     const uint8_t* drop_mask;
     int64_t ld_mask;
     float* dbias_part;  // [nrb][n_p]
@@ -427,6 +441,7 @@ __global__ __launch_bounds__(256) void vae_bn_bwd_apply_kernel(const BnBwdArgs a
         const float m = a.mean[col], is = a.invstd[col], gm = a.gamma[col];
         const float c1 = a.S12[col] / (float)a.bs, c2 = a.S12[a.n_p + col] / (float)a.bs;
         const bool use_drop = (a.drop_scale != 1.0f) || (a.drop_mask != nullptr);
+        const uint64_t key = step_key(a.drop_key, a.step_ptr);
         for (int r = r0 + threadIdx.y; r < r1; r += kRL) {
             const int64_t i = (int64_t)r * a.n_p + col;
             float dz = 0.f;
@@ -438,7 +453,7 @@ __global__ __launch_bounds__(256) void vae_bn_bwd_apply_kernel(const BnBwdArgs a
                 if (use_drop) {
                     keep = a.drop_mask
                                ? (a.drop_mask[(int64_t)r * a.ld_mask + col] != 0)
-                               : (hash32(a.drop_key, (uint64_t)r * (uint64_t)a.n_p + (uint64_t)col) >= a.drop_thresh);
+                               : (hash32(key, (uint64_t)r * (uint64_t)a.n_p + (uint64_t)col) >= a.drop_thresh);
                     dh *= a.drop_scale;
                 }
                 dz = keep ? dh * (h > 0.f ? 1.0f : kLeakySlope) : 0.f;
@@ -521,6 +536,7 @@ __global__ __launch_bounds__(256) void vae_dadapt_kernel(const TensorDesc* __res
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     const double sqrt_b2d = sqrt(0.999);
     const double dlr = st->d;  // lr == 1
+    const float gscale = (float)st->wsum;  // the loss' factor sum(w), see LossArgs::inv_b2
     const float a_m = (float)(dlr * (1.0 - 0.9));
     const float a_s = (float)(dlr * (1.0 - sqrt_b2d));
     const float sqrt_b2 = (float)sqrt_b2d;
@@ -532,6 +548,7 @@ __global__ __launch_bounds__(256) void vae_dadapt_kernel(const TensorDesc* __res
             const float4 v = *reinterpret_cast<const float4*>(td.slab + (int64_t)s * td.stride + local);
             g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
         }
+        g.x *= gscale; g.y *= gscale; g.z *= gscale; g.w *= gscale;
         const int64_t o = td.p_off + local;
         float4 p = *reinterpret_cast<float4*>(P + o), m = *reinterpret_cast<float4*>(M1 + o),
                v = *reinterpret_cast<float4*>(M2 + o), s = *reinterpret_cast<float4*>(Sv + o);
@@ -598,7 +615,12 @@ __global__ __launch_bounds__(256) void vae_dadapt_finalize_kernel(const double* 
             st->numerator_weighted = nw;
             st->k += 1;
         }
+        st->step += 1;   // next step: fresh dropout / noise streams, next batch of the epoch's row list
+        st->batch += 1;
     }
 }
+
+// forward-only calls advance the random streams too
+__global__ void vae_advance_step_kernel(StepState* __restrict__ st) { st->step += 1; }
 
 }  // namespace vh
