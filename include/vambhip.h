@@ -142,7 +142,9 @@ int vh_vae_set_dataset(vh_vae* h, const float* depths, const float* tnf, const f
 int vh_vae_train_step(vh_vae* h, const int64_t* rows, int64_t batch, const float* eps, const uint8_t* masks,
                       double losses[5]);
 /* A whole epoch (encode.py:390-437): perm holds n_batches*batch dataset rows; the five per-batch means
- * are averaged over the batches exactly like the epoch log line.  One host sync per epoch. */
+ * are averaged over the batches exactly like the epoch log line.  One host sync per epoch.
+ * perm == NULL: the library shuffles on the device (a fresh keyed bijection of [0, n) per epoch, the
+ * counterpart of the DataLoader's RandomSampler, encode.py:33-50,129-144) -- no host permutation, no upload. */
 int vh_vae_train_epoch(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, double loss_means[5]);
 
 /* VAE.forward on explicit host inputs (encode.py:306-314); training != 0 uses batch statistics,
@@ -184,7 +186,9 @@ int vh_vae_attach_comm(vh_vae* h, vh_comm* comm);
  * step is normalised by the all-rank batch (global_batch rows, global_wsum[b] = sum of the weights
  * of global batch b) so that the summed gradients equal the single-GPU gradient of the global batch
  * (BatchNorm statistics stay per-rank).  loss_means are the all-rank epoch means.
- * global_batch <= 0 / global_wsum == NULL: plain single-GPU epoch. */
+ * perm == NULL: device-side shuffle of this rank's shard; global_wsum == NULL with global_batch > batch: the
+ * per-batch weight sums are computed on the device and all-reduced over the communicator.
+ * global_batch <= 0: plain single-GPU epoch. */
 int vh_vae_train_epoch_dp(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, int64_t global_batch,
                           const float* global_wsum, double loss_means[5]);
 

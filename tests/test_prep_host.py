@@ -74,3 +74,37 @@ def test_single_sample():
     assert abs(abs(single.mean()) - 1.0) < 1e-6 and abs(single.std()) < 1e-6
     assert (torch.argsort(dl.dataset.tensors[2], dim=0, stable=True)
             == torch.argsort(torch.from_numpy(cp), dim=0, stable=True)).all().item()
+
+
+def test_device_shuffle_formula_is_a_permutation():
+    """Python mirror of vae_kernels.hpp::shuffle_index (the device-side epoch shuffle): for every n and
+    key the map restricted to [0, n) by cycle walking must be a bijection."""
+    M = (1 << 64) - 1
+
+    def rnd(x, key, mask, bits):
+        s1, s2 = (bits + 1) // 2, max((bits + 2) // 3, 1)
+        x = (x * 0x9E3779B97F4A7C15 + key) & M & mask
+        x ^= x >> s1
+        x = (x * 0xBF58476D1CE4E5B9 + (key >> 17)) & M & mask
+        x ^= x >> s2
+        x = (x * 0x94D049BB133111EB + (key >> 31)) & M & mask
+        x ^= x >> s1
+        return x
+
+    for n in (1, 2, 3, 7, 111, 1000, 4097):
+        bits = 1
+        while (1 << bits) < n:
+            bits += 1
+        mask = (1 << bits) - 1
+        for key in (1, 0x1234567890ABCDEF, 2 ** 63 + 12345):
+            out = []
+            for i in range(n):
+                x = i
+                while True:
+                    x = rnd(x, key, mask, bits)
+                    if x < n:
+                        break
+                out.append(x)
+            assert sorted(out) == list(range(n)), (n, key)
+            if n >= 1000:   # not the identity, and different keys give different orders
+                assert sum(1 for i, v in enumerate(out) if i == v) < n // 50

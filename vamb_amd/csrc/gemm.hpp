@@ -1,6 +1,6 @@
 // gemm.hpp -- fp32-input MFMA GEMM for the VAE's dense contractions (gfx950).
 //
-//   C[m][n] = sum_k A(m,k) * B(n,k)        m < M, n < N, k < K (K multiple of 32)
+//   C[m][n] = sum_k A'(m,k) * B'(n,k)        m < M, n < N, k < K (K multiple of 32)
 //
 // built on v_mfma_f32_32x32x2_f32: exact fp32 products accumulated as a k-ordered fmaf chain (the
 // guide's "SGEMM class": 64 FLOP/clk/SIMD, 157 TF/s chip peak), which is what BASELINE config C1
@@ -9,7 +9,15 @@
 // dX = dY*W reads W as [contraction n][k], dW = dY^T*X reads both operands as [contraction m][..]),
 // so no transposed copies of weights or activations are ever materialised.
 //
-// Tile: BM x BN x 32 per workgroup of 4 wavefronts (WM x WN), each wave TM x TN MFMA tiles of 32x32.
+// Operand transform (the primes above), applied in registers between the global load and the LDS store:
+//   XF_BN : a = h * scale[col] + shift[col]      BatchNorm1d (training statistics) of the producing layer
+// so the normalised activations are never written to HBM.  The per-column coefficients are derived once
+// per workgroup from the batch sums that the producing GEMM's epilogue accumulated with fp64 atomics, so
+// BatchNorm needs no finalize / apply kernels.  (Forming dZ on load as well was measured 2-3x slower per
+// GEMM -- every A tile is transformed once per column tile -- so the elementwise backward keeps its own
+// bandwidth-bound kernel, vae_dz_kernel.)
+//
+// Tile: BM x BN x BK per workgroup of WM x WN wavefronts, each wave TM x TN MFMA tiles of 32x32.
 // Global -> registers (float4, coalesced along the contiguous dimension) -> LDS [k][row] (stride
 // BM+1 for transposing ds_write_b32 of K-contiguous operands, BM+4 for ds_write_b128 of
 // row-contiguous ones; both conflict-free) -> ds_read_b32 fragments (lane l: row l&31, k l>>5).
@@ -24,13 +32,29 @@ namespace vh {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+constexpr float kBnEpsF = 1e-5f;     // torch.nn.BatchNorm1d eps (encode.py:238,246)
+constexpr float kLeakySlopeF = 0.01f;  // torch.nn.LeakyReLU default (encode.py:252)
+
 enum EpiKind : int {
     EPI_STORE = 0,         // C = acc
     EPI_BIAS = 1,          // C = acc + bias[n]
-    EPI_HIDDEN_TRAIN = 2,  // h = dropout(leaky_relu(acc + bias)); C = h; column sums of h, h^2 (encode.py:264,292)
+    EPI_HIDDEN_TRAIN = 2,  // h = dropout(leaky_relu(acc + bias)); C = h; batch sums of h, h^2 (encode.py:264,292)
     EPI_HIDDEN_EVAL = 3,   // C = leaky_relu(acc + bias) * scale[n] + shift[n]   (eval-mode BatchNorm folded)
     EPI_SPLITK = 4,        // C[blockIdx.z] = acc   (partial slabs, summed by the consumer)
-    EPI_LATENT_MASK = 5    // C = bits(acc + bias) & ~0xFFF   (encode.py:483, vambtools.py:324-330)
+    EPI_LATENT_MASK = 5,   // C = bits(acc + bias) & ~0xFFF   (encode.py:483, vambtools.py:324-330)
+    EPI_STORE_BNRED = 6    // C = acc (= dA of the layer below) + batch sums of dA and dA*xhat for its BatchNorm backward
+};
+
+enum XfKind : int { XF_NONE = 0, XF_BN = 1 };
+
+// Batch statistics of one BatchNorm1d layer as accumulated by EPI_HIDDEN_TRAIN: fstat[0][c] = sum h,
+// fstat[1][c] = sum h^2 over the bs real rows; plus its affine parameters.
+struct BnSrc {
+    const double* fstat;   // [2][n_p]
+    const float* gamma;
+    const float* beta;
+    int n_p;
+    int bs;
 };
 
 struct GemmArgs {
@@ -47,17 +71,22 @@ struct GemmArgs {
     const float* scale;
     const float* shift;
     int m_real;           // rows that belong to the batch (statistics / dropout rows)
-    float* stat_partial;  // [gridDim.y][2][ld_stat]
-    int ld_stat;
+    double* fstat_out;    // EPI_HIDDEN_TRAIN: [2][N] batch sums (fp64 atomics)
     float drop_scale;     // 1/(1-p); p == 0 disables dropout
     uint32_t drop_thresh; // keep iff hash32 >= drop_thresh  (p * 2^32)
     uint64_t drop_key;    // seed ^ layer (^ step, read from *step_ptr so that a captured graph stays valid)
     const unsigned long long* step_ptr;  // device-resident global step counter (may be nullptr)
     const uint8_t* drop_mask;  // injected keep-mask [m_real][ld_mask] (parity mode) or nullptr
     int64_t ld_mask;
+    // operand transforms
+    BnSrc bnA, bnB;       // XF_BN on A / B: statistics of the layer that produced the operand
+    // EPI_STORE_BNRED
+    const float* Hbelow;  // activations of the layer below (same shape / ld as C)
+    BnSrc bnC;            // its forward statistics
+    double* bstat_out;    // [2][N]
 };
 
-// counter-based uniform 32-bit hash (splitmix64 finaliser); also used by the backward kernels so the
+// counter-based uniform 32-bit hash (splitmix64 finaliser); also used by the backward transforms so the
 // dropout mask is regenerated instead of stored
 __host__ __device__ __forceinline__ uint32_t hash32(uint64_t key, uint64_t idx) {
     uint64_t z = key + idx * 0x9E3779B97F4A7C15ull;
@@ -71,12 +100,21 @@ __device__ __forceinline__ uint64_t step_key(uint64_t base, const unsigned long 
     return step_ptr ? (base ^ ((uint64_t)(*step_ptr) << 8)) : base;
 }
 
-__device__ __forceinline__ bool dropout_keep(const GemmArgs& g, uint64_t key, int row, int col) {
-    if (g.drop_mask) return g.drop_mask[(int64_t)row * g.ld_mask + col] != 0;
-    return hash32(key, (uint64_t)row * (uint64_t)g.N + (uint64_t)col) >= g.drop_thresh;
+// mean / 1/std / scale / shift of one BatchNorm column from the batch sums (biased variance)
+__device__ __forceinline__ void bn_column(const BnSrc& s, int col, float& mean, float& istd, float& scale,
+                                          float& shift) {
+    const double inv_bs = 1.0 / (double)s.bs;
+    const double m = s.fstat[col] * inv_bs;
+    double var = s.fstat[s.n_p + col] * inv_bs - m * m;   // fp64: E[h^2] - mean^2 cancels
+    if (var < 0.0) var = 0.0;
+    istd = 1.0f / sqrtf((float)var + kBnEpsF);
+    mean = (float)m;
+    scale = s.gamma[col] * istd;
+    shift = s.beta[col] - mean * scale;
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, int BK = 32>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE,
+          int BK = 32>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int NT = WM * WN * 64;       // threads per workgroup (1 wavefront per 32x32-tile group)
     constexpr int SA = BM + (A_KC ? 1 : 4);
@@ -92,6 +130,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
     float* As = gemm_smem;                 // [2][BK][SA]
     float* Bs = gemm_smem + 2 * BK * SA;   // [2][BK][SB]
+    float* coef = Bs + 2 * BK * SB;        // per-column coefficients of the operand transforms (see below)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -101,6 +140,46 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     const int kbeg = blockIdx.z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nchunks = (kend - kbeg) / BK;
+
+    // ---- coefficient tables in LDS ---------------------------------------------------------------
+    // The columns a transform indexes are the contraction range [kbeg, kend) for a K-contiguous operand
+    // and the workgroup's own BM (BN) rows for a row-contiguous one.
+    const int ncolA = A_KC ? (kend - kbeg) : BM;
+    const int colA0 = A_KC ? kbeg : m0;
+    const int ncolB = B_KC ? (kend - kbeg) : BN;
+    const int colB0 = B_KC ? kbeg : n0;
+    // layout: [A: XF_BN 2 arrays][B: XF_BN 2 arrays][C: BNRED 2 arrays of BN]
+    float* coefA = coef;
+    constexpr int NARR_A = XFA == XF_BN ? 2 : 0;
+    float* coefB = coefA + NARR_A * ncolA;
+    constexpr int NARR_B = XFB == XF_BN ? 2 : 0;
+    float* coefC = coefB + NARR_B * ncolB;
+    if constexpr (XFA == XF_BN) {
+        const int limit = A_KC ? g.K : g.M;
+        for (int c = tid; c < ncolA; c += NT) {
+            float mean, istd, sc = 0.f, sh = 0.f;
+            if (colA0 + c < limit) bn_column(g.bnA, colA0 + c, mean, istd, sc, sh);
+            coefA[c] = sc;
+            coefA[ncolA + c] = sh;
+        }
+    }
+    if constexpr (XFB == XF_BN) {
+        const int limit = B_KC ? g.K : g.N;
+        for (int c = tid; c < ncolB; c += NT) {
+            float mean, istd, sc = 0.f, sh = 0.f;
+            if (colB0 + c < limit) bn_column(g.bnB, colB0 + c, mean, istd, sc, sh);
+            coefB[c] = sc;
+            coefB[ncolB + c] = sh;
+        }
+    }
+    if constexpr (EPI == EPI_STORE_BNRED) {
+        for (int c = tid; c < BN; c += NT) {
+            float mean = 0.f, istd = 0.f, sc, sh;
+            if (n0 + c < g.N) bn_column(g.bnC, n0 + c, mean, istd, sc, sh);
+            coefC[c] = mean;
+            coefC[BN + c] = istd;
+        }
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -117,15 +196,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
 #pragma unroll
         for (int r = 0; r < UA; ++r) {
             const int u = tid + NT * r;
+            int64_t off;
+            bool ok;
             if constexpr (A_KC) {
                 const int row = u / KQ, kq = u % KQ, gm = m0 + row;
-                ra[r] = zero4;
-                if (gm < g.M) ra[r] = *reinterpret_cast<const float4*>(g.A + (int64_t)gm * g.lda + k0 + 4 * kq);
+                ok = gm < g.M;
+                off = (int64_t)gm * g.lda + k0 + 4 * kq;
             } else {
                 const int k = u / (BM / 4), mq = u % (BM / 4), gm = m0 + 4 * mq;
-                ra[r] = zero4;
-                if (gm < g.M) ra[r] = *reinterpret_cast<const float4*>(g.A + (int64_t)(k0 + k) * g.lda + gm);
+                ok = gm < g.M;
+                off = (int64_t)(k0 + k) * g.lda + gm;
             }
+            ra[r] = zero4;
+            if (ok) ra[r] = *reinterpret_cast<const float4*>(g.A + off);
         }
 #pragma unroll
         for (int r = 0; r < UB; ++r) {
@@ -142,43 +225,74 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
         }
     };
 
-    auto sstore = [&](int buf) {
+    // transform of the A registers of unit r of the K-tile starting at k0 (applied at LDS-store time,
+    // when the prefetched data has arrived)
+    auto xform_a = [&](int r, int k0) -> float4 {
+        float4 v = ra[r];
+        if constexpr (XFA == XF_BN) {
+            const int u = tid + NT * r;
+            int c0;   // index of the unit's first column in the coefficient table
+            if constexpr (A_KC) c0 = (k0 - kbeg) + 4 * (u % KQ);
+            else c0 = 4 * (u % (BM / 4));
+            const float4 s = *reinterpret_cast<const float4*>(coefA + c0);
+            const float4 t = *reinterpret_cast<const float4*>(coefA + ncolA + c0);
+            v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
+        }
+        return v;
+    };
+
+    auto xform_b = [&](int r, int k0) -> float4 {
+        float4 v = rb[r];
+        if constexpr (XFB == XF_BN) {
+            const int u = tid + NT * r;
+            int c0;
+            if constexpr (B_KC) c0 = (k0 - kbeg) + 4 * (u % KQ);
+            else c0 = 4 * (u % (BN / 4));
+            const float4 s = *reinterpret_cast<const float4*>(coefB + c0);
+            const float4 t = *reinterpret_cast<const float4*>(coefB + ncolB + c0);
+            v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
+        }
+        return v;
+    };
+
+    auto sstore = [&](int buf, int k0) {
         float* as = As + buf * BK * SA;
         float* bs = Bs + buf * BK * SB;
 #pragma unroll
         for (int r = 0; r < UA; ++r) {
             const int u = tid + NT * r;
+            const float4 v = xform_a(r, k0);
             if constexpr (A_KC) {
                 const int row = u / KQ, kq = u % KQ;
-                as[(4 * kq + 0) * SA + row] = ra[r].x;
-                as[(4 * kq + 1) * SA + row] = ra[r].y;
-                as[(4 * kq + 2) * SA + row] = ra[r].z;
-                as[(4 * kq + 3) * SA + row] = ra[r].w;
+                as[(4 * kq + 0) * SA + row] = v.x;
+                as[(4 * kq + 1) * SA + row] = v.y;
+                as[(4 * kq + 2) * SA + row] = v.z;
+                as[(4 * kq + 3) * SA + row] = v.w;
             } else {
                 const int k = u / (BM / 4), mq = u % (BM / 4);
-                *reinterpret_cast<float4*>(as + k * SA + 4 * mq) = ra[r];
+                *reinterpret_cast<float4*>(as + k * SA + 4 * mq) = v;
             }
         }
 #pragma unroll
         for (int r = 0; r < UB; ++r) {
             const int u = tid + NT * r;
+            const float4 v = xform_b(r, k0);
             if constexpr (B_KC) {
                 const int row = u / KQ, kq = u % KQ;
-                bs[(4 * kq + 0) * SB + row] = rb[r].x;
-                bs[(4 * kq + 1) * SB + row] = rb[r].y;
-                bs[(4 * kq + 2) * SB + row] = rb[r].z;
-                bs[(4 * kq + 3) * SB + row] = rb[r].w;
+                bs[(4 * kq + 0) * SB + row] = v.x;
+                bs[(4 * kq + 1) * SB + row] = v.y;
+                bs[(4 * kq + 2) * SB + row] = v.z;
+                bs[(4 * kq + 3) * SB + row] = v.w;
             } else {
                 const int k = u / (BN / 4), nq = u % (BN / 4);
-                *reinterpret_cast<float4*>(bs + k * SB + 4 * nq) = rb[r];
+                *reinterpret_cast<float4*>(bs + k * SB + 4 * nq) = v;
             }
         }
     };
 
-    if (nchunks > 0) {
-        gload(kbeg);
-        sstore(0);
-    }
+    if (nchunks > 0) gload(kbeg);
+    __syncthreads();   // coefficient tables are complete
+    if (nchunks > 0) sstore(0, kbeg);
     __syncthreads();
 
     const int frag_k = lane >> 5;   // which of the 2 k's of an MFMA step this lane feeds
@@ -205,7 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk / 2][i], bf[kk / 2][j], acc[i][j], 0, 0, 0);
         }
-        if (c + 1 < nchunks) sstore(buf ^ 1);
+        if (c + 1 < nchunks) sstore(buf ^ 1, kbeg + (c + 1) * BK);
         __syncthreads();
     }
 
@@ -224,14 +338,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
 
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + frag_r;
+        const int cb = (wn * TN + j) * 32 + frag_r;
+        const int col = n0 + cb;
         const bool col_ok = col < g.N;
-        float bias = 0.f, sc = 1.f, sh = 0.f;
+        float bias = 0.f, sc = 1.f, sh = 0.f, cmean = 0.f, cistd = 0.f;
         if constexpr (EPI == EPI_BIAS || EPI == EPI_HIDDEN_TRAIN || EPI == EPI_HIDDEN_EVAL || EPI == EPI_LATENT_MASK)
             bias = col_ok ? g.bias[col] : 0.f;
         if constexpr (EPI == EPI_HIDDEN_EVAL) {
             sc = col_ok ? g.scale[col] : 0.f;
             sh = col_ok ? g.shift[col] : 0.f;
+        }
+        if constexpr (EPI == EPI_STORE_BNRED) {
+            cmean = coefC[cb];
+            cistd = coefC[BN + cb];
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -244,27 +363,38 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
                     v += bias;
                 } else if constexpr (EPI == EPI_HIDDEN_TRAIN) {
                     v += bias;
-                    v = v > 0.f ? v : 0.01f * v;
+                    v = v > 0.f ? v : kLeakySlopeF * v;
                     if (g.drop_scale != 1.0f || g.drop_mask) {
-                        const bool keep = (row < g.m_real) && dropout_keep(g, drop_key, row, col);
+                        bool keep = row < g.m_real;
+                        if (keep)
+                            keep = g.drop_mask ? (g.drop_mask[(int64_t)row * g.ld_mask + col] != 0)
+                                               : (hash32(drop_key, (uint64_t)row * (uint64_t)g.N + (uint64_t)col) >=
+                                                  g.drop_thresh);
                         v = keep ? v * g.drop_scale : 0.f;
                     }
                     if (row < g.m_real) { s1[j] += v; s2[j] += v * v; }
                 } else if constexpr (EPI == EPI_HIDDEN_EVAL) {
                     v += bias;
-                    v = v > 0.f ? v : 0.01f * v;
+                    v = v > 0.f ? v : kLeakySlopeF * v;
                     v = v * sc + sh;
                 } else if constexpr (EPI == EPI_LATENT_MASK) {
                     v += bias;
                     v = __uint_as_float(__float_as_uint(v) & 0xFFFFF000u);
+                } else if constexpr (EPI == EPI_STORE_BNRED) {
+                    if (row < g.m_real) {
+                        const float xh = (g.Hbelow[(int64_t)row * g.ldc + col] - cmean) * cistd;
+                        s1[j] += v;
+                        s2[j] += v * xh;
+                    }
                 }
                 Cout[(int64_t)row * g.ldc + col] = v;
             }
         }
     }
 
-    if constexpr (EPI == EPI_HIDDEN_TRAIN) {
-        // per-column partial sums of this workgroup's BM rows -> stat_partial[blockIdx.y][{0,1}][col]
+    if constexpr (EPI == EPI_HIDDEN_TRAIN || EPI == EPI_STORE_BNRED) {
+        // per-column sums of this workgroup's BM rows, combined in a fixed order, then one fp64 atomic per
+        // column and statistic into the layer's [2][N] accumulator
         float* red = gemm_smem;  // [2][WM][BN], reuses the operand tiles (all waves are past the last barrier)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -277,20 +407,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
             }
         }
         __syncthreads();
+        double* out = EPI == EPI_HIDDEN_TRAIN ? g.fstat_out : g.bstat_out;
         for (int t = tid; t < 2 * BN; t += NT) {
             const int stat = t / BN, cb = t % BN;
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) s += red[(stat * WM + w) * BN + cb];
             const int col = n0 + cb;
-            if (col < g.N) g.stat_partial[((int64_t)blockIdx.y * 2 + stat) * g.ld_stat + col] = s;
+            if (col < g.N) atomicAdd(&out[(int64_t)stat * g.N + col], (double)s);
         }
     }
+
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int BK = 32>
-constexpr size_t gemm_smem_bytes() {
-    return sizeof(float) * 2 * BK * ((BM + (A_KC ? 1 : 4)) + (BN + (B_KC ? 1 : 4)));
+// dynamic LDS bytes: operand tiles + the coefficient tables of the requested transforms
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int XFA, int XFB, int BK = 32>
+inline size_t gemm_smem_bytes(int k_per_split) {
+    size_t fl = 2 * BK * ((BM + (A_KC ? 1 : 4)) + (BN + (B_KC ? 1 : 4)));
+    const int narr_a = XFA == XF_BN ? 2 : 0;
+    const int narr_b = XFB == XF_BN ? 2 : 0;
+    fl += (size_t)narr_a * (A_KC ? k_per_split : BM);
+    fl += (size_t)narr_b * (B_KC ? k_per_split : BN);
+    if (EPI == EPI_STORE_BNRED) fl += 2 * BN;
+    return sizeof(float) * fl;
 }
 
 }  // namespace vh

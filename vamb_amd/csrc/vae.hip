@@ -16,6 +16,7 @@
 #include "vae_kernels.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <map>
@@ -42,6 +43,7 @@ struct Tensor {
     float* slab = nullptr;
     int nslab = 0;
     int64_t stride = 0;
+    const double* dsrc = nullptr;   // gradient lives in an fp64 accumulator instead of slabs
     int64_t logical() const { return (int64_t)rows * cols; }
     int64_t padded() const { return (int64_t)rows_p * cols_p; }
 };
@@ -49,20 +51,28 @@ struct Tensor {
 struct Hidden {
     int nin = 0, nout = 0, nin_p = 0, nout_p = 0;
     int tW = -1, tb = -1, tG = -1, tB = -1, tRM = -1, tRV = -1;
-    DevBuf<float> H, A, DZ;             // post-dropout activations, post-BN activations, grad wrt pre-activation
+    DevBuf<float> H, A, DA, DZ;         // post-dropout activations, eval-mode BN outputs, grad wrt the BN output,
+                                        // grad wrt the pre-activation
+    double* fstat = nullptr;            // [2][nout_p] batch sums of h, h^2        (inside vh_vae::statbuf)
+    double* bstat = nullptr;            // [2][nout_p] batch sums of dA, dA*xhat
+    double* dbias = nullptr;            // [nout_p]    column sums of dZ
     DevBuf<float> mean, invstd, scale, shift;
     DevBuf<uint8_t> mask;               // injected dropout keep-mask (parity mode)
     long long batches_tracked = 0;
 };
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, int BK = 32>
+constexpr size_t kMaxDynLds = 120 * 1024;
+
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE,
+          int BK = 32>
 void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
     static bool attr_set = false;
-    constexpr size_t smem = gemm_smem_bytes<BM, BN, AKC, BKC, BK>();
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AKC, BKC, EPI, BK>;
+    const size_t smem = gemm_smem_bytes<BM, BN, AKC, BKC, EPI, XFA, XFB, BK>(g.k_per_split);
+    VH_REQUIRE(smem <= kMaxDynLds, "layer too wide for the fused GEMM (needs %zu bytes of LDS)", smem);
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AKC, BKC, EPI, XFA, XFB, BK>;
     if (!attr_set) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)smem));
+                                   (int)kMaxDynLds));
         attr_set = true;
     }
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits);
@@ -70,23 +80,28 @@ void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
     VH_HIP(hipGetLastError());
 }
 
-// tile: 0 = 64x128 (2x2 waves), 1 = 128x128 (2x2), 2 = 128x32 (4x1), 3 = 64x64 (2x2)
-template <bool AKC, bool BKC, int EPI>
+// production tiles: 3 = 64x64 (2x2 waves, 2 workgroups per CU), 2 = 128x32 (4x1) for latent-wide outputs
+template <bool AKC, bool BKC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE>
 void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
+    if (tile == 2) launch_gemm<128, 32, 4, 1, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
+    else launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
+}
+
+// every tile shape, no transforms (vh_debug_gemm): 0 = 64x128, 1 = 128x128, 2 = 128x32, 3 = 64x64,
+// 4 = 64x64 with BK = 64, 5 = one free-running wave per 32x32 tile
+template <bool AKC, bool BKC, int EPI>
+void gemm_tile_debug(hipStream_t s, int tile, const GemmArgs& g, int splits) {
     switch (tile) {
         case 0: launch_gemm<64, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
         case 1: launch_gemm<128, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
-        case 3: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
-        case 4: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, 64>(s, g, splits); break;   // BK = 64: half the barriers
-        case 5: launch_gemm<32, 32, 1, 1, AKC, BKC, EPI>(s, g, splits); break;       // one free-running wave per tile
-        default: launch_gemm<128, 32, 4, 1, AKC, BKC, EPI>(s, g, splits); break;
+        case 2: launch_gemm<128, 32, 4, 1, AKC, BKC, EPI>(s, g, splits); break;
+        case 4: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XF_NONE, XF_NONE, 64>(s, g, splits); break;
+        case 5: launch_gemm<32, 32, 1, 1, AKC, BKC, EPI>(s, g, splits); break;
+        default: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
     }
 }
 
-// measured on MI355X (profiles/r01_diag_gemm_tiles.json): the 64x64 tile (2 workgroups per CU) wins or ties
-// for every fp32 shape of the 512-wide network; skinny outputs use 128x32.
 int fwd_tile(int N) { return N <= 32 ? 2 : 3; }
-int stat_rows_per_block(int tile) { return tile == 5 ? 32 : ((tile == 0 || tile == 3 || tile == 4) ? 64 : 128); }
 
 GemmArgs base_args() {
     GemmArgs g;
@@ -119,12 +134,18 @@ struct vh_vae {
     int64_t n = 0;
     DevBuf<float> X, w;
     DevBuf<int64_t> perm;
+    // pinned staging: hipMemcpyAsync from pageable memory costs milliseconds (page pinning) per call
+    PinnedBuf<int64_t> h_perm;
+    PinnedBuf<float> h_gwsum;
+    PinnedBuf<StepState> h_state;
 
     // per-batch workspaces
     int bs = 0, bs_p = 0;
-    DevBuf<float> Xb, Wb, MU, Z, EPS, R, dR, dMUk, DA, dMU, stat_part, bwd_part, S12, loss_part, slabs, out_sm, skinny;
-    DevBuf<TensorDesc> descs;
-    DevBuf<int> blk_tensor, blk_local;
+    DevBuf<float> Xb, Wb, MU, Z, EPS, R, dR, dMUk, DA, dMU, loss_part, slabs, out_sm, skinny;
+    DevBuf<double> statbuf;          // every hidden layer's fstat | bstat | dbias, zeroed once per step
+    OptTable opt_tab, opt_tab_flat;  // parameter tensors -> gradient sources (slabs / fp64 accumulators / flat G)
+    bool stat_clean = false;         // statbuf is all zero (left so by the optimiser's finalize kernel)
+    bool keep_grads = false;         // single-step API: leave the accumulators for vh_vae_get_grad
     DevBuf<double> opt_part;
     DevBuf<StepState> state;
     int opt_blocks = 0;
@@ -145,8 +166,9 @@ struct vh_vae {
     // data parallelism (one process per GPU; gradients all-reduced over RCCL on `stream`)
     vh_comm* comm = nullptr;
     DevBuf<float> G, gwsum;          // flat gradient buffer; per-batch global weight sums
-    DevBuf<TensorDesc> descs_flat;   // descriptors that read G instead of the slabs
     const float* gwsum_src = nullptr; // per-batch all-rank weight sums of the running epoch (or nullptr)
+    ShuffleSpec shuffle{0, 0, 1};    // device-side epoch shuffle (key 0: explicit row list / identity)
+    uint64_t epoch_counter = 0;
     int global_bs = 0;               // rows of the all-rank batch (== bs without a communicator)
 
     // probe
@@ -172,7 +194,7 @@ struct vh_vae {
         for (auto e : ev_b) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side) (void)hipStreamDestroy(side);
+        if (side && side != stream) (void)hipStreamDestroy(side);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -277,10 +299,7 @@ void prepare_batch(vh_vae* h, int bs) {
     h->dMUk.ensure((size_t)bs_p * h->L_p);
     h->DA.ensure((size_t)bs_p * maxw);
     h->dMU.ensure((size_t)bs_p * h->L_p);
-    h->stat_part.ensure((size_t)(bs_p / 64) * 2 * maxw);
     const int nrb = bs_p / kRB;
-    h->bwd_part.ensure((size_t)nrb * 2 * maxw);
-    h->S12.ensure((size_t)2 * maxw);
     h->loss_blocks = bs_p / 4;
     h->loss_part.ensure((size_t)h->loss_blocks * 4);
     h->out_sm.ensure((size_t)bs_p * std::max(1, h->S));
@@ -288,7 +307,20 @@ void prepare_batch(vh_vae* h, int bs) {
     for (auto& hl : h->hidden) {
         hl.H.ensure((size_t)bs_p * hl.nout_p);
         hl.A.ensure((size_t)bs_p * hl.nout_p);
+        hl.DA.ensure((size_t)bs_p * hl.nout_p);
         hl.DZ.ensure((size_t)bs_p * hl.nout_p);
+    }
+    {   // fp64 accumulators of every hidden layer, contiguous so that one memset per step clears them
+        size_t tot = 0;
+        for (auto& hl : h->hidden) tot += (size_t)5 * hl.nout_p;
+        h->statbuf.ensure(tot);
+        size_t off = 0;
+        for (auto& hl : h->hidden) {
+            hl.fstat = h->statbuf.p + off;
+            hl.bstat = hl.fstat + (size_t)2 * hl.nout_p;
+            hl.dbias = hl.bstat + (size_t)2 * hl.nout_p;
+            off += (size_t)5 * hl.nout_p;
+        }
     }
     // gradient slabs: weights get split-K slabs, biases row-block partials, BN affine a single slab
     size_t total = 0;
@@ -302,9 +334,11 @@ void prepare_batch(vh_vae* h, int bs) {
     for (auto& hl : h->hidden) {
         const int tile = dw_tile(hl.nout_p, hl.nin_p);
         plan(hl.tW, dw_splits(hl.nout_p, hl.nin_p, bs_p, tile), (int64_t)hl.nout_p * hl.nin_p);
-        plan(hl.tb, nrb, hl.nout_p);
-        plan(hl.tG, 1, hl.nout_p);
-        plan(hl.tB, 1, hl.nout_p);
+        // bias / gamma / beta gradients are the fp64 accumulators filled by the GEMM loaders / epilogues
+        h->tensors[hl.tb].dsrc = hl.dbias;
+        h->tensors[hl.tG].dsrc = hl.bstat + hl.nout_p;   // sum dA * xhat
+        h->tensors[hl.tB].dsrc = hl.bstat;               // sum dA
+        for (int ti : {hl.tb, hl.tG, hl.tB}) { h->tensors[ti].nslab = 0; h->tensors[ti].stride = 0; h->tensors[ti].slab = nullptr; }
     }
     {
         const int hlast = h->hidden[h->nl - 1].nout_p;
@@ -315,37 +349,36 @@ void prepare_batch(vh_vae* h, int bs) {
         plan(h->tbo, nrb, h->D_p);
     }
     h->slabs.ensure(total);
-    std::vector<TensorDesc> descs;
-    std::vector<int> blk_tensor, blk_local;
+    OptTable tab;
+    memset(&tab, 0, sizeof(tab));
+    int nblk = 0;
     for (auto& t : h->tensors) {
         if (!t.optimised) continue;
-        t.slab = h->slabs.p + reinterpret_cast<size_t>(t.slab);
-        TensorDesc d;
+        VH_REQUIRE(tab.n < kMaxOptTensors, "too many parameter tensors");
+        if (!t.dsrc) t.slab = h->slabs.p + reinterpret_cast<size_t>(t.slab);
+        TensorDesc& d = tab.d[tab.n];
+        d.dsrc = t.dsrc;
         d.slab = t.slab;
         d.nslab = t.nslab;
         d.stride = t.stride;
         d.p_off = (int64_t)t.off;
         d.size = t.padded();
-        const int id = (int)descs.size();
-        descs.push_back(d);
-        for (int b = 0; b < (int)ceil_div(t.padded(), 1024); ++b) {
-            blk_tensor.push_back(id);
-            blk_local.push_back(b);
-        }
+        tab.blk_start[tab.n] = nblk;
+        nblk += (int)ceil_div(t.padded(), 1024);
+        tab.n++;
     }
-    std::vector<TensorDesc> descs_flat = descs;
+    tab.blk_start[tab.n] = nblk;
+    h->opt_tab = tab;
     h->G.ensure(h->flat_elems);
-    for (auto& d : descs_flat) { d.slab = h->G.p + d.p_off; d.nslab = 1; d.stride = 0; }
-    h->descs_flat.ensure(descs_flat.size());
-    VH_HIP(hipMemcpy(h->descs_flat.p, descs_flat.data(), sizeof(TensorDesc) * descs_flat.size(), hipMemcpyHostToDevice));
-    h->opt_blocks = (int)blk_tensor.size();
-    h->descs.ensure(descs.size());
-    h->blk_tensor.ensure(blk_tensor.size());
-    h->blk_local.ensure(blk_local.size());
+    h->opt_tab_flat = tab;
+    for (int i = 0; i < tab.n; ++i) {
+        TensorDesc& d = h->opt_tab_flat.d[i];
+        d.slab = h->G.p + d.p_off; d.nslab = 1; d.stride = 0; d.dsrc = nullptr;
+    }
+    h->opt_blocks = nblk;
     h->opt_part.ensure((size_t)h->opt_blocks * 2);
-    VH_HIP(hipMemcpy(h->descs.p, descs.data(), sizeof(TensorDesc) * descs.size(), hipMemcpyHostToDevice));
-    VH_HIP(hipMemcpy(h->blk_tensor.p, blk_tensor.data(), sizeof(int) * blk_tensor.size(), hipMemcpyHostToDevice));
-    VH_HIP(hipMemcpy(h->blk_local.p, blk_local.data(), sizeof(int) * blk_local.size(), hipMemcpyHostToDevice));
+    VH_HIP(hipMemset(h->statbuf.p, 0, h->statbuf.bytes()));
+    h->stat_clean = true;
 }
 
 struct DropCfg {
@@ -406,14 +439,47 @@ void probe_collect(vh_vae* h) {
     h->probe_used = 0;
 }
 
+// The side stream carries everything that is off the critical path of a step (weight-gradient GEMMs,
+// running statistics): fork after the producing kernel, join before the optimiser.
+void fork_side(vh_vae* h) {
+    if (h->side == h->stream) return;   // single-stream mode
+    VH_HIP(hipEventRecord(h->ev_fork, h->stream));
+    VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+}
+void join_side(vh_vae* h) {
+    if (h->side == h->stream) return;
+    VH_HIP(hipEventRecord(h->ev_join, h->side));
+    VH_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+}
+
 // ---- forward ---------------------------------------------------------------------------------------
-// Xb/Wb must hold the batch.  training: batch statistics + dropout + noise; else running statistics.
+BnSrc bn_src(vh_vae* h, const Hidden& hl) {
+    BnSrc b;
+    b.fstat = hl.fstat;
+    b.gamma = h->pptr(hl.tG);
+    b.beta = h->pptr(hl.tB);
+    b.n_p = hl.nout_p;
+    b.bs = h->bs;
+    return b;
+}
+
+// Xb/Wb must hold the batch.
+// training: every hidden layer is ONE launch -- the GEMM applies the previous layer's BatchNorm while
+//   staging its A operand (XF_BN), and its epilogue does bias + LeakyReLU + dropout, stores H and
+//   accumulates the batch sums of H for its own BatchNorm.  The normalised activations are never written.
+// eval: running statistics folded into the epilogue (EPI_HIDDEN_EVAL), activations in hl.A.
 void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, bool add_noise) {
     const int bs = h->bs, bs_p = h->bs_p;
     hipStream_t s = h->stream;
     const DropCfg dc = drop_cfg(h, training, masks_injected);
+    if (training) {
+        // the optimiser's finalize kernel leaves the accumulators zeroed; only a forward-only call dirties them
+        if (!h->stat_clean) VH_HIP(hipMemsetAsync(h->statbuf.p, 0, h->statbuf.bytes(), s));
+        h->stat_clean = false;
+    }
     const float* in = h->Xb.p;
     int in_w = h->D_p;
+    const Hidden* prev = nullptr;   // the layer whose BatchNorm still has to be applied to `in` (training)
     auto hidden_layer = [&](int li) {
         Hidden& hl = h->hidden[li];
         const int tile = fwd_tile(hl.nout_p);
@@ -423,25 +489,23 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
         g.M = bs_p; g.N = hl.nout_p; g.K = hl.nin_p; g.k_per_split = g.K;
         g.bias = h->pptr(hl.tb);
         g.m_real = bs;
-        const bool probed = h->probe_on && training && li == h->probe_layer;
         if (training) {
+            const bool probed = h->probe_on && li == h->probe_layer;
             g.C = hl.H.p; g.ldc = hl.nout_p;
-            g.stat_partial = h->stat_part.p; g.ld_stat = hl.nout_p;
+            g.fstat_out = hl.fstat;
             g.drop_scale = dc.scale; g.drop_thresh = dc.thresh; g.drop_key = layer_key(h, li);
             g.step_ptr = step_ptr(h);
             g.drop_mask = dc.injected ? hl.mask.p : nullptr; g.ld_mask = hl.nout_p;
             if (probed) { probe_record(h, true); h->probe_flops = 2.0 * bs * (double)hl.nin * hl.nout; }
-            gemm_tile<true, true, EPI_HIDDEN_TRAIN>(s, tile, g, 1);
+            if (prev) {
+                g.bnA = bn_src(h, *prev);
+                gemm_tile<true, true, EPI_HIDDEN_TRAIN, XF_BN>(s, tile, g, 1);
+            } else {
+                gemm_tile<true, true, EPI_HIDDEN_TRAIN>(s, tile, g, 1);
+            }
             if (probed) probe_record(h, false);
-            const int nb = bs_p / stat_rows_per_block(tile);
-            hipLaunchKernelGGL(vae_bn_finalize_kernel, dim3((unsigned)ceil_div(hl.nout_p, 16)), dim3(16, 16), 0, s,
-                               h->stat_part.p, nb, hl.nout_p, hl.nout_p, bs, h->pptr(hl.tG), h->pptr(hl.tB),
-                               h->pptr(hl.tRM), h->pptr(hl.tRV), hl.mean.p, hl.invstd.p, hl.scale.p, hl.shift.p);
-            VH_HIP(hipGetLastError());
-            const int64_t total4 = (int64_t)bs_p * hl.nout_p / 4;
-            hipLaunchKernelGGL(vae_bn_apply_kernel, dim3((unsigned)std::min<int64_t>(2048, ceil_div(total4, 256))),
-                               dim3(256), 0, s, hl.H.p, hl.A.p, total4, hl.nout_p, hl.scale.p, hl.shift.p);
-            VH_HIP(hipGetLastError());
+            in = hl.H.p;
+            prev = &hl;
         } else {
             hipLaunchKernelGGL(vae_bn_eval_coeff_kernel, dim3((unsigned)ceil_div(hl.nout_p, 256)), dim3(256), 0, s,
                                hl.nout_p, h->pptr(hl.tG), h->pptr(hl.tB), h->pptr(hl.tRM), h->pptr(hl.tRV),
@@ -450,8 +514,8 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
             g.C = hl.A.p; g.ldc = hl.nout_p;
             g.scale = hl.scale.p; g.shift = hl.shift.p;
             gemm_tile<true, true, EPI_HIDDEN_EVAL>(s, tile, g, 1);
+            in = hl.A.p;
         }
-        in = hl.A.p;
         in_w = hl.nout_p;
     };
     for (int li = 0; li < h->nl; ++li) hidden_layer(li);
@@ -468,7 +532,12 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
         g.k_per_split = (int)round_up(ceil_div(in_w, want), 32);
         mu_slabs = (int)ceil_div(in_w, g.k_per_split);
         g.slab_stride = (int64_t)bs_p * h->L_p;
-        gemm_tile<true, true, EPI_SPLITK>(s, fwd_tile(h->L_p), g, mu_slabs);
+        if (prev) {
+            g.bnA = bn_src(h, *prev);
+            gemm_tile<true, true, EPI_SPLITK, XF_BN>(s, fwd_tile(h->L_p), g, mu_slabs);
+        } else {
+            gemm_tile<true, true, EPI_SPLITK>(s, fwd_tile(h->L_p), g, mu_slabs);
+        }
     }
     {   // latent = mu + eps  (encode.py:276-286; sigma == 1); eps injected (parity) or generated in place
         const int64_t tot = (int64_t)bs_p * h->L_p;
@@ -480,6 +549,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
     }
     in = h->Z.p;
     in_w = h->L_p;
+    prev = nullptr;
     for (int li = h->nl; li < 2 * h->nl; ++li) hidden_layer(li);
     {   // reconstruction = a * Wo^T + bo  (encode.py:294)
         GemmArgs g = base_args();
@@ -488,7 +558,28 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
         g.C = h->R.p; g.ldc = h->D_p;
         g.M = bs_p; g.N = h->D_p; g.K = in_w; g.k_per_split = g.K;
         g.bias = h->pptr(h->tbo);
-        gemm_tile<true, true, EPI_BIAS>(s, fwd_tile(h->D_p), g, 1);
+        if (prev) {
+            g.bnA = bn_src(h, *prev);
+            gemm_tile<true, true, EPI_BIAS, XF_BN>(s, fwd_tile(h->D_p), g, 1);
+        } else {
+            gemm_tile<true, true, EPI_BIAS>(s, fwd_tile(h->D_p), g, 1);
+        }
+    }
+    if (training) {
+        // running statistics (momentum 0.1, unbiased variance): off the critical path, on the side stream
+        fork_side(h);
+        RunningTable rt;
+        memset(&rt, 0, sizeof(rt));
+        int maxn = 0;
+        for (auto& hl : h->hidden) {
+            rt.fstat[rt.n] = hl.fstat; rt.rm[rt.n] = h->pptr(hl.tRM); rt.rv[rt.n] = h->pptr(hl.tRV);
+            rt.n_p[rt.n] = hl.nout_p;
+            maxn = std::max(maxn, hl.nout_p);
+            rt.n++;
+        }
+        hipLaunchKernelGGL(vae_bn_running_kernel, dim3((unsigned)ceil_div(maxn, 256), rt.n), dim3(256), 0, h->side, rt,
+                           bs);
+        VH_HIP(hipGetLastError());
     }
 }
 
@@ -504,23 +595,16 @@ void loss_and_seed(vh_vae* h) {
     a.dR = h->dR.p; a.dMUk = h->dMUk.p; a.part = h->loss_part.p;
     hipLaunchKernelGGL(vae_loss_kernel, dim3(h->loss_blocks), dim3(256), 0, s, a);
     VH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, h->loss_part.p, h->loss_blocks, h->Wb.p,
-                       h->bs, h->gwsum_src, bs_global, h->state.p);
+    // the scalar reduction (loss means, sum of weights) is only needed by the optimiser: side stream
+    fork_side(h);
+    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, h->side, h->loss_part.p, h->loss_blocks,
+                       h->Wb.p, h->bs, h->gwsum_src, bs_global, h->state.p);
     VH_HIP(hipGetLastError());
 }
 
-// dW slabs = dZ^T * In  (both operands row-contiguous along the batch).  Runs on the side stream once the
-// main stream has produced dZ (fork event), concurrently with the rest of the backward chain.
-void fork_side(vh_vae* h) {
-    VH_HIP(hipEventRecord(h->ev_fork, h->stream));
-    VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-}
-void join_side(vh_vae* h) {
-    VH_HIP(hipEventRecord(h->ev_join, h->side));
-    VH_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-}
-
-void grad_weight(vh_vae* h, int tW, const float* dZ, int out_p, const float* In, int in_p) {
+// dW slabs = dZ^T * In on the side stream (both operands row-contiguous along the batch).
+//   inbn: when given, B = raw H of the previous hidden layer and its BatchNorm is applied on load (XF_BN)
+void grad_weight(vh_vae* h, int tW, const float* dZ, int out_p, const float* In, int in_p, const BnSrc* inbn) {
     Tensor& t = h->tensors[tW];
     const int tile = dw_tile(out_p, in_p);
     GemmArgs g = base_args();
@@ -534,122 +618,137 @@ void grad_weight(vh_vae* h, int tW, const float* dZ, int out_p, const float* In,
     if (splits < t.nslab)  // unused slabs must read as zero
         VH_HIP(hipMemsetAsync(t.slab + (int64_t)splits * t.stride, 0, sizeof(float) * (t.nslab - splits) * t.stride,
                               h->side));
-    gemm_tile<false, false, EPI_SPLITK>(h->side, tile, g, splits);
+    if (inbn) {
+        g.bnB = *inbn;
+        gemm_tile<false, false, EPI_SPLITK, XF_NONE, XF_BN>(h->side, tile, g, splits);
+    } else {
+        gemm_tile<false, false, EPI_SPLITK>(h->side, tile, g, splits);
+    }
 }
 
-// dIn = dZ * W   (dZ K-contiguous over the layer's outputs, W row-contiguous [out][in]).
-// Returns the number of slabs written: 1 (dIn itself) or, when the input is only nlatent wide, the
-// split-K slabs in h->skinny that the consumer sums.
-int grad_input(vh_vae* h, const float* dZ, int out_p, int tW, int in_p, float* dIn, bool to_latent = false) {
+// dIn = dZ * W on the main stream (dZ K-contiguous over the layer's outputs, W row-contiguous [out][in]).
+//   below: the hidden layer that produced this layer's input; the epilogue then also accumulates the two
+//          batch sums its BatchNorm backward needs (EPI_STORE_BNRED) and writes dIn into below->DA
+//   to_latent: the input is the latent code: split-K slabs into h->skinny (returns their count)
+int grad_input(vh_vae* h, const float* dZ, int out_p, int tW, int in_p, float* dIn, const Hidden* below,
+               bool to_latent) {
     GemmArgs g = base_args();
     g.A = dZ; g.lda = out_p;
     g.B = h->pptr(tW); g.ldb = in_p;
     g.M = h->bs_p; g.N = in_p; g.K = out_p;
-    if (to_latent && in_p <= 32 && out_p >= 128) {
-        const int want = std::max(1, std::min(kSkinnySplits, out_p / 64));
-        g.k_per_split = (int)round_up(ceil_div(out_p, want), 32);
-        const int splits = (int)ceil_div(out_p, g.k_per_split);
-        g.C = h->skinny.p; g.ldc = in_p;
-        g.slab_stride = (int64_t)h->bs_p * in_p;
-        gemm_tile<true, false, EPI_SPLITK>(h->stream, fwd_tile(in_p), g, splits);
+    g.m_real = h->bs;
+    const int tile = fwd_tile(in_p);
+    if (to_latent) {
+        int splits = 1;
+        g.k_per_split = g.K;
+        g.C = dIn; g.ldc = in_p;
+        if (in_p <= 32 && out_p >= 128) {
+            const int want = std::max(1, std::min(kSkinnySplits, out_p / 64));
+            g.k_per_split = (int)round_up(ceil_div(out_p, want), 32);
+            splits = (int)ceil_div(out_p, g.k_per_split);
+            g.C = h->skinny.p;
+            g.slab_stride = (int64_t)h->bs_p * in_p;
+        }
+        gemm_tile<true, false, EPI_SPLITK>(h->stream, tile, g, splits);
         return splits;
     }
     g.C = dIn; g.ldc = in_p;
     g.k_per_split = g.K;
-    gemm_tile<true, false, EPI_STORE>(h->stream, fwd_tile(in_p), g, 1);
+    g.Hbelow = below->H.p;
+    g.bnC = bn_src(h, *below);
+    g.bstat_out = below->bstat;
+    gemm_tile<true, false, EPI_STORE_BNRED>(h->stream, tile, g, 1);
     return 1;
 }
 
+// Backward of one step.  Critical path (main stream) per hidden layer: one bandwidth-bound dZ kernel and
+// one dIn GEMM whose epilogue leaves dA plus the BatchNorm-backward sums of the layer below (so BatchNorm
+// backward has no reduction / finalize kernels).  Weight gradients run on the side stream.
 void backward(vh_vae* h, bool masks_injected) {
     hipStream_t s = h->stream;
     const int bs = h->bs, bs_p = h->bs_p, nrb = bs_p / kRB;
     const DropCfg dc = drop_cfg(h, true, masks_injected);
-    // output layer: dR is ready (loss kernel) -> weight / bias gradients on the side stream
-    {
-        Hidden& last = h->hidden[2 * h->nl - 1];
+    const int nl = h->nl;
+    {   // output layer: dR is ready (loss kernel)
+        Hidden& last = h->hidden[2 * nl - 1];
+        const BnSrc inbn = bn_src(h, last);
         fork_side(h);
-        grad_weight(h, h->tWo, h->dR.p, h->D_p, last.A.p, last.nout_p);
+        grad_weight(h, h->tWo, h->dR.p, h->D_p, last.H.p, last.nout_p, &inbn);
         hipLaunchKernelGGL(vae_colsum_partial_kernel, dim3((unsigned)ceil_div(h->D_p, kCT), nrb), dim3(kCT, kRL), 0,
                            h->side, h->dR.p, (int64_t)h->D_p, h->D_p, bs_p, h->tensors[h->tbo].slab);
         VH_HIP(hipGetLastError());
-        grad_input(h, h->dR.p, h->D_p, h->tWo, last.nout_p, h->DA.p);
+        grad_input(h, h->dR.p, h->D_p, h->tWo, last.nout_p, last.DA.p, &last, false);
     }
     int latent_slabs = 1;
-    auto hidden_bwd = [&](int li, const float* In, int in_p, bool need_dinput) {
+    // hidden layer li: its dA (hl.DA) and the sums in hl.bstat are complete on the main stream
+    auto hidden_bwd = [&](int li) {
         Hidden& hl = h->hidden[li];
-        const dim3 grid((unsigned)ceil_div(hl.nout_p, kCT), nrb);
-        const dim3 block(kCT, kRL);
-        hipLaunchKernelGGL(vae_bn_bwd_reduce_kernel, grid, block, 0, s, h->DA.p, hl.H.p, hl.nout_p, bs, hl.mean.p,
-                           hl.invstd.p, h->bwd_part.p);
-        VH_HIP(hipGetLastError());
-        hipLaunchKernelGGL(vae_bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(hl.nout_p, 16)), dim3(16, 16), 0, s,
-                           h->bwd_part.p, nrb, hl.nout_p, h->S12.p, h->tensors[hl.tG].slab, h->tensors[hl.tB].slab);
-        VH_HIP(hipGetLastError());
-        BnBwdArgs a;
-        a.DA = h->DA.p; a.H = hl.H.p; a.DZ = hl.DZ.p;
+        DzArgs a;
+        a.DA = hl.DA.p; a.H = hl.H.p; a.DZ = hl.DZ.p;
         a.n_p = hl.nout_p; a.bs = bs; a.bs_p = bs_p;
-        a.mean = hl.mean.p; a.invstd = hl.invstd.p; a.gamma = h->pptr(hl.tG); a.S12 = h->S12.p;
-        a.drop_scale = dc.scale; a.drop_thresh = dc.thresh; a.drop_key = layer_key(h, li);
-        a.step_ptr = step_ptr(h);
+        a.bn = bn_src(h, hl);
+        a.bstat = hl.bstat;
+        a.drop_scale = dc.scale;
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
-        a.dbias_part = h->tensors[hl.tb].slab;
-        hipLaunchKernelGGL(vae_bn_bwd_apply_kernel, grid, block, 0, s, a);
+        a.dbias = hl.dbias;
+        hipLaunchKernelGGL(vae_dz_kernel, dim3((unsigned)ceil_div(hl.nout_p, kCT), nrb), dim3(kCT, kRL), 0, s, a);
         VH_HIP(hipGetLastError());
+        const bool from_input = (li == 0) || (li == nl);          // input is Xb / Z: no BatchNorm to apply
+        const Hidden* below = from_input ? nullptr : &h->hidden[li - 1];
+        const float* In = li == 0 ? h->Xb.p : (li == nl ? h->Z.p : below->H.p);
+        const int in_p = li == 0 ? h->D_p : (li == nl ? h->L_p : below->nout_p);
         fork_side(h);
-        grad_weight(h, hl.tW, hl.DZ.p, hl.nout_p, In, in_p);
-        if (need_dinput) {
-            const int n = grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, h->DA.p, li == h->nl);
-            if (li == h->nl) latent_slabs = n;
+        if (below) {
+            const BnSrc inbn = bn_src(h, *below);
+            grad_weight(h, hl.tW, hl.DZ.p, hl.nout_p, In, in_p, &inbn);
+        } else {
+            grad_weight(h, hl.tW, hl.DZ.p, hl.nout_p, In, in_p, nullptr);
         }
+        if (li == nl) latent_slabs = grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, h->DA.p, nullptr, true);
+        else if (li > 0) grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, below->DA.p, below, false);
+        // li == 0: the input gradient is never needed
     };
-    for (int li = 2 * h->nl - 1; li >= h->nl; --li) {
-        const bool first_dec = li == h->nl;
-        const float* In = first_dec ? h->Z.p : h->hidden[li - 1].A.p;
-        const int in_p = first_dec ? h->L_p : h->hidden[li - 1].nout_p;
-        hidden_bwd(li, In, in_p, true);
-    }
+    for (int li = 2 * nl - 1; li >= nl; --li) hidden_bwd(li);
     {   // latent: dMU = dZlat + d(KLD)/dmu; mu layer
-        Hidden& enc_last = h->hidden[h->nl - 1];
+        Hidden& enc_last = h->hidden[nl - 1];
         // latent_slabs == 1: the first decoder layer wrote dZlat into DA; otherwise split-K slabs in skinny
         const float* src = latent_slabs == 1 ? h->DA.p : h->skinny.p;
         hipLaunchKernelGGL(vae_latent_bwd_kernel, dim3((unsigned)ceil_div(h->L_p, kCT), nrb), dim3(kCT, kRL), 0, s, src,
                            latent_slabs, (int64_t)bs_p * h->L_p, h->dMUk.p, h->dMU.p, h->L_p, bs, bs_p,
                            h->tensors[h->tbmu].slab);
         VH_HIP(hipGetLastError());
+        const BnSrc inbn = bn_src(h, enc_last);
         fork_side(h);
-        grad_weight(h, h->tWmu, h->dMU.p, h->L_p, enc_last.A.p, enc_last.nout_p);
-        grad_input(h, h->dMU.p, h->L_p, h->tWmu, enc_last.nout_p, h->DA.p);
+        grad_weight(h, h->tWmu, h->dMU.p, h->L_p, enc_last.H.p, enc_last.nout_p, &inbn);
+        grad_input(h, h->dMU.p, h->L_p, h->tWmu, enc_last.nout_p, enc_last.DA.p, &enc_last, false);
     }
-    for (int li = h->nl - 1; li >= 0; --li) {
-        const float* In = li == 0 ? h->Xb.p : h->hidden[li - 1].A.p;
-        const int in_p = li == 0 ? h->D_p : h->hidden[li - 1].nout_p;
-        hidden_bwd(li, In, in_p, li > 0);  // the input gradient of layer 0 is never needed
-    }
-    join_side(h);  // every weight gradient is complete before the optimiser reads the slabs
+    for (int li = nl - 1; li >= 0; --li) hidden_bwd(li);
+    join_side(h);  // every weight gradient (and the running statistics) is complete before the optimiser
 }
 
 void optimizer_step(vh_vae* h) {
-    const TensorDesc* descs = h->descs.p;
+    const OptTable* tab = &h->opt_tab;
     if (h->comm) {
         // sum this rank's slabs into the flat buffer, all-reduce it over the ranks (RCCL, same stream,
         // no host synchronisation), then every rank applies the identical update
-        hipLaunchKernelGGL(vae_reduce_slabs_kernel, dim3(h->opt_blocks), dim3(256), 0, h->stream, h->descs.p,
-                           h->blk_tensor.p, h->blk_local.p, h->G.p);
+        hipLaunchKernelGGL(vae_reduce_slabs_kernel, dim3(h->opt_blocks), dim3(256), 0, h->stream, h->opt_tab, h->G.p);
         VH_HIP(hipGetLastError());
         rccl_allreduce_sum_f32(h->comm, h->G.p, h->flat_elems, h->stream);
-        descs = h->descs_flat.p;
+        tab = &h->opt_tab_flat;
     }
-    hipLaunchKernelGGL(vae_dadapt_kernel, dim3(h->opt_blocks), dim3(256), 0, h->stream, descs, h->blk_tensor.p,
-                       h->blk_local.p, h->P.p, h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p);
+    hipLaunchKernelGGL(vae_dadapt_kernel, dim3(h->opt_blocks), dim3(256), 0, h->stream, *tab, h->P.p, h->M1.p,
+                       h->M2.p, h->Sv.p, h->state.p, h->opt_part.p);
     VH_HIP(hipGetLastError());
     hipLaunchKernelGGL(vae_dadapt_finalize_kernel, dim3(1), dim3(256), 0, h->stream, h->opt_part.p, h->opt_blocks,
-                       h->state.p);
+                       h->state.p, h->statbuf.p, h->keep_grads ? 0 : (int)h->statbuf.n);
     VH_HIP(hipGetLastError());
+    h->stat_clean = !h->keep_grads;
 }
 
 void gather_rows(vh_vae* h, const int64_t* dev_idx) {
     hipLaunchKernelGGL(vae_gather_kernel, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, h->stream, h->X.p,
-                       (int64_t)h->D_p, h->w.p, dev_idx, &h->state.p->batch, h->bs, h->bs_p, h->Xb.p, h->Wb.p);
+                       (int64_t)h->D_p, h->w.p, dev_idx, h->shuffle, &h->state.p->batch, h->bs, h->bs_p, h->Xb.p,
+                       h->Wb.p);
     VH_HIP(hipGetLastError());
 }
 
@@ -668,9 +767,9 @@ void count_batches(vh_vae* h, long long n) {
     for (auto& hl : h->hidden) hl.batches_tracked += n;
 }
 
-void set_batch_index(vh_vae* h, long long b) {
-    VH_HIP(hipMemcpyAsync(&h->state.p->batch, &b, sizeof(b), hipMemcpyHostToDevice, h->stream));
-    VH_HIP(hipStreamSynchronize(h->stream));
+// the epoch's batch cursor restarts at 0 (stream-ordered, no host synchronisation)
+void reset_batch_index(vh_vae* h) {
+    VH_HIP(hipMemsetAsync(&h->state.p->batch, 0, sizeof(long long), h->stream));
 }
 
 // Run batches [first, n_batches) of the epoch whose row list is dev_idx.  The first step after a
@@ -685,7 +784,17 @@ void run_epoch_steps(vh_vae* h, const int64_t* dev_idx, int64_t n_batches) {
     count_batches(h, n_batches);
     int64_t b = 0;
     if (!graphs) {
+        const bool dbg = getenv("VAMBHIP_DEBUG_TIMING") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         for (; b < n_batches; ++b) train_step_device(h, dev_idx, false, false);
+        if (dbg) {
+            const auto t1 = std::chrono::steady_clock::now();
+            VH_HIP(hipStreamSynchronize(h->stream));
+            const auto t2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[vambhip] epoch: host enqueue %.2f ms, drain after enqueue %.2f ms (%lld steps)\n",
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(t2 - t1).count(), (long long)n_batches);
+        }
         return;
     }
     // step 0 of every epoch is eager: warm-up for a fresh configuration and the probe's measurement point
@@ -720,8 +829,10 @@ void run_epoch_steps(vh_vae* h, const int64_t* dev_idx, int64_t n_batches) {
 }
 
 void read_state(vh_vae* h, StepState* out) {
-    VH_HIP(hipMemcpyAsync(out, h->state.p, sizeof(StepState), hipMemcpyDeviceToHost, h->stream));
+    h->h_state.ensure(1);
+    VH_HIP(hipMemcpyAsync(h->h_state.p, h->state.p, sizeof(StepState), hipMemcpyDeviceToHost, h->stream));
     VH_HIP(hipStreamSynchronize(h->stream));
+    *out = *h->h_state.p;
 }
 
 void reset_epoch_sums(vh_vae* h) {
@@ -770,7 +881,8 @@ int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
         h->sse_w = (float)(a / VH_NTNF);
         h->kld_w = (float)(1.0 / ((double)cfg->nlatent * cfg->beta));
         VH_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        VH_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        if (getenv("VAMBHIP_SINGLE_STREAM")) h->side = h->stream;
+        else VH_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         VH_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         VH_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
 
@@ -886,13 +998,20 @@ int vh_vae_get_grad(vh_vae* h, const char* name, float* data, int64_t n) {
         const int ti = find_tensor(h, name);
         const Tensor& t = h->tensors[ti];
         VH_REQUIRE(t.optimised, "'%s' is a buffer, not a parameter", name);
-        VH_REQUIRE(t.slab != nullptr, "no training step has run yet");
+        VH_REQUIRE(t.slab != nullptr || t.dsrc != nullptr, "no training step has run yet");
         VH_REQUIRE(n == t.logical(), "parameter '%s' has %lld elements, got %lld", name, (long long)t.logical(),
                    (long long)n);
-        std::vector<float> slab((size_t)t.nslab * t.stride);
-        VH_HIP(hipMemcpyAsync(slab.data(), t.slab, sizeof(float) * slab.size(), hipMemcpyDeviceToHost, h->stream));
         StepState st;
         read_state(h, &st);
+        if (t.dsrc) {   // bias / gamma / beta of a hidden layer: fp64 accumulator
+            std::vector<double> acc((size_t)t.padded());
+            VH_HIP(hipMemcpy(acc.data(), t.dsrc, sizeof(double) * acc.size(), hipMemcpyDeviceToHost));
+            for (int c = 0; c < t.cols; ++c) data[c] = (float)acc[c] * (float)st.wsum;
+            return;
+        }
+        std::vector<float> slab((size_t)t.nslab * t.stride);
+        VH_HIP(hipMemcpyAsync(slab.data(), t.slab, sizeof(float) * slab.size(), hipMemcpyDeviceToHost, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
         const float gscale = (float)st.wsum;  // the loss' sum(w) factor is applied by the optimiser kernel
         for (int r = 0; r < t.rows; ++r)
             for (int c = 0; c < t.cols; ++c) {
@@ -942,7 +1061,9 @@ int vh_vae_train_step(vh_vae* h, const int64_t* rows, int64_t batch, const float
             VH_REQUIRE(rows[i] >= 0 && rows[i] < h->n, "row %lld out of range", (long long)rows[i]);
         prepare_batch(h, (int)batch);
         h->perm.ensure((size_t)batch);
-        VH_HIP(hipMemcpyAsync(h->perm.p, rows, sizeof(int64_t) * batch, hipMemcpyHostToDevice, h->stream));
+        h->h_perm.ensure((size_t)batch);
+        memcpy(h->h_perm.p, rows, sizeof(int64_t) * batch);
+        VH_HIP(hipMemcpyAsync(h->perm.p, h->h_perm.p, sizeof(int64_t) * batch, hipMemcpyHostToDevice, h->stream));
         if (eps) {
             std::vector<float> e((size_t)h->bs_p * h->L_p, 0.f);
             for (int r = 0; r < batch; ++r) memcpy(e.data() + (size_t)r * h->L_p, eps + (size_t)r * h->L, sizeof(float) * h->L);
@@ -951,10 +1072,12 @@ int vh_vae_train_step(vh_vae* h, const int64_t* rows, int64_t batch, const float
         }
         if (masks && h->cfg.dropout > 0) upload_masks(h, masks, (int)batch);
         reset_epoch_sums(h);
-        set_batch_index(h, 0);
+        reset_batch_index(h);
         h->gwsum_src = nullptr;
         h->global_bs = 0;
+        h->keep_grads = true;   // vh_vae_get_grad may be called afterwards
         train_step_device(h, h->perm.p, eps != nullptr, masks != nullptr && h->cfg.dropout > 0);
+        h->keep_grads = false;
         count_batches(h, 1);
         StepState st;
         read_state(h, &st);
@@ -967,35 +1090,84 @@ int vh_vae_train_step(vh_vae* h, const int64_t* rows, int64_t batch, const float
 int vh_vae_train_epoch_dp(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, int64_t global_batch,
                           const float* global_wsum, double loss_means[5]) {
     return guarded([&] {
-        VH_REQUIRE(h != nullptr && perm != nullptr, "NULL argument");
+        VH_REQUIRE(h != nullptr, "NULL argument");
         VH_REQUIRE(h->n > 0, "no dataset: call vh_vae_set_dataset first");
         VH_REQUIRE(n_batches >= 1, "no batches");
         VH_REQUIRE(batch >= 2, "BatchNorm1d needs more than 1 value per channel when training (batch=%lld)",
                    (long long)batch);
         VH_REQUIRE(batch <= (1 << 24), "batch too large");
+        VH_REQUIRE(n_batches * batch <= h->n || perm != nullptr, "epoch needs %lld rows but the dataset has %lld",
+                   (long long)(n_batches * batch), (long long)h->n);
         const bool dp = h->comm != nullptr && h->comm->world > 1;
+        const bool dbg = getenv("VAMBHIP_DEBUG_TIMING") != nullptr;
+        const auto T0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (dbg) fprintf(stderr, "[vambhip] %-18s %.3f ms\n", what,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+        };
         if (global_batch <= 0) global_batch = batch;
         VH_REQUIRE(global_batch >= batch, "global batch smaller than the local batch");
-        VH_REQUIRE(!(global_batch != batch && global_wsum == nullptr),
-                   "a global batch needs the per-batch global weight sums");
         VH_REQUIRE(!(global_batch != batch && h->comm == nullptr), "a global batch needs a communicator");
         const int64_t total = n_batches * batch;
-        for (int64_t i = 0; i < total; ++i)
-            VH_REQUIRE(perm[i] >= 0 && perm[i] < h->n, "row %lld out of range", (long long)perm[i]);
         prepare_batch(h, (int)batch);
-        h->perm.ensure((size_t)total);
-        VH_HIP(hipMemcpyAsync(h->perm.p, perm, sizeof(int64_t) * total, hipMemcpyHostToDevice, h->stream));
-        if (global_wsum) {
-            h->gwsum.ensure((size_t)n_batches);
-            VH_HIP(hipMemcpyAsync(h->gwsum.p, global_wsum, sizeof(float) * n_batches, hipMemcpyHostToDevice, h->stream));
+        const int64_t* dev_idx = nullptr;
+        if (perm) {
+            h->perm.ensure((size_t)total);
+            h->h_perm.ensure((size_t)total);
+            {   // validate while staging into pinned memory (one pass over the row list)
+                int64_t bad = -1;
+                const int64_t n = h->n;
+                for (int64_t i = 0; i < total; ++i) {
+                    const int64_t r = perm[i];
+                    if (r < 0 || r >= n) bad = r;
+                    h->h_perm.p[i] = r;
+                }
+                VH_REQUIRE(bad == -1, "row %lld out of range", (long long)bad);
+            }
+            VH_HIP(hipMemcpyAsync(h->perm.p, h->h_perm.p, sizeof(int64_t) * total, hipMemcpyHostToDevice, h->stream));
+            dev_idx = h->perm.p;
+            h->shuffle.key = 0ull;
+        } else {
+            // device-side shuffle: a fresh keyed bijection of [0, n) per epoch (vae_kernels.hpp)
+            h->epoch_counter++;
+            const uint64_t rank = h->comm ? (uint64_t)h->comm->rank : 0ull;
+            uint64_t key = (h->cfg.seed + 0x632BE59BD9B4E019ull) * 0x9E3779B97F4A7C15ull;
+            key ^= (h->epoch_counter * 0xD6E8FEB86659FD93ull) ^ (rank << 40);
+            key ^= key >> 29;
+            if (key == 0ull) key = 1ull;
+            h->shuffle.key = key;
+            h->shuffle.n = (unsigned long long)h->n;
+            int bits = 1;
+            while ((1ull << bits) < (unsigned long long)h->n) ++bits;
+            h->shuffle.bits = bits;
         }
-        h->global_bs = (global_wsum != nullptr) ? (int)global_batch : 0;
-        h->gwsum_src = global_wsum ? h->gwsum.p : nullptr;
-        reset_epoch_sums(h);
-        set_batch_index(h, 0);
-        run_epoch_steps(h, h->perm.p, n_batches);
         h->gwsum_src = nullptr;
         h->global_bs = 0;
+        if (global_batch != batch || global_wsum != nullptr) {
+            h->gwsum.ensure((size_t)n_batches);
+            if (global_wsum) {
+                h->h_gwsum.ensure((size_t)n_batches);
+                memcpy(h->h_gwsum.p, global_wsum, sizeof(float) * n_batches);
+                VH_HIP(hipMemcpyAsync(h->gwsum.p, h->h_gwsum.p, sizeof(float) * n_batches, hipMemcpyHostToDevice,
+                                      h->stream));
+            } else {
+                // plan on the device: local weight sum of every batch, all-reduced over the ranks
+                hipLaunchKernelGGL(vae_batch_wsum_kernel, dim3((unsigned)n_batches), dim3(256), 0, h->stream, h->w.p,
+                                   dev_idx, h->shuffle, (int)batch, h->gwsum.p);
+                VH_HIP(hipGetLastError());
+                if (h->comm) rccl_allreduce_sum_f32(h->comm, h->gwsum.p, (size_t)n_batches, h->stream);
+            }
+            h->gwsum_src = h->gwsum.p;
+            h->global_bs = (int)global_batch;
+        }
+        lap("staged");
+        reset_epoch_sums(h);
+        reset_batch_index(h);
+        run_epoch_steps(h, dev_idx, n_batches);
+        lap("enqueued");
+        h->gwsum_src = nullptr;
+        h->global_bs = 0;
+        h->shuffle.key = 0ull;
         if (dp) {
             // epoch log line: every rank holds local_sum / B_global, the sum over ranks is the global mean
             StepState* st = h->state.p;
@@ -1009,6 +1181,7 @@ int vh_vae_train_epoch_dp(vh_vae* h, const int64_t* perm, int64_t n_batches, int
         }
         StepState st;
         read_state(h, &st);
+        lap("state read");
         probe_collect(h);
         if (loss_means)
             for (int i = 0; i < 5; ++i) loss_means[i] = st.epoch_loss[i] / (double)n_batches;
@@ -1052,7 +1225,7 @@ int vh_vae_forward(vh_vae* h, const float* depths, const float* tnf, const float
         const bool inj_masks = training && masks != nullptr && h->cfg.dropout > 0;
         if (inj_masks) upload_masks(h, masks, (int)batch);
         forward(h, training != 0, eps != nullptr, inj_masks, true);
-        if (training) count_batches(h, 1);
+        if (training) { join_side(h); count_batches(h, 1); }
         hipLaunchKernelGGL(vae_advance_step_kernel, dim3(1), dim3(1), 0, h->stream, h->state.p);
         VH_HIP(hipGetLastError());
         // outputs
@@ -1193,12 +1366,12 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
         VH_HIP(hipEventCreate(&e1));
         auto run = [&] {
             if (a_kc && b_kc) {
-                if (bias) gemm_tile<true, true, EPI_BIAS>(s, tile, g, 1);
-                else gemm_tile<true, true, EPI_SPLITK>(s, tile, g, nsplit);
+                if (bias) gemm_tile_debug<true, true, EPI_BIAS>(s, tile, g, 1);
+                else gemm_tile_debug<true, true, EPI_SPLITK>(s, tile, g, nsplit);
             } else if (a_kc && !b_kc) {
-                gemm_tile<true, false, EPI_SPLITK>(s, tile, g, nsplit);
+                gemm_tile_debug<true, false, EPI_SPLITK>(s, tile, g, nsplit);
             } else {
-                gemm_tile<false, false, EPI_SPLITK>(s, tile, g, nsplit);
+                gemm_tile_debug<false, false, EPI_SPLITK>(s, tile, g, nsplit);
             }
         };
         run();  // warm-up (also sets the LDS attribute)

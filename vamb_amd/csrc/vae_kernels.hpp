@@ -32,17 +32,49 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- batch assembly ----------------------------------------------------------------------------
-// Xb[r][:] = X[idx[r]][:], Wb[r] = w[idx[r]] for r < bs; zero rows for the padding.  blockDim (64,4).
-// idx (if given) is the epoch's row list; the batch to use is *batch_ptr (device resident, advanced by
-// the optimiser's finalize kernel, so that one captured graph serves every step of the epoch).
+// Epoch shuffle without a permutation array: a keyed bijection of [0, 2^bits) (odd multiplies and
+// xor-shifts, each invertible modulo 2^bits) restricted to [0, n) by cycle walking.  Every epoch uses a
+// fresh key, so the gather kernel draws its rows directly from position (batch * bs + r) -- no host
+// randperm, no upload, no sort.
+struct ShuffleSpec {
+    unsigned long long key;   // 0 = identity (no shuffle)
+    unsigned long long n;     // rows in the (local) dataset
+    int bits;                 // ceil(log2(n)), >= 1
+};
+
+__host__ __device__ __forceinline__ unsigned long long shuffle_round(unsigned long long x, unsigned long long key,
+                                                                      unsigned long long mask, int bits) {
+    const int s1 = (bits + 1) / 2, s2 = (bits + 2) / 3 > 0 ? (bits + 2) / 3 : 1;
+    x = (x * 0x9E3779B97F4A7C15ull + key) & mask;
+    x ^= x >> s1;
+    x = (x * 0xBF58476D1CE4E5B9ull + (key >> 17)) & mask;
+    x ^= x >> s2;
+    x = (x * 0x94D049BB133111EBull + (key >> 31)) & mask;
+    x ^= x >> s1;
+    return x;
+}
+
+__host__ __device__ __forceinline__ unsigned long long shuffle_index(const ShuffleSpec& sp, unsigned long long i) {
+    if (sp.key == 0ull) return i;
+    const unsigned long long mask = (sp.bits >= 64) ? ~0ull : ((1ull << sp.bits) - 1ull);
+    unsigned long long x = i;
+    do { x = shuffle_round(x, sp.key, mask, sp.bits); } while (x >= sp.n);
+    return x;
+}
+
+// Xb[r][:] = X[src(r)][:], Wb[r] = w[src(r)] for r < bs; zero rows for the padding.  blockDim (64,4).
+// src(r) = idx[first + r] when an explicit row list is given, else shuffle(first + r); first = batch * bs
+// with the batch index read from device memory (advanced by the optimiser's finalize kernel).
 __global__ void vae_gather_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ w_all,
-                                  const int64_t* __restrict__ idx, const long long* __restrict__ batch_ptr, int bs,
-                                  int bs_p, float* __restrict__ Xb, float* __restrict__ Wb) {
+                                  const int64_t* __restrict__ idx, const ShuffleSpec shuffle,
+                                  const long long* __restrict__ batch_ptr, int bs, int bs_p,
+                                  float* __restrict__ Xb, float* __restrict__ Wb) {
     const int r = blockIdx.x * 4 + threadIdx.y;
     if (r >= bs_p) return;
     const bool real = r < bs;
     const int64_t first = batch_ptr ? (int64_t)(*batch_ptr) * bs : 0;
-    const int64_t src = real ? (idx ? idx[first + r] : (int64_t)r) : 0;
+    int64_t src = 0;
+    if (real) src = idx ? idx[first + r] : (int64_t)shuffle_index(shuffle, (unsigned long long)(first + r));
     const float4* s = reinterpret_cast<const float4*>(X + src * ldx);
     float4* d = reinterpret_cast<float4*>(Xb + (int64_t)r * ldx);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -53,6 +85,27 @@ __global__ void vae_gather_kernel(const float* __restrict__ X, int64_t ldx, cons
         d[c] = v;
     }
     if (threadIdx.x == 0) Wb[r] = real ? w_all[src] : 0.f;
+}
+
+// data-parallel planning on the device: out[b] = sum of the weights of this rank's rows of batch b
+__global__ __launch_bounds__(256) void vae_batch_wsum_kernel(const float* __restrict__ w_all,
+                                                             const int64_t* __restrict__ idx,
+                                                             const ShuffleSpec shuffle, int bs,
+                                                             float* __restrict__ out) {
+    __shared__ double red[256];
+    const int64_t first = (int64_t)blockIdx.x * bs;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < bs; r += 256) {
+        const int64_t src = idx ? idx[first + r] : (int64_t)shuffle_index(shuffle, (unsigned long long)(first + r));
+        s += (double)w_all[src];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)red[0];
 }
 
 // out[0] = sum of v[0..n)  (single workgroup, fixed tree => deterministic)
@@ -69,40 +122,28 @@ __global__ __launch_bounds__(256) void vae_sum_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) out[0] = (float)red[0];
 }
 
-// ---- BatchNorm1d forward (training): finalise statistics from the GEMM epilogue's partial sums --
-// blockDim (16, 16): 16 columns per workgroup, 16 lanes share the nb partials of each column
-// (fixed assignment and fixed combination order => deterministic).
-__global__ __launch_bounds__(256) void vae_bn_finalize_kernel(
-    const float* __restrict__ part, int nb, int ld, int n_p, int bs, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv, float* __restrict__ mean,
-    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double r1[16][17], r2[16][17];
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int col = blockIdx.x * 16 + tx;
-    double s1 = 0.0, s2 = 0.0;
-    if (col < n_p)
-        for (int b = ty; b < nb; b += 16) {
-            s1 += (double)part[((int64_t)b * 2 + 0) * ld + col];
-            s2 += (double)part[((int64_t)b * 2 + 1) * ld + col];
-        }
-    r1[ty][tx] = s1;
-    r2[ty][tx] = s2;
-    __syncthreads();
-    if (ty != 0 || col >= n_p) return;
-    s1 = 0.0; s2 = 0.0;
-    for (int i = 0; i < 16; ++i) { s1 += r1[i][tx]; s2 += r2[i][tx]; }
-    const double m = s1 / bs;
-    double var = s2 / bs - m * m;  // biased variance (normalisation)
+// ---- BatchNorm1d running statistics (training): momentum 0.1, unbiased variance for running_var -------
+// fstat = a layer's fp64 batch sums [2][n_p] accumulated by the forward GEMM's epilogue.  One launch
+// (blockIdx.y = layer) updates every hidden layer.
+struct RunningTable {
+    int n;
+    const double* fstat[16];
+    float* rm[16];
+    float* rv[16];
+    int n_p[16];
+};
+__global__ void vae_bn_running_kernel(const RunningTable tab, int bs) {
+    const int l = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= tab.n || col >= tab.n_p[l]) return;
+    const double* fstat = tab.fstat[l];
+    const int n_p = tab.n_p[l];
+    const double m = fstat[col] / bs;
+    double var = fstat[n_p + col] / bs - m * m;
     if (var < 0.0) var = 0.0;
-    const float istd = (float)(1.0 / sqrt(var + (double)kBnEps));
-    const float sc = gamma[col] * istd;
-    mean[col] = (float)m;
-    invstd[col] = istd;
-    scale[col] = sc;
-    shift[col] = beta[col] - (float)m * sc;
     const double unbiased = bs > 1 ? var * ((double)bs / (double)(bs - 1)) : var;
-    rm[col] = (1.0f - kBnMomentum) * rm[col] + kBnMomentum * (float)m;
-    rv[col] = (1.0f - kBnMomentum) * rv[col] + kBnMomentum * (float)unbiased;
+    tab.rm[l][col] = (1.0f - kBnMomentum) * tab.rm[l][col] + kBnMomentum * (float)m;
+    tab.rv[l][col] = (1.0f - kBnMomentum) * tab.rv[l][col] + kBnMomentum * (float)unbiased;
 }
 
 // eval mode: scale/shift from the running statistics
@@ -115,24 +156,6 @@ __global__ void vae_bn_eval_coeff_kernel(int n_p, const float* __restrict__ gamm
     const float sc = gamma[col] * istd;
     scale[col] = sc;
     shift[col] = beta[col] - rm[col] * sc;
-}
-
-// A = H * scale[col] + shift[col]
-__global__ void vae_bn_apply_kernel(const float* __restrict__ H, float* __restrict__ A, int64_t total4, int n_p,
-                                    const float* __restrict__ scale, const float* __restrict__ shift) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)((i * 4) % n_p);
-        const float4 h = reinterpret_cast<const float4*>(H)[i];
-        const float4 s = *reinterpret_cast<const float4*>(scale + col);
-        const float4 t = *reinterpret_cast<const float4*>(shift + col);
-        float4 a;
-        a.x = h.x * s.x + t.x;
-        a.y = h.y * s.y + t.y;
-        a.z = h.z * s.z + t.z;
-        a.w = h.w * s.w + t.w;
-        reinterpret_cast<float4*>(A)[i] = a;
-    }
 }
 
 // ---- reparameterisation (encode.py:276-286) ------------------------------------------------------
@@ -360,110 +383,67 @@ __global__ __launch_bounds__(256) void vae_colsum_partial_kernel(const float* __
     if (threadIdx.y == 0 && col < n_p) part[(int64_t)blockIdx.y * n_p + col] = s;
 }
 
-// BatchNorm backward, pass 1: partial sums of dA and dA * xhat
-__global__ __launch_bounds__(256) void vae_bn_bwd_reduce_kernel(const float* __restrict__ DA,
-                                                                const float* __restrict__ H, int n_p, int bs,
-                                                                const float* __restrict__ mean,
-                                                                const float* __restrict__ invstd,
-                                                                float* __restrict__ part /*[nrb][2][n_p]*/) {
-    __shared__ float red[kRL][kCT + 1];
-    const int col = blockIdx.x * kCT + threadIdx.x;
-    const int r0 = blockIdx.y * kRB, r1 = min(bs, r0 + kRB);
-    float s1 = 0.f, s2 = 0.f;
-    if (col < n_p) {
-        const float m = mean[col], is = invstd[col];
-        for (int r = r0 + threadIdx.y; r < r1; r += kRL) {
-            const float da = DA[(int64_t)r * n_p + col];
-            const float xh = (H[(int64_t)r * n_p + col] - m) * is;
-            s1 += da;
-            s2 += da * xh;
-        }
-    }
-    s1 = column_block_sum(s1, red);
-    s2 = column_block_sum(s2, red);
-    if (threadIdx.y == 0 && col < n_p) {
-        part[((int64_t)blockIdx.y * 2 + 0) * n_p + col] = s1;
-        part[((int64_t)blockIdx.y * 2 + 1) * n_p + col] = s2;
-    }
-}
-
-// pass 2: totals; these are also the gradients of beta (S1) and gamma (S2).  blockDim (16, 16).
-__global__ __launch_bounds__(256) void vae_bn_bwd_finalize_kernel(const float* __restrict__ part, int nrb, int n_p,
-                                                                  float* __restrict__ S12,
-                                                                  float* __restrict__ dgamma,
-                                                                  float* __restrict__ dbeta) {
-    __shared__ double r1[16][17], r2[16][17];
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int col = blockIdx.x * 16 + tx;
-    double s1 = 0.0, s2 = 0.0;
-    if (col < n_p)
-        for (int b = ty; b < nrb; b += 16) {
-            s1 += (double)part[((int64_t)b * 2 + 0) * n_p + col];
-            s2 += (double)part[((int64_t)b * 2 + 1) * n_p + col];
-        }
-    r1[ty][tx] = s1;
-    r2[ty][tx] = s2;
-    __syncthreads();
-    if (ty != 0 || col >= n_p) return;
-    s1 = 0.0; s2 = 0.0;
-    for (int i = 0; i < 16; ++i) { s1 += r1[i][tx]; s2 += r2[i][tx]; }
-    S12[col] = (float)s1;
-    S12[n_p + col] = (float)s2;
-    dbeta[col] = (float)s1;
-    dgamma[col] = (float)s2;
-}
-
-struct BnBwdArgs {
+// Elementwise backward of one hidden layer (encode.py:264: BN(dropout(leaky_relu(z)))), one pass:
+//   dZ = keep * slope(h) * drop_scale * istd*gamma * (dA - S1/B - xhat * S2/B),   xhat = (h - mean) * istd
+// with mean/istd from the forward batch sums (fstat) and S1 = sum dA, S2 = sum dA*xhat (bstat) that the
+// producing GEMM epilogues accumulated; also the column sums of dZ (bias gradient, fp64 atomics).
+// "kept" is read off H itself when the mask was generated (a dropped unit was stored as exactly 0; a kept
+// unit with z == 0.0f exactly is the only mis-classified case and carries the 0.01-slope gradient of a
+// measure-zero event); injected masks (parity tests) are looked up.
+struct DzArgs {
     const float* DA;
     const float* H;
     float* DZ;
     int n_p, bs, bs_p;
-    const float* mean;
-    const float* invstd;
-    const float* gamma;
-    const float* S12;
+    BnSrc bn;
+    const double* bstat;
     float drop_scale;
-    uint32_t drop_thresh;
-    uint64_t drop_key;
-    const unsigned long long* step_ptr;
     const uint8_t* drop_mask;
     int64_t ld_mask;
-    float* dbias_part;  // [nrb][n_p]
+    double* dbias;   // [n_p]
 };
 
-// pass 3: dZ = BN'(dA) * dropout' * leaky_relu'  and the per-workgroup column sums of dZ (bias grads)
-__global__ __launch_bounds__(256) void vae_bn_bwd_apply_kernel(const BnBwdArgs a) {
+__global__ __launch_bounds__(256) void vae_dz_kernel(const DzArgs a) {
     __shared__ float red[kRL][kCT + 1];
+    __shared__ float cf[3][kCT];
     const int col = blockIdx.x * kCT + threadIdx.x;
+    if (threadIdx.y == 0) {
+        float ca = 0.f, ch = 0.f, c0 = 0.f;
+        if (col < a.n_p) {
+            float mean, istd, sc, sh;
+            bn_column(a.bn, col, mean, istd, sc, sh);
+            const double inv_bs = 1.0 / (double)a.bs;
+            const float c1 = (float)(a.bstat[col] * inv_bs);
+            const float c2 = (float)(a.bstat[a.n_p + col] * inv_bs);
+            ca = a.drop_scale * istd * a.bn.gamma[col];
+            ch = -ca * istd * c2;
+            c0 = -ca * c1 - ch * mean;
+        }
+        cf[0][threadIdx.x] = ca; cf[1][threadIdx.x] = ch; cf[2][threadIdx.x] = c0;
+    }
+    __syncthreads();
+    const float ca = cf[0][threadIdx.x], ch = cf[1][threadIdx.x], c0 = cf[2][threadIdx.x];
     const int r0 = blockIdx.y * kRB, r1 = min(a.bs_p, r0 + kRB);
+    const bool hashed_drop = (a.drop_scale != 1.0f) && (a.drop_mask == nullptr);
     float s = 0.f;
     if (col < a.n_p) {
-        const float m = a.mean[col], is = a.invstd[col], gm = a.gamma[col];
-        const float c1 = a.S12[col] / (float)a.bs, c2 = a.S12[a.n_p + col] / (float)a.bs;
-        const bool use_drop = (a.drop_scale != 1.0f) || (a.drop_mask != nullptr);
-        const uint64_t key = step_key(a.drop_key, a.step_ptr);
         for (int r = r0 + threadIdx.y; r < r1; r += kRL) {
             const int64_t i = (int64_t)r * a.n_p + col;
             float dz = 0.f;
             if (r < a.bs) {
                 const float h = a.H[i];
-                const float xh = (h - m) * is;
-                float dh = is * gm * (a.DA[i] - c1 - xh * c2);
                 bool keep = true;
-                if (use_drop) {
-                    keep = a.drop_mask
-                               ? (a.drop_mask[(int64_t)r * a.ld_mask + col] != 0)
-                               : (hash32(key, (uint64_t)r * (uint64_t)a.n_p + (uint64_t)col) >= a.drop_thresh);
-                    dh *= a.drop_scale;
-                }
-                dz = keep ? dh * (h > 0.f ? 1.0f : kLeakySlope) : 0.f;
+                if (hashed_drop) keep = h != 0.f;
+                else if (a.drop_mask) keep = a.drop_mask[(int64_t)r * a.ld_mask + col] != 0;
+                const float lin = ca * a.DA[i] + ch * h + c0;
+                dz = keep ? lin * (h > 0.f ? 1.0f : kLeakySlope) : 0.f;
             }
             a.DZ[i] = dz;
             s += dz;
         }
     }
     s = column_block_sum(s, red);
-    if (threadIdx.y == 0 && col < a.n_p) a.dbias_part[(int64_t)blockIdx.y * a.n_p + col] = s;
+    if (threadIdx.y == 0 && col < a.n_p) atomicAdd(&a.dbias[col], (double)s);
 }
 
 // latent: dMU = (sum of the split-K slabs of dZlat) + KLD part (zero on padding rows); column partial
@@ -493,6 +473,7 @@ __global__ __launch_bounds__(256) void vae_latent_bwd_kernel(const float* __rest
 
 // ---- D-Adapt-Adam (dadaptation==3.2 DAdaptAdam.step as Vamb configures it, encode.py:578) ----------
 struct TensorDesc {
+    const double* dsrc;   // if non-null the gradient is this fp64 accumulator (bias / gamma / beta of hidden layers)
     const float* slab;    // gradient slabs; g[i] = sum_s slab[s*stride + i]
     int nslab;
     int64_t stride;
@@ -500,20 +481,49 @@ struct TensorDesc {
     int64_t size;         // padded element count actually used
 };
 
-// data-parallel path: G[flat] = sum of this rank's gradient slabs (then all-reduced over the ranks)
-__global__ __launch_bounds__(256) void vae_reduce_slabs_kernel(const TensorDesc* __restrict__ descs,
-                                                               const int* __restrict__ blk_tensor,
-                                                               const int* __restrict__ blk_local,
-                                                               float* __restrict__ G) {
-    const TensorDesc td = descs[blk_tensor[blockIdx.x]];
-    const int64_t local = (int64_t)blk_local[blockIdx.x] * 1024 + threadIdx.x * 4;
-    if (local >= td.size) return;
+// All parameter tensors of the model, passed BY VALUE in the kernel arguments (scalar loads, no
+// dependent global lookups): tensor t owns workgroups [blk_start[t], blk_start[t+1]), 1024 elements each.
+constexpr int kMaxOptTensors = 4 * 2 * 8 + 4;   // (W, b, gamma, beta) x (encoder + decoder) x 8 layers + mu + out
+struct OptTable {
+    int n;
+    int blk_start[kMaxOptTensors + 1];
+    TensorDesc d[kMaxOptTensors];
+};
+
+__device__ __forceinline__ int opt_find_tensor(const OptTable& tab, int blk) {
+    int t = 0;
+    while (t + 1 < tab.n && blk >= tab.blk_start[t + 1]) ++t;
+    return t;
+}
+
+__device__ __forceinline__ float4 fetch_grad(const TensorDesc& td, int64_t local) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (td.dsrc) {
+        g.x = (float)td.dsrc[local + 0]; g.y = (float)td.dsrc[local + 1];
+        g.z = (float)td.dsrc[local + 2]; g.w = (float)td.dsrc[local + 3];
+        return g;
+    }
+#pragma unroll 4
     for (int s = 0; s < td.nslab; ++s) {
         const float4 v = *reinterpret_cast<const float4*>(td.slab + (int64_t)s * td.stride + local);
         g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
     }
-    *reinterpret_cast<float4*>(G + td.p_off + local) = g;
+    return g;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// data-parallel path: G[flat] = sum of this rank's gradient slabs (then all-reduced over the ranks)
+__global__ __launch_bounds__(256) void vae_reduce_slabs_kernel(const OptTable tab, float* __restrict__ G) {
+    const int t = opt_find_tensor(tab, blockIdx.x);
+    const TensorDesc& td = tab.d[t];
+    const int64_t local = (int64_t)(blockIdx.x - tab.blk_start[t]) * 1024 + threadIdx.x * 4;
+    if (local >= td.size) return;
+    *reinterpret_cast<float4*>(G + td.p_off + local) = fetch_grad(td, local);
 }
 
 __global__ void vae_scale_kernel(float* __restrict__ v, int64_t n, float f) {
@@ -523,16 +533,14 @@ __global__ void vae_scale_kernel(float* __restrict__ v, int64_t n, float f) {
 
 // One pass over every parameter: moments, s, parameter update, and the two global reductions
 // (numerator dot and |s|_1) as per-workgroup partials.  Each workgroup covers 1024 elements of ONE tensor.
-__global__ __launch_bounds__(256) void vae_dadapt_kernel(const TensorDesc* __restrict__ descs,
-                                                         const int* __restrict__ blk_tensor,
-                                                         const int* __restrict__ blk_local,
-                                                         float* __restrict__ P, float* __restrict__ M1,
-                                                         float* __restrict__ M2, float* __restrict__ Sv,
-                                                         const StepState* __restrict__ st,
+__global__ __launch_bounds__(256) void vae_dadapt_kernel(const OptTable tab, float* __restrict__ P,
+                                                         float* __restrict__ M1, float* __restrict__ M2,
+                                                         float* __restrict__ Sv, const StepState* __restrict__ st,
                                                          double* __restrict__ partials /*[gridDim.x][2]*/) {
-    __shared__ double red[2][256];
-    const TensorDesc td = descs[blk_tensor[blockIdx.x]];
-    const int64_t local = (int64_t)blk_local[blockIdx.x] * 1024 + threadIdx.x * 4;
+    __shared__ double red[2][4];
+    const int t = opt_find_tensor(tab, blockIdx.x);
+    const TensorDesc& td = tab.d[t];
+    const int64_t local = (int64_t)(blockIdx.x - tab.blk_start[t]) * 1024 + threadIdx.x * 4;
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     const double sqrt_b2d = sqrt(0.999);
     const double dlr = st->d;  // lr == 1
@@ -543,11 +551,7 @@ __global__ __launch_bounds__(256) void vae_dadapt_kernel(const TensorDesc* __res
     const float one_m_b2 = (float)(1.0 - 0.999);
     float num = 0.f, sk = 0.f;
     if (local < td.size) {
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < td.nslab; ++s) {
-            const float4 v = *reinterpret_cast<const float4*>(td.slab + (int64_t)s * td.stride + local);
-            g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
-        }
+        float4 g = fetch_grad(td, local);
         g.x *= gscale; g.y *= gscale; g.z *= gscale; g.w *= gscale;
         const int64_t o = td.p_off + local;
         float4 p = *reinterpret_cast<float4*>(P + o), m = *reinterpret_cast<float4*>(M1 + o),
@@ -568,25 +572,22 @@ __global__ __launch_bounds__(256) void vae_dadapt_kernel(const TensorDesc* __res
         *reinterpret_cast<float4*>(M2 + o) = v;
         *reinterpret_cast<float4*>(Sv + o) = s;
     }
-    red[0][threadIdx.x] = (double)num;
-    red[1][threadIdx.x] = (double)sk;
+    const double wn = wave_sum_f64((double)num), ws = wave_sum_f64((double)sk);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = wn; red[1][wave] = ws; }
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + off];
-            red[1][threadIdx.x] += red[1][threadIdx.x + off];
-        }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        partials[(int64_t)blockIdx.x * 2 + 0] = red[0][0];
-        partials[(int64_t)blockIdx.x * 2 + 1] = red[1][0];
+        partials[(int64_t)blockIdx.x * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partials[(int64_t)blockIdx.x * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
 }
 
 // scalar part of DAdaptAdam.step: numerator_weighted, d_hat, d, k
+// ... and clears the hidden layers' fp64 batch accumulators for the next step (every reader has finished).
 __global__ __launch_bounds__(256) void vae_dadapt_finalize_kernel(const double* __restrict__ partials, int nblocks,
-                                                                  StepState* __restrict__ st) {
+                                                                  StepState* __restrict__ st,
+                                                                  double* __restrict__ statbuf, int nstat) {
+    for (int i = threadIdx.x; i < nstat; i += 256) statbuf[i] = 0.0;
     __shared__ double red[2][256];
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += 256) {

@@ -369,24 +369,30 @@ class VAE:
             data_loader = set_batchsize(data_loader, data_loader.batch_size * 2, n_seq)
         bs = data_loader.batch_size
         means = (ctypes.c_double * 5)()
-        # RandomSampler semantics: a fresh permutation per epoch; drop the ragged tail iff n > batch
-        perm = _torch.randperm(n_seq).numpy()
+        # RandomSampler semantics: a fresh shuffle per epoch, the ragged tail dropped iff n > batch.  The
+        # shuffle itself happens on the device (perm = NULL): no host randperm, no upload.
         if self._comm is not None:
-            # data parallel: `bs` is the ALL-RANK batch; this rank contributes bs / world local rows
-            from . import parallel as _parallel
-
-            weights = data_loader.dataset.tensors[3].numpy()
-            rows, n_batches, batch, gwsum = _parallel.plan_epoch(self._comm, n_seq, bs, weights, perm)
-            _lib.check(self._lib.vh_vae_train_epoch_dp(self._h, _lib.ptr(rows), n_batches, batch, bs,
-                                                       _lib.ptr(gwsum), means))
+            # data parallel: `bs` is the ALL-RANK batch; this rank contributes bs / world local rows and
+            # every rank must run the same number of collective steps
+            world = self._comm.world
+            if bs % world != 0:
+                raise ValueError(f"global batch {bs} is not divisible by the number of GPUs {world}")
+            batch = bs // world
+            if n_seq < batch:
+                raise ValueError(f"shard of {n_seq} rows is smaller than the per-GPU batch {batch}")
+            key = (n_seq, batch)
+            if getattr(self, "_dp_plan_key", None) != key:
+                nb = self._comm.all_reduce_min(_np.array([n_seq // batch], dtype=_np.int64))
+                self._dp_plan_key, self._dp_batches = key, int(nb[0])
+            n_batches = self._dp_batches
+            _lib.check(self._lib.vh_vae_train_epoch_dp(self._h, None, n_batches, batch, bs, None, means))
         else:
             if n_seq > bs:
                 n_batches = n_seq // bs
                 batch = bs
             else:
                 n_batches, batch = 1, n_seq
-            perm = _np.ascontiguousarray(perm[: n_batches * batch], dtype=_np.int64)
-            _lib.check(self._lib.vh_vae_train_epoch(self._h, _lib.ptr(perm), n_batches, batch, means))
+            _lib.check(self._lib.vh_vae_train_epoch(self._h, None, n_batches, batch, means))
         loss, ab, ce, sse, kld = tuple(means)
         logger.info(
             "\t\tEpoch: {:>3}  Loss: {:.5e}  CE: {:.5e}  AB: {:.5e}  SSE: {:.5e}  KLD: {:.5e}  Batchsize: {:>4}".format(
