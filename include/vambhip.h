@@ -74,6 +74,14 @@ int vh_clu_rows(vh_clu* h, int64_t* n_rows, int64_t* n_live);
  * are the rows medoid_rows[j] of this handle; otherwise queries is a host [k][L] array. 1 <= k <= 32. */
 int vh_clu_scan(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries, vh_scan_result* out);
 
+/* The scan also keeps, per medoid, the ascending rows within the medoid radius (sample_medoid's `cluster`
+ * tensor, cluster.py:621-626) on the device for the last 16 scans.  vh_clu_scan_seq returns the sequence
+ * number the NEXT scan will get; vh_clu_scan_list(h, seq, j, ...) returns medoid j's list of scan `seq`, or
+ * *n_out = -1 when that scan has left the ring or the list overflowed its 2048 entries (then use
+ * vh_clu_select with threshold 0.05f). */
+int vh_clu_scan_seq(vh_clu* h, int64_t* seq);
+int vh_clu_scan_list(vh_clu* h, int64_t seq, int j, int64_t* out_rows, int64_t cap, int64_t* n_out);
+
 /* _smaller_indices (cluster.py:640-650) / the `within` list of sample_medoid (cluster.py:621-626):
  * ascending physical rows that are live and have d <= threshold (float32 compare).  Writes at most
  * cap indices, returns the true count in *n_out.  remove != 0 also clears their live flag

@@ -53,9 +53,37 @@ def test_scan_accumulators_bit_exact(oracle_lib, n, L, k):
         assert g.n_within == w["n_within"] and g.n_lt == w["n_lt"], med
         assert np.array_equal(g.hist_fx, w["hist_fx"]), med
         assert g.density == co.density_value(w["density_fx"]), med
+        # the list the scan left on the device == a select pass at the medoid radius
+        assert np.array_equal(b.scan_list(g.list_ref), co.select(m, kept, med, 0.05)), med
         for thr in (0.05, 0.06, 0.123456, 0.3):
             rows = b.select(med, thr, remove=False)
             assert np.array_equal(rows, co.select(m, kept, med, thr)), (med, thr)
+    b.close()
+
+
+def test_scan_list_overflow_and_ring_expiry(oracle_lib):
+    """Lists longer than the device capacity (2048) and scans that left the 16-deep ring report None, and the
+    generator then falls back to a select pass with the same result."""
+    n, L = 6000, 32
+    rng = np.random.RandomState(4)
+    centre = rng.randn(L).astype(np.float32)
+    lat = (centre[None, :] + 0.01 * rng.randn(n, L)).astype(np.float32)    # one tight blob: every row within 0.05
+    lat[:50] = rng.randn(50, L)                                             # and a few far rows with short lists
+    lens = synth.lengths(n, 4)
+    m = co.normalize(lat.copy())
+    kept = np.ones(n, np.uint8)
+    b = _mk(m, lens, True)
+    st_big, st_small = b.scan([100, 3])
+    assert st_big.n_within > 2048 and b.scan_list(st_big.list_ref) is None
+    assert np.array_equal(b.scan_list(st_small.list_ref), co.select(m, kept, 3, 0.05))
+    gen = vc.ClusterGenerator.from_backend(b, lens, rng_seed=0)
+    gen._ensure_stats([100])
+    assert np.array_equal(gen._within(100), co.select(m, kept, 100, 0.05))
+    old = b.scan([7])[0]
+    for _ in range(16):
+        b.scan([8])
+    assert b.scan_list(old.list_ref) is None
+    assert np.array_equal(b.scan_list(b.scan([7])[0].list_ref), co.select(m, kept, 7, 0.05))
     b.close()
 
 

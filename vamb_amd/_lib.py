@@ -48,6 +48,8 @@ SIGNATURES = {
     "vh_clu_destroy": (_int, [_vp]),
     "vh_clu_rows": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "vh_clu_scan": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "vh_clu_scan_seq": (_int, [_vp, ctypes.POINTER(_i64)]),
+    "vh_clu_scan_list": (_int, [_vp, _i64, _int, _vp, _i64, ctypes.POINTER(_i64)]),
     "vh_clu_select": (_int, [_vp, _i64, _vp, _f32, _int, _vp, _i64, ctypes.POINTER(_i64)]),
     "vh_clu_remove": (_int, [_vp, _vp, _i64]),
     "vh_clu_pack": (_int, [_vp, ctypes.POINTER(_i64)]),

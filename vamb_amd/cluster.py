@@ -86,7 +86,7 @@ class Cluster:
 class ScanStats:
     """What one medoid scan returns to the host (all exact)."""
 
-    __slots__ = ("density", "n_within", "n_lt", "hist_fx")
+    __slots__ = ("density", "n_within", "n_lt", "hist_fx", "list_ref")
 
     def __init__(self, density_fx: int, n_within: int, n_lt: int, hist_fx: _np.ndarray):
         # the python float the reference gets from `.sum().item()` on a float32 tensor (cluster.py:629)
@@ -94,6 +94,9 @@ class ScanStats:
         self.n_within = n_within
         self.n_lt = n_lt
         self.hist_fx = hist_fx
+        # (scan sequence number, medoid slot) of the device-side list of rows within the medoid radius,
+        # or None when the backend keeps no such list (then the host asks for a select pass)
+        self.list_ref = None
 
 
 class HipScanBackend:
@@ -157,11 +160,25 @@ class HipScanBackend:
     def scan(self, medoids):
         """List of physical rows -> list of ScanStats (one pass per <= 32 medoids)."""
         out = []
+        seq = ctypes.c_int64(0)
         for lo in range(0, len(medoids), _MAX_MEDOIDS_PER_PASS):
+            _lib.check(self.lib.vh_clu_scan_seq(self.h, ctypes.byref(seq)))
             raw = self.scan_raw(medoids[lo:lo + _MAX_MEDOIDS_PER_PASS])
-            for r in raw:
-                out.append(ScanStats(int(r[0]), int(r[_NBINS + 1]), int(r[_NBINS + 2]), r[1:_NBINS + 1]))
+            for j, r in enumerate(raw):
+                st = ScanStats(int(r[0]), int(r[_NBINS + 1]), int(r[_NBINS + 2]), r[1:_NBINS + 1])
+                st.list_ref = (seq.value, j)
+                out.append(st)
         return out
+
+    def scan_list(self, list_ref) -> Optional[_np.ndarray]:
+        """Ascending rows within the medoid radius recorded by the scan `list_ref` came from, or None when
+        that scan has left the device ring / the list overflowed (the caller then runs a select pass)."""
+        n = ctypes.c_int64(0)
+        _lib.check(self.lib.vh_clu_scan_list(self.h, int(list_ref[0]), int(list_ref[1]), _lib.ptr(self._sel),
+                                             len(self._sel), ctypes.byref(n)))
+        if n.value < 0:
+            return None
+        return self._sel[: n.value].copy()
 
     def get_rows(self, rows) -> _np.ndarray:
         rows = _np.ascontiguousarray(rows, dtype=_np.int64)
@@ -435,7 +452,14 @@ class ClusterGenerator:
     def _within(self, medoid: int) -> _np.ndarray:
         hit = self._within_cache.get(medoid)
         if hit is None:
-            hit = self._backend.select(medoid, _MEDOID_RADIUS, remove=False)
+            st = self._stats_cache.get(medoid)
+            fetch = getattr(self._backend, "scan_list", None)
+            if st is not None and st.list_ref is not None and fetch is not None:
+                hit = fetch(st.list_ref)
+                if hit is not None:
+                    assert len(hit) == st.n_within
+            if hit is None:
+                hit = self._backend.select(medoid, _MEDOID_RADIUS, remove=False)
             self._within_cache[medoid] = hit
         return hit
 

@@ -30,8 +30,15 @@ namespace {
 constexpr int kRowsPerThread = 4;
 constexpr int kBlock = 256;
 constexpr int kRowsPerBlock = kBlock * kRowsPerThread;  // 1024
-constexpr int kResultWords = VH_NBINS + 3;              // density, hist[60], n_within, n_lt
+constexpr int kResultWords = VH_NBINS + 4;              // density, hist[60], n_within, n_lt, list cursor
 constexpr int kMaxMedoids = 32;
+constexpr int kListCap = 2048;    // rows within the medoid radius kept per medoid by the scan itself
+constexpr int kListRing = 16;     // scans whose lists stay readable (one cluster search rarely needs more)
+
+// medoid rows travel in the kernel arguments (no upload, no gather launch)
+struct MedoidRows {
+    long long row[kMaxMedoids];
+};
 
 // torch.linspace(0.0, 0.3, 61) float32 bit patterns (== edges torch.histogram writes, cluster.py:288,
 // 475-481).  tests/test_lib_abi.py asserts the table equals torch.linspace.
@@ -81,15 +88,6 @@ __global__ __launch_bounds__(64) void clu_normalize_transpose_kernel(float* __re
         r[k] = y;
         Mt[(int64_t)k * ld + row] = y;
     }
-}
-
-// gather query rows from the SoA matrix: q[j][c] = Mt[c][rows[j]]   (zero for the pad columns)
-__global__ void clu_gather_queries_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
-                                          const int64_t* __restrict__ rows, int k, float* __restrict__ q) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= k * L4) return;
-    const int j = idx / L4, c = idx - j * L4;
-    q[idx] = Mt[(int64_t)c * ld + rows[j]];
 }
 
 // row-major gather of arbitrary rows (get_rows): out[i][c] = Mt[c][rows ? rows[i] : i]
@@ -143,20 +141,23 @@ template <int KM, int RPT>
 __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
                                                           const float* __restrict__ lengths,
                                                           const uint8_t* __restrict__ kept, int64_t n,
-                                                          const float* __restrict__ q,
-                                                          const int64_t* __restrict__ medoid,
-                                                          unsigned long long* __restrict__ results) {
+                                                          const float* __restrict__ q_ext,
+                                                          const MedoidRows medoid,
+                                                          unsigned long long* __restrict__ results,
+                                                          int32_t* __restrict__ lists) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(smem_raw);       // [KM][kResultWords]
-    long long* med_s = reinterpret_cast<long long*>(acc_s + KM * kResultWords);         // [KM]
-    float* edges_s = reinterpret_cast<float*>(med_s + KM);                              // [64]
+    float* edges_s = reinterpret_cast<float*>(acc_s + KM * kResultWords);               // [64]
     float* q_s = edges_s + 64;                                                          // [KM][L4]
 
     const int tid = threadIdx.x;
     for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
-    for (int i = tid; i < KM; i += kBlock) med_s[i] = medoid[i];
     for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
-    for (int i = tid; i < KM * L4; i += kBlock) q_s[i] = q[i];
+    // query vectors: explicit (row-sharded execution) or row medoid.row[j] of the resident matrix
+    for (int i = tid; i < KM * L4; i += kBlock) {
+        const int j = i / L4, c = i - j * L4;
+        q_s[i] = q_ext ? q_ext[i] : Mt[(int64_t)c * ld + medoid.row[j]];
+    }
     __syncthreads();
 
     const float radius = 0.05f;
@@ -197,19 +198,23 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
         load_rows<RPT>(lengths + base, len);
 #pragma unroll
         for (int j = 0; j < KM; ++j) {
-            const long long med = med_s[j];
+            const long long med = medoid.row[j];
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
                 if (!live[r]) continue;
                 float d = 0.5f - acc[j][r];
                 if (base + r == med) d = 0.0f;
                 // rows inside the medoid radius are rare: accumulate straight into LDS (exact integers)
+                // and append the row to the medoid's candidate list (sample_medoid's `cluster`, cluster.py:621-626)
                 if (d <= radius) {
                     const float p = len[r] * (radius - d);
                     const long long pf = __double2ll_rn((double)p * VH_DENSITY_SCALE);
                     atomicAdd(&acc_s[j * kResultWords + 0], (unsigned long long)pf);
                     atomicAdd(&acc_s[j * kResultWords + 1 + VH_NBINS], 1ull);
                     if (d < radius) atomicAdd(&acc_s[j * kResultWords + 2 + VH_NBINS], 1ull);
+                    const unsigned int pos =
+                        atomicAdd(reinterpret_cast<unsigned int*>(&results[j * kResultWords + 3 + VH_NBINS]), 1u);
+                    if (pos < (unsigned int)kListCap) lists[j * kListCap + pos] = (int32_t)(base + r);
                 }
                 const int b = bin_of(d, edges_s);
                 if (b >= 0) {
@@ -233,14 +238,14 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void clu_select_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
                                                             uint8_t* __restrict__ kept, int64_t n,
-                                                            const float* __restrict__ q, int64_t medoid,
+                                                            const float* __restrict__ q_ext, int64_t medoid,
                                                             float threshold, int remove,
                                                             int32_t* __restrict__ out_rows,
                                                             unsigned int* __restrict__ out_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* q_s = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x;
-    for (int i = tid; i < L4; i += kBlock) q_s[i] = q[i];
+    for (int i = tid; i < L4; i += kBlock) q_s[i] = q_ext ? q_ext[i] : Mt[(int64_t)i * ld + medoid];
     __syncthreads();
     const int lane = tid & 63;
 
@@ -417,19 +422,23 @@ struct vh_clu {
     hipStream_t stream = nullptr;
     DevBuf<float> Mt, Mt_alt, lengths, lengths_alt, q;
     DevBuf<uint8_t> kept;
-    DevBuf<int64_t> medoids;
     DevBuf<unsigned long long> results;
+    DevBuf<int32_t> lists;        // [kListRing][kMaxMedoids][kListCap] rows within the medoid radius, per scan
+    uint64_t scan_seq = 0;        // number of scans issued; scan s wrote ring slot s % kListRing
+    int last_k = 0;
+    std::vector<unsigned int> last_counts[kListRing];   // list lengths of the scans still in the ring
+    hipEvent_t ev_done = nullptr; // recorded after the result copy: the host waits on it, not on the stream
     DevBuf<int32_t> sel_rows;   // select output / pack source list
     DevBuf<unsigned int> counts;  // [0]: select counter; [1..]: pack block counts
     DevBuf<unsigned long long> total;
     DevBuf<int64_t> row_idx;
     PinnedBuf<unsigned long long> h_results;
-    PinnedBuf<int64_t> h_medoids;
     PinnedBuf<float> h_q;
     std::vector<int32_t> h_sel;
     EventTimer timer;
 
     ~vh_clu() {
+        if (ev_done) (void)hipEventDestroy(ev_done);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -437,25 +446,25 @@ struct vh_clu {
 namespace {
 
 template <int KM>
-void launch_scan(vh_clu* h) {
+void launch_scan(vh_clu* h, const MedoidRows& med, const float* q_ext, int32_t* lists) {
     constexpr int RPT = (KM >= 12) ? 2 : 4;
-    const size_t smem = (size_t)KM * kResultWords * 8 + (size_t)KM * 8 + 64 * 4 + (size_t)KM * h->L4 * 4;
+    const size_t smem = (size_t)KM * kResultWords * 8 + 64 * 4 + (size_t)KM * h->L4 * 4;
     const int64_t blocks = ceil_div(h->ld, (int64_t)kBlock * RPT);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
     hipLaunchKernelGGL((clu_scan_kernel<KM, RPT>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
-                       h->lengths.p, h->kept.p, h->ld, h->q.p, h->medoids.p, h->results.p);
+                       h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, lists);
 }
 
-void dispatch_scan(vh_clu* h, int km) {
+void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext, int32_t* lists) {
     switch (km) {
-        case 1: launch_scan<1>(h); break;
-        case 2: launch_scan<2>(h); break;
-        case 4: launch_scan<4>(h); break;
-        case 8: launch_scan<8>(h); break;
-        case 12: launch_scan<12>(h); break;
-        case 16: launch_scan<16>(h); break;
-        case 24: launch_scan<24>(h); break;
-        default: launch_scan<32>(h); break;
+        case 1: launch_scan<1>(h, med, q_ext, lists); break;
+        case 2: launch_scan<2>(h, med, q_ext, lists); break;
+        case 4: launch_scan<4>(h, med, q_ext, lists); break;
+        case 8: launch_scan<8>(h, med, q_ext, lists); break;
+        case 12: launch_scan<12>(h, med, q_ext, lists); break;
+        case 16: launch_scan<16>(h, med, q_ext, lists); break;
+        case 24: launch_scan<24>(h, med, q_ext, lists); break;
+        default: launch_scan<32>(h, med, q_ext, lists); break;
     }
     VH_HIP(hipGetLastError());
 }
@@ -501,12 +510,14 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->lengths.alloc((size_t)h->ld);
         h->kept.alloc((size_t)h->ld);
         h->q.alloc((size_t)kMaxMedoids * h->L4);
-        h->medoids.alloc(kMaxMedoids);
         h->results.alloc((size_t)kMaxMedoids * kResultWords);
+        h->lists.alloc((size_t)kListRing * kMaxMedoids * kListCap);
+        VH_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+        VH_HIP(hipMemsetAsync(h->results.p, 0, h->results.bytes(), h->stream));
         h->counts.alloc((size_t)(1 + h->ld / kRowsPerBlock));
+        VH_HIP(hipMemsetAsync(h->counts.p, 0, sizeof(unsigned int), h->stream));
         h->total.alloc(1);
         h->h_results.ensure((size_t)kMaxMedoids * kResultWords);
-        h->h_medoids.ensure(kMaxMedoids);
         h->h_q.ensure((size_t)kMaxMedoids * h->L4);
 
         DevBuf<float> staging;
@@ -559,14 +570,14 @@ int vh_clu_scan(vh_clu* h, int k, const int64_t* medoid_rows, const float* queri
         VH_REQUIRE(h != nullptr && medoid_rows != nullptr && out != nullptr, "NULL argument");
         VH_REQUIRE(k >= 1 && k <= kMaxMedoids, "k=%d outside [1, %d]", k, kMaxMedoids);
         const int km = pick_km(k);
-        for (int j = 0; j < km; ++j) {
+        MedoidRows med;
+        for (int j = 0; j < kMaxMedoids; ++j) {
             const int64_t m = medoid_rows[j < k ? j : 0];
             VH_REQUIRE(m >= -1 && m < h->n_rows, "medoid row %lld out of range", (long long)m);
             VH_REQUIRE(queries != nullptr || m >= 0, "medoid row -1 needs an explicit query vector");
-            h->h_medoids.p[j] = m;
+            med.row[j] = m;
         }
-        VH_HIP(hipMemcpyAsync(h->medoids.p, h->h_medoids.p, (size_t)km * sizeof(int64_t), hipMemcpyHostToDevice,
-                              h->stream));
+        const float* q_ext = nullptr;
         if (queries) {
             for (int j = 0; j < km; ++j) {
                 const float* src = queries + (size_t)(j < k ? j : 0) * h->L;
@@ -575,27 +586,64 @@ int vh_clu_scan(vh_clu* h, int k, const int64_t* medoid_rows, const float* queri
             }
             VH_HIP(hipMemcpyAsync(h->q.p, h->h_q.p, (size_t)km * h->L4 * sizeof(float), hipMemcpyHostToDevice,
                                   h->stream));
-        } else {
-            const int tot = km * h->L4;
-            hipLaunchKernelGGL(clu_gather_queries_kernel, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->Mt.p,
-                               h->ld, h->L4, h->medoids.p, km, h->q.p);
-            VH_HIP(hipGetLastError());
+            q_ext = h->q.p;
         }
-        VH_HIP(hipMemsetAsync(h->results.p, 0, (size_t)km * kResultWords * 8, h->stream));
+        // One launch + one small copy per scan.  The accumulators were zeroed by the trailing memset of
+        // the previous scan (stream order), the medoid rows travel in the kernel arguments and the query
+        // vectors are gathered by the kernel itself.
+        const int slot = (int)(h->scan_seq % kListRing);
+        int32_t* lists = h->lists.p + (size_t)slot * kMaxMedoids * kListCap;
         h->timer.start(h->stream);
-        dispatch_scan(h, km);
+        dispatch_scan(h, km, med, q_ext, lists);
         h->timer.stop(h->stream);
         VH_HIP(hipMemcpyAsync(h->h_results.p, h->results.p, (size_t)k * kResultWords * 8, hipMemcpyDeviceToHost,
                               h->stream));
-        VH_HIP(hipStreamSynchronize(h->stream));
+        VH_HIP(hipEventRecord(h->ev_done, h->stream));
+        VH_HIP(hipMemsetAsync(h->results.p, 0, (size_t)km * kResultWords * 8, h->stream));  // for the next scan
+        VH_HIP(hipEventSynchronize(h->ev_done));
         h->timer.collect();
+        h->last_counts[slot].assign(kMaxMedoids, 0u);
         for (int j = 0; j < k; ++j) {
             const unsigned long long* r = h->h_results.p + (size_t)j * kResultWords;
             out[j].density_fx = (int64_t)r[0];
             for (int b = 0; b < VH_NBINS; ++b) out[j].hist_fx[b] = (int64_t)r[1 + b];
             out[j].n_within = (int64_t)r[1 + VH_NBINS];
             out[j].n_lt = (int64_t)r[2 + VH_NBINS];
+            h->last_counts[slot][j] = (unsigned int)r[3 + VH_NBINS];
         }
+        h->last_k = k;
+        h->scan_seq++;
+    });
+}
+
+int vh_clu_scan_seq(vh_clu* h, int64_t* seq) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && seq != nullptr, "NULL argument");
+        *seq = (int64_t)h->scan_seq;
+    });
+}
+
+int vh_clu_scan_list(vh_clu* h, int64_t seq, int j, int64_t* out_rows, int64_t cap, int64_t* n_out) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && n_out != nullptr, "NULL argument");
+        VH_REQUIRE(j >= 0 && j < kMaxMedoids, "medoid index out of range");
+        *n_out = -1;
+        // seq is the value vh_clu_scan_seq returned BEFORE the scan, i.e. the scan's own sequence number
+        if (seq < 0 || (uint64_t)seq >= h->scan_seq || h->scan_seq - (uint64_t)seq > (uint64_t)kListRing) return;
+        const int slot = (int)((uint64_t)seq % kListRing);
+        if (h->last_counts[slot].empty()) return;
+        const unsigned int cnt = h->last_counts[slot][j];
+        if (cnt > (unsigned int)kListCap) return;   // the list overflowed: the caller falls back to vh_clu_select
+        VH_REQUIRE(cap >= (int64_t)cnt && (cnt == 0 || out_rows != nullptr), "output buffer too small");
+        h->h_sel.resize(cnt);
+        if (cnt) {
+            VH_HIP(hipMemcpyAsync(h->h_sel.data(), h->lists.p + ((size_t)slot * kMaxMedoids + j) * kListCap,
+                                  (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            VH_HIP(hipStreamSynchronize(h->stream));
+            std::sort(h->h_sel.begin(), h->h_sel.end());
+        }
+        for (unsigned int i = 0; i < cnt; ++i) out_rows[i] = h->h_sel[i];
+        *n_out = cnt;
     });
 }
 
@@ -607,27 +655,25 @@ int vh_clu_select(vh_clu* h, int64_t medoid_row, const float* query, float thres
         VH_REQUIRE(query != nullptr || medoid_row >= 0, "medoid row -1 needs an explicit query vector");
         VH_REQUIRE(cap >= 0 && (cap == 0 || out_rows != nullptr), "bad output buffer");
         h->sel_rows.ensure((size_t)h->ld);
+        const float* q_ext = nullptr;
         if (query) {
             for (int c = 0; c < h->L4; ++c) h->h_q.p[c] = c < h->L ? query[c] : 0.0f;
             VH_HIP(hipMemcpyAsync(h->q.p, h->h_q.p, (size_t)h->L4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        } else {
-            h->h_medoids.p[0] = medoid_row;
-            VH_HIP(hipMemcpyAsync(h->medoids.p, h->h_medoids.p, sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-            hipLaunchKernelGGL(clu_gather_queries_kernel, dim3((h->L4 + 255) / 256), dim3(256), 0, h->stream, h->Mt.p,
-                               h->ld, h->L4, h->medoids.p, 1, h->q.p);
-            VH_HIP(hipGetLastError());
+            q_ext = h->q.p;
         }
-        VH_HIP(hipMemsetAsync(h->counts.p, 0, sizeof(unsigned int), h->stream));
+        // counts[0] is zero on entry (creation / trailing memset of the previous select)
         h->timer.start(h->stream);
         hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
-                           h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, h->q.p, medoid_row, threshold, remove,
+                           h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, q_ext, medoid_row, threshold, remove,
                            h->sel_rows.p, h->counts.p);
         VH_HIP(hipGetLastError());
         h->timer.stop(h->stream);
-        unsigned int cnt = 0;
-        VH_HIP(hipMemcpyAsync(&cnt, h->counts.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
-        VH_HIP(hipStreamSynchronize(h->stream));
+        VH_HIP(hipMemcpyAsync(h->h_results.p, h->counts.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+        VH_HIP(hipEventRecord(h->ev_done, h->stream));
+        VH_HIP(hipMemsetAsync(h->counts.p, 0, sizeof(unsigned int), h->stream));
+        VH_HIP(hipEventSynchronize(h->ev_done));
         h->timer.collect();
+        const unsigned int cnt = *reinterpret_cast<const unsigned int*>(h->h_results.p);
         h->h_sel.resize(cnt);
         if (cnt) {
             VH_HIP(hipMemcpyAsync(h->h_sel.data(), h->sel_rows.p, (size_t)cnt * sizeof(int32_t),
