@@ -242,7 +242,7 @@ def main():
                 "epochs": args.epochs, "parallelism": f"dp{world}" if world > 1 else "single",
             },
             "roofline": {
-                "kernel": "gemm_f32_kernel<64,128,KC,KC,HIDDEN_TRAIN> (encoder layer 0: M=batch, K=D, N=512)",
+                "kernel": "gemm_f32_kernel<64,64,2x2 waves,EPI_HIDDEN_TRAIN> (encoder layer 0: M=batch, K=D, N=512; bias+leaky-relu+dropout+BN batch sums fused)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS if probe_n else None, "traffic": None,
                 "avg_launch_ms": avg_ms, "launches": probe_n, "flops_per_launch": flops,

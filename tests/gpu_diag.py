@@ -72,6 +72,15 @@ def scan_bench():
             bytes_ = n * (4 * ((L + 3) // 4 * 4) + 5)
             res.append(dict(n=n, L=L, k=k, kernel_ms=kms, wall_ms=wall, GBps=bytes_ / (kms * 1e-3) / 1e9))
             print("scan", res[-1])
+            if k in (1, 16):
+                # the same pass with explicit query vectors (the row-sharded path): isolates the in-kernel gather
+                q = b.get_rows(meds)
+                b.scan_raw(meds, queries=q)
+                b.kernel_ms = 0.0
+                for _ in range(reps):
+                    b.scan_raw(meds, queries=q)
+                res.append(dict(n=n, L=L, k=k, mode="explicit_queries", kernel_ms=b.kernel_ms / reps))
+                print("scan", res[-1])
         b.kernel_ms = 0.0
         t0 = time.perf_counter()
         for _ in range(5):

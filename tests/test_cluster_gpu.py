@@ -54,7 +54,11 @@ def test_scan_accumulators_bit_exact(oracle_lib, n, L, k):
         assert np.array_equal(g.hist_fx, w["hist_fx"]), med
         assert g.density == co.density_value(w["density_fx"]), med
         # the list the scan left on the device == a select pass at the medoid radius
-        assert np.array_equal(b.scan_list(g.list_ref), co.select(m, kept, med, 0.05)), med
+        lst = b.scan_list(g.list_ref)
+        if lst is None:   # a block ran out of its 128 staging slots (or > 2048 rows): the caller selects instead
+            assert g.n_within > 128, med
+        else:
+            assert np.array_equal(lst, co.select(m, kept, med, 0.05)), med
         for thr in (0.05, 0.06, 0.123456, 0.3):
             rows = b.select(med, thr, remove=False)
             assert np.array_equal(rows, co.select(m, kept, med, thr)), (med, thr)

@@ -98,6 +98,23 @@ class ScanStats:
         # or None when the backend keeps no such list (then the host asks for a select pass)
         self.list_ref = None
 
+    @classmethod
+    def batch(cls, raw: _np.ndarray, seq=None) -> list:
+        """ScanStats for every row of a raw accumulator block [k, 63] (vectorised conversions)."""
+        dens = (raw[:, 0] / _lib.DENSITY_SCALE).astype(_np.float32).astype(_np.float64).tolist()
+        n_within = raw[:, _NBINS + 1].tolist()
+        n_lt = raw[:, _NBINS + 2].tolist()
+        out = []
+        for j in range(len(raw)):
+            st = cls.__new__(cls)
+            st.density = dens[j]
+            st.n_within = n_within[j]
+            st.n_lt = n_lt[j]
+            st.hist_fx = raw[j, 1:_NBINS + 1]
+            st.list_ref = None if seq is None else (seq, j)
+            out.append(st)
+        return out
+
 
 class HipScanBackend:
     """Single-GPU backend: one ``vh_clu`` handle holding the whole matrix."""
@@ -164,10 +181,7 @@ class HipScanBackend:
         for lo in range(0, len(medoids), _MAX_MEDOIDS_PER_PASS):
             _lib.check(self.lib.vh_clu_scan_seq(self.h, ctypes.byref(seq)))
             raw = self.scan_raw(medoids[lo:lo + _MAX_MEDOIDS_PER_PASS])
-            for j, r in enumerate(raw):
-                st = ScanStats(int(r[0]), int(r[_NBINS + 1]), int(r[_NBINS + 2]), r[1:_NBINS + 1])
-                st.list_ref = (seq.value, j)
-                out.append(st)
+            out.extend(ScanStats.batch(raw, seq.value))
         return out
 
     def scan_list(self, list_ref) -> Optional[_np.ndarray]:
@@ -235,10 +249,15 @@ class _MatrixView:
 def smooth_histogram(histogram: _np.ndarray) -> _np.ndarray:
     """31-tap smoothing of the 60-bin histogram, float32 multiply then float32 add in ascending bin
     order (cluster.py:495-500); returns the 60 densities of cluster.py:500."""
+    # densities[k] = sum_i pdf[k - i] * hist[i], products and running sum in float32, i ascending.  Walking
+    # the taps from the last to the first adds, for every k, the terms in ascending i -- the order of the
+    # reference's `densities[i:i+31] += pdf * histogram[i]` loop -- with 31 vector adds instead of 60.
     pdf_len = len(_NORMALPDF)
-    densities = _np.zeros(len(histogram) + pdf_len - 1, dtype=_np.float32)
-    for i in range(len(histogram)):
-        densities[i:i + pdf_len] += _NORMALPDF * histogram[i]
+    n = len(histogram)
+    histogram = _np.asarray(histogram, dtype=_np.float32)
+    densities = _np.zeros(n + pdf_len - 1, dtype=_np.float32)
+    for t in range(pdf_len - 1, -1, -1):
+        densities[t:t + n] += _NORMALPDF[t] * histogram
     return densities[15:-15]
 
 
@@ -367,6 +386,7 @@ class ClusterGenerator:
         n = self._backend.n_rows
         self.indices = _np.arange(n)                       # original row of every resident row
         self._kept = _np.ones(n, dtype=bool)               # host mirror of the device live mask
+        self._alive = _np.ones(n, dtype=bool)              # the same, indexed by ORIGINAL contig index
         self.order = _np.argsort(lengths)[::-1].copy()     # same call as cluster.py:275
         self.order_index = 0
         self.n_emitted_clusters = 0
@@ -391,6 +411,7 @@ class ClusterGenerator:
         self.n_emitted_clusters += 1
         self.n_remaining_points -= len(points)
         self._kept[points] = False
+        self._alive[self.indices[points]] = False
         n_rows = len(self._kept)
         if (self.n_remaining_points > 0 and n_rows >= self.PACK_MIN_ROWS
                 and self.n_remaining_points < self.PACK_FRACTION * n_rows):
@@ -413,22 +434,30 @@ class ClusterGenerator:
 
     # cluster.py:342-384
     def get_next_seed(self) -> int:
+        """Next live contig in descending-length order.  Same walk as the reference (dead entries are
+        overwritten with -1 as they are passed, the order array is compacted on every wrap-around once a
+        cluster has been emitted), but dead runs are skipped a vectorised chunk at a time."""
         n_order = len(self.order)
-        i = self.order_index - 1
+        i = self.order_index % n_order
+        chunk = 64
         while True:
-            i = (i + 1) % n_order
             if i == 0 and self.n_emitted_clusters > 0:
                 self.pack_order()
                 n_order = len(self.order)
-            order = self.order[i]
-            if order == -1:
-                continue
-            row = int(_np.searchsorted(self.indices, order))
-            if row >= len(self.indices) or self.indices[row] != order or not self._kept[row]:
-                self.order[i] = -1
-                continue
-            self.order_index = i + 1
-            return row
+            hi = min(i + chunk, n_order)
+            seg = self.order[i:hi]
+            live = seg > -1
+            live[live] = self._alive[seg[live]]
+            if live.any():
+                pos = int(live.argmax())
+                seg[:pos] = -1
+                self.order_index = i + pos + 1
+                row = int(_np.searchsorted(self.indices, seg[pos]))
+                assert self.indices[row] == seg[pos] and self._kept[row]
+                return row
+            seg[:] = -1
+            i = hi % n_order
+            chunk = min(chunk * 4, 1 << 16)
 
     # cluster.py:386-413
     def update_successes(self, success: bool):

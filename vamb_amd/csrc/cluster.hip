@@ -17,6 +17,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 
 namespace vh {
@@ -34,6 +35,7 @@ constexpr int kResultWords = VH_NBINS + 4;              // density, hist[60], n_
 constexpr int kMaxMedoids = 32;
 constexpr int kListCap = 2048;    // rows within the medoid radius kept per medoid by the scan itself
 constexpr int kListRing = 16;     // scans whose lists stay readable (one cluster search rarely needs more)
+constexpr int kLocalCap = 128;    // per-block, per-medoid staging of list entries in LDS
 
 // medoid rows travel in the kernel arguments (no upload, no gather launch)
 struct MedoidRows {
@@ -149,10 +151,13 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
     unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(smem_raw);       // [KM][kResultWords]
     float* edges_s = reinterpret_cast<float*>(acc_s + KM * kResultWords);               // [64]
     float* q_s = edges_s + 64;                                                          // [KM][L4]
+    unsigned int* lcnt_s = reinterpret_cast<unsigned int*>(q_s + KM * L4);              // [KM]
+    int32_t* llist_s = reinterpret_cast<int32_t*>(lcnt_s + KM);                         // [KM][kLocalCap]
 
     const int tid = threadIdx.x;
     for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
     for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
+    for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
     // query vectors: explicit (row-sharded execution) or row medoid.row[j] of the resident matrix
     for (int i = tid; i < KM * L4; i += kBlock) {
         const int j = i / L4, c = i - j * L4;
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
     __syncthreads();
 
     const float radius = 0.05f;
+    const float edge_hi = edges_s[VH_NBINS];
 
     for (int64_t base = ((int64_t)blockIdx.x * kBlock + tid) * RPT; base < n;
          base += (int64_t)gridDim.x * kBlock * RPT) {
@@ -204,6 +210,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                 if (!live[r]) continue;
                 float d = 0.5f - acc[j][r];
                 if (base + r == med) d = 0.0f;
+                if (d > edge_hi) continue;   // beyond the last histogram edge (0.3 > radius): nothing to record
                 // rows inside the medoid radius are rare: accumulate straight into LDS (exact integers)
                 // and append the row to the medoid's candidate list (sample_medoid's `cluster`, cluster.py:621-626)
                 if (d <= radius) {
@@ -212,9 +219,10 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                     atomicAdd(&acc_s[j * kResultWords + 0], (unsigned long long)pf);
                     atomicAdd(&acc_s[j * kResultWords + 1 + VH_NBINS], 1ull);
                     if (d < radius) atomicAdd(&acc_s[j * kResultWords + 2 + VH_NBINS], 1ull);
-                    const unsigned int pos =
-                        atomicAdd(reinterpret_cast<unsigned int*>(&results[j * kResultWords + 3 + VH_NBINS]), 1u);
-                    if (pos < (unsigned int)kListCap) lists[j * kListCap + pos] = (int32_t)(base + r);
+                    // candidate list (sample_medoid's `cluster`): appended block-locally in LDS, flushed once
+                    // per block -- per-row global atomics on one cursor serialise in L2 for dense medoids
+                    const unsigned int lp = atomicAdd(&lcnt_s[j], 1u);
+                    if (lp < (unsigned int)kLocalCap) llist_s[j * kLocalCap + lp] = (int32_t)(base + r);
                 }
                 const int b = bin_of(d, edges_s);
                 if (b >= 0) {
@@ -230,6 +238,46 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
         const unsigned long long v = acc_s[i];
         if (v != 0ull) atomicAdd(&results[i], v);
     }
+    // flush the block-local candidate lists: one cursor atomic per (block, medoid with hits).  A block that
+    // ran out of local room poisons the cursor; the host then sees cursor != n_within and runs a select pass.
+    for (int j = 0; j < KM; ++j) {
+        const unsigned int cnt = lcnt_s[j];
+        if (cnt == 0u) continue;
+        unsigned int* cursor = reinterpret_cast<unsigned int*>(&results[j * kResultWords + 3 + VH_NBINS]);
+        __shared__ unsigned int start_s;
+        if (tid == 0) start_s = cnt > (unsigned int)kLocalCap ? atomicOr(cursor, 0x80000000u) | 0x80000000u
+                                                              : atomicAdd(cursor, cnt);
+        __syncthreads();
+        const unsigned int start = start_s;
+        if (start + cnt <= (unsigned int)kListCap && tid < (int)cnt) lists[j * kListCap + start + tid] = llist_s[j * kLocalCap + tid];
+        __syncthreads();
+    }
+}
+
+// K6b: publication without a copy-engine round trip.  One block moves the accumulators and the candidate
+// lists into host-mapped memory, zeroes the accumulators for the next scan and then raises the sequence flag
+// the host spins on.  (A separate launch, not a last-block-done tail of the scan: the kernel boundary is the
+// cheap way to make the other XCDs' L2 contents visible -- a per-block agent-scope fence writes L2 back and
+// made the scan 5x slower.)
+__global__ __launch_bounds__(kBlock) void clu_publish_kernel(int km, unsigned long long* __restrict__ results,
+                                                             const int32_t* __restrict__ lists,
+                                                             int32_t* __restrict__ host_lists,
+                                                             unsigned long long* __restrict__ host_results,
+                                                             unsigned long long seq) {
+    const int tid = threadIdx.x;
+    for (int j = 0; j < km; ++j) {
+        const unsigned long long cnt = results[j * kResultWords + 3 + VH_NBINS];
+        const int m = cnt <= (unsigned long long)kListCap ? (int)cnt : 0;
+        for (int i = tid; i < m; i += kBlock) host_lists[j * kListCap + i] = lists[j * kListCap + i];
+    }
+    for (int i = tid; i < km * kResultWords; i += kBlock) {
+        host_results[i] = results[i];
+        results[i] = 0ull;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_store(&host_results[kMaxMedoids * kResultWords], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -423,7 +471,10 @@ struct vh_clu {
     DevBuf<float> Mt, Mt_alt, lengths, lengths_alt, q;
     DevBuf<uint8_t> kept;
     DevBuf<unsigned long long> results;
-    DevBuf<int32_t> lists;        // [kListRing][kMaxMedoids][kListCap] rows within the medoid radius, per scan
+    // host-mapped (pinned, coherent) publication buffers written by the scan kernel itself
+    int32_t* lists = nullptr;     // [kListRing][kMaxMedoids][kListCap] rows within the medoid radius, per scan
+    DevBuf<int32_t> lists_dev;    // [kMaxMedoids][kListCap] staging of the running scan (its last block copies out)
+    unsigned long long* host_results = nullptr;   // [kMaxMedoids][kResultWords] + 1 flag word
     uint64_t scan_seq = 0;        // number of scans issued; scan s wrote ring slot s % kListRing
     int last_k = 0;
     std::vector<unsigned int> last_counts[kListRing];   // list lengths of the scans still in the ring
@@ -439,32 +490,53 @@ struct vh_clu {
 
     ~vh_clu() {
         if (ev_done) (void)hipEventDestroy(ev_done);
+        if (lists) (void)hipHostFree(lists);
+        if (host_results) (void)hipHostFree(host_results);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
 
 namespace {
 
+// Spin on the sequence flag the scan kernel's last block stores into host-mapped memory (a few hundred ns
+// after the kernel retires, against ~10 us for a copy + event wait).  The stream is polled now and then so
+// that a faulted kernel surfaces as an error instead of a hang.
+void wait_for_scan(vh_clu* h, unsigned long long seq) {
+    volatile unsigned long long* flag = h->host_results + (size_t)kMaxMedoids * kResultWords;
+    for (unsigned long long spins = 1;; ++spins) {
+        if (*flag == seq) break;
+        if ((spins & 0xFFFFull) == 0) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) {
+                if (*flag == seq) break;
+                throw ::vh::HipError{hipErrorUnknown, "scan kernel retired without publishing its results", __FILE__, __LINE__};
+            }
+            if (q != hipErrorNotReady) VH_HIP(q);
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+}
+
 template <int KM>
-void launch_scan(vh_clu* h, const MedoidRows& med, const float* q_ext, int32_t* lists) {
+void launch_scan(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     constexpr int RPT = (KM >= 12) ? 2 : 4;
-    const size_t smem = (size_t)KM * kResultWords * 8 + 64 * 4 + (size_t)KM * h->L4 * 4;
+    const size_t smem = (size_t)KM * kResultWords * 8 + 64 * 4 + (size_t)KM * h->L4 * 4 + (size_t)KM * 4 * (1 + kLocalCap);
     const int64_t blocks = ceil_div(h->ld, (int64_t)kBlock * RPT);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
     hipLaunchKernelGGL((clu_scan_kernel<KM, RPT>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
-                       h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, lists);
+                       h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_dev.p);
 }
 
-void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext, int32_t* lists) {
+void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext) {
     switch (km) {
-        case 1: launch_scan<1>(h, med, q_ext, lists); break;
-        case 2: launch_scan<2>(h, med, q_ext, lists); break;
-        case 4: launch_scan<4>(h, med, q_ext, lists); break;
-        case 8: launch_scan<8>(h, med, q_ext, lists); break;
-        case 12: launch_scan<12>(h, med, q_ext, lists); break;
-        case 16: launch_scan<16>(h, med, q_ext, lists); break;
-        case 24: launch_scan<24>(h, med, q_ext, lists); break;
-        default: launch_scan<32>(h, med, q_ext, lists); break;
+        case 1: launch_scan<1>(h, med, q_ext); break;
+        case 2: launch_scan<2>(h, med, q_ext); break;
+        case 4: launch_scan<4>(h, med, q_ext); break;
+        case 8: launch_scan<8>(h, med, q_ext); break;
+        case 12: launch_scan<12>(h, med, q_ext); break;
+        case 16: launch_scan<16>(h, med, q_ext); break;
+        case 24: launch_scan<24>(h, med, q_ext); break;
+        default: launch_scan<32>(h, med, q_ext); break;
     }
     VH_HIP(hipGetLastError());
 }
@@ -511,7 +583,12 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->kept.alloc((size_t)h->ld);
         h->q.alloc((size_t)kMaxMedoids * h->L4);
         h->results.alloc((size_t)kMaxMedoids * kResultWords);
-        h->lists.alloc((size_t)kListRing * kMaxMedoids * kListCap);
+        h->lists_dev.alloc((size_t)kMaxMedoids * kListCap);
+        VH_HIP(hipHostMalloc((void**)&h->lists, (size_t)kListRing * kMaxMedoids * kListCap * sizeof(int32_t),
+                             hipHostMallocMapped | hipHostMallocCoherent));
+        VH_HIP(hipHostMalloc((void**)&h->host_results, ((size_t)kMaxMedoids * kResultWords + 1) * 8,
+                             hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h->host_results, 0, ((size_t)kMaxMedoids * kResultWords + 1) * 8);
         VH_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
         VH_HIP(hipMemsetAsync(h->results.p, 0, h->results.bytes(), h->stream));
         h->counts.alloc((size_t)(1 + h->ld / kRowsPerBlock));
@@ -592,24 +669,28 @@ int vh_clu_scan(vh_clu* h, int k, const int64_t* medoid_rows, const float* queri
         // the previous scan (stream order), the medoid rows travel in the kernel arguments and the query
         // vectors are gathered by the kernel itself.
         const int slot = (int)(h->scan_seq % kListRing);
-        int32_t* lists = h->lists.p + (size_t)slot * kMaxMedoids * kListCap;
+        int32_t* lists = h->lists + (size_t)slot * kMaxMedoids * kListCap;
         h->timer.start(h->stream);
-        dispatch_scan(h, km, med, q_ext, lists);
+        dispatch_scan(h, km, med, q_ext);
         h->timer.stop(h->stream);
-        VH_HIP(hipMemcpyAsync(h->h_results.p, h->results.p, (size_t)k * kResultWords * 8, hipMemcpyDeviceToHost,
-                              h->stream));
-        VH_HIP(hipEventRecord(h->ev_done, h->stream));
-        VH_HIP(hipMemsetAsync(h->results.p, 0, (size_t)km * kResultWords * 8, h->stream));  // for the next scan
-        VH_HIP(hipEventSynchronize(h->ev_done));
-        h->timer.collect();
+        hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kBlock), 0, h->stream, km, h->results.p, h->lists_dev.p,
+                           lists, h->host_results, (unsigned long long)(h->scan_seq + 1));
+        VH_HIP(hipGetLastError());
+        wait_for_scan(h, h->scan_seq + 1);
+        if (h->timer.enabled) {
+            VH_HIP(hipStreamSynchronize(h->stream));
+            h->timer.collect();
+        }
         h->last_counts[slot].assign(kMaxMedoids, 0u);
         for (int j = 0; j < k; ++j) {
-            const unsigned long long* r = h->h_results.p + (size_t)j * kResultWords;
+            const unsigned long long* r = h->host_results + (size_t)j * kResultWords;
             out[j].density_fx = (int64_t)r[0];
             for (int b = 0; b < VH_NBINS; ++b) out[j].hist_fx[b] = (int64_t)r[1 + b];
             out[j].n_within = (int64_t)r[1 + VH_NBINS];
             out[j].n_lt = (int64_t)r[2 + VH_NBINS];
-            h->last_counts[slot][j] = (unsigned int)r[3 + VH_NBINS];
+            // the list is complete iff every within-radius row was appended: cursor == n_within <= capacity
+            h->last_counts[slot][j] = (r[3 + VH_NBINS] == r[1 + VH_NBINS] && r[1 + VH_NBINS] <= (unsigned long long)kListCap)
+                                          ? (unsigned int)r[1 + VH_NBINS] : (unsigned int)kListCap + 1u;
         }
         h->last_k = k;
         h->scan_seq++;
@@ -635,13 +716,9 @@ int vh_clu_scan_list(vh_clu* h, int64_t seq, int j, int64_t* out_rows, int64_t c
         const unsigned int cnt = h->last_counts[slot][j];
         if (cnt > (unsigned int)kListCap) return;   // the list overflowed: the caller falls back to vh_clu_select
         VH_REQUIRE(cap >= (int64_t)cnt && (cnt == 0 || out_rows != nullptr), "output buffer too small");
-        h->h_sel.resize(cnt);
-        if (cnt) {
-            VH_HIP(hipMemcpyAsync(h->h_sel.data(), h->lists.p + ((size_t)slot * kMaxMedoids + j) * kListCap,
-                                  (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            VH_HIP(hipStreamSynchronize(h->stream));
-            std::sort(h->h_sel.begin(), h->h_sel.end());
-        }
+        const int32_t* src = h->lists + ((size_t)slot * kMaxMedoids + j) * kListCap;
+        h->h_sel.assign(src, src + cnt);
+        std::sort(h->h_sel.begin(), h->h_sel.end());
         for (unsigned int i = 0; i < cnt; ++i) out_rows[i] = h->h_sel[i];
         *n_out = cnt;
     });

@@ -170,8 +170,7 @@ class ShardedScanBackend:
             self.scan_passes += 1
             self.scan_medoids += len(chunk)
             self.rows_streamed += self.local.n_rows
-            for j in range(len(chunk)):
-                out.append(ScanStats(int(raw[j, 0]), int(raw[j, 61]), int(raw[j, 62]), raw[j, 1:61].copy()))
+            out.extend(ScanStats.batch(_np.asarray(raw, dtype=_np.int64)))
         return out
 
     def select(self, medoid: int, threshold: float, remove: bool) -> _np.ndarray:
