@@ -84,6 +84,7 @@ struct GemmArgs {
     const float* Hbelow;  // activations of the layer below (same shape / ld as C)
     BnSrc bnC;            // its forward statistics
     double* bstat_out;    // [2][N]
+    int xcd_remap;        // 1: give every XCD a contiguous chunk of the tile grid (L2 reuse of operand panels)
 };
 
 // counter-based uniform 32-bit hash (splitmix64 finaliser); also used by the backward transforms so the
@@ -136,8 +137,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.k_per_split;
+    // Workgroup b is observed to run on XCD b % 8, each XCD with a private 4 MiB L2.  With the plain mapping
+    // every XCD walks one column of tiles over ALL row panels of A; the bijective remap below hands XCD x the
+    // x-th contiguous eighth of the (z, m, n)-ordered tile list, so the A / B panels of neighbouring tiles are
+    // fetched once per XCD instead of once per workgroup.  Speed only, never correctness.  (Measured neutral
+    // at the C1 shapes, where both operands fit the L2s / Infinity Cache either way -- DESIGN.md section 5.)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.xcd_remap) {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int nwg = gx * gy * (int)gridDim.z;
+        const int bid = bx + gx * (by + gy * bz);
+        const int xcd = bid & 7, local = bid >> 3;
+        const int t = xcd * (nwg >> 3) + min(xcd, nwg & 7) + local;
+        bx = t % gx;
+        by = (t / gx) % gy;
+        bz = t / (gx * gy);
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nchunks = (kend - kbeg) / BK;
 
@@ -328,7 +345,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     //   row = m0 + (wm*TM + i)*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5),  col = n0 + (wn*TN + j)*32 + (lane&31)
     // ---------------------------------------------------------------------------------------
     float* Cout = g.C;
-    if constexpr (EPI == EPI_SPLITK) Cout += (int64_t)blockIdx.z * g.slab_stride;
+    if constexpr (EPI == EPI_SPLITK) Cout += (int64_t)bz * g.slab_stride;
 
     float s1[TN], s2[TN];
 #pragma unroll

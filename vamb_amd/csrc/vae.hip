@@ -12,6 +12,8 @@
 // bandwidth-bound kernel from vae_kernels.hpp.  One stream, no host synchronisation inside an epoch.
 #include "comm.hpp"
 #include "common.hpp"
+
+#include <hip/hip_ext.h>
 #include "gemm.hpp"
 #include "vae_kernels.hpp"
 
@@ -63,6 +65,10 @@ struct Hidden {
 
 constexpr size_t kMaxDynLds = 120 * 1024;
 
+// When set, the next launch_gemm records the kernel's own begin / end timestamps into this event pair
+// (hipExtLaunchKernelGGL: the dispatch packet's timestamps, the same source rocprofv3 reads) and clears it.
+thread_local hipEvent_t t_probe_start = nullptr, t_probe_stop = nullptr;
+
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE,
           int BK = 32>
 void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
@@ -74,9 +80,21 @@ void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kMaxDynLds));
         attr_set = true;
+        if (getenv("VAMBHIP_DEBUG_OCC")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), WM * WN * 64,
+                                                               smem);
+            fprintf(stderr, "[vambhip] gemm<%d,%d,%d,%d,%d,%d,epi %d,xf %d %d,bk %d> smem %zu B: %d workgroups/CU\n", BM,
+                    BN, WM, WN, (int)AKC, (int)BKC, EPI, XFA, XFB, BK, smem, nb);
+        }
     }
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g);
+    if (t_probe_start) {
+        hipExtLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, t_probe_start, t_probe_stop, 0, g);
+        t_probe_start = t_probe_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g);
+    }
     VH_HIP(hipGetLastError());
 }
 
@@ -107,6 +125,11 @@ GemmArgs base_args() {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.drop_scale = 1.0f;
+    static const int remap = [] {
+        const char* e = getenv("VAMBHIP_XCD_REMAP");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    g.xcd_remap = remap;
     return g;
 }
 
@@ -416,7 +439,8 @@ void upload_masks(vh_vae* h, const uint8_t* masks, int bs) {
     }
 }
 
-void probe_record(vh_vae* h, bool start) {
+// arm the exact-timestamp event pair for the next GEMM launch
+void probe_arm(vh_vae* h) {
     if (!h->probe_on || h->probe_used >= kProbeRing) return;
     if ((int)h->ev_a.size() <= h->probe_used) {
         hipEvent_t a, b;
@@ -425,8 +449,9 @@ void probe_record(vh_vae* h, bool start) {
         h->ev_a.push_back(a);
         h->ev_b.push_back(b);
     }
-    if (start) VH_HIP(hipEventRecord(h->ev_a[h->probe_used], h->stream));
-    else { VH_HIP(hipEventRecord(h->ev_b[h->probe_used], h->stream)); h->probe_used++; }
+    t_probe_start = h->ev_a[h->probe_used];
+    t_probe_stop = h->ev_b[h->probe_used];
+    h->probe_used++;
 }
 
 void probe_collect(vh_vae* h) {
@@ -496,14 +521,13 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
             g.drop_scale = dc.scale; g.drop_thresh = dc.thresh; g.drop_key = layer_key(h, li);
             g.step_ptr = step_ptr(h);
             g.drop_mask = dc.injected ? hl.mask.p : nullptr; g.ld_mask = hl.nout_p;
-            if (probed) { probe_record(h, true); h->probe_flops = 2.0 * bs * (double)hl.nin * hl.nout; }
+            if (probed) { probe_arm(h); h->probe_flops = 2.0 * bs * (double)hl.nin * hl.nout; }
             if (prev) {
                 g.bnA = bn_src(h, *prev);
                 gemm_tile<true, true, EPI_HIDDEN_TRAIN, XF_BN>(s, tile, g, 1);
             } else {
                 gemm_tile<true, true, EPI_HIDDEN_TRAIN>(s, tile, g, 1);
             }
-            if (probed) probe_record(h, false);
             in = hl.H.p;
             prev = &hl;
         } else {
