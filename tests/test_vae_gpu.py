@@ -40,7 +40,7 @@ def loader_from(g, batch):
     return torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=True, drop_last=len(ds) > batch)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5])
 @pytest.mark.parametrize("layout", [(1, 1), (1, 0), (0, 0)])
 @pytest.mark.parametrize("shape", [(128, 128, 32, 1), (192, 96, 64, 2), (260, 36, 160, 1), (512, 512, 512, 4)])
 def test_gemm_instantiations(tile, layout, shape):

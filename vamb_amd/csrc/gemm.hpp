@@ -118,20 +118,30 @@ template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, int XFA
           int BK = 32>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int NT = WM * WN * 64;       // threads per workgroup (1 wavefront per 32x32-tile group)
-    constexpr int SA = BM + (A_KC ? 1 : 4);
-    constexpr int SB = BN + (B_KC ? 1 : 4);
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
-    constexpr int KQ = BK / 4;             // float4 units along K of a K-contiguous operand row
-    constexpr int UA = BM * KQ / NT;       // float4 units per thread per tile
-    constexpr int UB = BN * KQ / NT;
+    constexpr int KQ = BK / 4;             // float4 units along K of an operand row
+    constexpr int UA = (BM * KQ + NT - 1) / NT;   // float4 registers per thread per K-tile
+    constexpr int UB = (BN * KQ + NT - 1) / NT;
+    static_assert(BK == 32, "the swizzled LDS image is 8 quads (32 floats) wide");
     static_assert(WM * WN == 4 || WM * WN == 1, "4 wavefronts per workgroup, or a single free-running one");
-    static_assert(TM >= 1 && TN >= 1 && UA >= 1 && UB >= 1, "tile too small");
+    static_assert(TM >= 1 && TN >= 1, "tile too small");
 
+    // LDS image of an operand tile: [rows][32 floats], i.e. K-contiguous rows of 8 quads (16 B each), the
+    // quad of logical index kq stored in slot kq ^ swz(row).  Every fragment read is one ds_read_b128 (256
+    // B/clk/CU, full rate from one wave per SIMD; ds_read_b32 needs ~4 waves per SIMD for half of that) and
+    // conflict-free: the 16 lanes a b128 access services together hold 16 distinct (row & 1, swz(row)).
+    // A row-contiguous operand (element (k, row) at k*ld + row) keeps the image [32 k][rows + 4]: its float4
+    // loads are stored as they are (one ds_write_b128) and its fragments are single ds_read_b32 -- transposing
+    // it into the K-contiguous image costs more in conflicting ds_write_b64 than the wide reads give back
+    // (measured: dW GEMM 57 -> 52 TF/s).
+    constexpr int SA = BM + 4, SB = BN + 4;                 // row-contiguous image: floats per k row
+    constexpr int TILE_A = A_KC ? BM * BK : BK * SA;        // floats per buffer
+    constexpr int TILE_B = B_KC ? BN * BK : BK * SB;
     extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
-    float* As = gemm_smem;                 // [2][BK][SA]
-    float* Bs = gemm_smem + 2 * BK * SA;   // [2][BK][SB]
-    float* coef = Bs + 2 * BK * SB;        // per-column coefficients of the operand transforms (see below)
+    float* As = gemm_smem;                 // [2][TILE_A]
+    float* Bs = gemm_smem + 2 * TILE_A;    // [2][TILE_B]
+    float* coef = Bs + 2 * TILE_B;         // per-column coefficients of the operand transforms (see below)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -209,100 +219,87 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     float4 ra[UA], rb[UB];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // Global -> registers for the K-tile starting at k0.
+    //   K-contiguous operand: unit u = (row u/8, quad u%8): one float4 = 4 consecutive k of one row.
+    //   row-contiguous operand (element (k, row) at k*ld + row): unit u = (k u / (rows/4), row-quad
+    //   u % (rows/4)): one float4 = rows 4q..4q+3 of one k (coalesced along the rows).
     auto gload = [&](int k0) {
+        if constexpr (A_KC) {
 #pragma unroll
-        for (int r = 0; r < UA; ++r) {
-            const int u = tid + NT * r;
-            int64_t off;
-            bool ok;
-            if constexpr (A_KC) {
+            for (int r = 0; r < UA; ++r) {
+                const int u = tid + NT * r;
                 const int row = u / KQ, kq = u % KQ, gm = m0 + row;
-                ok = gm < g.M;
-                off = (int64_t)gm * g.lda + k0 + 4 * kq;
-            } else {
-                const int k = u / (BM / 4), mq = u % (BM / 4), gm = m0 + 4 * mq;
-                ok = gm < g.M;
-                off = (int64_t)(k0 + k) * g.lda + gm;
+                ra[r] = zero4;
+                if (u < BM * KQ && gm < g.M) ra[r] = *reinterpret_cast<const float4*>(g.A + (int64_t)gm * g.lda + k0 + 4 * kq);
             }
-            ra[r] = zero4;
-            if (ok) ra[r] = *reinterpret_cast<const float4*>(g.A + off);
-        }
+        } else {
 #pragma unroll
-        for (int r = 0; r < UB; ++r) {
-            const int u = tid + NT * r;
-            if constexpr (B_KC) {
+            for (int r = 0; r < UA; ++r) {
+                const int u = tid + NT * r;
+                const int k = u / (BM / 4), mq = u % (BM / 4), gm = m0 + 4 * mq;
+                ra[r] = zero4;
+                if (u < BM * KQ && gm < g.M) ra[r] = *reinterpret_cast<const float4*>(g.A + (int64_t)(k0 + k) * g.lda + gm);
+            }
+        }
+        if constexpr (B_KC) {
+#pragma unroll
+            for (int r = 0; r < UB; ++r) {
+                const int u = tid + NT * r;
                 const int row = u / KQ, kq = u % KQ, gn = n0 + row;
                 rb[r] = zero4;
-                if (gn < g.N) rb[r] = *reinterpret_cast<const float4*>(g.B + (int64_t)gn * g.ldb + k0 + 4 * kq);
-            } else {
+                if (u < BN * KQ && gn < g.N) rb[r] = *reinterpret_cast<const float4*>(g.B + (int64_t)gn * g.ldb + k0 + 4 * kq);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < UB; ++r) {
+                const int u = tid + NT * r;
                 const int k = u / (BN / 4), nq = u % (BN / 4), gn = n0 + 4 * nq;
                 rb[r] = zero4;
-                if (gn < g.N) rb[r] = *reinterpret_cast<const float4*>(g.B + (int64_t)(k0 + k) * g.ldb + gn);
+                if (u < BN * KQ && gn < g.N) rb[r] = *reinterpret_cast<const float4*>(g.B + (int64_t)(k0 + k) * g.ldb + gn);
             }
         }
     };
 
-    // transform of the A registers of unit r of the K-tile starting at k0 (applied at LDS-store time,
-    // when the prefetched data has arrived)
-    auto xform_a = [&](int r, int k0) -> float4 {
-        float4 v = ra[r];
-        if constexpr (XFA == XF_BN) {
-            const int u = tid + NT * r;
-            int c0;   // index of the unit's first column in the coefficient table
-            if constexpr (A_KC) c0 = (k0 - kbeg) + 4 * (u % KQ);
-            else c0 = 4 * (u % (BM / 4));
-            const float4 s = *reinterpret_cast<const float4*>(coefA + c0);
-            const float4 t = *reinterpret_cast<const float4*>(coefA + ncolA + c0);
-            v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
-        }
+    // BatchNorm-on-load (XF_BN): v * scale[col] + shift[col]; the column is the k index of a K-contiguous
+    // operand (4 consecutive coefficients per float4) and the row index of a row-contiguous one.
+    auto bn4 = [](float4 v, const float* sc, const float* sh) -> float4 {
+        const float4 s4 = *reinterpret_cast<const float4*>(sc);
+        const float4 t4 = *reinterpret_cast<const float4*>(sh);
+        v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w;
         return v;
     };
+    auto swz = [](int row) -> int { return ((row >> 1) ^ (row >> 4)) & 7; };
 
-    auto xform_b = [&](int r, int k0) -> float4 {
-        float4 v = rb[r];
-        if constexpr (XFB == XF_BN) {
-            const int u = tid + NT * r;
-            int c0;
-            if constexpr (B_KC) c0 = (k0 - kbeg) + 4 * (u % KQ);
-            else c0 = 4 * (u % (BN / 4));
-            const float4 s = *reinterpret_cast<const float4*>(coefB + c0);
-            const float4 t = *reinterpret_cast<const float4*>(coefB + ncolB + c0);
-            v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
-        }
-        return v;
-    };
-
+    // registers -> LDS (applied when the prefetched data has arrived)
     auto sstore = [&](int buf, int k0) {
-        float* as = As + buf * BK * SA;
-        float* bs = Bs + buf * BK * SB;
+        float* as = As + buf * TILE_A;
+        float* bs = Bs + buf * TILE_B;
 #pragma unroll
         for (int r = 0; r < UA; ++r) {
             const int u = tid + NT * r;
-            const float4 v = xform_a(r, k0);
+            float4 v = ra[r];
             if constexpr (A_KC) {
                 const int row = u / KQ, kq = u % KQ;
-                as[(4 * kq + 0) * SA + row] = v.x;
-                as[(4 * kq + 1) * SA + row] = v.y;
-                as[(4 * kq + 2) * SA + row] = v.z;
-                as[(4 * kq + 3) * SA + row] = v.w;
+                if constexpr (XFA == XF_BN) v = bn4(v, coefA + (k0 - kbeg) + 4 * kq, coefA + ncolA + (k0 - kbeg) + 4 * kq);
+                if (u < BM * KQ) *reinterpret_cast<float4*>(as + row * BK + 4 * (kq ^ swz(row))) = v;
             } else {
                 const int k = u / (BM / 4), mq = u % (BM / 4);
-                *reinterpret_cast<float4*>(as + k * SA + 4 * mq) = v;
+                if constexpr (XFA == XF_BN) v = bn4(v, coefA + 4 * mq, coefA + ncolA + 4 * mq);
+                if (u < BM * KQ) *reinterpret_cast<float4*>(as + k * SA + 4 * mq) = v;
             }
         }
 #pragma unroll
         for (int r = 0; r < UB; ++r) {
             const int u = tid + NT * r;
-            const float4 v = xform_b(r, k0);
+            float4 v = rb[r];
             if constexpr (B_KC) {
                 const int row = u / KQ, kq = u % KQ;
-                bs[(4 * kq + 0) * SB + row] = v.x;
-                bs[(4 * kq + 1) * SB + row] = v.y;
-                bs[(4 * kq + 2) * SB + row] = v.z;
-                bs[(4 * kq + 3) * SB + row] = v.w;
+                if constexpr (XFB == XF_BN) v = bn4(v, coefB + (k0 - kbeg) + 4 * kq, coefB + ncolB + (k0 - kbeg) + 4 * kq);
+                if (u < BN * KQ) *reinterpret_cast<float4*>(bs + row * BK + 4 * (kq ^ swz(row))) = v;
             } else {
                 const int k = u / (BN / 4), nq = u % (BN / 4);
-                *reinterpret_cast<float4*>(bs + k * SB + 4 * nq) = v;
+                if constexpr (XFB == XF_BN) v = bn4(v, coefB + 4 * nq, coefB + ncolB + 4 * nq);
+                if (u < BN * KQ) *reinterpret_cast<float4*>(bs + k * SB + 4 * nq) = v;
             }
         }
     };
@@ -312,30 +309,66 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     if (nchunks > 0) sstore(0, kbeg);
     __syncthreads();
 
-    const int frag_k = lane >> 5;   // which of the 2 k's of an MFMA step this lane feeds
-    const int frag_r = lane & 31;   // row (A) / column (B) within the 32x32 tile
+    // MFMA 32x32x2: lanes 0-31 feed k-slot 0, lanes 32-63 k-slot 1 of each step.  Lane (r, h) reads the
+    // quads 2q + h of its row, so step 4q + j contracts k = 8q + j (h = 0) with k = 8q + 4 + j (h = 1):
+    // every k of the tile exactly once, A and B alike.
+    const int frag_h = lane >> 5;
+    const int frag_r = lane & 31;
+    //   K-contiguous image: offset of quad 2q + h of the lane's row; row-contiguous image: offset of
+    //   (k = 4h, lane's row), the step (q, e) then adds (8q + e) * S.
+    int a_off[TM][4], b_off[TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + frag_r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            a_off[i][q] = A_KC ? row * BK + 4 * ((2 * q + frag_h) ^ swz(row)) : (8 * q + 4 * frag_h) * SA + row;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 32 + frag_r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            b_off[j][q] = B_KC ? row * BK + 4 * ((2 * q + frag_h) ^ swz(row)) : (8 * q + 4 * frag_h) * SB + row;
+    }
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) gload(kbeg + (c + 1) * BK);
-        const float* as = As + buf * BK * SA + (wm * TM * 32 + frag_r);
-        const float* bs = Bs + buf * BK * SB + (wn * TN * 32 + frag_r);
-        // all fragments of this K-tile first (ds_read_b32 burst), then an uninterrupted MFMA chain
-        float af[BK / 2][TM], bf[BK / 2][TN];
+        const float* as = As + buf * TILE_A;
+        const float* bs = Bs + buf * TILE_B;
+        float af[TM][4][4], bf[TN][4][4];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[kk / 2][i] = as[(kk + frag_k) * SA + i * 32];
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (A_KC) {
+                    const float4 v = *reinterpret_cast<const float4*>(as + a_off[i][q]);
+                    af[i][q][0] = v.x; af[i][q][1] = v.y; af[i][q][2] = v.z; af[i][q][3] = v.w;
+                } else {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[kk / 2][j] = bs[(kk + frag_k) * SB + j * 32];
+                    for (int e = 0; e < 4; ++e) af[i][q][e] = as[a_off[i][q] + e * SA];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (B_KC) {
+                    const float4 v = *reinterpret_cast<const float4*>(bs + b_off[j][q]);
+                    bf[j][q][0] = v.x; bf[j][q][1] = v.y; bf[j][q][2] = v.z; bf[j][q][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bf[j][q][e] = bs[b_off[j][q] + e * SB];
+                }
+            }
         }
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk / 2][i], bf[kk / 2][j], acc[i][j], 0, 0, 0);
-        }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q][e], bf[j][q][e], acc[i][j], 0, 0, 0);
         if (c + 1 < nchunks) sstore(buf ^ 1, kbeg + (c + 1) * BK);
         __syncthreads();
     }
@@ -373,7 +406,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * frag_k;
+                const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * frag_h;
                 if (!col_ok || row >= g.M) continue;
                 float v = acc[i][j][reg];
                 if constexpr (EPI == EPI_BIAS) {
@@ -440,7 +473,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
 // dynamic LDS bytes: operand tiles + the coefficient tables of the requested transforms
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int XFA, int XFB, int BK = 32>
 inline size_t gemm_smem_bytes(int k_per_split) {
-    size_t fl = 2 * BK * ((BM + (A_KC ? 1 : 4)) + (BN + (B_KC ? 1 : 4)));
+    size_t fl = 2 * BK * ((A_KC ? BM : BM + 4) + (B_KC ? BN : BN + 4));
     const int narr_a = XFA == XF_BN ? 2 : 0;
     const int narr_b = XFB == XF_BN ? 2 : 0;
     fl += (size_t)narr_a * (A_KC ? k_per_split : BM);

@@ -106,14 +106,13 @@ void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
 }
 
 // every tile shape, no transforms (vh_debug_gemm): 0 = 64x128, 1 = 128x128, 2 = 128x32, 3 = 64x64,
-// 4 = 64x64 with BK = 64, 5 = one free-running wave per 32x32 tile
+// 5 = one free-running wave per 32x32 tile
 template <bool AKC, bool BKC, int EPI>
 void gemm_tile_debug(hipStream_t s, int tile, const GemmArgs& g, int splits) {
     switch (tile) {
         case 0: launch_gemm<64, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
         case 1: launch_gemm<128, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
         case 2: launch_gemm<128, 32, 4, 1, AKC, BKC, EPI>(s, g, splits); break;
-        case 4: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XF_NONE, XF_NONE, 64>(s, g, splits); break;
         case 5: launch_gemm<32, 32, 1, 1, AKC, BKC, EPI>(s, g, splits); break;
         default: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
     }
@@ -1362,8 +1361,7 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
                   int N, int K, int splits, float* ms) {
     return guarded([&] {
         VH_REQUIRE(A && B && C, "NULL argument");
-        VH_REQUIRE(tile >= 0 && tile <= 5, "tile in {0..5}");
-        VH_REQUIRE(tile != 4 || (K % 64 == 0 && (K / std::max(1, splits)) % 64 == 0), "tile 4 needs K multiple of 64");
+        VH_REQUIRE(tile >= 0 && tile <= 5 && tile != 4, "tile in {0, 1, 2, 3, 5}");
         VH_REQUIRE(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && M % 4 == 0 && N % 4 == 0,
                    "need K multiple of 32 and M, N multiples of 4");
         VH_REQUIRE(splits >= 1 && (K / 32) >= splits, "bad split count");
