@@ -714,7 +714,8 @@ void backward(vh_vae* h, bool masks_injected) {
         a.drop_scale = dc.scale;
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
         a.dbias = hl.dbias;
-        hipLaunchKernelGGL(vae_dz_kernel, dim3((unsigned)ceil_div(hl.nout_p, kCT), nrb), dim3(kCT, kRL), 0, s, a);
+        hipLaunchKernelGGL(vae_dz_kernel, dim3((unsigned)ceil_div(hl.nout_p, kDzCols), (unsigned)ceil_div(bs_p, kDzRows)),
+                           dim3(32, kRL), 0, s, a);
         VH_HIP(hipGetLastError());
         const bool from_input = (li == 0) || (li == nl);          // input is Xb / Z: no BatchNorm to apply
         const Hidden* below = from_input ? nullptr : &h->hidden[li - 1];

@@ -403,11 +403,18 @@ struct DzArgs {
     double* dbias;   // [n_p]
 };
 
+// blockDim (32, 8): a workgroup owns kDzCols = 128 columns (one float4 quad per threadIdx.x) x kDzRows = 64
+// rows (8 per thread): 512-byte row segments, 16 independent 16-byte loads in flight per thread, one
+// workgroup per CU at the C1 shape (4096 x 512).
+constexpr int kDzCols = 128;
+constexpr int kDzRows = 64;
+
 __global__ __launch_bounds__(256) void vae_dz_kernel(const DzArgs a) {
-    __shared__ float red[kRL][kCT + 1];
-    __shared__ float cf[3][kCT];
-    const int col = blockIdx.x * kCT + threadIdx.x;
-    if (threadIdx.y == 0) {
+    __shared__ float red[kRL][kDzCols + 4];
+    __shared__ float cf[3][kDzCols];
+    const int tid = threadIdx.y * 32 + threadIdx.x;
+    if (tid < kDzCols) {
+        const int col = blockIdx.x * kDzCols + tid;
         float ca = 0.f, ch = 0.f, c0 = 0.f;
         if (col < a.n_p) {
             float mean, istd, sc, sh;
@@ -419,31 +426,67 @@ __global__ __launch_bounds__(256) void vae_dz_kernel(const DzArgs a) {
             ch = -ca * istd * c2;
             c0 = -ca * c1 - ch * mean;
         }
-        cf[0][threadIdx.x] = ca; cf[1][threadIdx.x] = ch; cf[2][threadIdx.x] = c0;
+        cf[0][tid] = ca; cf[1][tid] = ch; cf[2][tid] = c0;
     }
     __syncthreads();
-    const float ca = cf[0][threadIdx.x], ch = cf[1][threadIdx.x], c0 = cf[2][threadIdx.x];
-    const int r0 = blockIdx.y * kRB, r1 = min(a.bs_p, r0 + kRB);
+    const int cq = 4 * threadIdx.x;                       // first of this thread's 4 columns inside the tile
+    const int col = blockIdx.x * kDzCols + cq;
+    const float4 ca = *reinterpret_cast<const float4*>(&cf[0][cq]);
+    const float4 ch = *reinterpret_cast<const float4*>(&cf[1][cq]);
+    const float4 c0 = *reinterpret_cast<const float4*>(&cf[2][cq]);
+    const int r0 = blockIdx.y * kDzRows;
     const bool hashed_drop = (a.drop_scale != 1.0f) && (a.drop_mask == nullptr);
-    float s = 0.f;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < a.n_p) {
-        for (int r = r0 + threadIdx.y; r < r1; r += kRL) {
-            const int64_t i = (int64_t)r * a.n_p + col;
-            float dz = 0.f;
+        constexpr int RPT = kDzRows / kRL;
+        float4 da[RPT], hh[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + threadIdx.y + kRL * k;
+            da[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            hh[k] = da[k];
             if (r < a.bs) {
-                const float h = a.H[i];
-                bool keep = true;
-                if (hashed_drop) keep = h != 0.f;
-                else if (a.drop_mask) keep = a.drop_mask[(int64_t)r * a.ld_mask + col] != 0;
-                const float lin = ca * a.DA[i] + ch * h + c0;
-                dz = keep ? lin * (h > 0.f ? 1.0f : kLeakySlope) : 0.f;
+                const int64_t i = (int64_t)r * a.n_p + col;
+                da[k] = *reinterpret_cast<const float4*>(a.DA + i);
+                hh[k] = *reinterpret_cast<const float4*>(a.H + i);
             }
-            a.DZ[i] = dz;
-            s += dz;
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + threadIdx.y + kRL * k;
+            if (r >= a.bs_p) continue;
+            float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < a.bs) {
+                bool k0 = true, k1 = true, k2 = true, k3 = true;
+                if (hashed_drop) {
+                    k0 = hh[k].x != 0.f; k1 = hh[k].y != 0.f; k2 = hh[k].z != 0.f; k3 = hh[k].w != 0.f;
+                } else if (a.drop_mask) {
+                    const uint8_t* m = a.drop_mask + (int64_t)r * a.ld_mask + col;
+                    k0 = m[0] != 0; k1 = m[1] != 0; k2 = m[2] != 0; k3 = m[3] != 0;
+                }
+                const float l0 = ca.x * da[k].x + ch.x * hh[k].x + c0.x;
+                const float l1 = ca.y * da[k].y + ch.y * hh[k].y + c0.y;
+                const float l2 = ca.z * da[k].z + ch.z * hh[k].z + c0.z;
+                const float l3 = ca.w * da[k].w + ch.w * hh[k].w + c0.w;
+                dz.x = k0 ? l0 * (hh[k].x > 0.f ? 1.0f : kLeakySlope) : 0.f;
+                dz.y = k1 ? l1 * (hh[k].y > 0.f ? 1.0f : kLeakySlope) : 0.f;
+                dz.z = k2 ? l2 * (hh[k].z > 0.f ? 1.0f : kLeakySlope) : 0.f;
+                dz.w = k3 ? l3 * (hh[k].w > 0.f ? 1.0f : kLeakySlope) : 0.f;
+            }
+            *reinterpret_cast<float4*>(a.DZ + (int64_t)r * a.n_p + col) = dz;
+            s.x += dz.x; s.y += dz.y; s.z += dz.z; s.w += dz.w;
         }
     }
-    s = column_block_sum(s, red);
-    if (threadIdx.y == 0 && col < a.n_p) atomicAdd(&a.dbias[col], (double)s);
+    // bias gradient: the 8 row lanes combined through LDS in a fixed order, one fp64 atomic per column
+    *reinterpret_cast<float4*>(&red[threadIdx.y][cq]) = s;
+    __syncthreads();
+    if (tid < kDzCols) {
+        const int c = blockIdx.x * kDzCols + tid;
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < kRL; ++i) t += red[i][tid];
+        if (c < a.n_p) atomicAdd(&a.dbias[c], (double)t);
+    }
 }
 
 // latent: dMU = (sum of the split-K slabs of dZlat) + KLD part (zero on padding rows); column partial
