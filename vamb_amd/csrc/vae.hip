@@ -904,9 +904,15 @@ int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
         h->ab_w = (float)((1 - a) * (1 / S));
         h->sse_w = (float)(a / VH_NTNF);
         h->kld_w = (float)(1.0 / ((double)cfg->nlatent * cfg->beta));
-        VH_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        // the main stream carries the critical path of a step (forward chain, dX chain, optimiser): highest
+        // priority, so that its workgroups are dispatched ahead of the side stream's weight-gradient GEMMs
+        // whenever both have work queued
+        int prio_lo = 0, prio_hi = 0;
+        VH_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // lo = least urgent (largest number)
+        const bool flat = getenv("VAMBHIP_FLAT_PRIORITY") != nullptr;
+        VH_HIP(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, flat ? prio_lo : prio_hi));
         if (getenv("VAMBHIP_SINGLE_STREAM")) h->side = h->stream;
-        else VH_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        else VH_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
         VH_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         VH_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
 
