@@ -102,6 +102,37 @@ int vh_clu_last_kernel_ms(vh_clu* h, float* ms);
 int vh_clu_set_timing(vh_clu* h, int enable);
 
 
+/* ---------------------------------------------------------------------------------------------
+ * The host state machine of ClusterGenerator in native code: __next__ / find_cluster / wander_medoid /
+ * find_threshold / get_next_seed / update_successes / the packing policy (cluster.py:294-604) on top of a
+ * vh_clu handle, including CPython's random.Random(seed).sample (cluster.py:269,430,445).  `order` is
+ * np.argsort(lengths)[::-1] (cluster.py:275; computed by the caller because numpy's unstable sort order is part
+ * of the reference's behaviour).  The handle borrows `clu`; destroy it first.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct vh_gen vh_gen;
+typedef struct {
+    int64_t medoid;        /* original contig index (Cluster.medoid) */
+    int64_t seed;          /* index of the seed in the reference's packed matrix (Cluster.seed) */
+    int64_t n_members;     /* 0: the generator is exhausted (StopIteration) */
+    int32_t kind;          /* 0 normal, 1 loner, 2 fallback (Cluster.kind_str) */
+    int32_t pad_;
+    double maximal_pvr;    /* peak_valley_ratio when the cluster was emitted */
+    double observed_pvr;   /* valid for kind 0 */
+    double radius;         /* valid for kind 0 and 2 */
+    int64_t successes;
+    int64_t attempts;
+} vh_cluster_info;
+
+int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, int windowsize, int minsuccesses,
+                  uint64_t rng_seed, double pack_fraction, int64_t pack_min_rows, vh_gen** out);
+int vh_gen_destroy(vh_gen* g);
+/* one Cluster (cluster.py:298-316, 545-604); members = original contig indices, ascending */
+int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap);
+/* accounting: passes over the matrix, medoids scanned, rows streamed, summed kernel time (when timing is on) */
+int vh_gen_counters(vh_gen* g, int64_t* scan_passes, int64_t* scan_medoids, int64_t* rows_streamed,
+                    double* kernel_ms, int64_t* n_emitted, int64_t* n_remaining);
+
+
 /* =============================================================================================
  * VAE  (replaces the torch / dadaptation arithmetic inside vamb/encode.py)
  * ============================================================================================= */

@@ -29,6 +29,13 @@ class ScanResult(ctypes.Structure):
                 ("n_within", ctypes.c_int64), ("n_lt", ctypes.c_int64)]
 
 
+class ClusterInfo(ctypes.Structure):                                    # vh_cluster_info
+    _fields_ = [("medoid", ctypes.c_int64), ("seed", ctypes.c_int64), ("n_members", ctypes.c_int64),
+                ("kind", ctypes.c_int32), ("pad_", ctypes.c_int32), ("maximal_pvr", ctypes.c_double),
+                ("observed_pvr", ctypes.c_double), ("radius", ctypes.c_double), ("successes", ctypes.c_int64),
+                ("attempts", ctypes.c_int64)]
+
+
 _lib = None
 
 _i64 = ctypes.c_int64
@@ -50,6 +57,12 @@ SIGNATURES = {
     "vh_clu_scan": (_int, [_vp, _int, _vp, _vp, _vp]),
     "vh_clu_scan_seq": (_int, [_vp, ctypes.POINTER(_i64)]),
     "vh_clu_scan_list": (_int, [_vp, _i64, _int, _vp, _i64, ctypes.POINTER(_i64)]),
+    "vh_gen_create": (_int, [_vp, _vp, _i64, _int, _int, _int, ctypes.c_uint64, ctypes.c_double, _i64,
+                             ctypes.POINTER(_vp)]),
+    "vh_gen_destroy": (_int, [_vp]),
+    "vh_gen_next": (_int, [_vp, ctypes.POINTER(ClusterInfo), _vp, _i64]),
+    "vh_gen_counters": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
+                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "vh_clu_select": (_int, [_vp, _i64, _vp, _f32, _int, _vp, _i64, ctypes.POINTER(_i64)]),
     "vh_clu_remove": (_int, [_vp, _vp, _i64]),
     "vh_clu_pack": (_int, [_vp, ctypes.POINTER(_i64)]),

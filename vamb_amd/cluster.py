@@ -25,6 +25,7 @@ Differences from the reference that do not change results
 from __future__ import annotations
 
 import ctypes
+import os as _os
 import random as _random
 from collections import deque as _deque
 from typing import Optional
@@ -141,6 +142,10 @@ class HipScanBackend:
 
     def close(self):
         if self.h is not None and self.h.value:
+            gen = getattr(self, "gen_handle", None)   # the native state machine borrows this handle
+            if gen is not None:
+                self.lib.vh_gen_destroy(gen)
+                self.gen_handle = None
             self.lib.vh_clu_destroy(self.h)
             self.h = None
 
@@ -354,7 +359,7 @@ class ClusterGenerator:
         if inplace_target is not None and normalized_out is not None:
             inplace_target[...] = normalized_out
 
-        self._setup(lengths, maxsteps, windowsize, minsuccesses, rng_seed)
+        self._setup(lengths, maxsteps, windowsize, minsuccesses, rng_seed, native=_backend_factory is None)
 
     @classmethod
     def from_backend(cls, backend, lengths: _np.ndarray, maxsteps: int = 25, windowsize: int = 300,
@@ -377,7 +382,7 @@ class ClusterGenerator:
         self._setup(lengths, maxsteps, windowsize, minsuccesses, rng_seed)
         return self
 
-    def _setup(self, lengths, maxsteps, windowsize, minsuccesses, rng_seed):
+    def _setup(self, lengths, maxsteps, windowsize, minsuccesses, rng_seed, native=False):
         self.maxsteps: int = maxsteps
         self.minsuccesses: int = minsuccesses
         self.cuda: bool = True
@@ -396,12 +401,54 @@ class ClusterGenerator:
         self.successes = 0
         self._stats_cache: dict[int, ScanStats] = {}
         self._within_cache: dict[int, _np.ndarray] = {}
+        # Single-GPU handles run the state machine below in native code (vh_gen_*, same scans, same
+        # random.Random stream); the Python methods remain the implementation for every other backend
+        # (row-sharded multi-GPU, the CPU oracle backend of the tests) and the specification of both.
+        self._gen = None
+        self._members_buf = None
+        if (native and isinstance(self._backend, HipScanBackend) and isinstance(rng_seed, int)
+                and abs(rng_seed) < 2 ** 64 and not _os.environ.get("VAMBHIP_PY_GENERATOR")):
+            handle = ctypes.c_void_p()
+            order = _np.ascontiguousarray(self.order, dtype=_np.int64)
+            _lib.check(self._backend.lib.vh_gen_create(self._backend.h, _lib.ptr(order), n, int(maxsteps),
+                                                       int(windowsize), int(minsuccesses), abs(rng_seed),
+                                                       float(self.PACK_FRACTION), int(self.PACK_MIN_ROWS),
+                                                       ctypes.byref(handle)))
+            self._gen = handle
+            self._backend.gen_handle = handle      # destroyed by the backend, before the handle it borrows
+            self._members_buf = _np.empty(n, _np.int64)
+
+    def _next_native(self) -> Cluster:
+        info = _lib.ClusterInfo()
+        lib = self._backend.lib
+        _lib.check(lib.vh_gen_next(self._gen, ctypes.byref(info), _lib.ptr(self._members_buf), len(self._members_buf)))
+        if info.n_members == 0:
+            raise StopIteration
+        members = self._members_buf[: info.n_members].copy()
+        observed = info.observed_pvr if info.kind == 0 else None
+        radius = None if info.kind == 1 else info.radius
+        # mirror the native counters on the Python objects (bench accounting, repr)
+        b = self._backend
+        passes, medoids, rows = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        emitted, remaining, ms = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(lib.vh_gen_counters(self._gen, ctypes.byref(passes), ctypes.byref(medoids), ctypes.byref(rows),
+                                       ctypes.byref(ms), ctypes.byref(emitted), ctypes.byref(remaining)))
+        b.scan_passes, b.scan_medoids, b.rows_streamed, b.kernel_ms = passes.value, medoids.value, rows.value, ms.value
+        self.n_emitted_clusters, self.n_remaining_points = emitted.value, remaining.value
+        self.peak_valley_ratio = info.maximal_pvr
+        n_rows, n_live = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(lib.vh_clu_rows(b.h, ctypes.byref(n_rows), ctypes.byref(n_live)))
+        b.n_rows = n_rows.value
+        return Cluster(int(info.medoid), int(info.seed), members, info.maximal_pvr, observed, radius,
+                       int(info.successes), int(info.attempts))
 
     def __iter__(self):
         return self
 
     # cluster.py:298-316
     def __next__(self) -> Cluster:
+        if self._gen is not None:
+            return self._next_native()
         if self.n_remaining_points == 0:
             raise StopIteration
         assert self.n_remaining_points > 0

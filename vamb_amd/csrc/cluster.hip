@@ -17,6 +17,9 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cmath>
+#include <deque>
+#include <unordered_map>
 #include <atomic>
 #include <memory>
 
@@ -864,6 +867,448 @@ int vh_clu_get_kept(vh_clu* h, uint8_t* out) {
         VH_REQUIRE(h != nullptr && out != nullptr, "NULL argument");
         VH_HIP(hipMemcpyAsync(out, h->kept.p, (size_t)h->n_rows, hipMemcpyDeviceToHost, h->stream));
         VH_HIP(hipStreamSynchronize(h->stream));
+    });
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// Host state machine of ClusterGenerator (cluster.py:294-604) in C++: seed walk, wander_medoid,
+// find_threshold, success window, packing policy.  It issues the same scans / selects as the Python
+// class in vamb_amd/cluster.py (which remains the implementation behind the row-sharded multi-GPU
+// backend) -- the Python interpreter was 60 % of a C1 sweep.
+// =============================================================================================
+namespace {
+
+// CPython's random.Random for an int seed: MT19937 seeded with init_by_array(32-bit chunks of |seed|),
+// getrandbits(k <= 32) = genrand_uint32() >> (32 - k), _randbelow_with_getrandbits and random.sample
+// (Lib/random.py; cluster.py:269, 430, 445 use rng.sample only).
+struct PyRandom {
+    uint32_t mt[624];
+    int idx = 625;
+    void init_genrand(uint32_t s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    void seed(uint64_t a) {
+        uint32_t key[2] = {(uint32_t)(a & 0xFFFFFFFFu), (uint32_t)(a >> 32)};
+        const int klen = key[1] ? 2 : 1;
+        init_genrand(19650218u);
+        int i = 1, j = 0;
+        for (int k = (624 > klen ? 624 : klen); k; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (++j >= klen) j = 0;
+        }
+        for (int k = 623; k; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+    }
+    uint32_t next32() {
+        if (idx >= 624) {
+            for (int k = 0; k < 624; ++k) {
+                const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7FFFFFFFu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9D2C5680u;
+        y ^= (y << 15) & 0xEFC60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    uint32_t randbelow(uint32_t n) {   // n >= 1
+        int bits = 0;
+        for (uint32_t t = n; t; t >>= 1) ++bits;
+        uint32_t r = next32() >> (32 - bits);
+        while (r >= n) r = next32() >> (32 - bits);
+        return r;
+    }
+    // random.sample(population, k): pool swap for small populations, rejection set for large ones
+    void sample(const std::vector<int64_t>& pop, int k, std::vector<int64_t>& out) {
+        const size_t n = pop.size();
+        out.assign((size_t)k, 0);
+        double setsize = 21.0;
+        if (k > 5) setsize += std::pow(4.0, std::ceil(std::log((double)k * 3.0) / std::log(4.0)));
+        if ((double)n <= setsize) {
+            std::vector<int64_t> pool(pop);
+            for (int i = 0; i < k; ++i) {
+                const uint32_t j = randbelow((uint32_t)(n - (size_t)i));
+                out[i] = pool[j];
+                pool[j] = pool[n - (size_t)i - 1];
+            }
+        } else {
+            std::vector<uint32_t> chosen;
+            for (int i = 0; i < k; ++i) {
+                uint32_t j = randbelow((uint32_t)n);
+                while (std::find(chosen.begin(), chosen.end(), j) != chosen.end()) j = randbelow((uint32_t)n);
+                chosen.push_back(j);
+                out[i] = pop[j];
+            }
+        }
+    }
+};
+
+struct GenStats {
+    double density = 0.0;
+    int64_t n_within = 0, n_lt = 0;
+    int64_t hist_fx[VH_NBINS];
+    bool have_list = false;
+    std::vector<int64_t> within;   // ascending rows inside the medoid radius (when have_list)
+};
+
+// float32(0.005) * float32(N(0, 0.01) pdf) -- the _NORMALPDF table of cluster.py:39-73
+constexpr int kPdfLen = 31;
+const float kPdfRaw[kPdfLen] = {
+    2.43432053e-11f, 9.13472041e-10f, 2.66955661e-08f, 6.07588285e-07f, 1.07697600e-05f, 1.48671951e-04f,
+    1.59837411e-03f, 1.33830226e-02f, 8.72682695e-02f, 4.43184841e-01f, 1.75283005e00f, 5.39909665e00f,
+    1.29517596e01f, 2.41970725e01f, 3.52065327e01f, 3.98942280e01f, 3.52065327e01f, 2.41970725e01f,
+    1.29517596e01f, 5.39909665e00f, 1.75283005e00f, 4.43184841e-01f, 8.72682695e-02f, 1.33830226e-02f,
+    1.59837411e-03f, 1.48671951e-04f, 1.07697600e-05f, 6.07588285e-07f, 2.66955661e-08f, 9.13472041e-10f,
+    2.43432053e-11f};
+
+enum ThresholdKind { kLoner = 0, kNoThreshold = 1, kThreshold = 2 };
+
+}  // namespace
+
+struct vh_gen {
+    vh_clu* clu = nullptr;          // borrowed
+    int maxsteps = 25, minsuccesses = 15;
+    size_t windowsize = 300;
+    double pack_fraction = 0.5;
+    int64_t pack_min_rows = 8192;
+    PyRandom rng;
+    std::vector<int64_t> order;     // contig indices by descending length, -1 = tombstone
+    std::vector<int64_t> indices;   // original contig index of every physical row (ascending)
+    std::vector<uint8_t> kept;      // host mirror of the device live mask (physical rows)
+    std::vector<uint8_t> alive;     // the same by original contig index
+    int64_t order_index = 0;
+    int64_t n_emitted = 0, n_remaining = 0;
+    double pvr = 0.1;
+    std::deque<bool> attempts;
+    int successes = 0;
+    std::unordered_map<int64_t, GenStats> stats;
+    // counters (bench accounting)
+    int64_t scan_passes = 0, scan_medoids = 0, rows_streamed = 0;
+    double kernel_ms = 0.0;
+    std::vector<int64_t> sel;       // scratch
+};
+
+namespace {
+
+void gen_check(int rc) {
+    if (rc != VH_OK) throw ::vh::HipError{hipErrorUnknown, g_last_error.c_str(), __FILE__, __LINE__};
+}
+
+void gen_collect_ms(vh_gen* g) {
+    if (g->clu->timer.enabled) g->kernel_ms += g->clu->timer.last_ms;
+}
+
+// sample_medoid's device half for every medoid not cached yet (one pass per <= 32 of them)
+void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
+    std::vector<int64_t> missing;
+    for (size_t i = 0; i < n; ++i) {
+        const int64_t m = medoids[i];
+        if (g->stats.count(m)) continue;
+        if (std::find(missing.begin(), missing.end(), m) != missing.end()) continue;
+        missing.push_back(m);
+    }
+    vh_scan_result res[kMaxMedoids];
+    for (size_t lo = 0; lo < missing.size(); lo += kMaxMedoids) {
+        const int k = (int)std::min<size_t>(kMaxMedoids, missing.size() - lo);
+        const uint64_t seq = g->clu->scan_seq;
+        gen_check(vh_clu_scan(g->clu, k, missing.data() + lo, nullptr, res));
+        g->scan_passes++;
+        g->scan_medoids += k;
+        g->rows_streamed += g->clu->n_rows;
+        gen_collect_ms(g);
+        const int slot = (int)(seq % kListRing);
+        for (int j = 0; j < k; ++j) {
+            GenStats& st = g->stats[missing[lo + j]];
+            // the python float the reference gets from `.sum().item()` on a float32 tensor (cluster.py:629)
+            st.density = (double)(float)((double)res[j].density_fx / VH_DENSITY_SCALE);
+            st.n_within = res[j].n_within;
+            st.n_lt = res[j].n_lt;
+            for (int b = 0; b < VH_NBINS; ++b) st.hist_fx[b] = res[j].hist_fx[b];
+            const unsigned int cnt = g->clu->last_counts[slot][j];
+            st.have_list = cnt <= (unsigned int)kListCap;
+            if (st.have_list) {
+                const int32_t* src = g->clu->lists + ((size_t)slot * kMaxMedoids + j) * kListCap;
+                st.within.assign(src, src + cnt);
+                std::sort(st.within.begin(), st.within.end());
+            }
+        }
+    }
+}
+
+int64_t gen_select(vh_gen* g, int64_t medoid, float threshold, bool remove) {
+    int64_t n = 0;
+    g->sel.resize((size_t)std::max<int64_t>(1, g->clu->n_rows));
+    gen_check(vh_clu_select(g->clu, medoid, nullptr, threshold, remove ? 1 : 0, g->sel.data(), (int64_t)g->sel.size(), &n));
+    g->scan_passes++;
+    g->rows_streamed += g->clu->n_rows;
+    gen_collect_ms(g);
+    return n;
+}
+
+const std::vector<int64_t>& gen_within(vh_gen* g, int64_t medoid) {
+    GenStats& st = g->stats.at(medoid);
+    if (!st.have_list) {
+        const int64_t n = gen_select(g, medoid, 0.05f, false);
+        st.within.assign(g->sel.begin(), g->sel.begin() + n);
+        st.have_list = true;
+    }
+    return st.within;
+}
+
+// cluster.py:342-384
+int64_t gen_next_seed(vh_gen* g) {
+    int64_t n_order = (int64_t)g->order.size();
+    int64_t i = g->order_index - 1;
+    while (true) {
+        i = (i + 1) % n_order;
+        if (i == 0 && g->n_emitted > 0) {   // pack_order (cluster.py:337-340)
+            g->order.erase(std::remove(g->order.begin(), g->order.end(), (int64_t)-1), g->order.end());
+            n_order = (int64_t)g->order.size();
+            if (n_order == 0) throw ::vh::HipError{hipErrorUnknown, "seed order exhausted", __FILE__, __LINE__};
+        }
+        const int64_t o = g->order[i];
+        if (o == -1) continue;
+        if (!g->alive[o]) { g->order[i] = -1; continue; }
+        g->order_index = i + 1;
+        const auto it = std::lower_bound(g->indices.begin(), g->indices.end(), o);
+        return (int64_t)(it - g->indices.begin());
+    }
+}
+
+// cluster.py:386-413
+void gen_update_successes(vh_gen* g, bool success) {
+    if (g->attempts.size() == g->windowsize) {
+        g->successes -= g->attempts.front() ? 1 : 0;
+        g->attempts.pop_front();
+    }
+    g->successes += success ? 1 : 0;
+    g->attempts.push_back(success);
+    if (g->attempts.size() == g->windowsize && g->successes < g->minsuccesses) {
+        g->pvr += 0.1;
+        g->attempts.clear();
+        g->successes = 0;
+        g->order_index = 0;
+    }
+}
+
+// cluster.py:415-450
+int64_t gen_wander(vh_gen* g, int64_t seed) {
+    int64_t medoid = seed;
+    std::vector<int64_t> tried{medoid};
+    gen_ensure_stats(g, &seed, 1);
+    double local_density = g->stats.at(seed).density;
+    auto untried = [&](const std::vector<int64_t>& rows) {
+        std::vector<int64_t> c;
+        for (int64_t r : rows)
+            if (std::find(tried.begin(), tried.end(), r) == tried.end()) c.push_back(r);
+        return c;
+    };
+    std::vector<int64_t> pool = untried(gen_within(g, seed)), candidates;
+    g->rng.sample(pool, (int)std::min<size_t>(pool.size(), (size_t)g->maxsteps), candidates);
+    size_t i = 0;
+    while (i < candidates.size()) {
+        // look ahead: every not-yet-scanned candidate of this round shares one matrix pass
+        gen_ensure_stats(g, candidates.data() + i, candidates.size() - i);
+        const int64_t sampled = candidates[i];
+        tried.push_back(sampled);
+        const double d = g->stats.at(sampled).density;
+        if (d > local_density) {
+            medoid = sampled;
+            local_density = d;
+            pool = untried(gen_within(g, sampled));
+            g->rng.sample(pool, (int)std::min<size_t>(pool.size(), (size_t)g->maxsteps), candidates);
+            i = 0;
+        } else {
+            ++i;
+        }
+    }
+    return medoid;
+}
+
+// cluster.py:452-543 on the exact histogram of the scan
+ThresholdKind gen_find_threshold(const vh_gen* g, const GenStats& st, double* threshold, double* observed_pvr) {
+    if (st.n_lt == 1) return kLoner;
+    float hist[VH_NBINS];
+    for (int b = 0; b < VH_NBINS; ++b) hist[b] = (float)((double)st.hist_fx[b] / VH_HIST_SCALE);
+    // densities[k] = sum_i pdf[k - i] * hist[i]: float32 products, float32 running sum, i ascending
+    // (cluster.py:495-500), then the middle 60 of the 90 values
+    float dens[VH_NBINS];
+    for (int k = 15; k < 15 + VH_NBINS; ++k) {
+        float acc = 0.0f;
+        for (int i = std::max(0, k - (kPdfLen - 1)); i <= std::min(VH_NBINS - 1, k); ++i) {
+            const float w = 0.005f * kPdfRaw[k - i];
+            const float prod = w * hist[i];
+            acc = acc + prod;
+        }
+        dens[k - 15] = acc;
+    }
+    double peak_density = 0.0, minimum_x = 0.0, density_at_minimum = 0.0, thr = 0.0;
+    bool peak_over = false, have_thr = false;
+    const double delta_x = 0.3 / (double)VH_NBINS;
+    double x = 0.0;
+    for (int b = 0; b < VH_NBINS; ++b) {
+        const double density = (double)dens[b];
+        if (!peak_over && density > peak_density) {
+            if (x > 0.1) return kNoThreshold;
+            peak_density = density;
+        }
+        if (!peak_over && density < 0.6 * peak_density) {
+            peak_over = true;
+            density_at_minimum = density;
+        }
+        if (peak_over && density > 1.5 * density_at_minimum) break;
+        if (peak_over && density < density_at_minimum) {
+            minimum_x = x;
+            density_at_minimum = density;
+            if (density < g->pvr * peak_density) { thr = minimum_x; have_thr = true; }
+        }
+        x += delta_x;
+    }
+    if (!have_thr || thr > 0.2 + g->pvr) return kNoThreshold;
+    *threshold = thr;
+    *observed_pvr = density_at_minimum / peak_density;
+    return kThreshold;
+}
+
+int64_t gen_logical_index(const vh_gen* g, int64_t row) {
+    int64_t c = 0;
+    for (int64_t r = 0; r < row; ++r) c += g->kept[r] ? 1 : 0;
+    return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, int windowsize, int minsuccesses,
+                  uint64_t rng_seed, double pack_fraction, int64_t pack_min_rows, vh_gen** out) {
+    return guarded([&] {
+        VH_REQUIRE(clu != nullptr && order != nullptr && out != nullptr, "NULL argument");
+        VH_REQUIRE(n == clu->n_rows && n >= 1, "order length does not match the matrix");
+        VH_REQUIRE(maxsteps >= 1, "maxsteps must be a positive integer, not %d", maxsteps);
+        VH_REQUIRE(windowsize >= 1, "windowsize must be at least 1, not %d", windowsize);
+        VH_REQUIRE(minsuccesses >= 1 && minsuccesses <= windowsize, "minsuccesses must be between 1 and windowsize, not %d",
+                   minsuccesses);
+        std::unique_ptr<vh_gen> g(new vh_gen());
+        g->clu = clu;
+        g->maxsteps = maxsteps;
+        g->windowsize = (size_t)windowsize;
+        g->minsuccesses = minsuccesses;
+        g->pack_fraction = pack_fraction;
+        g->pack_min_rows = pack_min_rows;
+        g->rng.seed(rng_seed);
+        g->order.assign(order, order + n);
+        g->indices.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) g->indices[(size_t)i] = i;
+        g->kept.assign((size_t)n, 1);
+        g->alive.assign((size_t)n, 1);
+        g->n_remaining = n;
+        *out = g.release();
+    });
+}
+
+int vh_gen_destroy(vh_gen* g) {
+    delete g;
+    return VH_OK;
+}
+
+// __next__ (cluster.py:298-316) + find_cluster (cluster.py:545-604).  info->n_members == 0: StopIteration.
+int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap) {
+    return guarded([&] {
+        VH_REQUIRE(g != nullptr && info != nullptr && members != nullptr, "NULL argument");
+        memset(info, 0, sizeof(*info));
+        if (g->n_remaining == 0) return;
+        int64_t n_points = 0;
+        std::vector<int64_t> points;
+        while (true) {
+            const int64_t seed = gen_next_seed(g);
+            const int64_t medoid = gen_wander(g, seed);
+            const GenStats& st = g->stats.at(medoid);
+            double threshold = 0.0, observed = 0.0;
+            const ThresholdKind kind = gen_find_threshold(g, st, &threshold, &observed);
+            const int64_t original = g->indices[(size_t)medoid];
+            info->medoid = original;
+            info->maximal_pvr = g->pvr;
+            if (kind == kLoner) {
+                info->seed = gen_logical_index(g, seed);
+                info->kind = 1;
+                info->successes = g->successes;
+                info->attempts = (int64_t)g->attempts.size();
+                points.assign(1, medoid);
+                gen_check(vh_clu_remove(g->clu, points.data(), 1));
+                break;
+            }
+            if (kind == kNoThreshold) {
+                if (g->pvr > 0.55) {
+                    info->seed = gen_logical_index(g, seed);
+                    info->kind = 2;
+                    info->radius = 0.06;
+                    info->successes = g->successes;
+                    info->attempts = (int64_t)g->attempts.size();
+                    n_points = gen_select(g, medoid, (float)0.06, true);
+                    points.assign(g->sel.begin(), g->sel.begin() + n_points);
+                    break;
+                }
+                gen_update_successes(g, false);
+                continue;
+            }
+            info->seed = gen_logical_index(g, seed);
+            info->kind = 0;
+            info->radius = threshold;
+            info->observed_pvr = observed;
+            info->successes = g->successes;
+            info->attempts = (int64_t)g->attempts.size();
+            n_points = gen_select(g, medoid, (float)threshold, true);
+            points.assign(g->sel.begin(), g->sel.begin() + n_points);
+            if (g->pvr < 0.55) gen_update_successes(g, true);
+            break;
+        }
+        VH_REQUIRE((int64_t)points.size() <= cap, "members buffer too small");
+        for (size_t i = 0; i < points.size(); ++i) members[i] = g->indices[(size_t)points[i]];
+        info->n_members = (int64_t)points.size();
+        // __next__ bookkeeping
+        g->stats.clear();
+        g->n_emitted++;
+        g->n_remaining -= (int64_t)points.size();
+        for (int64_t r : points) {
+            g->kept[(size_t)r] = 0;
+            g->alive[(size_t)g->indices[(size_t)r]] = 0;
+        }
+        const int64_t n_rows = (int64_t)g->kept.size();
+        if (g->n_remaining > 0 && n_rows >= g->pack_min_rows && (double)g->n_remaining < g->pack_fraction * (double)n_rows) {
+            int64_t new_n = 0;
+            gen_check(vh_clu_pack(g->clu, &new_n));
+            size_t w = 0;
+            for (size_t r = 0; r < g->kept.size(); ++r)
+                if (g->kept[r]) g->indices[w++] = g->indices[r];
+            VH_REQUIRE((int64_t)w == new_n, "pack bookkeeping mismatch");
+            g->indices.resize(w);
+            g->kept.assign(w, 1);
+        }
+    });
+}
+
+int vh_gen_counters(vh_gen* g, int64_t* scan_passes, int64_t* scan_medoids, int64_t* rows_streamed, double* kernel_ms,
+                    int64_t* n_emitted, int64_t* n_remaining) {
+    return guarded([&] {
+        VH_REQUIRE(g != nullptr, "NULL argument");
+        if (scan_passes) *scan_passes = g->scan_passes;
+        if (scan_medoids) *scan_medoids = g->scan_medoids;
+        if (rows_streamed) *rows_streamed = g->rows_streamed;
+        if (kernel_ms) *kernel_ms = g->kernel_ms;
+        if (n_emitted) *n_emitted = g->n_emitted;
+        if (n_remaining) *n_remaining = g->n_remaining;
     });
 }
 
