@@ -17,6 +17,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <deque>
 #include <unordered_map>
@@ -265,7 +266,9 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
 __global__ __launch_bounds__(kBlock) void clu_publish_kernel(int km, unsigned long long* __restrict__ results,
                                                              const int32_t* __restrict__ lists,
                                                              int32_t* __restrict__ host_lists,
-                                                             unsigned long long* __restrict__ host_results,
+                                                             unsigned long long* __restrict__ host_summary,
+                                                             unsigned long long* __restrict__ host_hist,
+                                                             unsigned long long* __restrict__ host_flag,
                                                              unsigned long long seq) {
     const int tid = threadIdx.x;
     for (int j = 0; j < km; ++j) {
@@ -273,14 +276,21 @@ __global__ __launch_bounds__(kBlock) void clu_publish_kernel(int km, unsigned lo
         const int m = cnt <= (unsigned long long)kListCap ? (int)cnt : 0;
         for (int i = tid; i < m; i += kBlock) host_lists[j * kListCap + i] = lists[j * kListCap + i];
     }
-    for (int i = tid; i < km * kResultWords; i += kBlock) {
-        host_results[i] = results[i];
-        results[i] = 0ull;
+    // the four words every candidate needs (density, n_within, n_lt, list cursor) go to a compact block of
+    // their own: the host reads 32 bytes per medoid instead of 512 (host reads of this memory are expensive)
+    for (int i = tid; i < km * 4; i += kBlock) {
+        const int j = i >> 2, w = i & 3;
+        host_summary[i] = results[j * kResultWords + (w == 0 ? 0 : VH_NBINS + w)];
     }
+    for (int i = tid; i < km * VH_NBINS; i += kBlock) {
+        const int j = i / VH_NBINS, b = i - j * VH_NBINS;
+        host_hist[i] = results[j * kResultWords + 1 + b];
+    }
+    __syncthreads();
+    for (int i = tid; i < km * kResultWords; i += kBlock) results[i] = 0ull;
     __threadfence_system();
     __syncthreads();
-    if (tid == 0)
-        __hip_atomic_store(&host_results[kMaxMedoids * kResultWords], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -477,10 +487,17 @@ struct vh_clu {
     // host-mapped (pinned, coherent) publication buffers written by the scan kernel itself
     int32_t* lists = nullptr;     // [kListRing][kMaxMedoids][kListCap] rows within the medoid radius, per scan
     DevBuf<int32_t> lists_dev;    // [kMaxMedoids][kListCap] staging of the running scan (its last block copies out)
-    unsigned long long* host_results = nullptr;   // [kMaxMedoids][kResultWords] + 1 flag word
+    unsigned long long* host_results = nullptr;   // [kListRing][kMaxMedoids][4] summaries, [kListRing][kMaxMedoids]
+                                                  // [VH_NBINS] histograms, 1 flag word (offsets below)
+    unsigned long long* summary(int slot) { return host_results + (size_t)slot * kMaxMedoids * 4; }
+    unsigned long long* hist(int slot) {
+        return host_results + (size_t)kListRing * kMaxMedoids * 4 + (size_t)slot * kMaxMedoids * VH_NBINS;
+    }
+    unsigned long long* flag() { return host_results + (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS); }
     uint64_t scan_seq = 0;        // number of scans issued; scan s wrote ring slot s % kListRing
     int last_k = 0;
     std::vector<unsigned int> last_counts[kListRing];   // list lengths of the scans still in the ring
+    std::vector<unsigned long long> last_summary[kListRing];   // (density, n_within, n_lt, cursor) per medoid
     hipEvent_t ev_done = nullptr; // recorded after the result copy: the host waits on it, not on the stream
     DevBuf<int32_t> sel_rows;   // select output / pack source list
     DevBuf<unsigned int> counts;  // [0]: select counter; [1..]: pack block counts
@@ -505,7 +522,7 @@ namespace {
 // after the kernel retires, against ~10 us for a copy + event wait).  The stream is polled now and then so
 // that a faulted kernel surfaces as an error instead of a hang.
 void wait_for_scan(vh_clu* h, unsigned long long seq) {
-    volatile unsigned long long* flag = h->host_results + (size_t)kMaxMedoids * kResultWords;
+    volatile unsigned long long* flag = h->flag();
     for (unsigned long long spins = 1;; ++spins) {
         if (*flag == seq) break;
         if ((spins & 0xFFFFull) == 0) {
@@ -589,9 +606,9 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->lists_dev.alloc((size_t)kMaxMedoids * kListCap);
         VH_HIP(hipHostMalloc((void**)&h->lists, (size_t)kListRing * kMaxMedoids * kListCap * sizeof(int32_t),
                              hipHostMallocMapped | hipHostMallocCoherent));
-        VH_HIP(hipHostMalloc((void**)&h->host_results, ((size_t)kMaxMedoids * kResultWords + 1) * 8,
-                             hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset(h->host_results, 0, ((size_t)kMaxMedoids * kResultWords + 1) * 8);
+        const size_t host_words = (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS) + 1;
+        VH_HIP(hipHostMalloc((void**)&h->host_results, host_words * 8, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h->host_results, 0, host_words * 8);
         VH_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
         VH_HIP(hipMemsetAsync(h->results.p, 0, h->results.bytes(), h->stream));
         h->counts.alloc((size_t)(1 + h->ld / kRowsPerBlock));
@@ -645,58 +662,80 @@ int vh_clu_last_kernel_ms(vh_clu* h, float* ms) {
     });
 }
 
+}  // extern "C"
+
+namespace {
+
+// Launch one pass for k medoids and wait for its publication; returns the ring slot of the results.
+// The accumulators were zeroed by the publish kernel of the previous pass, the medoid rows travel in the
+// kernel arguments and the query vectors are gathered by the scan kernel itself.
+int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries) {
+    VH_REQUIRE(h != nullptr && medoid_rows != nullptr, "NULL argument");
+    VH_REQUIRE(k >= 1 && k <= kMaxMedoids, "k=%d outside [1, %d]", k, kMaxMedoids);
+    const int km = pick_km(k);
+    MedoidRows med;
+    for (int j = 0; j < kMaxMedoids; ++j) {
+        const int64_t m = medoid_rows[j < k ? j : 0];
+        VH_REQUIRE(m >= -1 && m < h->n_rows, "medoid row %lld out of range", (long long)m);
+        VH_REQUIRE(queries != nullptr || m >= 0, "medoid row -1 needs an explicit query vector");
+        med.row[j] = m;
+    }
+    const float* q_ext = nullptr;
+    if (queries) {
+        for (int j = 0; j < km; ++j) {
+            const float* src = queries + (size_t)(j < k ? j : 0) * h->L;
+            float* dst = h->h_q.p + (size_t)j * h->L4;
+            for (int c = 0; c < h->L4; ++c) dst[c] = c < h->L ? src[c] : 0.0f;
+        }
+        VH_HIP(hipMemcpyAsync(h->q.p, h->h_q.p, (size_t)km * h->L4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        q_ext = h->q.p;
+    }
+    const int slot = (int)(h->scan_seq % kListRing);
+    int32_t* lists = h->lists + (size_t)slot * kMaxMedoids * kListCap;
+    h->timer.start(h->stream);
+    dispatch_scan(h, km, med, q_ext);
+    h->timer.stop(h->stream);
+    hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kBlock), 0, h->stream, km, h->results.p, h->lists_dev.p, lists,
+                       h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1));
+    VH_HIP(hipGetLastError());
+    wait_for_scan(h, h->scan_seq + 1);
+    if (h->timer.enabled) {
+        VH_HIP(hipStreamSynchronize(h->stream));
+        h->timer.collect();
+    }
+    // one bulk copy of the compact summaries into ordinary memory
+    unsigned long long sm[kMaxMedoids * 4];
+    memcpy(sm, h->summary(slot), (size_t)k * 4 * 8);
+    h->last_summary[slot].assign(sm, sm + (size_t)k * 4);
+    h->last_counts[slot].assign(kMaxMedoids, 0u);
+    for (int j = 0; j < k; ++j) {
+        const unsigned long long n_within = sm[4 * j + 1], cursor = sm[4 * j + 3];
+        // the list is complete iff every within-radius row was appended: cursor == n_within <= capacity
+        h->last_counts[slot][j] = (cursor == n_within && n_within <= (unsigned long long)kListCap)
+                                      ? (unsigned int)n_within : (unsigned int)kListCap + 1u;
+    }
+    h->last_k = k;
+    h->scan_seq++;
+    return slot;
+}
+
+}  // namespace
+
+extern "C" {
+
 int vh_clu_scan(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries, vh_scan_result* out) {
     return guarded([&] {
-        VH_REQUIRE(h != nullptr && medoid_rows != nullptr && out != nullptr, "NULL argument");
-        VH_REQUIRE(k >= 1 && k <= kMaxMedoids, "k=%d outside [1, %d]", k, kMaxMedoids);
-        const int km = pick_km(k);
-        MedoidRows med;
-        for (int j = 0; j < kMaxMedoids; ++j) {
-            const int64_t m = medoid_rows[j < k ? j : 0];
-            VH_REQUIRE(m >= -1 && m < h->n_rows, "medoid row %lld out of range", (long long)m);
-            VH_REQUIRE(queries != nullptr || m >= 0, "medoid row -1 needs an explicit query vector");
-            med.row[j] = m;
-        }
-        const float* q_ext = nullptr;
-        if (queries) {
-            for (int j = 0; j < km; ++j) {
-                const float* src = queries + (size_t)(j < k ? j : 0) * h->L;
-                float* dst = h->h_q.p + (size_t)j * h->L4;
-                for (int c = 0; c < h->L4; ++c) dst[c] = c < h->L ? src[c] : 0.0f;
-            }
-            VH_HIP(hipMemcpyAsync(h->q.p, h->h_q.p, (size_t)km * h->L4 * sizeof(float), hipMemcpyHostToDevice,
-                                  h->stream));
-            q_ext = h->q.p;
-        }
-        // One launch + one small copy per scan.  The accumulators were zeroed by the trailing memset of
-        // the previous scan (stream order), the medoid rows travel in the kernel arguments and the query
-        // vectors are gathered by the kernel itself.
-        const int slot = (int)(h->scan_seq % kListRing);
-        int32_t* lists = h->lists + (size_t)slot * kMaxMedoids * kListCap;
-        h->timer.start(h->stream);
-        dispatch_scan(h, km, med, q_ext);
-        h->timer.stop(h->stream);
-        hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kBlock), 0, h->stream, km, h->results.p, h->lists_dev.p,
-                           lists, h->host_results, (unsigned long long)(h->scan_seq + 1));
-        VH_HIP(hipGetLastError());
-        wait_for_scan(h, h->scan_seq + 1);
-        if (h->timer.enabled) {
-            VH_HIP(hipStreamSynchronize(h->stream));
-            h->timer.collect();
-        }
-        h->last_counts[slot].assign(kMaxMedoids, 0u);
+        VH_REQUIRE(out != nullptr, "NULL argument");
+        const int slot = scan_core(h, k, medoid_rows, queries);
+        const std::vector<unsigned long long>& sm = h->last_summary[slot];
+        std::vector<unsigned long long> hist((size_t)k * VH_NBINS);
+        memcpy(hist.data(), h->hist(slot), hist.size() * 8);
         for (int j = 0; j < k; ++j) {
-            const unsigned long long* r = h->host_results + (size_t)j * kResultWords;
-            out[j].density_fx = (int64_t)r[0];
-            for (int b = 0; b < VH_NBINS; ++b) out[j].hist_fx[b] = (int64_t)r[1 + b];
-            out[j].n_within = (int64_t)r[1 + VH_NBINS];
-            out[j].n_lt = (int64_t)r[2 + VH_NBINS];
-            // the list is complete iff every within-radius row was appended: cursor == n_within <= capacity
-            h->last_counts[slot][j] = (r[3 + VH_NBINS] == r[1 + VH_NBINS] && r[1 + VH_NBINS] <= (unsigned long long)kListCap)
-                                          ? (unsigned int)r[1 + VH_NBINS] : (unsigned int)kListCap + 1u;
+            out[j].density_fx = (int64_t)sm[4 * j + 0];
+            for (int b = 0; b < VH_NBINS; ++b) out[j].hist_fx[b] = (int64_t)hist[(size_t)j * VH_NBINS + b];
+            out[j].n_within = (int64_t)sm[4 * j + 1];
+            out[j].n_lt = (int64_t)sm[4 * j + 2];
         }
-        h->last_k = k;
-        h->scan_seq++;
     });
 }
 
@@ -957,9 +996,13 @@ struct PyRandom {
 struct GenStats {
     double density = 0.0;
     int64_t n_within = 0, n_lt = 0;
-    int64_t hist_fx[VH_NBINS];
+    int64_t hist_fx[VH_NBINS];     // fetched on demand (only the medoid a cluster is built around needs it)
+    bool have_hist = false;
     bool have_list = false;
     std::vector<int64_t> within;   // ascending rows inside the medoid radius (when have_list)
+    uint64_t seq = 0;              // scan that produced the statistics; its results sit in ring slot seq % kListRing
+    int slot_j = 0;
+    unsigned int list_count = 0;   // > kListCap: the device list is incomplete
 };
 
 // float32(0.005) * float32(N(0, 0.01) pdf) -- the _NORMALPDF table of cluster.py:39-73
@@ -997,9 +1040,19 @@ struct vh_gen {
     int64_t scan_passes = 0, scan_medoids = 0, rows_streamed = 0;
     double kernel_ms = 0.0;
     std::vector<int64_t> sel;       // scratch
+    // optional wall-clock breakdown (VAMBHIP_GEN_PROFILE=1): scan calls, select calls, seed walk, logical index
+    bool profile = false;
+    double t_scan = 0, t_select = 0, t_seed = 0, t_logical = 0, t_total = 0;
 };
 
 namespace {
+
+struct GenTimer {
+    double* acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit GenTimer(double* a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~GenTimer() { *acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 void gen_check(int rc) {
     if (rc != VH_OK) throw ::vh::HipError{hipErrorUnknown, g_last_error.c_str(), __FILE__, __LINE__};
@@ -1018,30 +1071,32 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         if (std::find(missing.begin(), missing.end(), m) != missing.end()) continue;
         missing.push_back(m);
     }
-    vh_scan_result res[kMaxMedoids];
     for (size_t lo = 0; lo < missing.size(); lo += kMaxMedoids) {
         const int k = (int)std::min<size_t>(kMaxMedoids, missing.size() - lo);
         const uint64_t seq = g->clu->scan_seq;
-        gen_check(vh_clu_scan(g->clu, k, missing.data() + lo, nullptr, res));
+        int slot;
+        {
+            GenTimer t(&g->t_scan);
+            slot = scan_core(g->clu, k, missing.data() + lo, nullptr);
+        }
         g->scan_passes++;
         g->scan_medoids += k;
         g->rows_streamed += g->clu->n_rows;
         gen_collect_ms(g);
-        const int slot = (int)(seq % kListRing);
+        const std::vector<unsigned long long>& sm = g->clu->last_summary[slot];
         for (int j = 0; j < k; ++j) {
             GenStats& st = g->stats[missing[lo + j]];
             // the python float the reference gets from `.sum().item()` on a float32 tensor (cluster.py:629)
-            st.density = (double)(float)((double)res[j].density_fx / VH_DENSITY_SCALE);
-            st.n_within = res[j].n_within;
-            st.n_lt = res[j].n_lt;
-            for (int b = 0; b < VH_NBINS; ++b) st.hist_fx[b] = res[j].hist_fx[b];
-            const unsigned int cnt = g->clu->last_counts[slot][j];
-            st.have_list = cnt <= (unsigned int)kListCap;
-            if (st.have_list) {
-                const int32_t* src = g->clu->lists + ((size_t)slot * kMaxMedoids + j) * kListCap;
-                st.within.assign(src, src + cnt);
-                std::sort(st.within.begin(), st.within.end());
-            }
+            st.density = (double)(float)((double)(int64_t)sm[4 * j] / VH_DENSITY_SCALE);
+            st.n_within = (int64_t)sm[4 * j + 1];
+            st.n_lt = (int64_t)sm[4 * j + 2];
+            st.have_hist = false;
+            // histogram and candidate list stay in the host-mapped ring; they are fetched only for the few
+            // medoids that need them (host reads of that memory are slow: one bulk copy, on demand)
+            st.seq = seq;
+            st.slot_j = j;
+            st.list_count = g->clu->last_counts[slot][j];
+            st.have_list = false;
         }
     }
 }
@@ -1049,6 +1104,7 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
 int64_t gen_select(vh_gen* g, int64_t medoid, float threshold, bool remove) {
     int64_t n = 0;
     g->sel.resize((size_t)std::max<int64_t>(1, g->clu->n_rows));
+    GenTimer t(&g->t_select);
     gen_check(vh_clu_select(g->clu, medoid, nullptr, threshold, remove ? 1 : 0, g->sel.data(), (int64_t)g->sel.size(), &n));
     g->scan_passes++;
     g->rows_streamed += g->clu->n_rows;
@@ -1059,8 +1115,19 @@ int64_t gen_select(vh_gen* g, int64_t medoid, float threshold, bool remove) {
 const std::vector<int64_t>& gen_within(vh_gen* g, int64_t medoid) {
     GenStats& st = g->stats.at(medoid);
     if (!st.have_list) {
-        const int64_t n = gen_select(g, medoid, 0.05f, false);
-        st.within.assign(g->sel.begin(), g->sel.begin() + n);
+        const bool in_ring = g->clu->scan_seq - st.seq <= (uint64_t)kListRing;
+        if (in_ring && st.list_count <= (unsigned int)kListCap) {
+            const int slot = (int)(st.seq % kListRing);
+            g->clu->h_sel.resize(st.list_count);
+            if (st.list_count)
+                memcpy(g->clu->h_sel.data(), g->clu->lists + ((size_t)slot * kMaxMedoids + st.slot_j) * kListCap,
+                       (size_t)st.list_count * sizeof(int32_t));
+            std::sort(g->clu->h_sel.begin(), g->clu->h_sel.end());
+            st.within.assign(g->clu->h_sel.begin(), g->clu->h_sel.end());
+        } else {
+            const int64_t n = gen_select(g, medoid, 0.05f, false);
+            st.within.assign(g->sel.begin(), g->sel.begin() + n);
+        }
         st.have_list = true;
     }
     return st.within;
@@ -1068,6 +1135,7 @@ const std::vector<int64_t>& gen_within(vh_gen* g, int64_t medoid) {
 
 // cluster.py:342-384
 int64_t gen_next_seed(vh_gen* g) {
+    GenTimer t(&g->t_seed);
     int64_t n_order = (int64_t)g->order.size();
     int64_t i = g->order_index - 1;
     while (true) {
@@ -1137,6 +1205,29 @@ int64_t gen_wander(vh_gen* g, int64_t seed) {
 }
 
 // cluster.py:452-543 on the exact histogram of the scan
+void gen_fetch_hist(vh_gen* g, int64_t medoid, GenStats& st) {
+    if (st.have_hist) return;
+    if (g->clu->scan_seq - st.seq > (uint64_t)kListRing) {
+        // its scan has left the ring: one more pass for this medoid alone (same exact accumulators)
+        const uint64_t seq = g->clu->scan_seq;
+        {
+            GenTimer t(&g->t_scan);
+            (void)scan_core(g->clu, 1, &medoid, nullptr);
+        }
+        g->scan_passes++;
+        g->scan_medoids += 1;
+        g->rows_streamed += g->clu->n_rows;
+        gen_collect_ms(g);
+        st.seq = seq;
+        st.slot_j = 0;
+        st.list_count = g->clu->last_counts[(int)(seq % kListRing)][0];
+    }
+    unsigned long long tmp[VH_NBINS];
+    memcpy(tmp, g->clu->hist((int)(st.seq % kListRing)) + (size_t)st.slot_j * VH_NBINS, sizeof(tmp));
+    for (int b = 0; b < VH_NBINS; ++b) st.hist_fx[b] = (int64_t)tmp[b];
+    st.have_hist = true;
+}
+
 ThresholdKind gen_find_threshold(const vh_gen* g, const GenStats& st, double* threshold, double* observed_pvr) {
     if (st.n_lt == 1) return kLoner;
     float hist[VH_NBINS];
@@ -1181,7 +1272,8 @@ ThresholdKind gen_find_threshold(const vh_gen* g, const GenStats& st, double* th
     return kThreshold;
 }
 
-int64_t gen_logical_index(const vh_gen* g, int64_t row) {
+int64_t gen_logical_index(vh_gen* g, int64_t row) {
+    GenTimer t(&g->t_logical);
     int64_t c = 0;
     for (int64_t r = 0; r < row; ++r) c += g->kept[r] ? 1 : 0;
     return c;
@@ -1208,6 +1300,7 @@ int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, in
         g->pack_fraction = pack_fraction;
         g->pack_min_rows = pack_min_rows;
         g->rng.seed(rng_seed);
+        g->profile = getenv("VAMBHIP_GEN_PROFILE") != nullptr;
         g->order.assign(order, order + n);
         g->indices.resize((size_t)n);
         for (int64_t i = 0; i < n; ++i) g->indices[(size_t)i] = i;
@@ -1219,6 +1312,10 @@ int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, in
 }
 
 int vh_gen_destroy(vh_gen* g) {
+    if (g && g->profile)
+        fprintf(stderr, "[vambhip] generator: total %.1f ms = scans %.1f + selects %.1f + seed walk %.1f + logical index %.1f + rest %.1f\n",
+                g->t_total, g->t_scan, g->t_select, g->t_seed, g->t_logical,
+                g->t_total - g->t_scan - g->t_select - g->t_seed - g->t_logical);
     delete g;
     return VH_OK;
 }
@@ -1229,13 +1326,15 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
         VH_REQUIRE(g != nullptr && info != nullptr && members != nullptr, "NULL argument");
         memset(info, 0, sizeof(*info));
         if (g->n_remaining == 0) return;
+        GenTimer t_all(&g->t_total);
         int64_t n_points = 0;
         std::vector<int64_t> points;
         while (true) {
             const int64_t seed = gen_next_seed(g);
             const int64_t medoid = gen_wander(g, seed);
-            const GenStats& st = g->stats.at(medoid);
+            GenStats& st = g->stats.at(medoid);
             double threshold = 0.0, observed = 0.0;
+            if (st.n_lt != 1) gen_fetch_hist(g, medoid, st);
             const ThresholdKind kind = gen_find_threshold(g, st, &threshold, &observed);
             const int64_t original = g->indices[(size_t)medoid];
             info->medoid = original;
