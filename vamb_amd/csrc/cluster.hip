@@ -38,6 +38,7 @@ constexpr int kRowsPerBlock = kBlock * kRowsPerThread;  // 1024
 constexpr int kResultWords = VH_NBINS + 4;              // density, hist[60], n_within, n_lt, list cursor
 constexpr int kMaxMedoids = 32;
 constexpr int kListCap = 2048;    // rows within the medoid radius kept per medoid by the scan itself
+constexpr int64_t kMinScanBlocks = 768;   // workgroups wanted before lanes are given more than one row
 constexpr int kListRing = 16;     // scans whose lists stay readable (one cluster search rarely needs more)
 constexpr int kLocalCap = 128;    // per-block, per-medoid staging of list entries in LDS
 
@@ -126,9 +127,11 @@ __device__ __forceinline__ void load_rows(const float* __restrict__ p, float (&x
     if constexpr (RPT == 4) {
         const float4 v = *reinterpret_cast<const float4*>(p);
         x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-    } else {
+    } else if constexpr (RPT == 2) {
         const float2 v = *reinterpret_cast<const float2*>(p);
         x[0] = v.x; x[1] = v.y;
+    } else {
+        x[0] = *p;
     }
 }
 
@@ -137,9 +140,11 @@ __device__ __forceinline__ void load_live(const uint8_t* __restrict__ p, unsigne
     if constexpr (RPT == 4) {
         const uchar4 v = *reinterpret_cast<const uchar4*>(p);
         x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-    } else {
+    } else if constexpr (RPT == 2) {
         const uchar2 v = *reinterpret_cast<const uchar2*>(p);
         x[0] = v.x; x[1] = v.y;
+    } else {
+        x[0] = *p;
     }
 }
 
@@ -494,6 +499,7 @@ struct vh_clu {
         return host_results + (size_t)kListRing * kMaxMedoids * 4 + (size_t)slot * kMaxMedoids * VH_NBINS;
     }
     unsigned long long* flag() { return host_results + (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS); }
+    bool small_rpt = true;        // VAMBHIP_SCAN_WIDE=1 disables the narrow variant (A/B measurements)
     uint64_t scan_seq = 0;        // number of scans issued; scan s wrote ring slot s % kListRing
     int last_k = 0;
     std::vector<unsigned int> last_counts[kListRing];   // list lengths of the scans still in the ring
@@ -537,14 +543,27 @@ void wait_for_scan(vh_clu* h, unsigned long long seq) {
     std::atomic_thread_fence(std::memory_order_acquire);
 }
 
-template <int KM>
-void launch_scan(vh_clu* h, const MedoidRows& med, const float* q_ext) {
-    constexpr int RPT = (KM >= 12) ? 2 : 4;
+template <int KM, int RPT>
+void launch_scan_rpt(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     const size_t smem = (size_t)KM * kResultWords * 8 + 64 * 4 + (size_t)KM * h->L4 * 4 + (size_t)KM * 4 * (1 + kLocalCap);
     const int64_t blocks = ceil_div(h->ld, (int64_t)kBlock * RPT);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
     hipLaunchKernelGGL((clu_scan_kernel<KM, RPT>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
                        h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_dev.p);
+}
+
+// Rows per lane: 4 (few medoids) or 2 keep the loads wide for matrices that stream from HBM.  A matrix that
+// fits the Infinity Cache is latency-bound instead: it gets the widest variant that still yields ~3 workgroups
+// per CU, down to one row per lane (C1 sweep: scan kernels 262 -> 206 ms with this rule).
+template <int KM>
+void launch_scan(vh_clu* h, const MedoidRows& med, const float* q_ext) {
+    constexpr int RPT = (KM >= 12) ? 2 : 4;
+    int rpt = RPT;
+    if (h->small_rpt)
+        while (rpt > 1 && ceil_div(h->n_rows, (int64_t)kBlock * rpt) < kMinScanBlocks) rpt >>= 1;
+    if (rpt == 1) launch_scan_rpt<KM, 1>(h, med, q_ext);
+    else if (rpt == 2) launch_scan_rpt<KM, 2>(h, med, q_ext);
+    else launch_scan_rpt<KM, RPT>(h, med, q_ext);
 }
 
 void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext) {
@@ -602,6 +621,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->lengths.alloc((size_t)h->ld);
         h->kept.alloc((size_t)h->ld);
         h->q.alloc((size_t)kMaxMedoids * h->L4);
+        h->small_rpt = getenv("VAMBHIP_SCAN_WIDE") == nullptr;
         h->results.alloc((size_t)kMaxMedoids * kResultWords);
         h->lists_dev.alloc((size_t)kMaxMedoids * kListCap);
         VH_HIP(hipHostMalloc((void**)&h->lists, (size_t)kListRing * kMaxMedoids * kListCap * sizeof(int32_t),
