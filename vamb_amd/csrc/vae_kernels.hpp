@@ -499,17 +499,35 @@ __global__ __launch_bounds__(256) void vae_latent_bwd_kernel(const float* __rest
     const int col = blockIdx.x * kCT + threadIdx.x;
     const int r0 = blockIdx.y * kRB, r1 = min(bs_p, r0 + kRB);
     float s = 0.f;
-    if (col < L_p)
-        for (int r = r0 + threadIdx.y; r < r1; r += kRL) {
+    if (col < L_p) {
+        // every load of the thread's kRB / kRL rows is issued before the first add (the kernel is a chain of
+        // dependent L2 latencies otherwise: 10.6 us for 4.7 MB)
+        constexpr int RPT = kRB / kRL;
+        constexpr int kMaxSlabs = 8;
+        float v[RPT], sl[RPT][kMaxSlabs];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + threadIdx.y + kRL * k;
             const int64_t i = (int64_t)r * L_p + col;
-            float v = 0.f;
-            if (r < bs) {
-                v = dMUk[i];
-                for (int k = 0; k < nslab; ++k) v += slabs[(int64_t)k * stride + i];
-            }
-            DZ[i] = v;
-            s += v;
+            const bool live = r < r1 && r < bs;
+            v[k] = live ? dMUk[i] : 0.f;
+#pragma unroll
+            for (int q = 0; q < kMaxSlabs; ++q) sl[k][q] = (live && q < nslab) ? slabs[(int64_t)q * stride + i] : 0.f;
         }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + threadIdx.y + kRL * k;
+            if (r >= r1) continue;
+            float t = v[k];
+#pragma unroll
+            for (int q = 0; q < kMaxSlabs; ++q)
+                if (q < nslab) t += sl[k][q];
+            if (r < bs)
+                for (int q = kMaxSlabs; q < nslab; ++q) t += slabs[(int64_t)q * stride + (int64_t)r * L_p + col];
+            DZ[(int64_t)r * L_p + col] = t;
+            s += t;
+        }
+    }
     s = column_block_sum(s, red);
     if (threadIdx.y == 0 && col < L_p) part[(int64_t)blockIdx.y * L_p + col] = s;
 }
