@@ -200,6 +200,11 @@ int vh_vae_encode(vh_vae* h, float* latent);
 /* D-Adapt-Adam group state (d, numerator_weighted, k) */
 int vh_vae_opt_state(vh_vae* h, double* d, double* numerator_weighted, int64_t* k);
 
+/* Arithmetic of the dense contractions: 0 (default) = fp32 operands on the fp32 MFMA (BASELINE config C1);
+ * 1 = operands rounded to bf16 while they are staged, bf16 MFMA with fp32 accumulation (configs C2-C4).
+ * Tensors in memory, BatchNorm, loss and optimiser stay fp32 either way.  May be changed between calls. */
+int vh_vae_set_precision(vh_vae* h, int bf16_operands);
+
 /* Optional HIP-event probe around the forward GEMM of encoder layer `layer` (bench.py roofline):
  * after vh_vae_train_epoch, *ms_total is the summed duration of the probed launches and *launches
  * their number; *flops_per_launch = 2*batch*K*N of that GEMM. */

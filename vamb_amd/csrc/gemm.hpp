@@ -84,6 +84,7 @@ struct GemmArgs {
     const float* Hbelow;  // activations of the layer below (same shape / ld as C)
     BnSrc bnC;            // its forward statistics
     double* bstat_out;    // [2][N]
+    int bf16;             // 1: launch the bf16-operand instantiation (host-side dispatch only)
     int xcd_remap;        // 1: give every XCD a contiguous chunk of the tile grid (L2 reuse of operand panels)
 };
 
@@ -114,15 +115,22 @@ __device__ __forceinline__ void bn_column(const BnSrc& s, int col, float& mean, 
     shift = s.beta[col] - mean * scale;
 }
 
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE,
-          int BK = 32>
+          int BK = 32, int DT = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g) {
+    // DT = 0: fp32 operands on v_mfma_f32_32x32x2_f32.  DT = 1 (BASELINE configs C2+): the operands are
+    // rounded to bf16 (RNE) while they are staged into LDS and contracted on v_mfma_f32_32x32x16_bf16 with
+    // fp32 accumulation; global tensors, transforms and epilogues stay fp32.
+    constexpr bool BF = DT == 1;
     constexpr int NT = WM * WN * 64;       // threads per workgroup (1 wavefront per 32x32-tile group)
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     constexpr int KQ = BK / 4;             // float4 units along K of an operand row
-    constexpr int UA = (BM * KQ + NT - 1) / NT;   // float4 registers per thread per K-tile
-    constexpr int UB = (BN * KQ + NT - 1) / NT;
+    // float4 registers per thread per K-tile (bf16, row-contiguous operand: pairs of K rows)
+    constexpr int UA = (BF && !A_KC) ? 2 * ((4 * BM + NT - 1) / NT) : (BM * KQ + NT - 1) / NT;
+    constexpr int UB = (BF && !B_KC) ? 2 * ((4 * BN + NT - 1) / NT) : (BN * KQ + NT - 1) / NT;
     static_assert(BK == 32, "the swizzled LDS image is 8 quads (32 floats) wide");
     static_assert(WM * WN == 4 || WM * WN == 1, "4 wavefronts per workgroup, or a single free-running one");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
@@ -136,8 +144,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     // it into the K-contiguous image costs more in conflicting ds_write_b64 than the wide reads give back
     // (measured: dW GEMM 57 -> 52 TF/s).
     constexpr int SA = BM + 4, SB = BN + 4;                 // row-contiguous image: floats per k row
-    constexpr int TILE_A = A_KC ? BM * BK : BK * SA;        // floats per buffer
-    constexpr int TILE_B = B_KC ? BN * BK : BK * SB;
+    // bf16: every operand uses the K-contiguous image [rows][32 bf16] (64 B per row, 4 quads of 8 elements, quad q
+    // in slot q ^ ((row >> 2) & 3)): one ds_read_b128 is the 8-element operand of one 32x32x16 MFMA.
+    constexpr int TILE_A = BF ? BM * BK / 2 : (A_KC ? BM * BK : BK * SA);        // floats per buffer
+    constexpr int TILE_B = BF ? BN * BK / 2 : (B_KC ? BN * BK : BK * SB);
     extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
     float* As = gemm_smem;                 // [2][TILE_A]
     float* Bs = gemm_smem + 2 * TILE_A;    // [2][TILE_B]
@@ -232,6 +242,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
                 ra[r] = zero4;
                 if (u < BM * KQ && gm < g.M) ra[r] = *reinterpret_cast<const float4*>(g.A + (int64_t)gm * g.lda + k0 + 4 * kq);
             }
+        } else if constexpr (BF) {
+            // pair unit u = (k-pair u / (rows/4), row-quad u % (rows/4)): rows 4q..4q+3 at k = 2p and 2p + 1
+#pragma unroll
+            for (int r = 0; r < UA / 2; ++r) {
+                const int u = tid + NT * r;
+                const int kp = u / (BM / 4), mq = u % (BM / 4), gm = m0 + 4 * mq;
+                ra[2 * r] = zero4;
+                ra[2 * r + 1] = zero4;
+                if (u < 4 * BM && gm < g.M) {
+                    const float* src = g.A + (int64_t)(k0 + 2 * kp) * g.lda + gm;
+                    ra[2 * r] = *reinterpret_cast<const float4*>(src);
+                    ra[2 * r + 1] = *reinterpret_cast<const float4*>(src + g.lda);
+                }
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < UA; ++r) {
@@ -248,6 +272,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
                 const int row = u / KQ, kq = u % KQ, gn = n0 + row;
                 rb[r] = zero4;
                 if (u < BN * KQ && gn < g.N) rb[r] = *reinterpret_cast<const float4*>(g.B + (int64_t)gn * g.ldb + k0 + 4 * kq);
+            }
+        } else if constexpr (BF) {
+#pragma unroll
+            for (int r = 0; r < UB / 2; ++r) {
+                const int u = tid + NT * r;
+                const int kp = u / (BN / 4), nq = u % (BN / 4), gn = n0 + 4 * nq;
+                rb[2 * r] = zero4;
+                rb[2 * r + 1] = zero4;
+                if (u < 4 * BN && gn < g.N) {
+                    const float* src = g.B + (int64_t)(k0 + 2 * kp) * g.ldb + gn;
+                    rb[2 * r] = *reinterpret_cast<const float4*>(src);
+                    rb[2 * r + 1] = *reinterpret_cast<const float4*>(src + g.ldb);
+                }
             }
         } else {
 #pragma unroll
@@ -270,8 +307,84 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     };
     auto swz = [](int row) -> int { return ((row >> 1) ^ (row >> 4)) & 7; };
 
+    // bf16 image helpers: element (row, k) at row * 32 + 8 * ((k >> 3) ^ swzb(row)) + (k & 7)   [bf16 units]
+    auto swzb = [](int row) -> int { return (row >> 2) & 3; };
+    auto pack2 = [](float lo, float hi) -> unsigned int {
+        const __bf16 a = (__bf16)lo, b = (__bf16)hi;   // round to nearest even (v_cvt_pk_bf16_f32)
+        return (unsigned int)__builtin_bit_cast(unsigned short, a) | ((unsigned int)__builtin_bit_cast(unsigned short, b) << 16);
+    };
+    auto sstore_bf16 = [&](int buf, int k0) {
+        unsigned short* as = reinterpret_cast<unsigned short*>(As + buf * TILE_A);
+        unsigned short* bs = reinterpret_cast<unsigned short*>(Bs + buf * TILE_B);
+        if constexpr (A_KC) {
+#pragma unroll
+            for (int r = 0; r < UA; ++r) {
+                const int u = tid + NT * r;
+                const int row = u / KQ, kq = u % KQ;
+                float4 v = ra[r];
+                if constexpr (XFA == XF_BN) v = bn4(v, coefA + (k0 - kbeg) + 4 * kq, coefA + ncolA + (k0 - kbeg) + 4 * kq);
+                if (u < BM * KQ)
+                    *reinterpret_cast<uint2*>(as + row * 32 + 8 * ((kq >> 1) ^ swzb(row)) + 4 * (kq & 1)) =
+                        make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < UA / 2; ++r) {
+                const int u = tid + NT * r;
+                const int kp = u / (BM / 4), mq = u % (BM / 4);
+                float4 v0 = ra[2 * r], v1 = ra[2 * r + 1];
+                if constexpr (XFA == XF_BN) {
+                    v0 = bn4(v0, coefA + 4 * mq, coefA + ncolA + 4 * mq);
+                    v1 = bn4(v1, coefA + 4 * mq, coefA + ncolA + 4 * mq);
+                }
+                if (u < 4 * BM) {
+                    const float e0[4] = {v0.x, v0.y, v0.z, v0.w}, e1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 4 * mq + i;
+                        *reinterpret_cast<unsigned int*>(as + row * 32 + 8 * ((kp >> 2) ^ swzb(row)) + 2 * (kp & 3)) =
+                            pack2(e0[i], e1[i]);
+                    }
+                }
+            }
+        }
+        if constexpr (B_KC) {
+#pragma unroll
+            for (int r = 0; r < UB; ++r) {
+                const int u = tid + NT * r;
+                const int row = u / KQ, kq = u % KQ;
+                float4 v = rb[r];
+                if constexpr (XFB == XF_BN) v = bn4(v, coefB + (k0 - kbeg) + 4 * kq, coefB + ncolB + (k0 - kbeg) + 4 * kq);
+                if (u < BN * KQ)
+                    *reinterpret_cast<uint2*>(bs + row * 32 + 8 * ((kq >> 1) ^ swzb(row)) + 4 * (kq & 1)) =
+                        make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < UB / 2; ++r) {
+                const int u = tid + NT * r;
+                const int kp = u / (BN / 4), nq = u % (BN / 4);
+                float4 v0 = rb[2 * r], v1 = rb[2 * r + 1];
+                if constexpr (XFB == XF_BN) {
+                    v0 = bn4(v0, coefB + 4 * nq, coefB + ncolB + 4 * nq);
+                    v1 = bn4(v1, coefB + 4 * nq, coefB + ncolB + 4 * nq);
+                }
+                if (u < 4 * BN) {
+                    const float e0[4] = {v0.x, v0.y, v0.z, v0.w}, e1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 4 * nq + i;
+                        *reinterpret_cast<unsigned int*>(bs + row * 32 + 8 * ((kp >> 2) ^ swzb(row)) + 2 * (kp & 3)) =
+                            pack2(e0[i], e1[i]);
+                    }
+                }
+            }
+        }
+    };
+
     // registers -> LDS (applied when the prefetched data has arrived)
     auto sstore = [&](int buf, int k0) {
+        if constexpr (BF) { sstore_bf16(buf, k0); return; }
         float* as = As + buf * TILE_A;
         float* bs = Bs + buf * TILE_B;
 #pragma unroll
@@ -334,6 +447,35 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) gload(kbeg + (c + 1) * BK);
+        if constexpr (BF) {
+            // two 32x32x16 steps per K-tile: lane (r, h) supplies k = 16 t + 8 h .. + 7 of its row (A and B alike)
+            const unsigned short* as16 = reinterpret_cast<const unsigned short*>(As + buf * TILE_A);
+            const unsigned short* bs16 = reinterpret_cast<const unsigned short*>(Bs + buf * TILE_B);
+            bf16x8 a8[TM][2], b8[TN][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wm * TM + i) * 32 + frag_r;
+                    a8[i][t] = *reinterpret_cast<const bf16x8*>(as16 + row * 32 + 8 * ((2 * t + frag_h) ^ swzb(row)));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = (wn * TN + j) * 32 + frag_r;
+                    b8[j][t] = *reinterpret_cast<const bf16x8*>(bs16 + row * 32 + 8 * ((2 * t + frag_h) ^ swzb(row)));
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i][t], b8[j][t], acc[i][j], 0, 0, 0);
+            if (c + 1 < nchunks) sstore(buf ^ 1, kbeg + (c + 1) * BK);
+            __syncthreads();
+            continue;
+        }
         const float* as = As + buf * TILE_A;
         const float* bs = Bs + buf * TILE_B;
         float af[TM][4][4], bf[TN][4][4];
@@ -471,9 +613,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
 }
 
 // dynamic LDS bytes: operand tiles + the coefficient tables of the requested transforms
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int XFA, int XFB, int BK = 32>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int XFA, int XFB, int BK = 32, int DT = 0>
 inline size_t gemm_smem_bytes(int k_per_split) {
-    size_t fl = 2 * BK * ((A_KC ? BM : BM + 4) + (B_KC ? BN : BN + 4));
+    size_t fl = DT == 1 ? (size_t)BK * (BM + BN) : 2 * BK * ((A_KC ? BM : BM + 4) + (B_KC ? BN : BN + 4));
     const int narr_a = XFA == XF_BN ? 2 : 0;
     const int narr_b = XFB == XF_BN ? 2 : 0;
     fl += (size_t)narr_a * (A_KC ? k_per_split : BM);

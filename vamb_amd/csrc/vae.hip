@@ -70,12 +70,12 @@ constexpr size_t kMaxDynLds = 120 * 1024;
 thread_local hipEvent_t t_probe_start = nullptr, t_probe_stop = nullptr;
 
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE,
-          int BK = 32>
+          int BK = 32, int DT = 0>
 void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
     static bool attr_set = false;
-    const size_t smem = gemm_smem_bytes<BM, BN, AKC, BKC, EPI, XFA, XFB, BK>(g.k_per_split);
+    const size_t smem = gemm_smem_bytes<BM, BN, AKC, BKC, EPI, XFA, XFB, BK, DT>(g.k_per_split);
     VH_REQUIRE(smem <= kMaxDynLds, "layer too wide for the fused GEMM (needs %zu bytes of LDS)", smem);
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AKC, BKC, EPI, XFA, XFB, BK>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AKC, BKC, EPI, XFA, XFB, BK, DT>;
     if (!attr_set) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kMaxDynLds));
@@ -101,6 +101,11 @@ void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
 // production tiles: 3 = 64x64 (2x2 waves, 2 workgroups per CU), 2 = 128x32 (4x1) for latent-wide outputs
 template <bool AKC, bool BKC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE>
 void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
+    if (g.bf16) {   // bf16 operands, fp32 accumulation (BASELINE configs C2+)
+        if (tile == 2) launch_gemm<128, 32, 4, 1, AKC, BKC, EPI, XFA, XFB, 32, 1>(s, g, splits);
+        else launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB, 32, 1>(s, g, splits);
+        return;
+    }
     if (tile == 2) launch_gemm<128, 32, 4, 1, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
     else launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
 }
@@ -109,6 +114,16 @@ void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
 // 5 = one free-running wave per 32x32 tile
 template <bool AKC, bool BKC, int EPI>
 void gemm_tile_debug(hipStream_t s, int tile, const GemmArgs& g, int splits) {
+    if (g.bf16) {
+        switch (tile) {
+            case 0: launch_gemm<64, 128, 2, 2, AKC, BKC, EPI, XF_NONE, XF_NONE, 32, 1>(s, g, splits); break;
+            case 1: launch_gemm<128, 128, 2, 2, AKC, BKC, EPI, XF_NONE, XF_NONE, 32, 1>(s, g, splits); break;
+            case 2: launch_gemm<128, 32, 4, 1, AKC, BKC, EPI, XF_NONE, XF_NONE, 32, 1>(s, g, splits); break;
+            case 5: launch_gemm<32, 32, 1, 1, AKC, BKC, EPI, XF_NONE, XF_NONE, 32, 1>(s, g, splits); break;
+            default: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XF_NONE, XF_NONE, 32, 1>(s, g, splits); break;
+        }
+        return;
+    }
     switch (tile) {
         case 0: launch_gemm<64, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
         case 1: launch_gemm<128, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
@@ -120,9 +135,10 @@ void gemm_tile_debug(hipStream_t s, int tile, const GemmArgs& g, int splits) {
 
 int fwd_tile(int N) { return N <= 32 ? 2 : 3; }
 
-GemmArgs base_args() {
+GemmArgs base_args(bool bf16 = false) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
+    g.bf16 = bf16 ? 1 : 0;
     g.drop_scale = 1.0f;
     static const int remap = [] {
         const char* e = getenv("VAMBHIP_XCD_REMAP");
@@ -136,6 +152,7 @@ GemmArgs base_args() {
 
 struct vh_vae {
     vh_vae_config cfg;
+    bool bf16 = false;   // GEMM operands rounded to bf16, fp32 accumulation (vh_vae_set_precision)
     int nl = 0;       // hidden layers per side
     int S = 0, D = 0, D_p = 0, L = 0, L_p = 0;
     float ce_w = 0, ab_w = 0, sse_w = 0, kld_w = 0;
@@ -507,7 +524,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
     auto hidden_layer = [&](int li) {
         Hidden& hl = h->hidden[li];
         const int tile = fwd_tile(hl.nout_p);
-        GemmArgs g = base_args();
+        GemmArgs g = base_args(h->bf16);
         g.A = in; g.lda = in_w;
         g.B = h->pptr(hl.tW); g.ldb = hl.nin_p;
         g.M = bs_p; g.N = hl.nout_p; g.K = hl.nin_p; g.k_per_split = g.K;
@@ -546,7 +563,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
     {   // mu = a * Wmu^T + bmu  (encode.py:268).  The output is only nlatent wide, so the contraction is
         // split over up to 8 workgroup slices (slabs); bias and the slab sum are folded into the
         // reparameterisation kernel below.
-        GemmArgs g = base_args();
+        GemmArgs g = base_args(h->bf16);
         g.A = in; g.lda = in_w;
         g.B = h->pptr(h->tWmu); g.ldb = in_w;
         g.C = h->skinny.p; g.ldc = h->L_p;
@@ -575,7 +592,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
     prev = nullptr;
     for (int li = h->nl; li < 2 * h->nl; ++li) hidden_layer(li);
     {   // reconstruction = a * Wo^T + bo  (encode.py:294)
-        GemmArgs g = base_args();
+        GemmArgs g = base_args(h->bf16);
         g.A = in; g.lda = in_w;
         g.B = h->pptr(h->tWo); g.ldb = in_w;
         g.C = h->R.p; g.ldc = h->D_p;
@@ -630,7 +647,7 @@ void loss_and_seed(vh_vae* h) {
 void grad_weight(vh_vae* h, int tW, const float* dZ, int out_p, const float* In, int in_p, const BnSrc* inbn) {
     Tensor& t = h->tensors[tW];
     const int tile = dw_tile(out_p, in_p);
-    GemmArgs g = base_args();
+    GemmArgs g = base_args(h->bf16);
     g.A = dZ; g.lda = out_p;
     g.B = In; g.ldb = in_p;
     g.C = t.slab; g.ldc = in_p;
@@ -655,7 +672,7 @@ void grad_weight(vh_vae* h, int tW, const float* dZ, int out_p, const float* In,
 //   to_latent: the input is the latent code: split-K slabs into h->skinny (returns their count)
 int grad_input(vh_vae* h, const float* dZ, int out_p, int tW, int in_p, float* dIn, const Hidden* below,
                bool to_latent) {
-    GemmArgs g = base_args();
+    GemmArgs g = base_args(h->bf16);
     g.A = dZ; g.lda = out_p;
     g.B = h->pptr(tW); g.ldb = in_p;
     g.M = h->bs_p; g.N = in_p; g.K = out_p;
@@ -1308,7 +1325,7 @@ int vh_vae_encode(vh_vae* h, float* latent) {
             float* bufs[2] = {a0.p, a1.p};
             for (int li = 0; li < h->nl; ++li) {
                 Hidden& hl = h->hidden[li];
-                GemmArgs g = base_args();
+                GemmArgs g = base_args(h->bf16);
                 g.A = in; g.lda = in_w;
                 g.B = h->pptr(hl.tW); g.ldb = hl.nin_p;
                 g.C = bufs[li & 1]; g.ldc = hl.nout_p;
@@ -1318,7 +1335,7 @@ int vh_vae_encode(vh_vae* h, float* latent) {
                 in = bufs[li & 1];
                 in_w = hl.nout_p;
             }
-            GemmArgs g = base_args();
+            GemmArgs g = base_args(h->bf16);
             g.A = in; g.lda = in_w;
             g.B = h->pptr(h->tWmu); g.ldb = in_w;
             g.C = lat.p; g.ldc = h->L;          // compact [m][L]: only the logical columns are stored
@@ -1340,6 +1357,13 @@ int vh_vae_opt_state(vh_vae* h, double* d, double* numerator_weighted, int64_t* 
         if (d) *d = st.d;
         if (numerator_weighted) *numerator_weighted = st.numerator_weighted;
         if (k) *k = st.k;
+    });
+}
+
+int vh_vae_set_precision(vh_vae* h, int bf16_operands) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "NULL handle");
+        h->bf16 = bf16_operands != 0;
     });
 }
 
@@ -1368,7 +1392,9 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
                   int N, int K, int splits, float* ms) {
     return guarded([&] {
         VH_REQUIRE(A && B && C, "NULL argument");
-        VH_REQUIRE(tile >= 0 && tile <= 5 && tile != 4, "tile in {0, 1, 2, 3, 5}");
+        const bool use_bf16 = tile >= 100;   // tile + 100: the bf16-operand instantiation of that tile
+        if (use_bf16) tile -= 100;
+        VH_REQUIRE(tile >= 0 && tile <= 5 && tile != 4, "tile in {0, 1, 2, 3, 5} (+100 for bf16 operands)");
         VH_REQUIRE(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && M % 4 == 0 && N % 4 == 0,
                    "need K multiple of 32 and M, N multiples of 4");
         VH_REQUIRE(splits >= 1 && (K / 32) >= splits, "bad split count");
@@ -1384,7 +1410,7 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
         VH_HIP(hipMemcpy(dA.p, A, sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
         VH_HIP(hipMemcpy(dB.p, B, sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice));
         if (bias) { dbias.alloc(N); VH_HIP(hipMemcpy(dbias.p, bias, sizeof(float) * N, hipMemcpyHostToDevice)); }
-        GemmArgs g = base_args();
+        GemmArgs g = base_args(use_bf16);
         g.A = dA.p; g.lda = a_kc ? K : M;
         g.B = dB.p; g.ldb = b_kc ? K : N;
         g.C = dC.p; g.ldc = N;

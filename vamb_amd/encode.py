@@ -31,6 +31,24 @@ from . import _lib
 logger = logging.getLogger("vamb_amd.encode")
 NTNF = 103
 
+# Arithmetic of the dense contractions of VAEs created from now on: "fp32" (fp32 MFMA, BASELINE config C1; the
+# default) or "bf16" (operands rounded to bf16, fp32 accumulation; BASELINE configs C2-C4).  The reference
+# signature of VAE() has no such argument, so it is a module setting (environment override: VAMBHIP_PRECISION).
+_COMPUTE_DTYPE = "fp32"
+
+
+def set_compute_dtype(dtype: str) -> None:
+    global _COMPUTE_DTYPE
+    if dtype not in ("fp32", "bf16"):
+        raise ValueError(f"compute dtype must be 'fp32' or 'bf16', not {dtype!r}")
+    _COMPUTE_DTYPE = dtype
+
+
+def get_compute_dtype() -> str:
+    import os
+
+    return os.environ.get("VAMBHIP_PRECISION", _COMPUTE_DTYPE)
+
 
 def _zscore_inplace(array: _np.ndarray, axis: Optional[int] = None) -> None:
     """In-place z-score with the reference's conventions (vambtools.py:250-288): population std,
@@ -187,6 +205,10 @@ class VAE:
         self._dataset_key = None
         self._n_rows = 0
         self._comm = None
+        self.compute_dtype = get_compute_dtype()
+        if self.compute_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"compute dtype must be 'fp32' or 'bf16', not {self.compute_dtype!r}")
+        _lib.check(self._lib.vh_vae_set_precision(self._h, int(self.compute_dtype == "bf16")))
 
     def attach_communicator(self, comm) -> None:
         """Data-parallel training over ``comm`` (``vamb_amd.parallel.Communicator``): this process holds
