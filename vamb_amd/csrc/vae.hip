@@ -68,6 +68,9 @@ constexpr size_t kMaxDynLds = 120 * 1024;
 // When set, the next launch_gemm records the kernel's own begin / end timestamps into this event pair
 // (hipExtLaunchKernelGGL: the dispatch packet's timestamps, the same source rocprofv3 reads) and clears it.
 thread_local hipEvent_t t_probe_start = nullptr, t_probe_stop = nullptr;
+// When set (and no probe is armed), the next launch_gemm signals this event from the kernel's own completion
+// signal -- a cross-stream fork without an extra barrier packet in the producing stream (fork_after below).
+thread_local hipEvent_t t_fork_stop = nullptr;
 
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE,
           int BK = 32, int DT = 0>
@@ -92,6 +95,9 @@ void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
     if (t_probe_start) {
         hipExtLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, t_probe_start, t_probe_stop, 0, g);
         t_probe_start = t_probe_stop = nullptr;
+    } else if (t_fork_stop) {
+        hipExtLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, nullptr, t_fork_stop, 0, g);
+        t_fork_stop = nullptr;
     } else {
         hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g);
     }
@@ -152,6 +158,8 @@ GemmArgs base_args(bool bf16 = false) {
 
 struct vh_vae {
     vh_vae_config cfg;
+    bool tail_on_main = true;   // VAMBHIP_TAIL_SIDE=1: keep the last weight-gradient GEMM on the side stream
+    bool fork_ext = true;   // forks ride on the producing kernel's completion signal (VAMBHIP_FORK_EVENTS=1: records)
     bool bf16 = false;   // GEMM operands rounded to bf16, fp32 accumulation (vh_vae_set_precision)
     int nl = 0;       // hidden layers per side
     int S = 0, D = 0, D_p = 0, L = 0, L_p = 0;
@@ -487,6 +495,22 @@ void fork_side(vh_vae* h) {
     VH_HIP(hipEventRecord(h->ev_fork, h->stream));
     VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
 }
+// An event record costs the recording stream one more barrier packet (~6 us before its next kernel starts, 7
+// forks per step).  Instead the producing kernel is launched with the fork event as its stop event
+// (hipExtLaunchKernelGGL: the event is the dispatch's own completion signal) and the side stream waits on that.
+bool fork_from_kernel(const vh_vae* h) { return h->side != h->stream && h->fork_ext; }
+template <class K, class... Args>
+void launch_forking(vh_vae* h, K kernel, dim3 grid, dim3 block, size_t smem, Args... args) {
+    if (fork_from_kernel(h)) {
+        hipExtLaunchKernelGGL(kernel, grid, block, smem, h->stream, nullptr, h->ev_fork, 0, args...);
+        VH_HIP(hipGetLastError());
+        VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, smem, h->stream, args...);
+        VH_HIP(hipGetLastError());
+        fork_side(h);
+    }
+}
 void join_side(vh_vae* h) {
     if (h->side == h->stream) return;
     VH_HIP(hipEventRecord(h->ev_join, h->side));
@@ -598,16 +622,19 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
         g.C = h->R.p; g.ldc = h->D_p;
         g.M = bs_p; g.N = h->D_p; g.K = in_w; g.k_per_split = g.K;
         g.bias = h->pptr(h->tbo);
+        const bool ext_fork = training && fork_from_kernel(h);
+        if (ext_fork) t_fork_stop = h->ev_fork;   // the running-statistics kernel below forks off this GEMM
         if (prev) {
             g.bnA = bn_src(h, *prev);
             gemm_tile<true, true, EPI_BIAS, XF_BN>(s, fwd_tile(h->D_p), g, 1);
         } else {
             gemm_tile<true, true, EPI_BIAS>(s, fwd_tile(h->D_p), g, 1);
         }
+        if (ext_fork) VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     }
     if (training) {
         // running statistics (momentum 0.1, unbiased variance): off the critical path, on the side stream
-        fork_side(h);
+        if (!fork_from_kernel(h)) fork_side(h);
         RunningTable rt;
         memset(&rt, 0, sizeof(rt));
         int maxn = 0;
@@ -624,7 +651,6 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
 }
 
 void loss_and_seed(vh_vae* h) {
-    hipStream_t s = h->stream;
     const int bs_global = h->global_bs > 0 ? h->global_bs : h->bs;
     LossArgs a;
     a.R = h->R.p; a.X = h->Xb.p; a.ld = h->D_p;
@@ -633,10 +659,9 @@ void loss_and_seed(vh_vae* h) {
     a.bs = h->bs; a.bs_p = h->bs_p; a.S = h->S; a.L = h->L;
     a.ce_w = h->ce_w; a.ab_w = h->ab_w; a.sse_w = h->sse_w; a.kld_w = h->kld_w;
     a.dR = h->dR.p; a.dMUk = h->dMUk.p; a.part = h->loss_part.p;
-    hipLaunchKernelGGL(vae_loss_kernel, dim3(h->loss_blocks), dim3(256), 0, s, a);
-    VH_HIP(hipGetLastError());
-    // the scalar reduction (loss means, sum of weights) is only needed by the optimiser: side stream
-    fork_side(h);
+    // the scalar reduction (loss means, sum of weights) is only needed by the optimiser: side stream; the
+    // output layer's weight gradient (backward) forks off the same point
+    launch_forking(h, vae_loss_kernel, dim3(h->loss_blocks), dim3(256), 0, a);
     hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, h->side, h->loss_part.p, h->loss_blocks,
                        h->Wb.p, h->bs, h->gwsum_src, bs_global, h->state.p);
     VH_HIP(hipGetLastError());
@@ -644,7 +669,9 @@ void loss_and_seed(vh_vae* h) {
 
 // dW slabs = dZ^T * In on the side stream (both operands row-contiguous along the batch).
 //   inbn: when given, B = raw H of the previous hidden layer and its BatchNorm is applied on load (XF_BN)
-void grad_weight(vh_vae* h, int tW, const float* dZ, int out_p, const float* In, int in_p, const BnSrc* inbn) {
+void grad_weight(vh_vae* h, int tW, const float* dZ, int out_p, const float* In, int in_p, const BnSrc* inbn,
+                 hipStream_t st = nullptr) {
+    if (!st) st = h->side;
     Tensor& t = h->tensors[tW];
     const int tile = dw_tile(out_p, in_p);
     GemmArgs g = base_args(h->bf16);
@@ -657,12 +684,12 @@ void grad_weight(vh_vae* h, int tW, const float* dZ, int out_p, const float* In,
     const int splits = (int)ceil_div(h->bs_p, g.k_per_split);
     if (splits < t.nslab)  // unused slabs must read as zero
         VH_HIP(hipMemsetAsync(t.slab + (int64_t)splits * t.stride, 0, sizeof(float) * (t.nslab - splits) * t.stride,
-                              h->side));
+                              st));
     if (inbn) {
         g.bnB = *inbn;
-        gemm_tile<false, false, EPI_SPLITK, XF_NONE, XF_BN>(h->side, tile, g, splits);
+        gemm_tile<false, false, EPI_SPLITK, XF_NONE, XF_BN>(st, tile, g, splits);
     } else {
-        gemm_tile<false, false, EPI_SPLITK>(h->side, tile, g, splits);
+        gemm_tile<false, false, EPI_SPLITK>(st, tile, g, splits);
     }
 }
 
@@ -705,14 +732,13 @@ int grad_input(vh_vae* h, const float* dZ, int out_p, int tW, int in_p, float* d
 // one dIn GEMM whose epilogue leaves dA plus the BatchNorm-backward sums of the layer below (so BatchNorm
 // backward has no reduction / finalize kernels).  Weight gradients run on the side stream.
 void backward(vh_vae* h, bool masks_injected) {
-    hipStream_t s = h->stream;
     const int bs = h->bs, bs_p = h->bs_p, nrb = bs_p / kRB;
     const DropCfg dc = drop_cfg(h, true, masks_injected);
     const int nl = h->nl;
     {   // output layer: dR is ready (loss kernel)
         Hidden& last = h->hidden[2 * nl - 1];
         const BnSrc inbn = bn_src(h, last);
-        fork_side(h);
+        // (the side stream already waits on the loss kernel: loss_and_seed)
         grad_weight(h, h->tWo, h->dR.p, h->D_p, last.H.p, last.nout_p, &inbn);
         hipLaunchKernelGGL(vae_colsum_partial_kernel, dim3((unsigned)ceil_div(h->D_p, kCT), nrb), dim3(kCT, kRL), 0,
                            h->side, h->dR.p, (int64_t)h->D_p, h->D_p, bs_p, h->tensors[h->tbo].slab);
@@ -731,19 +757,27 @@ void backward(vh_vae* h, bool masks_injected) {
         a.drop_scale = dc.scale;
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
         a.dbias = hl.dbias;
-        hipLaunchKernelGGL(vae_dz_kernel, dim3((unsigned)ceil_div(hl.nout_p, kDzCols), (unsigned)ceil_div(bs_p, kDzRows)),
-                           dim3(32, kRL), 0, s, a);
-        VH_HIP(hipGetLastError());
+        // The first encoder layer is the end of the chain: nothing is left on the main stream for its weight
+        // gradient to hide behind, so it runs there too (no fork, and the optimiser does not wait for a
+        // cross-stream hop: dZ -> dW -> join was 25 us longer on the side stream).
+        const bool tail = (li == 0) && h->tail_on_main;
+        if (tail) {
+            hipLaunchKernelGGL(vae_dz_kernel, dim3((unsigned)ceil_div(hl.nout_p, kDzCols), (unsigned)ceil_div(bs_p, kDzRows)),
+                               dim3(32, kRL), 0, h->stream, a);
+            VH_HIP(hipGetLastError());
+        } else {
+            launch_forking(h, vae_dz_kernel, dim3((unsigned)ceil_div(hl.nout_p, kDzCols), (unsigned)ceil_div(bs_p, kDzRows)),
+                           dim3(32, kRL), 0, a);
+        }
         const bool from_input = (li == 0) || (li == nl);          // input is Xb / Z: no BatchNorm to apply
         const Hidden* below = from_input ? nullptr : &h->hidden[li - 1];
         const float* In = li == 0 ? h->Xb.p : (li == nl ? h->Z.p : below->H.p);
         const int in_p = li == 0 ? h->D_p : (li == nl ? h->L_p : below->nout_p);
-        fork_side(h);
         if (below) {
             const BnSrc inbn = bn_src(h, *below);
             grad_weight(h, hl.tW, hl.DZ.p, hl.nout_p, In, in_p, &inbn);
         } else {
-            grad_weight(h, hl.tW, hl.DZ.p, hl.nout_p, In, in_p, nullptr);
+            grad_weight(h, hl.tW, hl.DZ.p, hl.nout_p, In, in_p, nullptr, tail ? h->stream : nullptr);
         }
         if (li == nl) latent_slabs = grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, h->DA.p, nullptr, true);
         else if (li > 0) grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, below->DA.p, below, false);
@@ -754,12 +788,10 @@ void backward(vh_vae* h, bool masks_injected) {
         Hidden& enc_last = h->hidden[nl - 1];
         // latent_slabs == 1: the first decoder layer wrote dZlat into DA; otherwise split-K slabs in skinny
         const float* src = latent_slabs == 1 ? h->DA.p : h->skinny.p;
-        hipLaunchKernelGGL(vae_latent_bwd_kernel, dim3((unsigned)ceil_div(h->L_p, kCT), nrb), dim3(kCT, kRL), 0, s, src,
-                           latent_slabs, (int64_t)bs_p * h->L_p, h->dMUk.p, h->dMU.p, h->L_p, bs, bs_p,
-                           h->tensors[h->tbmu].slab);
-        VH_HIP(hipGetLastError());
+        launch_forking(h, vae_latent_bwd_kernel, dim3((unsigned)ceil_div(h->L_p, kCT), nrb), dim3(kCT, kRL), 0, src,
+                       latent_slabs, (int64_t)bs_p * h->L_p, (const float*)h->dMUk.p, h->dMU.p, h->L_p, bs, bs_p,
+                       h->tensors[h->tbmu].slab);
         const BnSrc inbn = bn_src(h, enc_last);
-        fork_side(h);
         grad_weight(h, h->tWmu, h->dMU.p, h->L_p, enc_last.H.p, enc_last.nout_p, &inbn);
         grad_input(h, h->dMU.p, h->L_p, h->tWmu, enc_last.nout_p, enc_last.DA.p, &enc_last, false);
     }
@@ -930,8 +962,14 @@ int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
         VH_HIP(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, flat ? prio_lo : prio_hi));
         if (getenv("VAMBHIP_SINGLE_STREAM")) h->side = h->stream;
         else VH_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
-        VH_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        VH_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        // device-scope release: these events only order our two streams on the same GPU; the default
+        // (system-scope) release flushes L2 for a host that never waits on them
+        h->tail_on_main = getenv("VAMBHIP_TAIL_SIDE") == nullptr;
+        h->fork_ext = getenv("VAMBHIP_FORK_EVENTS") == nullptr && getenv("VAMBHIP_GRAPH") == nullptr;
+        const unsigned ev_flags = getenv("VAMBHIP_EVENT_SYSTEM") ? hipEventDisableTiming
+                                                                 : (hipEventDisableTiming | hipEventReleaseToDevice);
+        VH_HIP(hipEventCreateWithFlags(&h->ev_fork, ev_flags));
+        VH_HIP(hipEventCreateWithFlags(&h->ev_join, ev_flags));
 
         h->hidden.resize(2 * h->nl);
         auto make_hidden = [&](int li, const std::string& lin, const std::string& norm, int nin, int nout) {
