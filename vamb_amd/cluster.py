@@ -241,13 +241,18 @@ class HipScanBackend:
 class _MatrixView:
     """``ClusterGenerator.matrix`` -- supports ``.numpy()`` and ``len()`` like the reference's tensor."""
 
-    def __init__(self, backend):
+    def __init__(self, backend, sync=None):
         self._backend = backend
+        self._sync = sync          # refreshes backend.n_rows when the native state machine has packed the matrix
 
     def numpy(self) -> _np.ndarray:
+        if self._sync is not None:
+            self._sync()
         return self._backend.matrix()
 
     def __len__(self):
+        if self._sync is not None:
+            self._sync()
         return self._backend.n_rows
 
 
@@ -383,11 +388,12 @@ class ClusterGenerator:
         return self
 
     def _setup(self, lengths, maxsteps, windowsize, minsuccesses, rng_seed, native=False):
+        self._gen = None
         self.maxsteps: int = maxsteps
         self.minsuccesses: int = minsuccesses
         self.cuda: bool = True
         self.rng = _random.Random(rng_seed)
-        self.matrix = _MatrixView(self._backend)
+        self.matrix = _MatrixView(self._backend, self._sync_native_counters)
         n = self._backend.n_rows
         self.indices = _np.arange(n)                       # original row of every resident row
         self._kept = _np.ones(n, dtype=bool)               # host mirror of the device live mask
@@ -423,24 +429,32 @@ class ClusterGenerator:
         lib = self._backend.lib
         _lib.check(lib.vh_gen_next(self._gen, ctypes.byref(info), _lib.ptr(self._members_buf), len(self._members_buf)))
         if info.n_members == 0:
+            self._sync_native_counters()
             raise StopIteration
         members = self._members_buf[: info.n_members].copy()
         observed = info.observed_pvr if info.kind == 0 else None
         radius = None if info.kind == 1 else info.radius
-        # mirror the native counters on the Python objects (bench accounting, repr)
-        b = self._backend
+        self.n_emitted_clusters += 1
+        self.n_remaining_points -= int(info.n_members)
+        self.peak_valley_ratio = info.maximal_pvr
+        self._counters_stale = True
+        return Cluster(int(info.medoid), int(info.seed), members, info.maximal_pvr, observed, radius,
+                       int(info.successes), int(info.attempts))
+
+    def _sync_native_counters(self):
+        """Mirror the native counters on the Python objects (bench accounting, repr, len(matrix))."""
+        if self._gen is None or not getattr(self, "_counters_stale", False):
+            return
+        b, lib = self._backend, self._backend.lib
         passes, medoids, rows = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         emitted, remaining, ms = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double()
         _lib.check(lib.vh_gen_counters(self._gen, ctypes.byref(passes), ctypes.byref(medoids), ctypes.byref(rows),
                                        ctypes.byref(ms), ctypes.byref(emitted), ctypes.byref(remaining)))
         b.scan_passes, b.scan_medoids, b.rows_streamed, b.kernel_ms = passes.value, medoids.value, rows.value, ms.value
-        self.n_emitted_clusters, self.n_remaining_points = emitted.value, remaining.value
-        self.peak_valley_ratio = info.maximal_pvr
         n_rows, n_live = ctypes.c_int64(), ctypes.c_int64()
         _lib.check(lib.vh_clu_rows(b.h, ctypes.byref(n_rows), ctypes.byref(n_live)))
         b.n_rows = n_rows.value
-        return Cluster(int(info.medoid), int(info.seed), members, info.maximal_pvr, observed, radius,
-                       int(info.successes), int(info.attempts))
+        self._counters_stale = False
 
     def __iter__(self):
         return self

@@ -276,10 +276,17 @@ __global__ __launch_bounds__(kBlock) void clu_publish_kernel(int km, unsigned lo
                                                              unsigned long long* __restrict__ host_flag,
                                                              unsigned long long seq) {
     const int tid = threadIdx.x;
-    for (int j = 0; j < km; ++j) {
-        const unsigned long long cnt = results[j * kResultWords + 3 + VH_NBINS];
-        const int m = cnt <= (unsigned long long)kListCap ? (int)cnt : 0;
-        for (int i = tid; i < m; i += kBlock) host_lists[j * kListCap + i] = lists[j * kListCap + i];
+    // list lengths first (one parallel load), then the copies: 8 lanes per medoid, no dependent load per medoid
+    __shared__ int len_s[kMaxMedoids];
+    if (tid < km) {
+        const unsigned long long cnt = results[tid * kResultWords + 3 + VH_NBINS];
+        len_s[tid] = cnt <= (unsigned long long)kListCap ? (int)cnt : 0;
+    }
+    __syncthreads();
+    {
+        const int j = tid >> 3, l = tid & 7;   // 256 threads = 32 medoids x 8 lanes
+        if (j < km)
+            for (int i = l; i < len_s[j]; i += 8) host_lists[j * kListCap + i] = lists[j * kListCap + i];
     }
     // the four words every candidate needs (density, n_within, n_lt, list cursor) go to a compact block of
     // their own: the host reads 32 bytes per medoid instead of 512 (host reads of this memory are expensive)
@@ -1294,8 +1301,22 @@ ThresholdKind gen_find_threshold(const vh_gen* g, const GenStats& st, double* th
 
 int64_t gen_logical_index(vh_gen* g, int64_t row) {
     GenTimer t(&g->t_logical);
-    int64_t c = 0;
-    for (int64_t r = 0; r < row; ++r) c += g->kept[r] ? 1 : 0;
+    // count of live rows before `row`: the mask holds 0 / 1 bytes, summed eight at a time
+    const uint8_t* k = g->kept.data();
+    int64_t c = 0, r = 0;
+    while (r + 8 <= row) {
+        uint64_t acc = 0;
+        const int64_t stop = std::min<int64_t>(row - 7, r + 8 * 255);   // a byte lane holds at most 255 ones
+        for (; r < stop; r += 8) {
+            uint64_t w;
+            memcpy(&w, k + r, 8);
+            acc += w;
+        }
+        acc = (acc & 0x00FF00FF00FF00FFull) + ((acc >> 8) & 0x00FF00FF00FF00FFull);
+        acc = (acc & 0x0000FFFF0000FFFFull) + ((acc >> 16) & 0x0000FFFF0000FFFFull);
+        c += (int64_t)((acc & 0xFFFFFFFFull) + (acc >> 32));
+    }
+    for (; r < row; ++r) c += k[r];
     return c;
 }
 
