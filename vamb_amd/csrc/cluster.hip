@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                                                           const float* __restrict__ q_ext,
                                                           const MedoidRows medoid,
                                                           unsigned long long* __restrict__ results,
-                                                          int32_t* __restrict__ lists) {
+                                                          int32_t* __restrict__ lists, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(smem_raw);       // [KM][kResultWords]
     float* edges_s = reinterpret_cast<float*>(acc_s + KM * kResultWords);               // [64]
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                 float d = 0.5f - acc[j][r];
                 if (base + r == med) d = 0.0f;
                 if (d > edge_hi) continue;   // beyond the last histogram edge (0.3 > radius): nothing to record
+                if (dbg & 1) continue;       // timing experiment: no accumulation at all
                 // rows inside the medoid radius are rare: accumulate straight into LDS (exact integers)
                 // and append the row to the medoid's candidate list (sample_medoid's `cluster`, cluster.py:621-626)
                 if (d <= radius) {
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                     const unsigned int lp = atomicAdd(&lcnt_s[j], 1u);
                     if (lp < (unsigned int)kLocalCap) llist_s[j * kLocalCap + lp] = (int32_t)(base + r);
                 }
+                if (dbg & 2) continue;       // timing experiment: no histogram
                 const int b = bin_of(d, edges_s);
                 if (b >= 0) {
                     const long long w = __double2ll_rn((double)len[r] * VH_HIST_SCALE);
@@ -506,6 +508,7 @@ struct vh_clu {
         return host_results + (size_t)kListRing * kMaxMedoids * 4 + (size_t)slot * kMaxMedoids * VH_NBINS;
     }
     unsigned long long* flag() { return host_results + (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS); }
+    int scan_dbg = 0;             // VAMBHIP_SCAN_DBG: timing experiments only (wrong results)
     bool small_rpt = true;        // VAMBHIP_SCAN_WIDE=1 disables the narrow variant (A/B measurements)
     uint64_t scan_seq = 0;        // number of scans issued; scan s wrote ring slot s % kListRing
     int last_k = 0;
@@ -556,7 +559,7 @@ void launch_scan_rpt(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     const int64_t blocks = ceil_div(h->ld, (int64_t)kBlock * RPT);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
     hipLaunchKernelGGL((clu_scan_kernel<KM, RPT>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
-                       h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_dev.p);
+                       h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_dev.p, h->scan_dbg);
 }
 
 // Rows per lane: 4 (few medoids) or 2 keep the loads wide for matrices that stream from HBM.  A matrix that
@@ -629,6 +632,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->kept.alloc((size_t)h->ld);
         h->q.alloc((size_t)kMaxMedoids * h->L4);
         h->small_rpt = getenv("VAMBHIP_SCAN_WIDE") == nullptr;
+        h->scan_dbg = getenv("VAMBHIP_SCAN_DBG") ? atoi(getenv("VAMBHIP_SCAN_DBG")) : 0;
         h->results.alloc((size_t)kMaxMedoids * kResultWords);
         h->lists_dev.alloc((size_t)kMaxMedoids * kListCap);
         VH_HIP(hipHostMalloc((void**)&h->lists, (size_t)kListRing * kMaxMedoids * kListCap * sizeof(int32_t),
