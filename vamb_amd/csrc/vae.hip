@@ -317,7 +317,11 @@ void init_parameters(vh_vae* h) {
 int dw_splits(int M, int N, int K, int tile) {
     const int bm = (tile == 0 || tile == 3) ? 64 : 128, bn = tile == 2 ? 32 : (tile == 3 ? 64 : 128);
     const int tiles = (int)(ceil_div(M, bm) * ceil_div(N, bn));
-    int want = (int)std::max<int64_t>(1, ceil_div(256, tiles));
+    static const int target = [] {
+        const char* e = getenv("VAMBHIP_DW_WGS");
+        return e ? atoi(e) : 256;
+    }();
+    int want = (int)std::max<int64_t>(1, ceil_div(target, tiles));
     want = std::min(want, K / 32);
     return std::max(1, want);
 }
