@@ -197,6 +197,10 @@ int vh_vae_forward(vh_vae* h, const float* depths, const float* tnf, const float
  * cleared (vambtools.py:324-330); latent is a host [n][nlatent] array. */
 int vh_vae_encode(vh_vae* h, float* latent);
 
+/* post-dropout activations dropout(leaky_relu(x W^T + b)) of hidden layer `layer` (encoder layers first) for the
+ * batch of the last training-mode forward: [batch][nhidden] (tests: dropout statistics) */
+int vh_vae_get_hidden(vh_vae* h, int layer, float* out, int64_t n);
+
 /* D-Adapt-Adam group state (d, numerator_weighted, k) */
 int vh_vae_opt_state(vh_vae* h, double* d, double* numerator_weighted, int64_t* k);
 

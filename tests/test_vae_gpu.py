@@ -277,6 +277,32 @@ def test_free_running_training_learns():
     assert np.isfinite(lat).all() and lat.std() > 1e-3
 
 
+def test_generated_dropout_statistics():
+    """The device-generated keep mask (two decisions per 32-bit hash): drop rate p within 4 sigma on every hidden
+    layer, decisions of vertically adjacent elements (which share a hash) and of horizontally adjacent ones
+    independent, and a different mask every step."""
+    n, S, B, p = 4096, 8, 2048, 0.2
+    ab, tnf, lens, _ = synth.features(n, S, seed=9)
+    dl = ve.make_dataloader(ab, tnf, lens, batchsize=B, destroy=True)
+    vae = ve.VAE(S, dropout=p, seed=7)
+    vae._ensure_dataset(dl)
+    rows = np.arange(B)
+    masks = []
+    for step in range(2):
+        vae.train_batch(rows)
+        for layer in range(4):
+            dropped = vae.hidden_activations(layer, B) == 0.0
+            m = dropped.size
+            assert abs(dropped.mean() - p) < 4 * np.sqrt(p * (1 - p) / m), (step, layer, dropped.mean())
+            both_v = (dropped[0::2] & dropped[1::2]).mean()          # rows 2r, 2r + 1 share one hash
+            both_h = (dropped[:, 0::2] & dropped[:, 1::2]).mean()
+            tol = 4 * np.sqrt(p * p * (1 - p * p) / (m / 2))
+            assert abs(both_v - p * p) < tol and abs(both_h - p * p) < tol, (step, layer, both_v, both_h)
+            if layer == 0:
+                masks.append(dropped)
+    assert 0.25 < (masks[0] != masks[1]).mean() < 0.40        # 2 p (1 - p) = 0.32 for independent steps
+
+
 def test_large_batch_properties():
     """BASELINE-sized batch (4096 x 154 features, 512-512-32): size-independent checks -- a step with
     dropout 0 and eps 0 on duplicated rows gives the same loss as on the unique rows (BatchNorm

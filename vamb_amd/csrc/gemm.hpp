@@ -98,6 +98,20 @@ __host__ __device__ __forceinline__ uint32_t hash32(uint64_t key, uint64_t idx) 
     return (uint32_t)(z >> 32);
 }
 
+// dropout keep bits: one 32-bit mix (3 integer multiplies instead of the 4 64-bit ones of hash32 + index)
+// yields two 16-bit uniforms, i.e. the decisions of two vertically adjacent elements.  The backward pass never
+// re-evaluates it (a dropped unit is stored as exactly 0), and parity tests inject their masks.
+__device__ __forceinline__ uint32_t hash_drop(uint64_t key, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u + (uint32_t)key;
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x ^= (uint32_t)(key >> 32);
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+
 __device__ __forceinline__ uint64_t step_key(uint64_t base, const unsigned long long* step_ptr) {
     return step_ptr ? (base ^ ((uint64_t)(*step_ptr) << 8)) : base;
 }
@@ -132,6 +146,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     constexpr int UA = (BF && !A_KC) ? 2 * ((4 * BM + NT - 1) / NT) : (BM * KQ + NT - 1) / NT;
     constexpr int UB = (BF && !B_KC) ? 2 * ((4 * BN + NT - 1) / NT) : (BN * KQ + NT - 1) / NT;
     static_assert(BK == 32, "the swizzled LDS image is 8 quads (32 floats) wide");
+    static_assert(NT % KQ == 0, "every unit of a thread shares its k-quad");
     static_assert(WM * WN == 4 || WM * WN == 1, "4 wavefronts per workgroup, or a single free-running one");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
 
@@ -387,13 +402,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
         if constexpr (BF) { sstore_bf16(buf, k0); return; }
         float* as = As + buf * TILE_A;
         float* bs = Bs + buf * TILE_B;
+        // every unit of a thread has the same k-quad (NT is a multiple of 8): one coefficient pair per K-tile
+        float4 sA = zero4, tA = zero4, sB = zero4, tB = zero4;
+        if constexpr (A_KC && XFA == XF_BN) {
+            sA = *reinterpret_cast<const float4*>(coefA + (k0 - kbeg) + 4 * (tid % KQ));
+            tA = *reinterpret_cast<const float4*>(coefA + ncolA + (k0 - kbeg) + 4 * (tid % KQ));
+        }
+        if constexpr (B_KC && XFB == XF_BN) {
+            sB = *reinterpret_cast<const float4*>(coefB + (k0 - kbeg) + 4 * (tid % KQ));
+            tB = *reinterpret_cast<const float4*>(coefB + ncolB + (k0 - kbeg) + 4 * (tid % KQ));
+        }
+        auto fma4 = [](float4 v, const float4& s4, const float4& t4) -> float4 {
+            v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w;
+            return v;
+        };
 #pragma unroll
         for (int r = 0; r < UA; ++r) {
             const int u = tid + NT * r;
             float4 v = ra[r];
             if constexpr (A_KC) {
                 const int row = u / KQ, kq = u % KQ;
-                if constexpr (XFA == XF_BN) v = bn4(v, coefA + (k0 - kbeg) + 4 * kq, coefA + ncolA + (k0 - kbeg) + 4 * kq);
+                if constexpr (XFA == XF_BN) v = fma4(v, sA, tA);
                 if (u < BM * KQ) *reinterpret_cast<float4*>(as + row * BK + 4 * (kq ^ swz(row))) = v;
             } else {
                 const int k = u / (BM / 4), mq = u % (BM / 4);
@@ -407,7 +436,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
             float4 v = rb[r];
             if constexpr (B_KC) {
                 const int row = u / KQ, kq = u % KQ;
-                if constexpr (XFB == XF_BN) v = bn4(v, coefB + (k0 - kbeg) + 4 * kq, coefB + ncolB + (k0 - kbeg) + 4 * kq);
+                if constexpr (XFB == XF_BN) v = fma4(v, sB, tB);
                 if (u < BN * KQ) *reinterpret_cast<float4*>(bs + row * BK + 4 * (kq ^ swz(row))) = v;
             } else {
                 const int k = u / (BN / 4), nq = u % (BN / 4);
@@ -546,6 +575,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            uint32_t pair_bits = 0;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * frag_h;
@@ -558,10 +588,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
                     v = v > 0.f ? v : kLeakySlopeF * v;
                     if (g.drop_scale != 1.0f || g.drop_mask) {
                         bool keep = row < g.m_real;
-                        if (keep)
-                            keep = g.drop_mask ? (g.drop_mask[(int64_t)row * g.ld_mask + col] != 0)
-                                               : (hash32(drop_key, (uint64_t)row * (uint64_t)g.N + (uint64_t)col) >=
-                                                  g.drop_thresh);
+                        if (keep) {
+                            if (g.drop_mask) {
+                                keep = g.drop_mask[(int64_t)row * g.ld_mask + col] != 0;
+                            } else {
+                                // rows 2p and 2p + 1 of a column share one hash (reg and reg ^ 1 of this lane)
+                                if ((reg & 1) == 0) pair_bits = hash_drop(drop_key, (uint32_t)(row >> 1) * (uint32_t)g.N + (uint32_t)col);
+                                const uint32_t u16 = (reg & 1) ? (pair_bits >> 16) : (pair_bits & 0xFFFFu);
+                                keep = u16 >= (g.drop_thresh >> 16);
+                            }
+                        }
                         v = keep ? v * g.drop_scale : 0.f;
                     }
                     if (row < g.m_real) { s1[j] += v; s2[j] += v * v; }

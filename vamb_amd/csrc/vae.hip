@@ -1111,6 +1111,22 @@ int vh_vae_get_grad(vh_vae* h, const char* name, float* data, int64_t n) {
     });
 }
 
+int vh_vae_get_hidden(vh_vae* h, int layer, float* out, int64_t n) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && out != nullptr, "NULL argument");
+        VH_REQUIRE(layer >= 0 && layer < 2 * h->nl, "layer %d out of range", layer);
+        const Hidden& hl = h->hidden[layer];
+        VH_REQUIRE(h->bs > 0 && hl.H.p != nullptr, "no training step has run yet");
+        VH_REQUIRE(n == (int64_t)h->bs * hl.nout, "layer %d holds %d x %d activations, got %lld", layer, h->bs, hl.nout,
+                   (long long)n);
+        std::vector<float> buf((size_t)h->bs * hl.nout_p);
+        VH_HIP(hipMemcpyAsync(buf.data(), hl.H.p, sizeof(float) * buf.size(), hipMemcpyDeviceToHost, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+        for (int r = 0; r < h->bs; ++r)
+            memcpy(out + (size_t)r * hl.nout, buf.data() + (size_t)r * hl.nout_p, sizeof(float) * hl.nout);
+    });
+}
+
 int vh_vae_set_dataset(vh_vae* h, const float* depths, const float* tnf, const float* abundance, const float* weights,
                        int64_t n) {
     return guarded([&] {

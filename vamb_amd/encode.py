@@ -302,6 +302,13 @@ class VAE:
         _lib.check(self._lib.vh_vae_get_grad(self._h, name.encode(), _lib.ptr(buf), n))
         return buf.reshape(shape)
 
+    def hidden_activations(self, layer: int, batch: int) -> _np.ndarray:
+        """Post-dropout activations of hidden layer ``layer`` (encoder layers first) for the last training batch."""
+        width = self.nhiddens[layer] if layer < len(self.nhiddens) else list(reversed(self.nhiddens))[layer - len(self.nhiddens)]
+        buf = _np.empty((batch, width), _np.float32)
+        _lib.check(self._lib.vh_vae_get_hidden(self._h, int(layer), _lib.ptr(buf), buf.size))
+        return buf
+
     def optimizer_state(self):
         d, nw, k = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         _lib.check(self._lib.vh_vae_opt_state(self._h, ctypes.byref(d), ctypes.byref(nw), ctypes.byref(k)))
