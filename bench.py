@@ -166,7 +166,25 @@ def cpu_baseline(args, latent, lens):
                 epoch_s=t_epoch, encode_s=t_enc, cluster_s=t_clu)
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  gloo and RCCL print banners there, RCCL through C stdio that is
+    only flushed at exit (i.e. AFTER the result line).  So file descriptor 1 is pointed at stderr for the whole
+    run and the result line is written to a private duplicate of the original stdout."""
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit_result(line: dict):
+    os.write(_RESULT_FD, (json.dumps(line) + "\n").encode())
+
+
 def main():
+    claim_stdout()
     args = parse()
     rank, local, world = dist_env()
     if world != args.gpus:
@@ -191,19 +209,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        # gloo / RCCL print banners on stdout; the contract is ONE JSON line there -> send them to stderr
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group(backend="gloo")
-            from vamb_amd import parallel
+        dist.init_process_group(backend="gloo")
+        from vamb_amd import parallel
 
-            comm = parallel.Communicator.from_torch_distributed(dist)
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        comm = parallel.Communicator.from_torch_distributed(dist)
 
     # synthetic inputs of the named shape (per-rank shard under weak scaling), normalised on the host
     # exactly as `vamb bin default` does, then uploaded once: resident in HBM before the clock starts
@@ -294,7 +303,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args, results[-1]["latent"], lens)
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        emit_result(line)
     if comm is not None:
         comm.close()
     if dist is not None:

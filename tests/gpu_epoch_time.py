@@ -8,7 +8,7 @@ os.environ["VAMBHIP_PRECISION"] = sys.argv[5] if len(sys.argv) > 5 else "fp32"
 from vamb_amd import encode as ve, synth
 ab, tnf, lens, _ = synth.features(n, S, seed=1)
 dl = ve.make_dataloader(ab, tnf, lens, batchsize=bs, destroy=True)
-vae = ve.VAE(S, seed=1)
+vae = ve.VAE(S, seed=int(os.environ.get("VAE_SEED", "1")))
 vae.trainmodel(dl, nepochs=2, batchsteps=None)
 t0 = time.perf_counter()
 vae.trainmodel(dl, nepochs=E, batchsteps=None)
