@@ -204,6 +204,12 @@ int vh_vae_get_hidden(vh_vae* h, int layer, float* out, int64_t n);
 /* D-Adapt-Adam group state (d, numerator_weighted, k) */
 int vh_vae_opt_state(vh_vae* h, double* d, double* numerator_weighted, int64_t* k);
 
+/* n_epochs consecutive epochs of the same shape with the device-side shuffle and a single host synchronisation
+ * at the end (the loop of trainmodel, encode.py:598-601, between two batch-size changes).  global_batch = 0
+ * without a communicator.  loss_means: [n_epochs][5] = the five means trainepoch logs per epoch. */
+int vh_vae_train_epochs(vh_vae* h, int64_t n_epochs, int64_t n_batches, int64_t batch, int64_t global_batch,
+                        double* loss_means);
+
 /* Arithmetic of the dense contractions: 0 (default) = fp32 operands on the fp32 MFMA (BASELINE config C1);
  * 1 = operands rounded to bf16 while they are staged, bf16 MFMA with fp32 accumulation (configs C2-C4).
  * Tensors in memory, BatchNorm, loss and optimiser stay fp32 either way.  May be changed between calls. */

@@ -222,7 +222,8 @@ struct vh_vae {
     bool probe_on = false;
     int probe_layer = 0;
     std::vector<hipEvent_t> ev_a, ev_b;
-    int probe_used = 0;
+    int probe_used = 0, probe_head = 0;   // armed pairs form the circular range [head, head + used)
+    PinnedBuf<double> h_epoch_loss;        // per-epoch loss sums of vh_vae_train_epochs
     double probe_ms = 0.0;
     int64_t probe_launches = 0;
     double probe_flops = 0.0;
@@ -467,29 +468,41 @@ void upload_masks(vh_vae* h, const uint8_t* masks, int bs) {
     }
 }
 
-// arm the exact-timestamp event pair for the next GEMM launch
+// arm the exact-timestamp event pair for the next GEMM launch (circular ring of kProbeRing pairs; a launch is
+// simply not sampled while the ring is full)
 void probe_arm(vh_vae* h) {
     if (!h->probe_on || h->probe_used >= kProbeRing) return;
-    if ((int)h->ev_a.size() <= h->probe_used) {
+    if ((int)h->ev_a.size() < kProbeRing) {
         hipEvent_t a, b;
         VH_HIP(hipEventCreate(&a));
         VH_HIP(hipEventCreate(&b));
         h->ev_a.push_back(a);
         h->ev_b.push_back(b);
     }
-    t_probe_start = h->ev_a[h->probe_used];
-    t_probe_stop = h->ev_b[h->probe_used];
+    const int slot = (h->probe_head + h->probe_used) % kProbeRing;
+    if (slot >= (int)h->ev_a.size()) return;   // ring still growing and wrapped: skip this sample
+    t_probe_start = h->ev_a[slot];
+    t_probe_stop = h->ev_b[slot];
     h->probe_used++;
 }
 
+void probe_pop(vh_vae* h) {
+    float ms = 0.f;
+    VH_HIP(hipEventElapsedTime(&ms, h->ev_a[h->probe_head], h->ev_b[h->probe_head]));
+    h->probe_ms += ms;
+    h->probe_launches++;
+    h->probe_head = (h->probe_head + 1) % kProbeRing;
+    h->probe_used--;
+}
+
+// after a stream synchronisation: every armed pair is complete
 void probe_collect(vh_vae* h) {
-    for (int i = 0; i < h->probe_used; ++i) {
-        float ms = 0.f;
-        VH_HIP(hipEventElapsedTime(&ms, h->ev_a[i], h->ev_b[i]));
-        h->probe_ms += ms;
-        h->probe_launches++;
-    }
-    h->probe_used = 0;
+    while (h->probe_used > 0) probe_pop(h);
+}
+
+// without waiting: pop the pairs whose kernels have already retired (oldest first)
+void probe_collect_ready(vh_vae* h) {
+    while (h->probe_used > 0 && hipEventQuery(h->ev_b[h->probe_head]) == hipSuccess) probe_pop(h);
 }
 
 // The side stream carries everything that is off the critical path of a step (weight-gradient GEMMs,
@@ -1192,9 +1205,15 @@ int vh_vae_train_step(vh_vae* h, const int64_t* rows, int64_t batch, const float
     });
 }
 
-int vh_vae_train_epoch_dp(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, int64_t global_batch,
-                          const float* global_wsum, double loss_means[5]) {
-    return guarded([&] {
+}  // extern "C"
+
+namespace {
+
+// Enqueue one epoch (validation, shuffle key, per-batch weight sums, every step, the per-epoch collectives of the
+// data-parallel path).  Nothing here waits for the GPU.
+void enqueue_epoch(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, int64_t global_batch,
+                   const float* global_wsum) {
+    {
         VH_REQUIRE(h != nullptr, "NULL argument");
         VH_REQUIRE(h->n > 0, "no dataset: call vh_vae_set_dataset first");
         VH_REQUIRE(n_batches >= 1, "no batches");
@@ -1284,12 +1303,43 @@ int vh_vae_train_epoch_dp(vh_vae* h, const int64_t* perm, int64_t n_batches, int
                                1.0f / (float)h->comm->world);
             VH_HIP(hipGetLastError());
         }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vh_vae_train_epoch_dp(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, int64_t global_batch,
+                          const float* global_wsum, double loss_means[5]) {
+    return guarded([&] {
+        enqueue_epoch(h, perm, n_batches, batch, global_batch, global_wsum);
         StepState st;
         read_state(h, &st);
-        lap("state read");
         probe_collect(h);
         if (loss_means)
             for (int i = 0; i < 5; ++i) loss_means[i] = st.epoch_loss[i] / (double)n_batches;
+    });
+}
+
+// Several epochs of the same shape (device-side shuffle) with ONE host synchronisation at the end: each epoch's
+// loss sums are copied into pinned memory in stream order, so the GPU never idles at an epoch boundary
+// (the per-epoch read-back cost ~0.4 ms of 17.4 at C1).
+int vh_vae_train_epochs(vh_vae* h, int64_t n_epochs, int64_t n_batches, int64_t batch, int64_t global_batch,
+                        double* loss_means /* [n_epochs][5] */) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && loss_means != nullptr, "NULL argument");
+        VH_REQUIRE(n_epochs >= 1, "no epochs");
+        h->h_epoch_loss.ensure((size_t)n_epochs * 5);
+        for (int64_t e = 0; e < n_epochs; ++e) {
+            enqueue_epoch(h, nullptr, n_batches, batch, global_batch, nullptr);
+            VH_HIP(hipMemcpyAsync(h->h_epoch_loss.p + 5 * e, h->state.p->epoch_loss, 5 * sizeof(double),
+                                  hipMemcpyDeviceToHost, h->stream));
+            probe_collect_ready(h);
+        }
+        VH_HIP(hipStreamSynchronize(h->stream));
+        probe_collect(h);
+        for (int64_t i = 0; i < n_epochs * 5; ++i) loss_means[i] = h->h_epoch_loss.p[i] / (double)n_batches;
     });
 }
 
@@ -1434,6 +1484,7 @@ int vh_vae_set_probe(vh_vae* h, int enable, int layer) {
         h->probe_ms = 0.0;
         h->probe_launches = 0;
         h->probe_used = 0;
+        h->probe_head = 0;
     });
 }
 

@@ -430,6 +430,47 @@ class VAE:
         self.eval()
         return data_loader
 
+    def _train_segment(self, data_loader, first_epoch: int, count: int, batchsteps) -> "_DataLoader":
+        """`count` epochs starting at `first_epoch`, none of which except the first changes the batch size."""
+        n_seq = self._ensure_dataset(data_loader)
+        if n_seq < 2:
+            raise ValueError(
+                f"Cannot train on a dataset with fewer than 2 sequences, but got {n_seq} sequences. "
+                "If you are trying to fit a DL model to this few sequences, "
+                "something probably went wrong in your pipeline.")
+        self.train()
+        if first_epoch in batchsteps:
+            data_loader = set_batchsize(data_loader, data_loader.batch_size * 2, n_seq)
+        bs = data_loader.batch_size
+        means = (ctypes.c_double * (5 * count))()
+        if self._comm is not None:
+            world = self._comm.world
+            if bs % world != 0:
+                raise ValueError(f"global batch {bs} is not divisible by the number of GPUs {world}")
+            batch = bs // world
+            if n_seq < batch:
+                raise ValueError(f"shard of {n_seq} rows is smaller than the per-GPU batch {batch}")
+            key = (n_seq, batch)
+            if getattr(self, "_dp_plan_key", None) != key:
+                nb = self._comm.all_reduce_min(_np.array([n_seq // batch], dtype=_np.int64))
+                self._dp_plan_key, self._dp_batches = key, int(nb[0])
+            n_batches, global_batch = self._dp_batches, bs
+        else:
+            if n_seq > bs:
+                n_batches, batch = n_seq // bs, bs
+            else:
+                n_batches, batch = 1, n_seq
+            global_batch = 0
+        _lib.check(self._lib.vh_vae_train_epochs(self._h, count, n_batches, batch, global_batch, means))
+        for e in range(count):
+            loss, ab, ce, sse, kld = tuple(means[5 * e: 5 * e + 5])
+            logger.info(
+                "\t\tEpoch: {:>3}  Loss: {:.5e}  CE: {:.5e}  AB: {:.5e}  SSE: {:.5e}  KLD: {:.5e}  Batchsize: {:>4}".format(
+                    first_epoch + e + 1, loss, ce, ab, sse, kld, bs))
+        self.last_epoch_losses = dict(loss=loss, ce=ce, ab=ab, sse=sse, kld=kld, batchsize=bs)
+        self.eval()
+        return data_loader
+
     def trainmodel(self, dataloader, nepochs: int = 500, batchsteps: Optional[list[int]] = [25, 75, 150, 300],
                    modelfile: Union[None, str, Path, IO[bytes]] = None):
         """Train the autoencoder (encode.py:543-610).  Output: None"""
@@ -459,8 +500,13 @@ class VAE:
         logger.info(f"\t    Batchsteps: {steps}")
         logger.info(f"\t    N sequences: {ncontigs}")
         logger.info(f"\t    N samples: {nsamples}")
-        for epoch in range(nepochs):
-            dataloader = self.trainepoch(dataloader, epoch, None, sorted(batchsteps_set))
+        # the epochs between two batch-size changes are enqueued by ONE library call (a single host
+        # synchronisation per segment instead of one per epoch); the log lines are those of trainepoch
+        epoch = 0
+        while epoch < nepochs:
+            nxt = min([b for b in batchsteps_set if b > epoch] + [nepochs])
+            dataloader = self._train_segment(dataloader, epoch, nxt - epoch, batchsteps_set)
+            epoch = nxt
         if modelfile is not None:
             try:
                 self.save(modelfile)
