@@ -190,6 +190,11 @@ struct vh_vae {
     int bs = 0, bs_p = 0;
     DevBuf<float> Xb, Wb, MU, Z, EPS, R, dR, dMUk, DA, dMU, loss_part, slabs, out_sm, skinny;
     DevBuf<double> statbuf;          // every hidden layer's fstat | bstat | dbias, zeroed once per step
+    int opt_dec_blk0 = 0;            // first optimiser workgroup of the decoder-side tensors
+    bool early_dec = false;          // this step's decoder-side update was already enqueued on the side stream
+    bool split_opt = false;          // VAMBHIP_OPT_SPLIT=1: decoder half of the optimiser early on the side stream
+                                     // (measured SLOWER: 364 vs 353 us/step -- it competes with the GEMMs)
+    hipEvent_t ev_fork2 = nullptr;
     OptTable opt_tab, opt_tab_flat;  // parameter tensors -> gradient sources (slabs / fp64 accumulators / flat G)
     bool stat_clean = false;         // statbuf is all zero (left so by the optimiser's finalize kernel)
     bool keep_grads = false;         // single-step API: leave the accumulators for vh_vae_get_grad
@@ -420,6 +425,17 @@ void prepare_batch(vh_vae* h, int bs) {
         tab.n++;
     }
     tab.blk_start[tab.n] = nblk;
+    // decoder-side tensors (decoder hidden layers + output layer) are the tail of the table (creation order:
+    // encoder, mu, decoder, output): their optimiser update can run as soon as their gradients are complete
+    h->opt_dec_blk0 = nblk;
+    {
+        int ti = 0;
+        for (size_t k = 0; k < h->tensors.size(); ++k) {
+            if (!h->tensors[k].optimised) continue;
+            if ((int)k == h->hidden[h->nl].tW) h->opt_dec_blk0 = tab.blk_start[ti];
+            ++ti;
+        }
+    }
     h->opt_tab = tab;
     h->G.ensure(h->flat_elems);
     h->opt_tab_flat = tab;
@@ -796,8 +812,24 @@ void backward(vh_vae* h, bool masks_injected) {
         } else {
             grad_weight(h, hl.tW, hl.DZ.p, hl.nout_p, In, in_p, nullptr, tail ? h->stream : nullptr);
         }
-        if (li == nl) latent_slabs = grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, h->DA.p, nullptr, true);
-        else if (li > 0) grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, below->DA.p, below, false);
+        if (li == nl) {
+            // Last reader of a decoder-side parameter on the main stream: the GEMM below (W of this layer).  Once
+            // it has retired and this layer's dW is in (side stream order), the decoder half of the optimiser
+            // step can run on the side stream while the encoder's backward continues here.  Single-GPU only:
+            // the data-parallel path all-reduces the whole gradient first.
+            const bool early = h->split_opt && fork_from_kernel(h) && h->comm == nullptr && !h->keep_grads &&
+                               h->opt_dec_blk0 > 0 && h->opt_dec_blk0 < h->opt_blocks;
+            if (early) t_fork_stop = h->ev_fork2;
+            latent_slabs = grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, h->DA.p, nullptr, true);
+            if (early) {
+                VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork2, 0));
+                hipLaunchKernelGGL(vae_dadapt_kernel, dim3(h->opt_blocks - h->opt_dec_blk0), dim3(256), 0, h->side,
+                                   h->opt_tab, h->P.p, h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p,
+                                   h->opt_dec_blk0);
+                VH_HIP(hipGetLastError());
+                h->early_dec = true;
+            }
+        } else if (li > 0) grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, below->DA.p, below, false);
         // li == 0: the input gradient is never needed
     };
     for (int li = 2 * nl - 1; li >= nl; --li) hidden_bwd(li);
@@ -826,9 +858,14 @@ void optimizer_step(vh_vae* h) {
         rccl_allreduce_sum_f32(h->comm, h->G.p, h->flat_elems, h->stream);
         tab = &h->opt_tab_flat;
     }
-    hipLaunchKernelGGL(vae_dadapt_kernel, dim3(h->opt_blocks), dim3(256), 0, h->stream, *tab, h->P.p, h->M1.p,
-                       h->M2.p, h->Sv.p, h->state.p, h->opt_part.p);
-    VH_HIP(hipGetLastError());
+    // the decoder-side tensors were updated on the side stream during the encoder's backward (backward())
+    const int nblk = h->early_dec ? h->opt_dec_blk0 : h->opt_blocks;
+    h->early_dec = false;
+    if (nblk > 0) {
+        hipLaunchKernelGGL(vae_dadapt_kernel, dim3(nblk), dim3(256), 0, h->stream, *tab, h->P.p, h->M1.p, h->M2.p,
+                           h->Sv.p, h->state.p, h->opt_part.p, 0);
+        VH_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(vae_dadapt_finalize_kernel, dim3(1), dim3(256), 0, h->stream, h->opt_part.p, h->opt_blocks,
                        h->state.p, h->statbuf.p, h->keep_grads ? 0 : (int)h->statbuf.n);
     VH_HIP(hipGetLastError());
@@ -987,6 +1024,8 @@ int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
                                                                  : (hipEventDisableTiming | hipEventReleaseToDevice);
         VH_HIP(hipEventCreateWithFlags(&h->ev_fork, ev_flags));
         VH_HIP(hipEventCreateWithFlags(&h->ev_join, ev_flags));
+        VH_HIP(hipEventCreateWithFlags(&h->ev_fork2, ev_flags));
+        { const char* e = getenv("VAMBHIP_OPT_SPLIT"); h->split_opt = e && e[0] == '1'; }
 
         h->hidden.resize(2 * h->nl);
         auto make_hidden = [&](int li, const std::string& lin, const std::string& norm, int nin, int nout) {

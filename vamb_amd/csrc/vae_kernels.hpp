@@ -597,11 +597,12 @@ __global__ void vae_scale_kernel(float* __restrict__ v, int64_t n, float f) {
 __global__ __launch_bounds__(256) void vae_dadapt_kernel(const OptTable tab, float* __restrict__ P,
                                                          float* __restrict__ M1, float* __restrict__ M2,
                                                          float* __restrict__ Sv, const StepState* __restrict__ st,
-                                                         double* __restrict__ partials /*[gridDim.x][2]*/) {
+                                                         double* __restrict__ partials /*[all blocks][2]*/, int blk0) {
     __shared__ double red[2][4];
-    const int t = opt_find_tensor(tab, blockIdx.x);
+    const int blk = blockIdx.x + blk0;   // the launch covers the table's workgroups [blk0, blk0 + gridDim.x)
+    const int t = opt_find_tensor(tab, blk);
     const TensorDesc& td = tab.d[t];
-    const int64_t local = (int64_t)(blockIdx.x - tab.blk_start[t]) * 1024 + threadIdx.x * 4;
+    const int64_t local = (int64_t)(blk - tab.blk_start[t]) * 1024 + threadIdx.x * 4;
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     const double sqrt_b2d = sqrt(0.999);
     const double dlr = st->d;  // lr == 1
@@ -638,8 +639,8 @@ __global__ __launch_bounds__(256) void vae_dadapt_kernel(const OptTable tab, flo
     if ((threadIdx.x & 63) == 0) { red[0][wave] = wn; red[1][wave] = ws; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        partials[(int64_t)blockIdx.x * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        partials[(int64_t)blockIdx.x * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        partials[(int64_t)blk * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partials[(int64_t)blk * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
 }
 
