@@ -204,6 +204,14 @@ int vh_vae_get_hidden(vh_vae* h, int layer, float* out, int64_t n);
 /* D-Adapt-Adam group state (d, numerator_weighted, k) */
 int vh_vae_opt_state(vh_vae* h, double* d, double* numerator_weighted, int64_t* k);
 
+/* A dataset that outlives / is shared between VAE handles (one upload per `vamb bin default` run, however many
+ * models are trained on it).  The handle must stay alive while a VAE uses it. */
+typedef struct vh_dataset vh_dataset;
+int vh_dataset_create(const float* depths, const float* tnf, const float* abundance, const float* weights, int64_t n,
+                      int nsamples, vh_dataset** out);
+int vh_dataset_destroy(vh_dataset* d);
+int vh_vae_use_dataset(vh_vae* h, vh_dataset* d);
+
 /* n_epochs consecutive epochs of the same shape with the device-side shuffle and a single host synchronisation
  * at the end (the loop of trainmodel, encode.py:598-601, between two batch-size changes).  global_batch = 0
  * without a communicator.  loss_means: [n_epochs][5] = the five means trainepoch logs per epoch. */

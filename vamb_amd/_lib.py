@@ -83,6 +83,9 @@ SIGNATURES = {
     "vh_vae_encode": (_int, [_vp, _vp]),
     "vh_vae_opt_state": (_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                 ctypes.POINTER(_i64)]),
+    "vh_dataset_create": (_int, [_vp, _vp, _vp, _vp, _i64, _int, ctypes.POINTER(_vp)]),
+    "vh_dataset_destroy": (_int, [_vp]),
+    "vh_vae_use_dataset": (_int, [_vp, _vp]),
     "vh_vae_train_epochs": (_int, [_vp, _i64, _i64, _i64, _i64, _vp]),
     "vh_vae_get_hidden": (_int, [_vp, _int, _vp, _i64]),
     "vh_vae_set_precision": (_int, [_vp, _int]),

@@ -156,6 +156,15 @@ GemmArgs base_args(bool bf16 = false) {
 
 }  // namespace
 
+// The feature matrix [n][D_p] (zero padded) + weights [n], resident in HBM.  Owned by a VAE handle
+// (vh_vae_set_dataset) or shared between handles (vh_dataset_create + vh_vae_use_dataset): the dataset of one
+// `vamb bin default` run is uploaded once however many models are trained on it.
+struct vh_dataset {
+    DevBuf<float> X, w;
+    int64_t n = 0;
+    int S = 0, D_p = 0;
+};
+
 struct vh_vae {
     vh_vae_config cfg;
     bool tail_on_main = true;   // VAMBHIP_TAIL_SIDE=1: keep the last weight-gradient GEMM on the side stream
@@ -179,7 +188,8 @@ struct vh_vae {
 
     // dataset
     int64_t n = 0;
-    DevBuf<float> X, w;
+    vh_dataset own;                   // storage of vh_vae_set_dataset
+    struct { float* p = nullptr; } X, w;   // the dataset in use (own or shared)
     DevBuf<int64_t> perm;
     // pinned staging: hipMemcpyAsync from pageable memory costs milliseconds (page pinning) per call
     PinnedBuf<int64_t> h_perm;
@@ -1179,30 +1189,78 @@ int vh_vae_get_hidden(vh_vae* h, int layer, float* out, int64_t n) {
     });
 }
 
+}  // extern "C"
+
+namespace {
+
+void upload_dataset(vh_dataset* d, int S, int D_p, const float* depths, const float* tnf, const float* abundance,
+                    const float* weights, int64_t n) {
+    VH_REQUIRE(depths && tnf && abundance && weights, "NULL argument");
+    VH_REQUIRE(n >= 1, "empty dataset");
+    d->n = n;
+    d->S = S;
+    d->D_p = D_p;
+    d->X.alloc((size_t)n * D_p);
+    d->w.alloc((size_t)n);
+    // assemble padded rows on the host in chunks (one H2D per chunk)
+    const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / (D_p * 4));
+    std::vector<float> buf((size_t)std::min(chunk, n) * D_p);
+    for (int64_t lo = 0; lo < n; lo += chunk) {
+        const int64_t hi = std::min(n, lo + chunk);
+        std::fill(buf.begin(), buf.end(), 0.0f);
+        for (int64_t r = lo; r < hi; ++r) {
+            float* dst = buf.data() + (size_t)(r - lo) * D_p;
+            memcpy(dst, depths + (size_t)r * S, sizeof(float) * S);
+            memcpy(dst + S, tnf + (size_t)r * VH_NTNF, sizeof(float) * VH_NTNF);
+            dst[S + VH_NTNF] = abundance[r];
+        }
+        VH_HIP(hipMemcpy(d->X.p + (size_t)lo * D_p, buf.data(), sizeof(float) * (size_t)(hi - lo) * D_p,
+                         hipMemcpyHostToDevice));
+    }
+    VH_HIP(hipMemcpy(d->w.p, weights, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+}
+
+}  // namespace
+
+extern "C" {
+
 int vh_vae_set_dataset(vh_vae* h, const float* depths, const float* tnf, const float* abundance, const float* weights,
                        int64_t n) {
     return guarded([&] {
-        VH_REQUIRE(h != nullptr && depths && tnf && abundance && weights, "NULL argument");
-        VH_REQUIRE(n >= 1, "empty dataset");
+        VH_REQUIRE(h != nullptr, "NULL argument");
+        upload_dataset(&h->own, h->S, h->D_p, depths, tnf, abundance, weights, n);
         h->n = n;
-        h->X.alloc((size_t)n * h->D_p);
-        h->w.alloc((size_t)n);
-        // assemble padded rows on the host in chunks (one H2D per chunk)
-        const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / (h->D_p * 4));
-        std::vector<float> buf((size_t)std::min(chunk, n) * h->D_p);
-        for (int64_t lo = 0; lo < n; lo += chunk) {
-            const int64_t hi = std::min(n, lo + chunk);
-            std::fill(buf.begin(), buf.end(), 0.0f);
-            for (int64_t r = lo; r < hi; ++r) {
-                float* dst = buf.data() + (size_t)(r - lo) * h->D_p;
-                memcpy(dst, depths + (size_t)r * h->S, sizeof(float) * h->S);
-                memcpy(dst + h->S, tnf + (size_t)r * VH_NTNF, sizeof(float) * VH_NTNF);
-                dst[h->S + VH_NTNF] = abundance[r];
-            }
-            VH_HIP(hipMemcpy(h->X.p + (size_t)lo * h->D_p, buf.data(), sizeof(float) * (size_t)(hi - lo) * h->D_p,
-                             hipMemcpyHostToDevice));
-        }
-        VH_HIP(hipMemcpy(h->w.p, weights, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+        h->X.p = h->own.X.p;
+        h->w.p = h->own.w.p;
+    });
+}
+
+int vh_dataset_create(const float* depths, const float* tnf, const float* abundance, const float* weights, int64_t n,
+                      int nsamples, vh_dataset** out) {
+    return guarded([&] {
+        VH_REQUIRE(out != nullptr, "NULL argument");
+        VH_REQUIRE(nsamples >= 1, "nsamples must be positive");
+        std::unique_ptr<vh_dataset> d(new vh_dataset());
+        upload_dataset(d.get(), nsamples, (int)round_up(nsamples + VH_NTNF + 1, kColPad), depths, tnf, abundance, weights, n);
+        *out = d.release();
+    });
+}
+
+int vh_dataset_destroy(vh_dataset* d) {
+    delete d;
+    return VH_OK;
+}
+
+int vh_vae_use_dataset(vh_vae* h, vh_dataset* d) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && d != nullptr, "NULL argument");
+        VH_REQUIRE(d->S == h->S && d->D_p == h->D_p, "dataset has %d samples, the model %d", d->S, h->S);
+        VH_HIP(hipStreamSynchronize(h->stream));
+        h->own.X.release();
+        h->own.w.release();
+        h->n = d->n;
+        h->X.p = d->X.p;
+        h->w.p = d->w.p;
     });
 }
 

@@ -142,6 +142,25 @@ def _as_f32(x) -> _np.ndarray:
     return _np.ascontiguousarray(x, dtype=_np.float32)
 
 
+class _DeviceDataset:
+    """Feature matrix + weights resident in HBM (vh_dataset), keyed by the host tensors it was made from."""
+
+    def __init__(self, lib, key, d, t, a, w, n, nsamples):
+        self._lib = lib
+        self.key = key
+        h = ctypes.c_void_p()
+        _lib.check(lib.vh_dataset_create(_lib.ptr(d), _lib.ptr(t), _lib.ptr(a), _lib.ptr(w), n, nsamples, ctypes.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                self._lib.vh_dataset_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class VAE:
     """Variational autoencoder with the reference's interface (encode.py:149-257); the network lives
     on the GPU behind ``libvambhip``.
@@ -360,6 +379,8 @@ class VAE:
 
     # ---- dataset residency --------------------------------------------------------------------------
     def _ensure_dataset(self, data_loader) -> int:
+        """Make the loader's four tensors resident in HBM (once per loader: the device copy is cached on the
+        dataset object and shared by every VAE trained / encoded on it)."""
         tensors = data_loader.dataset.tensors
         if len(tensors) != 4:
             raise ValueError("expected a DataLoader made by make_dataloader (4 tensors)")
@@ -369,7 +390,16 @@ class VAE:
             d, t, a, w = (_as_f32(x) for x in tensors)
             if d.shape != (n, self.nsamples) or t.shape != (n, NTNF) or a.shape != (n, 1) or w.shape != (n, 1):
                 raise ValueError("dataset tensors do not match this VAE (nsamples / 103 TNF / 1 / 1 columns)")
-            _lib.check(self._lib.vh_vae_set_dataset(self._h, _lib.ptr(d), _lib.ptr(t), _lib.ptr(a), _lib.ptr(w), n))
+            holder = data_loader.dataset
+            cached = getattr(holder, "_vambhip_device", None)
+            if cached is None or cached.key != key:
+                cached = _DeviceDataset(self._lib, key, d, t, a, w, n, self.nsamples)
+                try:
+                    holder._vambhip_device = cached
+                except AttributeError:
+                    pass
+            _lib.check(self._lib.vh_vae_use_dataset(self._h, cached.handle))
+            self._device_dataset = cached      # keeps the shared device copy alive while this VAE uses it
             self._dataset_key = key
             self._n_rows = n
         return n
