@@ -118,6 +118,23 @@ __device__ __forceinline__ int bin_of(float d, const float* edges) {
     return b;
 }
 
+// the same rule without loops: the estimate (int)(d * 200) is off by at most one bin (edges are linspace(0, 0.3, 61)
+// in float32), so one downward or one upward correction is exact; callers guarantee edges[0] <= d <= edges[60]
+__device__ __forceinline__ int bin_of_in_range(float d, const float* edges) {
+    int b = (int)(d * 200.0f);
+    b = b > VH_NBINS - 1 ? VH_NBINS - 1 : b;
+    if (b > 0 && d < edges[b]) --b;
+    else if (b < VH_NBINS - 1 && d >= edges[b + 1]) ++b;
+    return b;
+}
+
+// round-to-nearest-even of a non-negative float product to an unsigned 64-bit integer; the float path is exact
+// for x < 2^32 (rintf of an exactly representable product), larger values take the double path
+__device__ __forceinline__ unsigned long long rn_u64(float x) {
+    return x < 4.0e9f ? (unsigned long long)(unsigned int)__builtin_rintf(x)
+                      : (unsigned long long)__double2ll_rn((double)x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K6: multi-medoid scan.  Each thread owns RPT consecutive rows (4 for few medoids: 1 KiB coalesced
 // loads per wave-instruction; 2 when KM >= 12 so that KM*RPT accumulators stay within ~128 VGPRs).
@@ -211,6 +228,10 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
 
         float len[RPT];
         load_rows<RPT>(lengths + base, len);
+        // fixed-point histogram weight of every row, once (not per medoid): len * 2^8 is exact in float32
+        unsigned long long wfx[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) wfx[r] = rn_u64(len[r] * (float)VH_HIST_SCALE);
 #pragma unroll
         for (int j = 0; j < KM; ++j) {
             const long long med = medoid.row[j];
@@ -224,9 +245,9 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                 // rows inside the medoid radius are rare: accumulate straight into LDS (exact integers)
                 // and append the row to the medoid's candidate list (sample_medoid's `cluster`, cluster.py:621-626)
                 if (d <= radius) {
+                    // len * (radius - d) in float32 as the reference computes it, then * 2^16 (exact) and RNE
                     const float p = len[r] * (radius - d);
-                    const long long pf = __double2ll_rn((double)p * VH_DENSITY_SCALE);
-                    atomicAdd(&acc_s[j * kResultWords + 0], (unsigned long long)pf);
+                    atomicAdd(&acc_s[j * kResultWords + 0], rn_u64(p * (float)VH_DENSITY_SCALE));
                     atomicAdd(&acc_s[j * kResultWords + 1 + VH_NBINS], 1ull);
                     if (d < radius) atomicAdd(&acc_s[j * kResultWords + 2 + VH_NBINS], 1ull);
                     // candidate list (sample_medoid's `cluster`): appended block-locally in LDS, flushed once
@@ -235,11 +256,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                     if (lp < (unsigned int)kLocalCap) llist_s[j * kLocalCap + lp] = (int32_t)(base + r);
                 }
                 if (dbg & 2) continue;       // timing experiment: no histogram
-                const int b = bin_of(d, edges_s);
-                if (b >= 0) {
-                    const long long w = __double2ll_rn((double)len[r] * VH_HIST_SCALE);
-                    atomicAdd(&acc_s[j * kResultWords + 1 + b], (unsigned long long)w);
-                }
+                if (d >= edges_s[0]) atomicAdd(&acc_s[j * kResultWords + 1 + bin_of_in_range(d, edges_s)], wfx[r]);
             }
         }
     }
