@@ -67,6 +67,25 @@ def test_gemm_instantiations(tile, layout, shape):
         assert rel(C, want + bias) < 2e-6 * np.sqrt(K)
 
 
+@pytest.mark.parametrize("layout", [(1, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("shape", [(128, 128, 64, 1), (260, 36, 192, 1), (512, 512, 512, 4), (512, 160, 4096, 8)])
+def test_gemm_wide_k_tile(layout, shape):
+    """Tile 4 = the 64x64 workgroup tile with 64-wide K-tiles (16-quad swizzle)."""
+    M, N, K, splits = shape
+    a_kc, b_kc = layout
+    rng = np.random.RandomState(M + N + K + 7)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = (rng.standard_normal((N, K)) + 0.25 * np.arange(N)[:, None] / N).astype(np.float32)
+    want = A.astype(np.float64) @ B.astype(np.float64).T
+    Ad = np.ascontiguousarray(A if a_kc else A.T)
+    Bd = np.ascontiguousarray(B if b_kc else B.T)
+    C = np.zeros((M, N), np.float32)
+    ms = ctypes.c_float()
+    _lib.check(_lib.load().vh_debug_gemm(4, a_kc, b_kc, _lib.ptr(Ad), _lib.ptr(Bd), None, _lib.ptr(C), M, N, K, splits,
+                                         ctypes.byref(ms)))
+    assert rel(C, want) < 2e-6 * np.sqrt(K)
+
+
 def bf16_round(x):
     """float32 -> bf16 (round to nearest even) -> float32, as the staging path of the bf16 GEMMs does."""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)

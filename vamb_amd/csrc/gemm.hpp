@@ -84,6 +84,7 @@ struct GemmArgs {
     const float* Hbelow;  // activations of the layer below (same shape / ld as C)
     BnSrc bnC;            // its forward statistics
     double* bstat_out;    // [2][N]
+    int wide_k;           // 1: 64-wide K-tiles (host-side dispatch only; forward GEMMs, which run alone on the GPU)
     int bf16;             // 1: launch the bf16-operand instantiation (host-side dispatch only)
     int xcd_remap;        // 1: give every XCD a contiguous chunk of the tile grid (L2 reuse of operand panels)
 };
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     // float4 registers per thread per K-tile (bf16, row-contiguous operand: pairs of K rows)
     constexpr int UA = (BF && !A_KC) ? 2 * ((4 * BM + NT - 1) / NT) : (BM * KQ + NT - 1) / NT;
     constexpr int UB = (BF && !B_KC) ? 2 * ((4 * BN + NT - 1) / NT) : (BN * KQ + NT - 1) / NT;
-    static_assert(BK == 32, "the swizzled LDS image is 8 quads (32 floats) wide");
+    static_assert(BK == 32 || (BK == 64 && DT == 0), "the swizzled LDS image is 8 or 16 quads wide (bf16: 32 elements)");
     static_assert(NT % KQ == 0, "every unit of a thread shares its k-quad");
     static_assert(WM * WN == 4 || WM * WN == 1, "4 wavefronts per workgroup, or a single free-running one");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
@@ -320,7 +321,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
         v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w;
         return v;
     };
-    auto swz = [](int row) -> int { return ((row >> 1) ^ (row >> 4)) & 7; };
+    // 8 quads per row (128 B): rows r, r + 1 share a bank half, so the slot mixes (row >> 1) and (row >> 4);
+    // 16 quads per row (256 B = all 64 banks): every row starts at bank 0, slot = quad ^ (row & 15)
+    auto swz = [](int row) -> int { return KQ == 8 ? (((row >> 1) ^ (row >> 4)) & 7) : (row & 15); };
 
     // bf16 image helpers: element (row, k) at row * 32 + 8 * ((k >> 3) ^ swzb(row)) + (k & 7)   [bf16 units]
     auto swzb = [](int row) -> int { return (row >> 2) & 3; };
@@ -458,19 +461,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     const int frag_r = lane & 31;
     //   K-contiguous image: offset of quad 2q + h of the lane's row; row-contiguous image: offset of
     //   (k = 4h, lane's row), the step (q, e) then adds (8q + e) * S.
-    int a_off[TM][4], b_off[TN][4];
+    constexpr int NQ = KQ / 2;             // quad pairs (8 k) per K-tile
+    int a_off[TM][NQ], b_off[TN][NQ];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = (wm * TM + i) * 32 + frag_r;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NQ; ++q)
             a_off[i][q] = A_KC ? row * BK + 4 * ((2 * q + frag_h) ^ swz(row)) : (8 * q + 4 * frag_h) * SA + row;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int row = (wn * TN + j) * 32 + frag_r;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NQ; ++q)
             b_off[j][q] = B_KC ? row * BK + 4 * ((2 * q + frag_h) ^ swz(row)) : (8 * q + 4 * frag_h) * SB + row;
     }
     for (int c = 0; c < nchunks; ++c) {
@@ -507,9 +511,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
         }
         const float* as = As + buf * TILE_A;
         const float* bs = Bs + buf * TILE_B;
-        float af[TM][4][4], bf[TN][4][4];
+        float af[TM][NQ][4], bf[TN][NQ][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if constexpr (A_KC) {
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll

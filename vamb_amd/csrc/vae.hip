@@ -104,6 +104,15 @@ void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
     VH_HIP(hipGetLastError());
 }
 
+// 64-wide K-tiles (tile 4 of vh_debug_gemm): +4-7 % for an isolated GEMM (4096x512x512: 71 -> 74 TF/s, K = 4096:
+// 89 -> 95), but the doubled LDS footprint halves the co-residency of the dX / dW GEMMs that share the CUs in the
+// backward pass (376 vs 353 us per step with every GEMM on them) and for the forward GEMMs alone the step time
+// does not move (351.5 vs 351.0 us).  Opt-in (VAMBHIP_BK64=1, forward GEMMs only).
+bool bk64_enabled() {
+    static const bool on = [] { const char* e = getenv("VAMBHIP_BK64"); return e && e[0] == '1'; }();
+    return on;
+}
+
 // production tiles: 3 = 64x64 (2x2 waves, 2 workgroups per CU), 2 = 128x32 (4x1) for latent-wide outputs
 template <bool AKC, bool BKC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE>
 void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
@@ -113,6 +122,8 @@ void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
         return;
     }
     if (tile == 2) launch_gemm<128, 32, 4, 1, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
+    else if (g.wide_k && bk64_enabled() && g.K % 64 == 0 && g.k_per_split % 64 == 0)
+        launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB, 64>(s, g, splits);   // 64-wide K-tiles: half the barriers
     else launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
 }
 
@@ -134,6 +145,7 @@ void gemm_tile_debug(hipStream_t s, int tile, const GemmArgs& g, int splits) {
         case 0: launch_gemm<64, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
         case 1: launch_gemm<128, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
         case 2: launch_gemm<128, 32, 4, 1, AKC, BKC, EPI>(s, g, splits); break;
+        case 4: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XF_NONE, XF_NONE, 64>(s, g, splits); break;
         case 5: launch_gemm<32, 32, 1, 1, AKC, BKC, EPI>(s, g, splits); break;
         default: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
     }
@@ -597,6 +609,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
         g.M = bs_p; g.N = hl.nout_p; g.K = hl.nin_p; g.k_per_split = g.K;
         g.bias = h->pptr(hl.tb);
         g.m_real = bs;
+        g.wide_k = 1;
         if (training) {
             const bool probed = h->probe_on && li == h->probe_layer;
             g.C = hl.H.p; g.ldc = hl.nout_p;
@@ -665,6 +678,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
         g.C = h->R.p; g.ldc = h->D_p;
         g.M = bs_p; g.N = h->D_p; g.K = in_w; g.k_per_split = g.K;
         g.bias = h->pptr(h->tbo);
+        g.wide_k = 1;
         const bool ext_fork = training && fork_from_kernel(h);
         if (ext_fork) t_fork_stop = h->ev_fork;   // the running-statistics kernel below forks off this GEMM
         if (prev) {
@@ -1600,7 +1614,8 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
         VH_REQUIRE(A && B && C, "NULL argument");
         const bool use_bf16 = tile >= 100;   // tile + 100: the bf16-operand instantiation of that tile
         if (use_bf16) tile -= 100;
-        VH_REQUIRE(tile >= 0 && tile <= 5 && tile != 4, "tile in {0, 1, 2, 3, 5} (+100 for bf16 operands)");
+        VH_REQUIRE(tile >= 0 && tile <= 5 && !(tile == 4 && use_bf16), "tile in {0..5} (+100 for bf16 operands, not tile 4)");
+        VH_REQUIRE(tile != 4 || (K % 64 == 0 && (K / std::max(1, splits)) % 64 == 0), "tile 4 needs K multiple of 64");
         VH_REQUIRE(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && M % 4 == 0 && N % 4 == 0,
                    "need K multiple of 32 and M, N multiples of 4");
         VH_REQUIRE(splits >= 1 && (K / 32) >= splits, "bad split count");
