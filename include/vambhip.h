@@ -128,6 +128,9 @@ int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, in
 int vh_gen_destroy(vh_gen* g);
 /* one Cluster (cluster.py:298-316, 545-604); members = original contig indices, ascending */
 int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap);
+/* test hook (host only): n_calls consecutive random.Random(seed).sample(range(ns[i]), ks[i]) on one generator,
+ * results concatenated into out (sum of ks entries) */
+int vh_debug_pyrandom_sample(uint64_t seed, int n_calls, const int64_t* ns, const int64_t* ks, int64_t* out);
 /* accounting: passes over the matrix, medoids scanned, rows streamed, summed kernel time (when timing is on) */
 int vh_gen_counters(vh_gen* g, int64_t* scan_passes, int64_t* scan_medoids, int64_t* rows_streamed,
                     double* kernel_ms, int64_t* n_emitted, int64_t* n_remaining);

@@ -1460,6 +1460,23 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
     });
 }
 
+// test hook (host only, no GPU): consecutive random.Random(seed).sample(range(ns[i]), ks[i]) calls on ONE generator
+int vh_debug_pyrandom_sample(uint64_t seed, int n_calls, const int64_t* ns, const int64_t* ks, int64_t* out) {
+    return guarded([&] {
+        VH_REQUIRE(ns != nullptr && ks != nullptr && out != nullptr && n_calls >= 0, "bad argument");
+        PyRandom rng;
+        rng.seed(seed);
+        std::vector<int64_t> pop, got;
+        for (int i = 0; i < n_calls; ++i) {
+            VH_REQUIRE(ks[i] >= 0 && ks[i] <= ns[i] && ns[i] < (1ll << 31), "need 0 <= k <= n < 2^31");
+            pop.resize((size_t)ns[i]);
+            for (int64_t v = 0; v < ns[i]; ++v) pop[(size_t)v] = v;
+            rng.sample(pop, (int)ks[i], got);
+            for (int64_t v : got) *out++ = v;
+        }
+    });
+}
+
 int vh_gen_counters(vh_gen* g, int64_t* scan_passes, int64_t* scan_medoids, int64_t* rows_streamed, double* kernel_ms,
                     int64_t* n_emitted, int64_t* n_remaining) {
     return guarded([&] {
