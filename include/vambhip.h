@@ -128,6 +128,10 @@ int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, in
 int vh_gen_destroy(vh_gen* g);
 /* one Cluster (cluster.py:298-316, 545-604); members = original contig indices, ascending */
 int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap);
+/* test hook (host only): find_threshold (cluster.py:452-543) on exact histogram accumulators; kind 0 loner,
+ * 1 no threshold, 2 threshold (then *threshold and *observed_pvr are set) */
+int vh_debug_find_threshold(const int64_t* hist_fx, int64_t n_lt, double pvr, int* kind, double* threshold,
+                            double* observed_pvr);
 /* test hook (host only): n_calls consecutive random.Random(seed).sample(range(ns[i]), ks[i]) on one generator,
  * results concatenated into out (sum of ks entries) */
 int vh_debug_pyrandom_sample(uint64_t seed, int n_calls, const int64_t* ns, const int64_t* ks, int64_t* out);

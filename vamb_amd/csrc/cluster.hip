@@ -1460,6 +1460,22 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
     });
 }
 
+// test hook (host only, no GPU): find_threshold of the native state machine on a given exact histogram
+int vh_debug_find_threshold(const int64_t* hist_fx, int64_t n_lt, double pvr, int* kind, double* threshold,
+                            double* observed_pvr) {
+    return guarded([&] {
+        VH_REQUIRE(hist_fx != nullptr && kind != nullptr && threshold != nullptr && observed_pvr != nullptr, "NULL argument");
+        vh_gen g;
+        g.pvr = pvr;
+        GenStats st;
+        st.n_lt = n_lt;
+        for (int b = 0; b < VH_NBINS; ++b) st.hist_fx[b] = hist_fx[b];
+        *threshold = 0.0;
+        *observed_pvr = 0.0;
+        *kind = (int)gen_find_threshold(&g, st, threshold, observed_pvr);
+    });
+}
+
 // test hook (host only, no GPU): consecutive random.Random(seed).sample(range(ns[i]), ks[i]) calls on ONE generator
 int vh_debug_pyrandom_sample(uint64_t seed, int n_calls, const int64_t* ns, const int64_t* ks, int64_t* out) {
     return guarded([&] {
