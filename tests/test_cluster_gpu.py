@@ -184,3 +184,24 @@ def test_large_sweep_properties(oracle_lib):
     assert (seen == 1).all()                              # every contig emitted exactly once
     assert clusters >= synth.n_genomes(n) * 0.9
     assert purity_ok >= 0.95 * clusters
+
+
+def test_c2_sized_sweep_properties(oracle_lib):
+    """The cluster sweep at the row count of BASELINE configs C2 / C3 (2 M x 32): every contig emitted exactly once,
+    members ascending, >= 95 % pure clusters, and the matrix is physically packed several times on the way."""
+    n = 2_000_000
+    lat, labels = synth.blob_latent(n, 32, 0.08, seed=3)
+    lens = synth.lengths(n, 3)
+    seen = np.zeros(n, np.int32)
+    pure = clusters = 0
+    gen = vc.ClusterGenerator(lat, lens, destroy=True, rng_seed=2)
+    for c in gen:
+        seen[c.members] += 1
+        assert c.members[0] >= 0 and np.all(np.diff(c.members) > 0)
+        lab = labels[c.members]
+        pure += np.bincount(lab).max() == len(lab)
+        clusters += 1
+    assert (seen == 1).all()
+    assert clusters >= synth.n_genomes(n) * 0.9
+    assert pure >= 0.95 * clusters
+    assert len(gen.matrix) < n // 4          # order-preserving compaction ran (rows are dropped as they are emitted)
