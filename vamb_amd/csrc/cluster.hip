@@ -1078,6 +1078,7 @@ struct vh_gen {
     std::vector<int64_t> indices;   // original contig index of every physical row (ascending)
     std::vector<uint8_t> kept;      // host mirror of the device live mask (physical rows)
     std::vector<uint8_t> alive;     // the same by original contig index
+    std::vector<int32_t> bit;       // Fenwick tree over kept[] (prefix counts of live rows)
     int64_t order_index = 0;
     int64_t n_emitted = 0, n_remaining = 0;
     double pvr = 0.1;
@@ -1320,24 +1321,25 @@ ThresholdKind gen_find_threshold(const vh_gen* g, const GenStats& st, double* th
     return kThreshold;
 }
 
+// Cluster.seed is the seed's index in the reference's PACKED matrix = the number of live rows before it
+// (cluster.py:553, 570, 590).  Counted with a Fenwick tree over the physical rows (O(log n) per query / removal;
+// a linear count is 10 M byte-adds per cluster at config C4).
+void gen_bit_build(vh_gen* g) {
+    const size_t n = g->kept.size();
+    g->bit.assign(n + 1, 0);
+    for (size_t i = 1; i <= n; ++i) {
+        g->bit[i] += 1;
+        const size_t j = i + (i & (~i + 1));
+        if (j <= n) g->bit[j] += g->bit[i];
+    }
+}
+void gen_bit_remove(vh_gen* g, int64_t row) {
+    for (size_t i = (size_t)row + 1; i < g->bit.size(); i += i & (~i + 1)) g->bit[i] -= 1;
+}
 int64_t gen_logical_index(vh_gen* g, int64_t row) {
     GenTimer t(&g->t_logical);
-    // count of live rows before `row`: the mask holds 0 / 1 bytes, summed eight at a time
-    const uint8_t* k = g->kept.data();
-    int64_t c = 0, r = 0;
-    while (r + 8 <= row) {
-        uint64_t acc = 0;
-        const int64_t stop = std::min<int64_t>(row - 7, r + 8 * 255);   // a byte lane holds at most 255 ones
-        for (; r < stop; r += 8) {
-            uint64_t w;
-            memcpy(&w, k + r, 8);
-            acc += w;
-        }
-        acc = (acc & 0x00FF00FF00FF00FFull) + ((acc >> 8) & 0x00FF00FF00FF00FFull);
-        acc = (acc & 0x0000FFFF0000FFFFull) + ((acc >> 16) & 0x0000FFFF0000FFFFull);
-        c += (int64_t)((acc & 0xFFFFFFFFull) + (acc >> 32));
-    }
-    for (; r < row; ++r) c += k[r];
+    int64_t c = 0;
+    for (size_t i = (size_t)row; i > 0; i -= i & (~i + 1)) c += g->bit[i];
     return c;
 }
 
@@ -1368,6 +1370,7 @@ int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, in
         for (int64_t i = 0; i < n; ++i) g->indices[(size_t)i] = i;
         g->kept.assign((size_t)n, 1);
         g->alive.assign((size_t)n, 1);
+        gen_bit_build(g.get());
         g->n_remaining = n;
         *out = g.release();
     });
@@ -1445,6 +1448,7 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
         for (int64_t r : points) {
             g->kept[(size_t)r] = 0;
             g->alive[(size_t)g->indices[(size_t)r]] = 0;
+            gen_bit_remove(g, r);
         }
         const int64_t n_rows = (int64_t)g->kept.size();
         if (g->n_remaining > 0 && n_rows >= g->pack_min_rows && (double)g->n_remaining < g->pack_fraction * (double)n_rows) {
@@ -1456,6 +1460,7 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
             VH_REQUIRE((int64_t)w == new_n, "pack bookkeeping mismatch");
             g->indices.resize(w);
             g->kept.assign(w, 1);
+            gen_bit_build(g);
         }
     });
 }
