@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 HIDDEN = 512
 NTNF = 103
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table (fp32-input MFMA == fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (same table); only used with VAMBHIP_PRECISION=bf16
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -256,6 +257,11 @@ def main():
         flops = results[-1]["probe_flops"] if results else 0.0
         avg_ms = probe_ms / probe_n if probe_n else float("nan")
         achieved = flops / (avg_ms * 1e-3) / 1e12 if probe_n else float("nan")
+        bf16 = ve.get_compute_dtype() == "bf16"
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+        shape = (args.contigs, args.samples, args.batch, args.latent)
+        cfg_name = {(200_000, 50, 4096, 32): "C1", (2_000_000, 200, 8192, 32): "C2",
+                    (2_000_000, 1000, 8192, 32): "C3", (10_000_000, 1000, 8192, 64): "C4"}.get(shape, "custom")
         scan_src = warm if warm else results          # the steps that ran with scan-kernel timing on
         scan_ms = sum(r["scan_kernel_ms"] for r in scan_src)
         scan_bytes = sum(r["scan_bytes"] for r in scan_src)
@@ -270,11 +276,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if bf16 else "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"C1: {args.contigs} contigs x {args.samples} samples per GPU (D={D}), hidden 512-512, "
-                             f"latent {args.latent}, batch {args.batch}, fp32 MFMA; {args.epochs} train epochs "
+                "workload": (f"{cfg_name}: {args.contigs} contigs x {args.samples} samples per GPU (D={D}), hidden 512-512, "
+                             f"latent {args.latent}, batch {args.batch}, {'bf16 MFMA / fp32 accumulate' if bf16 else 'fp32 MFMA'}; "
+                             f"{args.epochs} train epochs "
                              f"(reference CLI default) + encode + full cluster sweep per step"),
                 "contigs_per_gpu": args.contigs, "samples": args.samples, "batch": args.batch,
                 "epochs": args.epochs, "parallelism": f"dp{world}" if world > 1 else "single",
@@ -283,8 +290,8 @@ def main():
                 "kernel": ("gemm_f32_kernel<64,64,2x2 waves,EPI_HIDDEN_TRAIN,XF_BN> (encoder layer 1, the FLOP-dominant "
                            "encoder GEMM: M=batch, K=512, N=512; BatchNorm of layer 0 applied on load, "
                            "bias+leaky-relu+dropout+BN batch sums in the epilogue)"),
-                "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS if probe_n else None, "traffic": pmc_traffic(),
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak if probe_n else None, "traffic": pmc_traffic() if cfg_name == "C1" else None,
                 "avg_launch_ms": avg_ms, "launches": probe_n, "flops_per_launch": flops,
                 "timing": "kernel begin/end timestamps (hipExtLaunchKernelGGL start/stop events) of every launch in the timed steps",
             },
