@@ -74,3 +74,30 @@ def test_no_gpu_fails_loudly(built_lib):
 
     with pytest.raises(_lib.VambHipError):
         vc.ClusterGenerator(np.ones((4, 3), np.float32), np.ones(4))
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/vambhip.h is the C-ABI contract: it must compile as C99 (no C++ types, no torch types) and a C
+    program that references every declared entry point must link against the library."""
+    import os
+    import re
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "vambhip.h")).read()
+    names = sorted(set(re.findall(r"\b(vh_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 40
+    src = tmp_path / "use_all.c"
+    body = "\n".join(f"    p[{i}] = (fn)&{n};" for i, n in enumerate(names))
+    src.write_text('#include "vambhip.h"\ntypedef void (*fn)(void);\nint main(void) {\n    fn p[%d];\n%s\n'
+                   '    return p[0] == p[1];\n}\n' % (len(names), body))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(root, "include"), str(src)])
+    lib = os.path.join(root, "vamb_amd", "libvambhip.so")
+    if os.path.exists(lib):
+        out = tmp_path / "use_all"
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(out), lib,
+                               "-Wl,-rpath," + os.path.dirname(lib), "-Wl,--allow-shlib-undefined"])
