@@ -564,8 +564,16 @@ __device__ __forceinline__ float4 fetch_grad(const TensorDesc& td, int64_t local
         g.z = (float)td.dsrc[local + 2]; g.w = (float)td.dsrc[local + 3];
         return g;
     }
-#pragma unroll 4
-    for (int s = 0; s < td.nslab; ++s) {
+    // eight slab loads in flight per round (same ascending summation order as before)
+    int s = 0;
+    for (; s + 8 <= td.nslab; s += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(td.slab + (int64_t)(s + q) * td.stride + local);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { g.x += v[q].x; g.y += v[q].y; g.z += v[q].z; g.w += v[q].w; }
+    }
+    for (; s < td.nslab; ++s) {
         const float4 v = *reinterpret_cast<const float4*>(td.slab + (int64_t)s * td.stride + local);
         g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
     }
