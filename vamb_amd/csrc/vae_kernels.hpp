@@ -176,7 +176,16 @@ __global__ void vae_reparam_kernel(const float* __restrict__ slabs, int nslab, i
     if (i >= (int64_t)bs_p * L_p) return;
     const int r = (int)(i / L_p), c = (int)(i % L_p);
     float m = bias[c];
-    for (int s = 0; s < nslab; ++s) m += slabs[(int64_t)s * stride + i];
+    {   // all slab loads in flight before the first add (ascending order kept)
+        constexpr int kMaxSlabs = 8;
+        float v[kMaxSlabs];
+#pragma unroll
+        for (int s = 0; s < kMaxSlabs; ++s) v[s] = s < nslab ? slabs[(int64_t)s * stride + i] : 0.f;
+#pragma unroll
+        for (int s = 0; s < kMaxSlabs; ++s)
+            if (s < nslab) m += v[s];
+        for (int s = kMaxSlabs; s < nslab; ++s) m += slabs[(int64_t)s * stride + i];
+    }
     MU[i] = m;
     float z = 0.f;
     if (r < bs && c < L) {
