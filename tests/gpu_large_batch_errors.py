@@ -1,0 +1,38 @@
+"""Diagnostic: per-tensor gradient error against the fp64 oracle at a large batch (python tests/gpu_large_batch_errors.py 16384)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import vae_oracle as vo
+from vamb_amd import encode as ve, synth
+batch = int(sys.argv[1]); drop = float(sys.argv[2]) if len(sys.argv) > 2 else 0.2
+S, hid, L = 6, [512, 512], 32
+ab, tnf, lens, _ = synth.features(batch, S, seed=21)
+dl = ve.make_dataloader(ab, tnf, lens, batchsize=batch, destroy=True)
+d, t, a, w = (x.numpy() for x in dl.dataset.tensors)
+st0 = vo.init_state(S, hid, L, 5)
+vae = ve.VAE(S, nhiddens=hid, nlatent=L, dropout=drop, seed=0)
+vae.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st0.items()})
+vae._ensure_dataset(dl)
+oracle = vo.OracleVAE(S, hid, L, vae.alpha, vae.beta, drop, state=st0)
+rng = np.random.RandomState(1)
+eps = rng.standard_normal((batch, L)).astype(np.float32)
+masks = [(rng.random_sample((batch, 512)) >= drop).astype(np.uint8) for _ in range(4)]
+losses = vae.train_batch(np.arange(batch), eps=eps, masks=masks if drop > 0 else None)
+want = oracle.train_step(d, t, a, w, eps, masks)
+print("batch", batch, "loss rel", max(abs(x - y) / abs(y) for x, y in zip(losses, want)))
+for name in oracle.names:
+    got = vae.parameters_gradient(name); ref = oracle.grads[name]
+    print("  %-26s max/max %.2e  fro %.2e  |ref|max %.2e" % (name, np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30),
+          np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30), np.abs(ref).max()))
+for name in ("encoderlayers.1.weight", "encoderlayers.1.bias", "encodernorms.1.weight", "encodernorms.0.weight"):
+    got = vae.parameters_gradient(name); ref = oracle.grads[name]
+    err = np.abs(got - ref)
+    idx = np.argsort(err.ravel())[::-1][:6]
+    print(name, [(tuple(int(x) for x in np.unravel_index(i, err.shape)), float("%.2e" % err.ravel()[i]), float("%.2e" % ref.ravel()[i])) for i in idx])
+    if err.ndim == 2:
+        print("   rows with large error:", np.argsort(err.max(axis=1))[::-1][:8].tolist(), " cols:", np.argsort(err.max(axis=0))[::-1][:8].tolist())
+# forward statistics of encoder layer 1: mean / variance per column from the GPU activations
+H = vae.hidden_activations(1, batch)
+print("H1 column std min/median:", float(H.std(axis=0).min()), float(np.median(H.std(axis=0))), "argmin", int(H.std(axis=0).argmin()))

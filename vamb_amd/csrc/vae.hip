@@ -122,6 +122,8 @@ void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
         return;
     }
     if (tile == 2) launch_gemm<128, 32, 4, 1, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
+    else if (tile == 1) launch_gemm<128, 128, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
+    else if (tile == 0) launch_gemm<64, 128, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
     else if (g.wide_k && bk64_enabled() && g.K % 64 == 0 && g.k_per_split % 64 == 0)
         launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB, 64>(s, g, splits);   // 64-wide K-tiles: half the barriers
     else launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
@@ -151,7 +153,20 @@ void gemm_tile_debug(hipStream_t s, int tile, const GemmArgs& g, int splits) {
     }
 }
 
-int fwd_tile(int N) { return N <= 32 ? 2 : 3; }
+// Output [M][N] of a forward / input-gradient GEMM.  VAMBHIP_BIG_TILES=1 picks the largest tile that still yields
+// two workgroups per CU (a 64x64 accumulator per wavefront needs one fresh LDS operand per MFMA instead of two:
+// isolated, 16384x512x512 runs at 99 instead of 86 TF/s and 8192x512x1120 at 95 instead of 87).  Inside the real
+// training step at C2 (batch 8192) it measured SLOWER (665 vs 634 us): opt-in, parity-tested
+// (tests/test_vae_gpu.py::test_large_batch_tiles_match_oracle).
+int fwd_tile(int M, int N) {
+    if (N <= 32) return 2;
+    static const bool big = [] { const char* e = getenv("VAMBHIP_BIG_TILES"); return e && e[0] == '1'; }();
+    if (big) {
+        if (ceil_div(M, 128) * ceil_div(N, 128) >= 512) return 1;
+        if (ceil_div(M, 64) * ceil_div(N, 128) >= 512) return 0;
+    }
+    return 3;
+}
 
 GemmArgs base_args(bool bf16 = false) {
     GemmArgs g;
@@ -602,7 +617,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
     const Hidden* prev = nullptr;   // the layer whose BatchNorm still has to be applied to `in` (training)
     auto hidden_layer = [&](int li) {
         Hidden& hl = h->hidden[li];
-        const int tile = fwd_tile(hl.nout_p);
+        const int tile = fwd_tile(bs_p, hl.nout_p);
         GemmArgs g = base_args(h->bf16);
         g.A = in; g.lda = in_w;
         g.B = h->pptr(hl.tW); g.ldb = hl.nin_p;
@@ -654,9 +669,9 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
         g.slab_stride = (int64_t)bs_p * h->L_p;
         if (prev) {
             g.bnA = bn_src(h, *prev);
-            gemm_tile<true, true, EPI_SPLITK, XF_BN>(s, fwd_tile(h->L_p), g, mu_slabs);
+            gemm_tile<true, true, EPI_SPLITK, XF_BN>(s, fwd_tile(bs_p, h->L_p), g, mu_slabs);
         } else {
-            gemm_tile<true, true, EPI_SPLITK>(s, fwd_tile(h->L_p), g, mu_slabs);
+            gemm_tile<true, true, EPI_SPLITK>(s, fwd_tile(bs_p, h->L_p), g, mu_slabs);
         }
     }
     {   // latent = mu + eps  (encode.py:276-286; sigma == 1); eps injected (parity) or generated in place
@@ -683,9 +698,9 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
         if (ext_fork) t_fork_stop = h->ev_fork;   // the running-statistics kernel below forks off this GEMM
         if (prev) {
             g.bnA = bn_src(h, *prev);
-            gemm_tile<true, true, EPI_BIAS, XF_BN>(s, fwd_tile(h->D_p), g, 1);
+            gemm_tile<true, true, EPI_BIAS, XF_BN>(s, fwd_tile(bs_p, h->D_p), g, 1);
         } else {
-            gemm_tile<true, true, EPI_BIAS>(s, fwd_tile(h->D_p), g, 1);
+            gemm_tile<true, true, EPI_BIAS>(s, fwd_tile(bs_p, h->D_p), g, 1);
         }
         if (ext_fork) VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     }
@@ -761,7 +776,7 @@ int grad_input(vh_vae* h, const float* dZ, int out_p, int tW, int in_p, float* d
     g.B = h->pptr(tW); g.ldb = in_p;
     g.M = h->bs_p; g.N = in_p; g.K = out_p;
     g.m_real = h->bs;
-    const int tile = fwd_tile(in_p);
+    const int tile = fwd_tile(h->bs_p, in_p);
     if (to_latent) {
         int splits = 1;
         g.k_per_split = g.K;
@@ -1550,7 +1565,7 @@ int vh_vae_encode(vh_vae* h, float* latent) {
                 g.C = bufs[li & 1]; g.ldc = hl.nout_p;
                 g.M = m; g.N = hl.nout_p; g.K = hl.nin_p; g.k_per_split = g.K;
                 g.bias = h->pptr(hl.tb); g.scale = hl.scale.p; g.shift = hl.shift.p; g.m_real = m;
-                gemm_tile<true, true, EPI_HIDDEN_EVAL>(s, fwd_tile(hl.nout_p), g, 1);
+                gemm_tile<true, true, EPI_HIDDEN_EVAL>(s, fwd_tile(m, hl.nout_p), g, 1);
                 in = bufs[li & 1];
                 in_w = hl.nout_p;
             }
@@ -1560,7 +1575,7 @@ int vh_vae_encode(vh_vae* h, float* latent) {
             g.C = lat.p; g.ldc = h->L;          // compact [m][L]: only the logical columns are stored
             g.M = m; g.N = h->L; g.K = in_w; g.k_per_split = g.K;
             g.bias = h->pptr(h->tbmu);
-            gemm_tile<true, true, EPI_LATENT_MASK>(s, fwd_tile(h->L_p), g, 1);
+            gemm_tile<true, true, EPI_LATENT_MASK>(s, fwd_tile(m, h->L_p), g, 1);
             VH_HIP(hipMemcpyAsync(latent + (size_t)lo * h->L, lat.p, sizeof(float) * (size_t)m * h->L,
                                   hipMemcpyDeviceToHost, s));
             VH_HIP(hipStreamSynchronize(s));
