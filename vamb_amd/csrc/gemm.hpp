@@ -415,6 +415,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
             sB = *reinterpret_cast<const float4*>(coefB + (k0 - kbeg) + 4 * (tid % KQ));
             tB = *reinterpret_cast<const float4*>(coefB + ncolB + (k0 - kbeg) + 4 * (tid % KQ));
         }
+        // row-contiguous operands: the coefficient index is the unit's row quad, the same for every unit of a thread
+        // when NT is a multiple of rows / 4 (64- and 128-row tiles with 256 threads)
+        constexpr bool kRowQuadA = !A_KC && XFA == XF_BN && NT % (BM / 4) == 0;
+        constexpr bool kRowQuadB = !B_KC && XFB == XF_BN && NT % (BN / 4) == 0;
+        if constexpr (kRowQuadA) {
+            sA = *reinterpret_cast<const float4*>(coefA + 4 * (tid % (BM / 4)));
+            tA = *reinterpret_cast<const float4*>(coefA + ncolA + 4 * (tid % (BM / 4)));
+        }
+        if constexpr (kRowQuadB) {
+            sB = *reinterpret_cast<const float4*>(coefB + 4 * (tid % (BN / 4)));
+            tB = *reinterpret_cast<const float4*>(coefB + ncolB + 4 * (tid % (BN / 4)));
+        }
         auto fma4 = [](float4 v, const float4& s4, const float4& t4) -> float4 {
             v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w;
             return v;
@@ -429,7 +441,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
                 if (u < BM * KQ) *reinterpret_cast<float4*>(as + row * BK + 4 * (kq ^ swz(row))) = v;
             } else {
                 const int k = u / (BM / 4), mq = u % (BM / 4);
-                if constexpr (XFA == XF_BN) v = bn4(v, coefA + 4 * mq, coefA + ncolA + 4 * mq);
+                if constexpr (kRowQuadA) v = fma4(v, sA, tA);
+                else if constexpr (XFA == XF_BN) v = bn4(v, coefA + 4 * mq, coefA + ncolA + 4 * mq);
                 if (u < BM * KQ) *reinterpret_cast<float4*>(as + k * SA + 4 * mq) = v;
             }
         }
@@ -443,7 +456,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
                 if (u < BN * KQ) *reinterpret_cast<float4*>(bs + row * BK + 4 * (kq ^ swz(row))) = v;
             } else {
                 const int k = u / (BN / 4), nq = u % (BN / 4);
-                if constexpr (XFB == XF_BN) v = bn4(v, coefB + 4 * nq, coefB + ncolB + 4 * nq);
+                if constexpr (kRowQuadB) v = fma4(v, sB, tB);
+                else if constexpr (XFB == XF_BN) v = bn4(v, coefB + 4 * nq, coefB + ncolB + 4 * nq);
                 if (u < BN * KQ) *reinterpret_cast<float4*>(bs + k * SB + 4 * nq) = v;
             }
         }
