@@ -267,6 +267,15 @@ int vh_vae_train_epoch_dp(vh_vae* h, const int64_t* perm, int64_t n_batches, int
 int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, const float* bias, float* C,
                   int M, int N, int K, int splits, float* ms);
 
+/* Diagnostic: one launch configuration of the bf16-storage GEMM (gemm_bf16.hpp: bf16 operands in memory, LDS-DMA
+ * staging, bf16 MFMA with fp32 accumulation) on host data.  A [M][K] and B [N][K] are rounded to bf16 (nearest even) on
+ * the host; C[m][n] = sum_k A[m][k] B[n][k].  epi: 0 = split-K fp32 slabs (summed on return), 1 = fp32 + bias,
+ * 3 = hidden-layer epilogue without dropout: C = bf16(leaky_relu(acc + bias)) as float, CT (optional) the transposed
+ * bf16 copy [N][M] as float, stats (optional) [2][N] the fp64 batch sums of C and C^2.  The tile is chosen from the
+ * output shape as in the training step.  *ms = average duration of `reps` back-to-back launches. */
+int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, float* C, float* CT, double* stats, int M,
+                    int N, int K, int splits, int reps, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,28 +93,57 @@ def bf16_round(x):
     return u.astype(np.uint32).view(np.float32)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5])
-@pytest.mark.parametrize("layout", [(1, 1), (1, 0), (0, 0)])
-@pytest.mark.parametrize("shape", [(128, 128, 32, 1), (192, 96, 64, 2), (260, 36, 160, 1), (512, 512, 512, 4)])
-def test_gemm_instantiations_bf16(tile, layout, shape):
-    """The bf16-operand instantiations (tile + 100): exact against float64 of the bf16-ROUNDED operands up to fp32
-    accumulation error (bf16 x bf16 products are exact in fp32), and within bf16 resolution of the unrounded product."""
+def _gemm16(epi, A, B, bias=None, splits=1, want_t=False, want_stats=False):
+    M, K = A.shape
+    N = B.shape[0]
+    C = np.zeros((M, N), np.float32)
+    CT = np.zeros((N, M), np.float32) if want_t else None
+    stats = np.zeros((2, N), np.float64) if want_stats else None
+    ms = ctypes.c_float()
+    _lib.check(_lib.load().vh_debug_gemm16(epi, _lib.ptr(np.ascontiguousarray(A)), _lib.ptr(np.ascontiguousarray(B)),
+                                           _lib.ptr(bias), _lib.ptr(C), _lib.ptr(CT), _lib.ptr(stats), M, N, K, splits, 1,
+                                           ctypes.byref(ms)))
+    return C, CT, stats
+
+
+# shapes: one tile exactly; ragged in every dimension (K = 8 * odd, N < tile, M > tile); the latent-wide (N <= 32) and
+# latent-tall (M <= 32) tiles; a split-K weight-gradient shape; the C3 encoder shape D_p = 1120 (17.5 K-tiles)
+@pytest.mark.parametrize("shape", [(128, 128, 64, 1), (256, 96, 136, 1), (384, 320, 512, 1), (512, 32, 512, 4),
+                                   (32, 512, 2048, 4), (512, 512, 4096, 8), (320, 512, 1024, 2), (1024, 512, 1120, 1)])
+def test_gemm16_split_k_and_bias(shape):
+    """The bf16-storage GEMM (LDS-DMA staging, source-side swizzle, bf16 MFMA): exact against float64 of the
+    bf16-ROUNDED operands up to fp32 accumulation error; asymmetric operands so that a transposed or mis-mapped
+    fragment, a wrong swizzle or a stale LDS buffer cannot pass."""
     M, N, K, splits = shape
-    a_kc, b_kc = layout
     rng = np.random.RandomState(M + N + K + 1)
     A = rng.standard_normal((M, K)).astype(np.float32)
     B = (rng.standard_normal((N, K)) + 0.25 * np.arange(N)[:, None] / N).astype(np.float32)
-    want_rounded = bf16_round(A).astype(np.float64) @ bf16_round(B).astype(np.float64).T
-    want_exact = A.astype(np.float64) @ B.astype(np.float64).T
-    Ad = np.ascontiguousarray(A if a_kc else A.T)
-    Bd = np.ascontiguousarray(B if b_kc else B.T)
-    C = np.zeros((M, N), np.float32)
-    ms = ctypes.c_float()
-    lib = _lib.load()
-    _lib.check(lib.vh_debug_gemm(100 + tile, a_kc, b_kc, _lib.ptr(Ad), _lib.ptr(Bd), None, _lib.ptr(C), M, N, K, splits,
-                                 ctypes.byref(ms)))
-    assert rel(C, want_rounded) < 2e-6 * np.sqrt(K)
-    assert rel(C, want_exact) < 1e-2
+    want = bf16_round(A).astype(np.float64) @ bf16_round(B).astype(np.float64).T
+    C, _, _ = _gemm16(0, A, B, splits=splits)
+    assert rel(C, want) < 2e-6 * np.sqrt(K)
+    if splits == 1:
+        bias = rng.standard_normal(N).astype(np.float32)
+        C, _, _ = _gemm16(1, A, B, bias=bias)
+        assert rel(C, want + bias) < 2e-6 * np.sqrt(K)
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 96, 136), (384, 320, 512), (1024, 512, 1120)])
+def test_gemm16_hidden_epilogue(shape):
+    """Hidden-layer epilogue: bf16 image through LDS (row-major copy), direct transposed copy, fp64 batch sums of
+    the ROUNDED outputs."""
+    M, N, K = shape
+    rng = np.random.RandomState(M + N + K + 2)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = (rng.standard_normal((N, K)) / np.sqrt(K) + 0.25 * np.arange(N)[:, None] / N).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    z = bf16_round(A).astype(np.float64) @ bf16_round(B).astype(np.float64).T + bias
+    want = np.where(z > 0, z, 0.01 * z)
+    C, CT, stats = _gemm16(3, A, B, bias=bias, want_t=True, want_stats=True)
+    assert rel(C, want) < 2.0 ** -8                      # one bf16 rounding of the output
+    assert np.array_equal(CT, C.T)                       # both copies carry the same bits
+    assert np.array_equal(bf16_round(C), C)              # ... which are bf16 values
+    assert np.allclose(stats[0], C.astype(np.float64).sum(axis=0), rtol=1e-5, atol=1e-3)
+    assert np.allclose(stats[1], (C.astype(np.float64) ** 2).sum(axis=0), rtol=1e-5, atol=1e-3)
 
 
 @pytest.mark.parametrize("name", ["vae_small_drop", "vae_default_arch"])

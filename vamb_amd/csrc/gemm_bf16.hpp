@@ -1,0 +1,468 @@
+// gemm_bf16.hpp -- bf16-storage GEMM for the VAE's dense contractions at BASELINE configs C2-C4
+// ("bf16 MFMA with fp32 accumulate"), gfx950.
+//
+//   C[m][n] = sum_k A[m][k] * B[n][k]        A: [M][K] bf16, B: [N][K] bf16, both K-contiguous ("NT")
+//
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulators.  Unlike gemm.hpp (fp32 tensors in HBM, operands
+// rounded while they are staged through registers) every operand here already IS bf16 in memory, so a
+// K-tile travels HBM/L2 -> LDS without touching a VGPR:
+//   * staging: global_load_lds_dwordx4 (LDS-DMA).  One wave instruction moves 8 tile rows x 128 B (64 bf16)
+//     = 1 KiB into a lane-linear LDS span; the 16-byte slots of a row are XOR-permuted on the SOURCE side
+//     (lane (row, s) fetches k-slot s ^ f(row)) and read back with the same involution, so the LDS image
+//     is the swizzled [rows][64 bf16] tile whose ds_read_b128 fragment reads are bank-conflict free
+//     (f(row) = ((row >> 1) ^ (row >> 4)) & 7: the 16 lanes a b128 access services together hit 16 distinct
+//     (row & 1, slot) pairs = all 64 banks).
+//   * two LDS buffers, BK = 64 (four 32x32x16 steps), next tile's DMA in flight under the MFMAs of the
+//     current one, one barrier per K-tile (the structure the CDNA4 guide lists for a one-workgroup-per-CU
+//     GEMM whose LDS image can be lane-linear).
+//   * pieces outside the matrix (rows >= M / N, k >= the split's end) are fetched from a 16-byte block of
+//     zeros instead -- no divergent control flow around the DMA, any K that is a multiple of 8 works.
+//   * all four operand layouts the training step needs (forward, dX, dW) are expressed as NT products by
+//     keeping a transposed bf16 copy of whatever is contracted along its slow dimension: the producing
+//     kernels write it for free from the MFMA C layout (a lane holds 4 consecutive rows of one column).
+//
+// Epilogues (fp32 math on the accumulators):
+//   E16_SPLITK      C32[slab z] = acc                                   (dW, latent-wide outputs)
+//   E16_BIAS        C32 = acc + bias[n]                                 (reconstruction)
+//   E16_LATENT_MASK C32 = bits(acc + bias) & ~0xFFF, compact [M][N]     (encode, vambtools.py:324-330)
+//   E16_HIDDEN_TRAIN h = dropout(leaky_relu(acc + bias)) rounded to bf16; C16 = h, C16T = h^T; fp64 batch sums
+//                   of h and h^2 (of the ROUNDED values: the statistics every consumer of C16 sees)
+//   E16_HIDDEN_EVAL C16 = bf16(leaky_relu(acc + bias) * scale[n] + shift[n])
+//   E16_STORE_BNRED C16 = bf16(acc) (= dA of the layer below) + fp64 batch sums of dA and dA * xhat(Hbelow)
+// bf16 outputs leave through an LDS image of the tile and 16-byte row-major stores; the transposed copy goes
+// straight from the accumulator layout as 8-byte stores.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include "gemm.hpp"
+
+namespace vh {
+
+typedef unsigned short bf16_t;   // raw bfloat16 bits
+
+enum Epi16 : int {
+    E16_SPLITK = 0,
+    E16_BIAS = 1,
+    E16_LATENT_MASK = 2,
+    E16_HIDDEN_TRAIN = 3,
+    E16_HIDDEN_EVAL = 4,
+    E16_STORE_BNRED = 5
+};
+
+struct Gemm16Args {
+    const bf16_t* A;
+    int64_t lda;
+    const bf16_t* B;
+    int64_t ldb;
+    int M, N, K;
+    int k_per_split;       // contraction elements per blockIdx.z (multiple of 64 unless there is one split)
+    int64_t slab_stride;   // elements between split-K slabs of C32
+    const bf16_t* zeros;   // >= 16 bytes of zeros
+    float* C32;
+    int64_t ldc32;
+    bf16_t* C16;
+    int64_t ldc16;
+    bf16_t* C16T;          // [N][M] (may be nullptr)
+    int64_t ldc16t;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    int m_real;            // rows that belong to the batch (statistics / dropout rows)
+    double* fstat_out;     // E16_HIDDEN_TRAIN: [2][N]
+    float drop_scale;
+    uint32_t drop_thresh;
+    uint64_t drop_key;
+    const unsigned long long* step_ptr;
+    const uint8_t* drop_mask;
+    int64_t ld_mask;
+    // E16_STORE_BNRED
+    const bf16_t* Hbelow;  // raw activations of the layer below, [M][N] bf16 with leading dimension ldh
+    int64_t ldh;
+    BnSrc bnC;
+    double* bstat_out;     // [2][N]
+    int xcd_remap;
+};
+
+__device__ __forceinline__ bf16_t f2bf(float x) {
+    const __bf16 b = (__bf16)x;   // round to nearest even
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+// slot permutation of the [rows][64 bf16] LDS image (8 slots of 16 B per 128-byte row)
+__device__ __forceinline__ int swz16(int row) { return ((row >> 1) ^ (row >> 4)) & 7; }
+
+__device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Args g) {
+    constexpr int NWAVE = WM * WN;
+    constexpr int NT = NWAVE * 64;
+    constexpr int TM = BM / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    constexpr int BK = 64;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;   // one buffer of each operand
+    constexpr int PA = BM / 8, PB = BN / 8;                 // 1 KiB DMA pieces per K-tile
+    constexpr int RA = PA / NWAVE, RB = PB / NWAVE;         // pieces per wave
+    static_assert(TM >= 1 && TN >= 1 && PA % NWAVE == 0 && PB % NWAVE == 0, "tile / wave layout");
+    // ALL LDS of the kernel is this one array (a second __shared__ object makes hipcc drain the DMA queue
+    // in front of every fragment read)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    unsigned char* const As = smem16;                  // [2][A_BYTES]
+    unsigned char* const Bs = smem16 + 2 * A_BYTES;    // [2][B_BYTES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.xcd_remap) {   // XCD x gets the x-th contiguous eighth of the (z, m, n)-ordered tile list (speed only)
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int nwg = gx * gy * (int)gridDim.z;
+        const int bid = bx + gx * (by + gy * bz);
+        const int xcd = bid & 7, local = bid >> 3;
+        const int t = xcd * (nwg >> 3) + min(xcd, nwg & 7) + local;
+        bx = t % gx;
+        by = (t / gx) % gy;
+        bz = t / (gx * gy);
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    // ---- DMA source addresses: lane (row = 8 piece + lane / 8, LDS slot s = lane % 8) fetches k-slot s ^ f(row)
+    const bf16_t* a_src[RA];
+    const bf16_t* b_src[RB];
+    int a_k[RA], b_k[RB];      // k offset of the lane's slot inside a K-tile; >= BK marks a row outside the matrix
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+        const int row = 8 * (wave + NWAVE * r) + (lane >> 3);
+        const int ks = 8 * ((lane & 7) ^ swz16(row));
+        const bool ok = m0 + row < g.M;
+        a_k[r] = ok ? ks : (1 << 30);
+        a_src[r] = g.A + (int64_t)(ok ? m0 + row : 0) * g.lda + ks;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int row = 8 * (wave + NWAVE * r) + (lane >> 3);
+        const int ks = 8 * ((lane & 7) ^ swz16(row));
+        const bool ok = n0 + row < g.N;
+        b_k[r] = ok ? ks : (1 << 30);
+        b_src[r] = g.B + (int64_t)(ok ? n0 + row : 0) * g.ldb + ks;
+    }
+    auto stage = [&](unsigned char* abuf, unsigned char* bbuf, int k0) {
+        const int room = kend - k0;   // slots with k offset >= room are past the end of this split
+#pragma unroll
+        for (int r = 0; r < RA; ++r)
+            glds16(a_k[r] < room ? a_src[r] + k0 : g.zeros, abuf + (wave + NWAVE * r) * 1024);
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            glds16(b_k[r] < room ? b_src[r] + k0 : g.zeros, bbuf + (wave + NWAVE * r) * 1024);
+    };
+
+    // ---- fragment addresses: lane (r = lane & 31, h = lane >> 5) reads k = 16 t + 8 h .. + 7 of its row
+    const int frag_r = lane & 31, frag_h = lane >> 5;
+    int a_off[TM], a_swz[TM], b_off[TN], b_swz[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + frag_r;
+        a_off[i] = row * 128;
+        a_swz[i] = swz16(row);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 32 + frag_r;
+        b_off[j] = row * 128;
+        b_swz[j] = swz16(row);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto compute = [&](const unsigned char* abuf, const unsigned char* bbuf) {
+        // Software pipeline inside the K-tile: the fragments of step t + 2 are requested while step t multiplies
+        // (hipcc on its own sinks every ds_read_b128 to just in front of its MFMA and waits lgkmcnt(0) four times per
+        // tile).  sched_barrier(0) pins the order; the compiler still places the counted lgkmcnt waits.
+        bf16x8 a8[BK / 16][TM], b8[BK / 16][TN];
+        auto frags = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a8[t][i] = *reinterpret_cast<const bf16x8*>(abuf + a_off[i] + 16 * ((2 * t + frag_h) ^ a_swz[i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b8[t][j] = *reinterpret_cast<const bf16x8*>(bbuf + b_off[j] + 16 * ((2 * t + frag_h) ^ b_swz[j]));
+        };
+        auto mfmas = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[t][i], b8[t][j], acc[i][j], 0, 0, 0);
+        };
+        frags(0);
+        frags(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        frags(2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1);
+        frags(3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(2);
+        mfmas(3);
+        __builtin_amdgcn_sched_barrier(0);   // the barrier (and its DMA drain) stays BEHIND the MFMAs
+    };
+
+    // K loop, unrolled by two so that every LDS address is a compile-time offset of the one array
+    if (nk > 0) stage(As, Bs, kbeg);
+    __syncthreads();   // (hipcc drains the DMA queue in front of this barrier)
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        stage(As + A_BYTES, Bs + B_BYTES, kbeg + (kt + 1) * BK);
+        compute(As, Bs);
+        __syncthreads();
+        if (kt + 2 < nk) stage(As, Bs, kbeg + (kt + 2) * BK);
+        compute(As + A_BYTES, Bs + B_BYTES);
+        __syncthreads();
+    }
+    if (kt < nk) {   // odd number of K-tiles: the last one sits in buffer 0
+        compute(As, Bs);
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------------------------------------------
+    // epilogue.  acc[i][j][reg] is C[row][col] with
+    //   row = m0 + (wm*TM + i)*32 + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5),   col = n0 + (wn*TN + j)*32 + (lane & 31)
+    // ---------------------------------------------------------------------------------------------------
+    if constexpr (EPI == E16_SPLITK || EPI == E16_BIAS || EPI == E16_LATENT_MASK) {
+        float* Cout = g.C32;
+        if constexpr (EPI == E16_SPLITK) Cout += (int64_t)bz * g.slab_stride;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + frag_r;
+            const bool col_ok = col < g.N;
+            float bias = 0.f;
+            if constexpr (EPI != E16_SPLITK) bias = col_ok ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * frag_h;
+                    if (!col_ok || row >= g.M) continue;
+                    float v = acc[i][j][reg] + bias;
+                    if constexpr (EPI == E16_LATENT_MASK) v = __uint_as_float(__float_as_uint(v) & 0xFFFFF000u);
+                    Cout[(int64_t)row * g.ldc32 + col] = v;
+                }
+        }
+        return;
+    } else {
+        // bf16 image of the output tile in LDS: [BM][CP] (operand buffers are free: every wave is past the last barrier)
+        constexpr int CP = BN + 8;                         // elements per image row (keeps 16-byte alignment)
+        constexpr int CT_BYTES = BM * CP * 2;
+        bf16_t* const ct = reinterpret_cast<bf16_t*>(smem16);
+        float* const red = reinterpret_cast<float*>(smem16 + CT_BYTES);   // reduction scratch behind the image
+        float s1[TN], s2[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+        uint64_t drop_key = 0;
+        if constexpr (EPI == E16_HIDDEN_TRAIN) drop_key = step_key(g.drop_key, g.step_ptr);
+        // phase 1 (accumulator layout): transform, round, write the image (+ the transposed copy, + the sums).
+        // DROP = 0: no dropout, 1: counter-based hash, 2: injected keep-masks -- chosen once per workgroup
+        auto phase1 = [&](auto drop_mode) {
+            constexpr int DROP = decltype(drop_mode)::value;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cl = (wn * TN + j) * 32 + frag_r;
+                const int col = n0 + cl;
+                const bool col_ok = col < g.N;
+                float bias = 0.f, sc = 1.f, sh = 0.f;
+                if constexpr (EPI == E16_HIDDEN_TRAIN || EPI == E16_HIDDEN_EVAL) bias = col_ok ? g.bias[col] : 0.f;
+                if constexpr (EPI == E16_HIDDEN_EVAL) {
+                    sc = col_ok ? g.scale[col] : 0.f;
+                    sh = col_ok ? g.shift[col] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bf16_t hb[4];
+                        uint32_t pair_bits = 0;
+                        const int rl4 = (wm * TM + i) * 32 + 8 * q + 4 * frag_h;
+                        if constexpr (DROP == 1) {
+                            // rows 2p and 2p + 1 of a column share one hash (same rule as gemm.hpp); rl4 is a multiple of 4
+                            pair_bits = hash_drop(drop_key, (uint32_t)((m0 + rl4) >> 1) * (uint32_t)g.N + (uint32_t)col);
+                        }
+                        uint32_t pair_bits2 = 0;
+                        if constexpr (DROP == 1)
+                            pair_bits2 = hash_drop(drop_key, (uint32_t)(((m0 + rl4) >> 1) + 1) * (uint32_t)g.N + (uint32_t)col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int rl = rl4 + e;
+                            const int row = m0 + rl;
+                            float v = acc[i][j][4 * q + e];
+                            if constexpr (EPI == E16_HIDDEN_TRAIN) {
+                                v += bias;
+                                v = v > 0.f ? v : kLeakySlopeF * v;
+                                if constexpr (DROP != 0) {
+                                    bool keep = row < g.m_real && col_ok;
+                                    if constexpr (DROP == 2) {
+                                        if (keep) keep = g.drop_mask[(int64_t)row * g.ld_mask + col] != 0;
+                                    } else {
+                                        const uint32_t pb = e < 2 ? pair_bits : pair_bits2;
+                                        const uint32_t u16 = (e & 1) ? (pb >> 16) : (pb & 0xFFFFu);
+                                        keep = keep && (u16 >= (g.drop_thresh >> 16));
+                                    }
+                                    v = keep ? v * g.drop_scale : 0.f;
+                                }
+                            } else if constexpr (EPI == E16_HIDDEN_EVAL) {
+                                v += bias;
+                                v = v > 0.f ? v : kLeakySlopeF * v;
+                                v = v * sc + sh;
+                            }
+                            const bf16_t b = col_ok ? f2bf(v) : (bf16_t)0;
+                            if constexpr (EPI == E16_HIDDEN_TRAIN) {
+                                if (row < g.m_real && col_ok) {
+                                    const float vr = bf2f(b);
+                                    s1[j] += vr;
+                                    s2[j] += vr * vr;
+                                }
+                            }
+                            hb[e] = b;
+                            ct[rl * CP + cl] = b;
+                        }
+                        if constexpr (EPI == E16_HIDDEN_TRAIN) {
+                            // transposed copy: 4 consecutive rows of this lane's column = 8 contiguous bytes of C16T
+                            const int row4 = m0 + rl4;
+                            if (g.C16T != nullptr && col_ok && row4 < g.M) {
+                                uint2 w;
+                                w.x = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16);
+                                w.y = (uint32_t)hb[2] | ((uint32_t)hb[3] << 16);
+                                *reinterpret_cast<uint2*>(g.C16T + (int64_t)col * g.ldc16t + row4) = w;
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        if constexpr (EPI == E16_HIDDEN_TRAIN) {
+            if (g.drop_mask) phase1(std::integral_constant<int, 2>{});
+            else if (g.drop_scale != 1.0f) phase1(std::integral_constant<int, 1>{});
+            else phase1(std::integral_constant<int, 0>{});
+        } else {
+            phase1(std::integral_constant<int, 0>{});
+        }
+        if constexpr (EPI == E16_HIDDEN_TRAIN) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                s1[j] += __shfl_xor(s1[j], 32);
+                s2[j] += __shfl_xor(s2[j], 32);
+                if (lane < 32) {
+                    const int cl = (wn * TN + j) * 32 + lane;
+                    red[(0 * WM + wm) * BN + cl] = s1[j];
+                    red[(1 * WM + wm) * BN + cl] = s2[j];
+                }
+            }
+        }
+        __syncthreads();
+        // row-major pass over the image: 16-byte chunks (8 columns), CPR chunks per row
+        constexpr int CPR = BN / 8;
+        constexpr int RPP = NT / CPR;         // rows covered by one pass of the workgroup
+        static_assert(NT % CPR == 0 && BM % RPP == 0, "row-major pass layout");
+        const int cc = tid % CPR, r0 = tid / CPR;
+        const int col8 = n0 + 8 * cc;
+        if constexpr (EPI == E16_STORE_BNRED) {
+            // per-thread BatchNorm coefficients of its 8 columns (layer below), then the two batch sums
+            float mean8[8], istd8[8], t1[8], t2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float sc, sh;
+                mean8[e] = 0.f; istd8[e] = 0.f; t1[e] = 0.f; t2[e] = 0.f;
+                if (col8 + e < g.N) bn_column(g.bnC, col8 + e, mean8[e], istd8[e], sc, sh);
+            }
+            // all Hbelow loads of the thread in flight before the first use
+            uint4 hv[BM / RPP], dv[BM / RPP];
+#pragma unroll
+            for (int p = 0; p < BM / RPP; ++p) {
+                const int rl = r0 + RPP * p, row = m0 + rl;
+                hv[p] = make_uint4(0, 0, 0, 0);
+                if (row < g.M && col8 < g.N) hv[p] = *reinterpret_cast<const uint4*>(g.Hbelow + (int64_t)row * g.ldh + col8);
+                dv[p] = *reinterpret_cast<const uint4*>(ct + rl * CP + 8 * cc);
+            }
+#pragma unroll
+            for (int p = 0; p < BM / RPP; ++p) {
+                const int rl = r0 + RPP * p, row = m0 + rl;
+                if (row < g.M && col8 < g.N) {
+                    *reinterpret_cast<uint4*>(g.C16 + (int64_t)row * g.ldc16 + col8) = dv[p];
+                    if (row < g.m_real) {
+                        const uint32_t dw[4] = {dv[p].x, dv[p].y, dv[p].z, dv[p].w};
+                        const uint32_t hw[4] = {hv[p].x, hv[p].y, hv[p].z, hv[p].w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float d = __uint_as_float((e & 1) ? (dw[e >> 1] & 0xFFFF0000u) : (dw[e >> 1] << 16));
+                            const float hh = __uint_as_float((e & 1) ? (hw[e >> 1] & 0xFFFF0000u) : (hw[e >> 1] << 16));
+                            t1[e] += d;
+                            t2[e] += d * ((hh - mean8[e]) * istd8[e]);
+                        }
+                    }
+                }
+            }
+            // combine the RPP row groups that share a chunk: red[2][RPP][BN]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(0 * RPP + r0) * BN + 8 * cc + e] = t1[e];
+                red[(1 * RPP + r0) * BN + 8 * cc + e] = t2[e];
+            }
+            __syncthreads();
+            for (int t = tid; t < 2 * BN; t += NT) {
+                const int stat = t / BN, cb = t % BN;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < RPP; ++w) s += red[(stat * RPP + w) * BN + cb];
+                if (n0 + cb < g.N) atomicAdd(&g.bstat_out[(int64_t)stat * g.N + n0 + cb], (double)s);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < BM / RPP; ++p) {
+                const int rl = r0 + RPP * p, row = m0 + rl;
+                if (row < g.M && col8 < g.N)
+                    *reinterpret_cast<uint4*>(g.C16 + (int64_t)row * g.ldc16 + col8) =
+                        *reinterpret_cast<const uint4*>(ct + rl * CP + 8 * cc);
+            }
+            if constexpr (EPI == E16_HIDDEN_TRAIN) {
+                for (int t = tid; t < 2 * BN; t += NT) {
+                    const int stat = t / BN, cb = t % BN;
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) s += red[(stat * WM + w) * BN + cb];
+                    if (n0 + cb < g.N) atomicAdd(&g.fstat_out[(int64_t)stat * g.N + n0 + cb], (double)s);
+                }
+            }
+        }
+    }
+}
+
+// dynamic LDS bytes of an instantiation: the operand buffers, or the output image + reduction scratch if larger
+template <int BM, int BN, int WM, int WN, int EPI>
+constexpr size_t gemm16_smem_bytes() {
+    size_t ops = 2 * (size_t)(BM + BN) * 128;
+    if (EPI == E16_SPLITK || EPI == E16_BIAS || EPI == E16_LATENT_MASK) return ops;
+    const size_t img = (size_t)BM * (BN + 8) * 2;
+    const size_t nt = (size_t)WM * WN * 64, rpp = nt / (BN / 8);
+    const size_t red = EPI == E16_STORE_BNRED ? 2 * rpp * BN * 4 : 2 * (size_t)WM * BN * 4;
+    return ops > img + red ? ops : img + red;
+}
+
+}  // namespace vh

@@ -15,7 +15,9 @@
 
 #include <hip/hip_ext.h>
 #include "gemm.hpp"
+#include "gemm_bf16.hpp"
 #include "vae_kernels.hpp"
+#include "vae_kernels16.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -41,6 +43,7 @@ struct Tensor {
     size_t off = 0;              // offset in the flat buffers (optimised tensors) or in bnbuf
     size_t slot = 0;             // allocated elements (multiple of 1024)
     bool optimised = true;
+    bool matrix = false;         // weight matrix [rows][cols] (vectors are [1][cols])
     // gradient slabs for the current batch size
     float* slab = nullptr;
     int nslab = 0;
@@ -61,6 +64,9 @@ struct Hidden {
     DevBuf<float> mean, invstd, scale, shift;
     DevBuf<uint8_t> mask;               // injected dropout keep-mask (parity mode)
     long long batches_tracked = 0;
+    // bf16-storage step (vae_step16.hpp): activations / gradients row-major and transposed, BatchNorm-folded weights
+    DevBuf<bf16_t> H16, H16T, DA16, DZ16, DZ16T, Wf16;
+    DevBuf<float> biasf;
 };
 
 constexpr size_t kMaxDynLds = 120 * 1024;
@@ -252,6 +258,15 @@ struct vh_vae {
     bool use_graph = true;
     bool warmed_up = false;   // one eager step has run (kernel attributes set, workspaces touched)
 
+    // bf16-storage step (configs C2-C4; vae_step16.hpp)
+    DevBuf<bf16_t> W16, W16T, zeros16;       // bf16 shadows of the flat parameter buffer (plain / transposed matrices)
+    DevBuf<bf16_t> Xb16, Xb16T, Z16, Z16T, dR16, dR16T, dMU16, dMU16T, Wf16_mu, Wf16_out;
+    DevBuf<float> biasf_mu, biasf_out;
+    double* dbias_mu = nullptr;              // fp64 column sums of dMU / dR (inside statbuf)
+    double* dbias_out = nullptr;
+    DevBuf<Opt16Tensor> opt16_tab, opt16_tab_flat;
+    int opt16_n = 0, opt16_blocks = 0;
+
     // data parallelism (one process per GPU; gradients all-reduced over RCCL on `stream`)
     vh_comm* comm = nullptr;
     DevBuf<float> G, gwsum;          // flat gradient buffer; per-batch global weight sums
@@ -288,12 +303,13 @@ struct vh_vae {
         if (stream) (void)hipStreamDestroy(stream);
     }
 
-    int add_tensor(const std::string& name, int rows, int cols, bool optimised) {
+    int add_tensor(const std::string& name, int rows, int cols, bool optimised, bool matrix = false) {
         Tensor t;
         t.name = name;
         t.rows = rows;
         t.cols = cols;
-        t.rows_p = rows == 1 ? 1 : (int)round_up(rows, kColPad);
+        t.rows_p = matrix ? (int)round_up(rows, kColPad) : 1;   // a 1-row weight matrix is still padded to 32 rows
+        t.matrix = matrix;
         t.cols_p = (int)round_up(cols, kColPad);
         t.optimised = optimised;
         t.slot = (size_t)round_up(t.padded(), 1024);
@@ -307,6 +323,16 @@ struct vh_vae {
 };
 
 namespace {
+
+namespace step16 {   // bf16-storage step, defined in vae_step16.hpp (included below, after the shared helpers)
+int dw_splits16(int M, int N, int K);
+void prepare_batch16(vh_vae* h);
+void build_opt16_table(vh_vae* h);
+void refresh_shadows(vh_vae* h, int only);
+void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected, bool add_noise);
+void train_step16(vh_vae* h, const int64_t* dev_idx, bool eps_injected, bool masks_injected);
+void encode16(vh_vae* h, float* latent);
+}  // namespace step16
 
 // ---- host <-> padded device layout ---------------------------------------------------------------
 void upload_tensor(vh_vae* h, int ti, const float* data) {
@@ -407,6 +433,7 @@ void prepare_batch(vh_vae* h, int bs) {
     {   // fp64 accumulators of every hidden layer, contiguous so that one memset per step clears them
         size_t tot = 0;
         for (auto& hl : h->hidden) tot += (size_t)5 * hl.nout_p;
+        tot += (size_t)h->L_p + h->D_p;   // bf16 step: bias gradients of mu / output layer
         h->statbuf.ensure(tot);
         size_t off = 0;
         for (auto& hl : h->hidden) {
@@ -415,6 +442,8 @@ void prepare_batch(vh_vae* h, int bs) {
             hl.dbias = hl.bstat + (size_t)2 * hl.nout_p;
             off += (size_t)5 * hl.nout_p;
         }
+        h->dbias_mu = h->statbuf.p + off;
+        h->dbias_out = h->dbias_mu + h->L_p;
     }
     // gradient slabs: weights get split-K slabs, biases row-block partials, BN affine a single slab
     size_t total = 0;
@@ -427,7 +456,8 @@ void prepare_batch(vh_vae* h, int bs) {
     };
     for (auto& hl : h->hidden) {
         const int tile = dw_tile(hl.nout_p, hl.nin_p);
-        plan(hl.tW, dw_splits(hl.nout_p, hl.nin_p, bs_p, tile), (int64_t)hl.nout_p * hl.nin_p);
+        plan(hl.tW, h->bf16 ? step16::dw_splits16(hl.nout_p, hl.nin_p, bs_p) : dw_splits(hl.nout_p, hl.nin_p, bs_p, tile),
+             (int64_t)hl.nout_p * hl.nin_p);
         // bias / gamma / beta gradients are the fp64 accumulators filled by the GEMM loaders / epilogues
         h->tensors[hl.tb].dsrc = hl.dbias;
         h->tensors[hl.tG].dsrc = hl.bstat + hl.nout_p;   // sum dA * xhat
@@ -436,11 +466,21 @@ void prepare_batch(vh_vae* h, int bs) {
     }
     {
         const int hlast = h->hidden[h->nl - 1].nout_p;
-        plan(h->tWmu, dw_splits(h->L_p, hlast, bs_p, dw_tile(h->L_p, hlast)), (int64_t)h->L_p * hlast);
-        plan(h->tbmu, nrb, h->L_p);
+        plan(h->tWmu, h->bf16 ? step16::dw_splits16(h->L_p, hlast, bs_p) : dw_splits(h->L_p, hlast, bs_p, dw_tile(h->L_p, hlast)),
+             (int64_t)h->L_p * hlast);
         const int hdec = h->hidden[2 * h->nl - 1].nout_p;
-        plan(h->tWo, dw_splits(h->D_p, hdec, bs_p, dw_tile(h->D_p, hdec)), (int64_t)h->D_p * hdec);
-        plan(h->tbo, nrb, h->D_p);
+        plan(h->tWo, h->bf16 ? step16::dw_splits16(h->D_p, hdec, bs_p) : dw_splits(h->D_p, hdec, bs_p, dw_tile(h->D_p, hdec)),
+             (int64_t)h->D_p * hdec);
+        if (h->bf16) {   // bf16 step: fp64 accumulators filled by the transposing kernels
+            h->tensors[h->tbmu].dsrc = h->dbias_mu;
+            h->tensors[h->tbo].dsrc = h->dbias_out;
+            for (int ti : {h->tbmu, h->tbo}) { h->tensors[ti].nslab = 0; h->tensors[ti].stride = 0; h->tensors[ti].slab = nullptr; }
+        } else {
+            h->tensors[h->tbmu].dsrc = nullptr;
+            h->tensors[h->tbo].dsrc = nullptr;
+            plan(h->tbmu, nrb, h->L_p);
+            plan(h->tbo, nrb, h->D_p);
+        }
     }
     h->slabs.ensure(total);
     OptTable tab;
@@ -482,6 +522,10 @@ void prepare_batch(vh_vae* h, int bs) {
     }
     h->opt_blocks = nblk;
     h->opt_part.ensure((size_t)h->opt_blocks * 2);
+    if (h->bf16) {
+        step16::prepare_batch16(h);
+        step16::build_opt16_table(h);
+    }
     VH_HIP(hipMemset(h->statbuf.p, 0, h->statbuf.bytes()));
     h->stat_clean = true;
 }
@@ -918,9 +962,12 @@ void gather_rows(vh_vae* h, const int64_t* dev_idx) {
     VH_HIP(hipGetLastError());
 }
 
+#include "vae_step16.hpp"
+
 // One optimisation step on the batch `state->batch` of the row list dev_idx.  Every launch argument
 // is identical from step to step, so the same sequence can be captured once and replayed.
 void train_step_device(vh_vae* h, const int64_t* dev_idx, bool eps_injected, bool masks_injected) {
+    if (h->bf16) { step16::train_step16(h, dev_idx, eps_injected, masks_injected); return; }
     gather_rows(h, dev_idx);
     forward(h, true, eps_injected, masks_injected, true);
     loss_and_seed(h);
@@ -1072,7 +1119,7 @@ int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
             hl.nin = nin; hl.nout = nout;
             hl.nin_p = (int)round_up(nin, kColPad);
             hl.nout_p = (int)round_up(nout, kColPad);
-            hl.tW = h->add_tensor(lin + ".weight", nout, nin, true);
+            hl.tW = h->add_tensor(lin + ".weight", nout, nin, true, true);
             hl.tb = h->add_tensor(lin + ".bias", 1, nout, true);
             hl.tG = h->add_tensor(norm + ".weight", 1, nout, true);
             hl.tB = h->add_tensor(norm + ".bias", 1, nout, true);
@@ -1086,7 +1133,7 @@ int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
                         cfg->nhiddens[i]);
             nin = cfg->nhiddens[i];
         }
-        h->tWmu = h->add_tensor("mu.weight", h->L, nin, true);
+        h->tWmu = h->add_tensor("mu.weight", h->L, nin, true, true);
         h->tbmu = h->add_tensor("mu.bias", 1, h->L, true);
         nin = h->L;
         for (int i = 0; i < h->nl; ++i) {
@@ -1094,7 +1141,7 @@ int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
             make_hidden(h->nl + i, "decoderlayers." + std::to_string(i), "decodernorms." + std::to_string(i), nin, nout);
             nin = nout;
         }
-        h->tWo = h->add_tensor("outputlayer.weight", h->D, nin, true);
+        h->tWo = h->add_tensor("outputlayer.weight", h->D, nin, true, true);
         h->tbo = h->add_tensor("outputlayer.bias", 1, h->D, true);
 
         h->P.alloc(h->flat_elems); h->M1.alloc(h->flat_elems); h->M2.alloc(h->flat_elems); h->Sv.alloc(h->flat_elems);
@@ -1149,6 +1196,10 @@ int vh_vae_set_param(vh_vae* h, const char* name, const float* data, int64_t n) 
         VH_REQUIRE(n == h->tensors[ti].logical(), "parameter '%s' has %lld elements, got %lld", name,
                    (long long)h->tensors[ti].logical(), (long long)n);
         upload_tensor(h, ti, data);
+        if (h->bf16) {
+            step16::refresh_shadows(h, ti);
+            VH_HIP(hipStreamSynchronize(h->stream));
+        }
     });
 }
 
@@ -1179,10 +1230,24 @@ int vh_vae_get_grad(vh_vae* h, const char* name, float* data, int64_t n) {
         const Tensor& t = h->tensors[ti];
         VH_REQUIRE(t.optimised, "'%s' is a buffer, not a parameter", name);
         VH_REQUIRE(t.slab != nullptr || t.dsrc != nullptr, "no training step has run yet");
+        VH_REQUIRE(h->bs > 0, "no training step has run yet");
         VH_REQUIRE(n == t.logical(), "parameter '%s' has %lld elements, got %lld", name, (long long)t.logical(),
                    (long long)n);
         StepState st;
         read_state(h, &st);
+        if (h->bf16) {
+            // the complete gradient (slab sums + BatchNorm completion) as the optimiser forms it, through the flat buffer
+            hipLaunchKernelGGL(vae_grad16_kernel, dim3(h->opt16_blocks), dim3(256), 0, h->stream, h->opt16_tab.p, h->opt16_n,
+                               h->bs, h->G.p);
+            VH_HIP(hipGetLastError());
+            std::vector<float> buf((size_t)t.padded());
+            VH_HIP(hipMemcpyAsync(buf.data(), h->G.p + t.off, sizeof(float) * buf.size(), hipMemcpyDeviceToHost, h->stream));
+            VH_HIP(hipStreamSynchronize(h->stream));
+            for (int r = 0; r < t.rows; ++r)
+                for (int c = 0; c < t.cols; ++c)
+                    data[(size_t)r * t.cols + c] = buf[(size_t)r * t.cols_p + c] * (float)st.wsum;
+            return;
+        }
         if (t.dsrc) {   // bias / gamma / beta of a hidden layer: fp64 accumulator
             std::vector<double> acc((size_t)t.padded());
             VH_HIP(hipMemcpy(acc.data(), t.dsrc, sizeof(double) * acc.size(), hipMemcpyDeviceToHost));
@@ -1207,12 +1272,23 @@ int vh_vae_get_hidden(vh_vae* h, int layer, float* out, int64_t n) {
         VH_REQUIRE(h != nullptr && out != nullptr, "NULL argument");
         VH_REQUIRE(layer >= 0 && layer < 2 * h->nl, "layer %d out of range", layer);
         const Hidden& hl = h->hidden[layer];
-        VH_REQUIRE(h->bs > 0 && hl.H.p != nullptr, "no training step has run yet");
+        VH_REQUIRE(h->bs > 0 && (hl.H.p != nullptr || hl.H16.p != nullptr), "no training step has run yet");
         VH_REQUIRE(n == (int64_t)h->bs * hl.nout, "layer %d holds %d x %d activations, got %lld", layer, h->bs, hl.nout,
                    (long long)n);
         std::vector<float> buf((size_t)h->bs * hl.nout_p);
-        VH_HIP(hipMemcpyAsync(buf.data(), hl.H.p, sizeof(float) * buf.size(), hipMemcpyDeviceToHost, h->stream));
-        VH_HIP(hipStreamSynchronize(h->stream));
+        if (h->bf16) {
+            VH_REQUIRE(hl.H16.p != nullptr, "no training step has run yet");
+            std::vector<bf16_t> b16(buf.size());
+            VH_HIP(hipMemcpyAsync(b16.data(), hl.H16.p, sizeof(bf16_t) * b16.size(), hipMemcpyDeviceToHost, h->stream));
+            VH_HIP(hipStreamSynchronize(h->stream));
+            for (size_t i = 0; i < buf.size(); ++i) {
+                const uint32_t u = (uint32_t)b16[i] << 16;
+                memcpy(&buf[i], &u, 4);
+            }
+        } else {
+            VH_HIP(hipMemcpyAsync(buf.data(), hl.H.p, sizeof(float) * buf.size(), hipMemcpyDeviceToHost, h->stream));
+            VH_HIP(hipStreamSynchronize(h->stream));
+        }
         for (int r = 0; r < h->bs; ++r)
             memcpy(out + (size_t)r * hl.nout, buf.data() + (size_t)r * hl.nout_p, sizeof(float) * hl.nout);
     });
@@ -1505,7 +1581,15 @@ int vh_vae_forward(vh_vae* h, const float* depths, const float* tnf, const float
         VH_HIP(hipStreamSynchronize(h->stream));
         const bool inj_masks = training && masks != nullptr && h->cfg.dropout > 0;
         if (inj_masks) upload_masks(h, masks, (int)batch);
-        forward(h, training != 0, eps != nullptr, inj_masks, true);
+        if (h->bf16) {
+            const int64_t n4 = (int64_t)h->bs_p * h->D_p / 4;
+            hipLaunchKernelGGL(vae_cast16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n4, 256), 4096)), dim3(256), 0,
+                               h->stream, h->Xb.p, h->Xb16.p, n4);
+            VH_HIP(hipGetLastError());
+            step16::forward16(h, training != 0, eps != nullptr, inj_masks, true);
+        } else {
+            forward(h, training != 0, eps != nullptr, inj_masks, true);
+        }
         if (training) { join_side(h); count_batches(h, 1); }
         hipLaunchKernelGGL(vae_advance_step_kernel, dim3(1), dim3(1), 0, h->stream, h->state.p);
         VH_HIP(hipGetLastError());
@@ -1537,6 +1621,7 @@ int vh_vae_encode(vh_vae* h, float* latent) {
     return guarded([&] {
         VH_REQUIRE(h != nullptr && latent != nullptr, "NULL argument");
         VH_REQUIRE(h->n > 0, "no dataset: call vh_vae_set_dataset first");
+        if (h->bf16) { step16::encode16(h, latent); return; }
         hipStream_t s = h->stream;
         const int64_t chunk = 16384;
         int maxw = 0;
@@ -1597,7 +1682,21 @@ int vh_vae_opt_state(vh_vae* h, double* d, double* numerator_weighted, int64_t* 
 int vh_vae_set_precision(vh_vae* h, int bf16_operands) {
     return guarded([&] {
         VH_REQUIRE(h != nullptr, "NULL handle");
-        h->bf16 = bf16_operands != 0;
+        const bool on = bf16_operands != 0;
+        if (on == h->bf16) return;
+        VH_HIP(hipStreamSynchronize(h->stream));
+        h->bf16 = on;
+        h->bs = 0;   // the per-batch plan (gradient slabs, optimiser table, workspaces) depends on the mode
+        if (on) {
+            h->W16.ensure(h->flat_elems);
+            h->W16T.ensure(h->flat_elems);
+            h->zeros16.ensure(128);
+            VH_HIP(hipMemsetAsync(h->W16.p, 0, h->W16.bytes(), h->stream));
+            VH_HIP(hipMemsetAsync(h->W16T.p, 0, h->W16T.bytes(), h->stream));
+            VH_HIP(hipMemsetAsync(h->zeros16.p, 0, h->zeros16.bytes(), h->stream));
+            step16::refresh_shadows(h, -1);
+            VH_HIP(hipStreamSynchronize(h->stream));
+        }
     });
 }
 
@@ -1679,6 +1778,91 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
             float acc = 0.f;
             for (int sp = 0; sp < nsplit; ++sp) acc += hc[(size_t)sp * M * N + i];
             C[i] = acc;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(s);
+    });
+}
+
+int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, float* C, float* CT, double* stats, int M,
+                    int N, int K, int splits, int reps, float* ms) {
+    return guarded([&] {
+        VH_REQUIRE(A && B && C, "NULL argument");
+        VH_REQUIRE(epi == E16_SPLITK || epi == E16_BIAS || epi == E16_HIDDEN_TRAIN, "epi in {0 split-K, 1 bias, 3 hidden}");
+        VH_REQUIRE(M >= 1 && N >= 1 && K >= 8 && K % 8 == 0 && N % 8 == 0 && M % 8 == 0, "need M, N, K multiples of 8");
+        VH_REQUIRE(splits >= 1 && reps >= 1, "bad split / repetition count");
+        VH_REQUIRE(epi == E16_SPLITK || splits == 1, "only the split-K epilogue takes splits > 1");
+        VH_REQUIRE(epi == E16_SPLITK || bias != nullptr, "bias is NULL");
+        auto to_bf16 = [](const float* src, size_t n) {
+            std::vector<bf16_t> out(n);
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t u;
+                memcpy(&u, &src[i], 4);
+                u += 0x7FFFu + ((u >> 16) & 1u);
+                out[i] = (bf16_t)(u >> 16);
+            }
+            return out;
+        };
+        hipStream_t s;
+        VH_HIP(hipStreamCreate(&s));
+        DevBuf<bf16_t> dA, dB, dC16, dC16T, dz;
+        DevBuf<float> dC32, dbias;
+        DevBuf<double> dstat;
+        const std::vector<bf16_t> hA = to_bf16(A, (size_t)M * K), hB = to_bf16(B, (size_t)N * K);
+        dA.alloc(hA.size()); dB.alloc(hB.size()); dz.alloc(128);
+        VH_HIP(hipMemcpy(dA.p, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+        VH_HIP(hipMemcpy(dB.p, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+        VH_HIP(hipMemset(dz.p, 0, dz.bytes()));
+        const int k_per = splits == 1 ? K : (int)round_up(ceil_div(K, splits), 64);
+        const int nsplit = (int)ceil_div(K, k_per);
+        dC32.alloc((size_t)nsplit * M * N);
+        dC16.alloc((size_t)M * N); dC16T.alloc((size_t)M * N);
+        dstat.alloc((size_t)2 * N);
+        if (bias) { dbias.alloc(N); VH_HIP(hipMemcpy(dbias.p, bias, sizeof(float) * N, hipMemcpyHostToDevice)); }
+        Gemm16Args g;
+        memset(&g, 0, sizeof(g));
+        g.A = dA.p; g.lda = K; g.B = dB.p; g.ldb = K; g.M = M; g.N = N; g.K = K;
+        g.k_per_split = k_per; g.slab_stride = (int64_t)M * N; g.zeros = dz.p;
+        g.C32 = dC32.p; g.ldc32 = N; g.C16 = dC16.p; g.ldc16 = N; g.C16T = dC16T.p; g.ldc16t = M;
+        g.bias = dbias.p; g.m_real = M; g.fstat_out = dstat.p; g.drop_scale = 1.0f; g.xcd_remap = 1;
+        auto run = [&] {
+            if (epi == E16_SPLITK) step16::gemm16<E16_SPLITK>(s, g, nsplit);
+            else if (epi == E16_BIAS) step16::gemm16<E16_BIAS>(s, g, 1);
+            else step16::gemm16<E16_HIDDEN_TRAIN>(s, g, 1);
+        };
+        run();   // warm-up (sets the LDS attribute)
+        VH_HIP(hipMemsetAsync(dstat.p, 0, dstat.bytes(), s));
+        hipEvent_t e0, e1;
+        VH_HIP(hipEventCreate(&e0));
+        VH_HIP(hipEventCreate(&e1));
+        VH_HIP(hipEventRecord(e0, s));
+        for (int r = 0; r < reps; ++r) run();
+        VH_HIP(hipEventRecord(e1, s));
+        VH_HIP(hipStreamSynchronize(s));
+        float t = 0.f;
+        VH_HIP(hipEventElapsedTime(&t, e0, e1));
+        if (ms) *ms = t / (float)reps;
+        if (epi == E16_HIDDEN_TRAIN) {
+            std::vector<bf16_t> hc((size_t)M * N), hct((size_t)M * N);
+            VH_HIP(hipMemcpy(hc.data(), dC16.p, hc.size() * 2, hipMemcpyDeviceToHost));
+            VH_HIP(hipMemcpy(hct.data(), dC16T.p, hct.size() * 2, hipMemcpyDeviceToHost));
+            auto tof = [](bf16_t b) { const uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+            for (size_t i = 0; i < hc.size(); ++i) C[i] = tof(hc[i]);
+            if (CT) for (size_t i = 0; i < hct.size(); ++i) CT[i] = tof(hct[i]);
+            if (stats) {
+                std::vector<double> hs((size_t)2 * N);
+                VH_HIP(hipMemcpy(hs.data(), dstat.p, hs.size() * 8, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < hs.size(); ++i) stats[i] = hs[i] / (double)reps;   // accumulated once per timed launch
+            }
+        } else {
+            std::vector<float> hc((size_t)nsplit * M * N);
+            VH_HIP(hipMemcpy(hc.data(), dC32.p, sizeof(float) * hc.size(), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < (size_t)M * N; ++i) {
+                float acc = 0.f;
+                for (int sp = 0; sp < nsplit; ++sp) acc += hc[(size_t)sp * M * N + i];
+                C[i] = acc;
+            }
         }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);

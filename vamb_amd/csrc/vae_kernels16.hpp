@@ -1,0 +1,597 @@
+// vae_kernels16.hpp -- the non-GEMM kernels of the bf16-storage training step (BASELINE configs C2-C4), gfx950.
+//
+// In this mode every activation / gradient tensor that feeds a contraction lives in HBM as bfloat16, row-major
+// [bs_p][n_p], plus -- where the weight-gradient GEMM contracts over the batch -- a transposed copy [n_p][bs_p],
+// so that all GEMMs are K-contiguous "NT" products staged by LDS-DMA (gemm_bf16.hpp).  Master parameters, the
+// optimiser moments, BatchNorm statistics (fp64 sums), the loss and the reconstruction stay fp32.
+//
+// BatchNorm between two Linear layers is folded into the consumer's weights once per step:
+//     BN(h) W^T + b = h (W diag(s))^T + (b + W t),   s = gamma / sqrt(var + eps),  t = beta - mean s
+// (vae_fold_bn_kernel), so the raw activations stream into the next GEMM untouched; the weight gradient of such
+// a layer is recovered from the raw product G = dZ^T h as dW = G diag(s) + dbias t^T inside the optimiser kernel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "gemm_bf16.hpp"
+#include "vae_kernels.hpp"
+
+namespace vh {
+
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+
+// ---- batch assembly: Xb (fp32, the loss targets), Xb16 (the first GEMM's operand), Wb ----------------------------
+// blockDim (64, 4): one wavefront per row, float4 per lane.
+__global__ void vae_gather16_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ w_all,
+                                    const int64_t* __restrict__ idx, const ShuffleSpec shuffle,
+                                    const long long* __restrict__ batch_ptr, int bs, int bs_p,
+                                    float* __restrict__ Xb, bf16_t* __restrict__ Xb16, float* __restrict__ Wb) {
+    const int r = blockIdx.x * 4 + threadIdx.y;
+    if (r >= bs_p) return;
+    const bool real = r < bs;
+    const int64_t first = batch_ptr ? (int64_t)(*batch_ptr) * bs : 0;
+    int64_t src = 0;
+    if (real) src = idx ? idx[first + r] : (int64_t)shuffle_index(shuffle, (unsigned long long)(first + r));
+    const float4* s = reinterpret_cast<const float4*>(X + src * ldx);
+    float4* d = reinterpret_cast<float4*>(Xb + (int64_t)r * ldx);
+    uint2* d16 = reinterpret_cast<uint2*>(Xb16 + (int64_t)r * ldx);
+    const int dq = (int)(ldx / 4);
+    for (int c = threadIdx.x; c < dq; c += 64) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (real) v = s[c];
+        d[c] = v;
+        d16[c] = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    }
+    if (threadIdx.x == 0) Wb[r] = real ? w_all[src] : 0.f;
+}
+
+// rows of an fp32 matrix -> bf16 (encode pass: the resident feature matrix is fp32)
+__global__ void vae_cast16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        reinterpret_cast<uint2*>(out)[i] = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    }
+}
+
+// ---- bf16 transpose: out[c][r] = in[r][c] for r < R, c < C (both multiples of 64 after padding: the caller passes
+// padded extents).  64 x 64 tiles through LDS, 16-byte accesses on both sides.  Optional fp64 column sums of `in`
+// over the rows r < r_real (bias gradients: sum over the batch), one atomic per column and tile.
+constexpr int kTrTile = 64;
+__global__ __launch_bounds__(256) void vae_transpose16_kernel(const bf16_t* __restrict__ in, int64_t ld_in, int R, int C,
+                                                              bf16_t* __restrict__ out, int64_t ld_out,
+                                                              double* __restrict__ colsum, int r_real) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[kTrTile][kTrTile + 8];
+    __shared__ float csum[4][kTrTile];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.y * kTrTile, c0 = blockIdx.x * kTrTile;
+    // load: 8 threads per row (16 B each), 32 rows per pass
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = (tid >> 3) + 32 * p, c8 = (tid & 7) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + r < R && c0 + c8 < C) v = *reinterpret_cast<const uint4*>(in + (int64_t)(r0 + r) * ld_in + c0 + c8);
+        *reinterpret_cast<uint4*>(&tile[r][c8]) = v;
+    }
+    __syncthreads();
+    // store: chunk = (column c, row group rg of 8 rows); lanes of a wave take consecutive columns
+    const int wave = tid >> 6;
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int id = tid + 256 * p;
+        const int c = id & 63, rg = id >> 6;
+        bf16_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = tile[rg * 8 + k][c];
+        if (colsum) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (r0 + rg * 8 + k < r_real) s += bf2f(e[k]);
+        }
+        if (c0 + c < C && r0 + rg * 8 < R) {
+            uint4 v;
+            v.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+            v.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+            v.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
+            v.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
+            *reinterpret_cast<uint4*>(out + (int64_t)(c0 + c) * ld_out + r0 + rg * 8) = v;
+        }
+    }
+    if (colsum) {   // thread (wave, lane) summed column `lane` over row groups {wave, wave + 4}: combine the 4 waves
+        csum[wave][tid & 63] = s;
+        __syncthreads();
+        if (tid < kTrTile && c0 + tid < C) {
+            const float t = (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]);
+            atomicAdd(&colsum[c0 + tid], (double)t);
+        }
+    }
+}
+
+// ---- BatchNorm folded into the consumer's weights ------------------------------------------------------------------
+// W [n_rows][ldw] fp32 (master), stats of the producing layer over its K columns -> W16 = bf16(W diag(s)) [n_rows][ldw],
+// bias_out[n] = bias[n] + sum_k W[n][k] t_k.  One wavefront per weight row; s, t are rebuilt per workgroup.
+// from_running != 0: eval mode, s / t from the running statistics (scale_in / shift_in precomputed by
+// vae_bn_eval_coeff_kernel).
+__global__ __launch_bounds__(256) void vae_fold_bn_kernel(const float* __restrict__ W, int64_t ldw, int n_rows, int K,
+                                                          const float* __restrict__ bias, const BnSrc bn,
+                                                          const float* __restrict__ scale_in,
+                                                          const float* __restrict__ shift_in,
+                                                          bf16_t* __restrict__ W16, float* __restrict__ bias_out) {
+    extern __shared__ __attribute__((aligned(16))) float fold_st[];   // [2][K]
+    float* s_s = fold_st;
+    float* t_s = fold_st + K;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float sc, sh;
+        if (scale_in) {
+            sc = scale_in[k];
+            sh = shift_in[k];
+        } else {
+            float mean, istd;
+            bn_column(bn, k, mean, istd, sc, sh);
+        }
+        s_s[k] = sc;
+        t_s[k] = sh;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= n_rows) return;
+    const float* w = W + (int64_t)n * ldw;
+    bf16_t* o = W16 + (int64_t)n * ldw;
+    float dot = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(w + k);
+        const float4 s4 = *reinterpret_cast<const float4*>(s_s + k);
+        const float4 t4 = *reinterpret_cast<const float4*>(t_s + k);
+        dot += v.x * t4.x + v.y * t4.y + v.z * t4.z + v.w * t4.w;
+        *reinterpret_cast<uint2*>(o + k) = make_uint2(pack_bf2(v.x * s4.x, v.y * s4.y), pack_bf2(v.z * s4.z, v.w * s4.w));
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) bias_out[n] = bias[n] + dot;
+}
+
+// ---- bf16 shadows of the weights (init / set_param; during training the optimiser writes them itself) --------------
+// W16[r][c] = bf16(P[r][c]);  W16T[c][r] = the same, for r < rows_p, c < cols_p.
+__global__ void vae_shadow_kernel(const float* __restrict__ P, int rows_p, int cols_p, bf16_t* __restrict__ W16,
+                                  bf16_t* __restrict__ W16T) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows_p * cols_p) return;
+    const int r = (int)(i / cols_p), c = (int)(i % cols_p);
+    const bf16_t b = f2bf(P[i]);
+    W16[i] = b;
+    if (W16T) W16T[(int64_t)c * rows_p + r] = b;
+}
+
+// ---- reparameterisation: MU (fp32) = slabs + bias; Z16 = bf16(MU + eps) on real rows / columns ---------------------
+__global__ void vae_reparam16_kernel(const float* __restrict__ slabs, int nslab, int64_t stride,
+                                     const float* __restrict__ bias, const float* __restrict__ E, uint64_t key,
+                                     const unsigned long long* __restrict__ step_ptr, int noise,
+                                     float* __restrict__ MU, bf16_t* __restrict__ Z16, int bs, int L, int L_p, int bs_p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)bs_p * L_p) return;
+    const int r = (int)(i / L_p), c = (int)(i % L_p);
+    float m = bias[c];
+    {
+        constexpr int kMaxSlabs = 8;
+        float v[kMaxSlabs];
+#pragma unroll
+        for (int s = 0; s < kMaxSlabs; ++s) v[s] = s < nslab ? slabs[(int64_t)s * stride + i] : 0.f;
+#pragma unroll
+        for (int s = 0; s < kMaxSlabs; ++s)
+            if (s < nslab) m += v[s];
+        for (int s = kMaxSlabs; s < nslab; ++s) m += slabs[(int64_t)s * stride + i];
+    }
+    MU[i] = m;
+    float z = 0.f;
+    if (r < bs && c < L) {
+        float e = 0.f;
+        if (E) e = E[i];
+        else if (noise) e = hash_randn(step_key(key, step_ptr), (uint64_t)i);
+        z = m + e;
+    }
+    Z16[i] = f2bf(z);
+}
+
+// ---- loss + backward seed, bf16 gradient of the reconstruction ------------------------------------------------------
+// Same arithmetic as vae_loss_kernel (encode.py:316-357); dR leaves as bf16 (the operand of the two GEMMs that
+// consume it), the KLD part of dL/dmu stays fp32.
+struct Loss16Args {
+    const float* R;
+    const float* X;
+    int64_t ld;
+    const float* MU;
+    int64_t ldl;
+    float inv_b2;
+    int bs, bs_p, S, L;
+    float ce_w, ab_w, sse_w, kld_w;
+    bf16_t* dR16;
+    float* dMUk;
+    float* part;
+};
+
+__global__ __launch_bounds__(256) void vae_loss16_kernel(const Loss16Args a) {
+    __shared__ float red[4][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    float ab_t = 0.f, ce_t = 0.f, sse_t = 0.f, kld_t = 0.f;
+    if (row < a.bs_p) {
+        bf16_t* dr = a.dR16 + (int64_t)row * a.ld;
+        float* dm = a.dMUk + (int64_t)row * a.ldl;
+        if (row >= a.bs) {
+            for (int c = lane; c < a.ld; c += 64) dr[c] = 0;
+            for (int c = lane; c < a.ldl; c += 64) dm[c] = 0.f;
+        } else {
+            const float* r = a.R + (int64_t)row * a.ld;
+            const float* x = a.X + (int64_t)row * a.ld;
+            const float g = a.inv_b2;
+            const int S = a.S;
+            float mx = -3.0e38f;
+            for (int c = lane; c < S; c += 64) mx = fmaxf(mx, r[c]);
+            mx = wave_max(mx);
+            float se = 0.f;
+            for (int c = lane; c < S; c += 64) se += expf(r[c] - mx);
+            se = wave_sum(se);
+            const float inv = 1.0f / se;
+            float ce = 0.f, pdp = 0.f;
+            for (int c = lane; c < S; c += 64) {
+                const float p = expf(r[c] - mx) * inv;
+                const float q = p + 1e-9f;
+                ce -= logf(q) * x[c];
+                pdp += p * (-x[c] / q);
+            }
+            ce = wave_sum(ce);
+            pdp = wave_sum(pdp);
+            const float gce = g * a.ce_w;
+            for (int c = lane; c < S; c += 64) {
+                const float p = expf(r[c] - mx) * inv;
+                const float dp = -x[c] / (p + 1e-9f);
+                dr[c] = f2bf(gce * p * (dp - pdp));
+            }
+            float sse = 0.f;
+            const float gsse = g * a.sse_w * 2.0f;
+            for (int c = S + lane; c < S + 103; c += 64) {
+                const float diff = r[c] - x[c];
+                sse += diff * diff;
+                dr[c] = f2bf(gsse * diff);
+            }
+            sse = wave_sum(sse);
+            float ab = 0.f;
+            if (lane == 0) {
+                const int c = S + 103;
+                const float diff = r[c] - x[c];
+                ab = diff * diff;
+                dr[c] = f2bf(g * a.ab_w * 2.0f * diff);
+            }
+            ab = wave_sum(ab);
+            for (int c = S + 104 + lane; c < a.ld; c += 64) dr[c] = 0;
+            const float* mu = a.MU + (int64_t)row * a.ldl;
+            float kld = 0.f;
+            const float gk = g * a.kld_w;
+            for (int c = lane; c < a.ldl; c += 64) {
+                const float m = c < a.L ? mu[c] : 0.f;
+                kld += m * m;
+                dm[c] = gk * m;
+            }
+            kld = 0.5f * wave_sum(kld);
+            ab_t = ab * a.ab_w;
+            ce_t = ce * a.ce_w;
+            sse_t = sse * a.sse_w;
+            kld_t = kld * a.kld_w;
+        }
+    }
+    if (lane == 0) { red[wave][0] = ab_t; red[wave][1] = ce_t; red[wave][2] = sse_t; red[wave][3] = kld_t; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int t = threadIdx.x;
+        a.part[(int64_t)blockIdx.x * 4 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    }
+}
+
+// ---- elementwise backward of one hidden layer, bf16 in / out ---------------------------------------------------------
+//   dZ = keep * slope(h) * drop_scale * istd*gamma * (dA - S1/B - xhat * S2/B)      (see vae_dz_kernel)
+// reads dA16, H16 [bs_p][n_p]; writes dZ16 [bs_p][n_p] and dZ16T [n_p][bs_p] (the A operand of the weight-gradient
+// GEMM) and accumulates the fp64 column sums of dZ (bias gradient).  A workgroup owns 64 rows x 128 columns.
+struct Dz16Args {
+    const bf16_t* DA;
+    const bf16_t* H;
+    bf16_t* DZ;
+    bf16_t* DZT;
+    int64_t ldt;       // leading dimension of DZT (= bs_p)
+    int n_p, bs, bs_p;
+    BnSrc bn;
+    const double* bstat;
+    float drop_scale;
+    const uint8_t* drop_mask;
+    int64_t ld_mask;
+    double* dbias;
+};
+constexpr int kDz16Cols = 128;
+constexpr int kDz16Rows = 64;
+
+__global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[kDz16Rows][kDz16Cols + 8];
+    __shared__ float red[16][kDz16Cols];
+    __shared__ float cf[3][kDz16Cols];
+    const int tid = threadIdx.x;
+    const int col0 = blockIdx.x * kDz16Cols, row0 = blockIdx.y * kDz16Rows;
+    if (tid < kDz16Cols) {
+        const int col = col0 + tid;
+        float ca = 0.f, ch = 0.f, c0 = 0.f;
+        if (col < a.n_p) {
+            float mean, istd, sc, sh;
+            bn_column(a.bn, col, mean, istd, sc, sh);
+            const double inv_bs = 1.0 / (double)a.bs;
+            const float c1 = (float)(a.bstat[col] * inv_bs);
+            const float c2 = (float)(a.bstat[a.n_p + col] * inv_bs);
+            ca = a.drop_scale * istd * a.bn.gamma[col];
+            ch = -ca * istd * c2;
+            c0 = -ca * c1 - ch * mean;
+        }
+        cf[0][tid] = ca; cf[1][tid] = ch; cf[2][tid] = c0;
+    }
+    __syncthreads();
+    const int c8 = (tid & 15) * 8;          // this thread's 8 columns inside the tile
+    const int rt = tid >> 4;                // row lane 0..15
+    const int col = col0 + c8;
+    const bool hashed_drop = (a.drop_scale != 1.0f) && (a.drop_mask == nullptr);
+    float ca[8], ch[8], c0[8], s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ca[e] = cf[0][c8 + e]; ch[e] = cf[1][c8 + e]; c0[e] = cf[2][c8 + e]; s[e] = 0.f; }
+    constexpr int PASS = kDz16Rows / 16;
+    uint4 da[PASS], hh[PASS];
+#pragma unroll
+    for (int p = 0; p < PASS; ++p) {
+        const int r = row0 + rt + 16 * p;
+        da[p] = make_uint4(0, 0, 0, 0);
+        hh[p] = da[p];
+        if (r < a.bs && col < a.n_p) {
+            const int64_t i = (int64_t)r * a.n_p + col;
+            da[p] = *reinterpret_cast<const uint4*>(a.DA + i);
+            hh[p] = *reinterpret_cast<const uint4*>(a.H + i);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PASS; ++p) {
+        const int rl = rt + 16 * p, r = row0 + rl;
+        const uint32_t dw[4] = {da[p].x, da[p].y, da[p].z, da[p].w};
+        const uint32_t hw[4] = {hh[p].x, hh[p].y, hh[p].z, hh[p].w};
+        uint32_t ow[4] = {0, 0, 0, 0};
+        if (r < a.bs && col < a.n_p) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (e & 1) ? bf_hi(dw[e >> 1]) : bf_lo(dw[e >> 1]);
+                const float h = (e & 1) ? bf_hi(hw[e >> 1]) : bf_lo(hw[e >> 1]);
+                bool keep = true;
+                if (hashed_drop) keep = h != 0.f;
+                else if (a.drop_mask) keep = a.drop_mask[(int64_t)r * a.ld_mask + col + e] != 0;
+                const float l = ca[e] * d + ch[e] * h + c0[e];
+                const float dz = keep ? l * (h > 0.f ? 1.0f : kLeakySlope) : 0.f;
+                const bf16_t b = f2bf(dz);
+                s[e] += bf2f(b);
+                ow[e >> 1] |= (uint32_t)b << (16 * (e & 1));
+            }
+        }
+        const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        *reinterpret_cast<uint4*>(&tile[rl][c8]) = o;
+        if (r < a.bs_p && col < a.n_p) *reinterpret_cast<uint4*>(a.DZ + (int64_t)r * a.n_p + col) = o;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rt][c8 + e] = s[e];
+    __syncthreads();
+    // transposed copy: chunk = (column c, 8 consecutive rows); lanes of a wave take consecutive columns
+#pragma unroll
+    for (int p = 0; p < (kDz16Cols * (kDz16Rows / 8)) / 256; ++p) {
+        const int id = tid + 256 * p;
+        const int c = id % kDz16Cols, rg = id / kDz16Cols;
+        bf16_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = tile[rg * 8 + k][c];
+        if (col0 + c < a.n_p && row0 + rg * 8 < a.bs_p) {
+            uint4 v;
+            v.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+            v.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+            v.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
+            v.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
+            *reinterpret_cast<uint4*>(a.DZT + (int64_t)(col0 + c) * a.ldt + row0 + rg * 8) = v;
+        }
+    }
+    if (tid < kDz16Cols) {
+        const int c = col0 + tid;
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][tid];
+        if (c < a.n_p) atomicAdd(&a.dbias[c], (double)t);
+    }
+}
+
+// latent: dMU16 = bf16((sum of the split-K slabs of dZlat) + KLD part) on the real rows, 0 on the padding
+__global__ void vae_latent_bwd16_kernel(const float* __restrict__ slabs, int nslab, int64_t stride,
+                                        const float* __restrict__ dMUk, bf16_t* __restrict__ dMU16, int L_p, int bs,
+                                        int bs_p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)bs_p * L_p) return;
+    const int r = (int)(i / L_p);
+    float t = 0.f;
+    if (r < bs) {
+        constexpr int kMaxSlabs = 8;
+        float v[kMaxSlabs];
+#pragma unroll
+        for (int s = 0; s < kMaxSlabs; ++s) v[s] = s < nslab ? slabs[(int64_t)s * stride + i] : 0.f;
+        t = dMUk[i];
+#pragma unroll
+        for (int s = 0; s < kMaxSlabs; ++s)
+            if (s < nslab) t += v[s];
+        for (int s = kMaxSlabs; s < nslab; ++s) t += slabs[(int64_t)s * stride + i];
+    }
+    dMU16[i] = f2bf(t);
+}
+
+// ---- D-Adapt-Adam for the bf16 step ------------------------------------------------------------------------------------
+// Same update as vae_dadapt_kernel.  Differences: a workgroup that belongs to a weight MATRIX covers a 32 x 32 tile of
+// it (instead of 1024 consecutive elements), so that besides P / M1 / M2 / S it can write the bf16 shadow W16 and --
+// through one LDS transpose -- the transposed shadow W16T that the input-gradient GEMMs contract against; and the
+// gradient of a weight that consumes BatchNorm-ed activations is completed here:  dW = G diag(s) + dbias t^T.
+struct Opt16Tensor {
+    const double* dsrc;   // fp64 accumulator gradient (vectors), or nullptr
+    const float* slab;    // split-K slabs (matrices)
+    int nslab;
+    int rows_p, cols_p;   // padded shape (vectors: rows_p == 1)
+    int64_t stride;
+    int64_t p_off;        // offset in the flat parameter / moment buffers
+    bf16_t* w16;          // [rows_p][cols_p] shadow (matrices) or nullptr
+    bf16_t* w16t;         // [cols_p][rows_p] shadow or nullptr
+    // BatchNorm of the layer that produced this weight's input (nullptr: the input is not normalised)
+    const double* bn_fstat;
+    const float* bn_gamma;
+    const float* bn_beta;
+    int bn_np;
+    const double* dbias;  // [rows_p] fp64 column sums of this layer's dZ (needed with bn_fstat)
+    int blk_start;        // first workgroup of the tensor
+};
+constexpr int kMaxOpt16 = 4 * 2 * 8 + 4;
+
+// gradient of 4 consecutive elements (tensor-local index `local` = row * cols_p + col): slab sum or fp64 accumulator,
+// completed for weights that consume BatchNorm-ed activations:  dW = G diag(s) + dbias t^T
+__device__ __forceinline__ float4 opt16_grad(const Opt16Tensor& td, int64_t local, int row, int col, int bs) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (td.dsrc) {
+        g.x = (float)td.dsrc[local + 0]; g.y = (float)td.dsrc[local + 1];
+        g.z = (float)td.dsrc[local + 2]; g.w = (float)td.dsrc[local + 3];
+        return g;
+    }
+    int s = 0;
+    for (; s + 8 <= td.nslab; s += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(td.slab + (int64_t)(s + q) * td.stride + local);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { g.x += v[q].x; g.y += v[q].y; g.z += v[q].z; g.w += v[q].w; }
+    }
+    for (; s < td.nslab; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(td.slab + (int64_t)s * td.stride + local);
+        g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+    }
+    if (td.bn_fstat) {
+        BnSrc bn;
+        bn.fstat = td.bn_fstat; bn.gamma = td.bn_gamma; bn.beta = td.bn_beta; bn.n_p = td.bn_np; bn.bs = bs;
+        const float db = (float)td.dbias[row];
+        float* pg = &g.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float mean, istd, sc, sh;
+            bn_column(bn, col + e, mean, istd, sc, sh);
+            pg[e] = pg[e] * sc + db * sh;
+        }
+    }
+    return g;
+}
+
+// workgroup `lb` of a tensor -> (row, col, local index, live) of this thread's 4 elements
+__device__ __forceinline__ bool opt16_locate(const Opt16Tensor& td, int lb, int& row, int& col, int64_t& local) {
+    if (td.rows_p > 1) {
+        const int tiles_c = td.cols_p / 32;
+        row = (lb / tiles_c) * 32 + (threadIdx.x >> 3);
+        col = (lb % tiles_c) * 32 + (threadIdx.x & 7) * 4;
+        local = (int64_t)row * td.cols_p + col;
+        return row < td.rows_p;
+    }
+    row = 0;
+    local = (int64_t)lb * 1024 + threadIdx.x * 4;
+    col = (int)local;
+    return local < td.cols_p;
+}
+
+// data-parallel path: G[flat] = this rank's complete gradient (then all-reduced over the ranks)
+__global__ __launch_bounds__(256) void vae_grad16_kernel(const Opt16Tensor* __restrict__ tab, int ntensors, int bs,
+                                                         float* __restrict__ G) {
+    int t = 0;
+    while (t + 1 < ntensors && (int)blockIdx.x >= tab[t + 1].blk_start) ++t;
+    const Opt16Tensor td = tab[t];
+    int row, col;
+    int64_t local;
+    if (!opt16_locate(td, (int)blockIdx.x - td.blk_start, row, col, local)) return;
+    *reinterpret_cast<float4*>(G + td.p_off + local) = opt16_grad(td, local, row, col, bs);
+}
+
+__global__ __launch_bounds__(256) void vae_dadapt16_kernel(const Opt16Tensor* __restrict__ tab, int ntensors, int bs,
+                                                           float* __restrict__ P, float* __restrict__ M1,
+                                                           float* __restrict__ M2, float* __restrict__ Sv,
+                                                           const StepState* __restrict__ st,
+                                                           double* __restrict__ partials) {
+    __shared__ double red[2][4];
+    __shared__ bf16_t wt[32][32 + 2];
+    const int blk = blockIdx.x;
+    int t = 0;
+    while (t + 1 < ntensors && blk >= tab[t + 1].blk_start) ++t;
+    const Opt16Tensor td = tab[t];
+    const int lb = blk - td.blk_start;
+    const bool matrix = td.rows_p > 1;
+    int row, col;
+    int64_t local;
+    const bool live = opt16_locate(td, lb, row, col, local);
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const double sqrt_b2d = sqrt(0.999);
+    const double dlr = st->d;
+    const float gscale = (float)st->wsum;
+    const float a_m = (float)(dlr * (1.0 - 0.9));
+    const float a_s = (float)(dlr * (1.0 - sqrt_b2d));
+    const float sqrt_b2 = (float)sqrt_b2d;
+    const float one_m_b2 = (float)(1.0 - 0.999);
+    float num = 0.f, sk = 0.f;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        float4 g = opt16_grad(td, local, row, col, bs);
+        g.x *= gscale; g.y *= gscale; g.z *= gscale; g.w *= gscale;
+        const int64_t o = td.p_off + local;
+        p = *reinterpret_cast<float4*>(P + o);
+        float4 m = *reinterpret_cast<float4*>(M1 + o), v = *reinterpret_cast<float4*>(M2 + o),
+               s = *reinterpret_cast<float4*>(Sv + o);
+        float* pg = &g.x; float* pp = &p.x; float* pm = &m.x; float* pv = &v.x; float* ps = &s.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = pg[e];
+            num += gi * (ps[e] / (sqrtf(pv[e]) + eps));
+            pm[e] = pm[e] * b1 + a_m * gi;
+            pv[e] = pv[e] * b2 + one_m_b2 * gi * gi;
+            ps[e] = ps[e] * sqrt_b2 + a_s * gi;
+            sk += fabsf(ps[e]);
+            pp[e] -= pm[e] / (sqrtf(pv[e]) + eps);
+        }
+        *reinterpret_cast<float4*>(P + o) = p;
+        *reinterpret_cast<float4*>(M1 + o) = m;
+        *reinterpret_cast<float4*>(M2 + o) = v;
+        *reinterpret_cast<float4*>(Sv + o) = s;
+    }
+    if (matrix && td.w16) {   // uniform per workgroup
+        const uint2 w = make_uint2(pack_bf2(p.x, p.y), pack_bf2(p.z, p.w));
+        if (live) *reinterpret_cast<uint2*>(td.w16 + local) = w;
+        if (td.w16t) {
+            const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 4;
+            wt[tr][tc + 0] = (bf16_t)(w.x & 0xFFFFu); wt[tr][tc + 1] = (bf16_t)(w.x >> 16);
+            wt[tr][tc + 2] = (bf16_t)(w.y & 0xFFFFu); wt[tr][tc + 3] = (bf16_t)(w.y >> 16);
+            __syncthreads();
+            // thread (c = tid >> 3, r4 = (tid & 7) * 4): 4 consecutive rows of column c -> 8 contiguous bytes of W16T
+            const int c = threadIdx.x >> 3, r4 = (threadIdx.x & 7) * 4;
+            const int tiles_c = td.cols_p / 32;
+            const int gr = (lb / tiles_c) * 32 + r4, gc = (lb % tiles_c) * 32 + c;
+            uint2 o;
+            o.x = (uint32_t)wt[r4 + 0][c] | ((uint32_t)wt[r4 + 1][c] << 16);
+            o.y = (uint32_t)wt[r4 + 2][c] | ((uint32_t)wt[r4 + 3][c] << 16);
+            if (gr < td.rows_p && gc < td.cols_p) *reinterpret_cast<uint2*>(td.w16t + (int64_t)gc * td.rows_p + gr) = o;
+        }
+    }
+    const double wn = wave_sum_f64((double)num), ws = wave_sum_f64((double)sk);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = wn; red[1][wave] = ws; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[(int64_t)blk * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partials[(int64_t)blk * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+}  // namespace vh

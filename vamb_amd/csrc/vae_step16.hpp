@@ -1,0 +1,504 @@
+// vae_step16.hpp -- host side of the bf16-storage training / inference step (BASELINE configs C2-C4).
+// Included by vae.hip inside its anonymous namespace, after the helpers it shares with the fp32 step
+// (drop_cfg, layer_key, step_ptr, bn_src, launch_forking, fork_side, join_side, probe_arm).
+//
+// Tensors (per batch size, see prepare_batch16):
+//   Xb16 / Xb16T, Z16 / Z16T, dR16 / dR16T, dMU16 / dMU16T   bf16, row-major [bs_p][w] and transposed [w][bs_p]
+//   per hidden layer: H16 / H16T (post-dropout activations), DA16 (grad wrt the BatchNorm output), DZ16 / DZ16T
+//   W16 / W16T: bf16 shadows of every parameter tensor at the offsets of the flat fp32 buffer (transposed for
+//   matrices); Wf16 / biasf: the BatchNorm-folded weights of the layers that consume normalised activations.
+// Stream plan: the main stream carries gather -> forward -> loss -> dX chain -> optimiser; the side stream carries
+// the transposes of the narrow tensors, the running statistics and every weight-gradient GEMM but the last.
+#pragma once
+
+namespace step16 {
+
+constexpr int kDwTargetWgs = 128;   // workgroups wanted per weight-gradient GEMM (they share the chip with the dX chain)
+
+template <int BM, int BN, int WM, int WN, int EPI>
+void launch_gemm16(hipStream_t stream, const Gemm16Args& g, int splits) {
+    static bool attr_set = false;
+    constexpr size_t smem = gemm16_smem_bytes<BM, BN, WM, WN, EPI>();
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI>;
+    if (!attr_set) {
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kMaxDynLds));
+        attr_set = true;
+    }
+    static_assert(smem <= kMaxDynLds, "tile does not fit the LDS budget");
+    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits);
+    if (t_probe_start) {
+        hipExtLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, t_probe_start, t_probe_stop, 0, g);
+        t_probe_start = t_probe_stop = nullptr;
+    } else if (t_fork_stop) {
+        hipExtLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, nullptr, t_fork_stop, 0, g);
+        t_fork_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g);
+    }
+    VH_HIP(hipGetLastError());
+}
+
+// tile by output shape: 128x128 (2x2 waves of 64x64), 128x32 for latent-wide outputs, 32x128 for latent-tall ones
+template <int EPI>
+void gemm16(hipStream_t s, const Gemm16Args& g, int splits) {
+    if constexpr (EPI == E16_SPLITK) {
+        if (g.N <= 32) launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
+        else if (g.M <= 32) launch_gemm16<32, 128, 1, 4, EPI>(s, g, splits);
+        else launch_gemm16<128, 128, 2, 2, EPI>(s, g, splits);
+    } else if constexpr (EPI == E16_LATENT_MASK) {
+        launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
+    } else {
+        launch_gemm16<128, 128, 2, 2, EPI>(s, g, splits);
+    }
+}
+
+Gemm16Args args16(vh_vae* h) {
+    Gemm16Args g;
+    memset(&g, 0, sizeof(g));
+    g.zeros = h->zeros16.p;
+    g.drop_scale = 1.0f;
+    g.xcd_remap = 1;
+    return g;
+}
+
+bf16_t* w16(vh_vae* h, int t) { return h->W16.p + h->tensors[t].off; }
+bf16_t* w16t(vh_vae* h, int t) { return h->W16T.p + h->tensors[t].off; }
+
+// split-K plan of a weight-gradient GEMM C[M][N] over K = bs_p: slabs of >= 512 batch rows, ~kDwTargetWgs workgroups
+int dw_splits16(int M, int N, int K) {
+    const int bm = M <= 32 ? 32 : 128, bn = N <= 32 ? 32 : 128;
+    const int tiles = (int)(ceil_div(M, bm) * ceil_div(N, bn));
+    int want = (int)std::max<int64_t>(1, ceil_div(kDwTargetWgs, tiles));
+    want = std::min(want, std::max(1, K / 512));
+    return std::max(1, want);
+}
+
+void transpose16(vh_vae* h, hipStream_t s, const bf16_t* in, int R, int C, bf16_t* out, double* colsum, int r_real) {
+    hipLaunchKernelGGL(vae_transpose16_kernel, dim3((unsigned)ceil_div(C, kTrTile), (unsigned)ceil_div(R, kTrTile)),
+                       dim3(256), 0, s, in, (int64_t)C, R, C, out, (int64_t)R, colsum, r_real);
+    VH_HIP(hipGetLastError());
+}
+
+// bf16 shadows of one parameter tensor (or all of them) from the fp32 masters: init, set_param, precision switch
+void refresh_shadows(vh_vae* h, int only) {
+    for (int ti = 0; ti < (int)h->tensors.size(); ++ti) {
+        const Tensor& t = h->tensors[ti];
+        if (!t.optimised || !t.matrix || (only >= 0 && only != ti)) continue;
+        const int64_t n = t.padded();
+        hipLaunchKernelGGL(vae_shadow_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, h->stream, h->pptr(ti),
+                           t.rows_p, t.cols_p, w16(h, ti), w16t(h, ti));
+        VH_HIP(hipGetLastError());
+    }
+}
+
+// everything of the bf16 step that depends on the batch size (called from prepare_batch)
+void prepare_batch16(vh_vae* h) {
+    const int bs_p = h->bs_p;
+    h->Xb16.ensure((size_t)bs_p * h->D_p);
+    h->Xb16T.ensure((size_t)bs_p * h->D_p);
+    h->Z16.ensure((size_t)bs_p * h->L_p);
+    h->Z16T.ensure((size_t)bs_p * h->L_p);
+    h->dR16.ensure((size_t)bs_p * h->D_p);
+    h->dR16T.ensure((size_t)bs_p * h->D_p);
+    h->dMU16.ensure((size_t)bs_p * h->L_p);
+    h->dMU16T.ensure((size_t)bs_p * h->L_p);
+    for (auto& hl : h->hidden) {
+        const size_t n = (size_t)bs_p * hl.nout_p;
+        hl.H16.ensure(n); hl.H16T.ensure(n); hl.DA16.ensure(n); hl.DZ16.ensure(n); hl.DZ16T.ensure(n);
+        hl.Wf16.ensure((size_t)hl.nout_p * hl.nin_p);
+        hl.biasf.ensure((size_t)hl.nout_p);
+    }
+    h->Wf16_mu.ensure((size_t)h->L_p * h->hidden[h->nl - 1].nout_p);
+    h->biasf_mu.ensure((size_t)h->L_p);
+    h->Wf16_out.ensure((size_t)h->D_p * h->hidden[2 * h->nl - 1].nout_p);
+    h->biasf_out.ensure((size_t)h->D_p);
+}
+
+// gradient sources of the bf16 step: split-K slabs for matrices (planned by prepare_batch), fp64 accumulators for
+// every vector; BatchNorm completion for the weights that consume normalised activations
+void build_opt16_table(vh_vae* h) {
+    std::vector<Opt16Tensor> tab;
+    int nblk = 0;
+    const int nl = h->nl;
+    auto add = [&](int ti, const Hidden* prev_bn, const double* dbias) {
+        const Tensor& t = h->tensors[ti];
+        Opt16Tensor d;
+        memset(&d, 0, sizeof(d));
+        d.rows_p = t.rows_p; d.cols_p = t.cols_p;
+        d.p_off = (int64_t)t.off;
+        d.blk_start = nblk;
+        if (!t.matrix) {
+            d.dsrc = t.dsrc;
+            nblk += (int)ceil_div(t.cols_p, 1024);
+        } else {
+            d.slab = t.slab; d.nslab = t.nslab; d.stride = t.stride;
+            d.w16 = w16(h, ti); d.w16t = w16t(h, ti);
+            if (prev_bn) {
+                d.bn_fstat = prev_bn->fstat;
+                d.bn_gamma = h->pptr(prev_bn->tG);
+                d.bn_beta = h->pptr(prev_bn->tB);
+                d.bn_np = prev_bn->nout_p;
+                d.dbias = dbias;
+            }
+            nblk += (t.rows_p / 32) * (t.cols_p / 32);
+        }
+        tab.push_back(d);
+    };
+    // creation order of the tensors (encoder hidden layers, mu, decoder hidden layers, output)
+    for (int li = 0; li < 2 * nl; ++li) {
+        if (li == nl) {
+            add(h->tWmu, &h->hidden[nl - 1], h->dbias_mu);
+            add(h->tbmu, nullptr, nullptr);
+        }
+        Hidden& hl = h->hidden[li];
+        const bool from_input = (li == 0) || (li == nl);
+        add(hl.tW, from_input ? nullptr : &h->hidden[li - 1], hl.dbias);
+        add(hl.tb, nullptr, nullptr);
+        add(hl.tG, nullptr, nullptr);
+        add(hl.tB, nullptr, nullptr);
+    }
+    add(h->tWo, &h->hidden[2 * nl - 1], h->dbias_out);
+    add(h->tbo, nullptr, nullptr);
+    VH_REQUIRE((int)tab.size() <= kMaxOpt16, "too many parameter tensors");
+    h->opt16_n = (int)tab.size();
+    h->opt16_blocks = nblk;
+    h->opt16_tab.ensure(tab.size());
+    VH_HIP(hipMemcpy(h->opt16_tab.p, tab.data(), tab.size() * sizeof(Opt16Tensor), hipMemcpyHostToDevice));
+    // data-parallel variant: gradients already complete (and all-reduced) in the flat buffer G
+    for (auto& d : tab) {
+        d.dsrc = nullptr;
+        d.slab = h->G.p + d.p_off; d.nslab = 1; d.stride = 0;
+        d.bn_fstat = nullptr; d.dbias = nullptr;
+    }
+    h->opt16_tab_flat.ensure(tab.size());
+    VH_HIP(hipMemcpy(h->opt16_tab_flat.p, tab.data(), tab.size() * sizeof(Opt16Tensor), hipMemcpyHostToDevice));
+    h->opt_part.ensure((size_t)std::max(h->opt_blocks, nblk) * 2);
+}
+
+void fold_bn(vh_vae* h, hipStream_t s, int tW, int tb, int n_rows, int K, const Hidden& prev, bool training,
+             bf16_t* Wf16, float* biasf) {
+    BnSrc bn = bn_src(h, prev);
+    hipLaunchKernelGGL(vae_fold_bn_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), (size_t)2 * K * sizeof(float), s,
+                       h->pptr(tW), (int64_t)K, n_rows, K, h->pptr(tb), bn, training ? nullptr : prev.scale.p,
+                       training ? nullptr : prev.shift.p, Wf16, biasf);
+    VH_HIP(hipGetLastError());
+}
+
+// Xb / Xb16 / Wb must hold the batch.
+void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected, bool add_noise) {
+    const int bs = h->bs, bs_p = h->bs_p, nl = h->nl;
+    hipStream_t s = h->stream;
+    const DropCfg dc = drop_cfg(h, training, masks_injected);
+    if (training) {
+        if (!h->stat_clean) VH_HIP(hipMemsetAsync(h->statbuf.p, 0, h->statbuf.bytes(), s));
+        h->stat_clean = false;
+    } else {
+        for (int li = 0; li < 2 * nl; ++li) {
+            Hidden& hl = h->hidden[li];
+            hipLaunchKernelGGL(vae_bn_eval_coeff_kernel, dim3((unsigned)ceil_div(hl.nout_p, 256)), dim3(256), 0, s,
+                               hl.nout_p, h->pptr(hl.tG), h->pptr(hl.tB), h->pptr(hl.tRM), h->pptr(hl.tRV),
+                               hl.scale.p, hl.shift.p);
+            VH_HIP(hipGetLastError());
+        }
+    }
+    const bf16_t* in = h->Xb16.p;
+    int in_w = h->D_p;
+    const Hidden* prev = nullptr;   // training: the layer whose BatchNorm still has to be folded into the consumer
+    auto hidden_layer = [&](int li) {
+        Hidden& hl = h->hidden[li];
+        Gemm16Args g = args16(h);
+        g.A = in; g.lda = in_w;
+        g.M = bs_p; g.N = hl.nout_p; g.K = hl.nin_p; g.k_per_split = g.K;
+        g.m_real = bs;
+        g.C16 = hl.H16.p; g.ldc16 = hl.nout_p;
+        if (training) {
+            if (prev) {
+                fold_bn(h, s, hl.tW, hl.tb, hl.nout_p, hl.nin_p, *prev, true, hl.Wf16.p, hl.biasf.p);
+                g.B = hl.Wf16.p; g.bias = hl.biasf.p;
+            } else {
+                g.B = w16(h, hl.tW); g.bias = h->pptr(hl.tb);
+            }
+            g.ldb = hl.nin_p;
+            g.C16T = hl.H16T.p; g.ldc16t = bs_p;
+            g.fstat_out = hl.fstat;
+            g.drop_scale = dc.scale; g.drop_thresh = dc.thresh; g.drop_key = layer_key(h, li);
+            g.step_ptr = step_ptr(h);
+            g.drop_mask = dc.injected ? hl.mask.p : nullptr; g.ld_mask = hl.nout_p;
+            if (h->probe_on && li == h->probe_layer) { probe_arm(h); h->probe_flops = 2.0 * bs * (double)hl.nin * hl.nout; }
+            gemm16<E16_HIDDEN_TRAIN>(s, g, 1);
+            prev = &hl;
+        } else {
+            g.B = w16(h, hl.tW); g.ldb = hl.nin_p;
+            g.bias = h->pptr(hl.tb);
+            g.scale = hl.scale.p; g.shift = hl.shift.p;
+            gemm16<E16_HIDDEN_EVAL>(s, g, 1);
+        }
+        in = hl.H16.p;
+        in_w = hl.nout_p;
+    };
+    for (int li = 0; li < nl; ++li) hidden_layer(li);
+    int mu_slabs = 1;
+    const float* mu_bias = h->pptr(h->tbmu);
+    {   // mu (encode.py:268): latent-wide output, contraction split over up to 8 slabs (summed by the reparam kernel)
+        Gemm16Args g = args16(h);
+        g.A = in; g.lda = in_w;
+        g.B = w16(h, h->tWmu); g.ldb = in_w;
+        if (training && prev) {
+            fold_bn(h, s, h->tWmu, h->tbmu, h->L_p, in_w, *prev, true, h->Wf16_mu.p, h->biasf_mu.p);
+            g.B = h->Wf16_mu.p;
+            mu_bias = h->biasf_mu.p;
+        }
+        g.C32 = h->skinny.p; g.ldc32 = h->L_p;
+        g.M = bs_p; g.N = h->L_p; g.K = in_w;
+        const int want = std::max(1, std::min(kSkinnySplits, in_w / 128));
+        g.k_per_split = (int)round_up(ceil_div(in_w, want), 64);
+        mu_slabs = (int)ceil_div(in_w, g.k_per_split);
+        g.slab_stride = (int64_t)bs_p * h->L_p;
+        gemm16<E16_SPLITK>(s, g, mu_slabs);
+    }
+    {
+        const int64_t tot = (int64_t)bs_p * h->L_p;
+        const float* eps_ptr = eps_injected ? h->EPS.p : nullptr;
+        if (training) {   // the transposed latent code feeds the first decoder layer's weight gradient (side stream)
+            launch_forking(h, vae_reparam16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0,
+                           (const float*)h->skinny.p, mu_slabs, (int64_t)bs_p * h->L_p, mu_bias, eps_ptr, layer_key(h, 0xEE),
+                           step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z16.p, bs, h->L, h->L_p, bs_p);
+            transpose16(h, h->side, h->Z16.p, bs_p, h->L_p, h->Z16T.p, nullptr, 0);
+        } else {
+            hipLaunchKernelGGL(vae_reparam16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s,
+                               (const float*)h->skinny.p, mu_slabs, (int64_t)bs_p * h->L_p, mu_bias, eps_ptr,
+                               layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z16.p, bs, h->L, h->L_p, bs_p);
+            VH_HIP(hipGetLastError());
+        }
+    }
+    in = h->Z16.p;
+    in_w = h->L_p;
+    prev = nullptr;
+    for (int li = nl; li < 2 * nl; ++li) hidden_layer(li);
+    {   // reconstruction (encode.py:294), fp32
+        Gemm16Args g = args16(h);
+        g.A = in; g.lda = in_w;
+        g.B = w16(h, h->tWo); g.ldb = in_w;
+        g.bias = h->pptr(h->tbo);
+        if (training && prev) {
+            fold_bn(h, s, h->tWo, h->tbo, h->D_p, in_w, *prev, true, h->Wf16_out.p, h->biasf_out.p);
+            g.B = h->Wf16_out.p;
+            g.bias = h->biasf_out.p;
+        }
+        g.C32 = h->R.p; g.ldc32 = h->D_p;
+        g.M = bs_p; g.N = h->D_p; g.K = in_w; g.k_per_split = g.K;
+        const bool ext_fork = training && fork_from_kernel(h);
+        if (ext_fork) t_fork_stop = h->ev_fork;
+        gemm16<E16_BIAS>(s, g, 1);
+        if (ext_fork) VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    }
+    if (training) {
+        if (!fork_from_kernel(h)) fork_side(h);
+        RunningTable rt;
+        memset(&rt, 0, sizeof(rt));
+        int maxn = 0;
+        for (auto& hl : h->hidden) {
+            rt.fstat[rt.n] = hl.fstat; rt.rm[rt.n] = h->pptr(hl.tRM); rt.rv[rt.n] = h->pptr(hl.tRV);
+            rt.n_p[rt.n] = hl.nout_p;
+            maxn = std::max(maxn, hl.nout_p);
+            rt.n++;
+        }
+        hipLaunchKernelGGL(vae_bn_running_kernel, dim3((unsigned)ceil_div(maxn, 256), rt.n), dim3(256), 0, h->side, rt, bs);
+        VH_HIP(hipGetLastError());
+    }
+}
+
+void loss_and_seed16(vh_vae* h) {
+    const int bs_global = h->global_bs > 0 ? h->global_bs : h->bs;
+    Loss16Args a;
+    a.R = h->R.p; a.X = h->Xb.p; a.ld = h->D_p;
+    a.MU = h->MU.p; a.ldl = h->L_p;
+    a.inv_b2 = (float)(1.0 / ((double)bs_global * (double)bs_global));
+    a.bs = h->bs; a.bs_p = h->bs_p; a.S = h->S; a.L = h->L;
+    a.ce_w = h->ce_w; a.ab_w = h->ab_w; a.sse_w = h->sse_w; a.kld_w = h->kld_w;
+    a.dR16 = h->dR16.p; a.dMUk = h->dMUk.p; a.part = h->loss_part.p;
+    launch_forking(h, vae_loss16_kernel, dim3(h->loss_blocks), dim3(256), 0, a);
+    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, h->side, h->loss_part.p, h->loss_blocks,
+                       h->Wb.p, h->bs, h->gwsum_src, bs_global, h->state.p);
+    VH_HIP(hipGetLastError());
+}
+
+// dW slabs = A^T-copy [out][bs_p] x B^T-copy [in][bs_p] (both K-contiguous over the batch)
+void grad_weight16(vh_vae* h, int tW, const bf16_t* dZT, int out_p, const bf16_t* InT, int in_p, hipStream_t st) {
+    Tensor& t = h->tensors[tW];
+    Gemm16Args g = args16(h);
+    g.A = dZT; g.lda = h->bs_p;
+    g.B = InT; g.ldb = h->bs_p;
+    g.C32 = t.slab; g.ldc32 = in_p;
+    g.M = out_p; g.N = in_p; g.K = h->bs_p;
+    g.k_per_split = (int)round_up(ceil_div(h->bs_p, t.nslab), 64);
+    g.slab_stride = t.stride;
+    const int splits = (int)ceil_div(h->bs_p, g.k_per_split);
+    if (splits < t.nslab)
+        VH_HIP(hipMemsetAsync(t.slab + (int64_t)splits * t.stride, 0, sizeof(float) * (t.nslab - splits) * t.stride, st));
+    gemm16<E16_SPLITK>(st, g, splits);
+}
+
+// dIn16 = dZ16 [bs_p][out] x W16T [in][out]; the epilogue leaves the BatchNorm-backward sums of the layer below
+void grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidden& below) {
+    Gemm16Args g = args16(h);
+    g.A = dZ; g.lda = out_p;
+    g.B = w16t(h, tW); g.ldb = out_p;
+    g.M = h->bs_p; g.N = in_p; g.K = out_p; g.k_per_split = g.K;
+    g.m_real = h->bs;
+    g.C16 = below.DA16.p; g.ldc16 = in_p;
+    g.Hbelow = below.H16.p; g.ldh = in_p;
+    g.bnC = bn_src(h, below);
+    g.bstat_out = below.bstat;
+    gemm16<E16_STORE_BNRED>(h->stream, g, 1);
+}
+
+void backward16(vh_vae* h, bool masks_injected) {
+    const int bs = h->bs, bs_p = h->bs_p, nl = h->nl;
+    const DropCfg dc = drop_cfg(h, true, masks_injected);
+    {   // output layer: dR16 is ready (the side stream already waits on the loss kernel)
+        Hidden& last = h->hidden[2 * nl - 1];
+        transpose16(h, h->side, h->dR16.p, bs_p, h->D_p, h->dR16T.p, h->dbias_out, bs);
+        grad_weight16(h, h->tWo, h->dR16T.p, h->D_p, last.H16T.p, last.nout_p, h->side);
+        grad_input16(h, h->dR16.p, h->D_p, h->tWo, last.nout_p, last);
+    }
+    int latent_slabs = 1;
+    auto hidden_bwd = [&](int li) {
+        Hidden& hl = h->hidden[li];
+        Dz16Args a;
+        a.DA = hl.DA16.p; a.H = hl.H16.p; a.DZ = hl.DZ16.p; a.DZT = hl.DZ16T.p; a.ldt = bs_p;
+        a.n_p = hl.nout_p; a.bs = bs; a.bs_p = bs_p;
+        a.bn = bn_src(h, hl);
+        a.bstat = hl.bstat;
+        a.drop_scale = dc.scale;
+        a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
+        a.dbias = hl.dbias;
+        const bool tail = (li == 0) && h->tail_on_main;
+        const dim3 grid((unsigned)ceil_div(hl.nout_p, kDz16Cols), (unsigned)ceil_div(bs_p, kDz16Rows));
+        if (tail) {
+            hipLaunchKernelGGL(vae_dz16_kernel, grid, dim3(256), 0, h->stream, a);
+            VH_HIP(hipGetLastError());
+        } else {
+            launch_forking(h, vae_dz16_kernel, grid, dim3(256), 0, a);
+        }
+        const bf16_t* InT = li == 0 ? h->Xb16T.p : (li == nl ? h->Z16T.p : h->hidden[li - 1].H16T.p);
+        const int in_p = li == 0 ? h->D_p : (li == nl ? h->L_p : h->hidden[li - 1].nout_p);
+        if (tail) join_side(h);   // Xb16T (and every earlier weight gradient) is complete
+        grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, tail ? h->stream : h->side);
+        if (li == nl) {
+            // first decoder layer -> latent: latent-wide output, split-K slabs summed by the latent kernel
+            Gemm16Args g = args16(h);
+            g.A = hl.DZ16.p; g.lda = hl.nout_p;
+            g.B = w16t(h, hl.tW); g.ldb = hl.nout_p;
+            g.M = bs_p; g.N = in_p; g.K = hl.nout_p;
+            const int want = std::max(1, std::min(kSkinnySplits, hl.nout_p / 128));
+            g.k_per_split = (int)round_up(ceil_div(hl.nout_p, want), 64);
+            latent_slabs = (int)ceil_div(hl.nout_p, g.k_per_split);
+            g.C32 = h->skinny.p; g.ldc32 = in_p;
+            g.slab_stride = (int64_t)bs_p * in_p;
+            gemm16<E16_SPLITK>(h->stream, g, latent_slabs);
+        } else if (li > 0) {
+            grad_input16(h, hl.DZ16.p, hl.nout_p, hl.tW, in_p, h->hidden[li - 1]);
+        }
+    };
+    for (int li = 2 * nl - 1; li >= nl; --li) hidden_bwd(li);
+    {   // latent: dMU = dZlat + d(KLD)/dmu; mu layer
+        Hidden& enc_last = h->hidden[nl - 1];
+        const int64_t tot = (int64_t)bs_p * h->L_p;
+        launch_forking(h, vae_latent_bwd16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0,
+                       (const float*)h->skinny.p, latent_slabs, (int64_t)bs_p * h->L_p, (const float*)h->dMUk.p,
+                       h->dMU16.p, h->L_p, bs, bs_p);
+        transpose16(h, h->side, h->dMU16.p, bs_p, h->L_p, h->dMU16T.p, h->dbias_mu, bs);
+        grad_weight16(h, h->tWmu, h->dMU16T.p, h->L_p, enc_last.H16T.p, enc_last.nout_p, h->side);
+        grad_input16(h, h->dMU16.p, h->L_p, h->tWmu, enc_last.nout_p, enc_last);
+    }
+    for (int li = nl - 1; li >= 0; --li) hidden_bwd(li);
+    if (!h->tail_on_main) join_side(h);
+}
+
+void optimizer_step16(vh_vae* h) {
+    const Opt16Tensor* tab = h->opt16_tab.p;
+    if (h->comm) {
+        hipLaunchKernelGGL(vae_grad16_kernel, dim3(h->opt16_blocks), dim3(256), 0, h->stream, h->opt16_tab.p, h->opt16_n,
+                           h->bs, h->G.p);
+        VH_HIP(hipGetLastError());
+        rccl_allreduce_sum_f32(h->comm, h->G.p, h->flat_elems, h->stream);
+        tab = h->opt16_tab_flat.p;
+    }
+    hipLaunchKernelGGL(vae_dadapt16_kernel, dim3(h->opt16_blocks), dim3(256), 0, h->stream, tab, h->opt16_n, h->bs, h->P.p,
+                       h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p);
+    VH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(vae_dadapt_finalize_kernel, dim3(1), dim3(256), 0, h->stream, h->opt_part.p, h->opt16_blocks,
+                       h->state.p, h->statbuf.p, h->keep_grads ? 0 : (int)h->statbuf.n);
+    VH_HIP(hipGetLastError());
+    h->stat_clean = !h->keep_grads;
+}
+
+void gather_rows16(vh_vae* h, const int64_t* dev_idx) {
+    launch_forking(h, vae_gather16_kernel, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, (const float*)h->X.p,
+                   (int64_t)h->D_p, (const float*)h->w.p, dev_idx, h->shuffle, (const long long*)&h->state.p->batch, h->bs,
+                   h->bs_p, h->Xb.p, h->Xb16.p, h->Wb.p);
+    // transposed copy of the batch for the first layer's weight gradient (side stream; needed last)
+    transpose16(h, h->side, h->Xb16.p, h->bs_p, h->D_p, h->Xb16T.p, nullptr, 0);
+}
+
+void train_step16(vh_vae* h, const int64_t* dev_idx, bool eps_injected, bool masks_injected) {
+    gather_rows16(h, dev_idx);
+    forward16(h, true, eps_injected, masks_injected, true);
+    loss_and_seed16(h);
+    backward16(h, masks_injected);
+    optimizer_step16(h);
+}
+
+// VAE.encode in bf16: the resident feature matrix is fp32; each chunk is cast once, then runs the eval-mode encoder
+void encode16(vh_vae* h, float* latent) {
+    hipStream_t s = h->stream;
+    const int64_t chunk = 16384;
+    int maxw = h->D_p;
+    for (int li = 0; li < h->nl; ++li) maxw = std::max(maxw, h->hidden[li].nout_p);
+    DevBuf<bf16_t> a0, a1;
+    DevBuf<float> lat;
+    a0.alloc((size_t)chunk * maxw);
+    a1.alloc((size_t)chunk * maxw);
+    lat.alloc((size_t)chunk * h->L);
+    for (int li = 0; li < h->nl; ++li) {
+        Hidden& hl = h->hidden[li];
+        hipLaunchKernelGGL(vae_bn_eval_coeff_kernel, dim3((unsigned)ceil_div(hl.nout_p, 256)), dim3(256), 0, s, hl.nout_p,
+                           h->pptr(hl.tG), h->pptr(hl.tB), h->pptr(hl.tRM), h->pptr(hl.tRV), hl.scale.p, hl.shift.p);
+        VH_HIP(hipGetLastError());
+    }
+    for (int64_t lo = 0; lo < h->n; lo += chunk) {
+        const int m = (int)std::min<int64_t>(chunk, h->n - lo);
+        const int64_t n4 = (int64_t)m * h->D_p / 4;
+        hipLaunchKernelGGL(vae_cast16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n4, 256), 4096)), dim3(256), 0, s,
+                           h->X.p + (size_t)lo * h->D_p, a1.p, n4);
+        VH_HIP(hipGetLastError());
+        const bf16_t* in = a1.p;
+        int in_w = h->D_p;
+        bf16_t* bufs[2] = {a0.p, a1.p};
+        for (int li = 0; li < h->nl; ++li) {
+            Hidden& hl = h->hidden[li];
+            Gemm16Args g = args16(h);
+            g.A = in; g.lda = in_w;
+            g.B = w16(h, hl.tW); g.ldb = hl.nin_p;
+            g.C16 = bufs[li & 1]; g.ldc16 = hl.nout_p;
+            g.M = m; g.N = hl.nout_p; g.K = hl.nin_p; g.k_per_split = g.K;
+            g.bias = h->pptr(hl.tb); g.scale = hl.scale.p; g.shift = hl.shift.p; g.m_real = m;
+            gemm16<E16_HIDDEN_EVAL>(s, g, 1);
+            in = bufs[li & 1];
+            in_w = hl.nout_p;
+        }
+        Gemm16Args g = args16(h);
+        g.A = in; g.lda = in_w;
+        g.B = w16(h, h->tWmu); g.ldb = in_w;
+        g.C32 = lat.p; g.ldc32 = h->L;
+        g.M = m; g.N = h->L; g.K = in_w; g.k_per_split = g.K;
+        g.bias = h->pptr(h->tbmu);
+        gemm16<E16_LATENT_MASK>(s, g, 1);
+        VH_HIP(hipMemcpyAsync(latent + (size_t)lo * h->L, lat.p, sizeof(float) * (size_t)m * h->L, hipMemcpyDeviceToHost, s));
+        VH_HIP(hipStreamSynchronize(s));
+    }
+}
+
+}  // namespace step16
