@@ -1,24 +1,29 @@
 #!/usr/bin/env python
 """bench.py -- whole-job throughput of the hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--epochs E] [--contigs N] [--samples S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C1|C3] [--epochs E] [--scaling weak|strong]
 
 One "step" = one full pass of the hot path over a synthetic dataset resident in HBM:
     VAE.trainmodel (E epochs, fixed batch) -> VAE.encode -> list(ClusterGenerator(latent))
-i.e. exactly what `vamb bin default` runs between loading the abundance/TNF matrices and writing
-cluster files (reference vamb/__main__.py:1451-1488).  The default workload is BASELINE.json
-configs[1] ("C1"): 200k contigs x 50 samples (D = 154), 512-512 hidden, 32-d latent, batch 4096, fp32,
-with the reference CLI's default epoch count (-e 300, __main__.py:2412).
+i.e. what `vamb bin default` runs between loading the abundance / TNF matrices and writing the cluster files
+(reference vamb/__main__.py:1065-1107, 1254-1404).  The default workload is BASELINE.json configs[2] ("C2"), the
+largest single-GPU configuration: 2 M contigs x 200 samples (D = 304), 512-512 hidden, 32-d latent, batch 8192,
+bf16 MFMA with fp32 accumulation, the reference CLI's default epoch count (-e 300, __main__.py:2412).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     : HIP-event timing (the kernels' own begin/end timestamps) of the encoder layer-1 GEMM
-                 (M=batch, K=512, N=512 -- the FLOP-dominant encoder GEMM) over the timed region
-  cpu_baseline : the CPU oracle ("port") timed on a bounded sample of the same workload
-and extra per-stage fields (epoch_ms, encode_ms, cluster_ms, scan GB/s).
+  roofline        : kernel begin/end timestamps of the encoder's FIRST-layer GEMM (M = batch, K = D, N = 512 -- the
+                    GEMM BASELINE's >= 50 % target names) over the timed steps, against the dtype's MFMA peak
+  roofline_hidden : the same for a 512x512 hidden layer (the GEMM shape that dominates the step's time), warm-up steps
+  cluster_scan    : algorithmic bytes / kernel time of the scan + select passes (HBM bound), warm-up steps
+  c3_shape        : a short training + encode leg at the C3 shape (2 M x 1000, D = 1104) on this GPU
+  cpu_baseline    : the CPU oracle ("port") timed on a bounded sample, with its calibration against the real
+                    reference measured in the build container (oracle/cpu_calibration.json)
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank holds its own
-shard of `--contigs` contigs; training is data-parallel (RCCL all-reduce of the flat gradient on the
-library's stream, see DESIGN.md "multi-GPU"), encode and the cluster sweep are shard-local.
+N > 1: `python bench.py --gpus N` launches N ranks itself (one process per GPU; the driver's
+`python -m torch.distributed.run ... bench.py --gpus N` form works too).  weak scaling (default): every rank holds its
+own shard of `--contigs` contigs, training is data-parallel (RCCL all-reduce of the flat gradient inside the library),
+encode and the cluster sweep are shard-local.  --scaling strong: ONE dataset of `--contigs` contigs is row-sharded over
+the ranks and clustered through the sharded scan (vamb_amd.parallel.sharded_cluster_generator).
 """
 from __future__ import annotations
 
@@ -26,6 +31,7 @@ import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,9 +42,15 @@ sys.path.insert(0, ROOT)
 
 HIDDEN = 512
 NTNF = 103
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table (fp32-input MFMA == fp32 vector peak)
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (same table); only used with VAMBHIP_PRECISION=bf16
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md chip table (fp32-input MFMA == fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (same table)
 PEAK_HBM_GBPS = 8000.0
+
+CONFIGS = {  # BASELINE.json configs: (contigs, samples, batch, latent, dtype)
+    "C1": (200_000, 50, 4096, 32, "fp32"),
+    "C2": (2_000_000, 200, 8192, 32, "bf16"),
+    "C3": (2_000_000, 1000, 8192, 32, "bf16"),
+}
 
 
 def parse():
@@ -46,16 +58,28 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2)
     p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--config", choices=sorted(CONFIGS), default="C2")
     p.add_argument("--epochs", type=int, default=300, help="training epochs per step (reference CLI default 300)")
-    p.add_argument("--contigs", type=int, default=200_000, help="contigs per GPU")
-    p.add_argument("--samples", type=int, default=50)
-    p.add_argument("--batch", type=int, default=4096)
-    p.add_argument("--latent", type=int, default=32)
+    p.add_argument("--contigs", type=int, default=None, help="contigs per GPU (weak) / in total (strong)")
+    p.add_argument("--samples", type=int, default=None)
+    p.add_argument("--batch", type=int, default=None, help="rows per GPU and optimisation step")
+    p.add_argument("--latent", type=int, default=None)
+    p.add_argument("--dtype", choices=["fp32", "bf16"], default=None)
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=20_000)
+    p.add_argument("--no-c3", action="store_true", help="skip the C3-shape leg")
+    p.add_argument("--c3-epochs", type=int, default=3)
     p.add_argument("--force-dist", action="store_true",
                    help="take the multi-GPU code path (process group + RCCL communicator) even with one rank")
-    return p.parse_args()
+    a = p.parse_args()
+    c = CONFIGS[a.config]
+    a.contigs = c[0] if a.contigs is None else a.contigs
+    a.samples = c[1] if a.samples is None else a.samples
+    a.batch = c[2] if a.batch is None else a.batch
+    a.latent = c[3] if a.latent is None else a.latent
+    a.dtype = c[4] if a.dtype is None else a.dtype
+    return a
 
 
 def dist_env():
@@ -65,7 +89,27 @@ def dist_env():
     return rank, local, world
 
 
-def run_step(ve, vc, lib, _lib, dl, lens, args, seed, comm=None, probe_layer=1, time_scans=False):
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) and relay rank 0's
+    result line.  Rendezvous over 127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = None if r == 0 else subprocess.DEVNULL      # rank 0 owns stdout (the result line)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+def run_step(ve, vc, lib, _lib, dl, lens, args, seed, comm=None, probe_layer=0, time_scans=False, sharded=None):
     """One pass of the hot path.  Returns per-stage seconds and counters."""
     t0 = time.perf_counter()
     vae = ve.VAE(args.samples, nlatent=args.latent, seed=seed)
@@ -78,20 +122,27 @@ def run_step(ve, vc, lib, _lib, dl, lens, args, seed, comm=None, probe_layer=1, 
     t2 = time.perf_counter()
     latent = vae.encode(dl)
     t3 = time.perf_counter()
-    gen = vc.ClusterGenerator(latent, lens, destroy=True, rng_seed=seed)
+    if sharded is not None:
+        gen = sharded(latent, lens, seed)
+        backend = gen._backend
+    else:
+        gen = vc.ClusterGenerator(latent, lens, destroy=True, rng_seed=seed)
+        backend = gen._backend
     # HIP-event timing of every scan / select kernel costs a stream synchronisation per pass: it is switched on
     # in the warm-up steps only (cluster_scan statistics), the timed steps run the sweep as a user would
-    gen._backend.set_timing(time_scans)
+    backend.set_timing(time_scans)
     n_clusters = 0
     n_points = 0
     for c in gen:
         n_clusters += 1
         n_points += len(c.members)
     t4 = time.perf_counter()
-    assert n_points == len(lens)
+    if sharded is None:
+        assert n_points == len(lens)
+        gen._sync_native_counters()
     ms, nl, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
     _lib.check(lib.vh_vae_probe_result(vae._h, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl)))
-    b = gen._backend
+    b = backend
     L4 = (args.latent + 3) // 4 * 4
     out = dict(setup_s=t1 - t0, train_s=t2 - t1, encode_s=t3 - t2, cluster_s=t4 - t3, total_s=t4 - t0,
                clusters=n_clusters, probe_ms=ms.value, probe_launches=nl.value, probe_flops=fl.value,
@@ -101,9 +152,21 @@ def run_step(ve, vc, lib, _lib, dl, lens, args, seed, comm=None, probe_layer=1, 
     return out
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC pass (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_roofline_kernel.json")
+def probe_roofline(steps, what, peak):
+    ms = sum(r["probe_ms"] for r in steps)
+    n = sum(r["probe_launches"] for r in steps)
+    if not n:
+        return None
+    flops = steps[-1]["probe_flops"]
+    ach = flops / (ms / n * 1e-3) / 1e12
+    return {"kernel": what, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "avg_launch_ms": ms / n, "launches": n, "flops_per_launch": flops,
+            "timing": "kernel begin/end timestamps (hipExtLaunchKernelGGL start/stop events on the launching stream)"}
+
+
+def pmc_traffic(tag):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_roofline_{tag}.json")
     try:
         with open(path) as fh:
             return json.load(fh).get("hbm_bytes_per_launch")
@@ -111,30 +174,58 @@ def pmc_traffic():
         return None
 
 
-def layer0_roofline(warm):
-    ms = sum(r["probe_ms"] for r in warm)
-    n = sum(r["probe_launches"] for r in warm)
-    if not n:
-        return None
-    flops = warm[-1]["probe_flops"]
-    ach = flops / (ms / n * 1e-3) / 1e12
-    return {"kernel": "gemm_f32_kernel<64,64,EPI_HIDDEN_TRAIN> (encoder layer 0: M=batch, K=D, N=512), timed in the warm-up steps",
-            "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-            "avg_launch_ms": ms / n, "launches": n, "flops_per_launch": flops}
+def c3_shape_leg(args, ve, lib, _lib, synth):
+    """Training + encode at the C3 shape (2 M contigs x 1000 samples: 8.8 GB of features) on ONE GPU: the shape
+    BASELINE's 10x target is quoted on.  A few epochs only (the epoch time does not depend on the epoch count)."""
+    n, S, bs = CONFIGS["C3"][0], CONFIGS["C3"][1], CONFIGS["C3"][2]
+    t0 = time.perf_counter()
+    ab, tnf, lens, _ = synth.features(n, S, seed=3)
+    dl = ve.make_dataloader(ab, tnf, lens, batchsize=bs, destroy=True)
+    t_host = time.perf_counter() - t0
+    vae = ve.VAE(S, nlatent=32, seed=3)
+    _lib.check(lib.vh_vae_set_probe(vae._h, 1, 0))
+    t0 = time.perf_counter()
+    vae._ensure_dataset(dl)
+    t_up = time.perf_counter() - t0
+    vae.trainmodel(dl, nepochs=1, batchsteps=None)     # allocations, kernel attributes
+    _lib.check(lib.vh_vae_set_probe(vae._h, 1, 0))
+    t0 = time.perf_counter()
+    vae.trainmodel(dl, nepochs=args.c3_epochs, batchsteps=None)
+    t_epoch = (time.perf_counter() - t0) / args.c3_epochs
+    t0 = time.perf_counter()
+    vae.encode(dl)
+    t_enc = time.perf_counter() - t0
+    ms, nl, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+    _lib.check(lib.vh_vae_probe_result(vae._h, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl)))
+    D = S + NTNF + 1
+    flops_contig = 12 * HIDDEN * (D + HIDDEN + 32) - 2 * D * HIDDEN
+    peak = PEAK_BF16_MFMA_TFLOPS if vae.compute_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    ach = fl.value / (ms.value / max(nl.value, 1) * 1e-3) / 1e12 if nl.value else None
+    return {"workload": f"C3 shape on one GPU: {n} contigs x {S} samples (D={D}), batch {bs}, {vae.compute_dtype}; "
+                        f"{args.c3_epochs} epochs timed + encode, no cluster sweep",
+            "epoch_ms": t_epoch * 1e3, "us_per_step": t_epoch / (n // bs) * 1e6,
+            "train_contigs_per_s_per_epoch": n / t_epoch, "train_tflops_algorithmic": flops_contig * n / t_epoch / 1e12,
+            "encode_ms": t_enc * 1e3, "host_prep_s": t_host, "upload_s": t_up,
+            "roofline_encoder_gemm": None if ach is None else {
+                "kernel": f"first encoder layer, M={bs}, K=D={D} (padded 1120), N=512", "bound": "mfma", "achieved": ach,
+                "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "avg_launch_ms": ms.value / nl.value,
+                "launches": nl.value, "flops_per_launch": fl.value}}
 
 
 def cpu_baseline(args, latent, lens):
-    """The oracle (numpy VAE restatement + C cluster restatement) on a bounded sample of the workload."""
+    """The oracle (numpy VAE restatement + C cluster restatement) on a bounded sample of the workload, with the
+    reference's default thread count (min(cores, 8), vamb/__main__.py:27-28)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cluster_oracle as co
     import vae_oracle as vo
     from vamb_amd import encode as ve, synth
 
+    threads = min(8, os.cpu_count() or 1)
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
     except Exception:
-        cores = os.cpu_count() or 1
+        limiter = None
     n = min(args.cpu_sample, args.contigs)
     ab, tnf, ln, _ = synth.features(n, args.samples, seed=101)
     dl = ve.make_dataloader(ab, tnf, ln, batchsize=args.batch, destroy=True)
@@ -160,13 +251,27 @@ def cpu_baseline(args, latent, lens):
     t0 = time.perf_counter()
     nclu = sum(1 for _ in co.OracleClusterGenerator(np.ascontiguousarray(latent[:n]), lens[:n], rng_seed=1))
     t_clu = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits()
     total = args.epochs * t_epoch + t_enc + t_clu
-    return dict(value=n / total, unit="contigs/s", cores=int(cores), kind="port",
-                sample=(f"{n} contigs x {args.samples} samples: {cpu_epochs} oracle epochs timed "
-                        f"({t_epoch:.3f} s/epoch, numpy fp32 BLAS) extrapolated to {args.epochs}, + encode "
+    calib = None
+    try:
+        with open(os.path.join(ROOT, "oracle", "cpu_calibration.json")) as fh:
+            c = json.load(fh)
+        calib = {"reference_over_port": c["reference_over_port"], "measured_on": f"{c['cpu']}, {c['threads']} threads",
+                 "sample": c["sample"],
+                 "note": "the real reference (vamb/{encode,cluster}.py, torch CPU) and this port timed on the same sample "
+                         "in the build container (oracle/calibrate_cpu_baseline.py); > 1 means the reference is slower"}
+    except (OSError, ValueError, KeyError):
+        pass
+    ref_est = None if calib is None else n / (total * calib["reference_over_port"]["job_300_epochs"])
+    return dict(value=n / total, unit="contigs/s", cores=int(threads), kind="port",
+                sample=(f"{n} contigs x {args.samples} samples, batch {bs}: {cpu_epochs} oracle epochs timed "
+                        f"({t_epoch:.3f} s/epoch, numpy fp32 BLAS, {threads} threads) extrapolated to {args.epochs}, + encode "
                         f"{t_enc:.3f} s + full cluster sweep of the first {n} GPU latents {t_clu:.3f} s "
-                        f"({nclu} clusters, scalar C)"),
-                epoch_s=t_epoch, encode_s=t_enc, cluster_s=t_clu)
+                        f"({nclu} clusters, scalar C, 1 thread)"),
+                epoch_s=t_epoch, encode_s=t_enc, cluster_s=t_clu, calibration_vs_reference=calib,
+                reference_estimate_contigs_per_s=ref_est)
 
 
 _RESULT_FD = None
@@ -187,15 +292,16 @@ def emit_result(line: dict):
 
 
 def main():
-    claim_stdout()
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+    claim_stdout()
     rank, local, world = dist_env()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     from vamb_amd import _lib, cluster as vc, encode as ve, synth
 
+    ve.set_compute_dtype(args.dtype)
+    os.environ.pop("VAMBHIP_PRECISION", None)     # --dtype decides
     lib = _lib.load()
     _lib.require_gpu()
     _lib.check(lib.vh_set_device(local))
@@ -217,11 +323,29 @@ def main():
 
         comm = parallel.Communicator.from_torch_distributed(dist)
 
-    # synthetic inputs of the named shape (per-rank shard under weak scaling), normalised on the host
-    # exactly as `vamb bin default` does, then uploaded once: resident in HBM before the clock starts
-    ab, tnf, lens, _ = synth.features(args.contigs, args.samples, seed=1 + rank)
-    # under data parallelism the loader's batch size is the ALL-RANK batch: --batch rows per GPU
-    dl = ve.make_dataloader(ab, tnf, lens, batchsize=args.batch * world, destroy=True)
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        # ONE dataset, row-sharded: rank r holds rows [r n / world, (r + 1) n / world)
+        ab, tnf, lens_all, _ = synth.features(args.contigs, args.samples, seed=1)
+        lo, hi = rank * args.contigs // world, (rank + 1) * args.contigs // world
+        dl_full = ve.make_dataloader(ab, tnf, lens_all, batchsize=args.batch * world, destroy=True)
+        import torch
+
+        tens = [t[lo:hi].contiguous() for t in dl_full.dataset.tensors]
+        dl = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(*tens), batch_size=args.batch * world,
+                                         shuffle=True, drop_last=True)
+        lens = lens_all[lo:hi]
+        from vamb_amd import parallel as _par
+
+        def sharded(latent, lens_local, seed):
+            return _par.sharded_cluster_generator(comm, latent, lens_local, destroy=True, rng_seed=seed)
+    else:
+        # synthetic inputs of the named shape (per-rank shard under weak scaling), normalised on the host
+        # exactly as `vamb bin default` does, then uploaded once: resident in HBM before the clock starts
+        ab, tnf, lens, _ = synth.features(args.contigs, args.samples, seed=1 + rank)
+        # under data parallelism the loader's batch size is the ALL-RANK batch: --batch rows per GPU
+        dl = ve.make_dataloader(ab, tnf, lens, batchsize=args.batch * world, destroy=True)
+        sharded = None
 
     def barrier():
         _lib.check(lib.vh_device_synchronize())
@@ -231,14 +355,15 @@ def main():
 
     warm = []
     for i in range(args.warmup):
-        # the warm-up steps time the (much smaller) layer-0 GEMM instead; reported as roofline_layer0
-        warm.append(run_step(ve, vc, lib, _lib, dl, lens, args, seed=1000 + i, comm=comm, probe_layer=0,
-                             time_scans=True))
+        # the warm-up steps time a hidden 512x512 layer instead (roofline_hidden) and the scan kernels
+        warm.append(run_step(ve, vc, lib, _lib, dl, lens, args, seed=1000 + i, comm=comm, probe_layer=1,
+                             time_scans=True, sharded=sharded))
     barrier()
     t0 = time.perf_counter()
     results = []
     for i in range(args.steps):
-        results.append(run_step(ve, vc, lib, _lib, dl, lens, args, seed=i, comm=comm, time_scans=args.warmup == 0))
+        results.append(run_step(ve, vc, lib, _lib, dl, lens, args, seed=i, comm=comm, probe_layer=0,
+                                time_scans=args.warmup == 0, sharded=sharded))
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -250,56 +375,55 @@ def main():
 
     if rank == 0:
         K = max(1, args.steps)
-        total_contigs = args.contigs * world * K
+        job_contigs = args.contigs if strong else args.contigs * world
         D = args.samples + NTNF + 1
-        probe_ms = sum(r["probe_ms"] for r in results)
-        probe_n = sum(r["probe_launches"] for r in results)
-        flops = results[-1]["probe_flops"] if results else 0.0
-        avg_ms = probe_ms / probe_n if probe_n else float("nan")
-        achieved = flops / (avg_ms * 1e-3) / 1e12 if probe_n else float("nan")
-        bf16 = ve.get_compute_dtype() == "bf16"
+        bf16 = args.dtype == "bf16"
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-        shape = (args.contigs, args.samples, args.batch, args.latent)
-        cfg_name = {(200_000, 50, 4096, 32): "C1", (2_000_000, 200, 8192, 32): "C2",
-                    (2_000_000, 1000, 8192, 32): "C3", (10_000_000, 1000, 8192, 64): "C4"}.get(shape, "custom")
+        shape = (args.contigs, args.samples, args.batch, args.latent, args.dtype)
+        cfg_name = next((k for k, v in CONFIGS.items() if v == shape), "custom")
         scan_src = warm if warm else results          # the steps that ran with scan-kernel timing on
         scan_ms = sum(r["scan_kernel_ms"] for r in scan_src)
         scan_bytes = sum(r["scan_bytes"] for r in scan_src)
+        arith = "bf16 storage + bf16 MFMA / fp32 accumulate" if bf16 else "fp32 MFMA"
+        gemm_kind = "gemm_bf16_kernel<128,128,2x2 waves,E16_HIDDEN_TRAIN>" if bf16 else "gemm_f32_kernel<64,64,2x2 waves,EPI_HIDDEN_TRAIN>"
+        roof = probe_roofline(results, f"{gemm_kind}: encoder layer 0, M=batch={args.batch}, K=D={D}, N=512 "
+                                       "(bias + leaky-relu + dropout + BatchNorm batch sums in the epilogue)", peak)
+        if roof is not None:
+            roof["traffic"] = pmc_traffic(cfg_name.lower())
         line = {
             "metric": "contigs/sec through VAE-train+encode+cluster; VAE epoch step time",
-            "value": total_contigs / elapsed,
+            "value": job_contigs * K / elapsed,
             "unit": "contigs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"{cfg_name}: {args.contigs} contigs x {args.samples} samples per GPU (D={D}), hidden 512-512, "
-                             f"latent {args.latent}, batch {args.batch}, {'bf16 MFMA / fp32 accumulate' if bf16 else 'fp32 MFMA'}; "
-                             f"{args.epochs} train epochs "
-                             f"(reference CLI default) + encode + full cluster sweep per step"),
-                "contigs_per_gpu": args.contigs, "samples": args.samples, "batch": args.batch,
-                "epochs": args.epochs, "parallelism": f"dp{world}" if world > 1 else "single",
+                "workload": (f"{cfg_name}: {args.contigs} contigs x {args.samples} samples "
+                             f"{'in total' if strong else 'per GPU'} (D={D}), hidden 512-512, latent {args.latent}, "
+                             f"batch {args.batch} per GPU, {arith}; {args.epochs} train epochs"
+                             f"{' (reference CLI default)' if args.epochs == 300 else ' (reference CLI default is 300)'}"
+                             " + encode + full cluster sweep per step; features resident in HBM before the clock starts "
+                             "(host normalisation + one H2D upload outside the timed region)"),
+                "contigs_per_gpu": args.contigs if not strong else args.contigs // world, "samples": args.samples,
+                "batch": args.batch, "epochs": args.epochs,
+                "parallelism": (f"dp{world}" + ("+sharded-cluster" if strong else "")) if world > 1 else "single",
             },
-            "roofline": {
-                "kernel": ("gemm_f32_kernel<64,64,2x2 waves,EPI_HIDDEN_TRAIN,XF_BN> (encoder layer 1, the FLOP-dominant "
-                           "encoder GEMM: M=batch, K=512, N=512; BatchNorm of layer 0 applied on load, "
-                           "bias+leaky-relu+dropout+BN batch sums in the epilogue)"),
-                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak if probe_n else None, "traffic": pmc_traffic() if cfg_name == "C1" else None,
-                "avg_launch_ms": avg_ms, "launches": probe_n, "flops_per_launch": flops,
-                "timing": "kernel begin/end timestamps (hipExtLaunchKernelGGL start/stop events) of every launch in the timed steps",
-            },
-            "roofline_layer0": layer0_roofline(warm),
-            "epoch_ms": np.mean([r["train_s"] for r in results]) / args.epochs * 1e3,
-            "train_contigs_per_s_per_epoch": args.contigs * world / (np.mean([r["train_s"] for r in results]) / args.epochs),
-            "encode_ms": np.mean([r["encode_s"] for r in results]) * 1e3,
-            "cluster_ms": np.mean([r["cluster_s"] for r in results]) * 1e3,
+            "roofline": roof,
+            "roofline_hidden": probe_roofline(warm, f"{gemm_kind}: encoder layer 1, M=batch={args.batch}, K=512, N=512 "
+                                                    "(the GEMM shape that dominates the step), warm-up steps", peak),
+            "epoch_ms": float(np.mean([r["train_s"] for r in results]) / args.epochs * 1e3),
+            "us_per_train_step": float(np.mean([r["train_s"] for r in results]) / args.epochs /
+                                       max(1, (args.contigs if not strong else args.contigs // world) // args.batch) * 1e6),
+            "train_contigs_per_s_per_epoch": float(job_contigs / (np.mean([r["train_s"] for r in results]) / args.epochs)),
+            "train_s": float(np.mean([r["train_s"] for r in results])),
+            "encode_ms": float(np.mean([r["encode_s"] for r in results]) * 1e3),
+            "cluster_ms": float(np.mean([r["cluster_s"] for r in results]) * 1e3),
             "clusters_per_step": int(np.mean([r["clusters"] for r in results])),
             "cluster_scan": {
                 "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBPS,
@@ -311,8 +435,22 @@ def main():
             },
             "final_loss": results[-1]["loss"] if results else None,
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args, results[-1]["latent"], lens)
+        if world == 1 and not args.no_c3 and cfg_name != "C3":
+            # free the C2 dataset first (host arrays + the device copy cached on the loader)
+            latent_keep = results[-1]["latent"][: args.cpu_sample].copy() if results else None
+            lens_keep = lens[: args.cpu_sample].copy()
+            for r in results + warm:
+                r.pop("latent", None)
+            del dl, ab, tnf
+            try:
+                line["c3_shape"] = c3_shape_leg(args, ve, lib, _lib, synth)
+            except Exception as e:   # never lose the headline because of the extra leg
+                line["c3_shape"] = {"error": repr(e)}
+        else:
+            latent_keep = results[-1]["latent"] if results else None
+            lens_keep = lens
+        if not args.no_cpu_baseline and world == 1 and latent_keep is not None:
+            line["cpu_baseline"] = cpu_baseline(args, latent_keep, lens_keep)
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None
         emit_result(line)

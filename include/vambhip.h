@@ -272,9 +272,11 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
  * the host; C[m][n] = sum_k A[m][k] B[n][k].  epi: 0 = split-K fp32 slabs (summed on return), 1 = fp32 + bias,
  * 3 = hidden-layer epilogue without dropout: C = bf16(leaky_relu(acc + bias)) as float, CT (optional) the transposed
  * bf16 copy [N][M] as float, stats (optional) [2][N] the fp64 batch sums of C and C^2.  The tile is chosen from the
- * output shape as in the training step.  *ms = average duration of `reps` back-to-back launches. */
+ * output shape as in the training step (variant 0) or forced (variant 1..6: the tile / pipeline variants listed in
+ * csrc/vae_step16.hpp; + 256 * flags switches parts of the epilogue off for timing experiments, results then wrong).
+ * *ms = average duration of `reps` back-to-back launches. */
 int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, float* C, float* CT, double* stats, int M,
-                    int N, int K, int splits, int reps, float* ms);
+                    int N, int K, int splits, int reps, int variant, float* ms);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ for what, epi, M, N, K, splits in shapes:
     bias = np.zeros(N, np.float32)
     C = np.zeros((M, N), np.float32)
     ms = ctypes.c_float()
-    _lib.check(lib.vh_debug_gemm16(epi, _lib.ptr(A), _lib.ptr(B), _lib.ptr(bias), _lib.ptr(C), None, None, M, N, K, splits, 50,
+    _lib.check(lib.vh_debug_gemm16(epi, _lib.ptr(A), _lib.ptr(B), _lib.ptr(bias), _lib.ptr(C), None, None, M, N, K, splits, 50, 0,
                                    ctypes.byref(ms)))
     tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
     rows.append(dict(what=what, epi=epi, M=M, N=N, K=K, splits=splits, us=ms.value * 1e3, tflops=tf, frac_bf16_peak=tf / 2500.0))

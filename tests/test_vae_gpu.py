@@ -93,7 +93,7 @@ def bf16_round(x):
     return u.astype(np.uint32).view(np.float32)
 
 
-def _gemm16(epi, A, B, bias=None, splits=1, want_t=False, want_stats=False):
+def _gemm16(epi, A, B, bias=None, splits=1, want_t=False, want_stats=False, variant=0):
     M, K = A.shape
     N = B.shape[0]
     C = np.zeros((M, N), np.float32)
@@ -102,7 +102,7 @@ def _gemm16(epi, A, B, bias=None, splits=1, want_t=False, want_stats=False):
     ms = ctypes.c_float()
     _lib.check(_lib.load().vh_debug_gemm16(epi, _lib.ptr(np.ascontiguousarray(A)), _lib.ptr(np.ascontiguousarray(B)),
                                            _lib.ptr(bias), _lib.ptr(C), _lib.ptr(CT), _lib.ptr(stats), M, N, K, splits, 1,
-                                           ctypes.byref(ms)))
+                                           variant, ctypes.byref(ms)))
     return C, CT, stats
 
 

@@ -103,7 +103,7 @@ SIGNATURES = {
     "vh_vae_train_epoch_dp": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, ctypes.POINTER(ctypes.c_double)]),
     "vh_debug_gemm": (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _int, _int, _int, _int,
                              ctypes.POINTER(_f32)]),
-    "vh_debug_gemm16": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int,
+    "vh_debug_gemm16": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,
                                ctypes.POINTER(_f32)]),
 }
 

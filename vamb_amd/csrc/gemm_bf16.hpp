@@ -85,6 +85,7 @@ struct Gemm16Args {
     BnSrc bnC;
     double* bstat_out;     // [2][N]
     int xcd_remap;
+    int dbg;               // timing experiments (vh_debug_gemm16): 1 no fp64 atomics, 2 no transposed copy, 4 no row-major copy
 };
 
 __device__ __forceinline__ bf16_t f2bf(float x) {
@@ -101,7 +102,7 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_wav
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Args g) {
     constexpr int NWAVE = WM * WN;
     constexpr int NT = NWAVE * 64;
@@ -115,8 +116,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
     // ALL LDS of the kernel is this one array (a second __shared__ object makes hipcc drain the DMA queue
     // in front of every fragment read)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
-    unsigned char* const As = smem16;                  // [2][A_BYTES]
-    unsigned char* const Bs = smem16 + 2 * A_BYTES;    // [2][B_BYTES]
+    static_assert(STAGES == 2 || STAGES == 3, "two or three LDS buffers per operand");
+    unsigned char* const As = smem16;                       // [STAGES][A_BYTES]
+    unsigned char* const Bs = smem16 + STAGES * A_BYTES;    // [STAGES][B_BYTES]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -226,20 +228,43 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
         __builtin_amdgcn_sched_barrier(0);   // the barrier (and its DMA drain) stays BEHIND the MFMAs
     };
 
-    // K loop, unrolled by two so that every LDS address is a compile-time offset of the one array
-    if (nk > 0) stage(As, Bs, kbeg);
-    __syncthreads();   // (hipcc drains the DMA queue in front of this barrier)
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        stage(As + A_BYTES, Bs + B_BYTES, kbeg + (kt + 1) * BK);
-        compute(As, Bs);
-        __syncthreads();
-        if (kt + 2 < nk) stage(As, Bs, kbeg + (kt + 2) * BK);
-        compute(As + A_BYTES, Bs + B_BYTES);
-        __syncthreads();
-    }
-    if (kt < nk) {   // odd number of K-tiles: the last one sits in buffer 0
-        compute(As, Bs);
+    if constexpr (STAGES == 2) {
+        // K loop, unrolled by two so that every LDS address is a compile-time offset of the one array
+        if (nk > 0) stage(As, Bs, kbeg);
+        __syncthreads();   // (hipcc drains the DMA queue in front of this barrier)
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            stage(As + A_BYTES, Bs + B_BYTES, kbeg + (kt + 1) * BK);
+            compute(As, Bs);
+            __syncthreads();
+            if (kt + 2 < nk) stage(As, Bs, kbeg + (kt + 2) * BK);
+            compute(As + A_BYTES, Bs + B_BYTES);
+            __syncthreads();
+        }
+        if (kt < nk) {   // odd number of K-tiles: the last one sits in buffer 0
+            compute(As, Bs);
+            __syncthreads();
+        }
+    } else {
+        // Three buffers: the DMA of K-tile t + 2 is issued before K-tile t is multiplied and stays in flight ACROSS the
+        // barrier that ends K-tile t (counted vmcnt + raw s_barrier; __syncthreads() would drain the queue).  A wave's
+        // own vmcnt covers its own pieces; the barrier extends that to every wave's pieces of the tile.
+        constexpr int PIECES = RA + RB;   // DMA instructions per wave and K-tile
+        if (nk > 0) stage(As, Bs, kbeg);
+        if (nk > 1) stage(As + A_BYTES, Bs + B_BYTES, kbeg + BK);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;   // buffer of K-tile kt
+        for (int kt = 0; kt < nk; ++kt) {
+            const int nxt2 = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
+            if (kt + 2 < nk) stage(As + nxt2 * A_BYTES, Bs + nxt2 * B_BYTES, kbeg + (kt + 2) * BK);
+            compute(As + cur * A_BYTES, Bs + cur * B_BYTES);
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur = cur == 2 ? 0 : cur + 1;
+        }
         __syncthreads();
     }
 
@@ -346,7 +371,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                         if constexpr (EPI == E16_HIDDEN_TRAIN) {
                             // transposed copy: 4 consecutive rows of this lane's column = 8 contiguous bytes of C16T
                             const int row4 = m0 + rl4;
-                            if (g.C16T != nullptr && col_ok && row4 < g.M) {
+                            if (g.C16T != nullptr && col_ok && row4 < g.M && !(g.dbg & 2)) {
                                 uint2 w;
                                 w.x = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16);
                                 w.y = (uint32_t)hb[2] | ((uint32_t)hb[3] << 16);
@@ -437,7 +462,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
 #pragma unroll
             for (int p = 0; p < BM / RPP; ++p) {
                 const int rl = r0 + RPP * p, row = m0 + rl;
-                if (row < g.M && col8 < g.N)
+                if (row < g.M && col8 < g.N && !(g.dbg & 4))
                     *reinterpret_cast<uint4*>(g.C16 + (int64_t)row * g.ldc16 + col8) =
                         *reinterpret_cast<const uint4*>(ct + rl * CP + 8 * cc);
             }
@@ -447,7 +472,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                     float s = 0.f;
 #pragma unroll
                     for (int w = 0; w < WM; ++w) s += red[(stat * WM + w) * BN + cb];
-                    if (n0 + cb < g.N) atomicAdd(&g.fstat_out[(int64_t)stat * g.N + n0 + cb], (double)s);
+                    if (n0 + cb < g.N && !(g.dbg & 1)) atomicAdd(&g.fstat_out[(int64_t)stat * g.N + n0 + cb], (double)s);
                 }
             }
         }
@@ -455,9 +480,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
 }
 
 // dynamic LDS bytes of an instantiation: the operand buffers, or the output image + reduction scratch if larger
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2>
 constexpr size_t gemm16_smem_bytes() {
-    size_t ops = 2 * (size_t)(BM + BN) * 128;
+    size_t ops = (size_t)STAGES * (BM + BN) * 128;
     if (EPI == E16_SPLITK || EPI == E16_BIAS || EPI == E16_LATENT_MASK) return ops;
     const size_t img = (size_t)BM * (BN + 8) * 2;
     const size_t nt = (size_t)WM * WN * 64, rpp = nt / (BN / 8);

@@ -1786,7 +1786,7 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
 }
 
 int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, float* C, float* CT, double* stats, int M,
-                    int N, int K, int splits, int reps, float* ms) {
+                    int N, int K, int splits, int reps, int variant, float* ms) {
     return guarded([&] {
         VH_REQUIRE(A && B && C, "NULL argument");
         VH_REQUIRE(epi == E16_SPLITK || epi == E16_BIAS || epi == E16_HIDDEN_TRAIN, "epi in {0 split-K, 1 bias, 3 hidden}");
@@ -1826,10 +1826,13 @@ int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, 
         g.k_per_split = k_per; g.slab_stride = (int64_t)M * N; g.zeros = dz.p;
         g.C32 = dC32.p; g.ldc32 = N; g.C16 = dC16.p; g.ldc16 = N; g.C16T = dC16T.p; g.ldc16t = M;
         g.bias = dbias.p; g.m_real = M; g.fstat_out = dstat.p; g.drop_scale = 1.0f; g.xcd_remap = 1;
+        const int tile = variant & 0xFF;
+        g.dbg = variant >> 8;
+        VH_REQUIRE(tile >= 0 && tile <= 6, "variant: tile 0..6 (+ 256 * timing-experiment flags)");
         auto run = [&] {
-            if (epi == E16_SPLITK) step16::gemm16<E16_SPLITK>(s, g, nsplit);
-            else if (epi == E16_BIAS) step16::gemm16<E16_BIAS>(s, g, 1);
-            else step16::gemm16<E16_HIDDEN_TRAIN>(s, g, 1);
+            if (epi == E16_SPLITK) step16::gemm16_variant<E16_SPLITK>(s, tile, g, nsplit);
+            else if (epi == E16_BIAS) step16::gemm16_variant<E16_BIAS>(s, tile, g, 1);
+            else step16::gemm16_variant<E16_HIDDEN_TRAIN>(s, tile, g, 1);
         };
         run();   // warm-up (sets the LDS attribute)
         VH_HIP(hipMemsetAsync(dstat.p, 0, dstat.bytes(), s));

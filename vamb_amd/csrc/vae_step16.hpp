@@ -15,11 +15,11 @@ namespace step16 {
 
 constexpr int kDwTargetWgs = 128;   // workgroups wanted per weight-gradient GEMM (they share the chip with the dX chain)
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2>
 void launch_gemm16(hipStream_t stream, const Gemm16Args& g, int splits) {
     static bool attr_set = false;
-    constexpr size_t smem = gemm16_smem_bytes<BM, BN, WM, WN, EPI>();
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI>;
+    constexpr size_t smem = gemm16_smem_bytes<BM, BN, WM, WN, EPI, STAGES>();
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STAGES>;
     if (!attr_set) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kMaxDynLds));
@@ -50,6 +50,22 @@ void gemm16(hipStream_t s, const Gemm16Args& g, int splits) {
         launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
     } else {
         launch_gemm16<128, 128, 2, 2, EPI>(s, g, splits);
+    }
+}
+
+// every tile / pipeline variant of one epilogue (vh_debug_gemm16): 0 = the production choice by output shape,
+// 1 = 128x128 / 8 waves (2x4), 2 = 256x128 / 8 waves (4x2), 3 = 64x128 / 4 waves, 4 = 128x64 / 4 waves,
+// 5 = 128x128 / 4 waves with three LDS buffers, 6 = 128x128 / 8 waves with three LDS buffers
+template <int EPI>
+void gemm16_variant(hipStream_t s, int tile, const Gemm16Args& g, int splits) {
+    switch (tile) {
+        case 1: launch_gemm16<128, 128, 2, 4, EPI>(s, g, splits); break;
+        case 2: launch_gemm16<256, 128, 4, 2, EPI>(s, g, splits); break;
+        case 3: launch_gemm16<64, 128, 2, 2, EPI>(s, g, splits); break;
+        case 4: launch_gemm16<128, 64, 2, 2, EPI>(s, g, splits); break;
+        case 5: launch_gemm16<128, 128, 2, 2, EPI, 3>(s, g, splits); break;
+        case 6: launch_gemm16<128, 128, 2, 4, EPI, 3>(s, g, splits); break;
+        default: gemm16<EPI>(s, g, splits); break;
     }
 }
 
