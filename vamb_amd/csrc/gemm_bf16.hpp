@@ -29,8 +29,8 @@
 //                   of h and h^2 (of the ROUNDED values: the statistics every consumer of C16 sees)
 //   E16_HIDDEN_EVAL C16 = bf16(leaky_relu(acc + bias) * scale[n] + shift[n])
 //   E16_STORE_BNRED C16 = bf16(acc) (= dA of the layer below) + fp64 batch sums of dA and dA * xhat(Hbelow)
-// bf16 outputs leave through an LDS image of the tile and 16-byte row-major stores; the transposed copy goes
-// straight from the accumulator layout as 8-byte stores.
+// bf16 outputs leave through LDS images of the tile (row-major and, for the hidden-train epilogue, transposed) and
+// 16-byte stores (the transposed copy as direct 8-byte stores from the accumulator layout cost 4 us per GEMM more).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -102,7 +102,7 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_wav
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2>
+template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Args g) {
     constexpr int NWAVE = WM * WN;
     constexpr int NT = NWAVE * 64;
@@ -116,9 +116,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
     // ALL LDS of the kernel is this one array (a second __shared__ object makes hipcc drain the DMA queue
     // in front of every fragment read)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
-    static_assert(STAGES == 2 || STAGES == 3, "two or three LDS buffers per operand");
-    unsigned char* const As = smem16;                       // [STAGES][A_BYTES]
-    unsigned char* const Bs = smem16 + STAGES * A_BYTES;    // [STAGES][B_BYTES]
+    unsigned char* const As = smem16;                  // [2][A_BYTES]
+    unsigned char* const Bs = smem16 + 2 * A_BYTES;    // [2][B_BYTES]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -228,43 +227,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
         __builtin_amdgcn_sched_barrier(0);   // the barrier (and its DMA drain) stays BEHIND the MFMAs
     };
 
-    if constexpr (STAGES == 2) {
-        // K loop, unrolled by two so that every LDS address is a compile-time offset of the one array
-        if (nk > 0) stage(As, Bs, kbeg);
-        __syncthreads();   // (hipcc drains the DMA queue in front of this barrier)
-        int kt = 0;
-        for (; kt + 1 < nk; kt += 2) {
-            stage(As + A_BYTES, Bs + B_BYTES, kbeg + (kt + 1) * BK);
-            compute(As, Bs);
-            __syncthreads();
-            if (kt + 2 < nk) stage(As, Bs, kbeg + (kt + 2) * BK);
-            compute(As + A_BYTES, Bs + B_BYTES);
-            __syncthreads();
-        }
-        if (kt < nk) {   // odd number of K-tiles: the last one sits in buffer 0
-            compute(As, Bs);
-            __syncthreads();
-        }
-    } else {
-        // Three buffers: the DMA of K-tile t + 2 is issued before K-tile t is multiplied and stays in flight ACROSS the
-        // barrier that ends K-tile t (counted vmcnt + raw s_barrier; __syncthreads() would drain the queue).  A wave's
-        // own vmcnt covers its own pieces; the barrier extends that to every wave's pieces of the tile.
-        constexpr int PIECES = RA + RB;   // DMA instructions per wave and K-tile
-        if (nk > 0) stage(As, Bs, kbeg);
-        if (nk > 1) stage(As + A_BYTES, Bs + B_BYTES, kbeg + BK);
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int cur = 0;   // buffer of K-tile kt
-        for (int kt = 0; kt < nk; ++kt) {
-            const int nxt2 = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
-            if (kt + 2 < nk) stage(As + nxt2 * A_BYTES, Bs + nxt2 * B_BYTES, kbeg + (kt + 2) * BK);
-            compute(As + cur * A_BYTES, Bs + cur * B_BYTES);
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            cur = cur == 2 ? 0 : cur + 1;
-        }
+    // K loop, unrolled by two so that every LDS address is a compile-time offset of the one array.  (A third buffer with
+    // the DMA of tile t + 2 in flight across the barrier measured 0-8 % slower: the loop is bound by the per-CU LDS-DMA
+    // rate, not by its latency.)
+    if (nk > 0) stage(As, Bs, kbeg);
+    __syncthreads();   // (hipcc drains the DMA queue in front of this barrier)
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        stage(As + A_BYTES, Bs + B_BYTES, kbeg + (kt + 1) * BK);
+        compute(As, Bs);
+        __syncthreads();
+        if (kt + 2 < nk) stage(As, Bs, kbeg + (kt + 2) * BK);
+        compute(As + A_BYTES, Bs + B_BYTES);
+        __syncthreads();
+    }
+    if (kt < nk) {   // odd number of K-tiles: the last one sits in buffer 0
+        compute(As, Bs);
         __syncthreads();
     }
 
@@ -298,7 +276,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
         constexpr int CP = BN + 8;                         // elements per image row (keeps 16-byte alignment)
         constexpr int CT_BYTES = BM * CP * 2;
         bf16_t* const ct = reinterpret_cast<bf16_t*>(smem16);
-        float* const red = reinterpret_cast<float*>(smem16 + CT_BYTES);   // reduction scratch behind the image
+        // second image, transposed [BN][CPT], for the transposed copy (hidden-train epilogue only)
+        constexpr int CPT = BM + 8;
+        constexpr int CTT_BYTES = EPI == E16_HIDDEN_TRAIN ? BN * CPT * 2 : 0;
+        bf16_t* const ctT = reinterpret_cast<bf16_t*>(smem16 + CT_BYTES);
+        float* const red = reinterpret_cast<float*>(smem16 + CT_BYTES + CTT_BYTES);   // reduction scratch behind the images
         float s1[TN], s2[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
@@ -369,14 +351,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                             ct[rl * CP + cl] = b;
                         }
                         if constexpr (EPI == E16_HIDDEN_TRAIN) {
-                            // transposed copy: 4 consecutive rows of this lane's column = 8 contiguous bytes of C16T
-                            const int row4 = m0 + rl4;
-                            if (g.C16T != nullptr && col_ok && row4 < g.M && !(g.dbg & 2)) {
-                                uint2 w;
-                                w.x = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16);
-                                w.y = (uint32_t)hb[2] | ((uint32_t)hb[3] << 16);
-                                *reinterpret_cast<uint2*>(g.C16T + (int64_t)col * g.ldc16t + row4) = w;
-                            }
+                            // transposed image: 4 consecutive rows of this lane's column are 8 contiguous bytes
+                            uint2 w;
+                            w.x = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16);
+                            w.y = (uint32_t)hb[2] | ((uint32_t)hb[3] << 16);
+                            *reinterpret_cast<uint2*>(ctT + cl * CPT + rl4) = w;
                         }
                     }
                 }
@@ -467,6 +446,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                         *reinterpret_cast<const uint4*>(ct + rl * CP + 8 * cc);
             }
             if constexpr (EPI == E16_HIDDEN_TRAIN) {
+                // transposed copy: 16-byte chunks of 8 rows, consecutive threads along the rows of one column
+                if (g.C16T != nullptr && !(g.dbg & 2)) {
+                    constexpr int CPC = BM / 8;   // chunks per column
+                    for (int idx = tid; idx < BN * CPC; idx += NT) {
+                        const int c = idx / CPC, mc = idx % CPC;
+                        if (n0 + c < g.N && m0 + 8 * mc < g.M)
+                            *reinterpret_cast<uint4*>(g.C16T + (int64_t)(n0 + c) * g.ldc16t + m0 + 8 * mc) =
+                                *reinterpret_cast<const uint4*>(ctT + c * CPT + 8 * mc);
+                    }
+                }
                 for (int t = tid; t < 2 * BN; t += NT) {
                     const int stat = t / BN, cb = t % BN;
                     float s = 0.f;
@@ -480,11 +469,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
 }
 
 // dynamic LDS bytes of an instantiation: the operand buffers, or the output image + reduction scratch if larger
-template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2>
+template <int BM, int BN, int WM, int WN, int EPI>
 constexpr size_t gemm16_smem_bytes() {
-    size_t ops = (size_t)STAGES * (BM + BN) * 128;
+    size_t ops = 2 * (size_t)(BM + BN) * 128;
     if (EPI == E16_SPLITK || EPI == E16_BIAS || EPI == E16_LATENT_MASK) return ops;
-    const size_t img = (size_t)BM * (BN + 8) * 2;
+    const size_t img = (size_t)BM * (BN + 8) * 2 + (EPI == E16_HIDDEN_TRAIN ? (size_t)BN * (BM + 8) * 2 : 0);
     const size_t nt = (size_t)WM * WN * 64, rpp = nt / (BN / 8);
     const size_t red = EPI == E16_STORE_BNRED ? 2 * rpp * BN * 4 : 2 * (size_t)WM * BN * 4;
     return ops > img + red ? ops : img + red;

@@ -23,6 +23,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstddef>
+#include <functional>
 #include <map>
 #include <memory>
 #include <random>
@@ -329,7 +330,8 @@ int dw_splits16(int M, int N, int K);
 void prepare_batch16(vh_vae* h);
 void build_opt16_table(vh_vae* h);
 void refresh_shadows(vh_vae* h, int only);
-void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected, bool add_noise);
+struct SideQueue;
+void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected, bool add_noise, SideQueue* defer);
 void train_step16(vh_vae* h, const int64_t* dev_idx, bool eps_injected, bool masks_injected);
 void encode16(vh_vae* h, float* latent);
 }  // namespace step16
@@ -1586,7 +1588,7 @@ int vh_vae_forward(vh_vae* h, const float* depths, const float* tnf, const float
             hipLaunchKernelGGL(vae_cast16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n4, 256), 4096)), dim3(256), 0,
                                h->stream, h->Xb.p, h->Xb16.p, n4);
             VH_HIP(hipGetLastError());
-            step16::forward16(h, training != 0, eps != nullptr, inj_masks, true);
+            step16::forward16(h, training != 0, eps != nullptr, inj_masks, true, nullptr);
         } else {
             forward(h, training != 0, eps != nullptr, inj_masks, true);
         }
@@ -1828,7 +1830,7 @@ int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, 
         g.bias = dbias.p; g.m_real = M; g.fstat_out = dstat.p; g.drop_scale = 1.0f; g.xcd_remap = 1;
         const int tile = variant & 0xFF;
         g.dbg = variant >> 8;
-        VH_REQUIRE(tile >= 0 && tile <= 6, "variant: tile 0..6 (+ 256 * timing-experiment flags)");
+        VH_REQUIRE(tile == 0 || tile == 1 || tile == 3 || tile == 4 || tile == 7, "variant: tile 0, 1, 3, 4 or 7 (+ 256 * timing-experiment flags)");
         auto run = [&] {
             if (epi == E16_SPLITK) step16::gemm16_variant<E16_SPLITK>(s, tile, g, nsplit);
             else if (epi == E16_BIAS) step16::gemm16_variant<E16_BIAS>(s, tile, g, 1);

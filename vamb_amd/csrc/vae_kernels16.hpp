@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void vae_transpose16_kernel(const bf16_t* __re
 // bias_out[n] = bias[n] + sum_k W[n][k] t_k.  One wavefront per weight row; s, t are rebuilt per workgroup.
 // from_running != 0: eval mode, s / t from the running statistics (scale_in / shift_in precomputed by
 // vae_bn_eval_coeff_kernel).
+constexpr int kFoldRowsPerWave = 4;   // 16 weight rows per workgroup: the per-workgroup rebuild of s, t is the fixed cost
 __global__ __launch_bounds__(256) void vae_fold_bn_kernel(const float* __restrict__ W, int64_t ldw, int n_rows, int K,
                                                           const float* __restrict__ bias, const BnSrc bn,
                                                           const float* __restrict__ scale_in,
@@ -138,20 +139,23 @@ __global__ __launch_bounds__(256) void vae_fold_bn_kernel(const float* __restric
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= n_rows) return;
-    const float* w = W + (int64_t)n * ldw;
-    bf16_t* o = W16 + (int64_t)n * ldw;
-    float dot = 0.f;
-    for (int k = 4 * lane; k < K; k += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(w + k);
-        const float4 s4 = *reinterpret_cast<const float4*>(s_s + k);
-        const float4 t4 = *reinterpret_cast<const float4*>(t_s + k);
-        dot += v.x * t4.x + v.y * t4.y + v.z * t4.z + v.w * t4.w;
-        *reinterpret_cast<uint2*>(o + k) = make_uint2(pack_bf2(v.x * s4.x, v.y * s4.y), pack_bf2(v.z * s4.z, v.w * s4.w));
+#pragma unroll 1
+    for (int r = 0; r < kFoldRowsPerWave; ++r) {
+        const int n = (blockIdx.x * 4 + wave) * kFoldRowsPerWave + r;
+        if (n >= n_rows) return;
+        const float* w = W + (int64_t)n * ldw;
+        bf16_t* o = W16 + (int64_t)n * ldw;
+        float dot = 0.f;
+        for (int k = 4 * lane; k < K; k += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(w + k);
+            const float4 s4 = *reinterpret_cast<const float4*>(s_s + k);
+            const float4 t4 = *reinterpret_cast<const float4*>(t_s + k);
+            dot += v.x * t4.x + v.y * t4.y + v.z * t4.z + v.w * t4.w;
+            *reinterpret_cast<uint2*>(o + k) = make_uint2(pack_bf2(v.x * s4.x, v.y * s4.y), pack_bf2(v.z * s4.z, v.w * s4.w));
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) bias_out[n] = bias[n] + dot;
     }
-    dot = wave_sum(dot);
-    if (lane == 0) bias_out[n] = bias[n] + dot;
 }
 
 // ---- bf16 shadows of the weights (init / set_param; during training the optimiser writes them itself) --------------
@@ -214,6 +218,9 @@ struct Loss16Args {
 };
 
 __global__ __launch_bounds__(256) void vae_loss16_kernel(const Loss16Args a) {
+    // dynamic LDS: per wave the reconstruction row and the target row, read from HBM once with 16-byte loads (the
+    // softmax / CE / SSE passes below re-read them four times)
+    extern __shared__ __attribute__((aligned(16))) float loss_rows[];   // [4 waves][2][ld]
     __shared__ float red[4][4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
@@ -225,8 +232,16 @@ __global__ __launch_bounds__(256) void vae_loss16_kernel(const Loss16Args a) {
             for (int c = lane; c < a.ld; c += 64) dr[c] = 0;
             for (int c = lane; c < a.ldl; c += 64) dm[c] = 0.f;
         } else {
-            const float* r = a.R + (int64_t)row * a.ld;
-            const float* x = a.X + (int64_t)row * a.ld;
+            float* r = loss_rows + (size_t)wave * 2 * a.ld;
+            float* x = r + a.ld;
+            {
+                const float4* rg = reinterpret_cast<const float4*>(a.R + (int64_t)row * a.ld);
+                const float4* xg = reinterpret_cast<const float4*>(a.X + (int64_t)row * a.ld);
+                for (int c = lane; c < (int)(a.ld / 4); c += 64) {
+                    reinterpret_cast<float4*>(r)[c] = rg[c];
+                    reinterpret_cast<float4*>(x)[c] = xg[c];
+                }
+            }
             const float g = a.inv_b2;
             const int S = a.S;
             float mx = -3.0e38f;
@@ -318,29 +333,10 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
     __shared__ float cf[3][kDz16Cols];
     const int tid = threadIdx.x;
     const int col0 = blockIdx.x * kDz16Cols, row0 = blockIdx.y * kDz16Rows;
-    if (tid < kDz16Cols) {
-        const int col = col0 + tid;
-        float ca = 0.f, ch = 0.f, c0 = 0.f;
-        if (col < a.n_p) {
-            float mean, istd, sc, sh;
-            bn_column(a.bn, col, mean, istd, sc, sh);
-            const double inv_bs = 1.0 / (double)a.bs;
-            const float c1 = (float)(a.bstat[col] * inv_bs);
-            const float c2 = (float)(a.bstat[a.n_p + col] * inv_bs);
-            ca = a.drop_scale * istd * a.bn.gamma[col];
-            ch = -ca * istd * c2;
-            c0 = -ca * c1 - ch * mean;
-        }
-        cf[0][tid] = ca; cf[1][tid] = ch; cf[2][tid] = c0;
-    }
-    __syncthreads();
     const int c8 = (tid & 15) * 8;          // this thread's 8 columns inside the tile
     const int rt = tid >> 4;                // row lane 0..15
     const int col = col0 + c8;
-    const bool hashed_drop = (a.drop_scale != 1.0f) && (a.drop_mask == nullptr);
-    float ca[8], ch[8], c0[8], s[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { ca[e] = cf[0][c8 + e]; ch[e] = cf[1][c8 + e]; c0[e] = cf[2][c8 + e]; s[e] = 0.f; }
+    // the thread's 16-byte loads go out first; the per-column coefficients (fp64 statistics) are formed underneath them
     constexpr int PASS = kDz16Rows / 16;
     uint4 da[PASS], hh[PASS];
 #pragma unroll
@@ -354,6 +350,26 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
             hh[p] = *reinterpret_cast<const uint4*>(a.H + i);
         }
     }
+    if (tid < kDz16Cols) {
+        const int colc = col0 + tid;
+        float ca = 0.f, ch = 0.f, c0 = 0.f;
+        if (colc < a.n_p) {
+            float mean, istd, sc, sh;
+            bn_column(a.bn, colc, mean, istd, sc, sh);
+            const double inv_bs = 1.0 / (double)a.bs;
+            const float c1 = (float)(a.bstat[colc] * inv_bs);
+            const float c2 = (float)(a.bstat[a.n_p + colc] * inv_bs);
+            ca = a.drop_scale * istd * a.bn.gamma[colc];
+            ch = -ca * istd * c2;
+            c0 = -ca * c1 - ch * mean;
+        }
+        cf[0][tid] = ca; cf[1][tid] = ch; cf[2][tid] = c0;
+    }
+    __syncthreads();
+    const bool hashed_drop = (a.drop_scale != 1.0f) && (a.drop_mask == nullptr);
+    float ca[8], ch[8], c0[8], s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ca[e] = cf[0][c8 + e]; ch[e] = cf[1][c8 + e]; c0[e] = cf[2][c8 + e]; s[e] = 0.f; }
 #pragma unroll
     for (int p = 0; p < PASS; ++p) {
         const int rl = rt + 16 * p, r = row0 + rl;

@@ -13,13 +13,13 @@
 
 namespace step16 {
 
-constexpr int kDwTargetWgs = 128;   // workgroups wanted per weight-gradient GEMM (they share the chip with the dX chain)
+constexpr int kDwTargetWgs = 256;   // workgroups wanted per weight-gradient GEMM (they share the chip with the dX chain)
 
-template <int BM, int BN, int WM, int WN, int EPI, int STAGES = 2>
+template <int BM, int BN, int WM, int WN, int EPI>
 void launch_gemm16(hipStream_t stream, const Gemm16Args& g, int splits) {
     static bool attr_set = false;
-    constexpr size_t smem = gemm16_smem_bytes<BM, BN, WM, WN, EPI, STAGES>();
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STAGES>;
+    constexpr size_t smem = gemm16_smem_bytes<BM, BN, WM, WN, EPI>();
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI>;
     if (!attr_set) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kMaxDynLds));
@@ -39,32 +39,34 @@ void launch_gemm16(hipStream_t stream, const Gemm16Args& g, int splits) {
     VH_HIP(hipGetLastError());
 }
 
-// tile by output shape: 128x128 (2x2 waves of 64x64), 128x32 for latent-wide outputs, 32x128 for latent-tall ones
+// Tile by output shape (measured, profiles/r02_gemm16_variants.json): batch-tall outputs take 128x128 tiles with 8 waves
+// (2x4, two per SIMD: one wave's DMA issue and fragment reads overlap the other's MFMAs), weight gradients 64x128 tiles
+// (twice the workgroups per split), 128x32 / 32x128 for latent-wide / latent-tall outputs.
 template <int EPI>
 void gemm16(hipStream_t s, const Gemm16Args& g, int splits) {
     if constexpr (EPI == E16_SPLITK) {
         if (g.N <= 32) launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
         else if (g.M <= 32) launch_gemm16<32, 128, 1, 4, EPI>(s, g, splits);
-        else launch_gemm16<128, 128, 2, 2, EPI>(s, g, splits);
+        else launch_gemm16<64, 128, 2, 2, EPI>(s, g, splits);
     } else if constexpr (EPI == E16_LATENT_MASK) {
         launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
     } else {
-        launch_gemm16<128, 128, 2, 2, EPI>(s, g, splits);
+        launch_gemm16<128, 128, 2, 4, EPI>(s, g, splits);
     }
 }
 
 // every tile / pipeline variant of one epilogue (vh_debug_gemm16): 0 = the production choice by output shape,
-// 1 = 128x128 / 8 waves (2x4), 2 = 256x128 / 8 waves (4x2), 3 = 64x128 / 4 waves, 4 = 128x64 / 4 waves,
-// 5 = 128x128 / 4 waves with three LDS buffers, 6 = 128x128 / 8 waves with three LDS buffers
+// 1 = 128x128 / 8 waves (2x4), 3 = 64x128 / 4 waves, 4 = 128x64 / 4 waves, 7 = 128x128 / 4 waves.  (Measured and
+// removed, profiles/r02_gemm16_variants.json: 256x128 / 8 waves -- half the workgroups, 20-30 % slower at M = 8192,
+// N = 512; three LDS buffers with counted vmcnt across a raw barrier -- 0-8 % slower: the K loop is bound by the
+// per-CU LDS-DMA rate, ~17 B/clk, not by DMA latency.)
 template <int EPI>
 void gemm16_variant(hipStream_t s, int tile, const Gemm16Args& g, int splits) {
     switch (tile) {
         case 1: launch_gemm16<128, 128, 2, 4, EPI>(s, g, splits); break;
-        case 2: launch_gemm16<256, 128, 4, 2, EPI>(s, g, splits); break;
         case 3: launch_gemm16<64, 128, 2, 2, EPI>(s, g, splits); break;
         case 4: launch_gemm16<128, 64, 2, 2, EPI>(s, g, splits); break;
-        case 5: launch_gemm16<128, 128, 2, 2, EPI, 3>(s, g, splits); break;
-        case 6: launch_gemm16<128, 128, 2, 4, EPI, 3>(s, g, splits); break;
+        case 7: launch_gemm16<128, 128, 2, 2, EPI>(s, g, splits); break;
         default: gemm16<EPI>(s, g, splits); break;
     }
 }
@@ -83,7 +85,7 @@ bf16_t* w16t(vh_vae* h, int t) { return h->W16T.p + h->tensors[t].off; }
 
 // split-K plan of a weight-gradient GEMM C[M][N] over K = bs_p: slabs of >= 512 batch rows, ~kDwTargetWgs workgroups
 int dw_splits16(int M, int N, int K) {
-    const int bm = M <= 32 ? 32 : 128, bn = N <= 32 ? 32 : 128;
+    const int bm = M <= 32 ? 32 : (N <= 32 ? 128 : 64), bn = N <= 32 ? 32 : 128;
     const int tiles = (int)(ceil_div(M, bm) * ceil_div(N, bn));
     int want = (int)std::max<int64_t>(1, ceil_div(kDwTargetWgs, tiles));
     want = std::min(want, std::max(1, K / 512));
@@ -95,6 +97,20 @@ void transpose16(vh_vae* h, hipStream_t s, const bf16_t* in, int R, int C, bf16_
                        dim3(256), 0, s, in, (int64_t)C, R, C, out, (int64_t)R, colsum, r_real);
     VH_HIP(hipGetLastError());
 }
+
+// Work that is off the critical path of a step (transposes of the narrow tensors, running statistics, the loss
+// reduction, weight-gradient GEMMs) is queued in program order and handed to the side stream at a few fork points
+// only: every cross-stream fork costs the main stream ~5 us (measured, profiles/r02_c_step_timeline.txt: one fork per
+// producing kernel = 9 forks = 45 us of a 350 us step).  An item may be flushed at any fork that follows the launch of
+// its last producer on the main stream.
+struct SideQueue {
+    std::vector<std::function<void(hipStream_t)>> items;
+    void add(std::function<void(hipStream_t)> f) { items.push_back(std::move(f)); }
+    void flush(hipStream_t s) {
+        for (auto& f : items) f(s);
+        items.clear();
+    }
+};
 
 // bf16 shadows of one parameter tensor (or all of them) from the fp32 masters: init, set_param, precision switch
 void refresh_shadows(vh_vae* h, int only) {
@@ -195,14 +211,14 @@ void build_opt16_table(vh_vae* h) {
 void fold_bn(vh_vae* h, hipStream_t s, int tW, int tb, int n_rows, int K, const Hidden& prev, bool training,
              bf16_t* Wf16, float* biasf) {
     BnSrc bn = bn_src(h, prev);
-    hipLaunchKernelGGL(vae_fold_bn_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), (size_t)2 * K * sizeof(float), s,
+    hipLaunchKernelGGL(vae_fold_bn_kernel, dim3((unsigned)ceil_div(n_rows, 4 * kFoldRowsPerWave)), dim3(256), (size_t)2 * K * sizeof(float), s,
                        h->pptr(tW), (int64_t)K, n_rows, K, h->pptr(tb), bn, training ? nullptr : prev.scale.p,
                        training ? nullptr : prev.shift.p, Wf16, biasf);
     VH_HIP(hipGetLastError());
 }
 
 // Xb / Xb16 / Wb must hold the batch.
-void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected, bool add_noise) {
+void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected, bool add_noise, SideQueue* defer) {
     const int bs = h->bs, bs_p = h->bs_p, nl = h->nl;
     hipStream_t s = h->stream;
     const DropCfg dc = drop_cfg(h, training, masks_injected);
@@ -276,17 +292,12 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
     {
         const int64_t tot = (int64_t)bs_p * h->L_p;
         const float* eps_ptr = eps_injected ? h->EPS.p : nullptr;
-        if (training) {   // the transposed latent code feeds the first decoder layer's weight gradient (side stream)
-            launch_forking(h, vae_reparam16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0,
-                           (const float*)h->skinny.p, mu_slabs, (int64_t)bs_p * h->L_p, mu_bias, eps_ptr, layer_key(h, 0xEE),
-                           step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z16.p, bs, h->L, h->L_p, bs_p);
-            transpose16(h, h->side, h->Z16.p, bs_p, h->L_p, h->Z16T.p, nullptr, 0);
-        } else {
-            hipLaunchKernelGGL(vae_reparam16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s,
-                               (const float*)h->skinny.p, mu_slabs, (int64_t)bs_p * h->L_p, mu_bias, eps_ptr,
-                               layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z16.p, bs, h->L, h->L_p, bs_p);
-            VH_HIP(hipGetLastError());
-        }
+        hipLaunchKernelGGL(vae_reparam16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s,
+                           (const float*)h->skinny.p, mu_slabs, (int64_t)bs_p * h->L_p, mu_bias, eps_ptr,
+                           layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z16.p, bs, h->L, h->L_p, bs_p);
+        VH_HIP(hipGetLastError());
+        // the transposed latent code feeds the first decoder layer's weight gradient
+        if (defer) defer->add([h, bs_p](hipStream_t st) { transpose16(h, st, h->Z16.p, bs_p, h->L_p, h->Z16T.p, nullptr, 0); });
     }
     in = h->Z16.p;
     in_w = h->L_p;
@@ -304,28 +315,33 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
         }
         g.C32 = h->R.p; g.ldc32 = h->D_p;
         g.M = bs_p; g.N = h->D_p; g.K = in_w; g.k_per_split = g.K;
-        const bool ext_fork = training && fork_from_kernel(h);
-        if (ext_fork) t_fork_stop = h->ev_fork;
         gemm16<E16_BIAS>(s, g, 1);
-        if (ext_fork) VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     }
     if (training) {
-        if (!fork_from_kernel(h)) fork_side(h);
-        RunningTable rt;
-        memset(&rt, 0, sizeof(rt));
-        int maxn = 0;
-        for (auto& hl : h->hidden) {
-            rt.fstat[rt.n] = hl.fstat; rt.rm[rt.n] = h->pptr(hl.tRM); rt.rv[rt.n] = h->pptr(hl.tRV);
-            rt.n_p[rt.n] = hl.nout_p;
-            maxn = std::max(maxn, hl.nout_p);
-            rt.n++;
+        // running statistics (momentum 0.1, unbiased variance): off the critical path
+        auto running = [h, bs](hipStream_t st) {
+            RunningTable rt;
+            memset(&rt, 0, sizeof(rt));
+            int maxn = 0;
+            for (auto& hl : h->hidden) {
+                rt.fstat[rt.n] = hl.fstat; rt.rm[rt.n] = h->pptr(hl.tRM); rt.rv[rt.n] = h->pptr(hl.tRV);
+                rt.n_p[rt.n] = hl.nout_p;
+                maxn = std::max(maxn, hl.nout_p);
+                rt.n++;
+            }
+            hipLaunchKernelGGL(vae_bn_running_kernel, dim3((unsigned)ceil_div(maxn, 256), rt.n), dim3(256), 0, st, rt, bs);
+            VH_HIP(hipGetLastError());
+        };
+        if (defer) {
+            defer->add(running);
+        } else {   // forward-only call: run it now
+            fork_side(h);
+            running(h->side);
         }
-        hipLaunchKernelGGL(vae_bn_running_kernel, dim3((unsigned)ceil_div(maxn, 256), rt.n), dim3(256), 0, h->side, rt, bs);
-        VH_HIP(hipGetLastError());
     }
 }
 
-void loss_and_seed16(vh_vae* h) {
+void loss_and_seed16(vh_vae* h, SideQueue& q) {
     const int bs_global = h->global_bs > 0 ? h->global_bs : h->bs;
     Loss16Args a;
     a.R = h->R.p; a.X = h->Xb.p; a.ld = h->D_p;
@@ -334,10 +350,23 @@ void loss_and_seed16(vh_vae* h) {
     a.bs = h->bs; a.bs_p = h->bs_p; a.S = h->S; a.L = h->L;
     a.ce_w = h->ce_w; a.ab_w = h->ab_w; a.sse_w = h->sse_w; a.kld_w = h->kld_w;
     a.dR16 = h->dR16.p; a.dMUk = h->dMUk.p; a.part = h->loss_part.p;
-    launch_forking(h, vae_loss16_kernel, dim3(h->loss_blocks), dim3(256), 0, a);
-    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, h->side, h->loss_part.p, h->loss_blocks,
-                       h->Wb.p, h->bs, h->gwsum_src, bs_global, h->state.p);
+    const size_t loss_lds = (size_t)8 * h->D_p * sizeof(float);   // 4 waves x (reconstruction row + target row)
+    VH_REQUIRE(loss_lds <= 160 * 1024 - 256, "nsamples = %d is too wide for the bf16 step's loss kernel (fp32 mode has no limit)", h->S);
+    static bool loss_attr = false;
+    if (!loss_attr) {
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_loss16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024 - 256));
+        loss_attr = true;
+    }
+    hipLaunchKernelGGL(vae_loss16_kernel, dim3(h->loss_blocks), dim3(256), loss_lds, h->stream, a);
     VH_HIP(hipGetLastError());
+    // the scalar reduction (loss means, sum of weights) is only needed by the optimiser
+    const float* gw = h->gwsum_src;
+    q.add([h, bs_global, gw](hipStream_t st) {
+        hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, st, h->loss_part.p, h->loss_blocks, h->Wb.p,
+                           h->bs, gw, bs_global, h->state.p);
+        VH_HIP(hipGetLastError());
+    });
 }
 
 // dW slabs = A^T-copy [out][bs_p] x B^T-copy [in][bs_p] (both K-contiguous over the batch)
@@ -370,13 +399,15 @@ void grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidd
     gemm16<E16_STORE_BNRED>(h->stream, g, 1);
 }
 
-void backward16(vh_vae* h, bool masks_injected) {
+void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
     const int bs = h->bs, bs_p = h->bs_p, nl = h->nl;
     const DropCfg dc = drop_cfg(h, true, masks_injected);
-    {   // output layer: dR16 is ready (the side stream already waits on the loss kernel)
+    {   // output layer: dR16 is ready
         Hidden& last = h->hidden[2 * nl - 1];
-        transpose16(h, h->side, h->dR16.p, bs_p, h->D_p, h->dR16T.p, h->dbias_out, bs);
-        grad_weight16(h, h->tWo, h->dR16T.p, h->D_p, last.H16T.p, last.nout_p, h->side);
+        q.add([h, bs_p, bs, &last](hipStream_t st) {
+            transpose16(h, st, h->dR16.p, bs_p, h->D_p, h->dR16T.p, h->dbias_out, bs);
+            grad_weight16(h, h->tWo, h->dR16T.p, h->D_p, last.H16T.p, last.nout_p, st);
+        });
         grad_input16(h, h->dR16.p, h->D_p, h->tWo, last.nout_p, last);
     }
     int latent_slabs = 1;
@@ -390,19 +421,24 @@ void backward16(vh_vae* h, bool masks_injected) {
         a.drop_scale = dc.scale;
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
         a.dbias = hl.dbias;
-        const bool tail = (li == 0) && h->tail_on_main;
-        const dim3 grid((unsigned)ceil_div(hl.nout_p, kDz16Cols), (unsigned)ceil_div(bs_p, kDz16Rows));
-        if (tail) {
-            hipLaunchKernelGGL(vae_dz16_kernel, grid, dim3(256), 0, h->stream, a);
-            VH_HIP(hipGetLastError());
-        } else {
-            launch_forking(h, vae_dz16_kernel, grid, dim3(256), 0, a);
-        }
         const bf16_t* InT = li == 0 ? h->Xb16T.p : (li == nl ? h->Z16T.p : h->hidden[li - 1].H16T.p);
         const int in_p = li == 0 ? h->D_p : (li == nl ? h->L_p : h->hidden[li - 1].nout_p);
-        if (tail) join_side(h);   // Xb16T (and every earlier weight gradient) is complete
-        grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, tail ? h->stream : h->side);
-        if (li == nl) {
+        // Fork points: the top decoder layer and encoder layer 1 (and layer 0 when something is still queued): each
+        // hands everything queued so far to the side stream.  The first layer's weight gradient is the end of the
+        // chain -- nothing is left on the main stream for it to hide behind -- so it runs there.
+        if (li > 0) q.add([h, &hl, InT, in_p](hipStream_t st) { grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, st); });
+        const bool fork = li == 2 * nl - 1 || li == 1 || (li == 0 && !q.items.empty());
+        const dim3 grid((unsigned)ceil_div(hl.nout_p, kDz16Cols), (unsigned)ceil_div(bs_p, kDz16Rows));
+        if (fork) {
+            launch_forking(h, vae_dz16_kernel, grid, dim3(256), 0, a);
+            q.flush(h->side);
+        } else {
+            hipLaunchKernelGGL(vae_dz16_kernel, grid, dim3(256), 0, h->stream, a);
+            VH_HIP(hipGetLastError());
+        }
+        if (li == 0) {
+            grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, h->stream);
+        } else if (li == nl) {
             // first decoder layer -> latent: latent-wide output, split-K slabs summed by the latent kernel
             Gemm16Args g = args16(h);
             g.A = hl.DZ16.p; g.lda = hl.nout_p;
@@ -414,7 +450,7 @@ void backward16(vh_vae* h, bool masks_injected) {
             g.C32 = h->skinny.p; g.ldc32 = in_p;
             g.slab_stride = (int64_t)bs_p * in_p;
             gemm16<E16_SPLITK>(h->stream, g, latent_slabs);
-        } else if (li > 0) {
+        } else {
             grad_input16(h, hl.DZ16.p, hl.nout_p, hl.tW, in_p, h->hidden[li - 1]);
         }
     };
@@ -422,15 +458,18 @@ void backward16(vh_vae* h, bool masks_injected) {
     {   // latent: dMU = dZlat + d(KLD)/dmu; mu layer
         Hidden& enc_last = h->hidden[nl - 1];
         const int64_t tot = (int64_t)bs_p * h->L_p;
-        launch_forking(h, vae_latent_bwd16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0,
-                       (const float*)h->skinny.p, latent_slabs, (int64_t)bs_p * h->L_p, (const float*)h->dMUk.p,
-                       h->dMU16.p, h->L_p, bs, bs_p);
-        transpose16(h, h->side, h->dMU16.p, bs_p, h->L_p, h->dMU16T.p, h->dbias_mu, bs);
-        grad_weight16(h, h->tWmu, h->dMU16T.p, h->L_p, enc_last.H16T.p, enc_last.nout_p, h->side);
+        hipLaunchKernelGGL(vae_latent_bwd16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, h->stream,
+                           (const float*)h->skinny.p, latent_slabs, (int64_t)bs_p * h->L_p, (const float*)h->dMUk.p,
+                           h->dMU16.p, h->L_p, bs, bs_p);
+        VH_HIP(hipGetLastError());
+        q.add([h, bs_p, bs, &enc_last](hipStream_t st) {
+            transpose16(h, st, h->dMU16.p, bs_p, h->L_p, h->dMU16T.p, h->dbias_mu, bs);
+            grad_weight16(h, h->tWmu, h->dMU16T.p, h->L_p, enc_last.H16T.p, enc_last.nout_p, st);
+        });
         grad_input16(h, h->dMU16.p, h->L_p, h->tWmu, enc_last.nout_p, enc_last);
     }
     for (int li = nl - 1; li >= 0; --li) hidden_bwd(li);
-    if (!h->tail_on_main) join_side(h);
+    join_side(h);   // every weight gradient, the loss reduction and the running statistics are complete
 }
 
 void optimizer_step16(vh_vae* h) {
@@ -451,19 +490,21 @@ void optimizer_step16(vh_vae* h) {
     h->stat_clean = !h->keep_grads;
 }
 
-void gather_rows16(vh_vae* h, const int64_t* dev_idx) {
-    launch_forking(h, vae_gather16_kernel, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, (const float*)h->X.p,
-                   (int64_t)h->D_p, (const float*)h->w.p, dev_idx, h->shuffle, (const long long*)&h->state.p->batch, h->bs,
-                   h->bs_p, h->Xb.p, h->Xb16.p, h->Wb.p);
-    // transposed copy of the batch for the first layer's weight gradient (side stream; needed last)
-    transpose16(h, h->side, h->Xb16.p, h->bs_p, h->D_p, h->Xb16T.p, nullptr, 0);
+void gather_rows16(vh_vae* h, const int64_t* dev_idx, SideQueue& q) {
+    hipLaunchKernelGGL(vae_gather16_kernel, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, h->stream,
+                       (const float*)h->X.p, (int64_t)h->D_p, (const float*)h->w.p, dev_idx, h->shuffle,
+                       (const long long*)&h->state.p->batch, h->bs, h->bs_p, h->Xb.p, h->Xb16.p, h->Wb.p);
+    VH_HIP(hipGetLastError());
+    // transposed copy of the batch for the first layer's weight gradient (needed last)
+    q.add([h](hipStream_t st) { transpose16(h, st, h->Xb16.p, h->bs_p, h->D_p, h->Xb16T.p, nullptr, 0); });
 }
 
 void train_step16(vh_vae* h, const int64_t* dev_idx, bool eps_injected, bool masks_injected) {
-    gather_rows16(h, dev_idx);
-    forward16(h, true, eps_injected, masks_injected, true);
-    loss_and_seed16(h);
-    backward16(h, masks_injected);
+    SideQueue q;
+    gather_rows16(h, dev_idx, q);
+    forward16(h, true, eps_injected, masks_injected, true, &q);
+    loss_and_seed16(h, q);
+    backward16(h, masks_injected, q);
     optimizer_step16(h);
 }
 
