@@ -399,6 +399,32 @@ __global__ __launch_bounds__(kBlock) void clu_select_kernel(const float* __restr
     }
 }
 
+// kept[row] = 0 for up to 32 rows passed in the kernel arguments (no upload, no host synchronisation)
+__global__ void clu_remove_args_kernel(uint8_t* __restrict__ kept, const MedoidRows rows, int n) {
+    if ((int)threadIdx.x < n) kept[rows.row[threadIdx.x]] = 0;
+}
+
+// publication of a select pass: count + the first kSelHostCap rows into host-mapped memory, counter re-armed, then the
+// sequence flag the host spins on (same scheme as clu_publish_kernel: no copy-engine round trip, no event wait)
+constexpr int kSelHostCap = 4096;
+__global__ __launch_bounds__(kBlock) void clu_publish_select_kernel(unsigned int* __restrict__ count,
+                                                                    const int32_t* __restrict__ rows,
+                                                                    int32_t* __restrict__ host_rows,
+                                                                    unsigned long long* __restrict__ host_meta,
+                                                                    unsigned long long seq) {
+    const unsigned int cnt = *count;
+    const unsigned int ncopy = cnt < (unsigned int)kSelHostCap ? cnt : (unsigned int)kSelHostCap;
+    for (unsigned int i = threadIdx.x; i < ncopy; i += kBlock) host_rows[i] = rows[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        host_meta[0] = cnt;
+        *count = 0u;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_meta + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void clu_remove_kernel(uint8_t* __restrict__ kept, const int64_t* __restrict__ rows, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) kept[rows[i]] = 0;
@@ -540,11 +566,20 @@ struct vh_clu {
     PinnedBuf<float> h_q;
     std::vector<int32_t> h_sel;
     EventTimer timer;
+    // select publication (host-mapped): rows [kSelHostCap], meta {count, sequence flag}
+    int32_t* sel_host = nullptr;
+    unsigned long long* sel_meta = nullptr;
+    uint64_t sel_seq = 0;
+    // host copy of the normalised matrix, row-major, by ORIGINAL row (the generator's validity checks of
+    // speculatively scanned seeds; never used for a decision that reaches the output)
+    std::vector<float> host_rows;
 
     ~vh_clu() {
         if (ev_done) (void)hipEventDestroy(ev_done);
         if (lists) (void)hipHostFree(lists);
         if (host_results) (void)hipHostFree(host_results);
+        if (sel_host) (void)hipHostFree(sel_host);
+        if (sel_meta) (void)hipHostFree(sel_meta);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -657,6 +692,9 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         const size_t host_words = (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS) + 1;
         VH_HIP(hipHostMalloc((void**)&h->host_results, host_words * 8, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(h->host_results, 0, host_words * 8);
+        VH_HIP(hipHostMalloc((void**)&h->sel_host, (size_t)kSelHostCap * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        VH_HIP(hipHostMalloc((void**)&h->sel_meta, 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+        h->sel_meta[0] = h->sel_meta[1] = 0ull;
         VH_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
         VH_HIP(hipMemsetAsync(h->results.p, 0, h->results.bytes(), h->stream));
         h->counts.alloc((size_t)(1 + h->ld / kRowsPerBlock));
@@ -679,6 +717,9 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         if (normalized_out)
             VH_HIP(hipMemcpyAsync(normalized_out, staging.p, (size_t)n * L * sizeof(float), hipMemcpyDeviceToHost,
                                   h->stream));
+        h->host_rows.resize((size_t)n * L);
+        VH_HIP(hipMemcpyAsync(h->host_rows.data(), staging.p, (size_t)n * L * sizeof(float), hipMemcpyDeviceToHost,
+                              h->stream));
         VH_HIP(hipStreamSynchronize(h->stream));
         *out = h.release();
     });
@@ -828,24 +869,47 @@ int vh_clu_select(vh_clu* h, int64_t medoid_row, const float* query, float thres
             VH_HIP(hipMemcpyAsync(h->q.p, h->h_q.p, (size_t)h->L4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
             q_ext = h->q.p;
         }
-        // counts[0] is zero on entry (creation / trailing memset of the previous select)
+        // counts[0] is zero on entry (creation / re-armed by the publish kernel of the previous select)
         h->timer.start(h->stream);
         hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
                            h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, q_ext, medoid_row, threshold, remove,
                            h->sel_rows.p, h->counts.p);
         VH_HIP(hipGetLastError());
         h->timer.stop(h->stream);
-        VH_HIP(hipMemcpyAsync(h->h_results.p, h->counts.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
-        VH_HIP(hipEventRecord(h->ev_done, h->stream));
-        VH_HIP(hipMemsetAsync(h->counts.p, 0, sizeof(unsigned int), h->stream));
-        VH_HIP(hipEventSynchronize(h->ev_done));
-        h->timer.collect();
-        const unsigned int cnt = *reinterpret_cast<const unsigned int*>(h->h_results.p);
+        // count and (short) row list travel through host-mapped memory; the host spins on the sequence flag
+        const unsigned long long seq = ++h->sel_seq;
+        hipLaunchKernelGGL(clu_publish_select_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->counts.p, h->sel_rows.p,
+                           h->sel_host, h->sel_meta, seq);
+        VH_HIP(hipGetLastError());
+        {
+            volatile unsigned long long* flag = h->sel_meta + 1;
+            for (unsigned long long spins = 1;; ++spins) {
+                if (*flag == seq) break;
+                if ((spins & 0xFFFFull) == 0) {
+                    const hipError_t qe = hipStreamQuery(h->stream);
+                    if (qe == hipSuccess) {
+                        if (*flag == seq) break;
+                        throw ::vh::HipError{hipErrorUnknown, "select kernel retired without publishing its results", __FILE__, __LINE__};
+                    }
+                    if (qe != hipErrorNotReady) VH_HIP(qe);
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (h->timer.enabled) {
+            VH_HIP(hipStreamSynchronize(h->stream));
+            h->timer.collect();
+        }
+        const unsigned int cnt = (unsigned int)h->sel_meta[0];
         h->h_sel.resize(cnt);
         if (cnt) {
-            VH_HIP(hipMemcpyAsync(h->h_sel.data(), h->sel_rows.p, (size_t)cnt * sizeof(int32_t),
-                                  hipMemcpyDeviceToHost, h->stream));
-            VH_HIP(hipStreamSynchronize(h->stream));
+            if (cnt <= (unsigned int)kSelHostCap) {
+                memcpy(h->h_sel.data(), h->sel_host, (size_t)cnt * sizeof(int32_t));
+            } else {   // long list: the device copy is intact until the next select
+                VH_HIP(hipMemcpyAsync(h->h_sel.data(), h->sel_rows.p, (size_t)cnt * sizeof(int32_t),
+                                      hipMemcpyDeviceToHost, h->stream));
+                VH_HIP(hipStreamSynchronize(h->stream));
+            }
             std::sort(h->h_sel.begin(), h->h_sel.end());
         }
         const int64_t w = std::min<int64_t>(cap, cnt);
@@ -1051,6 +1115,7 @@ struct GenStats {
     uint64_t seq = 0;              // scan that produced the statistics; its results sit in ring slot seq % kListRing
     int slot_j = 0;
     unsigned int list_count = 0;   // > kListCap: the device list is incomplete
+    bool spec = false;             // scanned ahead of time (an upcoming seed): survives cluster emissions while provably valid
 };
 
 // float32(0.005) * float32(N(0, 0.01) pdf) -- the _NORMALPDF table of cluster.py:39-73
@@ -1089,6 +1154,9 @@ struct vh_gen {
     int64_t scan_passes = 0, scan_medoids = 0, rows_streamed = 0;
     double kernel_ms = 0.0;
     std::vector<int64_t> sel;       // scratch
+    // speculative seed scans: upcoming seeds share the pass of whatever has to be scanned anyway
+    int64_t spec_scanned = 0, spec_used = 0, spec_dropped = 0;
+    bool speculate = true;
     // optional wall-clock breakdown (VAMBHIP_GEN_PROFILE=1): scan calls, select calls, seed walk, logical index
     bool profile = false;
     double t_scan = 0, t_select = 0, t_seed = 0, t_logical = 0, t_total = 0;
@@ -1111,6 +1179,35 @@ void gen_collect_ms(vh_gen* g) {
     if (g->clu->timer.enabled) g->kernel_ms += g->clu->timer.last_ms;
 }
 
+// kept[row] = 0 for rows the state machine knows to be live: stream-ordered launch, no read-back, no wait
+void gen_remove_live(vh_gen* g, const int64_t* rows, int64_t n) {
+    vh_clu* h = g->clu;
+    for (int64_t lo = 0; lo < n; lo += kMaxMedoids) {
+        const int k = (int)std::min<int64_t>(kMaxMedoids, n - lo);
+        MedoidRows mr;
+        for (int j = 0; j < kMaxMedoids; ++j) mr.row[j] = rows[lo + (j < k ? j : 0)];
+        hipLaunchKernelGGL(clu_remove_args_kernel, dim3(1), dim3(64), 0, h->stream, h->kept.p, mr, k);
+        VH_HIP(hipGetLastError());
+    }
+    h->n_live -= n;
+}
+
+// The next live seeds of the length-ordered walk (cluster.py:342-384) after order_index, without touching the walk's
+// state: physical rows not scanned yet.  Bounded look-ahead (dead stretches are not tombstoned by a peek).
+void gen_upcoming_seeds(vh_gen* g, size_t want, const std::vector<int64_t>& exclude, std::vector<int64_t>& out) {
+    const int64_t n_order = (int64_t)g->order.size();
+    int64_t looked = 0;
+    for (int64_t i = g->order_index; i < n_order && out.size() < want && looked < 4096; ++i, ++looked) {
+        const int64_t o = g->order[(size_t)i];
+        if (o == -1 || !g->alive[(size_t)o]) continue;
+        const int64_t row = (int64_t)(std::lower_bound(g->indices.begin(), g->indices.end(), o) - g->indices.begin());
+        if (g->stats.count(row)) continue;
+        if (std::find(exclude.begin(), exclude.end(), row) != exclude.end()) continue;
+        if (std::find(out.begin(), out.end(), row) != out.end()) continue;
+        out.push_back(row);
+    }
+}
+
 // sample_medoid's device half for every medoid not cached yet (one pass per <= 32 of them)
 void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
     std::vector<int64_t> missing;
@@ -1119,6 +1216,22 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         if (g->stats.count(m)) continue;
         if (std::find(missing.begin(), missing.end(), m) != missing.end()) continue;
         missing.push_back(m);
+    }
+    if (missing.empty()) return;
+    // Speculation: sample_medoid is a pure function of the live matrix, so the statistics of UPCOMING seeds can be taken
+    // in the same pass (free slots of the medoid-count bucket; a lone seed scan is widened).  They are used only while no
+    // row removed since lies within the histogram range of the seed (vh_gen_next), i.e. while they are exactly what a
+    // scan at the time of use would return.
+    size_t n_needed = missing.size();
+    if (g->speculate) {
+        size_t target = (size_t)pick_km((int)std::min<size_t>(missing.size(), kMaxMedoids));
+        if (missing.size() <= 8 && g->clu->n_rows <= 600000) target = kMaxMedoids;       // latency-bound pass: extra medoids are free
+        else if (missing.size() == 1) target = 8;
+        if (missing.size() < target && missing.size() < (size_t)kMaxMedoids) {
+            std::vector<int64_t> extra;
+            gen_upcoming_seeds(g, target - missing.size(), missing, extra);
+            missing.insert(missing.end(), extra.begin(), extra.end());
+        }
     }
     for (size_t lo = 0; lo < missing.size(); lo += kMaxMedoids) {
         const int k = (int)std::min<size_t>(kMaxMedoids, missing.size() - lo);
@@ -1146,6 +1259,17 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
             st.slot_j = j;
             st.list_count = g->clu->last_counts[slot][j];
             st.have_list = false;
+            st.spec = lo + (size_t)j >= n_needed;
+            if (st.spec) {
+                g->spec_scanned++;
+                // a speculative entry may be used after its scan has left the ring: keep its (short) list now
+                if (st.list_count <= 32u) {
+                    const int32_t* src = g->clu->lists + ((size_t)slot * kMaxMedoids + j) * kListCap;
+                    st.within.assign(src, src + st.list_count);
+                    std::sort(st.within.begin(), st.within.end());
+                    st.have_list = true;
+                }
+            }
         }
     }
 }
@@ -1223,6 +1347,10 @@ void gen_update_successes(vh_gen* g, bool success) {
 int64_t gen_wander(vh_gen* g, int64_t seed) {
     int64_t medoid = seed;
     std::vector<int64_t> tried{medoid};
+    {
+        const auto it = g->stats.find(seed);
+        if (it != g->stats.end() && it->second.spec) { g->spec_used++; it->second.spec = false; }
+    }
     gen_ensure_stats(g, &seed, 1);
     double local_density = g->stats.at(seed).density;
     auto untried = [&](const std::vector<int64_t>& rows) {
@@ -1365,6 +1493,7 @@ int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, in
         g->pack_min_rows = pack_min_rows;
         g->rng.seed(rng_seed);
         g->profile = getenv("VAMBHIP_GEN_PROFILE") != nullptr;
+        g->speculate = getenv("VAMBHIP_NO_SPECULATION") == nullptr;
         g->order.assign(order, order + n);
         g->indices.resize((size_t)n);
         for (int64_t i = 0; i < n; ++i) g->indices[(size_t)i] = i;
@@ -1378,9 +1507,11 @@ int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, in
 
 int vh_gen_destroy(vh_gen* g) {
     if (g && g->profile)
-        fprintf(stderr, "[vambhip] generator: total %.1f ms = scans %.1f + selects %.1f + seed walk %.1f + logical index %.1f + rest %.1f\n",
+        fprintf(stderr, "[vambhip] generator: total %.1f ms = scans %.1f + selects %.1f + seed walk %.1f + logical index %.1f + rest %.1f; "
+                "%lld passes, %lld medoids; speculative seed scans %lld, used %lld, invalidated %lld\n",
                 g->t_total, g->t_scan, g->t_select, g->t_seed, g->t_logical,
-                g->t_total - g->t_scan - g->t_select - g->t_seed - g->t_logical);
+                g->t_total - g->t_scan - g->t_select - g->t_seed - g->t_logical, (long long)g->scan_passes,
+                (long long)g->scan_medoids, (long long)g->spec_scanned, (long long)g->spec_used, (long long)g->spec_dropped);
     delete g;
     return VH_OK;
 }
@@ -1410,7 +1541,7 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
                 info->successes = g->successes;
                 info->attempts = (int64_t)g->attempts.size();
                 points.assign(1, medoid);
-                gen_check(vh_clu_remove(g->clu, points.data(), 1));
+                gen_remove_live(g, points.data(), 1);
                 break;
             }
             if (kind == kNoThreshold) {
@@ -1441,8 +1572,30 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
         VH_REQUIRE((int64_t)points.size() <= cap, "members buffer too small");
         for (size_t i = 0; i < points.size(); ++i) members[i] = g->indices[(size_t)points[i]];
         info->n_members = (int64_t)points.size();
-        // __next__ bookkeeping
-        g->stats.clear();
+        // __next__ bookkeeping.  The reference clears its sample_medoid cache here because a removal may change any
+        // cached result; the speculative seed scans are kept exactly when none of the removed rows lies within the
+        // histogram range (d <= 0.3, widened by a margin that covers any float32 summation order) of the seed.
+        {
+            std::unordered_map<int64_t, GenStats> keep;
+            const int L = g->clu->L;
+            const float* hm = g->clu->host_rows.data();
+            for (auto& kv : g->stats) {
+                if (!kv.second.spec) continue;
+                const float* vm = hm + (size_t)g->indices[(size_t)kv.first] * L;
+                bool valid = true;
+                for (int64_t r : points) {
+                    if (r == kv.first) { valid = false; break; }
+                    const float* vr = hm + (size_t)g->indices[(size_t)r] * L;
+                    float dot = 0.0f;
+                    for (int c = 0; c < L; ++c) dot += vm[c] * vr[c];
+                    if (0.5f - dot <= 0.3f + 2e-3f) { valid = false; break; }
+                }
+                if (valid) keep.emplace(kv.first, std::move(kv.second));
+                else g->spec_dropped++;
+            }
+            if (keep.size() > 256) { g->spec_dropped += (int64_t)keep.size(); keep.clear(); }   // bounded validity work per emission
+            g->stats.swap(keep);
+        }
         g->n_emitted++;
         g->n_remaining -= (int64_t)points.size();
         for (int64_t r : points) {
@@ -1454,6 +1607,7 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
         if (g->n_remaining > 0 && n_rows >= g->pack_min_rows && (double)g->n_remaining < g->pack_fraction * (double)n_rows) {
             int64_t new_n = 0;
             gen_check(vh_clu_pack(g->clu, &new_n));
+            g->stats.clear();   // physical row numbers change
             size_t w = 0;
             for (size_t r = 0; r < g->kept.size(); ++r)
                 if (g->kept[r]) g->indices[w++] = g->indices[r];
