@@ -39,8 +39,17 @@ CLUSTER_CASES = {
 }
 
 
+# 100 k-point streams (SURVEY.md section 8c asks for N in {1 k, 10 k, 100 k}): GPU tests and golden generation only --
+# the pure-Python / scalar-C oracle would need minutes per case.  Lengths are UNIQUE (a permutation), so that
+# np.argsort(lengths)[::-1] (cluster.py:275, an unstable sort) gives the same seed order on every CPU.
+CLUSTER_CASES_LARGE = {
+    "blob_s008_n100000": dict(kind="blob_unique_len", seed=41, n=100000, L=32, sigma=0.08, k=None),
+    "blob_s050_n100000": dict(kind="blob_unique_len", seed=42, n=100000, L=32, sigma=0.5, k=None),
+}
+
+
 def cluster_inputs(name):
-    c = CLUSTER_CASES[name]
+    c = CLUSTER_CASES[name] if name in CLUSTER_CASES else CLUSTER_CASES_LARGE[name]
     kw = dict(c.get("kwargs", {}))
     if c["kind"] == "uniform":
         rng = np.random.RandomState(c["seed"])
@@ -53,6 +62,10 @@ def cluster_inputs(name):
     elif c["kind"] == "blob":
         mat, _ = synth.blob_latent(c["n"], c["L"], c["sigma"], c["seed"], c["k"])
         lens = synth.lengths(c["n"], c["seed"])
+        kw.setdefault("rng_seed", c["seed"])
+    elif c["kind"] == "blob_unique_len":
+        mat, _ = synth.blob_latent(c["n"], c["L"], c["sigma"], c["seed"], c["k"])
+        lens = 2000 + 9 * np.random.RandomState(c["seed"] + 99).permutation(c["n"]).astype(np.int64)
         kw.setdefault("rng_seed", c["seed"])
     elif c["kind"] == "zerodup":
         mat, _ = synth.blob_latent(c["n"], c["L"], c["sigma"], c["seed"], c["k"])

@@ -7,7 +7,7 @@ vambcore.overwrite_matrix and dadaptation.DAdaptAdam -- the latter restated, PAR
 The GPU box never runs this; tests read the committed .npz files.
 
     python tests/golden/make_golden.py            # regenerate everything
-    python tests/golden/make_golden.py cluster    # only one family (cluster | prep | vae)
+    python tests/golden/make_golden.py cluster    # only one family (cluster | cluster_large | prep | vae)
 
 Environment recorded in golden_manifest.json (torch / numpy versions, thread count).
 """
@@ -31,9 +31,9 @@ import ref_harness  # noqa: E402
 import vae_oracle  # noqa: E402
 
 
-def gen_cluster(cl):
+def gen_cluster(cl, cases=None):
     out = {}
-    for name in fd.CLUSTER_CASES:
+    for name in (fd.CLUSTER_CASES if cases is None else cases):
         mat, lens, kw = fd.cluster_inputs(name)
         clusters = list(cl.ClusterGenerator(mat.copy(), lens, **kw))
         packed = fd.pack_stream(clusters)
@@ -145,6 +145,8 @@ def main():
                                    reference="RasmussenLab/vamb @ /root/reference (v5.0.x)")
     if "cluster" in which:
         manifest["cluster"] = gen_cluster(cl)
+    if "cluster_large" in which:   # 100 k-point streams (minutes of reference CPU time each)
+        manifest["cluster_large"] = gen_cluster(cl, fd.CLUSTER_CASES_LARGE)
     if "prep" in which:
         manifest["prep"] = gen_prep(en)
     if "vae" in which:

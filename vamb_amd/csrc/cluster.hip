@@ -1116,6 +1116,7 @@ struct GenStats {
     int slot_j = 0;
     unsigned int list_count = 0;   // > kListCap: the device list is incomplete
     bool spec = false;             // scanned ahead of time (an upcoming seed): survives cluster emissions while provably valid
+    bool hist_stale = false;       // rows were removed since the scan: the histogram (range 0.3) must be taken again
 };
 
 // float32(0.005) * float32(N(0, 0.01) pdf) -- the _NORMALPDF table of cluster.py:39-73
@@ -1263,7 +1264,7 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
             if (st.spec) {
                 g->spec_scanned++;
                 // a speculative entry may be used after its scan has left the ring: keep its (short) list now
-                if (st.list_count <= 32u) {
+                if (st.list_count <= 8u) {
                     const int32_t* src = g->clu->lists + ((size_t)slot * kMaxMedoids + j) * kListCap;
                     st.within.assign(src, src + st.list_count);
                     std::sort(st.within.begin(), st.within.end());
@@ -1384,7 +1385,7 @@ int64_t gen_wander(vh_gen* g, int64_t seed) {
 // cluster.py:452-543 on the exact histogram of the scan
 void gen_fetch_hist(vh_gen* g, int64_t medoid, GenStats& st) {
     if (st.have_hist) return;
-    if (g->clu->scan_seq - st.seq > (uint64_t)kListRing) {
+    if (st.hist_stale || g->clu->scan_seq - st.seq > (uint64_t)kListRing) {
         // its scan has left the ring: one more pass for this medoid alone (same exact accumulators)
         const uint64_t seq = g->clu->scan_seq;
         {
@@ -1395,9 +1396,17 @@ void gen_fetch_hist(vh_gen* g, int64_t medoid, GenStats& st) {
         g->scan_medoids += 1;
         g->rows_streamed += g->clu->n_rows;
         gen_collect_ms(g);
-        st.seq = seq;
-        st.slot_j = 0;
-        st.list_count = g->clu->last_counts[(int)(seq % kListRing)][0];
+        if (!st.hist_stale) {   // (a stale entry keeps its own list: identical rows, already copied or still in the ring)
+            st.seq = seq;
+            st.slot_j = 0;
+            st.list_count = g->clu->last_counts[(int)(seq % kListRing)][0];
+        }
+        unsigned long long tmp0[VH_NBINS];
+        memcpy(tmp0, g->clu->hist((int)(seq % kListRing)), sizeof(tmp0));
+        for (int b = 0; b < VH_NBINS; ++b) st.hist_fx[b] = (int64_t)tmp0[b];
+        st.have_hist = true;
+        st.hist_stale = false;
+        return;
     }
     unsigned long long tmp[VH_NBINS];
     memcpy(tmp, g->clu->hist((int)(st.seq % kListRing)) + (size_t)st.slot_j * VH_NBINS, sizeof(tmp));
@@ -1573,8 +1582,10 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
         for (size_t i = 0; i < points.size(); ++i) members[i] = g->indices[(size_t)points[i]];
         info->n_members = (int64_t)points.size();
         // __next__ bookkeeping.  The reference clears its sample_medoid cache here because a removal may change any
-        // cached result; the speculative seed scans are kept exactly when none of the removed rows lies within the
-        // histogram range (d <= 0.3, widened by a margin that covers any float32 summation order) of the seed.
+        // cached result.  Of a speculative seed scan the NEAR-FIELD results (density, counts and the list of rows within
+        // the medoid radius 0.05: everything wander_medoid and the loner test read) stay exact as long as no removed row
+        // lies within that radius of the seed (checked with a margin that covers any float32 summation order); its
+        // histogram reaches out to 0.3 and is simply taken again if the seed ends up as the medoid of a cluster.
         {
             std::unordered_map<int64_t, GenStats> keep;
             const int L = g->clu->L;
@@ -1588,10 +1599,15 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
                     const float* vr = hm + (size_t)g->indices[(size_t)r] * L;
                     float dot = 0.0f;
                     for (int c = 0; c < L; ++c) dot += vm[c] * vr[c];
-                    if (0.5f - dot <= 0.3f + 2e-3f) { valid = false; break; }
+                    if (0.5f - dot <= 0.05f + 2e-3f) { valid = false; break; }
                 }
-                if (valid) keep.emplace(kv.first, std::move(kv.second));
-                else g->spec_dropped++;
+                if (valid) {
+                    kv.second.hist_stale = true;
+                    kv.second.have_hist = false;
+                    keep.emplace(kv.first, std::move(kv.second));
+                } else {
+                    g->spec_dropped++;
+                }
             }
             if (keep.size() > 256) { g->spec_dropped += (int64_t)keep.size(); keep.clear(); }   // bounded validity work per emission
             g->stats.swap(keep);
