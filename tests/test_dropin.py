@@ -35,3 +35,26 @@ def test_install_and_uninstall():
     finally:
         dropin.uninstall(saved, vamb)
     assert vamb.encode.VAE is ref_vae and vamb.cluster.ClusterGenerator is ref_cg
+
+
+@pytest.mark.reference
+def test_state_dict_spec_matches_reference():
+    """The names, order and shapes our VAE.state_dict()/save() writes (VAE._state_names / _shape_of) are exactly those
+    of the reference module's state_dict (encode.py:226-249, 486-502), for several architectures -- so a model.pt
+    written here passes the reference's strict load_state_dict and vice versa.  (The end-to-end check -- the
+    reference's VAE.load reading a file written on the GPU -- is oracle/check_model_pt.py, profiles/r02_model_pt_crossload.json.)"""
+    import types
+
+    import ref_harness
+    from vamb_amd import encode as ve
+
+    if not ref_harness.reference_available():
+        pytest.skip("needs /root/reference")
+    _, _, ref_encode = ref_harness.load_reference()
+    for nsamples, nhiddens, nlatent in [(6, [48, 40], 8), (1, [24, 24], 4), (7, [32, 24, 16], 6), (50, [512, 512], 32)]:
+        ref = ref_encode.VAE(nsamples, nhiddens=list(nhiddens), nlatent=nlatent).state_dict()
+        me = types.SimpleNamespace(nsamples=nsamples, nhiddens=list(nhiddens), nlatent=nlatent)
+        names = ve.VAE._state_names(me)
+        assert names == list(ref.keys())
+        for k in names:
+            assert tuple(ve.VAE._shape_of(me, k)) == tuple(ref[k].shape), k

@@ -41,6 +41,7 @@ constexpr int kListCap = 2048;    // rows within the medoid radius kept per medo
 constexpr int64_t kMinScanBlocks = 768;   // workgroups wanted before lanes are given more than one row
 constexpr int kListRing = 16;     // scans whose lists stay readable (one cluster search rarely needs more)
 constexpr int kLocalCap = 128;    // per-block, per-medoid staging of list entries in LDS
+constexpr int kSpecWindow = 40;   // speculative seed scans kept ahead of the walk by the native state machine
 
 // medoid rows travel in the kernel arguments (no upload, no gather launch)
 struct MedoidRows {
@@ -1228,9 +1229,13 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         size_t target = (size_t)pick_km((int)std::min<size_t>(missing.size(), kMaxMedoids));
         if (missing.size() <= 8 && g->clu->n_rows <= 600000) target = kMaxMedoids;       // latency-bound pass: extra medoids are free
         else if (missing.size() == 1) target = 8;
-        if (missing.size() < target && missing.size() < (size_t)kMaxMedoids) {
+        // look-ahead window: at most kSpecWindow unused speculative entries at any time (every emission re-validates them)
+        size_t n_spec = 0;
+        for (const auto& kv : g->stats) n_spec += kv.second.spec ? 1 : 0;
+        const size_t room = n_spec < (size_t)kSpecWindow ? (size_t)kSpecWindow - n_spec : 0;
+        if (missing.size() < target && missing.size() < (size_t)kMaxMedoids && room > 0) {
             std::vector<int64_t> extra;
-            gen_upcoming_seeds(g, target - missing.size(), missing, extra);
+            gen_upcoming_seeds(g, std::min(target - missing.size(), room), missing, extra);
             missing.insert(missing.end(), extra.begin(), extra.end());
         }
     }

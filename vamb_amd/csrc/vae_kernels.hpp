@@ -159,13 +159,6 @@ __global__ void vae_bn_eval_coeff_kernel(int n_p, const float* __restrict__ gamm
 }
 
 // ---- reparameterisation (encode.py:276-286) ------------------------------------------------------
-// standard-normal noise: Box-Muller over the counter-based hash (free-running mode)
-__device__ __forceinline__ float hash_randn(uint64_t key, uint64_t id) {
-    const float u1 = ((float)hash32(key, 2 * id) + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
-    const float u2 = (float)hash32(key, 2 * id + 1) * 2.3283064365386963e-10f;
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
-}
-
 // MU = sum of the split-K slabs + bias;  Z = MU + eps on the real rows / columns, 0 on the padding.
 // eps comes from E (injected, parity mode) or is generated in place (E == nullptr); noise == 0 disables it.
 __global__ void vae_reparam_kernel(const float* __restrict__ slabs, int nslab, int64_t stride,

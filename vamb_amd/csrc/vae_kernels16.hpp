@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void vae_transpose16_kernel(const bf16_t* __re
 // bias_out[n] = bias[n] + sum_k W[n][k] t_k.  One wavefront per weight row; s, t are rebuilt per workgroup.
 // from_running != 0: eval mode, s / t from the running statistics (scale_in / shift_in precomputed by
 // vae_bn_eval_coeff_kernel).
-constexpr int kFoldRowsPerWave = 4;   // 16 weight rows per workgroup: the per-workgroup rebuild of s, t is the fixed cost
+constexpr int kFoldRowsPerWave = 1;
+constexpr int kFoldRegQ = 5;   // float4 registers per lane holding the weight row (covers K <= 1280; longer rows loop)
 __global__ __launch_bounds__(256) void vae_fold_bn_kernel(const float* __restrict__ W, int64_t ldw, int n_rows, int K,
                                                           const float* __restrict__ bias, const BnSrc bn,
                                                           const float* __restrict__ scale_in,
@@ -125,6 +126,17 @@ __global__ __launch_bounds__(256) void vae_fold_bn_kernel(const float* __restric
     extern __shared__ __attribute__((aligned(16))) float fold_st[];   // [2][K]
     float* s_s = fold_st;
     float* t_s = fold_st + K;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    // this wave's weight row goes into registers first: the loads fly while s, t are rebuilt from the fp64 batch sums
+    const float* w = W + (int64_t)(n < n_rows ? n : 0) * ldw;
+    float4 wr[kFoldRegQ];
+#pragma unroll
+    for (int q = 0; q < kFoldRegQ; ++q) {
+        const int k = 4 * lane + 256 * q;
+        wr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K) wr[q] = *reinterpret_cast<const float4*>(w + k);
+    }
     for (int k = threadIdx.x; k < K; k += 256) {
         float sc, sh;
         if (scale_in) {
@@ -138,24 +150,29 @@ __global__ __launch_bounds__(256) void vae_fold_bn_kernel(const float* __restric
         t_s[k] = sh;
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll 1
-    for (int r = 0; r < kFoldRowsPerWave; ++r) {
-        const int n = (blockIdx.x * 4 + wave) * kFoldRowsPerWave + r;
-        if (n >= n_rows) return;
-        const float* w = W + (int64_t)n * ldw;
-        bf16_t* o = W16 + (int64_t)n * ldw;
-        float dot = 0.f;
-        for (int k = 4 * lane; k < K; k += 256) {
-            const float4 v = *reinterpret_cast<const float4*>(w + k);
+    if (n >= n_rows) return;
+    bf16_t* o = W16 + (int64_t)n * ldw;
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < kFoldRegQ; ++q) {
+        const int k = 4 * lane + 256 * q;
+        if (k < K) {
+            const float4 v = wr[q];
             const float4 s4 = *reinterpret_cast<const float4*>(s_s + k);
             const float4 t4 = *reinterpret_cast<const float4*>(t_s + k);
             dot += v.x * t4.x + v.y * t4.y + v.z * t4.z + v.w * t4.w;
             *reinterpret_cast<uint2*>(o + k) = make_uint2(pack_bf2(v.x * s4.x, v.y * s4.y), pack_bf2(v.z * s4.z, v.w * s4.w));
         }
-        dot = wave_sum(dot);
-        if (lane == 0) bias_out[n] = bias[n] + dot;
     }
+    for (int k = 4 * lane + 256 * kFoldRegQ; k < K; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(w + k);
+        const float4 s4 = *reinterpret_cast<const float4*>(s_s + k);
+        const float4 t4 = *reinterpret_cast<const float4*>(t_s + k);
+        dot += v.x * t4.x + v.y * t4.y + v.z * t4.z + v.w * t4.w;
+        *reinterpret_cast<uint2*>(o + k) = make_uint2(pack_bf2(v.x * s4.x, v.y * s4.y), pack_bf2(v.z * s4.z, v.w * s4.w));
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) bias_out[n] = bias[n] + dot;
 }
 
 // ---- bf16 shadows of the weights (init / set_param; during training the optimiser writes them itself) --------------
@@ -168,36 +185,6 @@ __global__ void vae_shadow_kernel(const float* __restrict__ P, int rows_p, int c
     const bf16_t b = f2bf(P[i]);
     W16[i] = b;
     if (W16T) W16T[(int64_t)c * rows_p + r] = b;
-}
-
-// ---- reparameterisation: MU (fp32) = slabs + bias; Z16 = bf16(MU + eps) on real rows / columns ---------------------
-__global__ void vae_reparam16_kernel(const float* __restrict__ slabs, int nslab, int64_t stride,
-                                     const float* __restrict__ bias, const float* __restrict__ E, uint64_t key,
-                                     const unsigned long long* __restrict__ step_ptr, int noise,
-                                     float* __restrict__ MU, bf16_t* __restrict__ Z16, int bs, int L, int L_p, int bs_p) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)bs_p * L_p) return;
-    const int r = (int)(i / L_p), c = (int)(i % L_p);
-    float m = bias[c];
-    {
-        constexpr int kMaxSlabs = 8;
-        float v[kMaxSlabs];
-#pragma unroll
-        for (int s = 0; s < kMaxSlabs; ++s) v[s] = s < nslab ? slabs[(int64_t)s * stride + i] : 0.f;
-#pragma unroll
-        for (int s = 0; s < kMaxSlabs; ++s)
-            if (s < nslab) m += v[s];
-        for (int s = kMaxSlabs; s < nslab; ++s) m += slabs[(int64_t)s * stride + i];
-    }
-    MU[i] = m;
-    float z = 0.f;
-    if (r < bs && c < L) {
-        float e = 0.f;
-        if (E) e = E[i];
-        else if (noise) e = hash_randn(step_key(key, step_ptr), (uint64_t)i);
-        z = m + e;
-    }
-    Z16[i] = f2bf(z);
 }
 
 // ---- loss + backward seed, bf16 gradient of the reconstruction ------------------------------------------------------
@@ -244,28 +231,35 @@ __global__ __launch_bounds__(256) void vae_loss16_kernel(const Loss16Args a) {
             }
             const float g = a.inv_b2;
             const int S = a.S;
+            // softmax / cross-entropy over the S abundance columns: one exponential and one logarithm per element (the
+            // staged rows are overwritten with exp(r - max) and x / (p + 1e-9)); hardware exp2 / log2 based intrinsics --
+            // the kernel was bound by libm-accurate transcendentals (3 expf + logf per element: 17 us at C2)
             float mx = -3.0e38f;
             for (int c = lane; c < S; c += 64) mx = fmaxf(mx, r[c]);
             mx = wave_max(mx);
             float se = 0.f;
-            for (int c = lane; c < S; c += 64) se += expf(r[c] - mx);
+            for (int c = lane; c < S; c += 64) {
+                const float e = __expf(r[c] - mx);
+                r[c] = e;
+                se += e;
+            }
             se = wave_sum(se);
             const float inv = 1.0f / se;
             float ce = 0.f, pdp = 0.f;
             for (int c = lane; c < S; c += 64) {
-                const float p = expf(r[c] - mx) * inv;
+                const float p = r[c] * inv;
                 const float q = p + 1e-9f;
-                ce -= logf(q) * x[c];
-                pdp += p * (-x[c] / q);
+                const float xv = x[c];
+                const float t = __fdividef(xv, q);
+                ce -= __logf(q) * xv;
+                pdp -= p * t;
+                r[c] = p;
+                x[c] = t;
             }
             ce = wave_sum(ce);
             pdp = wave_sum(pdp);
             const float gce = g * a.ce_w;
-            for (int c = lane; c < S; c += 64) {
-                const float p = expf(r[c] - mx) * inv;
-                const float dp = -x[c] / (p + 1e-9f);
-                dr[c] = f2bf(gce * p * (dp - pdp));
-            }
+            for (int c = lane; c < S; c += 64) dr[c] = f2bf(gce * r[c] * (-x[c] - pdp));
             float sse = 0.f;
             const float gsse = g * a.sse_w * 2.0f;
             for (int c = S + lane; c < S + 103; c += 64) {
@@ -325,32 +319,36 @@ struct Dz16Args {
     double* dbias;
 };
 constexpr int kDz16Cols = 128;
-constexpr int kDz16Rows = 64;
+constexpr int kDz16Rows = 128;
 
+// A workgroup owns 128 rows x 128 columns as 2 x 2 wavefronts of 64 x 64; a thread owns an 8 x 8 block: it reads 8 row
+// segments of 16 bytes of dA and H (lanes 0-7 of a group cover one full 128-byte line), writes dZ the same way and --
+// after an 8 x 8 transpose of the packed bf16 pairs in registers -- 8 column segments of 16 bytes of dZ^T (the 8 row
+// groups of a wave cover one full line of a column).  No LDS in the data path.
 __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
-    __shared__ __attribute__((aligned(16))) bf16_t tile[kDz16Rows][kDz16Cols + 8];
-    __shared__ float red[16][kDz16Cols];
     __shared__ float cf[3][kDz16Cols];
-    const int tid = threadIdx.x;
-    const int col0 = blockIdx.x * kDz16Cols, row0 = blockIdx.y * kDz16Rows;
-    const int c8 = (tid & 15) * 8;          // this thread's 8 columns inside the tile
-    const int rt = tid >> 4;                // row lane 0..15
-    const int col = col0 + c8;
-    // the thread's 16-byte loads go out first; the per-column coefficients (fp64 statistics) are formed underneath them
-    constexpr int PASS = kDz16Rows / 16;
-    uint4 da[PASS], hh[PASS];
+    __shared__ float red[2][kDz16Cols];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int cc = lane & 7, gq = lane >> 3;
+    const int col0 = blockIdx.x * kDz16Cols;
+    const int col_l = wc * 64 + cc * 8;
+    const int col = col0 + col_l;
+    const int row_base = blockIdx.y * kDz16Rows + wr * 64 + gq * 8;
+    const bool col_ok = col < a.n_p;
+    uint4 da[8], hh[8];
 #pragma unroll
-    for (int p = 0; p < PASS; ++p) {
-        const int r = row0 + rt + 16 * p;
-        da[p] = make_uint4(0, 0, 0, 0);
-        hh[p] = da[p];
-        if (r < a.bs && col < a.n_p) {
+    for (int k = 0; k < 8; ++k) {
+        const int r = row_base + k;
+        da[k] = make_uint4(0, 0, 0, 0);
+        hh[k] = da[k];
+        if (r < a.bs && col_ok) {
             const int64_t i = (int64_t)r * a.n_p + col;
-            da[p] = *reinterpret_cast<const uint4*>(a.DA + i);
-            hh[p] = *reinterpret_cast<const uint4*>(a.H + i);
+            da[k] = *reinterpret_cast<const uint4*>(a.DA + i);
+            hh[k] = *reinterpret_cast<const uint4*>(a.H + i);
         }
     }
-    if (tid < kDz16Cols) {
+    if (tid < kDz16Cols) {   // per-column coefficients from the fp64 batch sums, under the loads
         const int colc = col0 + tid;
         float ca = 0.f, ch = 0.f, c0 = 0.f;
         if (colc < a.n_p) {
@@ -369,14 +367,16 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
     const bool hashed_drop = (a.drop_scale != 1.0f) && (a.drop_mask == nullptr);
     float ca[8], ch[8], c0[8], s[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { ca[e] = cf[0][c8 + e]; ch[e] = cf[1][c8 + e]; c0[e] = cf[2][c8 + e]; s[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { ca[e] = cf[0][col_l + e]; ch[e] = cf[1][col_l + e]; c0[e] = cf[2][col_l + e]; s[e] = 0.f; }
+    uint32_t ow[8][4];
 #pragma unroll
-    for (int p = 0; p < PASS; ++p) {
-        const int rl = rt + 16 * p, r = row0 + rl;
-        const uint32_t dw[4] = {da[p].x, da[p].y, da[p].z, da[p].w};
-        const uint32_t hw[4] = {hh[p].x, hh[p].y, hh[p].z, hh[p].w};
-        uint32_t ow[4] = {0, 0, 0, 0};
-        if (r < a.bs && col < a.n_p) {
+    for (int k = 0; k < 8; ++k) {
+        const int r = row_base + k;
+        const uint32_t dw[4] = {da[k].x, da[k].y, da[k].z, da[k].w};
+        const uint32_t hw[4] = {hh[k].x, hh[k].y, hh[k].z, hh[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ow[k][j] = 0u;
+        if (r < a.bs && col_ok) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float d = (e & 1) ? bf_hi(dw[e >> 1]) : bf_lo(dw[e >> 1]);
@@ -388,62 +388,41 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
                 const float dz = keep ? l * (h > 0.f ? 1.0f : kLeakySlope) : 0.f;
                 const bf16_t b = f2bf(dz);
                 s[e] += bf2f(b);
-                ow[e >> 1] |= (uint32_t)b << (16 * (e & 1));
+                ow[k][e >> 1] |= (uint32_t)b << (16 * (e & 1));
             }
         }
-        const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-        *reinterpret_cast<uint4*>(&tile[rl][c8]) = o;
-        if (r < a.bs_p && col < a.n_p) *reinterpret_cast<uint4*>(a.DZ + (int64_t)r * a.n_p + col) = o;
+        if (r < a.bs_p && col_ok)
+            *reinterpret_cast<uint4*>(a.DZ + (int64_t)r * a.n_p + col) = make_uint4(ow[k][0], ow[k][1], ow[k][2], ow[k][3]);
     }
+    // 8 x 8 transpose of bf16 pairs: column 2m / 2m + 1 of rows 2j, 2j + 1 sit in ow[2j][m], ow[2j + 1][m]
+    if (col_ok && row_base < a.bs_p) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[rt][c8 + e] = s[e];
-    __syncthreads();
-    // transposed copy: chunk = (column c, 8 consecutive rows); lanes of a wave take consecutive columns
+        for (int m = 0; m < 4; ++m) {
+            uint32_t te[4], to[4];
 #pragma unroll
-    for (int p = 0; p < (kDz16Cols * (kDz16Rows / 8)) / 256; ++p) {
-        const int id = tid + 256 * p;
-        const int c = id % kDz16Cols, rg = id / kDz16Cols;
-        bf16_t e[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) e[k] = tile[rg * 8 + k][c];
-        if (col0 + c < a.n_p && row0 + rg * 8 < a.bs_p) {
-            uint4 v;
-            v.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
-            v.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
-            v.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
-            v.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
-            *reinterpret_cast<uint4*>(a.DZT + (int64_t)(col0 + c) * a.ldt + row0 + rg * 8) = v;
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = ow[2 * j][m], hi = ow[2 * j + 1][m];
+                te[j] = (lo & 0xFFFFu) | (hi << 16);
+                to[j] = (lo >> 16) | (hi & 0xFFFF0000u);
+            }
+            *reinterpret_cast<uint4*>(a.DZT + (int64_t)(col + 2 * m) * a.ldt + row_base) = make_uint4(te[0], te[1], te[2], te[3]);
+            *reinterpret_cast<uint4*>(a.DZT + (int64_t)(col + 2 * m + 1) * a.ldt + row_base) = make_uint4(to[0], to[1], to[2], to[3]);
         }
     }
+    // bias gradient: the 8 row groups of the wave (lanes cc + 8 g) through shuffles, the two wave rows through LDS
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = s[e];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (gq == 0) red[wr][col_l + e] = v;
+    }
+    __syncthreads();
     if (tid < kDz16Cols) {
         const int c = col0 + tid;
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += red[i][tid];
-        if (c < a.n_p) atomicAdd(&a.dbias[c], (double)t);
+        if (c < a.n_p) atomicAdd(&a.dbias[c], (double)(red[0][tid] + red[1][tid]));
     }
-}
-
-// latent: dMU16 = bf16((sum of the split-K slabs of dZlat) + KLD part) on the real rows, 0 on the padding
-__global__ void vae_latent_bwd16_kernel(const float* __restrict__ slabs, int nslab, int64_t stride,
-                                        const float* __restrict__ dMUk, bf16_t* __restrict__ dMU16, int L_p, int bs,
-                                        int bs_p) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)bs_p * L_p) return;
-    const int r = (int)(i / L_p);
-    float t = 0.f;
-    if (r < bs) {
-        constexpr int kMaxSlabs = 8;
-        float v[kMaxSlabs];
-#pragma unroll
-        for (int s = 0; s < kMaxSlabs; ++s) v[s] = s < nslab ? slabs[(int64_t)s * stride + i] : 0.f;
-        t = dMUk[i];
-#pragma unroll
-        for (int s = 0; s < kMaxSlabs; ++s)
-            if (s < nslab) t += v[s];
-        for (int s = kMaxSlabs; s < nslab; ++s) t += slabs[(int64_t)s * stride + i];
-    }
-    dMU16[i] = f2bf(t);
 }
 
 // ---- D-Adapt-Adam for the bf16 step ------------------------------------------------------------------------------------

@@ -48,7 +48,7 @@ void gemm16(hipStream_t s, const Gemm16Args& g, int splits) {
         if (g.N <= 32) launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
         else if (g.M <= 32) launch_gemm16<32, 128, 1, 4, EPI>(s, g, splits);
         else launch_gemm16<64, 128, 2, 2, EPI>(s, g, splits);
-    } else if constexpr (EPI == E16_LATENT_MASK) {
+    } else if constexpr (EPI == E16_LATENT_MASK || EPI == E16_LATENT_TRAIN || EPI == E16_LATENT_BWD) {
         launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
     } else {
         launch_gemm16<128, 128, 2, 4, EPI>(s, g, splits);
@@ -270,32 +270,25 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
         in_w = hl.nout_p;
     };
     for (int li = 0; li < nl; ++li) hidden_layer(li);
-    int mu_slabs = 1;
-    const float* mu_bias = h->pptr(h->tbmu);
-    {   // mu (encode.py:268): latent-wide output, contraction split over up to 8 slabs (summed by the reparam kernel)
+    {   // mu (encode.py:268) + reparameterisation (276-286) in one launch: MU fp32, Z16 = bf16(MU + eps)
         Gemm16Args g = args16(h);
         g.A = in; g.lda = in_w;
         g.B = w16(h, h->tWmu); g.ldb = in_w;
+        g.bias = h->pptr(h->tbmu);
         if (training && prev) {
             fold_bn(h, s, h->tWmu, h->tbmu, h->L_p, in_w, *prev, true, h->Wf16_mu.p, h->biasf_mu.p);
             g.B = h->Wf16_mu.p;
-            mu_bias = h->biasf_mu.p;
+            g.bias = h->biasf_mu.p;
         }
-        g.C32 = h->skinny.p; g.ldc32 = h->L_p;
-        g.M = bs_p; g.N = h->L_p; g.K = in_w;
-        const int want = std::max(1, std::min(kSkinnySplits, in_w / 128));
-        g.k_per_split = (int)round_up(ceil_div(in_w, want), 64);
-        mu_slabs = (int)ceil_div(in_w, g.k_per_split);
-        g.slab_stride = (int64_t)bs_p * h->L_p;
-        gemm16<E16_SPLITK>(s, g, mu_slabs);
-    }
-    {
-        const int64_t tot = (int64_t)bs_p * h->L_p;
-        const float* eps_ptr = eps_injected ? h->EPS.p : nullptr;
-        hipLaunchKernelGGL(vae_reparam16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s,
-                           (const float*)h->skinny.p, mu_slabs, (int64_t)bs_p * h->L_p, mu_bias, eps_ptr,
-                           layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z16.p, bs, h->L, h->L_p, bs_p);
-        VH_HIP(hipGetLastError());
+        g.C32 = h->MU.p; g.ldc32 = h->L_p;
+        g.C16 = h->Z16.p; g.ldc16 = h->L_p;
+        g.M = bs_p; g.N = h->L_p; g.K = in_w; g.k_per_split = g.K;
+        g.m_real = bs; g.n_real = h->L;
+        g.aux = eps_injected ? h->EPS.p : nullptr;
+        g.noise = add_noise ? 1 : 0;
+        g.drop_key = layer_key(h, 0xEE);
+        g.step_ptr = step_ptr(h);
+        gemm16<E16_LATENT_TRAIN>(s, g, 1);
         // the transposed latent code feeds the first decoder layer's weight gradient
         if (defer) defer->add([h, bs_p](hipStream_t st) { transpose16(h, st, h->Z16.p, bs_p, h->L_p, h->Z16T.p, nullptr, 0); });
     }
@@ -410,7 +403,6 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         });
         grad_input16(h, h->dR16.p, h->D_p, h->tWo, last.nout_p, last);
     }
-    int latent_slabs = 1;
     auto hidden_bwd = [&](int li) {
         Hidden& hl = h->hidden[li];
         Dz16Args a;
@@ -439,29 +431,22 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         if (li == 0) {
             grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, h->stream);
         } else if (li == nl) {
-            // first decoder layer -> latent: latent-wide output, split-K slabs summed by the latent kernel
+            // first decoder layer -> latent, fused with dMU = dZlat + d(KLD)/dmu (zero on the padding rows)
             Gemm16Args g = args16(h);
             g.A = hl.DZ16.p; g.lda = hl.nout_p;
             g.B = w16t(h, hl.tW); g.ldb = hl.nout_p;
-            g.M = bs_p; g.N = in_p; g.K = hl.nout_p;
-            const int want = std::max(1, std::min(kSkinnySplits, hl.nout_p / 128));
-            g.k_per_split = (int)round_up(ceil_div(hl.nout_p, want), 64);
-            latent_slabs = (int)ceil_div(hl.nout_p, g.k_per_split);
-            g.C32 = h->skinny.p; g.ldc32 = in_p;
-            g.slab_stride = (int64_t)bs_p * in_p;
-            gemm16<E16_SPLITK>(h->stream, g, latent_slabs);
+            g.M = bs_p; g.N = in_p; g.K = hl.nout_p; g.k_per_split = g.K;
+            g.C16 = h->dMU16.p; g.ldc16 = in_p;
+            g.aux = h->dMUk.p;
+            g.m_real = bs; g.n_real = in_p;
+            gemm16<E16_LATENT_BWD>(h->stream, g, 1);
         } else {
             grad_input16(h, hl.DZ16.p, hl.nout_p, hl.tW, in_p, h->hidden[li - 1]);
         }
     };
     for (int li = 2 * nl - 1; li >= nl; --li) hidden_bwd(li);
-    {   // latent: dMU = dZlat + d(KLD)/dmu; mu layer
+    {   // mu layer (dMU16 was written by the fused epilogue above)
         Hidden& enc_last = h->hidden[nl - 1];
-        const int64_t tot = (int64_t)bs_p * h->L_p;
-        hipLaunchKernelGGL(vae_latent_bwd16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, h->stream,
-                           (const float*)h->skinny.p, latent_slabs, (int64_t)bs_p * h->L_p, (const float*)h->dMUk.p,
-                           h->dMU16.p, h->L_p, bs, bs_p);
-        VH_HIP(hipGetLastError());
         q.add([h, bs_p, bs, &enc_last](hipStream_t st) {
             transpose16(h, st, h->dMU16.p, bs_p, h->L_p, h->dMU16T.p, h->dbias_mu, bs);
             grad_weight16(h, h->tWmu, h->dMU16T.p, h->L_p, enc_last.H16T.p, enc_last.nout_p, st);
