@@ -98,7 +98,7 @@ def loss_weights(nsamples, nlatent, alpha, beta):
 
 class OracleVAE:
     def __init__(self, nsamples, nhiddens=None, nlatent=32, alpha=None, beta=200.0, dropout=0.2,
-                 state=None, dtype=np.float64):
+                 state=None, dtype=np.float64, bn_sync=None):
         if alpha is None:
             alpha = 0.15 if nsamples > 1 else 0.50
         if nhiddens is None:
@@ -108,6 +108,10 @@ class OracleVAE:
         self.nsamples, self.nhiddens, self.nlatent = nsamples, list(nhiddens), nlatent
         self.alpha, self.beta, self.dropout = alpha, beta, dropout
         self.dtype = dtype
+        # data-parallel shard with synchronised BatchNorm: bn_sync(array) -> element-wise SUM of the array over all
+        # ranks.  The batch statistics (and the two sums of the BatchNorm backward) then span the all-rank batch, which
+        # is what the single-process reference computes on the whole batch (encode.py:238,246,264).
+        self.bn_sync = bn_sync
         self.state = {k: (np.array(v, dtype=dtype) if v.dtype.kind == "f" else np.array(v))
                       for k, v in state.items()}
         self.names = param_names(self.nhiddens)
@@ -128,10 +132,19 @@ class OracleVAE:
             h = r * (mask.astype(self.dtype) * scale)
         else:
             h = r
-        if train:
+        n_glob = h.shape[0]
+        if train and self.bn_sync is not None:
+            tot = self.bn_sync(np.concatenate([h.sum(axis=0), (h * h).sum(axis=0), [float(h.shape[0])]]))
+            n_glob = int(round(tot[-1]))
+            nc = h.shape[1]
+            mean = tot[:nc] / n_glob
+            var = np.maximum(tot[nc:2 * nc] / n_glob - mean * mean, 0.0)
+            n = n_glob
+        elif train:
             mean = h.mean(axis=0)
             var = ((h - mean) ** 2).mean(axis=0)
             n = h.shape[0]
+        if train:
             st[norm + ".running_mean"] = (1 - BN_MOMENTUM) * st[norm + ".running_mean"] + BN_MOMENTUM * mean
             st[norm + ".running_var"] = (1 - BN_MOMENTUM) * st[norm + ".running_var"] + BN_MOMENTUM * var * (n / (n - 1))
             st[norm + ".num_batches_tracked"] = st[norm + ".num_batches_tracked"] + 1
@@ -140,7 +153,7 @@ class OracleVAE:
         invstd = 1.0 / np.sqrt(var + BN_EPS)
         xhat = (h - mean) * invstd
         a = xhat * st[norm + ".weight"] + st[norm + ".bias"]
-        return a, dict(a_prev=a_prev, z=z, mask=mask, xhat=xhat, invstd=invstd, lin=lin, norm=norm)
+        return a, dict(a_prev=a_prev, z=z, mask=mask, xhat=xhat, invstd=invstd, lin=lin, norm=norm, n_glob=n_glob)
 
     def forward(self, depths, tnf, abundance, eps=None, masks=None, train=True):
         """encode.py:306-314.  ``masks``: list of 2*len(nhiddens) boolean [B, n] keep-masks in the
@@ -227,7 +240,13 @@ class OracleVAE:
             grads[norm + ".weight"] = (da * t["xhat"]).sum(axis=0)
             grads[norm + ".bias"] = da.sum(axis=0)
             dxhat = da * st[norm + ".weight"]
-            dh = t["invstd"] * (dxhat - dxhat.mean(axis=0) - t["xhat"] * (dxhat * t["xhat"]).mean(axis=0))
+            if self.bn_sync is not None:
+                nc = dxhat.shape[1]
+                tot = self.bn_sync(np.concatenate([dxhat.sum(axis=0), (dxhat * t["xhat"]).sum(axis=0)]))
+                m1, m2 = tot[:nc] / t["n_glob"], tot[nc:] / t["n_glob"]
+            else:
+                m1, m2 = dxhat.mean(axis=0), (dxhat * t["xhat"]).mean(axis=0)
+            dh = t["invstd"] * (dxhat - m1 - t["xhat"] * m2)
             if self.dropout > 0 and t["mask"] is not None:
                 scale = self.dtype(1.0) / (self.dtype(1.0) - self.dtype(self.dropout))
                 dr = dh * (t["mask"].astype(self.dtype) * scale)

@@ -101,8 +101,11 @@ def pack_stream(clusters):
                 successes=succ, attempts=att, sizes=sizes, members=members.astype(np.int32))
 
 
-def streams_equal(a, b):
-    """Exact comparison of two packed streams; returns (ok, message)."""
+def streams_equal(a, b, pvr_rtol=0.0):
+    """Exact comparison of two packed streams; returns (ok, message).  pvr_rtol > 0 relaxes ONLY the reported
+    `observed_pvr` (a ratio of smoothed histogram densities that the reference forms from torch.histogram's
+    order-dependent float32 bin sums; with thousands of members per bin its last bit can differ from the correctly
+    rounded exact sum although every decision -- medoid, radius, members -- is identical)."""
     for key in ("medoid", "seed", "kind", "successes", "attempts", "sizes", "members"):
         if a[key].shape != b[key].shape or not np.array_equal(a[key], b[key]):
             n = min(len(a[key]), len(b[key]))
@@ -110,8 +113,13 @@ def streams_equal(a, b):
             first = int(bad[0]) if len(bad) else n
             return False, f"{key} differs (first at {first}; lens {len(a[key])} vs {len(b[key])})"
     for key in ("radius", "observed_pvr", "maximal_pvr"):
-        if not np.array_equal(a[key], b[key], equal_nan=True):
-            return False, f"{key} differs"
+        if np.array_equal(a[key], b[key], equal_nan=True):
+            continue
+        if key == "observed_pvr" and pvr_rtol > 0 and np.array_equal(np.isnan(a[key]), np.isnan(b[key])):
+            m = ~np.isnan(a[key])
+            if np.all(np.abs(a[key][m] - b[key][m]) <= pvr_rtol * np.abs(b[key][m])):
+                continue
+        return False, f"{key} differs"
     return True, "identical"
 
 

@@ -213,14 +213,17 @@ def test_100k_stream_matches_reference_golden(name):
     (500 clusters of ~200 members: thousands of members per density sum, the regime where torch's order-dependent fp32
     `sum` (cluster.py:628-629) could disagree with the exact integer accumulation on a near-tie of
     `sample_density > local_density`) and sigma 0.5 (31 583 clusters: loner / NoThreshold / fallback / PVR
-    relaxation).  Every field of every cluster must be identical: medoid, seed, kind, radius, pvr, members,
-    successes, attempts -- i.e. no near-tie flipped a decision anywhere in either stream."""
+    relaxation).  Every decision of every cluster must be identical: medoid, seed, kind, radius, members, successes,
+    attempts, maximal pvr -- i.e. no near-tie flipped anything anywhere in either stream.  The only place where the
+    exact integer accumulation and torch's float32 sums disagree at this size is the REPORTED observed_pvr of 2 of the
+    500 sigma-0.08 clusters (relative 9e-8: the last bit of a valley density of ~2e-12 formed from torch.histogram's
+    order-dependent bin sums); it is compared to 1e-6 here and exactly in every smaller fixture."""
     mat, lens, kw = fd.cluster_inputs(name)
     golden = fd.load("cluster_" + name)
     order_hash = hashlib.sha256(np.argsort(lens)[::-1].astype(np.int64).tobytes()).hexdigest()
     assert str(golden["order_sha256"]) == order_hash      # lengths are unique: the seed order cannot depend on the CPU
     got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
-    ok, msg = fd.streams_equal(got, golden)
+    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-6)
     assert ok, "vs reference golden: " + msg
 
 
@@ -231,7 +234,7 @@ def test_100k_stream_python_state_machine(monkeypatch):
     name = "blob_s008_n100000"
     mat, lens, kw = fd.cluster_inputs(name)
     got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
-    ok, msg = fd.streams_equal(got, fd.load("cluster_" + name))
+    ok, msg = fd.streams_equal(got, fd.load("cluster_" + name), pvr_rtol=1e-6)
     assert ok, msg
 
 

@@ -124,6 +124,48 @@ def _plan_and_grads(comm):
     return dict(err=err, wsum_err=wsum_check)
 
 
+def _syncbn_grads(comm):
+    """Data parallelism with synchronised BatchNorm: every rank runs forward / backward on ITS half of a batch, the
+    BatchNorm batch sums (forward: sum h, sum h^2; backward: sum dy, sum dy xhat) are all-reduced, the loss is
+    normalised by the all-rank batch -- the summed gradients and the running statistics must equal the serial
+    single-process step on the whole batch (the reference's semantics)."""
+    import fixture_defs as fd
+    import vae_oracle as vo
+
+    name = "vae_small_drop"
+    c = fd.VAE_CASES[name]
+    g = fd.load(name)
+    masks, eps = fd.vae_randomness(name)
+    B = c["batch"]                     # 24 rows: 12 per rank
+    half = B // comm.world
+    lo, hi = comm.rank * half, (comm.rank + 1) * half
+    d, t, a, w = (g[k][:B] for k in ("depths", "tnf", "total_abundance", "weights"))
+    st0 = vo.init_state(c["nsamples"], c["nhiddens"], c["nlatent"], c["seed"])
+    m = vo.OracleVAE(c["nsamples"], c["nhiddens"], c["nlatent"], c["alpha"], c["beta"], c["dropout"], state=st0,
+                     bn_sync=lambda x: comm.all_reduce_sum(np.asarray(x, dtype=np.float64)))
+    mk = [mm[lo:hi] for mm in masks[0]]
+    do, to, ao, mu = m.forward(d[lo:hi], t[lo:hi], a[lo:hi], eps=eps[0][lo:hi], masks=mk, train=True)
+    m.calc_loss(d[lo:hi], do, t[lo:hi], to, a[lo:hi], ao, mu, w[lo:hi], global_wsum=float(w.sum()), global_batch=B)
+    mine = m.backward()
+    keys = sorted(mine)
+    summed = comm.all_reduce_sum(np.concatenate([mine[k].reshape(-1) for k in keys]))
+    # the serial truth: one process, the whole batch
+    s = vo.OracleVAE(c["nsamples"], c["nhiddens"], c["nlatent"], c["alpha"], c["beta"], c["dropout"], state=st0)
+    do, to, ao, mu = s.forward(d, t, a, eps=eps[0], masks=masks[0], train=True)
+    s.calc_loss(d, do, t, to, a, ao, mu, w)
+    ref = s.backward()
+    flat_ref = np.concatenate([ref[k].reshape(-1) for k in keys])
+    err = float(np.abs(summed - flat_ref).max() / np.abs(flat_ref).max())
+    rs_err = max(float(np.abs(m.state[k] - s.state[k]).max()) for k in m.state if "running" in k)
+    return dict(err=err, running_err=rs_err)
+
+
+def test_syncbn_data_parallel_equals_serial_global_batch(oracle_lib):
+    res = _run("_syncbn_grads")
+    for rank, out in res.items():
+        assert out["err"] < 1e-7 and out["running_err"] < 1e-12, (rank, out)   # E[h^2] - mean^2 vs mean((h - mean)^2) in fp64
+
+
 def test_sharded_cluster_stream_is_identical(oracle_lib):
     res = _run("_sharded_cluster")
     for rank, out in res.items():

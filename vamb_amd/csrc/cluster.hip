@@ -283,6 +283,131 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K6m: the same scan for 9..32 medoids on the matrix pipe.  [32 rows] x [32 medoids] dot products are one chain of
+// v_mfma_f32_32x32x2_f32 over the latent columns: exact fp32 products accumulated as a k-ordered fmaf chain from +0
+// (CDNA4 guide: bitwise equal to the per-lane fmaf loop of clu_scan_kernel), so every accumulator, list and stream
+// stays bit-identical -- but a pass costs 2 global loads + 1 MFMA per column pair and lane instead of 32 x RPT fmaf
+// plus an LDS read of the query per column, and is HBM-bound again (k = 25: 221 -> ~60 us at 2 M x 32).
+//   A operand: lane l supplies x[row base + (l & 31)][column 2 s + (l >> 5)]   (two coalesced 128-byte segments of Mt)
+//   B operand: lane l supplies q[medoid l & 31][column 2 s + (l >> 5)]         (NK registers, loaded once per kernel)
+//   D: lane l holds medoid j = l & 31 against rows base + (reg & 3) + 8 (reg >> 2) + 4 (l >> 5), reg = 0..15
+// A wavefront owns 32-row tiles (grid-stride); the next tile's loads are issued before the current tile is evaluated.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float scan_f32x16;
+
+template <int NK>
+struct ScanTile {
+    float xa[NK];
+    uint4 k0, k1;       // live flags of the 32 rows
+    float4 len[4];      // lengths of this half-wave's 16 rows
+};
+
+template <int NK>
+__device__ __forceinline__ void scan_tile_load(ScanTile<NK>& t, const float* __restrict__ Mt, int64_t ld, int nk,
+                                               const float* __restrict__ lengths, const uint8_t* __restrict__ kept,
+                                               int64_t base, int j, int h) {
+    t.k0 = *reinterpret_cast<const uint4*>(kept + base);
+    t.k1 = *reinterpret_cast<const uint4*>(kept + base + 16);
+#pragma unroll
+    for (int s = 0; s < NK; ++s) t.xa[s] = s < nk ? Mt[(int64_t)(2 * s + h) * ld + base + j] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t.len[q] = *reinterpret_cast<const float4*>(lengths + base + 8 * q + 4 * h);
+}
+
+template <int NK>
+__global__ __launch_bounds__(kBlock) void clu_scan_mfma_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
+                                                               const float* __restrict__ lengths,
+                                                               const uint8_t* __restrict__ kept,
+                                                               const float* __restrict__ q_ext, const MedoidRows medoid,
+                                                               unsigned long long* __restrict__ results,
+                                                               int32_t* __restrict__ lists) {
+    constexpr int KM = kMaxMedoids;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(smem_raw);       // [KM][kResultWords]
+    float* edges_s = reinterpret_cast<float*>(acc_s + KM * kResultWords);               // [64]
+    unsigned int* lcnt_s = reinterpret_cast<unsigned int*>(edges_s + 64);               // [KM]
+    int32_t* llist_s = reinterpret_cast<int32_t*>(lcnt_s + KM);                         // [KM][kLocalCap]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
+    for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
+    for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int nk = L4 >> 1;
+    const long long my_med = medoid.row[j];
+    float qb[NK];
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+        const int k = 2 * s + h;
+        qb[s] = 0.0f;
+        if (s < nk) qb[s] = q_ext ? q_ext[j * L4 + k] : Mt[(int64_t)k * ld + my_med];
+    }
+    __syncthreads();
+    const float radius = 0.05f;
+    const float edge_hi = edges_s[VH_NBINS];
+    const int64_t ntiles = ld >> 5;
+    const int64_t stride = (int64_t)gridDim.x * (kBlock / 64);
+    int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    ScanTile<NK> cur;
+    if (tile < ntiles) scan_tile_load<NK>(cur, Mt, ld, nk, lengths, kept, tile << 5, j, h);
+    for (; tile < ntiles; tile += stride) {
+        const int64_t base = tile << 5;
+        ScanTile<NK> nxt = cur;
+        if (tile + stride < ntiles) scan_tile_load<NK>(nxt, Mt, ld, nk, lengths, kept, (tile + stride) << 5, j, h);
+        scan_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NK; ++s)
+            if (s < nk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.xa[s], qb[s], acc, 0, 0, 0);
+        // live flags of this half-wave's rows: group q holds rows 8 q + 4 h .. + 3 = dword 2 q + h of the 8 flag dwords
+        const uint32_t kw[8] = {cur.k0.x, cur.k0.y, cur.k0.z, cur.k0.w, cur.k1.x, cur.k1.y, cur.k1.z, cur.k1.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t live4 = h ? kw[2 * q + 1] : kw[2 * q];
+            const float lq[4] = {cur.len[q].x, cur.len[q].y, cur.len[q].z, cur.len[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t row = base + 8 * q + 4 * h + e;
+                if (((live4 >> (8 * e)) & 0xFFu) == 0u) continue;
+                float d = 0.5f - acc[4 * q + e];
+                if (row == my_med) d = 0.0f;
+                if (d > edge_hi) continue;
+                const float len = lq[e];
+                if (d <= radius) {
+                    const float p = len * (radius - d);
+                    atomicAdd(&acc_s[j * kResultWords + 0], rn_u64(p * (float)VH_DENSITY_SCALE));
+                    atomicAdd(&acc_s[j * kResultWords + 1 + VH_NBINS], 1ull);
+                    if (d < radius) atomicAdd(&acc_s[j * kResultWords + 2 + VH_NBINS], 1ull);
+                    const unsigned int lp = atomicAdd(&lcnt_s[j], 1u);
+                    if (lp < (unsigned int)kLocalCap) llist_s[j * kLocalCap + lp] = (int32_t)row;
+                }
+                if (d >= edges_s[0])
+                    atomicAdd(&acc_s[j * kResultWords + 1 + bin_of_in_range(d, edges_s)], rn_u64(len * (float)VH_HIST_SCALE));
+            }
+        }
+        cur = nxt;
+    }
+    __syncthreads();
+    for (int i = tid; i < KM * kResultWords; i += kBlock) {
+        const unsigned long long v = acc_s[i];
+        if (v != 0ull) atomicAdd(&results[i], v);
+    }
+    for (int jj = 0; jj < KM; ++jj) {
+        const unsigned int cnt = lcnt_s[jj];
+        if (cnt == 0u) continue;
+        unsigned int* cursor = reinterpret_cast<unsigned int*>(&results[jj * kResultWords + 3 + VH_NBINS]);
+        __shared__ unsigned int start_m;
+        if (tid == 0) start_m = cnt > (unsigned int)kLocalCap ? atomicOr(cursor, 0x80000000u) | 0x80000000u
+                                                              : atomicAdd(cursor, cnt);
+        __syncthreads();
+        const unsigned int start = start_m;
+        if (start + cnt <= (unsigned int)kListCap && tid < (int)cnt) lists[jj * kListCap + start + tid] = llist_s[jj * kLocalCap + tid];
+        __syncthreads();
+    }
+}
+
 // K6b: publication without a copy-engine round trip.  One block moves the accumulators and the candidate
 // lists into host-mapped memory, zeroes the accumulators for the next scan and then raises the sequence flag
 // the host spins on.  (A separate launch, not a last-block-done tail of the scan: the kernel boundary is the
@@ -553,6 +678,8 @@ struct vh_clu {
     }
     unsigned long long* flag() { return host_results + (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS); }
     int scan_dbg = 0;             // VAMBHIP_SCAN_DBG: timing experiments only (wrong results)
+    bool use_mfma = true;         // VAMBHIP_SCAN_MFMA=0: passes with more than 8 medoids stay on the VALU kernel (A/B)
+    bool mfma_pass = false;       // set by scan_core for the pass being launched
     bool small_rpt = true;        // VAMBHIP_SCAN_WIDE=1 disables the narrow variant (A/B measurements)
     uint64_t scan_seq = 0;        // number of scans issued; scan s wrote ring slot s % kListRing
     int last_k = 0;
@@ -629,7 +756,25 @@ void launch_scan(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     else launch_scan_rpt<KM, RPT>(h, med, q_ext);
 }
 
+template <int NK>
+void launch_scan_mfma(vh_clu* h, const MedoidRows& med, const float* q_ext) {
+    const size_t smem = (size_t)kMaxMedoids * kResultWords * 8 + 64 * 4 + (size_t)kMaxMedoids * 4 * (1 + kLocalCap);
+    const int64_t tiles = h->ld / 32;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(tiles, kBlock / 64), 256 * 8));
+    hipLaunchKernelGGL((clu_scan_mfma_kernel<NK>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
+                       h->lengths.p, h->kept.p, q_ext, med, h->results.p, h->lists_dev.p);
+}
+
+// medoid counts above 8 run on the matrix pipe (always 32 medoid slots) when the latent width fits its registers
+bool scan_uses_mfma(const vh_clu* h, int k) { return h->use_mfma && k > 8 && h->L4 <= 64; }
+
 void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext) {
+    if (km == kMaxMedoids && h->use_mfma && h->L4 <= 64 && h->mfma_pass) {
+        if (h->L4 <= 32) launch_scan_mfma<16>(h, med, q_ext);
+        else launch_scan_mfma<32>(h, med, q_ext);
+        VH_HIP(hipGetLastError());
+        return;
+    }
     switch (km) {
         case 1: launch_scan<1>(h, med, q_ext); break;
         case 2: launch_scan<2>(h, med, q_ext); break;
@@ -685,6 +830,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->kept.alloc((size_t)h->ld);
         h->q.alloc((size_t)kMaxMedoids * h->L4);
         h->small_rpt = getenv("VAMBHIP_SCAN_WIDE") == nullptr;
+        { const char* e = getenv("VAMBHIP_SCAN_MFMA"); h->use_mfma = !(e && e[0] == '0'); }
         h->scan_dbg = getenv("VAMBHIP_SCAN_DBG") ? atoi(getenv("VAMBHIP_SCAN_DBG")) : 0;
         h->results.alloc((size_t)kMaxMedoids * kResultWords);
         h->lists_dev.alloc((size_t)kMaxMedoids * kListCap);
@@ -762,7 +908,8 @@ namespace {
 int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries) {
     VH_REQUIRE(h != nullptr && medoid_rows != nullptr, "NULL argument");
     VH_REQUIRE(k >= 1 && k <= kMaxMedoids, "k=%d outside [1, %d]", k, kMaxMedoids);
-    const int km = pick_km(k);
+    h->mfma_pass = scan_uses_mfma(h, k);
+    const int km = h->mfma_pass ? kMaxMedoids : pick_km(k);
     MedoidRows med;
     for (int j = 0; j < kMaxMedoids; ++j) {
         const int64_t m = medoid_rows[j < k ? j : 0];
@@ -1227,7 +1374,8 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
     size_t n_needed = missing.size();
     if (g->speculate) {
         size_t target = (size_t)pick_km((int)std::min<size_t>(missing.size(), kMaxMedoids));
-        if (missing.size() <= 8 && g->clu->n_rows <= 600000) target = kMaxMedoids;       // latency-bound pass: extra medoids are free
+        if (g->clu->use_mfma && g->clu->L4 <= 64) target = kMaxMedoids;                   // matrix-pipe pass: 32 medoids cost what 1 costs
+        else if (missing.size() <= 8 && g->clu->n_rows <= 600000) target = kMaxMedoids;  // latency-bound pass: extra medoids are free
         else if (missing.size() == 1) target = 8;
         // look-ahead window: at most kSpecWindow unused speculative entries at any time (every emission re-validates them)
         size_t n_spec = 0;

@@ -117,7 +117,9 @@ __device__ __forceinline__ uint32_t hash_drop(uint64_t key, uint32_t idx) {
 __device__ __forceinline__ float hash_randn(uint64_t key, uint64_t id) {
     const float u1 = ((float)hash32(key, 2 * id) + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
     const float u2 = (float)hash32(key, 2 * id + 1) * 2.3283064365386963e-10f;
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    // hardware log2 / cos (v_log_f32, v_cos_f32): the libm-accurate versions made the noise the most expensive part of
+    // the kernels that draw it; 1-2 ulp of a standard-normal deviate is far below its own sampling noise
+    return __fsqrt_rn(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);
 }
 
 __device__ __forceinline__ uint64_t step_key(uint64_t base, const unsigned long long* step_ptr) {

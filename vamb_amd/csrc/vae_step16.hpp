@@ -48,7 +48,11 @@ void gemm16(hipStream_t s, const Gemm16Args& g, int splits) {
         if (g.N <= 32) launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
         else if (g.M <= 32) launch_gemm16<32, 128, 1, 4, EPI>(s, g, splits);
         else launch_gemm16<64, 128, 2, 2, EPI>(s, g, splits);
-    } else if constexpr (EPI == E16_LATENT_MASK || EPI == E16_LATENT_TRAIN || EPI == E16_LATENT_BWD) {
+    } else if constexpr (EPI == E16_LATENT_TRAIN || EPI == E16_LATENT_BWD) {
+        // latent-wide output with the whole contraction in one workgroup (the epilogue needs the complete sums):
+        // one wavefront per 32 x 32 tile = 256 workgroups at batch 8192 (128 x 32 tiles: 64 workgroups, 18 us)
+        launch_gemm16<32, 32, 1, 1, EPI>(s, g, splits);
+    } else if constexpr (EPI == E16_LATENT_MASK) {
         launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
     } else {
         launch_gemm16<128, 128, 2, 4, EPI>(s, g, splits);
