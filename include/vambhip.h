@@ -67,6 +67,9 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
 int vh_clu_destroy(vh_clu* h);
 /* current number of physical rows (live + masked-out) */
 int vh_clu_rows(vh_clu* h, int64_t* n_rows, int64_t* n_live);
+/* medoids one vh_clu_scan pass takes for this handle's latent width: 32, fewer for very wide latent spaces (the
+ * query vectors are staged in LDS; the reference has no limit on the latent width, cluster.py:204-222) */
+int vh_clu_max_medoids(vh_clu* h, int* k);
 
 /* sample_medoid (cluster.py:606-637) + head of find_threshold (cluster.py:452-481) for k medoids in
  * ONE pass over the matrix.  medoid_rows[j] is the physical row whose distance is forced to 0
@@ -135,6 +138,9 @@ int vh_debug_find_threshold(const int64_t* hist_fx, int64_t n_lt, double pvr, in
 /* test hook (host only): n_calls consecutive random.Random(seed).sample(range(ns[i]), ks[i]) on one generator,
  * results concatenated into out (sum of ks entries) */
 int vh_debug_pyrandom_sample(uint64_t seed, int n_calls, const int64_t* ns, const int64_t* ks, int64_t* out);
+/* the generator's mutable search state AFTER the last vh_gen_next (ClusterGenerator.peak_valley_ratio / successes /
+ * len(attempts) / order_index, cluster.py:282-283, 386-413): what repr() and callers inspecting the attributes see */
+int vh_gen_state(vh_gen* g, double* peak_valley_ratio, int64_t* successes, int64_t* attempts, int64_t* order_index);
 /* accounting: passes over the matrix, medoids scanned, rows streamed, summed kernel time (when timing is on) */
 int vh_gen_counters(vh_gen* g, int64_t* scan_passes, int64_t* scan_medoids, int64_t* rows_streamed,
                     double* kernel_ms, int64_t* n_emitted, int64_t* n_remaining);
@@ -210,6 +216,14 @@ int vh_vae_get_hidden(vh_vae* h, int layer, float* out, int64_t n);
 
 /* D-Adapt-Adam group state (d, numerator_weighted, k) */
 int vh_vae_opt_state(vh_vae* h, double* d, double* numerator_weighted, int64_t* k);
+/* restore the group state (resuming a run whose moments were restored with vh_vae_set_opt_moments) */
+int vh_vae_opt_set_state(vh_vae* h, double d, double numerator_weighted, int64_t k);
+/* a fresh optimiser, as `DAdaptAdam(self.parameters(), decouple=True)` at the top of trainmodel (encode.py:578):
+ * exp_avg = exp_avg_sq = s = 0, d = 1e-6, numerator_weighted = 0, k = 0 */
+int vh_vae_reset_optimizer(vh_vae* h);
+/* per-parameter optimiser state by state_dict name: which = 0 exp_avg, 1 exp_avg_sq, 2 s */
+int vh_vae_get_opt_moment(vh_vae* h, const char* name, int which, float* data, int64_t n);
+int vh_vae_set_opt_moment(vh_vae* h, const char* name, int which, const float* data, int64_t n);
 
 /* A dataset that outlives / is shared between VAE handles (one upload per `vamb bin default` run, however many
  * models are trained on it).  The handle must stay alive while a VAE uses it. */

@@ -147,6 +147,25 @@ def main():
         manifest["cluster"] = gen_cluster(cl)
     if "cluster_large" in which:   # 100 k-point streams (minutes of reference CPU time each)
         manifest["cluster_large"] = gen_cluster(cl, fd.CLUSTER_CASES_LARGE)
+    if "cluster_large_defined_order" in which:
+        # The same inputs through the defined-order restatement (oracle/cluster_oracle.py + cluster_scan.c), stored
+        # because at this size the REAL reference is no longer reproducible bit for bit by anything but itself: see
+        # oracle/analyze_near_tie.py / profiles/r02_near_tie_100k_s050.txt.  The GPU must equal THIS stream exactly and
+        # the reference stream up to the documented divergence.
+        import cluster_oracle as co
+
+        out = {}
+        for name in fd.CLUSTER_CASES_LARGE:
+            mat, lens, kw = fd.cluster_inputs(name)
+            packed = fd.pack_stream(list(co.OracleClusterGenerator(mat.copy(), lens, **kw)))
+            np.savez_compressed(os.path.join(HERE, f"cluster_{name}.defined_order.npz"), **packed)
+            ref = fd.load("cluster_" + name)
+            n = min(len(packed["medoid"]), len(ref["medoid"]))
+            diff = np.flatnonzero(packed["medoid"][:n] != ref["medoid"][:n])
+            out[name] = dict(n_clusters=len(packed["medoid"]),
+                             identical_prefix_with_reference=int(diff[0]) if len(diff) else n)
+            print("defined-order", name, out[name])
+        manifest["cluster_large_defined_order"] = out
     if "prep" in which:
         manifest["prep"] = gen_prep(en)
     if "vae" in which:

@@ -54,6 +54,7 @@ SIGNATURES = {
     "vh_clu_create": (_int, [_vp, _vp, _i64, _int, _int, _vp, _pp]),
     "vh_clu_destroy": (_int, [_vp]),
     "vh_clu_rows": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "vh_clu_max_medoids": (_int, [_vp, ctypes.POINTER(_int)]),
     "vh_clu_scan": (_int, [_vp, _int, _vp, _vp, _vp]),
     "vh_clu_scan_seq": (_int, [_vp, ctypes.POINTER(_i64)]),
     "vh_clu_scan_list": (_int, [_vp, _i64, _int, _vp, _i64, ctypes.POINTER(_i64)]),
@@ -64,6 +65,8 @@ SIGNATURES = {
     "vh_debug_find_threshold": (_int, [_vp, _i64, ctypes.c_double, ctypes.POINTER(_int), ctypes.POINTER(ctypes.c_double),
                                        ctypes.POINTER(ctypes.c_double)]),
     "vh_debug_pyrandom_sample": (_int, [ctypes.c_uint64, _int, _vp, _vp, _vp]),
+    "vh_gen_state": (_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
+                            ctypes.POINTER(_i64)]),
     "vh_gen_counters": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "vh_clu_select": (_int, [_vp, _i64, _vp, _f32, _int, _vp, _i64, ctypes.POINTER(_i64)]),
@@ -86,6 +89,10 @@ SIGNATURES = {
     "vh_vae_encode": (_int, [_vp, _vp]),
     "vh_vae_opt_state": (_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                 ctypes.POINTER(_i64)]),
+    "vh_vae_opt_set_state": (_int, [_vp, ctypes.c_double, ctypes.c_double, _i64]),
+    "vh_vae_reset_optimizer": (_int, [_vp]),
+    "vh_vae_get_opt_moment": (_int, [_vp, ctypes.c_char_p, _int, _vp, _i64]),
+    "vh_vae_set_opt_moment": (_int, [_vp, ctypes.c_char_p, _int, _vp, _i64]),
     "vh_dataset_create": (_int, [_vp, _vp, _vp, _vp, _i64, _int, ctypes.POINTER(_vp)]),
     "vh_dataset_destroy": (_int, [_vp]),
     "vh_vae_use_dataset": (_int, [_vp, _vp]),

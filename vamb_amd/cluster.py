@@ -132,6 +132,9 @@ class HipScanBackend:
         self.L = matrix.shape[1]
         self.n_rows = matrix.shape[0]
         self._res = (_lib.ScanResult * _MAX_MEDOIDS_PER_PASS)()
+        k = ctypes.c_int(0)
+        _lib.check(self.lib.vh_clu_max_medoids(self.h, ctypes.byref(k)))
+        self.max_medoids = k.value          # < 32 for very wide latent spaces (query vectors are staged in LDS)
         self._sel = _np.empty(max(1, self.n_rows), _np.int64)
         # accounting for bench.py / DESIGN.md roofline: rows streamed by scan and select passes
         self.scan_passes = 0
@@ -183,9 +186,9 @@ class HipScanBackend:
         """List of physical rows -> list of ScanStats (one pass per <= 32 medoids)."""
         out = []
         seq = ctypes.c_int64(0)
-        for lo in range(0, len(medoids), _MAX_MEDOIDS_PER_PASS):
+        for lo in range(0, len(medoids), self.max_medoids):
             _lib.check(self.lib.vh_clu_scan_seq(self.h, ctypes.byref(seq)))
-            raw = self.scan_raw(medoids[lo:lo + _MAX_MEDOIDS_PER_PASS])
+            raw = self.scan_raw(medoids[lo:lo + self.max_medoids])
             out.extend(ScanStats.batch(raw, seq.value))
         return out
 
@@ -324,7 +327,10 @@ class ClusterGenerator:
         return (f"ClusterGenerator({len(self.matrix)} points, {self.n_emitted_clusters} clusters)\n"
                 f"  CUDA:         {self.cuda}\n  maxsteps:     {self.maxsteps}\n"
                 f"  minsuccesses: {self.minsuccesses}\n  pvr:          {self.peak_valley_ratio}\n"
-                f"  successes:    {self.successes}/{len(self.attempts)}\n")
+                f"  successes:    {self.successes}/{self._n_attempts()}\n")
+
+    def _n_attempts(self) -> int:
+        return self._native_attempts if self._gen is not None else len(self.attempts)
 
     @staticmethod
     def _check_params(matrix, lengths, maxsteps, windowsize, minsuccesses) -> None:
@@ -412,6 +418,7 @@ class ClusterGenerator:
         # (row-sharded multi-GPU, the CPU oracle backend of the tests) and the specification of both.
         self._gen = None
         self._members_buf = None
+        self._native_attempts = 0
         if (native and isinstance(self._backend, HipScanBackend) and isinstance(rng_seed, int)
                 and abs(rng_seed) < 2 ** 64 and not _os.environ.get("VAMBHIP_PY_GENERATOR")):
             handle = ctypes.c_void_p()
@@ -436,7 +443,13 @@ class ClusterGenerator:
         radius = None if info.kind == 1 else info.radius
         self.n_emitted_clusters += 1
         self.n_remaining_points -= int(info.n_members)
-        self.peak_valley_ratio = info.maximal_pvr
+        # the attributes the reference exposes (repr, callers inspecting the search state) AFTER update_successes
+        pvr, succ, att, oi = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(lib.vh_gen_state(self._gen, ctypes.byref(pvr), ctypes.byref(succ), ctypes.byref(att), ctypes.byref(oi)))
+        self.peak_valley_ratio = pvr.value
+        self.successes = succ.value
+        self._native_attempts = att.value
+        self.order_index = oi.value
         self._counters_stale = True
         return Cluster(int(info.medoid), int(info.seed), members, info.maximal_pvr, observed, radius,
                        int(info.successes), int(info.attempts))

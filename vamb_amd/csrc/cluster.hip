@@ -678,6 +678,7 @@ struct vh_clu {
     }
     unsigned long long* flag() { return host_results + (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS); }
     int scan_dbg = 0;             // VAMBHIP_SCAN_DBG: timing experiments only (wrong results)
+    int max_k = kMaxMedoids;      // medoids per pass the LDS can hold for this latent width (query vectors are staged there)
     bool use_mfma = true;         // VAMBHIP_SCAN_MFMA=0: passes with more than 8 medoids stay on the VALU kernel (A/B)
     bool mfma_pass = false;       // set by scan_core for the pass being launched
     bool small_rpt = true;        // VAMBHIP_SCAN_WIDE=1 disables the narrow variant (A/B measurements)
@@ -733,9 +734,22 @@ void wait_for_scan(vh_clu* h, unsigned long long seq) {
     std::atomic_thread_fence(std::memory_order_acquire);
 }
 
+constexpr size_t kScanLdsBudget = 160 * 1024 - 512;   // one workgroup may use (almost) the whole LDS of a CU
+
+size_t scan_smem_bytes(int km, int L4) {
+    return (size_t)km * kResultWords * 8 + 64 * 4 + (size_t)km * L4 * 4 + (size_t)km * 4 * (1 + kLocalCap);
+}
+
 template <int KM, int RPT>
 void launch_scan_rpt(vh_clu* h, const MedoidRows& med, const float* q_ext) {
-    const size_t smem = (size_t)KM * kResultWords * 8 + 64 * 4 + (size_t)KM * h->L4 * 4 + (size_t)KM * 4 * (1 + kLocalCap);
+    const size_t smem = scan_smem_bytes(KM, h->L4);
+    static bool attr_set = false;
+    if (!attr_set) {   // wide latent spaces need more than the default 64 KiB of dynamic LDS (query vectors live there)
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_kernel<KM, RPT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScanLdsBudget));
+        attr_set = true;
+    }
+    VH_REQUIRE(smem <= kScanLdsBudget, "internal: %d medoids x %d latent columns do not fit the LDS", KM, h->L4);
     const int64_t blocks = ceil_div(h->ld, (int64_t)kBlock * RPT);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
     hipLaunchKernelGGL((clu_scan_kernel<KM, RPT>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
@@ -829,6 +843,14 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->lengths.alloc((size_t)h->ld);
         h->kept.alloc((size_t)h->ld);
         h->q.alloc((size_t)kMaxMedoids * h->L4);
+        {   // the reference has no limit on the latent width; here the scan stages up to 32 query vectors in LDS, so wide
+            // latent spaces take fewer medoids per pass (L = 4096: 4) -- never a launch failure in the middle of a sweep
+            static const int buckets[] = {32, 24, 16, 12, 8, 4, 2, 1};
+            h->max_k = 0;
+            for (int b : buckets)
+                if (scan_smem_bytes(b, h->L4) <= kScanLdsBudget) { h->max_k = b; break; }
+            VH_REQUIRE(h->max_k >= 1, "latent width %d does not fit the scan kernel's LDS", L);
+        }
         h->small_rpt = getenv("VAMBHIP_SCAN_WIDE") == nullptr;
         { const char* e = getenv("VAMBHIP_SCAN_MFMA"); h->use_mfma = !(e && e[0] == '0'); }
         h->scan_dbg = getenv("VAMBHIP_SCAN_DBG") ? atoi(getenv("VAMBHIP_SCAN_DBG")) : 0;
@@ -876,6 +898,13 @@ int vh_clu_destroy(vh_clu* h) {
     return guarded([&] { delete h; });
 }
 
+int vh_clu_max_medoids(vh_clu* h, int* k) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && k != nullptr, "NULL argument");
+        *k = h->max_k;
+    });
+}
+
 int vh_clu_rows(vh_clu* h, int64_t* n_rows, int64_t* n_live) {
     return guarded([&] {
         VH_REQUIRE(h != nullptr, "handle is NULL");
@@ -907,7 +936,7 @@ namespace {
 // kernel arguments and the query vectors are gathered by the scan kernel itself.
 int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries) {
     VH_REQUIRE(h != nullptr && medoid_rows != nullptr, "NULL argument");
-    VH_REQUIRE(k >= 1 && k <= kMaxMedoids, "k=%d outside [1, %d]", k, kMaxMedoids);
+    VH_REQUIRE(k >= 1 && k <= h->max_k, "k=%d outside [1, %d] (vh_clu_max_medoids)", k, h->max_k);
     h->mfma_pass = scan_uses_mfma(h, k);
     const int km = h->mfma_pass ? kMaxMedoids : pick_km(k);
     MedoidRows med;
@@ -1374,7 +1403,8 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
     size_t n_needed = missing.size();
     if (g->speculate) {
         size_t target = (size_t)pick_km((int)std::min<size_t>(missing.size(), kMaxMedoids));
-        if (g->clu->use_mfma && g->clu->L4 <= 64) target = kMaxMedoids;                   // matrix-pipe pass: 32 medoids cost what 1 costs
+        if (g->clu->max_k < kMaxMedoids) target = std::min(missing.size(), (size_t)g->clu->max_k);   // wide latents: no widening
+        else if (g->clu->use_mfma && g->clu->L4 <= 64) target = kMaxMedoids;                   // matrix-pipe pass: 32 medoids cost what 1 costs
         else if (missing.size() <= 8 && g->clu->n_rows <= 600000) target = kMaxMedoids;  // latency-bound pass: extra medoids are free
         else if (missing.size() == 1) target = 8;
         // look-ahead window: at most kSpecWindow unused speculative entries at any time (every emission re-validates them)
@@ -1387,8 +1417,9 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
             missing.insert(missing.end(), extra.begin(), extra.end());
         }
     }
-    for (size_t lo = 0; lo < missing.size(); lo += kMaxMedoids) {
-        const int k = (int)std::min<size_t>(kMaxMedoids, missing.size() - lo);
+    const size_t max_k = (size_t)g->clu->max_k;
+    for (size_t lo = 0; lo < missing.size(); lo += max_k) {
+        const int k = (int)std::min<size_t>(max_k, missing.size() - lo);
         const uint64_t seq = g->clu->scan_seq;
         int slot;
         {
@@ -1818,6 +1849,16 @@ int vh_debug_pyrandom_sample(uint64_t seed, int n_calls, const int64_t* ns, cons
             rng.sample(pop, (int)ks[i], got);
             for (int64_t v : got) *out++ = v;
         }
+    });
+}
+
+int vh_gen_state(vh_gen* g, double* peak_valley_ratio, int64_t* successes, int64_t* attempts, int64_t* order_index) {
+    return guarded([&] {
+        VH_REQUIRE(g != nullptr, "NULL argument");
+        if (peak_valley_ratio) *peak_valley_ratio = g->pvr;
+        if (successes) *successes = g->successes;
+        if (attempts) *attempts = (int64_t)g->attempts.size();
+        if (order_index) *order_index = g->order_index;
     });
 }
 

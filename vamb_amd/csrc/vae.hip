@@ -1681,6 +1681,68 @@ int vh_vae_opt_state(vh_vae* h, double* d, double* numerator_weighted, int64_t* 
     });
 }
 
+int vh_vae_opt_set_state(vh_vae* h, double d, double numerator_weighted, int64_t k) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "NULL argument");
+        VH_REQUIRE(d > 0 && k >= 0, "d must be positive and k non-negative");
+        StepState st;
+        read_state(h, &st);
+        st.d = d;
+        st.numerator_weighted = numerator_weighted;
+        st.k = k;
+        VH_HIP(hipMemcpyAsync(h->state.p, &st, offsetof(StepState, step), hipMemcpyHostToDevice, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+    });
+}
+
+int vh_vae_reset_optimizer(vh_vae* h) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "NULL argument");
+        VH_HIP(hipMemsetAsync(h->M1.p, 0, h->M1.bytes(), h->stream));
+        VH_HIP(hipMemsetAsync(h->M2.p, 0, h->M2.bytes(), h->stream));
+        VH_HIP(hipMemsetAsync(h->Sv.p, 0, h->Sv.bytes(), h->stream));
+        StepState st;
+        read_state(h, &st);
+        st.d = 1e-6;
+        st.numerator_weighted = 0.0;
+        st.k = 0;
+        VH_HIP(hipMemcpyAsync(h->state.p, &st, offsetof(StepState, step), hipMemcpyHostToDevice, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+    });
+}
+
+namespace {
+float* moment_ptr(vh_vae* h, int which) {
+    VH_REQUIRE(which >= 0 && which <= 2, "which: 0 exp_avg, 1 exp_avg_sq, 2 s");
+    return which == 0 ? h->M1.p : (which == 1 ? h->M2.p : h->Sv.p);
+}
+}  // namespace
+
+int vh_vae_get_opt_moment(vh_vae* h, const char* name, int which, float* data, int64_t n) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && data != nullptr, "NULL argument");
+        const int ti = find_tensor(h, name);
+        const Tensor& t = h->tensors[ti];
+        VH_REQUIRE(t.optimised, "'%s' is a buffer, not a parameter", name);
+        VH_REQUIRE(n == t.logical(), "parameter '%s' has %lld elements, got %lld", name, (long long)t.logical(), (long long)n);
+        download_padded(h, t, moment_ptr(h, which) + t.off, data);
+    });
+}
+
+int vh_vae_set_opt_moment(vh_vae* h, const char* name, int which, const float* data, int64_t n) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && data != nullptr, "NULL argument");
+        const int ti = find_tensor(h, name);
+        const Tensor& t = h->tensors[ti];
+        VH_REQUIRE(t.optimised, "'%s' is a buffer, not a parameter", name);
+        VH_REQUIRE(n == t.logical(), "parameter '%s' has %lld elements, got %lld", name, (long long)t.logical(), (long long)n);
+        std::vector<float> buf((size_t)t.slot, 0.0f);
+        for (int r = 0; r < t.rows; ++r) memcpy(buf.data() + (size_t)r * t.cols_p, data + (size_t)r * t.cols, sizeof(float) * t.cols);
+        VH_HIP(hipMemcpyAsync(moment_ptr(h, which) + t.off, buf.data(), sizeof(float) * t.slot, hipMemcpyHostToDevice, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+    });
+}
+
 int vh_vae_set_precision(vh_vae* h, int bf16_operands) {
     return guarded([&] {
         VH_REQUIRE(h != nullptr, "NULL handle");

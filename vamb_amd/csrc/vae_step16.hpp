@@ -426,10 +426,10 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         const bool fork = li == 2 * nl - 1 || li == 1 || (li == 0 && !q.items.empty());
         const dim3 grid((unsigned)ceil_div(hl.nout_p, kDz16Cols), (unsigned)ceil_div(bs_p, kDz16Rows));
         if (fork) {
-            launch_forking(h, vae_dz16_kernel, grid, dim3(256), 0, a);
+            launch_forking(h, vae_dz16_kernel, grid, dim3(64), 0, a);
             q.flush(h->side);
         } else {
-            hipLaunchKernelGGL(vae_dz16_kernel, grid, dim3(256), 0, h->stream, a);
+            hipLaunchKernelGGL(vae_dz16_kernel, grid, dim3(64), 0, h->stream, a);
             VH_HIP(hipGetLastError());
         }
         if (li == 0) {

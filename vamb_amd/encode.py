@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes
 import logging
+import weakref
 from collections import OrderedDict
 from math import log as _log
 from pathlib import Path
@@ -28,7 +29,10 @@ from torch.utils.data.dataset import TensorDataset as _TensorDataset
 
 from . import _lib
 
-logger = logging.getLogger("vamb_amd.encode")
+try:   # the reference logs through loguru (encode.py:11): after dropin.install() the epoch lines land in vamb's log
+    from loguru import logger
+except ImportError:   # pragma: no cover - loguru is a dependency of vamb, not of this package
+    logger = logging.getLogger("vamb_amd.encode")
 NTNF = 103
 
 # Arithmetic of the dense contractions of VAEs created from now on: "fp32" (fp32 MFMA, BASELINE config C1; the
@@ -222,6 +226,7 @@ class VAE:
         _lib.check(self._lib.vh_vae_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
         self._dataset_key = None
+        self._dataset_ref = None
         self._n_rows = 0
         self._comm = None
         self.compute_dtype = get_compute_dtype()
@@ -384,13 +389,16 @@ class VAE:
         tensors = data_loader.dataset.tensors
         if len(tensors) != 4:
             raise ValueError("expected a DataLoader made by make_dataloader (4 tensors)")
-        key = tuple((t.data_ptr(), tuple(t.shape)) for t in tensors)
+        holder = data_loader.dataset
+        # identity of the host data: the dataset OBJECT (a weak reference: a new dataset allocated at a freed address
+        # is a different object), the tensors' storage and their in-place modification counters
+        key = tuple((t.data_ptr(), tuple(t.shape), t._version) for t in tensors)
         n = len(tensors[0])
-        if key != self._dataset_key:
+        same_object = self._dataset_ref is not None and self._dataset_ref() is holder
+        if not same_object or key != self._dataset_key:
             d, t, a, w = (_as_f32(x) for x in tensors)
             if d.shape != (n, self.nsamples) or t.shape != (n, NTNF) or a.shape != (n, 1) or w.shape != (n, 1):
                 raise ValueError("dataset tensors do not match this VAE (nsamples / 103 TNF / 1 / 1 columns)")
-            holder = data_loader.dataset
             cached = getattr(holder, "_vambhip_device", None)
             if cached is None or cached.key != key:
                 cached = _DeviceDataset(self._lib, key, d, t, a, w, n, self.nsamples)
@@ -401,8 +409,14 @@ class VAE:
             _lib.check(self._lib.vh_vae_use_dataset(self._h, cached.handle))
             self._device_dataset = cached      # keeps the shared device copy alive while this VAE uses it
             self._dataset_key = key
+            self._dataset_ref = weakref.ref(holder)
             self._n_rows = n
         return n
+
+    def invalidate_dataset(self) -> None:
+        """Forget the device copy of the dataset: the next train / encode call uploads the host tensors again."""
+        self._dataset_key = None
+        self._dataset_ref = None
 
     def train_batch(self, rows, eps=None, masks=None):
         """One optimisation step on explicit dataset rows with optionally injected randomness
@@ -417,6 +431,8 @@ class VAE:
 
     # ---- training (encode.py:359-440, 543-610) ------------------------------------------------------
     def trainepoch(self, data_loader, epoch: int, optimizer, batchsteps: list[int]):
+        """One epoch (encode.py:359-440).  `optimizer` is accepted for signature compatibility and NOT used: the
+        D-Adapt-Adam state lives in the native handle (reset by trainmodel, readable through optimizer_state())."""
         n_seq = self._ensure_dataset(data_loader)
         if n_seq < 2:
             raise ValueError(
@@ -530,6 +546,8 @@ class VAE:
         logger.info(f"\t    Batchsteps: {steps}")
         logger.info(f"\t    N sequences: {ncontigs}")
         logger.info(f"\t    N samples: {nsamples}")
+        # a fresh optimiser per call, as the reference's `DAdaptAdam(self.parameters(), decouple=True)` (encode.py:578)
+        _lib.check(self._lib.vh_vae_reset_optimizer(self._h))
         # the epochs between two batch-size changes are enqueued by ONE library call (a single host
         # synchronisation per segment instead of one per epoch); the log lines are those of trainepoch
         epoch = 0

@@ -162,8 +162,9 @@ class ShardedScanBackend:
 
     def scan(self, medoids):
         out = []
-        for lo in range(0, len(medoids), _MAX_MEDOIDS_PER_PASS):
-            chunk = medoids[lo:lo + _MAX_MEDOIDS_PER_PASS]
+        step = getattr(self.local, "max_medoids", _MAX_MEDOIDS_PER_PASS)
+        for lo in range(0, len(medoids), step):
+            chunk = medoids[lo:lo + step]
             q, local_rows = self._queries(chunk)
             raw = self.local.scan_raw(local_rows, q)          # int64 [k, 63]
             raw = self.comm.all_reduce_sum(raw)
