@@ -262,6 +262,11 @@ int vh_comm_create(int rank, int world, const unsigned char* id128, vh_comm** ou
 int vh_comm_destroy(vh_comm* c);
 /* hipDeviceSynchronize of the library's HIP runtime (the timing fence used by bench.py) */
 int vh_device_synchronize(void);
+/* Synchronised BatchNorm under data parallelism (default ON): the BatchNorm batch sums (forward: sum h, sum h^2;
+ * backward: sum dy, sum dy*xhat) are all-reduced over the ranks, so the statistics span the ALL-RANK batch exactly as
+ * the single-process reference computes them (encode.py:238,246,264).  0 = per-rank statistics (torch DDP without
+ * SyncBatchNorm): 8 small all-reduces per step fewer, different mathematics. */
+int vh_vae_set_syncbn(vh_vae* h, int enable);
 /* From now on every optimisation step all-reduces (sum) the flat gradient over `comm` before the
  * D-Adapt-Adam update; comm == NULL detaches.  All ranks must hold identical parameters. */
 int vh_vae_attach_comm(vh_vae* h, vh_comm* comm);

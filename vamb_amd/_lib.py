@@ -107,6 +107,7 @@ SIGNATURES = {
     "vh_comm_destroy": (_int, [_vp]),
     "vh_device_synchronize": (_int, []),
     "vh_vae_attach_comm": (_int, [_vp, _vp]),
+    "vh_vae_set_syncbn": (_int, [_vp, _int]),
     "vh_vae_train_epoch_dp": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, ctypes.POINTER(ctypes.c_double)]),
     "vh_debug_gemm": (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _int, _int, _int, _int,
                              ctypes.POINTER(_f32)]),

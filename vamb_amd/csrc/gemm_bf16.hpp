@@ -50,9 +50,7 @@ enum Epi16 : int {
     E16_LATENT_MASK = 2,
     E16_HIDDEN_TRAIN = 3,
     E16_HIDDEN_EVAL = 4,
-    E16_STORE_BNRED = 5,
-    E16_LATENT_TRAIN = 6,  // mu + reparameterisation fused: C32 = MU = acc + bias; C16 = Z16 = bf16(MU + eps)
-    E16_LATENT_BWD = 7     // C16 = dMU16 = bf16(acc + aux) on the batch rows, 0 on the padding (aux = KLD part of dL/dmu)
+    E16_STORE_BNRED = 5
 };
 
 struct Gemm16Args {
@@ -86,10 +84,6 @@ struct Gemm16Args {
     int64_t ldh;
     BnSrc bnC;
     double* bstat_out;     // [2][N]
-    // E16_LATENT_TRAIN / E16_LATENT_BWD
-    const float* aux;      // injected noise [M][ldc16] (or nullptr: generated) / KLD part of dL/dmu [M][ldc16]
-    int n_real;            // logical latent width (columns beyond it stay 0)
-    int noise;             // E16_LATENT_TRAIN: 0 = no noise at all
     int xcd_remap;
     int dbg;               // timing experiments (vh_debug_gemm16): 1 no fp64 atomics, 2 no transposed copy, 4 no row-major copy
 };
@@ -256,44 +250,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
     // epilogue.  acc[i][j][reg] is C[row][col] with
     //   row = m0 + (wm*TM + i)*32 + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5),   col = n0 + (wn*TN + j)*32 + (lane & 31)
     // ---------------------------------------------------------------------------------------------------
-    if constexpr (EPI == E16_LATENT_TRAIN || EPI == E16_LATENT_BWD) {
-        // latent-wide outputs (N = L_p): the reparameterisation (encode.py:276-286) / the latent gradient sum fused into
-        // the GEMM that used to write split-K slabs for a separate elementwise kernel
-        uint64_t nkey = 0;
-        if constexpr (EPI == E16_LATENT_TRAIN) nkey = step_key(g.drop_key, g.step_ptr);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + frag_r;
-            const bool col_ok = col < g.N;
-            float bias = 0.f;
-            if constexpr (EPI == E16_LATENT_TRAIN) bias = col_ok ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = m0 + (wm * TM + i) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * frag_h;
-                    if (!col_ok || row >= g.M) continue;
-                    const int64_t idx = (int64_t)row * g.ldc16 + col;
-                    const bool real = row < g.m_real && col < g.n_real;
-                    if constexpr (EPI == E16_LATENT_TRAIN) {
-                        const float m = acc[i][j][reg] + bias;
-                        g.C32[(int64_t)row * g.ldc32 + col] = m;
-                        float z = 0.f;
-                        if (real) {
-                            float e = 0.f;
-                            if (g.aux) e = g.aux[idx];
-                            else if (g.noise) e = hash_randn(nkey, (uint64_t)idx);
-                            z = m + e;
-                        }
-                        g.C16[idx] = f2bf(z);
-                    } else {
-                        const float t = row < g.m_real ? acc[i][j][reg] + g.aux[idx] : 0.f;
-                        g.C16[idx] = f2bf(t);
-                    }
-                }
-        }
-        return;
-    } else if constexpr (EPI == E16_SPLITK || EPI == E16_BIAS || EPI == E16_LATENT_MASK) {
+    if constexpr (EPI == E16_SPLITK || EPI == E16_BIAS || EPI == E16_LATENT_MASK) {
         float* Cout = g.C32;
         if constexpr (EPI == E16_SPLITK) Cout += (int64_t)bz * g.slab_stride;
 #pragma unroll
@@ -515,7 +472,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
 template <int BM, int BN, int WM, int WN, int EPI>
 constexpr size_t gemm16_smem_bytes() {
     size_t ops = 2 * (size_t)(BM + BN) * 128;
-    if (EPI == E16_SPLITK || EPI == E16_BIAS || EPI == E16_LATENT_MASK || EPI == E16_LATENT_TRAIN || EPI == E16_LATENT_BWD) return ops;
+    if (EPI == E16_SPLITK || EPI == E16_BIAS || EPI == E16_LATENT_MASK) return ops;
     const size_t img = (size_t)BM * (BN + 8) * 2 + (EPI == E16_HIDDEN_TRAIN ? (size_t)BN * (BM + 8) * 2 : 0);
     const size_t nt = (size_t)WM * WN * 64, rpp = nt / (BN / 8);
     const size_t red = EPI == E16_STORE_BNRED ? 2 * rpp * BN * 4 : 2 * (size_t)WM * BN * 4;

@@ -50,6 +50,7 @@ struct Tensor {
     int nslab = 0;
     int64_t stride = 0;
     const double* dsrc = nullptr;   // gradient lives in an fp64 accumulator instead of slabs
+    bool dsrc_allrank = false;      // ... that SyncBN turns into an all-rank sum (BatchNorm gamma / beta)
     int64_t logical() const { return (int64_t)rows * cols; }
     int64_t padded() const { return (int64_t)rows_p * cols_p; }
 };
@@ -270,6 +271,9 @@ struct vh_vae {
 
     // data parallelism (one process per GPU; gradients all-reduced over RCCL on `stream`)
     vh_comm* comm = nullptr;
+    bool syncbn = true;              // BatchNorm batch statistics over the ALL-RANK batch (reference semantics, encode.py:238,246)
+    int opt16_bucketA_blk0 = 0;      // bf16 step: first optimiser workgroup / flat offset of the decoder-side tensors
+    size_t opt16_bucketA_off = 0;    // (gradient bucket that is all-reduced while the encoder's backward still runs)
     DevBuf<float> G, gwsum;          // flat gradient buffer; per-batch global weight sums
     const float* gwsum_src = nullptr; // per-batch all-rank weight sums of the running epoch (or nullptr)
     ShuffleSpec shuffle{0, 0, 1};    // device-side epoch shuffle (key 0: explicit row list / identity)
@@ -464,6 +468,7 @@ void prepare_batch(vh_vae* h, int bs) {
         h->tensors[hl.tb].dsrc = hl.dbias;
         h->tensors[hl.tG].dsrc = hl.bstat + hl.nout_p;   // sum dA * xhat
         h->tensors[hl.tB].dsrc = hl.bstat;               // sum dA
+        h->tensors[hl.tG].dsrc_allrank = h->tensors[hl.tB].dsrc_allrank = true;
         for (int ti : {hl.tb, hl.tG, hl.tB}) { h->tensors[ti].nslab = 0; h->tensors[ti].stride = 0; h->tensors[ti].slab = nullptr; }
     }
     {
@@ -494,6 +499,7 @@ void prepare_batch(vh_vae* h, int bs) {
         if (!t.dsrc) t.slab = h->slabs.p + reinterpret_cast<size_t>(t.slab);
         TensorDesc& d = tab.d[tab.n];
         d.dsrc = t.dsrc;
+        d.dscale = t.dsrc_allrank && h->comm && h->syncbn && h->comm->world > 1 ? 1.0f / (float)h->comm->world : 1.0f;
         d.slab = t.slab;
         d.nslab = t.nslab;
         d.stride = t.stride;
@@ -634,13 +640,23 @@ void join_side(vh_vae* h) {
 }
 
 // ---- forward ---------------------------------------------------------------------------------------
+// Synchronised BatchNorm under data parallelism: the fp64 batch sums every GEMM epilogue accumulates are all-reduced
+// over the ranks (forward: sum h, sum h^2; backward: sum dA, sum dA xhat -- 2 x n doubles each, on the main stream) and
+// every consumer divides by the all-rank batch, so the data-parallel step computes the statistics of the whole batch
+// like the single-process reference (encode.py:238,246,264).
+bool syncbn_active(const vh_vae* h) { return h->comm != nullptr && h->syncbn && h->global_bs > 0; }
+int stat_bs(const vh_vae* h) { return syncbn_active(h) ? h->global_bs : h->bs; }
+void sync_stats(vh_vae* h, double* stats, int n_p) {
+    if (syncbn_active(h) && h->comm->world > 1) rccl_allreduce_sum_f64(h->comm, stats, (size_t)2 * n_p, h->stream);
+}
+
 BnSrc bn_src(vh_vae* h, const Hidden& hl) {
     BnSrc b;
     b.fstat = hl.fstat;
     b.gamma = h->pptr(hl.tG);
     b.beta = h->pptr(hl.tB);
     b.n_p = hl.nout_p;
-    b.bs = h->bs;
+    b.bs = stat_bs(h);
     return b;
 }
 
@@ -685,6 +701,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
             } else {
                 gemm_tile<true, true, EPI_HIDDEN_TRAIN>(s, tile, g, 1);
             }
+            sync_stats(h, hl.fstat, hl.nout_p);
             in = hl.H.p;
             prev = &hl;
         } else {
@@ -763,7 +780,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
             rt.n++;
         }
         hipLaunchKernelGGL(vae_bn_running_kernel, dim3((unsigned)ceil_div(maxn, 256), rt.n), dim3(256), 0, h->side, rt,
-                           bs);
+                           stat_bs(h));
         VH_HIP(hipGetLastError());
     }
 }
@@ -843,6 +860,7 @@ int grad_input(vh_vae* h, const float* dZ, int out_p, int tW, int in_p, float* d
     g.bnC = bn_src(h, *below);
     g.bstat_out = below->bstat;
     gemm_tile<true, false, EPI_STORE_BNRED>(h->stream, tile, g, 1);
+    sync_stats(h, below->bstat, below->nout_p);
     return 1;
 }
 
@@ -1240,7 +1258,7 @@ int vh_vae_get_grad(vh_vae* h, const char* name, float* data, int64_t n) {
         if (h->bf16) {
             // the complete gradient (slab sums + BatchNorm completion) as the optimiser forms it, through the flat buffer
             hipLaunchKernelGGL(vae_grad16_kernel, dim3(h->opt16_blocks), dim3(256), 0, h->stream, h->opt16_tab.p, h->opt16_n,
-                               h->bs, h->G.p);
+                               stat_bs(h), h->G.p, 0);
             VH_HIP(hipGetLastError());
             std::vector<float> buf((size_t)t.padded());
             VH_HIP(hipMemcpyAsync(buf.data(), h->G.p + t.off, sizeof(float) * buf.size(), hipMemcpyDeviceToHost, h->stream));
@@ -1551,10 +1569,25 @@ int vh_vae_train_epoch(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_
     return vh_vae_train_epoch_dp(h, perm, n_batches, batch, 0, nullptr, loss_means);
 }
 
+int vh_vae_set_syncbn(vh_vae* h, int enable) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "NULL argument");
+        if (h->syncbn != (enable != 0)) {
+            VH_HIP(hipStreamSynchronize(h->stream));
+            h->syncbn = enable != 0;
+            h->bs = 0;
+        }
+    });
+}
+
 int vh_vae_attach_comm(vh_vae* h, vh_comm* comm) {
     return guarded([&] {
         VH_REQUIRE(h != nullptr, "NULL argument");
-        h->comm = comm;
+        if (h->comm != comm) {
+            VH_HIP(hipStreamSynchronize(h->stream));
+            h->comm = comm;
+            h->bs = 0;   // the optimiser tables depend on the communicator (SyncBN scaling of the gamma / beta gradients)
+        }
     });
 }
 

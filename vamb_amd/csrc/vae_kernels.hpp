@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void vae_dz_kernel(const DzArgs a) {
         if (col < a.n_p) {
             float mean, istd, sc, sh;
             bn_column(a.bn, col, mean, istd, sc, sh);
-            const double inv_bs = 1.0 / (double)a.bs;
+            const double inv_bs = 1.0 / (double)a.bn.bs;   // the statistics' batch (all ranks under SyncBN)
             const float c1 = (float)(a.bstat[col] * inv_bs);
             const float c2 = (float)(a.bstat[a.n_p + col] * inv_bs);
             ca = a.drop_scale * istd * a.bn.gamma[col];
@@ -537,6 +537,7 @@ __global__ __launch_bounds__(256) void vae_latent_bwd_kernel(const float* __rest
 // ---- D-Adapt-Adam (dadaptation==3.2 DAdaptAdam.step as Vamb configures it, encode.py:578) ----------
 struct TensorDesc {
     const double* dsrc;   // if non-null the gradient is this fp64 accumulator (bias / gamma / beta of hidden layers)
+    float dscale;         // factor on dsrc: 1, or 1 / world for accumulators that are already all-rank sums (SyncBN)
     const float* slab;    // gradient slabs; g[i] = sum_s slab[s*stride + i]
     int nslab;
     int64_t stride;
@@ -562,8 +563,8 @@ __device__ __forceinline__ int opt_find_tensor(const OptTable& tab, int blk) {
 __device__ __forceinline__ float4 fetch_grad(const TensorDesc& td, int64_t local) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (td.dsrc) {
-        g.x = (float)td.dsrc[local + 0]; g.y = (float)td.dsrc[local + 1];
-        g.z = (float)td.dsrc[local + 2]; g.w = (float)td.dsrc[local + 3];
+        g.x = (float)td.dsrc[local + 0] * td.dscale; g.y = (float)td.dsrc[local + 1] * td.dscale;
+        g.z = (float)td.dsrc[local + 2] * td.dscale; g.w = (float)td.dsrc[local + 3] * td.dscale;
         return g;
     }
     // eight slab loads in flight per round (same ascending summation order as before)

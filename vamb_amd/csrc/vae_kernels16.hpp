@@ -187,6 +187,36 @@ __global__ void vae_shadow_kernel(const float* __restrict__ P, int rows_p, int c
     if (W16T) W16T[(int64_t)c * rows_p + r] = b;
 }
 
+// ---- reparameterisation: MU (fp32) = slabs + bias; Z16 = bf16(MU + eps) on real rows / columns ---------------------
+__global__ void vae_reparam16_kernel(const float* __restrict__ slabs, int nslab, int64_t stride,
+                                     const float* __restrict__ bias, const float* __restrict__ E, uint64_t key,
+                                     const unsigned long long* __restrict__ step_ptr, int noise,
+                                     float* __restrict__ MU, bf16_t* __restrict__ Z16, int bs, int L, int L_p, int bs_p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)bs_p * L_p) return;
+    const int r = (int)(i / L_p), c = (int)(i % L_p);
+    float m = bias[c];
+    {
+        constexpr int kMaxSlabs = 8;
+        float v[kMaxSlabs];
+#pragma unroll
+        for (int s = 0; s < kMaxSlabs; ++s) v[s] = s < nslab ? slabs[(int64_t)s * stride + i] : 0.f;
+#pragma unroll
+        for (int s = 0; s < kMaxSlabs; ++s)
+            if (s < nslab) m += v[s];
+        for (int s = kMaxSlabs; s < nslab; ++s) m += slabs[(int64_t)s * stride + i];
+    }
+    MU[i] = m;
+    float z = 0.f;
+    if (r < bs && c < L) {
+        float e = 0.f;
+        if (E) e = E[i];
+        else if (noise) e = hash_randn(step_key(key, step_ptr), (uint64_t)i);
+        z = m + e;
+    }
+    Z16[i] = f2bf(z);
+}
+
 // ---- loss + backward seed, bf16 gradient of the reconstruction ------------------------------------------------------
 // Same arithmetic as vae_loss_kernel (encode.py:316-357); dR leaves as bf16 (the operand of the two GEMMs that
 // consume it), the KLD part of dL/dmu stays fp32.
@@ -318,43 +348,41 @@ struct Dz16Args {
     int64_t ld_mask;
     double* dbias;
 };
-constexpr int kDz16Cols = 64;
+// (Two register-transposing variants without LDS -- a thread owning an 8 x 8 block, 128 x 128 tiles with 4 waves or
+// 64 x 64 tiles with one wave -- measured 18 and 37 us against 13.7 us for this kernel at 8192 x 512: profiles/README.md.)
+constexpr int kDz16Cols = 128;
 constexpr int kDz16Rows = 64;
 
-// A workgroup is ONE wavefront owning 64 rows x 64 columns (1024 workgroups at 8192 x 512: four per CU, so the load,
-// compute and store phases of different tiles overlap; one 128 x 128 tile per CU ran them back to back, 18 vs 13.7 us).
-// A thread owns an 8 x 8 block: it reads 8 row segments of 16 bytes of dA and H (lanes 0-7 of a group cover one full
-// 128-byte line), writes dZ the same way and -- after an 8 x 8 transpose of the packed bf16 pairs in registers --
-// 8 column segments of 16 bytes of dZ^T (the 8 row groups of the wave cover one full line of a column).  No LDS in
-// the data path.
-__global__ __launch_bounds__(64) void vae_dz16_kernel(const Dz16Args a) {
+__global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[kDz16Rows][kDz16Cols + 8];
+    __shared__ float red[16][kDz16Cols];
     __shared__ float cf[3][kDz16Cols];
-    const int tid = threadIdx.x, lane = tid;
-    const int cc = lane & 7, gq = lane >> 3;
-    const int col0 = blockIdx.x * kDz16Cols;
-    const int col_l = cc * 8;
-    const int col = col0 + col_l;
-    const int row_base = blockIdx.y * kDz16Rows + gq * 8;
-    const bool col_ok = col < a.n_p;
-    uint4 da[8], hh[8];
+    const int tid = threadIdx.x;
+    const int col0 = blockIdx.x * kDz16Cols, row0 = blockIdx.y * kDz16Rows;
+    const int c8 = (tid & 15) * 8;          // this thread's 8 columns inside the tile
+    const int rt = tid >> 4;                // row lane 0..15
+    const int col = col0 + c8;
+    // the thread's 16-byte loads go out first; the per-column coefficients (fp64 statistics) are formed underneath them
+    constexpr int PASS = kDz16Rows / 16;
+    uint4 da[PASS], hh[PASS];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int r = row_base + k;
-        da[k] = make_uint4(0, 0, 0, 0);
-        hh[k] = da[k];
-        if (r < a.bs && col_ok) {
+    for (int p = 0; p < PASS; ++p) {
+        const int r = row0 + rt + 16 * p;
+        da[p] = make_uint4(0, 0, 0, 0);
+        hh[p] = da[p];
+        if (r < a.bs && col < a.n_p) {
             const int64_t i = (int64_t)r * a.n_p + col;
-            da[k] = *reinterpret_cast<const uint4*>(a.DA + i);
-            hh[k] = *reinterpret_cast<const uint4*>(a.H + i);
+            da[p] = *reinterpret_cast<const uint4*>(a.DA + i);
+            hh[p] = *reinterpret_cast<const uint4*>(a.H + i);
         }
     }
-    if (tid < kDz16Cols) {   // per-column coefficients from the fp64 batch sums, under the loads
+    if (tid < kDz16Cols) {
         const int colc = col0 + tid;
         float ca = 0.f, ch = 0.f, c0 = 0.f;
         if (colc < a.n_p) {
             float mean, istd, sc, sh;
             bn_column(a.bn, colc, mean, istd, sc, sh);
-            const double inv_bs = 1.0 / (double)a.bs;
+            const double inv_bs = 1.0 / (double)a.bn.bs;   // the statistics' batch (all ranks under SyncBN)
             const float c1 = (float)(a.bstat[colc] * inv_bs);
             const float c2 = (float)(a.bstat[a.n_p + colc] * inv_bs);
             ca = a.drop_scale * istd * a.bn.gamma[colc];
@@ -367,16 +395,14 @@ __global__ __launch_bounds__(64) void vae_dz16_kernel(const Dz16Args a) {
     const bool hashed_drop = (a.drop_scale != 1.0f) && (a.drop_mask == nullptr);
     float ca[8], ch[8], c0[8], s[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { ca[e] = cf[0][col_l + e]; ch[e] = cf[1][col_l + e]; c0[e] = cf[2][col_l + e]; s[e] = 0.f; }
-    uint32_t ow[8][4];
+    for (int e = 0; e < 8; ++e) { ca[e] = cf[0][c8 + e]; ch[e] = cf[1][c8 + e]; c0[e] = cf[2][c8 + e]; s[e] = 0.f; }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int r = row_base + k;
-        const uint32_t dw[4] = {da[k].x, da[k].y, da[k].z, da[k].w};
-        const uint32_t hw[4] = {hh[k].x, hh[k].y, hh[k].z, hh[k].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ow[k][j] = 0u;
-        if (r < a.bs && col_ok) {
+    for (int p = 0; p < PASS; ++p) {
+        const int rl = rt + 16 * p, r = row0 + rl;
+        const uint32_t dw[4] = {da[p].x, da[p].y, da[p].z, da[p].w};
+        const uint32_t hw[4] = {hh[p].x, hh[p].y, hh[p].z, hh[p].w};
+        uint32_t ow[4] = {0, 0, 0, 0};
+        if (r < a.bs && col < a.n_p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float d = (e & 1) ? bf_hi(dw[e >> 1]) : bf_lo(dw[e >> 1]);
@@ -388,36 +414,62 @@ __global__ __launch_bounds__(64) void vae_dz16_kernel(const Dz16Args a) {
                 const float dz = keep ? l * (h > 0.f ? 1.0f : kLeakySlope) : 0.f;
                 const bf16_t b = f2bf(dz);
                 s[e] += bf2f(b);
-                ow[k][e >> 1] |= (uint32_t)b << (16 * (e & 1));
+                ow[e >> 1] |= (uint32_t)b << (16 * (e & 1));
             }
         }
-        if (r < a.bs_p && col_ok)
-            *reinterpret_cast<uint4*>(a.DZ + (int64_t)r * a.n_p + col) = make_uint4(ow[k][0], ow[k][1], ow[k][2], ow[k][3]);
+        const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        *reinterpret_cast<uint4*>(&tile[rl][c8]) = o;
+        if (r < a.bs_p && col < a.n_p) *reinterpret_cast<uint4*>(a.DZ + (int64_t)r * a.n_p + col) = o;
     }
-    // 8 x 8 transpose of bf16 pairs: column 2m / 2m + 1 of rows 2j, 2j + 1 sit in ow[2j][m], ow[2j + 1][m]
-    if (col_ok && row_base < a.bs_p) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            uint32_t te[4], to[4];
+    for (int e = 0; e < 8; ++e) red[rt][c8 + e] = s[e];
+    __syncthreads();
+    // transposed copy: chunk = (column c, 8 consecutive rows); lanes of a wave take consecutive columns
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t lo = ow[2 * j][m], hi = ow[2 * j + 1][m];
-                te[j] = (lo & 0xFFFFu) | (hi << 16);
-                to[j] = (lo >> 16) | (hi & 0xFFFF0000u);
-            }
-            *reinterpret_cast<uint4*>(a.DZT + (int64_t)(col + 2 * m) * a.ldt + row_base) = make_uint4(te[0], te[1], te[2], te[3]);
-            *reinterpret_cast<uint4*>(a.DZT + (int64_t)(col + 2 * m + 1) * a.ldt + row_base) = make_uint4(to[0], to[1], to[2], to[3]);
+    for (int p = 0; p < (kDz16Cols * (kDz16Rows / 8)) / 256; ++p) {
+        const int id = tid + 256 * p;
+        const int c = id % kDz16Cols, rg = id / kDz16Cols;
+        bf16_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = tile[rg * 8 + k][c];
+        if (col0 + c < a.n_p && row0 + rg * 8 < a.bs_p) {
+            uint4 v;
+            v.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+            v.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+            v.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
+            v.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
+            *reinterpret_cast<uint4*>(a.DZT + (int64_t)(col0 + c) * a.ldt + row0 + rg * 8) = v;
         }
     }
-    // bias gradient: the 8 row groups of the wave (lanes cc + 8 g) through shuffles, one fp64 atomic per column and tile
+    if (tid < kDz16Cols) {
+        const int c = col0 + tid;
+        float t = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float v = s[e];
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (gq == 0 && col + e < a.n_p) atomicAdd(&a.dbias[col + e], (double)v);
+        for (int i = 0; i < 16; ++i) t += red[i][tid];
+        if (c < a.n_p) atomicAdd(&a.dbias[c], (double)t);
     }
+}
+
+// latent: dMU16 = bf16((sum of the split-K slabs of dZlat) + KLD part) on the real rows, 0 on the padding
+__global__ void vae_latent_bwd16_kernel(const float* __restrict__ slabs, int nslab, int64_t stride,
+                                        const float* __restrict__ dMUk, bf16_t* __restrict__ dMU16, int L_p, int bs,
+                                        int bs_p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)bs_p * L_p) return;
+    const int r = (int)(i / L_p);
+    float t = 0.f;
+    if (r < bs) {
+        constexpr int kMaxSlabs = 8;
+        float v[kMaxSlabs];
+#pragma unroll
+        for (int s = 0; s < kMaxSlabs; ++s) v[s] = s < nslab ? slabs[(int64_t)s * stride + i] : 0.f;
+        t = dMUk[i];
+#pragma unroll
+        for (int s = 0; s < kMaxSlabs; ++s)
+            if (s < nslab) t += v[s];
+        for (int s = kMaxSlabs; s < nslab; ++s) t += slabs[(int64_t)s * stride + i];
+    }
+    dMU16[i] = f2bf(t);
 }
 
 // ---- D-Adapt-Adam for the bf16 step ------------------------------------------------------------------------------------
@@ -427,6 +479,7 @@ __global__ __launch_bounds__(64) void vae_dz16_kernel(const Dz16Args a) {
 // gradient of a weight that consumes BatchNorm-ed activations is completed here:  dW = G diag(s) + dbias t^T.
 struct Opt16Tensor {
     const double* dsrc;   // fp64 accumulator gradient (vectors), or nullptr
+    float dscale;         // factor on dsrc: 1, or 1 / world for accumulators that are already all-rank sums (SyncBN)
     const float* slab;    // split-K slabs (matrices)
     int nslab;
     int rows_p, cols_p;   // padded shape (vectors: rows_p == 1)
@@ -449,8 +502,8 @@ constexpr int kMaxOpt16 = 4 * 2 * 8 + 4;
 __device__ __forceinline__ float4 opt16_grad(const Opt16Tensor& td, int64_t local, int row, int col, int bs) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (td.dsrc) {
-        g.x = (float)td.dsrc[local + 0]; g.y = (float)td.dsrc[local + 1];
-        g.z = (float)td.dsrc[local + 2]; g.w = (float)td.dsrc[local + 3];
+        g.x = (float)td.dsrc[local + 0] * td.dscale; g.y = (float)td.dsrc[local + 1] * td.dscale;
+        g.z = (float)td.dsrc[local + 2] * td.dscale; g.w = (float)td.dsrc[local + 3] * td.dscale;
         return g;
     }
     int s = 0;
@@ -497,13 +550,14 @@ __device__ __forceinline__ bool opt16_locate(const Opt16Tensor& td, int lb, int&
 
 // data-parallel path: G[flat] = this rank's complete gradient (then all-reduced over the ranks)
 __global__ __launch_bounds__(256) void vae_grad16_kernel(const Opt16Tensor* __restrict__ tab, int ntensors, int bs,
-                                                         float* __restrict__ G) {
+                                                         float* __restrict__ G, int blk0) {
+    const int blk = (int)blockIdx.x + blk0;   // the launch covers the table's workgroups [blk0, blk0 + gridDim.x)
     int t = 0;
-    while (t + 1 < ntensors && (int)blockIdx.x >= tab[t + 1].blk_start) ++t;
+    while (t + 1 < ntensors && blk >= tab[t + 1].blk_start) ++t;
     const Opt16Tensor td = tab[t];
     int row, col;
     int64_t local;
-    if (!opt16_locate(td, (int)blockIdx.x - td.blk_start, row, col, local)) return;
+    if (!opt16_locate(td, blk - td.blk_start, row, col, local)) return;
     *reinterpret_cast<float4*>(G + td.p_off + local) = opt16_grad(td, local, row, col, bs);
 }
 

@@ -48,10 +48,6 @@ void gemm16(hipStream_t s, const Gemm16Args& g, int splits) {
         if (g.N <= 32) launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
         else if (g.M <= 32) launch_gemm16<32, 128, 1, 4, EPI>(s, g, splits);
         else launch_gemm16<64, 128, 2, 2, EPI>(s, g, splits);
-    } else if constexpr (EPI == E16_LATENT_TRAIN || EPI == E16_LATENT_BWD) {
-        // latent-wide output with the whole contraction in one workgroup (the epilogue needs the complete sums):
-        // one wavefront per 32 x 32 tile = 256 workgroups at batch 8192 (128 x 32 tiles: 64 workgroups, 18 us)
-        launch_gemm16<32, 32, 1, 1, EPI>(s, g, splits);
     } else if constexpr (EPI == E16_LATENT_MASK) {
         launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
     } else {
@@ -164,6 +160,7 @@ void build_opt16_table(vh_vae* h) {
         d.rows_p = t.rows_p; d.cols_p = t.cols_p;
         d.p_off = (int64_t)t.off;
         d.blk_start = nblk;
+        d.dscale = t.dsrc_allrank && h->comm && h->syncbn && h->comm->world > 1 ? 1.0f / (float)h->comm->world : 1.0f;
         if (!t.matrix) {
             d.dsrc = t.dsrc;
             nblk += (int)ceil_div(t.cols_p, 1024);
@@ -189,6 +186,10 @@ void build_opt16_table(vh_vae* h) {
         }
         Hidden& hl = h->hidden[li];
         const bool from_input = (li == 0) || (li == nl);
+        if (li == nl) {   // decoder-side tensors (the tail of the flat buffer): gradient bucket A
+            h->opt16_bucketA_blk0 = nblk;
+            h->opt16_bucketA_off = h->tensors[hl.tW].off;
+        }
         add(hl.tW, from_input ? nullptr : &h->hidden[li - 1], hl.dbias);
         add(hl.tb, nullptr, nullptr);
         add(hl.tG, nullptr, nullptr);
@@ -263,6 +264,7 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
             g.drop_mask = dc.injected ? hl.mask.p : nullptr; g.ld_mask = hl.nout_p;
             if (h->probe_on && li == h->probe_layer) { probe_arm(h); h->probe_flops = 2.0 * bs * (double)hl.nin * hl.nout; }
             gemm16<E16_HIDDEN_TRAIN>(s, g, 1);
+            sync_stats(h, hl.fstat, hl.nout_p);
             prev = &hl;
         } else {
             g.B = w16(h, hl.tW); g.ldb = hl.nin_p;
@@ -274,25 +276,34 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
         in_w = hl.nout_p;
     };
     for (int li = 0; li < nl; ++li) hidden_layer(li);
-    {   // mu (encode.py:268) + reparameterisation (276-286) in one launch: MU fp32, Z16 = bf16(MU + eps)
+    int mu_slabs = 1;
+    const float* mu_bias = h->pptr(h->tbmu);
+    {   // mu (encode.py:268): latent-wide output, contraction split over up to 8 slabs (summed by the reparam kernel).
+        // (One-pass variants with the reparameterisation fused into the epilogue -- 128x32 or 32x32 tiles, 64 / 256
+        // workgroups walking all of K -- measured 13.6-18 us against 5.1 + 4.9 us for slabs + reparam kernel.)
         Gemm16Args g = args16(h);
         g.A = in; g.lda = in_w;
         g.B = w16(h, h->tWmu); g.ldb = in_w;
-        g.bias = h->pptr(h->tbmu);
         if (training && prev) {
             fold_bn(h, s, h->tWmu, h->tbmu, h->L_p, in_w, *prev, true, h->Wf16_mu.p, h->biasf_mu.p);
             g.B = h->Wf16_mu.p;
-            g.bias = h->biasf_mu.p;
+            mu_bias = h->biasf_mu.p;
         }
-        g.C32 = h->MU.p; g.ldc32 = h->L_p;
-        g.C16 = h->Z16.p; g.ldc16 = h->L_p;
-        g.M = bs_p; g.N = h->L_p; g.K = in_w; g.k_per_split = g.K;
-        g.m_real = bs; g.n_real = h->L;
-        g.aux = eps_injected ? h->EPS.p : nullptr;
-        g.noise = add_noise ? 1 : 0;
-        g.drop_key = layer_key(h, 0xEE);
-        g.step_ptr = step_ptr(h);
-        gemm16<E16_LATENT_TRAIN>(s, g, 1);
+        g.C32 = h->skinny.p; g.ldc32 = h->L_p;
+        g.M = bs_p; g.N = h->L_p; g.K = in_w;
+        const int want = std::max(1, std::min(kSkinnySplits, in_w / 128));
+        g.k_per_split = (int)round_up(ceil_div(in_w, want), 64);
+        mu_slabs = (int)ceil_div(in_w, g.k_per_split);
+        g.slab_stride = (int64_t)bs_p * h->L_p;
+        gemm16<E16_SPLITK>(s, g, mu_slabs);
+    }
+    {
+        const int64_t tot = (int64_t)bs_p * h->L_p;
+        const float* eps_ptr = eps_injected ? h->EPS.p : nullptr;
+        hipLaunchKernelGGL(vae_reparam16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s,
+                           (const float*)h->skinny.p, mu_slabs, (int64_t)bs_p * h->L_p, mu_bias, eps_ptr,
+                           layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z16.p, bs, h->L, h->L_p, bs_p);
+        VH_HIP(hipGetLastError());
         // the transposed latent code feeds the first decoder layer's weight gradient
         if (defer) defer->add([h, bs_p](hipStream_t st) { transpose16(h, st, h->Z16.p, bs_p, h->L_p, h->Z16T.p, nullptr, 0); });
     }
@@ -316,7 +327,7 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
     }
     if (training) {
         // running statistics (momentum 0.1, unbiased variance): off the critical path
-        auto running = [h, bs](hipStream_t st) {
+        auto running = [h](hipStream_t st) {
             RunningTable rt;
             memset(&rt, 0, sizeof(rt));
             int maxn = 0;
@@ -326,7 +337,7 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
                 maxn = std::max(maxn, hl.nout_p);
                 rt.n++;
             }
-            hipLaunchKernelGGL(vae_bn_running_kernel, dim3((unsigned)ceil_div(maxn, 256), rt.n), dim3(256), 0, st, rt, bs);
+            hipLaunchKernelGGL(vae_bn_running_kernel, dim3((unsigned)ceil_div(maxn, 256), rt.n), dim3(256), 0, st, rt, stat_bs(h));
             VH_HIP(hipGetLastError());
         };
         if (defer) {
@@ -394,6 +405,7 @@ void grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidd
     g.bnC = bn_src(h, below);
     g.bstat_out = below.bstat;
     gemm16<E16_STORE_BNRED>(h->stream, g, 1);
+    sync_stats(h, below.bstat, below.nout_p);
 }
 
 void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
@@ -407,6 +419,7 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         });
         grad_input16(h, h->dR16.p, h->D_p, h->tWo, last.nout_p, last);
     }
+    int latent_slabs = 1;
     auto hidden_bwd = [&](int li) {
         Hidden& hl = h->hidden[li];
         Dz16Args a;
@@ -423,34 +436,52 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         // hands everything queued so far to the side stream.  The first layer's weight gradient is the end of the
         // chain -- nothing is left on the main stream for it to hide behind -- so it runs there.
         if (li > 0) q.add([h, &hl, InT, in_p](hipStream_t st) { grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, st); });
+        if (li == nl && h->comm) {
+            // data parallel: every decoder-side gradient is now queued -- materialise that bucket of the flat gradient and
+            // all-reduce it on the side stream while the encoder's backward still runs on the main stream
+            q.add([h](hipStream_t st) {
+                const int nb = h->opt16_blocks - h->opt16_bucketA_blk0;
+                hipLaunchKernelGGL(vae_grad16_kernel, dim3(nb), dim3(256), 0, st, h->opt16_tab.p, h->opt16_n, stat_bs(h), h->G.p,
+                                   h->opt16_bucketA_blk0);
+                VH_HIP(hipGetLastError());
+                rccl_allreduce_sum_f32(h->comm, h->G.p + h->opt16_bucketA_off, h->flat_elems - h->opt16_bucketA_off, st);
+            });
+        }
         const bool fork = li == 2 * nl - 1 || li == 1 || (li == 0 && !q.items.empty());
         const dim3 grid((unsigned)ceil_div(hl.nout_p, kDz16Cols), (unsigned)ceil_div(bs_p, kDz16Rows));
         if (fork) {
-            launch_forking(h, vae_dz16_kernel, grid, dim3(64), 0, a);
+            launch_forking(h, vae_dz16_kernel, grid, dim3(256), 0, a);
             q.flush(h->side);
         } else {
-            hipLaunchKernelGGL(vae_dz16_kernel, grid, dim3(64), 0, h->stream, a);
+            hipLaunchKernelGGL(vae_dz16_kernel, grid, dim3(256), 0, h->stream, a);
             VH_HIP(hipGetLastError());
         }
         if (li == 0) {
             grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, h->stream);
         } else if (li == nl) {
-            // first decoder layer -> latent, fused with dMU = dZlat + d(KLD)/dmu (zero on the padding rows)
+            // first decoder layer -> latent: latent-wide output, split-K slabs summed by the latent kernel
             Gemm16Args g = args16(h);
             g.A = hl.DZ16.p; g.lda = hl.nout_p;
             g.B = w16t(h, hl.tW); g.ldb = hl.nout_p;
-            g.M = bs_p; g.N = in_p; g.K = hl.nout_p; g.k_per_split = g.K;
-            g.C16 = h->dMU16.p; g.ldc16 = in_p;
-            g.aux = h->dMUk.p;
-            g.m_real = bs; g.n_real = in_p;
-            gemm16<E16_LATENT_BWD>(h->stream, g, 1);
+            g.M = bs_p; g.N = in_p; g.K = hl.nout_p;
+            const int want = std::max(1, std::min(kSkinnySplits, hl.nout_p / 128));
+            g.k_per_split = (int)round_up(ceil_div(hl.nout_p, want), 64);
+            latent_slabs = (int)ceil_div(hl.nout_p, g.k_per_split);
+            g.C32 = h->skinny.p; g.ldc32 = in_p;
+            g.slab_stride = (int64_t)bs_p * in_p;
+            gemm16<E16_SPLITK>(h->stream, g, latent_slabs);
         } else {
             grad_input16(h, hl.DZ16.p, hl.nout_p, hl.tW, in_p, h->hidden[li - 1]);
         }
     };
     for (int li = 2 * nl - 1; li >= nl; --li) hidden_bwd(li);
-    {   // mu layer (dMU16 was written by the fused epilogue above)
+    {   // latent: dMU = dZlat + d(KLD)/dmu; mu layer
         Hidden& enc_last = h->hidden[nl - 1];
+        const int64_t tot = (int64_t)bs_p * h->L_p;
+        hipLaunchKernelGGL(vae_latent_bwd16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, h->stream,
+                           (const float*)h->skinny.p, latent_slabs, (int64_t)bs_p * h->L_p, (const float*)h->dMUk.p,
+                           h->dMU16.p, h->L_p, bs, bs_p);
+        VH_HIP(hipGetLastError());
         q.add([h, bs_p, bs, &enc_last](hipStream_t st) {
             transpose16(h, st, h->dMU16.p, bs_p, h->L_p, h->dMU16T.p, h->dbias_mu, bs);
             grad_weight16(h, h->tWmu, h->dMU16T.p, h->L_p, enc_last.H16T.p, enc_last.nout_p, st);
@@ -464,13 +495,14 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
 void optimizer_step16(vh_vae* h) {
     const Opt16Tensor* tab = h->opt16_tab.p;
     if (h->comm) {
-        hipLaunchKernelGGL(vae_grad16_kernel, dim3(h->opt16_blocks), dim3(256), 0, h->stream, h->opt16_tab.p, h->opt16_n,
-                           h->bs, h->G.p);
+        // bucket B (encoder + mu; bucket A went out on the side stream during the encoder's backward, joined by now)
+        hipLaunchKernelGGL(vae_grad16_kernel, dim3(h->opt16_bucketA_blk0), dim3(256), 0, h->stream, h->opt16_tab.p, h->opt16_n,
+                           stat_bs(h), h->G.p, 0);
         VH_HIP(hipGetLastError());
-        rccl_allreduce_sum_f32(h->comm, h->G.p, h->flat_elems, h->stream);
+        rccl_allreduce_sum_f32(h->comm, h->G.p, h->opt16_bucketA_off, h->stream);
         tab = h->opt16_tab_flat.p;
     }
-    hipLaunchKernelGGL(vae_dadapt16_kernel, dim3(h->opt16_blocks), dim3(256), 0, h->stream, tab, h->opt16_n, h->bs, h->P.p,
+    hipLaunchKernelGGL(vae_dadapt16_kernel, dim3(h->opt16_blocks), dim3(256), 0, h->stream, tab, h->opt16_n, stat_bs(h), h->P.p,
                        h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p);
     VH_HIP(hipGetLastError());
     hipLaunchKernelGGL(vae_dadapt_finalize_kernel, dim3(1), dim3(256), 0, h->stream, h->opt_part.p, h->opt16_blocks,

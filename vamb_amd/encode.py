@@ -234,11 +234,14 @@ class VAE:
             raise ValueError(f"compute dtype must be 'fp32' or 'bf16', not {self.compute_dtype!r}")
         _lib.check(self._lib.vh_vae_set_precision(self._h, int(self.compute_dtype == "bf16")))
 
-    def attach_communicator(self, comm) -> None:
+    def attach_communicator(self, comm, syncbn: bool = True) -> None:
         """Data-parallel training over ``comm`` (``vamb_amd.parallel.Communicator``): this process holds
-        one row shard of the dataset; every step all-reduces the gradient over RCCL inside the library."""
+        one row shard of the dataset; every step all-reduces the gradient over RCCL inside the library.
+        ``syncbn`` (default): BatchNorm batch statistics span the all-rank batch, i.e. the step computes what the
+        single-process reference computes on the whole batch; False = per-rank statistics (fewer collectives)."""
         self._comm = comm
         _lib.check(self._lib.vh_vae_attach_comm(self._h, comm.handle if comm is not None else None))
+        _lib.check(self._lib.vh_vae_set_syncbn(self._h, int(bool(syncbn))))
 
     def __del__(self):
         try:
