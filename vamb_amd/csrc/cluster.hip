@@ -166,7 +166,47 @@ __device__ __forceinline__ void load_live(const uint8_t* __restrict__ p, unsigne
     }
 }
 
-template <int KM, int RPT>
+// Rows within the histogram range of a medoid (d <= 0.3) are rare (~1 % of the pairs) but nearly every wavefront has one
+// per (medoid, row slot): handled in place they cost a divergent ~50-instruction body each.  Instead a lane that
+// has such a pair appends it to its wavefront's queue in LDS (ballot + mbcnt, no atomics) and the queue is drained
+// with all lanes busy: one hit per lane.  All accumulators are integers, so the order of accumulation is free.
+constexpr int kHitCap = 256;      // queued hits per wavefront (drained when fewer than 64 slots remain)
+
+__device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn, int lane,
+                                           unsigned long long* __restrict__ acc_s, unsigned int* __restrict__ lcnt_s,
+                                           int32_t* __restrict__ llist_s, const float* __restrict__ edges_s, int dbg) {
+    const float radius = 0.05f;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int e = lane; e < qn; e += 64) {
+        const float4 v = hq[e];
+        const float d = v.x, len = v.y;
+        const int32_t row = __float_as_int(v.z);
+        const int j = __float_as_int(v.w);
+        // rows inside the medoid radius: exact integer accumulation and the medoid's candidate list
+        // (sample_medoid's `cluster`, cluster.py:621-626)
+        if (d <= radius) {
+            // len * (radius - d) in float32 as the reference computes it, then * 2^16 (exact) and RNE
+            const float p = len * (radius - d);
+            atomicAdd(&acc_s[j * kResultWords + 0], rn_u64(p * (float)VH_DENSITY_SCALE));
+            atomicAdd(&acc_s[j * kResultWords + 1 + VH_NBINS], 1ull);
+            if (d < radius) atomicAdd(&acc_s[j * kResultWords + 2 + VH_NBINS], 1ull);
+            // appended block-locally in LDS, flushed once per block -- per-row global atomics on one cursor
+            // serialise in L2 for dense medoids
+            const unsigned int lp = atomicAdd(&lcnt_s[j], 1u);
+            if (lp < (unsigned int)kLocalCap) llist_s[j * kLocalCap + lp] = row;
+        }
+        if (dbg & 2) continue;       // timing experiment: no histogram
+        // fixed-point histogram weight: len * 2^8 is exact in float32
+        if (d >= edges_s[0])
+            atomicAdd(&acc_s[j * kResultWords + 1 + bin_of_in_range(d, edges_s)], rn_u64(len * (float)VH_HIST_SCALE));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// LC: latent width known at compile time (0 = runtime L4).  With LC every column load of a lane's rows is issued
+// before the first fmaf, so a wavefront pays one memory round trip per row block instead of L4/4 dependent ones:
+// the matrices the generator scans late in a sweep (10^5 rows, ~1 workgroup per CU) are latency-bound.
+template <int KM, int RPT, int LC>
 __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
                                                           const float* __restrict__ lengths,
                                                           const uint8_t* __restrict__ kept, int64_t n,
@@ -175,13 +215,16 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                                                           unsigned long long* __restrict__ results,
                                                           int32_t* __restrict__ lists, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(smem_raw);       // [KM][kResultWords]
+    float4* hq_s = reinterpret_cast<float4*>(smem_raw);                                  // [kBlock/64][kHitCap]
+    unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(hq_s + (kBlock / 64) * kHitCap);   // [KM][kResultWords]
     float* edges_s = reinterpret_cast<float*>(acc_s + KM * kResultWords);               // [64]
     float* q_s = edges_s + 64;                                                          // [KM][L4]
     unsigned int* lcnt_s = reinterpret_cast<unsigned int*>(q_s + KM * L4);              // [KM]
     int32_t* llist_s = reinterpret_cast<int32_t*>(lcnt_s + KM);                         // [KM][kLocalCap]
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    float4* hq = hq_s + (tid >> 6) * kHitCap;
     for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
     for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
     for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
@@ -192,8 +235,8 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
     }
     __syncthreads();
 
-    const float radius = 0.05f;
     const float edge_hi = edges_s[VH_NBINS];
+    int qn = 0;   // hits queued by this wavefront (uniform)
 
     for (int64_t base = ((int64_t)blockIdx.x * kBlock + tid) * RPT; base < n;
          base += (int64_t)gridDim.x * kBlock * RPT) {
@@ -212,55 +255,81 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
             for (int r = 0; r < RPT; ++r) acc[j][r] = 0.0f;
 
         const float* col = Mt + base;
-        for (int c = 0; c < L4; c += 4) {
-            float x[4][RPT];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) load_rows<RPT>(col + (int64_t)(c + i) * ld, x[i]);
-#pragma unroll
-            for (int j = 0; j < KM; ++j) {
-                const float4 qq = *reinterpret_cast<const float4*>(q_s + j * L4 + c);
-                const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i)   // columns ascending: the defined fmaf order
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) acc[j][r] = __builtin_fmaf(x[i][r], qv[i], acc[j][r]);
-            }
-        }
-
         float len[RPT];
-        load_rows<RPT>(lengths + base, len);
-        // fixed-point histogram weight of every row, once (not per medoid): len * 2^8 is exact in float32
-        unsigned long long wfx[RPT];
+        if constexpr (LC > 0) {
+            // scalar column base + one 32-bit byte offset per lane (n < 2^30 rows, checked at creation): the
+            // 32 x RPT loads in flight do not need 32 address pairs
+            const uint32_t boff = (uint32_t)base * 4u;
+            float x[LC][RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) wfx[r] = rn_u64(len[r] * (float)VH_HIST_SCALE);
+            for (int c = 0; c < LC; ++c)
+                load_rows<RPT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mt + (int64_t)c * ld) + boff), x[c]);
+            load_rows<RPT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(lengths) + boff), len);
+            __builtin_amdgcn_sched_barrier(0);   // every load is issued before the first fmaf ...
+#pragma unroll
+            for (int c = 0; c < LC; c += 4) {
+#pragma unroll
+                for (int j = 0; j < KM; ++j) {
+                    const float4 qq = *reinterpret_cast<const float4*>(q_s + j * LC + c);
+                    const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)   // columns ascending: the defined fmaf order
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) acc[j][r] = __builtin_fmaf(x[c + i][r], qv[i], acc[j][r]);
+                    // ... and the query reads are not hoisted across the whole unrolled body (register pressure)
+                    if ((j & 3) == 3 || j == KM - 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            for (int c = 0; c < L4; c += 4) {
+                float x[4][RPT];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) load_rows<RPT>(col + (int64_t)(c + i) * ld, x[i]);
+#pragma unroll
+                for (int j = 0; j < KM; ++j) {
+                    const float4 qq = *reinterpret_cast<const float4*>(q_s + j * L4 + c);
+                    const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)   // columns ascending: the defined fmaf order
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) acc[j][r] = __builtin_fmaf(x[i][r], qv[i], acc[j][r]);
+                }
+            }
+            load_rows<RPT>(lengths + base, len);
+        }
+        // every dot product is finished here: without the pin the compiler sinks each medoid's fmaf chain into
+        // the branchy evaluation below and keeps the query registers of all medoids alive across it
+#pragma unroll
+        for (int j = 0; j < KM; ++j)
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) asm volatile("" : "+v"(acc[j][r]));
+
 #pragma unroll
         for (int j = 0; j < KM; ++j) {
             const long long med = medoid.row[j];
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
-                if (!live[r]) continue;
                 float d = 0.5f - acc[j][r];
                 if (base + r == med) d = 0.0f;
-                if (d > edge_hi) continue;   // beyond the last histogram edge (0.3 > radius): nothing to record
-                if (dbg & 1) continue;       // timing experiment: no accumulation at all
-                // rows inside the medoid radius are rare: accumulate straight into LDS (exact integers)
-                // and append the row to the medoid's candidate list (sample_medoid's `cluster`, cluster.py:621-626)
-                if (d <= radius) {
-                    // len * (radius - d) in float32 as the reference computes it, then * 2^16 (exact) and RNE
-                    const float p = len[r] * (radius - d);
-                    atomicAdd(&acc_s[j * kResultWords + 0], rn_u64(p * (float)VH_DENSITY_SCALE));
-                    atomicAdd(&acc_s[j * kResultWords + 1 + VH_NBINS], 1ull);
-                    if (d < radius) atomicAdd(&acc_s[j * kResultWords + 2 + VH_NBINS], 1ull);
-                    // candidate list (sample_medoid's `cluster`): appended block-locally in LDS, flushed once
-                    // per block -- per-row global atomics on one cursor serialise in L2 for dense medoids
-                    const unsigned int lp = atomicAdd(&lcnt_s[j], 1u);
-                    if (lp < (unsigned int)kLocalCap) llist_s[j * kLocalCap + lp] = (int32_t)(base + r);
+                // beyond the last histogram edge (0.3 > radius): nothing to record
+                const bool hit = live[r] != 0 && d <= edge_hi && !(dbg & 1);
+                const unsigned long long m = __ballot(hit);
+                if (m != 0ull) {
+                    if (hit) {
+                        const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                        hq[pos] = make_float4(d, len[r], __int_as_float((int32_t)(base + r)), __int_as_float(j));
+                    }
+                    qn += __popcll(m);
+                    if (qn > kHitCap - 64) {
+                        drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, dbg);
+                        qn = 0;
+                    }
                 }
-                if (dbg & 2) continue;       // timing experiment: no histogram
-                if (d >= edges_s[0]) atomicAdd(&acc_s[j * kResultWords + 1 + bin_of_in_range(d, edges_s)], wfx[r]);
             }
         }
     }
+    drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, dbg);
 
     __syncthreads();
     for (int i = tid; i < KM * kResultWords; i += kBlock) {
@@ -279,131 +348,6 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
         __syncthreads();
         const unsigned int start = start_s;
         if (start + cnt <= (unsigned int)kListCap && tid < (int)cnt) lists[j * kListCap + start + tid] = llist_s[j * kLocalCap + tid];
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K6m: the same scan for 9..32 medoids on the matrix pipe.  [32 rows] x [32 medoids] dot products are one chain of
-// v_mfma_f32_32x32x2_f32 over the latent columns: exact fp32 products accumulated as a k-ordered fmaf chain from +0
-// (CDNA4 guide: bitwise equal to the per-lane fmaf loop of clu_scan_kernel), so every accumulator, list and stream
-// stays bit-identical -- but a pass costs 2 global loads + 1 MFMA per column pair and lane instead of 32 x RPT fmaf
-// plus an LDS read of the query per column, and is HBM-bound again (k = 25: 221 -> ~60 us at 2 M x 32).
-//   A operand: lane l supplies x[row base + (l & 31)][column 2 s + (l >> 5)]   (two coalesced 128-byte segments of Mt)
-//   B operand: lane l supplies q[medoid l & 31][column 2 s + (l >> 5)]         (NK registers, loaded once per kernel)
-//   D: lane l holds medoid j = l & 31 against rows base + (reg & 3) + 8 (reg >> 2) + 4 (l >> 5), reg = 0..15
-// A wavefront owns 32-row tiles (grid-stride); the next tile's loads are issued before the current tile is evaluated.
-// ---------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(16))) float scan_f32x16;
-
-template <int NK>
-struct ScanTile {
-    float xa[NK];
-    uint4 k0, k1;       // live flags of the 32 rows
-    float4 len[4];      // lengths of this half-wave's 16 rows
-};
-
-template <int NK>
-__device__ __forceinline__ void scan_tile_load(ScanTile<NK>& t, const float* __restrict__ Mt, int64_t ld, int nk,
-                                               const float* __restrict__ lengths, const uint8_t* __restrict__ kept,
-                                               int64_t base, int j, int h) {
-    t.k0 = *reinterpret_cast<const uint4*>(kept + base);
-    t.k1 = *reinterpret_cast<const uint4*>(kept + base + 16);
-#pragma unroll
-    for (int s = 0; s < NK; ++s) t.xa[s] = s < nk ? Mt[(int64_t)(2 * s + h) * ld + base + j] : 0.0f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) t.len[q] = *reinterpret_cast<const float4*>(lengths + base + 8 * q + 4 * h);
-}
-
-template <int NK>
-__global__ __launch_bounds__(kBlock) void clu_scan_mfma_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
-                                                               const float* __restrict__ lengths,
-                                                               const uint8_t* __restrict__ kept,
-                                                               const float* __restrict__ q_ext, const MedoidRows medoid,
-                                                               unsigned long long* __restrict__ results,
-                                                               int32_t* __restrict__ lists) {
-    constexpr int KM = kMaxMedoids;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(smem_raw);       // [KM][kResultWords]
-    float* edges_s = reinterpret_cast<float*>(acc_s + KM * kResultWords);               // [64]
-    unsigned int* lcnt_s = reinterpret_cast<unsigned int*>(edges_s + 64);               // [KM]
-    int32_t* llist_s = reinterpret_cast<int32_t*>(lcnt_s + KM);                         // [KM][kLocalCap]
-    const int tid = threadIdx.x;
-    for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
-    for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
-    for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int nk = L4 >> 1;
-    const long long my_med = medoid.row[j];
-    float qb[NK];
-#pragma unroll
-    for (int s = 0; s < NK; ++s) {
-        const int k = 2 * s + h;
-        qb[s] = 0.0f;
-        if (s < nk) qb[s] = q_ext ? q_ext[j * L4 + k] : Mt[(int64_t)k * ld + my_med];
-    }
-    __syncthreads();
-    const float radius = 0.05f;
-    const float edge_hi = edges_s[VH_NBINS];
-    const int64_t ntiles = ld >> 5;
-    const int64_t stride = (int64_t)gridDim.x * (kBlock / 64);
-    int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + wave;
-    ScanTile<NK> cur;
-    if (tile < ntiles) scan_tile_load<NK>(cur, Mt, ld, nk, lengths, kept, tile << 5, j, h);
-    for (; tile < ntiles; tile += stride) {
-        const int64_t base = tile << 5;
-        ScanTile<NK> nxt = cur;
-        if (tile + stride < ntiles) scan_tile_load<NK>(nxt, Mt, ld, nk, lengths, kept, (tile + stride) << 5, j, h);
-        scan_f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < NK; ++s)
-            if (s < nk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.xa[s], qb[s], acc, 0, 0, 0);
-        // live flags of this half-wave's rows: group q holds rows 8 q + 4 h .. + 3 = dword 2 q + h of the 8 flag dwords
-        const uint32_t kw[8] = {cur.k0.x, cur.k0.y, cur.k0.z, cur.k0.w, cur.k1.x, cur.k1.y, cur.k1.z, cur.k1.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t live4 = h ? kw[2 * q + 1] : kw[2 * q];
-            const float lq[4] = {cur.len[q].x, cur.len[q].y, cur.len[q].z, cur.len[q].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t row = base + 8 * q + 4 * h + e;
-                if (((live4 >> (8 * e)) & 0xFFu) == 0u) continue;
-                float d = 0.5f - acc[4 * q + e];
-                if (row == my_med) d = 0.0f;
-                if (d > edge_hi) continue;
-                const float len = lq[e];
-                if (d <= radius) {
-                    const float p = len * (radius - d);
-                    atomicAdd(&acc_s[j * kResultWords + 0], rn_u64(p * (float)VH_DENSITY_SCALE));
-                    atomicAdd(&acc_s[j * kResultWords + 1 + VH_NBINS], 1ull);
-                    if (d < radius) atomicAdd(&acc_s[j * kResultWords + 2 + VH_NBINS], 1ull);
-                    const unsigned int lp = atomicAdd(&lcnt_s[j], 1u);
-                    if (lp < (unsigned int)kLocalCap) llist_s[j * kLocalCap + lp] = (int32_t)row;
-                }
-                if (d >= edges_s[0])
-                    atomicAdd(&acc_s[j * kResultWords + 1 + bin_of_in_range(d, edges_s)], rn_u64(len * (float)VH_HIST_SCALE));
-            }
-        }
-        cur = nxt;
-    }
-    __syncthreads();
-    for (int i = tid; i < KM * kResultWords; i += kBlock) {
-        const unsigned long long v = acc_s[i];
-        if (v != 0ull) atomicAdd(&results[i], v);
-    }
-    for (int jj = 0; jj < KM; ++jj) {
-        const unsigned int cnt = lcnt_s[jj];
-        if (cnt == 0u) continue;
-        unsigned int* cursor = reinterpret_cast<unsigned int*>(&results[jj * kResultWords + 3 + VH_NBINS]);
-        __shared__ unsigned int start_m;
-        if (tid == 0) start_m = cnt > (unsigned int)kLocalCap ? atomicOr(cursor, 0x80000000u) | 0x80000000u
-                                                              : atomicAdd(cursor, cnt);
-        __syncthreads();
-        const unsigned int start = start_m;
-        if (start + cnt <= (unsigned int)kListCap && tid < (int)cnt) lists[jj * kListCap + start + tid] = llist_s[jj * kLocalCap + tid];
         __syncthreads();
     }
 }
@@ -679,8 +623,7 @@ struct vh_clu {
     unsigned long long* flag() { return host_results + (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS); }
     int scan_dbg = 0;             // VAMBHIP_SCAN_DBG: timing experiments only (wrong results)
     int max_k = kMaxMedoids;      // medoids per pass the LDS can hold for this latent width (query vectors are staged there)
-    bool use_mfma = true;         // VAMBHIP_SCAN_MFMA=0: passes with more than 8 medoids stay on the VALU kernel (A/B)
-    bool mfma_pass = false;       // set by scan_core for the pass being launched
+    bool scan_lc = true;          // VAMBHIP_SCAN_LC=0: runtime-width column loop for every pass (A/B measurements)
     bool small_rpt = true;        // VAMBHIP_SCAN_WIDE=1 disables the narrow variant (A/B measurements)
     uint64_t scan_seq = 0;        // number of scans issued; scan s wrote ring slot s % kListRing
     int last_k = 0;
@@ -737,23 +680,37 @@ void wait_for_scan(vh_clu* h, unsigned long long seq) {
 constexpr size_t kScanLdsBudget = 160 * 1024 - 512;   // one workgroup may use (almost) the whole LDS of a CU
 
 size_t scan_smem_bytes(int km, int L4) {
-    return (size_t)km * kResultWords * 8 + 64 * 4 + (size_t)km * L4 * 4 + (size_t)km * 4 * (1 + kLocalCap);
+    return (size_t)(kBlock / 64) * kHitCap * 16 + (size_t)km * kResultWords * 8 + 64 * 4 + (size_t)km * L4 * 4 +
+           (size_t)km * 4 * (1 + kLocalCap);
 }
 
-template <int KM, int RPT>
-void launch_scan_rpt(vh_clu* h, const MedoidRows& med, const float* q_ext) {
+template <int KM, int RPT, int LC>
+void launch_scan_lc(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     const size_t smem = scan_smem_bytes(KM, h->L4);
     static bool attr_set = false;
     if (!attr_set) {   // wide latent spaces need more than the default 64 KiB of dynamic LDS (query vectors live there)
-        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_kernel<KM, RPT>),
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_kernel<KM, RPT, LC>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScanLdsBudget));
         attr_set = true;
     }
     VH_REQUIRE(smem <= kScanLdsBudget, "internal: %d medoids x %d latent columns do not fit the LDS", KM, h->L4);
     const int64_t blocks = ceil_div(h->ld, (int64_t)kBlock * RPT);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
-    hipLaunchKernelGGL((clu_scan_kernel<KM, RPT>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
+    hipLaunchKernelGGL((clu_scan_kernel<KM, RPT, LC>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
                        h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_dev.p, h->scan_dbg);
+}
+
+template <int KM, int RPT>
+void launch_scan_rpt(vh_clu* h, const MedoidRows& med, const float* q_ext) {
+    // the default latent width (32) has its column loads fully unrolled where the registers allow it
+    constexpr bool kUnroll = KM <= 8 && (KM + 32) * RPT <= 192;   // measured: +5-10 % up to 8 medoids, slower from 12
+    if constexpr (kUnroll) {
+        if (h->L4 == 32 && h->scan_lc && h->ld < ((int64_t)1 << 30)) {   // 32-bit byte offsets in the kernel
+            launch_scan_lc<KM, RPT, 32>(h, med, q_ext);
+            return;
+        }
+    }
+    launch_scan_lc<KM, RPT, 0>(h, med, q_ext);
 }
 
 // Rows per lane: 4 (few medoids) or 2 keep the loads wide for matrices that stream from HBM.  A matrix that
@@ -770,25 +727,7 @@ void launch_scan(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     else launch_scan_rpt<KM, RPT>(h, med, q_ext);
 }
 
-template <int NK>
-void launch_scan_mfma(vh_clu* h, const MedoidRows& med, const float* q_ext) {
-    const size_t smem = (size_t)kMaxMedoids * kResultWords * 8 + 64 * 4 + (size_t)kMaxMedoids * 4 * (1 + kLocalCap);
-    const int64_t tiles = h->ld / 32;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(tiles, kBlock / 64), 256 * 8));
-    hipLaunchKernelGGL((clu_scan_mfma_kernel<NK>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
-                       h->lengths.p, h->kept.p, q_ext, med, h->results.p, h->lists_dev.p);
-}
-
-// medoid counts above 8 run on the matrix pipe (always 32 medoid slots) when the latent width fits its registers
-bool scan_uses_mfma(const vh_clu* h, int k) { return h->use_mfma && k > 8 && h->L4 <= 64; }
-
 void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext) {
-    if (km == kMaxMedoids && h->use_mfma && h->L4 <= 64 && h->mfma_pass) {
-        if (h->L4 <= 32) launch_scan_mfma<16>(h, med, q_ext);
-        else launch_scan_mfma<32>(h, med, q_ext);
-        VH_HIP(hipGetLastError());
-        return;
-    }
     switch (km) {
         case 1: launch_scan<1>(h, med, q_ext); break;
         case 2: launch_scan<2>(h, med, q_ext); break;
@@ -852,7 +791,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
             VH_REQUIRE(h->max_k >= 1, "latent width %d does not fit the scan kernel's LDS", L);
         }
         h->small_rpt = getenv("VAMBHIP_SCAN_WIDE") == nullptr;
-        { const char* e = getenv("VAMBHIP_SCAN_MFMA"); h->use_mfma = !(e && e[0] == '0'); }
+        { const char* e = getenv("VAMBHIP_SCAN_LC"); h->scan_lc = !(e && e[0] == '0'); }
         h->scan_dbg = getenv("VAMBHIP_SCAN_DBG") ? atoi(getenv("VAMBHIP_SCAN_DBG")) : 0;
         h->results.alloc((size_t)kMaxMedoids * kResultWords);
         h->lists_dev.alloc((size_t)kMaxMedoids * kListCap);
@@ -937,8 +876,7 @@ namespace {
 int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries) {
     VH_REQUIRE(h != nullptr && medoid_rows != nullptr, "NULL argument");
     VH_REQUIRE(k >= 1 && k <= h->max_k, "k=%d outside [1, %d] (vh_clu_max_medoids)", k, h->max_k);
-    h->mfma_pass = scan_uses_mfma(h, k);
-    const int km = h->mfma_pass ? kMaxMedoids : pick_km(k);
+    const int km = pick_km(k);
     MedoidRows med;
     for (int j = 0; j < kMaxMedoids; ++j) {
         const int64_t m = medoid_rows[j < k ? j : 0];
@@ -1335,9 +1273,13 @@ struct vh_gen {
     // speculative seed scans: upcoming seeds share the pass of whatever has to be scanned anyway
     int64_t spec_scanned = 0, spec_used = 0, spec_dropped = 0;
     bool speculate = true;
+    int spec_window = kSpecWindow;
+    int spec_big_target = 0;      // experiment: widening target of passes over matrices above 600 k rows (0 = bucket fill)
     // optional wall-clock breakdown (VAMBHIP_GEN_PROFILE=1): scan calls, select calls, seed walk, logical index
     bool profile = false;
     double t_scan = 0, t_select = 0, t_seed = 0, t_logical = 0, t_total = 0;
+    double t_km[33] = {0};          // scan wall time by medoid count of the pass (profile)
+    int64_t n_km[33] = {0}, rows_km[33] = {0};
 };
 
 namespace {
@@ -1404,13 +1346,13 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
     if (g->speculate) {
         size_t target = (size_t)pick_km((int)std::min<size_t>(missing.size(), kMaxMedoids));
         if (g->clu->max_k < kMaxMedoids) target = std::min(missing.size(), (size_t)g->clu->max_k);   // wide latents: no widening
-        else if (g->clu->use_mfma && g->clu->L4 <= 64) target = kMaxMedoids;                   // matrix-pipe pass: 32 medoids cost what 1 costs
         else if (missing.size() <= 8 && g->clu->n_rows <= 600000) target = kMaxMedoids;  // latency-bound pass: extra medoids are free
+        else if (g->spec_big_target > 0 && missing.size() <= 8) target = std::max(target, (size_t)g->spec_big_target);
         else if (missing.size() == 1) target = 8;
         // look-ahead window: at most kSpecWindow unused speculative entries at any time (every emission re-validates them)
         size_t n_spec = 0;
         for (const auto& kv : g->stats) n_spec += kv.second.spec ? 1 : 0;
-        const size_t room = n_spec < (size_t)kSpecWindow ? (size_t)kSpecWindow - n_spec : 0;
+        const size_t room = n_spec < (size_t)g->spec_window ? (size_t)g->spec_window - n_spec : 0;
         if (missing.size() < target && missing.size() < (size_t)kMaxMedoids && room > 0) {
             std::vector<int64_t> extra;
             gen_upcoming_seeds(g, std::min(target - missing.size(), room), missing, extra);
@@ -1424,8 +1366,11 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         int slot;
         {
             GenTimer t(&g->t_scan);
+            GenTimer t2(&g->t_km[k]);
             slot = scan_core(g->clu, k, missing.data() + lo, nullptr);
         }
+        g->n_km[k]++;
+        g->rows_km[k] += g->clu->n_rows;
         g->scan_passes++;
         g->scan_medoids += k;
         g->rows_streamed += g->clu->n_rows;
@@ -1687,6 +1632,8 @@ int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, in
         g->rng.seed(rng_seed);
         g->profile = getenv("VAMBHIP_GEN_PROFILE") != nullptr;
         g->speculate = getenv("VAMBHIP_NO_SPECULATION") == nullptr;
+        if (const char* e = getenv("VAMBHIP_SPEC_WINDOW")) g->spec_window = atoi(e);
+        if (const char* e = getenv("VAMBHIP_SPEC_BIG_TARGET")) g->spec_big_target = atoi(e);
         g->order.assign(order, order + n);
         g->indices.resize((size_t)n);
         for (int64_t i = 0; i < n; ++i) g->indices[(size_t)i] = i;
@@ -1705,6 +1652,13 @@ int vh_gen_destroy(vh_gen* g) {
                 g->t_total, g->t_scan, g->t_select, g->t_seed, g->t_logical,
                 g->t_total - g->t_scan - g->t_select - g->t_seed - g->t_logical, (long long)g->scan_passes,
                 (long long)g->scan_medoids, (long long)g->spec_scanned, (long long)g->spec_used, (long long)g->spec_dropped);
+    if (g && g->profile) {
+        for (int k = 1; k <= 32; ++k)
+            if (g->n_km[k])
+                fprintf(stderr, "[vambhip]   passes with %2d medoids: %8lld, %7.1f ms, avg %6.1f us, avg rows %9.0f\n", k,
+                        (long long)g->n_km[k], g->t_km[k], 1e3 * g->t_km[k] / (double)g->n_km[k],
+                        (double)g->rows_km[k] / (double)g->n_km[k]);
+    }
     delete g;
     return VH_OK;
 }
