@@ -78,7 +78,9 @@ def test_global_batch_normalisation(comm):
     for gb in (256, 512):
         vae = ve.VAE(S, nhiddens=[64, 48], nlatent=8, dropout=0.0, seed=3)
         vae._ensure_dataset(dl)
-        vae.attach_communicator(comm)
+        # local BatchNorm statistics: with one rank standing in for half of a global batch the synchronised
+        # statistics (sums over all ranks / global batch) would be those of a half-empty batch
+        vae.attach_communicator(comm, syncbn=False)
         gw = np.array([w[rows].sum() * (gb // 256)], np.float32)
         means = (ctypes.c_double * 5)()
         _lib.check(lib.vh_vae_train_epoch_dp(vae._h, _lib.ptr(rows), 1, 256, gb, _lib.ptr(gw), means))

@@ -102,7 +102,9 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_wav
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+// STG: how a K-tile reaches the LDS.  0 = LDS-DMA (global_load_lds_dwordx4), 1 = through registers
+// (global_load_dwordx4 issued before the MFMAs of the current tile, ds_write_b128 after them; same LDS image).
+template <int BM, int BN, int WM, int WN, int EPI, int STG = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Args g) {
     constexpr int NWAVE = WM * WN;
     constexpr int NT = NWAVE * 64;
@@ -230,20 +232,57 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
     // K loop, unrolled by two so that every LDS address is a compile-time offset of the one array.  (A third buffer with
     // the DMA of tile t + 2 in flight across the barrier measured 0-8 % slower: the loop is bound by the per-CU LDS-DMA
     // rate, not by its latency.)
-    if (nk > 0) stage(As, Bs, kbeg);
-    __syncthreads();   // (hipcc drains the DMA queue in front of this barrier)
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        stage(As + A_BYTES, Bs + B_BYTES, kbeg + (kt + 1) * BK);
-        compute(As, Bs);
+    if constexpr (STG == 0) {
+        if (nk > 0) stage(As, Bs, kbeg);
+        __syncthreads();   // (hipcc drains the DMA queue in front of this barrier)
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            stage(As + A_BYTES, Bs + B_BYTES, kbeg + (kt + 1) * BK);
+            compute(As, Bs);
+            __syncthreads();
+            if (kt + 2 < nk) stage(As, Bs, kbeg + (kt + 2) * BK);
+            compute(As + A_BYTES, Bs + B_BYTES);
+            __syncthreads();
+        }
+        if (kt < nk) {   // odd number of K-tiles: the last one sits in buffer 0
+            compute(As, Bs);
+            __syncthreads();
+        }
+    } else {
+        uint4 ra[RA], rb[RB];
+        auto fetch = [&](int k0) {
+            const int room = kend - k0;
+#pragma unroll
+            for (int r = 0; r < RA; ++r) ra[r] = *reinterpret_cast<const uint4*>(a_k[r] < room ? a_src[r] + k0 : g.zeros);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) rb[r] = *reinterpret_cast<const uint4*>(b_k[r] < room ? b_src[r] + k0 : g.zeros);
+        };
+        auto put = [&](unsigned char* abuf, unsigned char* bbuf) {
+#pragma unroll
+            for (int r = 0; r < RA; ++r) *reinterpret_cast<uint4*>(abuf + (wave + NWAVE * r) * 1024 + lane * 16) = ra[r];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) *reinterpret_cast<uint4*>(bbuf + (wave + NWAVE * r) * 1024 + lane * 16) = rb[r];
+        };
+        if (nk > 0) {
+            fetch(kbeg);
+            put(As, Bs);
+        }
         __syncthreads();
-        if (kt + 2 < nk) stage(As, Bs, kbeg + (kt + 2) * BK);
-        compute(As + A_BYTES, Bs + B_BYTES);
-        __syncthreads();
-    }
-    if (kt < nk) {   // odd number of K-tiles: the last one sits in buffer 0
-        compute(As, Bs);
-        __syncthreads();
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            fetch(kbeg + (kt + 1) * BK);
+            compute(As, Bs);
+            put(As + A_BYTES, Bs + B_BYTES);
+            __syncthreads();
+            if (kt + 2 < nk) fetch(kbeg + (kt + 2) * BK);
+            compute(As + A_BYTES, Bs + B_BYTES);
+            if (kt + 2 < nk) put(As, Bs);
+            __syncthreads();
+        }
+        if (kt < nk) {
+            compute(As, Bs);
+            __syncthreads();
+        }
     }
 
     // ---------------------------------------------------------------------------------------------------

@@ -1925,7 +1925,8 @@ int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, 
         g.bias = dbias.p; g.m_real = M; g.fstat_out = dstat.p; g.drop_scale = 1.0f; g.xcd_remap = 1;
         const int tile = variant & 0xFF;
         g.dbg = variant >> 8;
-        VH_REQUIRE(tile == 0 || tile == 1 || tile == 3 || tile == 4 || tile == 7, "variant: tile 0, 1, 3, 4 or 7 (+ 256 * timing-experiment flags)");
+        VH_REQUIRE(tile == 0 || tile == 1 || tile == 3 || tile == 4 || tile == 7 || tile == 11 || tile == 13 || tile == 17,
+                   "variant: tile 0, 1, 3, 4, 7 or 11, 13, 17 (register-staged) (+ 256 * timing-experiment flags)");
         auto run = [&] {
             if (epi == E16_SPLITK) step16::gemm16_variant<E16_SPLITK>(s, tile, g, nsplit);
             else if (epi == E16_BIAS) step16::gemm16_variant<E16_BIAS>(s, tile, g, 1);

@@ -15,11 +15,11 @@ namespace step16 {
 
 constexpr int kDwTargetWgs = 256;   // workgroups wanted per weight-gradient GEMM (they share the chip with the dX chain)
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int STG = 0>
 void launch_gemm16(hipStream_t stream, const Gemm16Args& g, int splits) {
     static bool attr_set = false;
     constexpr size_t smem = gemm16_smem_bytes<BM, BN, WM, WN, EPI>();
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STG>;
     if (!attr_set) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kMaxDynLds));
@@ -67,6 +67,9 @@ void gemm16_variant(hipStream_t s, int tile, const Gemm16Args& g, int splits) {
         case 3: launch_gemm16<64, 128, 2, 2, EPI>(s, g, splits); break;
         case 4: launch_gemm16<128, 64, 2, 2, EPI>(s, g, splits); break;
         case 7: launch_gemm16<128, 128, 2, 2, EPI>(s, g, splits); break;
+        case 11: launch_gemm16<128, 128, 2, 4, EPI, 1>(s, g, splits); break;
+        case 13: launch_gemm16<64, 128, 2, 2, EPI, 1>(s, g, splits); break;
+        case 17: launch_gemm16<128, 128, 2, 2, EPI, 1>(s, g, splits); break;
         default: gemm16<EPI>(s, g, splits); break;
     }
 }
