@@ -70,6 +70,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=20_000)
     p.add_argument("--no-c3", action="store_true", help="skip the C3-shape leg")
+    p.add_argument("--no-cluster", action="store_true",
+                   help="PROFILING ONLY: leave the cluster sweep out of a step (a rocprofv3 trace of a short training "
+                        "run; with few epochs the latents are unstructured and the sweep degenerates).  The line is "
+                        "marked as such and is not a valid headline")
     p.add_argument("--c3-epochs", type=int, default=3)
     p.add_argument("--deadline", type=float, default=1650.0,
                    help="seconds from process start the whole run should fit in (the driver allows 1800): only the "
@@ -128,6 +132,12 @@ def run_step(ve, vc, lib, _lib, dl, lens, args, seed, comm=None, probe_layer=0, 
     t2 = time.perf_counter()
     latent = vae.encode(dl)
     t3 = time.perf_counter()
+    if args.no_cluster:
+        ms, nl, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(lib.vh_vae_probe_result(vae._h, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl)))
+        return dict(setup_s=t1 - t0, train_s=t2 - t1, encode_s=t3 - t2, cluster_s=0.0, total_s=t3 - t0, clusters=0,
+                    probe_ms=ms.value, probe_launches=nl.value, probe_flops=fl.value, scan_passes=0, scan_medoids=0,
+                    scan_kernel_ms=0.0, scan_bytes=0, loss=vae.last_epoch_losses["loss"], latent=latent)
     if sharded is not None:
         gen = sharded(latent, lens, seed)
         backend = gen._backend
@@ -430,7 +440,7 @@ def main():
                              f"{'in total' if strong else 'per GPU'} (D={D}), hidden 512-512, latent {args.latent}, "
                              f"batch {args.batch} per GPU, {arith}; {args.epochs} train epochs"
                              f"{' (reference CLI default)' if args.epochs == 300 else ' (reference CLI default is 300)'}"
-                             " + encode + full cluster sweep per step; features resident in HBM before the clock starts "
+                             f" + encode + {'NO cluster sweep (--no-cluster: profiling run, not a headline)' if args.no_cluster else 'full cluster sweep'} per step; features resident in HBM before the clock starts "
                              "(host normalisation + one H2D upload outside the timed region)"),
                 "contigs_per_gpu": args.contigs if not strong else args.contigs // world, "samples": args.samples,
                 "batch": args.batch, "epochs": args.epochs,
@@ -462,7 +472,7 @@ def main():
         lens_keep = lens[: args.cpu_sample].copy()
         for r in results + warm:
             r.pop("latent", None)
-        if not args.no_cpu_baseline and world == 1 and latent_keep is not None:
+        if not args.no_cpu_baseline and world == 1 and latent_keep is not None and not args.no_cluster:
             line["cpu_baseline"] = cpu_baseline(args, latent_keep, lens_keep)
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None

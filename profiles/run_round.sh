@@ -1,0 +1,50 @@
+#!/bin/bash
+# What is run on the GPU box to produce the profiles/rNN_* evidence of a round (gpurun -- bash profiles/run_round.sh TAG [parts]).
+# parts: any of  tests bench prof gemm scan pmc   (default: all but pmc)
+TAG=${1:-r02a}
+PARTS=${2:-"tests bench prof gemm scan"}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+
+if has tests; then
+  (cd $R && timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log)
+  tail -3 $O/pytest_gpu.log
+fi
+if has bench; then
+  (cd $R && timeout 1500 python bench.py --steps ${BENCH_STEPS:-1} --warmup ${BENCH_WARMUP:-1} > $O/bench.json 2> $O/bench.err; echo "rc=$?" >> $O/bench.err)
+  cat $O/bench.json
+  tail -3 $O/bench.err
+fi
+if has prof; then
+  rm -rf /tmp/prof
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o trace -- \
+      python $R/bench.py --epochs 3 --steps 1 --warmup 0 --no-cpu-baseline --no-c3 --no-cluster > $O/bench_under_rocprof.json 2> $O/prof.err
+  f=$(find /tmp/prof -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp $f $O/kernel_stats_bench_e3.csv
+  t=$(find /tmp/prof -name '*kernel_trace.csv' | head -1)
+  [ -n "$t" ] && python $R/tests/gpu_timeline16.py $t > $O/step_timeline.txt 2>&1
+  head -30 $O/kernel_stats_bench_e3.csv | cut -c1-200
+  tail -45 $O/step_timeline.txt
+fi
+if has gemm; then
+  (cd $R && timeout 300 python tests/gpu_gemm16_bench.py $O/gemm16_bench.json > $O/gemm16_bench.txt 2>&1)
+  cat $O/gemm16_bench.txt
+fi
+if has scan; then
+  (cd $R && timeout 300 python tests/gpu_scan_bench.py $O/scan_bench.json > $O/scan_bench.txt 2>&1)
+  cat $O/scan_bench.txt
+fi
+if has pmc; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_$c
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- \
+        python $R/bench.py --epochs 2 --steps 1 --warmup 0 --no-cpu-baseline --no-c3 --no-cluster > /dev/null 2> $O/pmc_$c.err
+    f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
+    [ -n "$f" ] && python $R/tests/gpu_pmc_summary.py $f $c > $O/pmc_$c.txt 2>&1
+    tail -15 $O/pmc_$c.txt
+  done
+fi
+exit 0
