@@ -388,8 +388,15 @@ def main():
             dist.all_reduce(e, op=dist.ReduceOp.MIN)
             ep = int(e.item())
         warm_epochs.append(ep)
+        # a shortened warm-up step leaves the cluster sweep out: after a tenth of the epochs the latents are barely
+        # structured and the sweep degenerates into 10^5..10^6 tiny clusters (minutes instead of seconds)
+        short = ep < args.epochs
+        if short:
+            args.no_cluster, keep = True, args.no_cluster
         warm.append(run_step(ve, vc, lib, _lib, dl, lens, args, seed=1000 + i, comm=comm, probe_layer=1,
                              time_scans=(i == 0), sharded=sharded, epochs=ep))
+        if short:
+            args.no_cluster = keep
     barrier()
     t0 = time.perf_counter()
     results = []
