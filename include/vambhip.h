@@ -233,6 +233,34 @@ int vh_dataset_create(const float* depths, const float* tnf, const float* abunda
 int vh_dataset_destroy(vh_dataset* d);
 int vh_vae_use_dataset(vh_vae* h, vh_dataset* d);
 
+/* ---- make_dataloader on the device -------------------------------------------------
+ * The matrix passes of vamb/encode.py:98-119 and vamb/vambtools.py:250-288 (column sums of the abundances, per-row
+ * scaling + total + relative abundance, column z-score of the TNF block) run on the RAW matrices after ONE upload and
+ * leave the normalised features in the resident matrix the VAE trains on; the O(n) / O(columns) vector work (1e6 / sums,
+ * log + z-score of the totals, mean / std from the sums, contig weights) stays in numpy on the host, fed by these calls,
+ * so every value is bit-identical to the reference's numpy result (summation orders reproduced, see csrc/prep.hip).
+ * Call order: create -> upload -> column_sums(0) -> normalise_rows -> column_sums(1) -> column_sums(1, centre = mean)
+ * -> zscore_tnf -> finish (which hands the handle's matrix over as a vh_dataset; destroy the vh_prep afterwards). */
+typedef struct vh_prep vh_prep;
+int vh_prep_create(int64_t n, int nsamples, vh_prep** out);
+int vh_prep_destroy(vh_prep* p);
+/* raw abundance [n][nsamples] and tnf [n][103], C-contiguous float32 */
+int vh_prep_upload(vh_prep* p, const float* abundance, const float* tnf);
+/* out[j] = sum over rows IN ROW ORDER (numpy's a.sum(axis=0)) of block 0 (depths, nsamples columns) or 1 (tnf, 103);
+ * with centre != NULL the summand is (x - centre[j])^2 (numpy's _var) */
+int vh_prep_column_sums(vh_prep* p, int block, const float* centre, float* out);
+/* depths[r][j] *= scale[j]; totals[r] = numpy pairwise row sum (program: n_ops x {kind, start, len} int32, postfix:
+ * kind 0 = leaf over [start, start + len), 1 = add); depths[r] /= totals[r], or = uniform where totals[r] == 0 */
+int vh_prep_normalise_rows(vh_prep* p, const float* scale, const int32_t* program, int n_ops, float uniform,
+                           float* totals);
+/* tnf[r][c] = (tnf[r][c] - mean[c]) / stdev[c] */
+int vh_prep_zscore_tnf(vh_prep* p, const float* mean, const float* stdev);
+/* total_abundance [n] (log + z-scored on the host) and weights [n] complete the dataset */
+int vh_prep_finish(vh_prep* p, const float* total_abundance, const float* weights, vh_dataset** out);
+int vh_dataset_shape(vh_dataset* d, int64_t* n, int* nsamples);
+/* host copies of the four tensors of make_dataloader's TensorDataset (any pointer may be NULL) */
+int vh_dataset_download(vh_dataset* d, float* depths, float* tnf, float* total_abundance, float* weights);
+
 /* n_epochs consecutive epochs of the same shape with the device-side shuffle and a single host synchronisation
  * at the end (the loop of trainmodel, encode.py:598-601, between two batch-size changes).  global_batch = 0
  * without a communicator.  loss_means: [n_epochs][5] = the five means trainepoch logs per epoch. */

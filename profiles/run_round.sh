@@ -37,6 +37,26 @@ if has scan; then
   (cd $R && timeout 300 python tests/gpu_scan_bench.py $O/scan_bench.json > $O/scan_bench.txt 2>&1)
   cat $O/scan_bench.txt
 fi
+if has prep; then
+  (cd $R && timeout 600 python -m pytest tests/test_prep_gpu.py -m gpu -x -q > $O/pytest_prep.log 2>&1; echo "rc=$?" >> $O/pytest_prep.log)
+  tail -15 $O/pytest_prep.log
+fi
+if has scanab; then      # the scan kernel's column-loop variants: bit-exactness (cluster tests) + duration per medoid count
+  for m in ${SCAN_MODES:-1 2 3 4}; do
+    (cd $R && VAMBHIP_SCAN_LC=$m timeout 300 python -m pytest tests/test_cluster_gpu.py -m gpu -x -q > $O/pytest_cluster_lc$m.log 2>&1; echo "rc=$?" >> $O/pytest_cluster_lc$m.log)
+    tail -2 $O/pytest_cluster_lc$m.log
+    (cd $R && VAMBHIP_SCAN_LC=$m timeout 300 python tests/gpu_scan_bench.py $O/scan_bench_lc$m.json > $O/scan_bench_lc$m.txt 2>&1)
+    grep -E "n=(100000|2000000) L=32 k=( 8|12|16|25|32)" $O/scan_bench_lc$m.txt
+  done
+fi
+if has gemmvar; then
+  (cd $R && timeout 300 python tests/gpu_gemm16_variants.py $O/gemm16_variants.json > $O/gemm16_variants.txt 2>&1)
+  cat $O/gemm16_variants.txt
+fi
+if has sweepab; then     # ONE trained C2 latent matrix clustered under several generator / kernel settings
+  (cd $R && timeout 900 python tests/gpu_cluster_sweep_ab.py 2000000 200 8192 bf16 300 "${SWEEP_SETTINGS:-VAMBHIP_GEN_PROFILE=1,VAMBHIP_SCAN_LC=1;VAMBHIP_GEN_PROFILE=1,VAMBHIP_SCAN_LC=2;VAMBHIP_GEN_PROFILE=1,VAMBHIP_SCAN_LC=3}" $O/sweep_ab.json > $O/sweep_ab.txt 2>&1)
+  cat $O/sweep_ab.txt | cut -c1-300
+fi
 if has pmc; then
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$c

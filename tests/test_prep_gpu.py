@@ -1,0 +1,104 @@
+"""make_dataloader on the device (csrc/prep.hip) against the host numpy path, which is the
+reference's own statements (vamb/encode.py:98-126) and is itself pinned to tensors produced by the real reference
+(tests/test_prep_host.py, tests/golden/prep_*.npz).  Bar: bit-exact float32 tensors."""
+import numpy as np
+import pytest
+import torch
+
+import fixture_defs as fd
+from vamb_amd import encode as ve, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(ab, tnf, lens, batchsize=64):
+    ve.set_prep_mode("host")
+    try:
+        host = [t.numpy() for t in ve.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=batchsize).dataset.tensors]
+        ve.set_prep_mode("device")
+        dl = ve.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=batchsize)
+        assert getattr(dl.dataset, "_vambhip_prepared", None) is not None     # the device path really ran
+        dev = [t.numpy() for t in dl.dataset.tensors]
+    finally:
+        ve.set_prep_mode("auto")
+    return host, dev, dl
+
+
+@pytest.mark.parametrize("name", list(fd.PREP_CASES))
+def test_device_prep_matches_reference_tensors(name):
+    ab, tnf, lens = fd.prep_inputs(name)
+    g = fd.load(name)
+    host, dev, _ = _both(ab, tnf, lens, 16)
+    for h, d, key in zip(host, dev, ("depths", "tnf", "total_abundance", "weights")):
+        assert d.dtype == np.float32 and d.shape == g[key].shape
+        assert np.array_equal(d, g[key]), key
+        assert np.array_equal(h, d), key
+
+
+@pytest.mark.parametrize("n,S", [(1, 1), (2, 3), (33, 7), (100, 8), (513, 9), (1000, 50), (4097, 129), (3000, 200),
+                                 (700, 1000), (257, 2500), (20011, 137)])
+def test_device_prep_bit_exact(n, S):
+    ab, tnf, lens, _ = synth.features(n, S, seed=n + S)
+    rng = np.random.RandomState(n)
+    if n > 10:      # contigs with zero depth everywhere take the 1 / n_samples branch (encode.py:109-113)
+        ab[rng.choice(n, size=max(1, n // 50), replace=False)] = 0.0
+    if n > 4:
+        tnf[:, 5] = tnf[0, 5]        # a constant TNF column: std == 0 -> 1 (vambtools.py:276)
+    host, dev, dl = _both(ab, tnf, lens)
+    for h, d, key in zip(host, dev, ("depths", "tnf", "total_abundance", "weights")):
+        assert h.shape == d.shape and np.array_equal(h, d, equal_nan=True), key
+    assert len(dl.dataset) == n and len(dl.dataset[0]) == 4
+
+
+def test_device_prep_full_size_properties():
+    """C2-sized input (2 M x 200): too large for an element-wise host comparison inside the test budget, so the
+    size-independent properties: rows of depths sum to 1, TNF columns have zero mean / unit variance, and a 64 k-row
+    prefix block equals the host path when the column statistics of the full matrix are reused (checked through the
+    first rows of the tensors only where they do not depend on the other rows: depths / total given the same scale)."""
+    n, S = 2_000_000, 200
+    ab, tnf, lens, _ = synth.features(n, S, seed=5)
+    ve.set_prep_mode("device")
+    try:
+        dl = ve.make_dataloader(ab, tnf, lens, batchsize=8192)
+    finally:
+        ve.set_prep_mode("auto")
+    d, t, a, w = (x.numpy() for x in dl.dataset.tensors)
+    assert np.abs(d.sum(axis=1, dtype=np.float64) - 1).max() < 1e-5
+    # (float32 row-order sums over 2 M rows, as numpy computes them: percent-level agreement with a float64 recomputation)
+    assert np.abs(t.mean(axis=0, dtype=np.float64)).max() < 5e-2 and np.abs(t.std(axis=0, dtype=np.float64) - 1).max() < 5e-2
+    # the depth block depends on the other rows only through the column sums: recompute it on the host for a prefix
+    sums = ab.sum(axis=0)
+    m = 65536
+    x = ab[:m] * (1_000_000 / sums)
+    tot = x.sum(axis=1)
+    assert np.array_equal(d[:m], x / tot.reshape(-1, 1))
+    assert abs(float(w.sum()) - n) < 1.0
+
+
+def test_zero_depth_sample_raises():
+    ab, tnf, lens, _ = synth.features(100, 6, seed=1)
+    ab[:, 2] = 0
+    ve.set_prep_mode("device")
+    try:
+        with pytest.raises(ValueError):
+            ve.make_dataloader(ab, tnf, lens, batchsize=32)
+    finally:
+        ve.set_prep_mode("auto")
+
+
+def test_training_from_a_prepared_loader_is_identical():
+    """The VAE consumes the device-prepared matrix directly (no host round trip): same seed -> same losses and the same
+    latents as training on the host-prepared loader."""
+    ab, tnf, lens, _ = synth.features(3000, 20, seed=2)
+    out = []
+    for mode in ("host", "device"):
+        ve.set_prep_mode(mode)
+        try:
+            dl = ve.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=256)
+        finally:
+            ve.set_prep_mode("auto")
+        vae = ve.VAE(20, seed=3)
+        vae.trainmodel(dl, nepochs=3, batchsteps=None)
+        out.append((vae.last_epoch_losses["loss"], vae.encode(dl)))
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1])

@@ -108,3 +108,62 @@ def test_device_shuffle_formula_is_a_permutation():
             assert sorted(out) == list(range(n)), (n, key)
             if n >= 1000:   # not the identity, and different keys give different orders
                 assert sum(1 for i, v in enumerate(out) if i == v) < n // 50
+
+
+# ---- the summation orders csrc/prep.hip reproduces (device side of make_dataloader) ----------
+def _run_pairwise_program(program, row):
+    """The postfix program of ve._pairwise_program executed in explicit float32 steps (what prep_rows_kernel does)."""
+    f = np.float32
+    stack = []
+    for kind, start, length in program:
+        if kind == 1:
+            right, left = stack.pop(), stack.pop()
+            stack.append(f(left + right))
+            continue
+        a = row[start:start + length]
+        if length < 8:
+            res = f(0.0)
+            for v in a:
+                res = f(res + v)
+        else:
+            body = length - length % 8
+            r = [f(a[j]) for j in range(8)]
+            for i in range(8, body, 8):
+                for j in range(8):
+                    r[j] = f(r[j] + a[i + j])
+            res = f(f(f(r[0] + r[1]) + f(r[2] + r[3])) + f(f(r[4] + r[5]) + f(r[6] + r[7])))
+            for i in range(body, length):
+                res = f(res + a[i])
+        stack.append(res)
+    assert len(stack) == 1
+    return f(f(0.0) + stack[0])
+
+
+@pytest.mark.parametrize("S", list(range(1, 20)) + [50, 127, 128, 129, 136, 137, 200, 255, 256, 257, 300, 1000, 1001, 2500])
+def test_pairwise_program_is_numpys_row_sum(S):
+    rng = np.random.RandomState(S)
+    a = np.exp(3 * rng.standard_normal((5, S))).astype(np.float32)
+    program = ve._pairwise_program(S)
+    got = np.array([_run_pairwise_program(program, r) for r in a], dtype=np.float32)
+    assert np.array_equal(got, a.sum(axis=1))
+
+
+def test_column_sums_are_sequential_in_row_order():
+    """a.sum(axis=0) / a.mean(axis=0) / a.std(axis=0) of a C-contiguous float32 matrix: one chain per column, rows
+    ascending; the mean and variance divide in double and round once (numpy _mean / _var with an intp count)."""
+    rng = np.random.RandomState(3)
+    for n, c in [(1000, 7), (4097, 103), (70001, 16)]:
+        a = np.exp(rng.standard_normal((n, c))).astype(np.float32)
+        acc = a[0].copy()
+        for i in range(1, n):
+            acc += a[i]
+        assert np.array_equal(acc, a.sum(axis=0))
+        mean = np.true_divide(acc.copy(), np.intp(n), casting="unsafe", out=acc.copy())
+        assert np.array_equal(mean, a.mean(axis=0))
+        x = a - mean
+        x = x * x
+        sq = x[0].copy()
+        for i in range(1, n):
+            sq += x[i]
+        var = np.true_divide(sq, np.intp(n), out=sq, casting="unsafe")
+        assert np.array_equal(np.sqrt(var), a.std(axis=0))

@@ -96,6 +96,15 @@ SIGNATURES = {
     "vh_dataset_create": (_int, [_vp, _vp, _vp, _vp, _i64, _int, ctypes.POINTER(_vp)]),
     "vh_dataset_destroy": (_int, [_vp]),
     "vh_vae_use_dataset": (_int, [_vp, _vp]),
+    "vh_prep_create": (_int, [_i64, _int, _pp]),
+    "vh_prep_destroy": (_int, [_vp]),
+    "vh_prep_upload": (_int, [_vp, _vp, _vp]),
+    "vh_prep_column_sums": (_int, [_vp, _int, _vp, _vp]),
+    "vh_prep_normalise_rows": (_int, [_vp, _vp, _vp, _int, _f32, _vp]),
+    "vh_prep_zscore_tnf": (_int, [_vp, _vp, _vp]),
+    "vh_prep_finish": (_int, [_vp, _vp, _vp, _pp]),
+    "vh_dataset_shape": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_int)]),
+    "vh_dataset_download": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "vh_vae_train_epochs": (_int, [_vp, _i64, _i64, _i64, _i64, _vp]),
     "vh_vae_get_hidden": (_int, [_vp, _int, _vp, _i64]),
     "vh_vae_set_precision": (_int, [_vp, _int]),

@@ -27,6 +27,8 @@ SOURCES = {
     # the wave-aggregation loops the optimizer wraps around each of them cost more than the few atomics they save
     "cluster.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "vae.hip": [],
+    # prep.hip reproduces numpy's float32 results bit for bit: no fused multiply-add
+    "prep.hip": ["-ffp-contract=off"],
     "comm.hip": [],
 }
 

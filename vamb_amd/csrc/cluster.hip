@@ -206,7 +206,8 @@ __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn
 // LC: latent width known at compile time (0 = runtime L4).  With LC every column load of a lane's rows is issued
 // before the first fmaf, so a wavefront pays one memory round trip per row block instead of L4/4 dependent ones:
 // the matrices the generator scans late in a sweep (10^5 rows, ~1 workgroup per CU) are latency-bound.
-template <int KM, int RPT, int LC>
+// JG: (unrolled loads only) medoids per accumulator group, see the kernel body.
+template <int KM, int RPT, int LC, int JG = KM>
 __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
                                                           const float* __restrict__ lengths,
                                                           const uint8_t* __restrict__ kept, int64_t n,
@@ -248,14 +249,44 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
         // whole wavefront dead (already emitted rows): skip the column loads
         if (__ballot(any) == 0ull) continue;
 
-        float acc[KM][RPT];
-#pragma unroll
-        for (int j = 0; j < KM; ++j)
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) acc[j][r] = 0.0f;
-
         const float* col = Mt + base;
+        (void)col;
         float len[RPT];
+        // evaluation of the finished dot products of medoids j0 .. j0 + NJ - 1 (compare, queue the rare hits)
+        auto evaluate = [&](auto& acc, int j0) {
+            constexpr int NJ = (int)(sizeof(acc) / sizeof(acc[0]));
+            // every dot product is finished here: without the pin the compiler sinks each medoid's fmaf chain into
+            // the branchy evaluation below and keeps the query registers of all medoids alive across it
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) asm volatile("" : "+v"(acc[j][r]));
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = j0 + jj;
+                const long long med = medoid.row[j];
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    float d = 0.5f - acc[jj][r];
+                    if (base + r == med) d = 0.0f;
+                    // beyond the last histogram edge (0.3 > radius): nothing to record
+                    const bool hit = live[r] != 0 && d <= edge_hi && !(dbg & 1);
+                    const unsigned long long m = __ballot(hit);
+                    if (m != 0ull) {
+                        if (hit) {
+                            const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32),
+                                                                                __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                            hq[pos] = make_float4(d, len[r], __int_as_float((int32_t)(base + r)), __int_as_float(j));
+                        }
+                        qn += __popcll(m);
+                        if (qn > kHitCap - 64) {
+                            drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, dbg);
+                            qn = 0;
+                        }
+                    }
+                }
+            }
+        };
         if constexpr (LC > 0) {
             // scalar column base + one 32-bit byte offset per lane (n < 2^30 rows, checked at creation): the
             // 32 x RPT loads in flight do not need 32 address pairs
@@ -266,21 +297,38 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                 load_rows<RPT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mt + (int64_t)c * ld) + boff), x[c]);
             load_rows<RPT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(lengths) + boff), len);
             __builtin_amdgcn_sched_barrier(0);   // every load is issued before the first fmaf ...
+            // The rows stay in registers while the medoids are taken in groups of JG: JG x RPT accumulators live at a
+            // time instead of KM x RPT, so the many-medoid variants keep >= 3 wavefronts per SIMD with all their column
+            // loads in flight (they were bound by memory-level parallelism: 1.5 TB/s at 2 M x 32, k = 25).
 #pragma unroll
-            for (int c = 0; c < LC; c += 4) {
+            for (int j0 = 0; j0 < KM; j0 += JG) {
+                float acc[JG][RPT];
 #pragma unroll
-                for (int j = 0; j < KM; ++j) {
-                    const float4 qq = *reinterpret_cast<const float4*>(q_s + j * LC + c);
-                    const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
+                for (int j = 0; j < JG; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)   // columns ascending: the defined fmaf order
+                    for (int r = 0; r < RPT; ++r) acc[j][r] = 0.0f;
 #pragma unroll
-                        for (int r = 0; r < RPT; ++r) acc[j][r] = __builtin_fmaf(x[c + i][r], qv[i], acc[j][r]);
-                    // ... and the query reads are not hoisted across the whole unrolled body (register pressure)
-                    if ((j & 3) == 3 || j == KM - 1) __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < LC; c += 4) {
+#pragma unroll
+                    for (int j = 0; j < JG; ++j) {
+                        const float4 qq = *reinterpret_cast<const float4*>(q_s + (j0 + j) * LC + c);
+                        const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)   // columns ascending: the defined fmaf order
+#pragma unroll
+                            for (int r = 0; r < RPT; ++r) acc[j][r] = __builtin_fmaf(x[c + i][r], qv[i], acc[j][r]);
+                        // ... and the query reads are not hoisted across the whole unrolled body (register pressure)
+                        if ((j & 3) == 3 || j == JG - 1) __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+                evaluate(acc, j0);
             }
         } else {
+            float acc[KM][RPT];
+#pragma unroll
+            for (int j = 0; j < KM; ++j)
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) acc[j][r] = 0.0f;
             for (int c = 0; c < L4; c += 4) {
                 float x[4][RPT];
 #pragma unroll
@@ -296,37 +344,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                 }
             }
             load_rows<RPT>(lengths + base, len);
-        }
-        // every dot product is finished here: without the pin the compiler sinks each medoid's fmaf chain into
-        // the branchy evaluation below and keeps the query registers of all medoids alive across it
-#pragma unroll
-        for (int j = 0; j < KM; ++j)
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) asm volatile("" : "+v"(acc[j][r]));
-
-#pragma unroll
-        for (int j = 0; j < KM; ++j) {
-            const long long med = medoid.row[j];
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                float d = 0.5f - acc[j][r];
-                if (base + r == med) d = 0.0f;
-                // beyond the last histogram edge (0.3 > radius): nothing to record
-                const bool hit = live[r] != 0 && d <= edge_hi && !(dbg & 1);
-                const unsigned long long m = __ballot(hit);
-                if (m != 0ull) {
-                    if (hit) {
-                        const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32),
-                                                                            __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                        hq[pos] = make_float4(d, len[r], __int_as_float((int32_t)(base + r)), __int_as_float(j));
-                    }
-                    qn += __popcll(m);
-                    if (qn > kHitCap - 64) {
-                        drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, dbg);
-                        qn = 0;
-                    }
-                }
-            }
+            evaluate(acc, 0);
         }
     }
     drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, dbg);
@@ -623,7 +641,10 @@ struct vh_clu {
     unsigned long long* flag() { return host_results + (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS); }
     int scan_dbg = 0;             // VAMBHIP_SCAN_DBG: timing experiments only (wrong results)
     int max_k = kMaxMedoids;      // medoids per pass the LDS can hold for this latent width (query vectors are staged there)
-    bool scan_lc = true;          // VAMBHIP_SCAN_LC=0: runtime-width column loop for every pass (A/B measurements)
+    int scan_lc = 1;              // column-loop variant (VAMBHIP_SCAN_LC, A/B measurements): 0 runtime-width loop everywhere,
+                                  // 1 unrolled loads up to 8 medoids, 2 unrolled loads for every medoid count,
+                                  // 3 / 4 = 2 with the medoids of a pass taken in 2 / 4 accumulator groups (24, 32: 2 / 4;
+                                  // 12, 16: 1 / 2)
     bool small_rpt = true;        // VAMBHIP_SCAN_WIDE=1 disables the narrow variant (A/B measurements)
     uint64_t scan_seq = 0;        // number of scans issued; scan s wrote ring slot s % kListRing
     int last_k = 0;
@@ -684,30 +705,37 @@ size_t scan_smem_bytes(int km, int L4) {
            (size_t)km * 4 * (1 + kLocalCap);
 }
 
-template <int KM, int RPT, int LC>
+template <int KM, int RPT, int LC, int JG = KM>
 void launch_scan_lc(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     const size_t smem = scan_smem_bytes(KM, h->L4);
     static bool attr_set = false;
     if (!attr_set) {   // wide latent spaces need more than the default 64 KiB of dynamic LDS (query vectors live there)
-        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_kernel<KM, RPT, LC>),
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_kernel<KM, RPT, LC, JG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScanLdsBudget));
         attr_set = true;
     }
     VH_REQUIRE(smem <= kScanLdsBudget, "internal: %d medoids x %d latent columns do not fit the LDS", KM, h->L4);
     const int64_t blocks = ceil_div(h->ld, (int64_t)kBlock * RPT);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
-    hipLaunchKernelGGL((clu_scan_kernel<KM, RPT, LC>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
+    hipLaunchKernelGGL((clu_scan_kernel<KM, RPT, LC, JG>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
                        h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_dev.p, h->scan_dbg);
 }
 
 template <int KM, int RPT>
 void launch_scan_rpt(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     // the default latent width (32) has its column loads fully unrolled where the registers allow it
-    constexpr bool kUnroll = KM <= 8 && (KM + 32) * RPT <= 192;   // measured: +5-10 % up to 8 medoids, slower from 12
-    if constexpr (kUnroll) {
-        if (h->L4 == 32 && h->scan_lc && h->ld < ((int64_t)1 << 30)) {   // 32-bit byte offsets in the kernel
-            launch_scan_lc<KM, RPT, 32>(h, med, q_ext);
-            return;
+    if constexpr (KM <= 8) {
+        if constexpr ((KM + 32) * RPT <= 192) {
+            if (h->L4 == 32 && h->scan_lc >= 1 && h->ld < ((int64_t)1 << 30)) {   // 32-bit byte offsets in the kernel
+                launch_scan_lc<KM, RPT, 32>(h, med, q_ext);
+                return;
+            }
+        }
+    } else if constexpr (RPT <= 2) {
+        if (h->L4 == 32 && h->ld < ((int64_t)1 << 30)) {
+            if (h->scan_lc == 2) { launch_scan_lc<KM, RPT, 32>(h, med, q_ext); return; }
+            if (h->scan_lc == 3) { launch_scan_lc<KM, RPT, 32, (KM >= 24 ? KM / 2 : KM)>(h, med, q_ext); return; }
+            if (h->scan_lc == 4) { launch_scan_lc<KM, RPT, 32, (KM >= 24 ? KM / 4 : KM / 2)>(h, med, q_ext); return; }
         }
     }
     launch_scan_lc<KM, RPT, 0>(h, med, q_ext);
@@ -791,7 +819,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
             VH_REQUIRE(h->max_k >= 1, "latent width %d does not fit the scan kernel's LDS", L);
         }
         h->small_rpt = getenv("VAMBHIP_SCAN_WIDE") == nullptr;
-        { const char* e = getenv("VAMBHIP_SCAN_LC"); h->scan_lc = !(e && e[0] == '0'); }
+        { const char* e = getenv("VAMBHIP_SCAN_LC"); h->scan_lc = e ? atoi(e) : 1; }
         h->scan_dbg = getenv("VAMBHIP_SCAN_DBG") ? atoi(getenv("VAMBHIP_SCAN_DBG")) : 0;
         h->results.alloc((size_t)kMaxMedoids * kResultWords);
         h->lists_dev.alloc((size_t)kMaxMedoids * kListCap);

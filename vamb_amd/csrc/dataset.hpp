@@ -1,0 +1,16 @@
+// dataset.hpp -- the feature matrix resident in HBM, shared by vae.hip (training / encoding) and prep.hip (the
+// device side of make_dataloader).
+#pragma once
+
+#include "common.hpp"
+
+constexpr int kDatasetColPad = 32;   // columns of X are padded to a multiple of this (the GEMM K-tiles)
+
+// The feature matrix [n][D_p] (zero padded; columns: S depths | 103 TNF | 1 total abundance) + weights [n], resident
+// in HBM.  Owned by a VAE handle (vh_vae_set_dataset) or shared between handles (vh_dataset_create / vh_prep_finish
+// + vh_vae_use_dataset): the dataset of one `vamb bin default` run is uploaded once however many models are trained on it.
+struct vh_dataset {
+    vh::DevBuf<float> X, w;
+    int64_t n = 0;
+    int S = 0, D_p = 0;
+};

@@ -12,6 +12,7 @@
 // bandwidth-bound kernel from vae_kernels.hpp.  One stream, no host synchronisation inside an epoch.
 #include "comm.hpp"
 #include "common.hpp"
+#include "dataset.hpp"
 
 #include <hip/hip_ext.h>
 #include "gemm.hpp"
@@ -32,7 +33,7 @@ using namespace vh;
 
 namespace {
 
-constexpr int kColPad = 32;
+constexpr int kColPad = kDatasetColPad;
 constexpr int kRowPad = 128;
 constexpr int kProbeRing = 512;
 constexpr int kSkinnySplits = 8;   // split-K slabs for the GEMMs whose output is only nlatent wide
@@ -190,15 +191,6 @@ GemmArgs base_args(bool bf16 = false) {
 }
 
 }  // namespace
-
-// The feature matrix [n][D_p] (zero padded) + weights [n], resident in HBM.  Owned by a VAE handle
-// (vh_vae_set_dataset) or shared between handles (vh_dataset_create + vh_vae_use_dataset): the dataset of one
-// `vamb bin default` run is uploaded once however many models are trained on it.
-struct vh_dataset {
-    DevBuf<float> X, w;
-    int64_t n = 0;
-    int S = 0, D_p = 0;
-};
 
 struct vh_vae {
     vh_vae_config cfg;

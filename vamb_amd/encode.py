@@ -54,6 +54,48 @@ def get_compute_dtype() -> str:
     return os.environ.get("VAMBHIP_PRECISION", _COMPUTE_DTYPE)
 
 
+# Where make_dataloader normalises the features: "host" (numpy, exactly the reference's statements), "device"
+# (the matrix passes as HIP kernels over ONE upload of the raw matrices, csrc/prep.hip; bit-identical tensors) or
+# "auto" (device when a GPU is visible and the inputs are C-contiguous).  Environment override: VAMBHIP_PREP.
+_PREP_MODE = "auto"
+
+
+def set_prep_mode(mode: str) -> None:
+    global _PREP_MODE
+    if mode not in ("auto", "host", "device"):
+        raise ValueError(f"prep mode must be 'auto', 'host' or 'device', not {mode!r}")
+    _PREP_MODE = mode
+
+
+def get_prep_mode() -> str:
+    import os
+
+    return os.environ.get("VAMBHIP_PREP", _PREP_MODE)
+
+
+def _pairwise_program(n: int) -> _np.ndarray:
+    """numpy's pairwise summation of n contiguous float32 values (numpy/_core/src/umath/loops_utils.h.src,
+    ``@TYPE@_pairwise_sum``) as a postfix program of int32 triples: (0, start, len) pushes the sum of a block of
+    at most 128 elements (eight interleaved accumulators, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the
+    len % 8 tail one by one; a plain loop below 8 elements), (1, 0, 0) adds the two topmost values.  Blocks larger
+    than 128 are split at n // 2 rounded down to a multiple of 8.  ``a.sum(axis=1)`` of a C-contiguous float32
+    matrix is 0 + this sum for every row (checked against numpy in tests/test_prep_host.py)."""
+    ops = []
+
+    def rec(start: int, length: int) -> None:
+        if length <= 128:
+            ops.append((0, start, length))
+            return
+        half = length // 2
+        half -= half % 8
+        rec(start, half)
+        rec(start + half, length - half)
+        ops.append((1, 0, 0))
+
+    rec(0, int(n))
+    return _np.asarray(ops, dtype=_np.int32).reshape(-1, 3)
+
+
 def _zscore_inplace(array: _np.ndarray, axis: Optional[int] = None) -> None:
     """In-place z-score with the reference's conventions (vambtools.py:250-288): population std,
     zero std replaced by 1."""
@@ -96,6 +138,9 @@ def make_dataloader(abundance: _np.ndarray, tnf: _np.ndarray, lengths: _np.ndarr
         raise ValueError("Lengths of abundance, TNF and lengths arrays must be the same")
     if not (abundance.dtype == tnf.dtype == _np.float32):
         raise ValueError("TNF and abundance must be Numpy arrays of dtype float32")
+    mode = get_prep_mode()
+    if mode != "host" and _device_prep_possible(abundance, tnf, required=(mode == "device")):
+        return _make_dataloader_device(abundance, tnf, lengths, batchsize)
     if not destroy:
         abundance = abundance.copy()
         tnf = tnf.copy()
@@ -120,11 +165,7 @@ def make_dataloader(abundance: _np.ndarray, tnf: _np.ndarray, lengths: _np.ndarr
     total_abundance.shape = (len(total_abundance), 1)
 
     # contig weights from lengths (122-126)
-    lengths = lengths.astype(_np.float32)
-    weights = _np.log(lengths).astype(_np.float32) - 5.0
-    weights[weights < 2.0] = 2.0
-    weights *= len(weights) / weights.sum()
-    weights.shape = (len(weights), 1)
+    weights = _weights_from_lengths(lengths)
 
     dataset = _TensorDataset(_torch.from_numpy(abundance), _torch.from_numpy(tnf),
                              _torch.from_numpy(total_abundance), _torch.from_numpy(weights))
@@ -132,6 +173,123 @@ def make_dataloader(abundance: _np.ndarray, tnf: _np.ndarray, lengths: _np.ndarr
     # so no worker processes are spawned.
     return _DataLoader(dataset=dataset, batch_size=batchsize, drop_last=(len(abundance) > batchsize),
                        shuffle=True, num_workers=0, pin_memory=False)
+
+
+def _weights_from_lengths(lengths: _np.ndarray) -> _np.ndarray:
+    """Contig weights (encode.py:122-126)."""
+    lengths = lengths.astype(_np.float32)
+    weights = _np.log(lengths).astype(_np.float32) - 5.0
+    weights[weights < 2.0] = 2.0
+    weights *= len(weights) / weights.sum()
+    weights.shape = (len(weights), 1)
+    return weights
+
+
+def _device_prep_possible(abundance: _np.ndarray, tnf: _np.ndarray, required: bool) -> bool:
+    why = None
+    if not (abundance.flags.c_contiguous and tnf.flags.c_contiguous):
+        why = "abundance / tnf are not C-contiguous (numpy's summation order depends on the layout)"
+    elif abundance.ndim != 2 or tnf.ndim != 2 or tnf.shape[1] != NTNF or abundance.shape[1] < 1 or len(abundance) < 1:
+        why = "unexpected matrix shapes"
+    else:
+        try:
+            if _lib.device_count() < 1:
+                why = "no HIP device visible"
+        except Exception as e:   # library not built / no driver
+            why = str(e)
+    if why is None:
+        return True
+    if required:
+        raise _lib.VambHipError(f"device feature preparation requested but not possible: {why}")
+    return False
+
+
+class _PreparedDataset(_torch.utils.data.Dataset):
+    """The TensorDataset of make_dataloader when the features were normalised on the device: the four tensors live
+    in HBM (``vh_dataset``); ``.tensors`` materialises host copies on first use (the reference's callers only hand
+    the loader to VAE.trainmodel / VAE.encode, which never need them)."""
+
+    def __init__(self, lib, handle, n: int, nsamples: int):
+        self._lib = lib
+        self.handle = handle
+        self.n = int(n)
+        self.nsamples = int(nsamples)
+        self._tensors = None
+
+    @property
+    def _vambhip_prepared(self):
+        return self
+
+    @property
+    def tensors(self):
+        if self._tensors is None:
+            d = _np.empty((self.n, self.nsamples), _np.float32)
+            t = _np.empty((self.n, NTNF), _np.float32)
+            a = _np.empty((self.n, 1), _np.float32)
+            w = _np.empty((self.n, 1), _np.float32)
+            _lib.check(self._lib.vh_dataset_download(self.handle, _lib.ptr(d), _lib.ptr(t), _lib.ptr(a), _lib.ptr(w)))
+            self._tensors = tuple(_torch.from_numpy(x) for x in (d, t, a, w))
+        return self._tensors
+
+    def __len__(self) -> int:
+        return self.n
+
+    def __getitem__(self, index):
+        return tuple(t[index] for t in self.tensors)
+
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                self._lib.vh_dataset_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _make_dataloader_device(abundance: _np.ndarray, tnf: _np.ndarray, lengths: _np.ndarray, batchsize: int) -> _DataLoader:
+    """make_dataloader (encode.py:98-126) with the O(N x columns) passes on the GPU.  The statements below are the
+    reference's, in its order; wherever it reduces or rescales a whole matrix the vector comes from / goes to a kernel
+    of csrc/prep.hip that reproduces numpy's float32 summation order, so the tensors are bit-identical to the host
+    path (tests/test_prep_gpu.py).  The raw arrays are uploaded once and never modified (``destroy`` is moot)."""
+    lib = _lib.load()
+    n, n_samples = abundance.shape
+    h = ctypes.c_void_p()
+    _lib.check(lib.vh_prep_create(n, n_samples, ctypes.byref(h)))
+    try:
+        _lib.check(lib.vh_prep_upload(h, _lib.ptr(abundance), _lib.ptr(tnf)))
+        # sample_depths_sum = abundance.sum(axis=0)
+        sample_depths_sum = _np.empty(n_samples, _np.float32)
+        _lib.check(lib.vh_prep_column_sums(h, 0, None, _lib.ptr(sample_depths_sum)))
+        if _np.any(sample_depths_sum == 0):
+            raise ValueError("One or more samples have zero depth in all sequences, so cannot be depth normalized")
+        scale = _np.ascontiguousarray(1_000_000 / sample_depths_sum, dtype=_np.float32)
+        # abundance *= scale; total_abundance = abundance.sum(axis=1); zero rows -> 1 / n_samples; abundance /= total
+        program = _np.ascontiguousarray(_pairwise_program(n_samples))
+        total_abundance = _np.empty(n, _np.float32)
+        _lib.check(lib.vh_prep_normalise_rows(h, _lib.ptr(scale), _lib.ptr(program), len(program),
+                                              ctypes.c_float(_np.float32(1 / n_samples)), _lib.ptr(total_abundance)))
+        total_abundance = _np.log(total_abundance.clip(min=0.001))
+        _zscore_inplace(total_abundance)
+        # zscore(tnf, axis=0): mean and std exactly as numpy's _mean / _var build them from the column sums
+        count = _np.intp(n)
+        mean = _np.empty(NTNF, _np.float32)
+        _lib.check(lib.vh_prep_column_sums(h, 1, None, _lib.ptr(mean)))
+        mean = _np.true_divide(mean, count, out=mean, casting="unsafe")
+        var = _np.empty(NTNF, _np.float32)
+        _lib.check(lib.vh_prep_column_sums(h, 1, _lib.ptr(mean), _lib.ptr(var)))
+        var = _np.true_divide(var, _np.maximum(count - 0, 0), out=var, casting="unsafe")
+        std = _np.sqrt(var, out=var)
+        std[std == 0.0] = 1
+        _lib.check(lib.vh_prep_zscore_tnf(h, _lib.ptr(mean), _lib.ptr(std)))
+        weights = _weights_from_lengths(lengths)
+        d = ctypes.c_void_p()
+        _lib.check(lib.vh_prep_finish(h, _lib.ptr(_np.ascontiguousarray(total_abundance)),
+                                      _lib.ptr(_np.ascontiguousarray(weights.reshape(-1))), ctypes.byref(d)))
+    finally:
+        lib.vh_prep_destroy(h)
+    dataset = _PreparedDataset(lib, d, n, n_samples)
+    return _DataLoader(dataset=dataset, batch_size=batchsize, drop_last=(n > batchsize), shuffle=True, num_workers=0,
+                       pin_memory=False)
 
 
 class _Config(ctypes.Structure):
@@ -389,6 +547,18 @@ class VAE:
     def _ensure_dataset(self, data_loader) -> int:
         """Make the loader's four tensors resident in HBM (once per loader: the device copy is cached on the
         dataset object and shared by every VAE trained / encoded on it)."""
+        prepared = getattr(data_loader.dataset, "_vambhip_prepared", None)
+        if prepared is not None:     # normalised on the device by make_dataloader: already resident
+            if prepared.nsamples != self.nsamples:
+                raise ValueError("dataset tensors do not match this VAE (nsamples / 103 TNF / 1 / 1 columns)")
+            key = ("prepared", id(prepared))
+            if self._dataset_ref is None or self._dataset_ref() is not prepared or self._dataset_key != key:
+                _lib.check(self._lib.vh_vae_use_dataset(self._h, prepared.handle))
+                self._device_dataset = prepared
+                self._dataset_key = key
+                self._dataset_ref = weakref.ref(prepared)
+                self._n_rows = prepared.n
+            return prepared.n
         tensors = data_loader.dataset.tensors
         if len(tensors) != 4:
             raise ValueError("expected a DataLoader made by make_dataloader (4 tensors)")
@@ -534,7 +704,11 @@ class VAE:
             if max(batchsteps, default=0) >= nepochs:
                 raise ValueError("Max batchsteps must not equal or exceed nepochs")
             batchsteps_set = set(batchsteps)
-        ncontigs, nsamples = dataloader.dataset.tensors[0].shape
+        prepared = getattr(dataloader.dataset, "_vambhip_prepared", None)
+        if prepared is not None:
+            ncontigs, nsamples = prepared.n, prepared.nsamples
+        else:
+            ncontigs, nsamples = dataloader.dataset.tensors[0].shape
         logger.info("\tNetwork properties:")
         logger.info(f"\t    CUDA: {self.usecuda}")
         logger.info(f"\t    Alpha: {self.alpha}")
