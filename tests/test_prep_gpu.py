@@ -31,8 +31,13 @@ def test_device_prep_matches_reference_tensors(name):
     host, dev, _ = _both(ab, tnf, lens, 16)
     for h, d, key in zip(host, dev, ("depths", "tnf", "total_abundance", "weights")):
         assert d.dtype == np.float32 and d.shape == g[key].shape
-        assert np.array_equal(d, g[key]), key
-        assert np.array_equal(h, d), key
+        assert np.array_equal(h, d), key          # device == host numpy path on this machine, bit for bit
+        if key in ("depths", "tnf"):
+            assert np.array_equal(d, g[key]), key
+        else:
+            # total_abundance and weights go through numpy's float32 log, whose SIMD kernel (AVX512F / AVX2 dispatch)
+            # differs in the last ulp between the CPU the goldens were made on and this host; everything else is exact
+            assert np.allclose(d, g[key], rtol=2e-6, atol=2e-6), key
 
 
 @pytest.mark.parametrize("n,S", [(1, 1), (2, 3), (33, 7), (100, 8), (513, 9), (1000, 50), (4097, 129), (3000, 200),

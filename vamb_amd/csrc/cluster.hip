@@ -206,8 +206,8 @@ __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn
 // LC: latent width known at compile time (0 = runtime L4).  With LC every column load of a lane's rows is issued
 // before the first fmaf, so a wavefront pays one memory round trip per row block instead of L4/4 dependent ones:
 // the matrices the generator scans late in a sweep (10^5 rows, ~1 workgroup per CU) are latency-bound.
-// JG: (unrolled loads only) medoids per accumulator group, see the kernel body.
-template <int KM, int RPT, int LC, int JG = KM>
+// PIPE: (runtime-width loop, many medoids) software pipeline, see the kernel body.
+template <int KM, int RPT, int LC, int PIPE = 0>
 __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
                                                           const float* __restrict__ lengths,
                                                           const uint8_t* __restrict__ kept, int64_t n,
@@ -230,9 +230,11 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
     for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
     for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
     // query vectors: explicit (row-sharded execution) or row medoid.row[j] of the resident matrix
-    for (int i = tid; i < KM * L4; i += kBlock) {
-        const int j = i / L4, c = i - j * L4;
-        q_s[i] = q_ext ? q_ext[i] : Mt[(int64_t)c * ld + medoid.row[j]];
+    if constexpr (PIPE == 0) {
+        for (int i = tid; i < KM * L4; i += kBlock) {
+            const int j = i / L4, c = i - j * L4;
+            q_s[i] = q_ext ? q_ext[i] : Mt[(int64_t)c * ld + medoid.row[j]];
+        }
     }
     __syncthreads();
 
@@ -297,32 +299,70 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                 load_rows<RPT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mt + (int64_t)c * ld) + boff), x[c]);
             load_rows<RPT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(lengths) + boff), len);
             __builtin_amdgcn_sched_barrier(0);   // every load is issued before the first fmaf ...
-            // The rows stay in registers while the medoids are taken in groups of JG: JG x RPT accumulators live at a
-            // time instead of KM x RPT, so the many-medoid variants keep >= 3 wavefronts per SIMD with all their column
-            // loads in flight (they were bound by memory-level parallelism: 1.5 TB/s at 2 M x 32, k = 25).
+            float acc[KM][RPT];
 #pragma unroll
-            for (int j0 = 0; j0 < KM; j0 += JG) {
-                float acc[JG][RPT];
+            for (int j = 0; j < KM; ++j)
 #pragma unroll
-                for (int j = 0; j < JG; ++j)
+                for (int r = 0; r < RPT; ++r) acc[j][r] = 0.0f;
 #pragma unroll
-                    for (int r = 0; r < RPT; ++r) acc[j][r] = 0.0f;
+            for (int c = 0; c < LC; c += 4) {
 #pragma unroll
-                for (int c = 0; c < LC; c += 4) {
+                for (int j = 0; j < KM; ++j) {
+                    const float4 qq = *reinterpret_cast<const float4*>(q_s + j * LC + c);
+                    const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
 #pragma unroll
-                    for (int j = 0; j < JG; ++j) {
-                        const float4 qq = *reinterpret_cast<const float4*>(q_s + (j0 + j) * LC + c);
-                        const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
+                    for (int i = 0; i < 4; ++i)   // columns ascending: the defined fmaf order
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)   // columns ascending: the defined fmaf order
-#pragma unroll
-                            for (int r = 0; r < RPT; ++r) acc[j][r] = __builtin_fmaf(x[c + i][r], qv[i], acc[j][r]);
-                        // ... and the query reads are not hoisted across the whole unrolled body (register pressure)
-                        if ((j & 3) == 3 || j == JG - 1) __builtin_amdgcn_sched_barrier(0);
-                    }
+                        for (int r = 0; r < RPT; ++r) acc[j][r] = __builtin_fmaf(x[c + i][r], qv[i], acc[j][r]);
+                    // ... and the query reads are not hoisted across the whole unrolled body (register pressure)
+                    if ((j & 3) == 3 || j == KM - 1) __builtin_amdgcn_sched_barrier(0);
                 }
-                evaluate(acc, j0);
             }
+            evaluate(acc, 0);
+        } else if constexpr (PIPE != 0) {
+            // Many medoids per pass.  Measured (profiles/r02b_scan_bench_lc*.json): 45 us + 4 us per medoid at 2 M x 32
+            // whether the column loads are issued up front or four at a time -- neither HBM nor the loads bound it.  The
+            // ISA shows why: each medoid's query quad was a broadcast ds_read_b128 issued immediately before the 8 fmaf
+            // that consume it, so a wavefront (2 per SIMD at ~190 VGPRs) sat out one LDS round trip per 2 medoids.  The
+            // queries are wave-uniform: here they come from global memory through the scalar cache (s_load_dwordx4 into
+            // SGPRs, batched by the compiler) and enter the fmaf as scalar operands -- no LDS traffic, no VGPRs -- and
+            // the rows of the column quad after the next are requested before the chains of the current one start.
+            float acc[KM][RPT];
+#pragma unroll
+            for (int j = 0; j < KM; ++j)
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) acc[j][r] = 0.0f;
+            float xc[4][RPT], xn[4][RPT], xnn[4][RPT];
+            auto load_x = [&](float (&x)[4][RPT], int c) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) load_rows<RPT>(col + (int64_t)(c + i) * ld, x[i]);
+            };
+            load_x(xc, 0);
+            if (4 < L4) load_x(xn, 4);
+            load_rows<RPT>(lengths + base, len);
+            for (int c = 0; c < L4; c += 4) {
+                if (c + 8 < L4) load_x(xnn, c + 8);
+                // q_ext is QUAD-MAJOR here (clu_gather_quads_kernel): [L4 / 4][KM][4], so the KM quads of this column
+                // quad are 16 KM contiguous bytes behind one scalar base
+                const float4* qquad = reinterpret_cast<const float4*>(q_ext) + (c >> 2) * KM;
+#pragma unroll
+                for (int j = 0; j < KM; ++j) {
+                    const float4 qq = qquad[j];   // uniform address: s_load_dwordx4/x8/x16
+                    const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)   // columns ascending: the defined fmaf order
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) acc[j][r] = __builtin_fmaf(xc[i][r], qv[i], acc[j][r]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        xc[i][r] = xn[i][r];
+                        xn[i][r] = xnn[i][r];
+                    }
+            }
+            evaluate(acc, 0);
         } else {
             float acc[KM][RPT];
 #pragma unroll
@@ -367,6 +407,18 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
         const unsigned int start = start_s;
         if (start + cnt <= (unsigned int)kListCap && tid < (int)cnt) lists[j * kListCap + start + tid] = llist_s[j * kLocalCap + tid];
         __syncthreads();
+    }
+}
+
+// Query vectors of a many-medoid pass in quad-major order [L4 / 4][km][4] for the scalar loads of the pipelined scan
+// kernel: from the resident rows medoid.row[j], or from explicit vectors q_src[km][L4] (row-sharded execution).
+__global__ __launch_bounds__(kBlock) void clu_gather_quads_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
+                                                                  const float* __restrict__ q_src, const MedoidRows medoid,
+                                                                  int km, float* __restrict__ qp) {
+    for (int i = threadIdx.x; i < km * L4; i += kBlock) {
+        const int j = i / L4, c = i - j * L4;
+        const float v = q_src ? q_src[i] : Mt[(int64_t)c * ld + medoid.row[j]];
+        qp[((c >> 2) * km + j) * 4 + (c & 3)] = v;
     }
 }
 
@@ -626,7 +678,7 @@ struct vh_clu {
     int64_t n_live = 0;
     int64_t ld = 0;       // leading dimension (>= n_rows, multiple of 1024)
     hipStream_t stream = nullptr;
-    DevBuf<float> Mt, Mt_alt, lengths, lengths_alt, q;
+    DevBuf<float> Mt, Mt_alt, lengths, lengths_alt, q, qp;   // qp: quad-major queries of a many-medoid pass
     DevBuf<uint8_t> kept;
     DevBuf<unsigned long long> results;
     // host-mapped (pinned, coherent) publication buffers written by the scan kernel itself
@@ -642,9 +694,7 @@ struct vh_clu {
     int scan_dbg = 0;             // VAMBHIP_SCAN_DBG: timing experiments only (wrong results)
     int max_k = kMaxMedoids;      // medoids per pass the LDS can hold for this latent width (query vectors are staged there)
     int scan_lc = 1;              // column-loop variant (VAMBHIP_SCAN_LC, A/B measurements): 0 runtime-width loop everywhere,
-                                  // 1 unrolled loads up to 8 medoids, 2 unrolled loads for every medoid count,
-                                  // 3 / 4 = 2 with the medoids of a pass taken in 2 / 4 accumulator groups (24, 32: 2 / 4;
-                                  // 12, 16: 1 / 2)
+                                  // 1 unrolled loads up to 8 medoids + pipelined query / row fetches from 12 medoids
     bool small_rpt = true;        // VAMBHIP_SCAN_WIDE=1 disables the narrow variant (A/B measurements)
     uint64_t scan_seq = 0;        // number of scans issued; scan s wrote ring slot s % kListRing
     int last_k = 0;
@@ -705,19 +755,19 @@ size_t scan_smem_bytes(int km, int L4) {
            (size_t)km * 4 * (1 + kLocalCap);
 }
 
-template <int KM, int RPT, int LC, int JG = KM>
+template <int KM, int RPT, int LC, int PIPE = 0>
 void launch_scan_lc(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     const size_t smem = scan_smem_bytes(KM, h->L4);
     static bool attr_set = false;
     if (!attr_set) {   // wide latent spaces need more than the default 64 KiB of dynamic LDS (query vectors live there)
-        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_kernel<KM, RPT, LC, JG>),
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_kernel<KM, RPT, LC, PIPE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScanLdsBudget));
         attr_set = true;
     }
     VH_REQUIRE(smem <= kScanLdsBudget, "internal: %d medoids x %d latent columns do not fit the LDS", KM, h->L4);
     const int64_t blocks = ceil_div(h->ld, (int64_t)kBlock * RPT);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
-    hipLaunchKernelGGL((clu_scan_kernel<KM, RPT, LC, JG>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
+    hipLaunchKernelGGL((clu_scan_kernel<KM, RPT, LC, PIPE>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
                        h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_dev.p, h->scan_dbg);
 }
 
@@ -731,11 +781,13 @@ void launch_scan_rpt(vh_clu* h, const MedoidRows& med, const float* q_ext) {
                 return;
             }
         }
-    } else if constexpr (RPT <= 2) {
-        if (h->L4 == 32 && h->ld < ((int64_t)1 << 30)) {
-            if (h->scan_lc == 2) { launch_scan_lc<KM, RPT, 32>(h, med, q_ext); return; }
-            if (h->scan_lc == 3) { launch_scan_lc<KM, RPT, 32, (KM >= 24 ? KM / 2 : KM)>(h, med, q_ext); return; }
-            if (h->scan_lc == 4) { launch_scan_lc<KM, RPT, 32, (KM >= 24 ? KM / 4 : KM / 2)>(h, med, q_ext); return; }
+    } else {
+        if (h->scan_lc >= 1) {
+            hipLaunchKernelGGL(clu_gather_quads_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->Mt.p, h->ld, h->L4, q_ext, med,
+                               KM, h->qp.p);
+            VH_HIP(hipGetLastError());
+            launch_scan_lc<KM, RPT, 0, 1>(h, med, h->qp.p);
+            return;
         }
     }
     launch_scan_lc<KM, RPT, 0>(h, med, q_ext);
@@ -810,6 +862,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->lengths.alloc((size_t)h->ld);
         h->kept.alloc((size_t)h->ld);
         h->q.alloc((size_t)kMaxMedoids * h->L4);
+        h->qp.alloc((size_t)kMaxMedoids * h->L4);
         {   // the reference has no limit on the latent width; here the scan stages up to 32 query vectors in LDS, so wide
             // latent spaces take fewer medoids per pass (L = 4096: 4) -- never a launch failure in the middle of a sweep
             static const int buckets[] = {32, 24, 16, 12, 8, 4, 2, 1};
