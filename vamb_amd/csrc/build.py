@@ -25,7 +25,10 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-cor
 SOURCES = {
     # -amdgpu-atomic-optimizer-strategy=None: the scan kernel's LDS atomics sit on a rare, sparsely populated path;
     # the wave-aggregation loops the optimizer wraps around each of them cost more than the few atomics they save
-    "cluster.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
+    # -fno-slp-vectorize: the SLP vectoriser pairs the fmaf chains of two rows into v_pk_fma_f32, which gfx950 issues at
+    # a quarter of the v_fma_f32 rate per lane-op (measured: 17 cycles per v_pk_fma_f32 in the scan kernel); plain
+    # v_fmac_f32 with a scalar query operand runs the chains at the VALU's 2 cycles per wavefront instruction
+    "cluster.hip": ["-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "vae.hip": [],
     # prep.hip reproduces numpy's float32 results bit for bit: no fused multiply-add
     "prep.hip": ["-ffp-contract=off"],

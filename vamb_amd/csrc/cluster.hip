@@ -345,14 +345,26 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                 // q_ext is QUAD-MAJOR here (clu_gather_quads_kernel): [L4 / 4][KM][4], so the KM quads of this column
                 // quad are 16 KM contiguous bytes behind one scalar base
                 const float4* qquad = reinterpret_cast<const float4*>(q_ext) + (c >> 2) * KM;
+                // Batches of G medoids, column-major inside a batch: consecutive fmaf belong to DIFFERENT chains (a
+                // chain's next link is G instructions away).  Medoid-major order put the 4 links of a quad back to
+                // back and the VALU spent ~4 issue slots per fmaf waiting for its own result (measured: 17 cycles per
+                // v_pk_fma_f32 at 2 wavefronts per SIMD).  Every chain still sees its columns in ascending order.
+                constexpr int G = (KM % 8 == 0) ? 8 : 4;
 #pragma unroll
-                for (int j = 0; j < KM; ++j) {
-                    const float4 qq = qquad[j];   // uniform address: s_load_dwordx4/x8/x16
-                    const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
+                for (int g = 0; g < KM / G; ++g) {
+                    float4 qb[G];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)   // columns ascending: the defined fmaf order
+                    for (int j = 0; j < G; ++j) qb[j] = qquad[g * G + j];   // uniform address: s_load_dwordx16
 #pragma unroll
-                        for (int r = 0; r < RPT; ++r) acc[j][r] = __builtin_fmaf(xc[i][r], qv[i], acc[j][r]);
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            const float qv = i == 0 ? qb[j].x : (i == 1 ? qb[j].y : (i == 2 ? qb[j].z : qb[j].w));
+#pragma unroll
+                            for (int r = 0; r < RPT; ++r)
+                                acc[g * G + j][r] = __builtin_fmaf(xc[i][r], qv, acc[g * G + j][r]);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
