@@ -174,14 +174,18 @@ constexpr int kHitCap = 256;      // queued hits per wavefront (drained when few
 
 __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn, int lane,
                                            unsigned long long* __restrict__ acc_s, unsigned int* __restrict__ lcnt_s,
-                                           int32_t* __restrict__ llist_s, const float* __restrict__ edges_s, int dbg) {
+                                           int32_t* __restrict__ llist_s, const float* __restrict__ edges_s,
+                                           const int32_t* __restrict__ med_s, int dbg) {
     const float radius = 0.05f;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int e = lane; e < qn; e += 64) {
         const float4 v = hq[e];
-        const float d = v.x, len = v.y;
+        const float len = v.y;
         const int32_t row = __float_as_int(v.z);
         const int j = __float_as_int(v.w);
+        // the distance of a medoid to itself is 0 by definition (cluster.py:619), not 0.5 - <q, q>: decided here, once
+        // per queued pair, instead of once per (row, medoid) pair in the scan loop
+        const float d = row == med_s[j] ? 0.0f : v.x;
         // rows inside the medoid radius: exact integer accumulation and the medoid's candidate list
         // (sample_medoid's `cluster`, cluster.py:621-626)
         if (d <= radius) {
@@ -222,10 +226,12 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
     float* q_s = edges_s + 64;                                                          // [KM][L4]
     unsigned int* lcnt_s = reinterpret_cast<unsigned int*>(q_s + KM * L4);              // [KM]
     int32_t* llist_s = reinterpret_cast<int32_t*>(lcnt_s + KM);                         // [KM][kLocalCap]
+    int32_t* med_s = llist_s + KM * kLocalCap;                                          // [KM] medoid rows (-1: none)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     float4* hq = hq_s + (tid >> 6) * kHitCap;
+    for (int i = tid; i < KM; i += kBlock) med_s[i] = (int32_t)medoid.row[i];
     for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
     for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
     for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
@@ -254,9 +260,20 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
         const float* col = Mt + base;
         (void)col;
         float len[RPT];
-        // evaluation of the finished dot products of medoids j0 .. j0 + NJ - 1 (compare, queue the rare hits)
+        // Liveness (and the timing switch) folded into a per-row threshold: a pair is of interest iff d <= thr[r]
+        // (beyond the last histogram edge, 0.3 > radius, there is nothing to record)
+        float thr[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) thr[r] = (live[r] != 0 && !(dbg & 1)) ? edge_hi : -__builtin_inff();
+        // Evaluation of the finished dot products of medoids j0 .. j0 + NJ - 1.  Pairs of interest are rare (a medoid's
+        // neighbourhood is a few hundred of 10^6 rows), so the common path is kept to two VALU instructions per pair --
+        // d = 0.5 - dot and one compare whose lane mask is OR-ed on the scalar unit -- and ONE branch per group of four
+        // medoids; the previous form (64-bit self-row compare, three conditions and a branch per pair) cost more than
+        // the fmaf chains themselves (measured, no pair of interest at all: 3.4 us per medoid at 2 M x 32 against 0.8 us
+        // of fmaf, profiles/r02d_scan_bench_dbg1.json).
         auto evaluate = [&](auto& acc, int j0) {
             constexpr int NJ = (int)(sizeof(acc) / sizeof(acc[0]));
+            constexpr int GE = NJ % 4 == 0 ? 4 : (NJ % 2 == 0 ? 2 : 1);
             // every dot product is finished here: without the pin the compiler sinks each medoid's fmaf chain into
             // the branchy evaluation below and keeps the query registers of all medoids alive across it
 #pragma unroll
@@ -264,26 +281,31 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
 #pragma unroll
                 for (int r = 0; r < RPT; ++r) asm volatile("" : "+v"(acc[j][r]));
 #pragma unroll
-            for (int jj = 0; jj < NJ; ++jj) {
-                const int j = j0 + jj;
-                const long long med = medoid.row[j];
+            for (int g0 = 0; g0 < NJ; g0 += GE) {
+                unsigned long long any = 0ull;
 #pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    float d = 0.5f - acc[jj][r];
-                    if (base + r == med) d = 0.0f;
-                    // beyond the last histogram edge (0.3 > radius): nothing to record
-                    const bool hit = live[r] != 0 && d <= edge_hi && !(dbg & 1);
-                    const unsigned long long m = __ballot(hit);
-                    if (m != 0ull) {
-                        if (hit) {
-                            const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32),
-                                                                                __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                            hq[pos] = make_float4(d, len[r], __int_as_float((int32_t)(base + r)), __int_as_float(j));
-                        }
-                        qn += __popcll(m);
-                        if (qn > kHitCap - 64) {
-                            drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, dbg);
-                            qn = 0;
+                for (int jj = g0; jj < g0 + GE; ++jj)
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) any |= __builtin_amdgcn_ballot_w64((0.5f - acc[jj][r]) <= thr[r]);
+                if (any == 0ull) continue;
+#pragma unroll
+                for (int jj = g0; jj < g0 + GE; ++jj) {
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        const float d = 0.5f - acc[jj][r];
+                        const bool hit = d <= thr[r];
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                        if (m != 0ull) {
+                            if (hit) {
+                                const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32),
+                                                                                    __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                                hq[pos] = make_float4(d, len[r], __int_as_float((int32_t)(base + r)), __int_as_float(j0 + jj));
+                            }
+                            qn += __popcll(m);
+                            if (qn > kHitCap - 64) {
+                                drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg);
+                                qn = 0;
+                            }
                         }
                     }
                 }
@@ -399,7 +421,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
             evaluate(acc, 0);
         }
     }
-    drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, dbg);
+    drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg);
 
     __syncthreads();
     for (int i = tid; i < KM * kResultWords; i += kBlock) {
@@ -764,7 +786,7 @@ constexpr size_t kScanLdsBudget = 160 * 1024 - 512;   // one workgroup may use (
 
 size_t scan_smem_bytes(int km, int L4) {
     return (size_t)(kBlock / 64) * kHitCap * 16 + (size_t)km * kResultWords * 8 + 64 * 4 + (size_t)km * L4 * 4 +
-           (size_t)km * 4 * (1 + kLocalCap);
+           (size_t)km * 4 * (2 + kLocalCap);
 }
 
 template <int KM, int RPT, int LC, int PIPE = 0>
