@@ -8,7 +8,7 @@ for r in rows:
     if 'gemm_f32' in n:
         n = 'gemm' + n[n.index('<'):n.index('>') + 1].replace(' ', '')
     else:
-        n = n.split('(')[0].replace('void ', '').replace('vh::', '')
+        n = n.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('vh::', '')
     agg[n][r['Counter_Name']].append(float(r['Counter_Value']))
 for n in sorted(agg):
     if len(sys.argv) > 2 and sys.argv[2] not in n:

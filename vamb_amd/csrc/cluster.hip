@@ -207,6 +207,32 @@ __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// End of a scan workgroup: non-zero LDS accumulators to the pass accumulators (exact integer atomics), then the
+// block-local candidate lists: one cursor atomic per (block, medoid with hits).  A block that ran out of local room
+// poisons the cursor; the host then sees cursor != n_within and runs a select pass.
+template <int KM>
+__device__ __forceinline__ void scan_flush(int tid, const unsigned long long* __restrict__ acc_s,
+                                           const unsigned int* __restrict__ lcnt_s, const int32_t* __restrict__ llist_s,
+                                           unsigned long long* __restrict__ results, int32_t* __restrict__ lists) {
+    __shared__ unsigned int start_s;
+    __syncthreads();
+    for (int i = tid; i < KM * kResultWords; i += kBlock) {
+        const unsigned long long v = acc_s[i];
+        if (v != 0ull) atomicAdd(&results[i], v);
+    }
+    for (int j = 0; j < KM; ++j) {
+        const unsigned int cnt = lcnt_s[j];
+        if (cnt == 0u) continue;
+        unsigned int* cursor = reinterpret_cast<unsigned int*>(&results[j * kResultWords + 3 + VH_NBINS]);
+        if (tid == 0) start_s = cnt > (unsigned int)kLocalCap ? atomicOr(cursor, 0x80000000u) | 0x80000000u
+                                                              : atomicAdd(cursor, cnt);
+        __syncthreads();
+        const unsigned int start = start_s;
+        if (start + cnt <= (unsigned int)kListCap && tid < (int)cnt) lists[j * kListCap + start + tid] = llist_s[j * kLocalCap + tid];
+        __syncthreads();
+    }
+}
+
 // LC: latent width known at compile time (0 = runtime L4).  With LC every column load of a lane's rows is issued
 // before the first fmaf, so a wavefront pays one memory round trip per row block instead of L4/4 dependent ones:
 // the matrices the generator scans late in a sweep (10^5 rows, ~1 workgroup per CU) are latency-bound.
@@ -423,25 +449,161 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
     }
     drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg);
 
+    scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6m: passes with more than 8 medoids on the matrix pipe.  The VALU issues one wavefront fmaf per 4 cycles (PMC of the
+// many-medoid VALU kernel, profiles/r02f_pmc_scan_*.txt: SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU quad-cycles, VALU ~70 % busy at
+// 2 wavefronts per SIMD, 114 us for 32 medoids over 2 M x 32 with no pair of interest at all), i.e. 16 fmaf lanes per clock
+// and SIMD; v_mfma_f32_32x32x2_f32 retires 32 exact fp32 multiply-adds per clock and SIMD on a pipe of its own.  One chain of
+// L4 / 2 such MFMAs is the [32 rows] x [32 medoids] block of dot products, each accumulated as the k-ordered fmaf chain from
+// +0 the VALU kernel runs (CDNA4 guide: bitwise equal), so accumulators, lists and cluster streams stay bit-identical.
+//   A operand: lane l supplies x[row base + (l & 31)][column 2 s + (l >> 5)]   (two coalesced 128-byte segments of Mt)
+//   B operand: lane l supplies q[medoid l & 31][column 2 s + (l >> 5)]         (NK registers, loaded once per kernel)
+//   D: lane l holds medoid j = l & 31 against rows base + (reg & 3) + 8 (reg >> 2) + 4 (l >> 5), reg = 0..15
+// A wavefront owns 32-row tiles (grid-stride) and keeps the loads of the next two tiles in flight.  The common path after
+// the chain is ONE compare per pair: d = 0.5 - dot <= 0.3 (the last histogram edge) iff dot >= a threshold found once per
+// kernel (float subtraction is monotonic), OR-ed over the 16 registers on the scalar unit; liveness, lengths and the
+// self-distance fix-up are looked at only for the rare pairs that pass, which go through the same per-wavefront hit queue
+// and drain as in the VALU kernel.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float scan_f32x16;
+
+template <int NK>
+struct ScanTile {
+    float xa[NK];
+    uint4 k0, k1;       // live flags of the 32 rows (every lane loads the same 32 bytes)
+};
+
+template <int NK>
+__device__ __forceinline__ void scan_tile_load(ScanTile<NK>& t, const float* __restrict__ Mt, int64_t ld, int nk,
+                                               const uint8_t* __restrict__ kept, int64_t base, int j, int h) {
+    t.k0 = *reinterpret_cast<const uint4*>(kept + base);
+    t.k1 = *reinterpret_cast<const uint4*>(kept + base + 16);
+    // scalar column-pair base + one 32-bit byte offset per lane (h ld + j < 2^30, checked by the dispatcher; the tile base is wave-uniform): the
+    // NK loads of a tile share one address register
+    const uint32_t off = (uint32_t)((int64_t)h * ld + j) * 4u;
+    // column pairs beyond the latent width re-read the last pair: their query operand is zero, so they add exactly nothing
+    // (finite x * 0 = +-0), and the loop stays free of branches
+#pragma unroll
+    for (int s = 0; s < NK; ++s)
+        t.xa[s] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mt + (int64_t)(2 * min(s, nk - 1)) * ld + base) + off);
+}
+
+template <int NK>
+__global__ __launch_bounds__(kBlock) void clu_scan_mfma_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
+                                                               const float* __restrict__ lengths,
+                                                               const uint8_t* __restrict__ kept,
+                                                               const float* __restrict__ q_ext, const MedoidRows medoid,
+                                                               int k_real, unsigned long long* __restrict__ results,
+                                                               int32_t* __restrict__ lists, int dbg) {
+    constexpr int KM = kMaxMedoids;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* hq_s = reinterpret_cast<float4*>(smem_raw);                                  // [kBlock/64][kHitCap]
+    unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(hq_s + (kBlock / 64) * kHitCap);   // [KM][kResultWords]
+    float* edges_s = reinterpret_cast<float*>(acc_s + KM * kResultWords);               // [64]
+    unsigned int* lcnt_s = reinterpret_cast<unsigned int*>(edges_s + 64);               // [KM]
+    int32_t* llist_s = reinterpret_cast<int32_t*>(lcnt_s + KM);                         // [KM][kLocalCap]
+    int32_t* med_s = llist_s + KM * kLocalCap;                                          // [KM]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: tile bases and live flags go scalar
+    float4* hq = hq_s + wave * kHitCap;
+    for (int i = tid; i < KM; i += kBlock) med_s[i] = (int32_t)medoid.row[i];
+    for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
+    for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
+    for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
+    const int j = lane & 31, h = lane >> 5;
+    const int nk = L4 >> 1;
+    const long long my_med = medoid.row[j];
+    float qb[NK];
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+        const int k = 2 * s + h;
+        qb[s] = 0.0f;   // unused medoid slots (j >= k_real, row -1) keep a zero query: dot = 0, never of interest
+        if (s < nk && j < k_real) qb[s] = q_ext ? q_ext[j * L4 + k] : Mt[(int64_t)k * ld + my_med];
+    }
     __syncthreads();
-    for (int i = tid; i < KM * kResultWords; i += kBlock) {
-        const unsigned long long v = acc_s[i];
-        if (v != 0ull) atomicAdd(&results[i], v);
+    const float edge_hi = edges_s[VH_NBINS];
+    // smallest dot product whose distance 0.5f - dot (float32, round to nearest) is <= the last histogram edge
+    float dot_min = 0.5f - edge_hi;
+    while (0.5f - __uint_as_float(__float_as_uint(dot_min) - 1u) <= edge_hi) dot_min = __uint_as_float(__float_as_uint(dot_min) - 1u);
+    while (!(0.5f - dot_min <= edge_hi)) dot_min = __uint_as_float(__float_as_uint(dot_min) + 1u);
+    if (dbg & 1) dot_min = __builtin_inff();   // timing experiment: no pair of interest
+    int qn = 0;   // hits queued by this wavefront (uniform)
+
+    const int64_t ntiles = ld >> 5;
+    const int64_t stride = (int64_t)gridDim.x * (kBlock / 64);
+    int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    // DEPTH tile buffers: the tile being multiplied plus DEPTH - 1 in flight; a buffer is reloaded (tile + DEPTH strides)
+    // as soon as its MFMA chain has been issued, before the chain's result is looked at
+    constexpr int DEPTH = NK <= 16 ? 3 : 2;
+    ScanTile<NK> tl[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+        tl[u].k0 = tl[u].k1 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int q = 0; q < NK; ++q) tl[u].xa[q] = 0.0f;
+        if (tile + u * stride < ntiles) scan_tile_load<NK>(tl[u], Mt, ld, nk, kept, (tile + u * stride) << 5, j, h);
     }
-    // flush the block-local candidate lists: one cursor atomic per (block, medoid with hits).  A block that
-    // ran out of local room poisons the cursor; the host then sees cursor != n_within and runs a select pass.
-    for (int j = 0; j < KM; ++j) {
-        const unsigned int cnt = lcnt_s[j];
-        if (cnt == 0u) continue;
-        unsigned int* cursor = reinterpret_cast<unsigned int*>(&results[j * kResultWords + 3 + VH_NBINS]);
-        __shared__ unsigned int start_s;
-        if (tid == 0) start_s = cnt > (unsigned int)kLocalCap ? atomicOr(cursor, 0x80000000u) | 0x80000000u
-                                                              : atomicAdd(cursor, cnt);
-        __syncthreads();
-        const unsigned int start = start_s;
-        if (start + cnt <= (unsigned int)kListCap && tid < (int)cnt) lists[j * kListCap + start + tid] = llist_s[j * kLocalCap + tid];
-        __syncthreads();
+    auto step = [&](ScanTile<NK>& t) {
+        const int64_t base = tile << 5;
+        const uint32_t kw[8] = {t.k0.x, t.k0.y, t.k0.z, t.k0.w, t.k1.x, t.k1.y, t.k1.z, t.k1.w};
+        const uint32_t any_live = (kw[0] | kw[1]) | (kw[2] | kw[3]) | (kw[4] | kw[5]) | (kw[6] | kw[7]);
+        // a tile of already emitted rows (uniform: every lane holds the same flags) costs no matrix-pipe time
+        const bool work = __builtin_amdgcn_readfirstlane(any_live) != 0u;
+        scan_f32x16 acc;
+        if (work) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            // column pairs beyond the latent width hold zeros on both sides: fmaf(0, 0, acc) == acc, bit for bit
+#pragma unroll
+            for (int q = 0; q < NK; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.xa[q], qb[q], acc, 0, 0, 0);
+        }
+        if (tile + DEPTH * stride < ntiles) scan_tile_load<NK>(t, Mt, ld, nk, kept, (tile + DEPTH * stride) << 5, j, h);
+        if (!work) return;
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) any |= __builtin_amdgcn_ballot_w64(acc[r] >= dot_min);
+        if (any == 0ull) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // live flags of this half-wave's rows 8 q + 4 h .. + 3 = dword 2 q + h of the 8 flag dwords
+            const unsigned long long pair = ((unsigned long long)kw[2 * q + 1] << 32) | kw[2 * q];
+            const uint32_t live4 = (uint32_t)(pair >> (32 * h));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool hit = acc[4 * q + e] >= dot_min && ((live4 >> (8 * e)) & 0xFFu) != 0u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                if (m != 0ull) {
+                    if (hit) {
+                        const int64_t row = base + 8 * q + 4 * h + e;
+                        const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                        hq[pos] = make_float4(0.5f - acc[4 * q + e], lengths[row], __int_as_float((int32_t)row),
+                                              __int_as_float(j));
+                    }
+                    qn += __popcll(m);
+                    if (qn > kHitCap - 64) {
+                        drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg);
+                        qn = 0;
+                    }
+                }
+            }
+        }
+    };
+    while (tile < ntiles) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            if (tile < ntiles) {
+                step(tl[u]);
+                tile += stride;
+            }
+        }
     }
+    drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg);
+    scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists);
 }
 
 // Query vectors of a many-medoid pass in quad-major order [L4 / 4][km][4] for the scalar loads of the pipelined scan
@@ -727,6 +889,9 @@ struct vh_clu {
     unsigned long long* flag() { return host_results + (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS); }
     int scan_dbg = 0;             // VAMBHIP_SCAN_DBG: timing experiments only (wrong results)
     int max_k = kMaxMedoids;      // medoids per pass the LDS can hold for this latent width (query vectors are staged there)
+    bool use_mfma = true;         // scan.mfma = 0: passes with more than 8 medoids stay on the VALU kernels (A/B)
+    bool mfma_pass = false;       // set by scan_core for the pass being launched
+    int mfma_k = 0;               // its medoid count
     int scan_lc = 1;              // column-loop variant (VAMBHIP_SCAN_LC, A/B measurements): 0 runtime-width loop everywhere,
                                   // 1 unrolled loads up to 8 medoids + pipelined query / row fetches from 12 medoids
     bool small_rpt = true;        // VAMBHIP_SCAN_WIDE=1 disables the narrow variant (A/B measurements)
@@ -841,7 +1006,34 @@ void launch_scan(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     else launch_scan_rpt<KM, RPT>(h, med, q_ext);
 }
 
+template <int NK>
+void launch_scan_mfma(vh_clu* h, const MedoidRows& med, const float* q_ext) {
+    const size_t smem = scan_smem_bytes(kMaxMedoids, 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_mfma_kernel<NK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScanLdsBudget));
+        attr_set = true;
+    }
+    const int64_t tiles = h->ld >> 5;
+    // three workgroups per CU are resident (LDS): one resident set, every wavefront strides over its tiles
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(tiles, kBlock / 64), 256 * 3));
+    hipLaunchKernelGGL((clu_scan_mfma_kernel<NK>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
+                       h->lengths.p, h->kept.p, q_ext, med, h->mfma_k, h->results.p, h->lists_dev.p, h->scan_dbg);
+}
+
+// more than 8 medoids and a latent width the B operand registers hold: the matrix-pipe kernel (always 32 medoid slots)
+bool scan_uses_mfma(const vh_clu* h, int k) {
+    return h->use_mfma && k > 8 && h->L4 <= 64 && h->max_k >= kMaxMedoids && h->ld < ((int64_t)1 << 28);   // 32-bit byte offsets
+}
+
 void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext) {
+    if (h->mfma_pass) {
+        if (h->L4 <= 32) launch_scan_mfma<16>(h, med, q_ext);
+        else launch_scan_mfma<32>(h, med, q_ext);
+        VH_HIP(hipGetLastError());
+        return;
+    }
     switch (km) {
         case 1: launch_scan<1>(h, med, q_ext); break;
         case 2: launch_scan<2>(h, med, q_ext); break;
@@ -907,6 +1099,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         }
         h->small_rpt = getenv("VAMBHIP_SCAN_WIDE") == nullptr;
         { const char* e = getenv("VAMBHIP_SCAN_LC"); h->scan_lc = e ? atoi(e) : 1; }
+        { const char* e = getenv("VAMBHIP_SCAN_MFMA"); h->use_mfma = !(e && e[0] == '0'); }
         h->scan_dbg = getenv("VAMBHIP_SCAN_DBG") ? atoi(getenv("VAMBHIP_SCAN_DBG")) : 0;
         h->results.alloc((size_t)kMaxMedoids * kResultWords);
         h->lists_dev.alloc((size_t)kMaxMedoids * kListCap);
@@ -991,13 +1184,15 @@ namespace {
 int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries) {
     VH_REQUIRE(h != nullptr && medoid_rows != nullptr, "NULL argument");
     VH_REQUIRE(k >= 1 && k <= h->max_k, "k=%d outside [1, %d] (vh_clu_max_medoids)", k, h->max_k);
-    const int km = pick_km(k);
+    h->mfma_pass = scan_uses_mfma(h, k);
+    const int km = h->mfma_pass ? kMaxMedoids : pick_km(k);
     MedoidRows med;
+    h->mfma_k = k;
     for (int j = 0; j < kMaxMedoids; ++j) {
         const int64_t m = medoid_rows[j < k ? j : 0];
         VH_REQUIRE(m >= -1 && m < h->n_rows, "medoid row %lld out of range", (long long)m);
         VH_REQUIRE(queries != nullptr || m >= 0, "medoid row -1 needs an explicit query vector");
-        med.row[j] = m;
+        med.row[j] = (h->mfma_pass && j >= k) ? -1 : m;   // the matrix-pipe kernel leaves unused slots empty
     }
     const float* q_ext = nullptr;
     if (queries) {
@@ -1014,7 +1209,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
     h->timer.start(h->stream);
     dispatch_scan(h, km, med, q_ext);
     h->timer.stop(h->stream);
-    hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kBlock), 0, h->stream, km, h->results.p, h->lists_dev.p, lists,
+    hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->mfma_pass ? k : km, h->results.p, h->lists_dev.p, lists,
                        h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1));
     VH_HIP(hipGetLastError());
     wait_for_scan(h, h->scan_seq + 1);
@@ -1461,6 +1656,7 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
     if (g->speculate) {
         size_t target = (size_t)pick_km((int)std::min<size_t>(missing.size(), kMaxMedoids));
         if (g->clu->max_k < kMaxMedoids) target = std::min(missing.size(), (size_t)g->clu->max_k);   // wide latents: no widening
+        else if (scan_uses_mfma(g->clu, (int)std::min<size_t>(missing.size(), kMaxMedoids))) target = kMaxMedoids;   // matrix-pipe pass: 32 medoids cost what 9 cost
         else if (missing.size() <= 8 && g->clu->n_rows <= 600000) target = kMaxMedoids;  // latency-bound pass: extra medoids are free
         else if (g->spec_big_target > 0 && missing.size() <= 8) target = std::max(target, (size_t)g->spec_big_target);
         else if (missing.size() == 1) target = 8;
