@@ -175,13 +175,16 @@ constexpr int kHitCap = 256;      // queued hits per wavefront (drained when few
 __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn, int lane,
                                            unsigned long long* __restrict__ acc_s, unsigned int* __restrict__ lcnt_s,
                                            int32_t* __restrict__ llist_s, const float* __restrict__ edges_s,
-                                           const int32_t* __restrict__ med_s, int dbg) {
+                                           const int32_t* __restrict__ med_s, int dbg,
+                                           const float* __restrict__ lengths = nullptr) {
     const float radius = 0.05f;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int e = lane; e < qn; e += 64) {
         const float4 v = hq[e];
-        const float len = v.y;
         const int32_t row = __float_as_int(v.z);
+        // the matrix-pipe kernel queues (d, row, medoid) only and leaves the length to this loop: a global load in its
+        // tile loop would make every tile with a pair of interest wait for the prefetched tiles behind it
+        const float len = lengths ? lengths[row] : v.y;
         const int j = __float_as_int(v.w);
         // the distance of a medoid to itself is 0 by definition (cluster.py:619), not 0.5 - <q, q>: decided here, once
         // per queued pair, instead of once per (row, medoid) pair in the scan loop
@@ -581,12 +584,11 @@ __global__ __launch_bounds__(kBlock) void clu_scan_mfma_kernel(const float* __re
                         const int64_t row = base + 8 * q + 4 * h + e;
                         const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32),
                                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                        hq[pos] = make_float4(0.5f - acc[4 * q + e], lengths[row], __int_as_float((int32_t)row),
-                                              __int_as_float(j));
+                        hq[pos] = make_float4(0.5f - acc[4 * q + e], 0.0f, __int_as_float((int32_t)row), __int_as_float(j));
                     }
                     qn += __popcll(m);
                     if (qn > kHitCap - 64) {
-                        drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg);
+                        drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, lengths);
                         qn = 0;
                     }
                 }
@@ -602,7 +604,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_mfma_kernel(const float* __re
             }
         }
     }
-    drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg);
+    drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, lengths);
     scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists);
 }
 
