@@ -34,6 +34,23 @@ typedef enum {
 
 const char* vh_last_error(void);
 const char* vh_version(void);
+
+/* Process-wide tuning / diagnostic options, read when a handle is created.  The library itself reads NO environment
+ * variables (the Python layer forwards its VAMBHIP_* variables through these calls, vamb_amd/_lib.py).  Integer options:
+ *   scan.column_loop (1)   0: runtime-width column loop in every scan kernel; 1: unrolled loads up to 8 medoids
+ *   scan.mfma (1)          passes with more than 8 medoids on the matrix-pipe kernel
+ *   scan.wide_rows (0)     fixed 4 / 2 rows per lane (no narrow variants for small matrices)
+ *   scan.debug (0)         timing experiments only (wrong results): 1 no pair of interest, 2 no histogram
+ *   gen.profile (0)        wall-clock breakdown of the native cluster state machine on stderr
+ *   gen.speculate (1), gen.spec_window (40), gen.spec_big_target (0)   speculative seed scans
+ *   vae.single_stream (0)  weight-gradient GEMMs on the main stream
+ *   vae.fork_events (0)    forks as event records instead of kernel completion signals
+ *   vae.big_tiles (0), vae.xcd_remap (1), vae.dw_workgroups (256), vae.debug_timing (0)
+ * String options: comm.rccl_library (path of librccl), comm.rocm_path (default /opt/rocm). */
+int vh_set_option(const char* name, int64_t value);
+int vh_unset_option(const char* name);
+int vh_get_option(const char* name, int64_t* value /* in: default, out: the value in force */);
+int vh_set_option_string(const char* name, const char* value);
 /* number of visible HIP devices (0 with an error message when there is no GPU) */
 int vh_device_count(int* n);
 /* bind the calling process to a device (LOCAL_RANK under torch.distributed.run) */

@@ -326,22 +326,17 @@ def test_free_running_training_learns():
 
 
 def test_step_scheduling_variants_are_bit_identical(monkeypatch):
-    """The scheduling of a step (forks on completion signals, last dW on the main stream, decoder half of the
-    optimiser early on the side stream) must not change a single bit: train the same model with every
-    optimisation switched off and with all of them on."""
+    """The scheduling of a step (weight-gradient GEMMs on a second stream, forks riding on kernel completion signals)
+    must not change a single bit: train the same model on one stream with event-record forks and with the defaults."""
     n, S = 5000, 6
     ab, tnf, lens, _ = synth.features(n, S, seed=11)
     states = []
     for plain in (True, False):
-        for var in ("VAMBHIP_OPT_SPLIT", "VAMBHIP_FORK_EVENTS", "VAMBHIP_TAIL_SIDE", "VAMBHIP_SINGLE_STREAM"):
+        for var in ("VAMBHIP_FORK_EVENTS", "VAMBHIP_SINGLE_STREAM"):
             monkeypatch.delenv(var, raising=False)
         if plain:
-            monkeypatch.setenv("VAMBHIP_OPT_SPLIT", "0")
             monkeypatch.setenv("VAMBHIP_FORK_EVENTS", "1")
-            monkeypatch.setenv("VAMBHIP_TAIL_SIDE", "1")
             monkeypatch.setenv("VAMBHIP_SINGLE_STREAM", "1")
-        else:
-            monkeypatch.setenv("VAMBHIP_OPT_SPLIT", "1")   # opt-in variant (measured slower, kept switchable)
         dl = ve.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=512, destroy=True)
         vae = ve.VAE(S, seed=4)
         vae.trainmodel(dl, nepochs=4, batchsteps=[2])

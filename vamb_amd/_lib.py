@@ -49,6 +49,10 @@ _pp = ctypes.POINTER(ctypes.c_void_p)
 SIGNATURES = {
     "vh_last_error": (ctypes.c_char_p, []),
     "vh_version": (ctypes.c_char_p, []),
+    "vh_set_option": (_int, [ctypes.c_char_p, _i64]),
+    "vh_unset_option": (_int, [ctypes.c_char_p]),
+    "vh_get_option": (_int, [ctypes.c_char_p, ctypes.POINTER(_i64)]),
+    "vh_set_option_string": (_int, [ctypes.c_char_p, ctypes.c_char_p]),
     "vh_device_count": (_int, [ctypes.POINTER(_int)]),
     "vh_set_device": (_int, [_int]),
     "vh_clu_create": (_int, [_vp, _vp, _i64, _int, _int, _vp, _pp]),
@@ -141,6 +145,63 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+# Environment variable -> (library option, how the value is read).  The C library reads no environment: every
+# constructor of a handle (VAE, scan backend, cluster generator) calls sync_env_options() first, so the variables
+# keep working for A/B runs from the shell and for monkeypatch.setenv in the tests.
+_ENV_OPTIONS = {
+    "VAMBHIP_SCAN_LC": ("scan.column_loop", int),
+    "VAMBHIP_SCAN_MFMA": ("scan.mfma", int),
+    "VAMBHIP_SCAN_WIDE": ("scan.wide_rows", lambda v: 1),
+    "VAMBHIP_SCAN_DBG": ("scan.debug", int),
+    "VAMBHIP_GEN_PROFILE": ("gen.profile", lambda v: 1),
+    "VAMBHIP_NO_SPECULATION": ("gen.speculate", lambda v: 0),
+    "VAMBHIP_SPEC_WINDOW": ("gen.spec_window", int),
+    "VAMBHIP_SPEC_BIG_TARGET": ("gen.spec_big_target", int),
+    "VAMBHIP_BIG_TILES": ("vae.big_tiles", int),
+    "VAMBHIP_XCD_REMAP": ("vae.xcd_remap", int),
+    "VAMBHIP_DW_WGS": ("vae.dw_workgroups", int),
+    "VAMBHIP_SINGLE_STREAM": ("vae.single_stream", lambda v: 1),
+    "VAMBHIP_FORK_EVENTS": ("vae.fork_events", lambda v: 1),
+    "VAMBHIP_DEBUG_TIMING": ("vae.debug_timing", lambda v: 1),
+}
+_ENV_STRING_OPTIONS = {"VAMBHIP_RCCL": "comm.rccl_library", "ROCM_PATH": "comm.rocm_path"}
+_explicit_options: dict = {}
+
+
+def set_option(name: str, value) -> None:
+    """Set a library option (include/vambhip.h lists them); it wins over the environment variables."""
+    lib = load()
+    if isinstance(value, str):
+        check(lib.vh_set_option_string(name.encode(), value.encode()))
+    else:
+        check(lib.vh_set_option(name.encode(), int(value)))
+    _explicit_options[name] = value
+
+
+def get_option(name: str, default: int = 0) -> int:
+    v = _i64(default)
+    check(load().vh_get_option(name.encode(), ctypes.byref(v)))
+    return v.value
+
+
+def sync_env_options() -> None:
+    lib = load()
+    for var, (name, conv) in _ENV_OPTIONS.items():
+        if name in _explicit_options:
+            continue
+        raw = os.environ.get(var)
+        if raw is None or raw == "":
+            check(lib.vh_unset_option(name.encode()))
+        else:
+            check(lib.vh_set_option(name.encode(), int(conv(raw))))
+    for var, name in _ENV_STRING_OPTIONS.items():
+        if name in _explicit_options:
+            continue
+        raw = os.environ.get(var)
+        if raw:
+            check(lib.vh_set_option_string(name.encode(), raw.encode()))
 
 
 def check(status: int):

@@ -125,6 +125,7 @@ class HipScanBackend:
         self.lib = _lib.load()
         _lib.require_gpu()
         handle = ctypes.c_void_p()
+        _lib.sync_env_options()   # VAMBHIP_* variables -> library options (the .so reads no environment)
         _lib.check(self.lib.vh_clu_create(_lib.ptr(matrix), _lib.ptr(lengths_f32), matrix.shape[0],
                                           matrix.shape[1], int(bool(normalized)), _lib.ptr(normalized_out),
                                           ctypes.byref(handle)))
@@ -423,6 +424,7 @@ class ClusterGenerator:
                 and abs(rng_seed) < 2 ** 64 and not _os.environ.get("VAMBHIP_PY_GENERATOR")):
             handle = ctypes.c_void_p()
             order = _np.ascontiguousarray(self.order, dtype=_np.int64)
+            _lib.sync_env_options()   # VAMBHIP_* variables -> library options (the .so reads no environment)
             _lib.check(self._backend.lib.vh_gen_create(self._backend.h, _lib.ptr(order), n, int(maxsteps),
                                                        int(windowsize), int(minsuccesses), abs(rng_seed),
                                                        float(self.PACK_FRACTION), int(self.PACK_MIN_ROWS),

@@ -17,6 +17,8 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <deque>
@@ -26,6 +28,30 @@
 
 namespace vh {
 thread_local std::string g_last_error;
+
+namespace {
+std::mutex g_option_mutex;
+std::map<std::string, int64_t>& option_table() {
+    static std::map<std::string, int64_t> t;
+    return t;
+}
+std::map<std::string, std::string>& option_strings() {
+    static std::map<std::string, std::string> t;
+    return t;
+}
+}  // namespace
+
+int64_t option(const char* name, int64_t dflt) {
+    std::lock_guard<std::mutex> lock(g_option_mutex);
+    const auto it = option_table().find(name);
+    return it == option_table().end() ? dflt : it->second;
+}
+
+const char* option_string(const char* name) {
+    std::lock_guard<std::mutex> lock(g_option_mutex);
+    const auto it = option_strings().find(name);
+    return it == option_strings().end() ? nullptr : it->second.c_str();
+}
 }
 
 using namespace vh;
@@ -1054,6 +1080,38 @@ void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext)
 extern "C" {
 
 const char* vh_last_error(void) { return g_last_error.c_str(); }
+
+int vh_set_option(const char* name, int64_t value) {
+    return guarded([&] {
+        VH_REQUIRE(name != nullptr && name[0] != 0, "NULL argument");
+        std::lock_guard<std::mutex> lock(g_option_mutex);
+        option_table()[name] = value;
+    });
+}
+
+int vh_unset_option(const char* name) {
+    return guarded([&] {
+        VH_REQUIRE(name != nullptr, "NULL argument");
+        std::lock_guard<std::mutex> lock(g_option_mutex);
+        option_table().erase(name);
+        option_strings().erase(name);
+    });
+}
+
+int vh_get_option(const char* name, int64_t* value) {
+    return guarded([&] {
+        VH_REQUIRE(name != nullptr && value != nullptr, "NULL argument");
+        *value = option(name, *value);
+    });
+}
+
+int vh_set_option_string(const char* name, const char* value) {
+    return guarded([&] {
+        VH_REQUIRE(name != nullptr && value != nullptr, "NULL argument");
+        std::lock_guard<std::mutex> lock(g_option_mutex);
+        option_strings()[name] = value;
+    });
+}
 const char* vh_version(void) { return "vambhip 0.1 (gfx950)"; }
 
 int vh_device_count(int* n) {
@@ -1099,10 +1157,10 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
                 if (scan_smem_bytes(b, h->L4) <= kScanLdsBudget) { h->max_k = b; break; }
             VH_REQUIRE(h->max_k >= 1, "latent width %d does not fit the scan kernel's LDS", L);
         }
-        h->small_rpt = getenv("VAMBHIP_SCAN_WIDE") == nullptr;
-        { const char* e = getenv("VAMBHIP_SCAN_LC"); h->scan_lc = e ? atoi(e) : 1; }
-        { const char* e = getenv("VAMBHIP_SCAN_MFMA"); h->use_mfma = !(e && e[0] == '0'); }
-        h->scan_dbg = getenv("VAMBHIP_SCAN_DBG") ? atoi(getenv("VAMBHIP_SCAN_DBG")) : 0;
+        h->small_rpt = option("scan.wide_rows", 0) == 0;
+        h->scan_lc = (int)option("scan.column_loop", 1);
+        h->use_mfma = option("scan.mfma", 1) != 0;
+        h->scan_dbg = (int)option("scan.debug", 0);
         h->results.alloc((size_t)kMaxMedoids * kResultWords);
         h->lists_dev.alloc((size_t)kMaxMedoids * kListCap);
         VH_HIP(hipHostMalloc((void**)&h->lists, (size_t)kListRing * kMaxMedoids * kListCap * sizeof(int32_t),
@@ -1943,10 +2001,10 @@ int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, in
         g->pack_fraction = pack_fraction;
         g->pack_min_rows = pack_min_rows;
         g->rng.seed(rng_seed);
-        g->profile = getenv("VAMBHIP_GEN_PROFILE") != nullptr;
-        g->speculate = getenv("VAMBHIP_NO_SPECULATION") == nullptr;
-        if (const char* e = getenv("VAMBHIP_SPEC_WINDOW")) g->spec_window = atoi(e);
-        if (const char* e = getenv("VAMBHIP_SPEC_BIG_TARGET")) g->spec_big_target = atoi(e);
+        g->profile = option("gen.profile", 0) != 0;
+        g->speculate = option("gen.speculate", 1) != 0;
+        g->spec_window = (int)option("gen.spec_window", kSpecWindow);
+        g->spec_big_target = (int)option("gen.spec_big_target", 0);
         g->order.assign(order, order + n);
         g->indices.resize((size_t)n);
         for (int64_t i = 0; i < n; ++i) g->indices[(size_t)i] = i;

@@ -38,9 +38,12 @@ Rccl& rccl() {
     static Rccl r;
     if (r.handle) return r;
     std::string tried;
-    const char* env = getenv("VAMBHIP_RCCL");
-    std::string rocm = getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "/opt/rocm";
-    const std::string candidates[] = {env ? env : "", rocm + "/lib/librccl.so.1", rocm + "/lib/librccl.so",
+    // library location: the string option comm.rccl_library (vh_set_option_string), then the ROCm installation
+    const char* opt = option_string("comm.rccl_library");
+    const std::string explicit_path = opt ? opt : "";
+    const char* rocm_opt = option_string("comm.rocm_path");
+    const std::string rocm = rocm_opt ? rocm_opt : "/opt/rocm";
+    const std::string candidates[] = {explicit_path, rocm + "/lib/librccl.so.1", rocm + "/lib/librccl.so",
                                       "/opt/rocm/lib/librccl.so.1"};
     for (const auto& c : candidates) {
         if (c.empty()) continue;

@@ -139,6 +139,11 @@ struct EventTimer {
     void collect() { if (enabled) VH_HIP(hipEventElapsedTime(&last_ms, a, b)); }
 };
 
+// Process-wide tuning / diagnostic options (vh_set_option / vh_get_option, defined in cluster.hip).  The library reads NO
+// environment variables: the Python layer forwards VAMBHIP_* variables through vh_set_option (vamb_amd/_lib.py).
+int64_t option(const char* name, int64_t dflt);
+const char* option_string(const char* name);   // nullptr when unset
+
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
 

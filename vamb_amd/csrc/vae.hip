@@ -92,13 +92,6 @@ void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kMaxDynLds));
         attr_set = true;
-        if (getenv("VAMBHIP_DEBUG_OCC")) {
-            int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), WM * WN * 64,
-                                                               smem);
-            fprintf(stderr, "[vambhip] gemm<%d,%d,%d,%d,%d,%d,epi %d,xf %d %d,bk %d> smem %zu B: %d workgroups/CU\n", BM,
-                    BN, WM, WN, (int)AKC, (int)BKC, EPI, XFA, XFB, BK, smem, nb);
-        }
     }
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits);
     if (t_probe_start) {
@@ -113,15 +106,8 @@ void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
     VH_HIP(hipGetLastError());
 }
 
-// 64-wide K-tiles (tile 4 of vh_debug_gemm): +4-7 % for an isolated GEMM (4096x512x512: 71 -> 74 TF/s, K = 4096:
-// 89 -> 95), but the doubled LDS footprint halves the co-residency of the dX / dW GEMMs that share the CUs in the
-// backward pass (376 vs 353 us per step with every GEMM on them) and for the forward GEMMs alone the step time
-// does not move (351.5 vs 351.0 us).  Opt-in (VAMBHIP_BK64=1, forward GEMMs only).
-bool bk64_enabled() {
-    static const bool on = [] { const char* e = getenv("VAMBHIP_BK64"); return e && e[0] == '1'; }();
-    return on;
-}
-
+// (64-wide K-tiles for the forward GEMMs of the step -- tile 4 of vh_debug_gemm -- measured +4-7 % for an isolated GEMM
+// and nothing for the step, 351.5 vs 351.0 us, and slower on the backward GEMMs: not wired into the step.)
 // production tiles: 3 = 64x64 (2x2 waves, 2 workgroups per CU), 2 = 128x32 (4x1) for latent-wide outputs
 template <bool AKC, bool BKC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE>
 void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
@@ -133,8 +119,6 @@ void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
     if (tile == 2) launch_gemm<128, 32, 4, 1, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
     else if (tile == 1) launch_gemm<128, 128, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
     else if (tile == 0) launch_gemm<64, 128, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
-    else if (g.wide_k && bk64_enabled() && g.K % 64 == 0 && g.k_per_split % 64 == 0)
-        launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB, 64>(s, g, splits);   // 64-wide K-tiles: half the barriers
     else launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
 }
 
@@ -162,15 +146,27 @@ void gemm_tile_debug(hipStream_t s, int tile, const GemmArgs& g, int splits) {
     }
 }
 
-// Output [M][N] of a forward / input-gradient GEMM.  VAMBHIP_BIG_TILES=1 picks the largest tile that still yields
+// Output [M][N] of a forward / input-gradient GEMM.  the option vae.big_tiles picks the largest tile that still yields
 // two workgroups per CU (a 64x64 accumulator per wavefront needs one fresh LDS operand per MFMA instead of two:
 // isolated, 16384x512x512 runs at 99 instead of 86 TF/s and 8192x512x1120 at 95 instead of 87).  Inside the real
 // training step at C2 (batch 8192) it measured SLOWER (665 vs 634 us): opt-in, parity-tested
 // (tests/test_vae_gpu.py::test_large_batch_tiles_match_oracle).
+// Process-wide tuning read from the option table (vh_set_option) whenever a VAE handle is created
+struct VaeTuning {
+    bool big_tiles = false;   // vae.big_tiles
+    int xcd_remap = 1;        // vae.xcd_remap
+    int dw_workgroups = 256;  // vae.dw_workgroups: workgroups wanted per weight-gradient GEMM (split-K target)
+} g_tuning;
+
+void refresh_tuning() {
+    g_tuning.big_tiles = option("vae.big_tiles", 0) != 0;
+    g_tuning.xcd_remap = (int)option("vae.xcd_remap", 1);
+    g_tuning.dw_workgroups = (int)option("vae.dw_workgroups", 256);
+}
+
 int fwd_tile(int M, int N) {
     if (N <= 32) return 2;
-    static const bool big = [] { const char* e = getenv("VAMBHIP_BIG_TILES"); return e && e[0] == '1'; }();
-    if (big) {
+    if (g_tuning.big_tiles) {
         if (ceil_div(M, 128) * ceil_div(N, 128) >= 512) return 1;
         if (ceil_div(M, 64) * ceil_div(N, 128) >= 512) return 0;
     }
@@ -182,11 +178,7 @@ GemmArgs base_args(bool bf16 = false) {
     memset(&g, 0, sizeof(g));
     g.bf16 = bf16 ? 1 : 0;
     g.drop_scale = 1.0f;
-    static const int remap = [] {
-        const char* e = getenv("VAMBHIP_XCD_REMAP");
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    g.xcd_remap = remap;
+    g.xcd_remap = g_tuning.xcd_remap;
     return g;
 }
 
@@ -194,8 +186,7 @@ GemmArgs base_args(bool bf16 = false) {
 
 struct vh_vae {
     vh_vae_config cfg;
-    bool tail_on_main = true;   // VAMBHIP_TAIL_SIDE=1: keep the last weight-gradient GEMM on the side stream
-    bool fork_ext = true;   // forks ride on the producing kernel's completion signal (VAMBHIP_FORK_EVENTS=1: records)
+    bool fork_ext = true;   // forks ride on the producing kernel's completion signal (option vae.fork_events: records)
     bool bf16 = false;   // GEMM operands rounded to bf16, fp32 accumulation (vh_vae_set_precision)
     int nl = 0;       // hidden layers per side
     int S = 0, D = 0, D_p = 0, L = 0, L_p = 0;
@@ -227,11 +218,6 @@ struct vh_vae {
     int bs = 0, bs_p = 0;
     DevBuf<float> Xb, Wb, MU, Z, EPS, R, dR, dMUk, DA, dMU, loss_part, slabs, out_sm, skinny;
     DevBuf<double> statbuf;          // every hidden layer's fstat | bstat | dbias, zeroed once per step
-    int opt_dec_blk0 = 0;            // first optimiser workgroup of the decoder-side tensors
-    bool early_dec = false;          // this step's decoder-side update was already enqueued on the side stream
-    bool split_opt = false;          // VAMBHIP_OPT_SPLIT=1: decoder half of the optimiser early on the side stream
-                                     // (measured SLOWER: 364 vs 353 us/step -- it competes with the GEMMs)
-    hipEvent_t ev_fork2 = nullptr;
     OptTable opt_tab, opt_tab_flat;  // parameter tensors -> gradient sources (slabs / fp64 accumulators / flat G)
     bool stat_clean = false;         // statbuf is all zero (left so by the optimiser's finalize kernel)
     bool keep_grads = false;         // single-step API: leave the accumulators for vh_vae_get_grad
@@ -240,16 +226,8 @@ struct vh_vae {
     int opt_blocks = 0;
     int loss_blocks = 0;
 
-    // the whole optimisation step as one replayable hipGraph (everything that changes from step to
-    // step -- batch index, RNG step, d, wsum -- lives in device memory)
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_bs = -1;
-    bool graph_dp = false;
-    const int64_t* graph_idx = nullptr;
-    const float* graph_gwsum = nullptr;
-    int graph_global_bs = 0;
-    bool use_graph = true;
+    // (hipGraph replay of the step measured 16 % slower than eager launches -- 36.3 vs 31.3 ms per C1 epoch,
+    // profiles/README.md -- and was removed; everything that changes from step to step lives in device memory.)
     bool warmed_up = false;   // one eager step has run (kernel attributes set, workspaces touched)
 
     // bf16-storage step (configs C2-C4; vae_step16.hpp)
@@ -282,16 +260,7 @@ struct vh_vae {
     int64_t probe_launches = 0;
     double probe_flops = 0.0;
 
-    void drop_graph() {
-        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-        if (graph) (void)hipGraphDestroy(graph);
-        graph_exec = nullptr;
-        graph = nullptr;
-        graph_bs = -1;
-    }
-
     ~vh_vae() {
-        drop_graph();
         for (auto e : ev_a) (void)hipEventDestroy(e);
         for (auto e : ev_b) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -384,11 +353,7 @@ void init_parameters(vh_vae* h) {
 int dw_splits(int M, int N, int K, int tile) {
     const int bm = (tile == 0 || tile == 3) ? 64 : 128, bn = tile == 2 ? 32 : (tile == 3 ? 64 : 128);
     const int tiles = (int)(ceil_div(M, bm) * ceil_div(N, bn));
-    static const int target = [] {
-        const char* e = getenv("VAMBHIP_DW_WGS");
-        return e ? atoi(e) : 256;
-    }();
-    int want = (int)std::max<int64_t>(1, ceil_div(target, tiles));
+    int want = (int)std::max<int64_t>(1, ceil_div(g_tuning.dw_workgroups, tiles));
     want = std::min(want, K / 32);
     return std::max(1, want);
 }
@@ -401,7 +366,6 @@ int dw_tile(int M, int N) {
 void prepare_batch(vh_vae* h, int bs) {
     if (bs == h->bs) return;
     VH_HIP(hipStreamSynchronize(h->stream));
-    h->drop_graph();
     const int bs_p = (int)round_up(bs, kRowPad);
     h->bs = bs;
     h->bs_p = bs_p;
@@ -502,17 +466,6 @@ void prepare_batch(vh_vae* h, int bs) {
         tab.n++;
     }
     tab.blk_start[tab.n] = nblk;
-    // decoder-side tensors (decoder hidden layers + output layer) are the tail of the table (creation order:
-    // encoder, mu, decoder, output): their optimiser update can run as soon as their gradients are complete
-    h->opt_dec_blk0 = nblk;
-    {
-        int ti = 0;
-        for (size_t k = 0; k < h->tensors.size(); ++k) {
-            if (!h->tensors[k].optimised) continue;
-            if ((int)k == h->hidden[h->nl].tW) h->opt_dec_blk0 = tab.blk_start[ti];
-            ++ti;
-        }
-    }
     h->opt_tab = tab;
     h->G.ensure(h->flat_elems);
     h->opt_tab_flat = tab;
@@ -888,7 +841,7 @@ void backward(vh_vae* h, bool masks_injected) {
         // The first encoder layer is the end of the chain: nothing is left on the main stream for its weight
         // gradient to hide behind, so it runs there too (no fork, and the optimiser does not wait for a
         // cross-stream hop: dZ -> dW -> join was 25 us longer on the side stream).
-        const bool tail = (li == 0) && h->tail_on_main;
+        const bool tail = li == 0;   // nothing left on the main stream to hide the last weight-gradient GEMM behind
         if (tail) {
             hipLaunchKernelGGL(vae_dz_kernel, dim3((unsigned)ceil_div(hl.nout_p, kDzCols), (unsigned)ceil_div(bs_p, kDzRows)),
                                dim3(32, kRL), 0, h->stream, a);
@@ -908,22 +861,9 @@ void backward(vh_vae* h, bool masks_injected) {
             grad_weight(h, hl.tW, hl.DZ.p, hl.nout_p, In, in_p, nullptr, tail ? h->stream : nullptr);
         }
         if (li == nl) {
-            // Last reader of a decoder-side parameter on the main stream: the GEMM below (W of this layer).  Once
-            // it has retired and this layer's dW is in (side stream order), the decoder half of the optimiser
-            // step can run on the side stream while the encoder's backward continues here.  Single-GPU only:
-            // the data-parallel path all-reduces the whole gradient first.
-            const bool early = h->split_opt && fork_from_kernel(h) && h->comm == nullptr && !h->keep_grads &&
-                               h->opt_dec_blk0 > 0 && h->opt_dec_blk0 < h->opt_blocks;
-            if (early) t_fork_stop = h->ev_fork2;
+            // (running the decoder half of the optimiser here, on the side stream, measured slower -- 364 vs 353 us per
+            // step: it competes with the GEMMs -- and was removed)
             latent_slabs = grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, h->DA.p, nullptr, true);
-            if (early) {
-                VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork2, 0));
-                hipLaunchKernelGGL(vae_dadapt_kernel, dim3(h->opt_blocks - h->opt_dec_blk0), dim3(256), 0, h->side,
-                                   h->opt_tab, h->P.p, h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p,
-                                   h->opt_dec_blk0);
-                VH_HIP(hipGetLastError());
-                h->early_dec = true;
-            }
         } else if (li > 0) grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, below->DA.p, below, false);
         // li == 0: the input gradient is never needed
     };
@@ -953,9 +893,7 @@ void optimizer_step(vh_vae* h) {
         rccl_allreduce_sum_f32(h->comm, h->G.p, h->flat_elems, h->stream);
         tab = &h->opt_tab_flat;
     }
-    // the decoder-side tensors were updated on the side stream during the encoder's backward (backward())
-    const int nblk = h->early_dec ? h->opt_dec_blk0 : h->opt_blocks;
-    h->early_dec = false;
+    const int nblk = h->opt_blocks;
     if (nblk > 0) {
         hipLaunchKernelGGL(vae_dadapt_kernel, dim3(nblk), dim3(256), 0, h->stream, *tab, h->P.p, h->M1.p, h->M2.p,
                            h->Sv.p, h->state.p, h->opt_part.p, 0);
@@ -997,60 +935,20 @@ void reset_batch_index(vh_vae* h) {
     VH_HIP(hipMemsetAsync(&h->state.p->batch, 0, sizeof(long long), h->stream));
 }
 
-// Run batches [first, n_batches) of the epoch whose row list is dev_idx.  The first step after a
-// (re)allocation runs eagerly (it sets kernel attributes and carries the optional HIP-event probe); the
-// remaining steps replay one captured graph.
+// Run the n_batches steps of the epoch whose row list is dev_idx: eager launches, no host synchronisation.
 void run_epoch_steps(vh_vae* h, const int64_t* dev_idx, int64_t n_batches) {
-    const bool dp = h->comm != nullptr;
-    // hipGraph replay of the 56-launch step measured 16 % SLOWER than eager launches on MI355X / ROCm 7.2
-    // (36.3 vs 31.3 ms per C1 epoch, profiles/README.md), so it is opt-in.
-    const bool graphs = h->use_graph && getenv("VAMBHIP_GRAPH") != nullptr &&
-                        !(dp && getenv("VAMBHIP_DP_GRAPH") == nullptr);
     count_batches(h, n_batches);
-    int64_t b = 0;
-    if (!graphs) {
-        const bool dbg = getenv("VAMBHIP_DEBUG_TIMING") != nullptr;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (; b < n_batches; ++b) train_step_device(h, dev_idx, false, false);
-        if (dbg) {
-            const auto t1 = std::chrono::steady_clock::now();
-            VH_HIP(hipStreamSynchronize(h->stream));
-            const auto t2 = std::chrono::steady_clock::now();
-            fprintf(stderr, "[vambhip] epoch: host enqueue %.2f ms, drain after enqueue %.2f ms (%lld steps)\n",
-                    std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                    std::chrono::duration<double, std::milli>(t2 - t1).count(), (long long)n_batches);
-        }
-        return;
+    const bool dbg = option("vae.debug_timing", 0) != 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int64_t b = 0; b < n_batches; ++b) train_step_device(h, dev_idx, false, false);
+    if (dbg) {
+        const auto t1 = std::chrono::steady_clock::now();
+        VH_HIP(hipStreamSynchronize(h->stream));
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vambhip] epoch: host enqueue %.2f ms, drain after enqueue %.2f ms (%lld steps)\n",
+                std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(t2 - t1).count(), (long long)n_batches);
     }
-    // step 0 of every epoch is eager: warm-up for a fresh configuration and the probe's measurement point
-    train_step_device(h, dev_idx, false, false);
-    b = 1;
-    if (b >= n_batches) return;
-    if (!h->graph_exec || h->graph_bs != h->bs || h->graph_dp != dp || h->graph_idx != dev_idx ||
-        h->graph_gwsum != h->gwsum_src || h->graph_global_bs != h->global_bs) {
-        h->drop_graph();
-        const bool probe = h->probe_on;
-        h->probe_on = false;  // no event records inside the captured sequence
-        VH_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        try {
-            train_step_device(h, dev_idx, false, false);
-        } catch (...) {
-            hipGraph_t g = nullptr;
-            (void)hipStreamEndCapture(h->stream, &g);
-            if (g) (void)hipGraphDestroy(g);
-            h->probe_on = probe;
-            throw;
-        }
-        VH_HIP(hipStreamEndCapture(h->stream, &h->graph));
-        h->probe_on = probe;
-        VH_HIP(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
-        h->graph_bs = h->bs;
-        h->graph_dp = dp;
-        h->graph_idx = dev_idx;
-        h->graph_gwsum = h->gwsum_src;
-        h->graph_global_bs = h->global_bs;
-    }
-    for (; b < n_batches; ++b) VH_HIP(hipGraphLaunch(h->graph_exec, h->stream));
 }
 
 void read_state(vh_vae* h, StepState* out) {
@@ -1110,20 +1008,16 @@ int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
         // whenever both have work queued
         int prio_lo = 0, prio_hi = 0;
         VH_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // lo = least urgent (largest number)
-        const bool flat = getenv("VAMBHIP_FLAT_PRIORITY") != nullptr;
-        VH_HIP(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, flat ? prio_lo : prio_hi));
-        if (getenv("VAMBHIP_SINGLE_STREAM")) h->side = h->stream;
+        refresh_tuning();
+        VH_HIP(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
+        if (option("vae.single_stream", 0) != 0) h->side = h->stream;   // A/B: weight-gradient GEMMs on the main stream
         else VH_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
         // device-scope release: these events only order our two streams on the same GPU; the default
         // (system-scope) release flushes L2 for a host that never waits on them
-        h->tail_on_main = getenv("VAMBHIP_TAIL_SIDE") == nullptr;
-        h->fork_ext = getenv("VAMBHIP_FORK_EVENTS") == nullptr && getenv("VAMBHIP_GRAPH") == nullptr;
-        const unsigned ev_flags = getenv("VAMBHIP_EVENT_SYSTEM") ? hipEventDisableTiming
-                                                                 : (hipEventDisableTiming | hipEventReleaseToDevice);
+        h->fork_ext = option("vae.fork_events", 0) == 0;
+        const unsigned ev_flags = hipEventDisableTiming | hipEventReleaseToDevice;
         VH_HIP(hipEventCreateWithFlags(&h->ev_fork, ev_flags));
         VH_HIP(hipEventCreateWithFlags(&h->ev_join, ev_flags));
-        VH_HIP(hipEventCreateWithFlags(&h->ev_fork2, ev_flags));
-        { const char* e = getenv("VAMBHIP_OPT_SPLIT"); h->split_opt = e && e[0] == '1'; }
 
         h->hidden.resize(2 * h->nl);
         auto make_hidden = [&](int li, const std::string& lin, const std::string& norm, int nin, int nout) {
@@ -1437,7 +1331,7 @@ void enqueue_epoch(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t ba
         VH_REQUIRE(n_batches * batch <= h->n || perm != nullptr, "epoch needs %lld rows but the dataset has %lld",
                    (long long)(n_batches * batch), (long long)h->n);
         const bool dp = h->comm != nullptr && h->comm->world > 1;
-        const bool dbg = getenv("VAMBHIP_DEBUG_TIMING") != nullptr;
+        const bool dbg = option("vae.debug_timing", 0) != 0;
         const auto T0 = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) {
             if (dbg) fprintf(stderr, "[vambhip] %-18s %.3f ms\n", what,

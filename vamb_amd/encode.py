@@ -381,6 +381,7 @@ class VAE:
             cfg.nhiddens[i] = n
         cfg.alpha, cfg.beta, cfg.dropout, cfg.seed = alpha, beta, dropout, seed & 0xFFFFFFFFFFFFFFFF
         h = ctypes.c_void_p()
+        _lib.sync_env_options()   # VAMBHIP_* variables -> library options (the .so reads no environment)
         _lib.check(self._lib.vh_vae_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
         self._dataset_key = None

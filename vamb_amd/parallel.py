@@ -43,6 +43,7 @@ class Communicator:
         self._lib = None
         if rccl:
             self._lib = _lib.load()
+            _lib.sync_env_options()
             ident = (ctypes.c_ubyte * 128)()
             if self.rank == 0:
                 _lib.check(self._lib.vh_comm_unique_id(ident))
