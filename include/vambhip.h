@@ -99,6 +99,19 @@ int vh_clu_scan(vh_clu* h, int k, const int64_t* medoid_rows, const float* queri
  * number the NEXT scan will get; vh_clu_scan_list(h, seq, j, ...) returns medoid j's list of scan `seq`, or
  * *n_out = -1 when that scan has left the ring or the list overflowed its 2048 entries (then use
  * vh_clu_select with threshold 0.05f). */
+/* ---- row-sharded clustering over RCCL (one process per GPU; rank order = global row order) -------------------------
+ * vh_clu_attach_comm binds the communicator (vh_comm_create) whose ranks hold the other row shards.  A sharded pass is
+ * issued by EVERY rank with the same medoids: local_rows[j] = the medoid's LOCAL row on its owner rank, -1 elsewhere.
+ * On the handle's stream, without a host round trip in between: the owners' query vectors are all-reduced (sum with
+ * zeros: exact), the shard is scanned, the exact int64 accumulators (density, 60 histogram bins, two counts per medoid)
+ * are all-reduced -- integer sums are order-free, so `out` is identical on every rank and for any number of shards. */
+typedef struct vh_comm vh_comm;
+int vh_clu_attach_comm(vh_clu* h, vh_comm* comm);
+int vh_clu_scan_sharded(vh_clu* h, int k, const int64_t* local_rows, vh_scan_result* out);
+/* sharded cluster.py:_smaller_indices: local select (+ removal), all-gather of the counts, all-gather of the rows;
+ * out_rows = GLOBAL rows, ascending (row_offsets[r] = first global row of rank r, world + 1 entries) */
+int vh_clu_select_sharded(vh_clu* h, int64_t local_row, float threshold, int remove, const int64_t* row_offsets,
+                          int64_t* out_rows, int64_t cap, int64_t* n_out);
 int vh_clu_scan_seq(vh_clu* h, int64_t* seq);
 int vh_clu_scan_list(vh_clu* h, int64_t seq, int j, int64_t* out_rows, int64_t cap, int64_t* n_out);
 
@@ -299,7 +312,6 @@ int vh_vae_probe_result(vh_vae* h, double* ms_total, int64_t* launches, double* 
  * Data-parallel training (one process per GPU, RCCL over xGMI).  The reference has no distributed
  * path; these entry points are what a multi-GPU host (vamb_amd/parallel.py) binds.
  * ============================================================================================= */
-typedef struct vh_comm vh_comm;
 /* rank 0: 128 opaque bytes (ncclUniqueId) to hand to every rank out of band */
 int vh_comm_unique_id(unsigned char* out128);
 /* collective over all ranks: ncclCommInitRank on the calling process' current device */

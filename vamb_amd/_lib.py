@@ -60,6 +60,9 @@ SIGNATURES = {
     "vh_clu_rows": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "vh_clu_max_medoids": (_int, [_vp, ctypes.POINTER(_int)]),
     "vh_clu_scan": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "vh_clu_attach_comm": (_int, [_vp, _vp]),
+    "vh_clu_scan_sharded": (_int, [_vp, _int, _vp, _vp]),
+    "vh_clu_select_sharded": (_int, [_vp, _i64, _f32, _int, _vp, _vp, _i64, ctypes.POINTER(_i64)]),
     "vh_clu_scan_seq": (_int, [_vp, ctypes.POINTER(_i64)]),
     "vh_clu_scan_list": (_int, [_vp, _i64, _int, _vp, _i64, ctypes.POINTER(_i64)]),
     "vh_gen_create": (_int, [_vp, _vp, _i64, _int, _int, _int, ctypes.c_uint64, ctypes.c_double, _i64,

@@ -14,6 +14,7 @@
 //   dot = fmaf chain over columns ascending from +0.0f; d = 0.5f - dot; d(medoid) = 0
 //   density / histogram accumulate exactly in int64 fixed point (order-free => atomics are legal)
 // This file is compiled with -ffp-contract=off so that nothing but the explicit fmaf is fused.
+#include "comm.hpp"
 #include "common.hpp"
 
 #include <algorithm>
@@ -646,6 +647,17 @@ __global__ __launch_bounds__(kBlock) void clu_gather_quads_kernel(const float* _
     }
 }
 
+// Row-sharded execution: query vectors of the medoids THIS rank owns (medoid.row[j] >= 0), zeros for the others; the sum
+// all-reduce over the ranks distributes every vector exactly (x + 0 + ... + 0).
+__global__ __launch_bounds__(kBlock) void clu_gather_owned_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
+                                                                  const MedoidRows medoid, int km, float* __restrict__ q) {
+    for (int i = threadIdx.x; i < km * L4; i += kBlock) {
+        const int j = i / L4, c = i - j * L4;
+        const long long row = medoid.row[j];
+        q[i] = row >= 0 ? Mt[(int64_t)c * ld + row] : 0.0f;
+    }
+}
+
 // K6b: publication without a copy-engine round trip.  One block moves the accumulators and the candidate
 // lists into host-mapped memory, zeroes the accumulators for the next scan and then raises the sequence flag
 // the host spins on.  (A separate launch, not a last-block-done tail of the scan: the kernel boundary is the
@@ -917,6 +929,9 @@ struct vh_clu {
     unsigned long long* flag() { return host_results + (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS); }
     int scan_dbg = 0;             // VAMBHIP_SCAN_DBG: timing experiments only (wrong results)
     int max_k = kMaxMedoids;      // medoids per pass the LDS can hold for this latent width (query vectors are staged there)
+    vh_comm* comm = nullptr;      // row-sharded execution (vh_clu_attach_comm): the ranks holding the other shards
+    int64_t max_shard_ld = 0;     // largest padded shard over the ranks (size of the select exchange buffers)
+    DevBuf<uint32_t> xch_counts, xch_rows;
     bool use_mfma = true;         // scan.mfma = 0: passes with more than 8 medoids stay on the VALU kernels (A/B)
     bool mfma_pass = false;       // set by scan_core for the pass being launched
     int mfma_k = 0;               // its medoid count
@@ -1241,8 +1256,9 @@ namespace {
 // Launch one pass for k medoids and wait for its publication; returns the ring slot of the results.
 // The accumulators were zeroed by the publish kernel of the previous pass, the medoid rows travel in the
 // kernel arguments and the query vectors are gathered by the scan kernel itself.
-int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries) {
+int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries, bool sharded = false) {
     VH_REQUIRE(h != nullptr && medoid_rows != nullptr, "NULL argument");
+    VH_REQUIRE(!sharded || (h->comm != nullptr && queries == nullptr), "sharded scan needs vh_clu_attach_comm and no explicit queries");
     VH_REQUIRE(k >= 1 && k <= h->max_k, "k=%d outside [1, %d] (vh_clu_max_medoids)", k, h->max_k);
     h->mfma_pass = scan_uses_mfma(h, k);
     const int km = h->mfma_pass ? kMaxMedoids : pick_km(k);
@@ -1251,7 +1267,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
     for (int j = 0; j < kMaxMedoids; ++j) {
         const int64_t m = medoid_rows[j < k ? j : 0];
         VH_REQUIRE(m >= -1 && m < h->n_rows, "medoid row %lld out of range", (long long)m);
-        VH_REQUIRE(queries != nullptr || m >= 0, "medoid row -1 needs an explicit query vector");
+        VH_REQUIRE(queries != nullptr || sharded || m >= 0, "medoid row -1 needs an explicit query vector");
         med.row[j] = (h->mfma_pass && j >= k) ? -1 : m;   // the matrix-pipe kernel leaves unused slots empty
     }
     const float* q_ext = nullptr;
@@ -1264,11 +1280,20 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
         VH_HIP(hipMemcpyAsync(h->q.p, h->h_q.p, (size_t)km * h->L4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
         q_ext = h->q.p;
     }
+    if (sharded) {
+        // owners contribute their medoids' vectors, RCCL sums them on this stream: no host round trip
+        hipLaunchKernelGGL(clu_gather_owned_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->Mt.p, h->ld, h->L4, med, km, h->q.p);
+        VH_HIP(hipGetLastError());
+        rccl_allreduce_sum_f32(h->comm, h->q.p, (size_t)km * h->L4, h->stream);
+        q_ext = h->q.p;
+    }
     const int slot = (int)(h->scan_seq % kListRing);
     int32_t* lists = h->lists + (size_t)slot * kMaxMedoids * kListCap;
     h->timer.start(h->stream);
     dispatch_scan(h, km, med, q_ext);
     h->timer.stop(h->stream);
+    // the exact integer accumulators of all shards: order-free sums, so the result does not depend on the sharding
+    if (sharded) rccl_allreduce_sum_u64(h->comm, h->results.p, (size_t)km * kResultWords, h->stream);
     hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->mfma_pass ? k : km, h->results.p, h->lists_dev.p, lists,
                        h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1));
     VH_HIP(hipGetLastError());
@@ -1310,6 +1335,91 @@ int vh_clu_scan(vh_clu* h, int k, const int64_t* medoid_rows, const float* queri
             out[j].n_within = (int64_t)sm[4 * j + 1];
             out[j].n_lt = (int64_t)sm[4 * j + 2];
         }
+    });
+}
+
+int vh_clu_attach_comm(vh_clu* h, vh_comm* comm) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "NULL argument");
+        h->comm = comm;
+        if (!comm) return;
+        // the select exchange gathers fixed-size chunks: learn the largest shard
+        h->xch_counts.ensure((size_t)comm->world + 1);
+        const uint32_t mine = (uint32_t)h->ld;
+        VH_HIP(hipMemcpyAsync(h->xch_counts.p + comm->world, &mine, 4, hipMemcpyHostToDevice, h->stream));
+        rccl_allgather_u32(comm, h->xch_counts.p + comm->world, h->xch_counts.p, 1, h->stream);
+        std::vector<uint32_t> all((size_t)comm->world);
+        VH_HIP(hipMemcpyAsync(all.data(), h->xch_counts.p, 4 * all.size(), hipMemcpyDeviceToHost, h->stream));
+        VH_HIP(hipStreamSynchronize(h->stream));
+        h->max_shard_ld = *std::max_element(all.begin(), all.end());
+        h->sel_rows.ensure((size_t)h->max_shard_ld);
+    });
+}
+
+int vh_clu_scan_sharded(vh_clu* h, int k, const int64_t* local_rows, vh_scan_result* out) {
+    return guarded([&] {
+        VH_REQUIRE(out != nullptr, "NULL argument");
+        const int slot = scan_core(h, k, local_rows, nullptr, true);
+        const std::vector<unsigned long long>& sm = h->last_summary[slot];
+        std::vector<unsigned long long> hist((size_t)k * VH_NBINS);
+        memcpy(hist.data(), h->hist(slot), hist.size() * 8);
+        for (int j = 0; j < k; ++j) {
+            out[j].density_fx = (int64_t)sm[4 * j + 0];
+            for (int b = 0; b < VH_NBINS; ++b) out[j].hist_fx[b] = (int64_t)hist[(size_t)j * VH_NBINS + b];
+            out[j].n_within = (int64_t)sm[4 * j + 1];
+            out[j].n_lt = (int64_t)sm[4 * j + 2];
+        }
+    });
+}
+
+int vh_clu_select_sharded(vh_clu* h, int64_t local_row, float threshold, int remove, const int64_t* row_offsets,
+                          int64_t* out_rows, int64_t cap, int64_t* n_out) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && n_out != nullptr && row_offsets != nullptr, "NULL argument");
+        VH_REQUIRE(h->comm != nullptr, "vh_clu_attach_comm has not been called");
+        VH_REQUIRE(local_row >= -1 && local_row < h->n_rows, "medoid row out of range");
+        VH_REQUIRE(cap >= 0 && (cap == 0 || out_rows != nullptr), "bad output buffer");
+        vh_comm* comm = h->comm;
+        const int world = comm->world;
+        h->sel_rows.ensure((size_t)std::max<int64_t>(h->ld, h->max_shard_ld));
+        // query vector from its owner
+        MedoidRows med;
+        for (int j = 0; j < kMaxMedoids; ++j) med.row[j] = j == 0 ? local_row : -1;
+        hipLaunchKernelGGL(clu_gather_owned_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->Mt.p, h->ld, h->L4, med, 1, h->q.p);
+        VH_HIP(hipGetLastError());
+        rccl_allreduce_sum_f32(comm, h->q.p, (size_t)h->L4, h->stream);
+        // local select (counts[0] is zero on entry), then the counts of all ranks
+        hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
+                           h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, h->q.p, local_row, threshold, remove,
+                           h->sel_rows.p, h->counts.p);
+        VH_HIP(hipGetLastError());
+        h->xch_counts.ensure((size_t)world + 1);
+        rccl_allgather_u32(comm, h->counts.p, h->xch_counts.p, 1, h->stream);
+        std::vector<uint32_t> counts((size_t)world);
+        VH_HIP(hipMemcpyAsync(counts.data(), h->xch_counts.p, 4 * counts.size(), hipMemcpyDeviceToHost, h->stream));
+        VH_HIP(hipMemsetAsync(h->counts.p, 0, 4, h->stream));   // re-arm the select counter
+        VH_HIP(hipStreamSynchronize(h->stream));
+        const uint32_t maxc = *std::max_element(counts.begin(), counts.end());
+        int64_t total = 0;
+        for (uint32_t c : counts) total += c;
+        std::vector<uint32_t> gathered;
+        if (maxc > 0) {
+            VH_REQUIRE((int64_t)maxc <= std::max<int64_t>(h->ld, h->max_shard_ld), "internal: select count exceeds the shard size");
+            h->xch_rows.ensure((size_t)world * maxc);
+            rccl_allgather_u32(comm, reinterpret_cast<const uint32_t*>(h->sel_rows.p), h->xch_rows.p, maxc, h->stream);
+            gathered.resize((size_t)world * maxc);
+            VH_HIP(hipMemcpyAsync(gathered.data(), h->xch_rows.p, 4 * gathered.size(), hipMemcpyDeviceToHost, h->stream));
+            VH_HIP(hipStreamSynchronize(h->stream));
+        }
+        // rank order is global row order: sort every rank's local rows, shift them by its offset
+        int64_t w = 0;
+        for (int r = 0; r < world; ++r) {
+            uint32_t* part = gathered.data() + (size_t)r * maxc;
+            std::sort(part, part + counts[(size_t)r]);
+            for (uint32_t i = 0; i < counts[(size_t)r] && w < cap; ++i) out_rows[w++] = row_offsets[r] + (int64_t)part[i];
+        }
+        *n_out = total;
+        if (remove) h->n_live -= counts[(size_t)comm->rank];
     });
 }
 

@@ -19,8 +19,11 @@ typedef int (*fn_get_unique_id)(UniqueId*);
 typedef int (*fn_comm_init_rank)(void**, int, UniqueId, int);
 typedef int (*fn_comm_destroy)(void*);
 typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_all_gather)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef const char* (*fn_error_string)(int);
 
+constexpr int kNcclUint32 = 3;   // ncclUint32
+constexpr int kNcclUint64 = 5;   // ncclUint64
 constexpr int kNcclFloat32 = 7;  // ncclFloat32 / ncclFloat
 constexpr int kNcclFloat64 = 8;  // ncclFloat64 / ncclDouble
 constexpr int kNcclSum = 0;      // ncclSum
@@ -31,6 +34,7 @@ struct Rccl {
     fn_comm_init_rank comm_init_rank = nullptr;
     fn_comm_destroy comm_destroy = nullptr;
     fn_all_reduce all_reduce = nullptr;
+    fn_all_gather all_gather = nullptr;
     fn_error_string error_string = nullptr;
 };
 
@@ -56,8 +60,9 @@ Rccl& rccl() {
     r.comm_init_rank = (fn_comm_init_rank)dlsym(r.handle, "ncclCommInitRank");
     r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
     r.all_reduce = (fn_all_reduce)dlsym(r.handle, "ncclAllReduce");
+    r.all_gather = (fn_all_gather)dlsym(r.handle, "ncclAllGather");
     r.error_string = (fn_error_string)dlsym(r.handle, "ncclGetErrorString");
-    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce)
+    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce || !r.all_gather)
         throw InvalidArg{"RCCL library lacks a required symbol"};
     return r;
 }
@@ -107,6 +112,14 @@ void rccl_allreduce_sum_f32(vh_comm* c, float* buf, size_t count, hipStream_t st
 
 void rccl_allreduce_sum_f64(vh_comm* c, double* buf, size_t count, hipStream_t stream) {
     check_nccl(rccl().all_reduce(buf, buf, count, kNcclFloat64, kNcclSum, c->nccl_comm, stream), "ncclAllReduce(f64)");
+}
+
+void rccl_allreduce_sum_u64(vh_comm* c, unsigned long long* buf, size_t count, hipStream_t stream) {
+    check_nccl(rccl().all_reduce(buf, buf, count, kNcclUint64, kNcclSum, c->nccl_comm, stream), "ncclAllReduce(u64)");
+}
+
+void rccl_allgather_u32(vh_comm* c, const uint32_t* send, uint32_t* recv, size_t count, hipStream_t stream) {
+    check_nccl(rccl().all_gather(send, recv, count, kNcclUint32, c->nccl_comm, stream), "ncclAllGather(u32)");
 }
 
 }  // namespace vh

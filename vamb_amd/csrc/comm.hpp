@@ -26,5 +26,9 @@ void rccl_comm_destroy(vh_comm* c);
 // in-place sum all-reduce on `stream` (float32 or float64 elements)
 void rccl_allreduce_sum_f32(vh_comm* c, float* buf, size_t count, hipStream_t stream);
 void rccl_allreduce_sum_f64(vh_comm* c, double* buf, size_t count, hipStream_t stream);
+// exact integer accumulators of the row-sharded cluster scan
+void rccl_allreduce_sum_u64(vh_comm* c, unsigned long long* buf, size_t count, hipStream_t stream);
+// every rank contributes `count` 32-bit words; recv holds world * count words in rank order
+void rccl_allgather_u32(vh_comm* c, const uint32_t* send, uint32_t* recv, size_t count, hipStream_t stream);
 
 }  // namespace vh

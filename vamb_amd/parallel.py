@@ -132,6 +132,16 @@ class ShardedScanBackend:
         self.comm = comm
         self.local = local_backend
         self.L = local_backend.L
+        # Device data plane: with an RCCL communicator and the HIP backend, the query-vector exchange, the accumulator
+        # all-reduce and the select gather run inside libvambhip on the scan stream (vh_clu_scan_sharded /
+        # vh_clu_select_sharded).  Otherwise (CPU tests with the oracle backend, rccl=False) the same exchanges go
+        # through the torch.distributed control plane below; integer accumulators make both bit-identical.
+        self.device_plane = getattr(comm, "handle", None) is not None and getattr(local_backend, "h", None) is not None \
+            and hasattr(local_backend, "lib")
+        if self.device_plane:
+            _lib.check(local_backend.lib.vh_clu_attach_comm(local_backend.h, comm.handle))
+            self._res = (_lib.ScanResult * _MAX_MEDOIDS_PER_PASS)()
+            self._sel = _np.empty(1, _np.int64)
         self._refresh_offsets()
         self.scan_passes = 0
         self.scan_medoids = 0
@@ -142,8 +152,10 @@ class ShardedScanBackend:
         counts = _np.zeros(self.comm.world, dtype=_np.int64)
         counts[self.comm.rank] = self.local.n_rows
         counts = self.comm.all_reduce_sum(counts)
-        self.offsets = _np.concatenate([[0], _np.cumsum(counts)])
+        self.offsets = _np.ascontiguousarray(_np.concatenate([[0], _np.cumsum(counts)]), dtype=_np.int64)
         self.n_rows = int(self.offsets[-1])
+        if getattr(self, "device_plane", False) and len(self._sel) < self.n_rows:
+            self._sel = _np.empty(max(1, self.n_rows), _np.int64)
 
     def _owner_local(self, rows):
         """global rows -> (local row or -1 per entry) for this rank"""
@@ -166,9 +178,16 @@ class ShardedScanBackend:
         step = getattr(self.local, "max_medoids", _MAX_MEDOIDS_PER_PASS)
         for lo in range(0, len(medoids), step):
             chunk = medoids[lo:lo + step]
-            q, local_rows = self._queries(chunk)
-            raw = self.local.scan_raw(local_rows, q)          # int64 [k, 63]
-            raw = self.comm.all_reduce_sum(raw)
+            if self.device_plane:
+                local_rows, _ = self._owner_local(chunk)
+                local_rows = _np.ascontiguousarray(local_rows, dtype=_np.int64)
+                k = len(local_rows)
+                _lib.check(self.local.lib.vh_clu_scan_sharded(self.local.h, k, _lib.ptr(local_rows), self._res))
+                raw = _np.frombuffer(self._res, dtype=_np.int64, count=k * 63).reshape(k, 63).copy()
+            else:
+                q, local_rows = self._queries(chunk)
+                raw = self.local.scan_raw(local_rows, q)          # int64 [k, 63]
+                raw = self.comm.all_reduce_sum(raw)
             self.scan_passes += 1
             self.scan_medoids += len(chunk)
             self.rows_streamed += self.local.n_rows
@@ -176,6 +195,16 @@ class ShardedScanBackend:
         return out
 
     def select(self, medoid: int, threshold: float, remove: bool) -> _np.ndarray:
+        if self.device_plane:
+            local_rows, _ = self._owner_local([medoid])
+            n = ctypes.c_int64(0)
+            thr = float(_np.float32(threshold))
+            _lib.check(self.local.lib.vh_clu_select_sharded(self.local.h, int(local_rows[0]), thr, int(remove),
+                                                            _lib.ptr(self.offsets), _lib.ptr(self._sel), len(self._sel),
+                                                            ctypes.byref(n)))
+            self.scan_passes += 1
+            self.rows_streamed += self.local.n_rows
+            return self._sel[: n.value].copy()
         q, local_rows = self._queries([medoid])
         rows = self.local.select_query(int(local_rows[0]), q[0], threshold, remove)
         self.scan_passes += 1
