@@ -123,11 +123,12 @@ def test_rccl_sharded_scan_equals_local_scan(comm):
     rng = np.random.RandomState(1)
     for k in (1, 3, 8, 9, 16, 25, 32):
         med = rng.choice(20000, k, replace=False).astype(np.int64)
-        want = a.scan_raw(med)
-        got = np.stack([np.concatenate([[round(st.density * 0)], st.hist_fx, [st.n_within, st.n_lt]]) for st in sh.scan(list(med))])
-        assert np.array_equal(got[:, 1:], want[:, 1:]), k
+        want = a.scan_raw(med)          # int64 [k, 63] = density_fx, hist_fx[60], n_within, n_lt
+        stats = sh.scan(list(med))
+        assert np.array_equal(np.stack([st.hist_fx for st in stats]), want[:, 1:61]), k
+        assert [st.n_within for st in stats] == want[:, 61].tolist() and [st.n_lt for st in stats] == want[:, 62].tolist(), k
         want_d = (want[:, 0] / _lib.DENSITY_SCALE).astype(np.float32).astype(np.float64)
-        assert np.array_equal(np.array([st.density for st in sh.scan(list(med))]), want_d), k
+        assert np.array_equal(np.array([st.density for st in stats]), want_d), k
     rows = sh.select(int(med[0]), 0.2, False)
     assert np.array_equal(rows, a.select(int(med[0]), 0.2, False))
     a.close()
