@@ -40,7 +40,7 @@ def test_device_prep_matches_reference_tensors(name):
             assert np.allclose(d, g[key], rtol=2e-6, atol=2e-6), key
 
 
-@pytest.mark.parametrize("n,S", [(1, 1), (2, 3), (33, 7), (100, 8), (513, 9), (1000, 50), (4097, 129), (3000, 200),
+@pytest.mark.parametrize("n,S", [(1, 1), (100, 1), (5000, 1), (2, 3), (600, 2), (33, 7), (100, 8), (513, 9), (1000, 50), (4097, 129), (3000, 200),
                                  (700, 1000), (257, 2500), (20011, 137)])
 def test_device_prep_bit_exact(n, S):
     ab, tnf, lens, _ = synth.features(n, S, seed=n + S)

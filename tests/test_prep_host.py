@@ -152,7 +152,10 @@ def test_column_sums_are_sequential_in_row_order():
     """a.sum(axis=0) / a.mean(axis=0) / a.std(axis=0) of a C-contiguous float32 matrix: one chain per column, rows
     ascending; the mean and variance divide in double and round once (numpy _mean / _var with an intp count)."""
     rng = np.random.RandomState(3)
-    for n, c in [(1000, 7), (4097, 103), (70001, 16)]:
+    # (a single column is a contiguous 1-d reduction: pairwise, not row order -- the device path leaves that case to numpy)
+    one = np.exp(rng.standard_normal((70001, 1))).astype(np.float32)
+    assert np.array_equal(one.sum(axis=0), np.array([one[:, 0].sum()], np.float32))
+    for n, c in [(1000, 2), (1000, 7), (4097, 103), (70001, 16)]:
         a = np.exp(rng.standard_normal((n, c))).astype(np.float32)
         acc = a[0].copy()
         for i in range(1, n):

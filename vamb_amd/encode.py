@@ -258,8 +258,13 @@ def _make_dataloader_device(abundance: _np.ndarray, tnf: _np.ndarray, lengths: _
     try:
         _lib.check(lib.vh_prep_upload(h, _lib.ptr(abundance), _lib.ptr(tnf)))
         # sample_depths_sum = abundance.sum(axis=0)
-        sample_depths_sum = _np.empty(n_samples, _np.float32)
-        _lib.check(lib.vh_prep_column_sums(h, 0, None, _lib.ptr(sample_depths_sum)))
+        if n_samples == 1:
+            # a single column is a contiguous 1-d reduction to numpy (PAIRWISE summation over the rows, not the row-order
+            # chain it runs for wider matrices): 4 n bytes, taken on the host from the caller's array
+            sample_depths_sum = abundance.sum(axis=0)
+        else:
+            sample_depths_sum = _np.empty(n_samples, _np.float32)
+            _lib.check(lib.vh_prep_column_sums(h, 0, None, _lib.ptr(sample_depths_sum)))
         if _np.any(sample_depths_sum == 0):
             raise ValueError("One or more samples have zero depth in all sequences, so cannot be depth normalized")
         scale = _np.ascontiguousarray(1_000_000 / sample_depths_sum, dtype=_np.float32)
