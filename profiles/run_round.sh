@@ -57,14 +57,17 @@ if has sweepab; then     # ONE trained C2 latent matrix clustered under several 
   (cd $R && timeout 900 python tests/gpu_cluster_sweep_ab.py 2000000 200 8192 bf16 300 "${SWEEP_SETTINGS:-VAMBHIP_GEN_PROFILE=1,VAMBHIP_SCAN_LC=1;VAMBHIP_GEN_PROFILE=1,VAMBHIP_SCAN_LC=2;VAMBHIP_GEN_PROFILE=1,VAMBHIP_SCAN_LC=3}" $O/sweep_ab.json > $O/sweep_ab.txt 2>&1)
   cat $O/sweep_ab.txt | cut -c1-300
 fi
-if has pmc; then
-  for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/pmc_$c
-    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- \
-        python $R/bench.py --epochs 2 --steps 1 --warmup 0 --no-cpu-baseline --no-c3 --no-cluster > /dev/null 2> $O/pmc_$c.err
-    f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
-    [ -n "$f" ] && python $R/tests/gpu_pmc_summary.py $f $c > $O/pmc_$c.txt 2>&1
-    tail -15 $O/pmc_$c.txt
+if has pmc; then     # HBM-side traffic of the roofline kernel (K = D encoder GEMM, C2 and C3 shapes) from two --pmc passes
+  for shape in "c2 8192 512 320" "c3 8192 512 1120"; do
+    set -- $shape; tag=$1; M=$2; N=$3; K=$4
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rm -rf /tmp/pmc_$c
+      timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- \
+          python $R/tests/gpu_gemm16_one.py 3 $M $N $K 30 > $O/pmc_${tag}_$c.out 2>&1
+    done
+    f=$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
+    w=$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
+    [ -n "$f" ] && [ -n "$w" ] && python $R/tests/gpu_pmc_traffic.py $f $w "gemm_bf16_kernel<128, 128, 2, 4, 3" $O/pmc_roofline_$tag.json
   done
 fi
 exit 0

@@ -68,7 +68,7 @@ constexpr int kListCap = 2048;    // rows within the medoid radius kept per medo
 constexpr int64_t kMinScanBlocks = 768;   // workgroups wanted before lanes are given more than one row
 constexpr int kListRing = 16;     // scans whose lists stay readable (one cluster search rarely needs more)
 constexpr int kLocalCap = 128;    // per-block, per-medoid staging of list entries in LDS
-constexpr int kSpecWindow = 40;   // speculative seed scans kept ahead of the walk by the native state machine
+constexpr int kSpecWindow = 8;   // speculative seed scans kept ahead of the walk by the native state machine
 
 // medoid rows travel in the kernel arguments (no upload, no gather launch)
 struct MedoidRows {
