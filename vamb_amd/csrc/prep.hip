@@ -88,6 +88,14 @@ __global__ __launch_bounds__(kSumThreads) void prep_column_sums_kernel(const flo
                 acc = tile[buf][0][tid];
                 r = 1;
             }
+            // batches of 16 LDS reads in flight, then the 16 dependent adds (the order of the adds is the row order)
+            for (; r + 16 <= (int)rows; r += 16) {
+                float x[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[i] = tile[buf][r + i][tid];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc = acc + x[i];
+            }
             for (; r < (int)rows; ++r) acc = acc + tile[buf][r][tid];
         }
         if (t + 1 < ntiles) stage(buf ^ 1);
