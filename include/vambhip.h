@@ -291,6 +291,19 @@ int vh_dataset_shape(vh_dataset* d, int64_t* n, int* nsamples);
 /* host copies of the four tensors of make_dataloader's TensorDataset (any pointer may be NULL) */
 int vh_dataset_download(vh_dataset* d, float* depths, float* tnf, float* total_abundance, float* weights);
 
+/* ---- tetranucleotide frequencies: the step upstream of make_dataloader --------------------
+ * vh_tnf_create takes the reference's projection kernel (vamb/kernel.npz, float32 [256][103], vamb/parsecontigs.py:9-15). */
+typedef struct vh_tnf vh_tnf;
+int vh_tnf_create(const float* kernel, vh_tnf** out);
+int vh_tnf_destroy(vh_tnf* t);
+/* vambcore.kmercounts (vamb/vambtools.py:444-447) for n sequences: sequence i = bases[offsets[i] .. offsets[i + 1]);
+ * counts [n][256] uint32 (NULL: keep them on the device for vh_tnf_project).  4-mers containing a byte other than
+ * A C G T (either case) are skipped (the definition test/test_vambtools.py:137-151 pins vambcore.kmercounts to). */
+int vh_tnf_kmercounts(vh_tnf* t, const uint8_t* bases, const int64_t* offsets, int64_t n, uint32_t* counts);
+/* Composition._project (vamb/parsecontigs.py:140-150) + mask_lower_bits(., mask_bits) (parsecontigs.py:211):
+ * fourmers [n][256] float32 (raw counts), or NULL = the counts of the last vh_tnf_kmercounts call; tnf [n][103] */
+int vh_tnf_project(vh_tnf* t, const float* fourmers, int64_t n, int mask_bits, float* tnf);
+
 /* n_epochs consecutive epochs of the same shape with the device-side shuffle and a single host synchronisation
  * at the end (the loop of trainmodel, encode.py:598-601, between two batch-size changes).  global_batch = 0
  * without a communicator.  loss_means: [n_epochs][5] = the five means trainepoch logs per epoch. */

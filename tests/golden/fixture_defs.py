@@ -188,3 +188,24 @@ def vae_randomness(name):
 
 def load(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
+
+
+# ------------------------------------------------------------------------------------------------
+# TNF case (row N2): seeded random sequences over the alphabet of the reference's own k-mer test
+# (test/testtools.py:75-86) plus U / u, lengths 4 .. 6000 and two degenerate ones
+# ------------------------------------------------------------------------------------------------
+TNF_ALPHABET = b"acgtACGTnNywsdbKuU"
+
+
+def tnf_sequences(seed=21, n=40):
+    rng = np.random.RandomState(seed)
+    p = np.array([0.12] * 8 + [0.004] * 10)
+    p = p / p.sum()
+    seqs = []
+    for i in range(n):
+        length = int(rng.choice([4, 5, 17, 128, 1000, 2500, 6000]))
+        idx = rng.choice(len(TNF_ALPHABET), size=length, p=p)
+        seqs.append(bytes(np.frombuffer(TNF_ALPHABET, dtype=np.uint8)[idx]))
+    seqs.append(b"ACG")                 # shorter than one 4-mer
+    seqs.append(b"NNNNNNNNNN")          # no countable 4-mer
+    return seqs

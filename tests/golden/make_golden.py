@@ -7,7 +7,7 @@ vambcore.overwrite_matrix and dadaptation.DAdaptAdam -- the latter restated, PAR
 The GPU box never runs this; tests read the committed .npz files.
 
     python tests/golden/make_golden.py            # regenerate everything
-    python tests/golden/make_golden.py cluster    # only one family (cluster | cluster_large | prep | vae)
+    python tests/golden/make_golden.py cluster    # only one family (cluster | cluster_large | prep | vae | tnf)
 
 Environment recorded in golden_manifest.json (torch / numpy versions, thread count).
 """
@@ -46,6 +46,39 @@ def gen_cluster(cl, cases=None):
                          fallback=int(kinds[2]))
         print("cluster", name, out[name])
     return out
+
+
+def gen_tnf():
+    """kernel.npz and Composition._project from the REAL reference (vamb/parsecontigs.py executed unmodified); the counts by
+    the definition the reference's own test pins vambcore.kmercounts to (test/test_vambtools.py:137-151) -- the Rust wheel is
+    not in this image."""
+    import importlib.util
+    import itertools
+
+    ref_harness.load_reference()
+    spec = importlib.util.spec_from_file_location(
+        "vamb.parsecontigs", os.path.join(ref_harness.REFERENCE_ROOT, "vamb", "parsecontigs.py"))
+    pc = importlib.util.module_from_spec(spec)
+    sys.modules["vamb.parsecontigs"] = pc
+    spec.loader.exec_module(pc)
+    vt = sys.modules["vamb.vambtools"]
+    indexof = {"".join(ncs): idx for (idx, ncs) in enumerate(itertools.product("ACGT", repeat=4))}
+    seqs = fd.tnf_sequences()
+    counts = np.zeros((len(seqs), 256), dtype=np.uint32)
+    for r, seq in enumerate(seqs):
+        text = seq.decode()
+        for i in range(len(text) - 3):
+            ind = indexof.get(text[i:i + 4].upper())
+            if ind is not None:
+                counts[r, ind] += 1
+    proj = pc.Composition._project(counts.astype(np.float32))
+    tnf = np.ascontiguousarray(proj, dtype=np.float32).copy()
+    flat = tnf.reshape(-1)           # a view: mask_lower_bits works in place (vambtools.py:324-330)
+    vt.mask_lower_bits(flat, 12)
+    np.savez_compressed(os.path.join(HERE, "tnf_case.npz"), kernel=np.asarray(pc._KERNEL, dtype=np.float32), counts=counts,
+                        projected=np.asarray(proj, dtype=np.float32), tnf=tnf)
+    print("tnf", counts.shape, proj.shape)
+    return dict(n=len(seqs))
 
 
 def gen_prep(en):
@@ -166,6 +199,8 @@ def main():
                              identical_prefix_with_reference=int(diff[0]) if len(diff) else n)
             print("defined-order", name, out[name])
         manifest["cluster_large_defined_order"] = out
+    if "tnf" in which:
+        manifest["tnf"] = gen_tnf()
     if "prep" in which:
         manifest["prep"] = gen_prep(en)
     if "vae" in which:

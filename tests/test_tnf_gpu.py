@@ -1,0 +1,77 @@
+"""GPU: vh_tnf_kmercounts / vh_tnf_project (csrc/tnf.hip) against the golden case from the real
+reference and the CPU restatement.  Counts: bit-exact.  Projection: everything before the matrix product is bit-identical to
+numpy; the product itself is BLAS sgemm in the reference (summation order unknowable), so the bar is a float32 tolerance:
+1e-6 of the row's largest entry before masking, one unit of the 11-bit masked mantissa after."""
+import numpy as np
+import pytest
+
+import fixture_defs as fd
+import kmer_oracle as ko
+from vamb_amd import composition
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def case():
+    g = fd.load("tnf_case")
+    return g, composition.TnfProjector(g["kernel"])
+
+
+def test_kmercounts_bit_exact(case):
+    g, proj = case
+    seqs = fd.tnf_sequences()
+    got = proj.kmercounts(seqs)
+    assert got.dtype == np.uint32 and np.array_equal(got, g["counts"])
+    assert np.array_equal(proj.kmercounts([]), np.zeros((0, 256), np.uint32))
+    assert np.array_equal(proj.kmercounts([b"", b"ACGTT"]), np.stack([ko.kmercounts(b""), ko.kmercounts(b"ACGTT")]))
+
+
+def test_long_and_many_sequences_bit_exact(case):
+    _, proj = case
+    rng = np.random.RandomState(5)
+    alphabet = np.frombuffer(fd.TNF_ALPHABET, dtype=np.uint8)
+    seqs = [bytes(alphabet[rng.randint(0, 10, size=int(n))]) for n in rng.randint(2000, 30000, size=300)]
+    seqs.append(bytes(alphabet[rng.randint(0, 8, size=1_500_000)]))          # one long contig
+    got = proj.kmercounts(seqs)
+    want = np.stack([ko.kmercounts(s) for s in seqs])
+    assert np.array_equal(got, want)
+    assert int(got[-1].sum()) == 1_500_000 - 3
+
+
+def test_projection_matches_reference(case):
+    g, proj = case
+    raw = g["counts"].astype(np.float32)
+    got = proj.project(raw)
+    ref = g["projected"]
+    scale = np.abs(ref).max(axis=1, keepdims=True) + 1e-30
+    assert np.abs(got - ref).max() <= 1e-6 * max(1.0, float(scale.max())) and np.all(np.abs(got - ref) <= 2e-6 * scale + 1e-9)
+    masked = proj.project(raw, mask_bits=12)
+    assert (masked.view(np.uint32) & 0xFFF).max() == 0
+    # one unit of the 11-bit mantissa that survives the mask
+    assert np.all(np.abs(masked - g["tnf"]) <= np.abs(g["tnf"]) * 2.0 ** -11 + 1e-12)
+    # a row of zero counts: s = 0 -> 1, every fourmer = -1/256 (parsecontigs.py:143-146)
+    z = proj.project(np.zeros((3, 256), np.float32))
+    assert np.allclose(z, ko.project(np.zeros((3, 256), np.float32), g["kernel"]), atol=1e-7)
+
+
+def test_fused_path_equals_separate_calls(case):
+    g, proj = case
+    seqs = fd.tnf_sequences()[:-2]          # the two degenerate sequences would raise, as in Composition.from_file
+    fused = proj.from_sequences(seqs)
+    sep = proj.project(proj.kmercounts(seqs).astype(np.float32), mask_bits=12)
+    assert np.array_equal(fused, sep)
+    with pytest.raises(ValueError):
+        proj.from_sequences(fd.tnf_sequences())
+
+
+def test_deterministic_and_size_independent(case):
+    """The projection of a row does not depend on the other rows of the call (fixed ascending-k accumulation)."""
+    g, proj = case
+    rng = np.random.RandomState(2)
+    raw = rng.poisson(30.0, size=(5000, 256)).astype(np.float32)
+    a = proj.project(raw)
+    b = proj.project(raw[1234:1300])
+    assert np.array_equal(a[1234:1300], b) and np.array_equal(a, proj.project(raw))
+    ref = ko.project(raw, g["kernel"])
+    assert np.abs(a - ref).max() <= 2e-6 * np.abs(ref).max()

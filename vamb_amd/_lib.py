@@ -103,6 +103,10 @@ SIGNATURES = {
     "vh_dataset_create": (_int, [_vp, _vp, _vp, _vp, _i64, _int, ctypes.POINTER(_vp)]),
     "vh_dataset_destroy": (_int, [_vp]),
     "vh_vae_use_dataset": (_int, [_vp, _vp]),
+    "vh_tnf_create": (_int, [_vp, _pp]),
+    "vh_tnf_destroy": (_int, [_vp]),
+    "vh_tnf_kmercounts": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "vh_tnf_project": (_int, [_vp, _vp, _i64, _int, _vp]),
     "vh_prep_create": (_int, [_i64, _int, _pp]),
     "vh_prep_destroy": (_int, [_vp]),
     "vh_prep_upload": (_int, [_vp, _vp, _vp]),

@@ -32,6 +32,7 @@ SOURCES = {
     "vae.hip": [],
     # prep.hip reproduces numpy's float32 results bit for bit: no fused multiply-add
     "prep.hip": ["-ffp-contract=off"],
+    "tnf.hip": ["-ffp-contract=off"],
     "comm.hip": [],
 }
 

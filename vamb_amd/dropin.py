@@ -5,6 +5,7 @@
 (``vamb/__main__.py:1075,1277,1458``), so replacing the attributes is enough for ``vamb bin default`` to
 run on the GPU path unchanged.  The reference's own classes stay importable under ``*_reference`` names;
 ``vamb.semisupervised_encode`` captured the original ``VAE`` base class at import time and is unaffected.
+When ``vamb.parsecontigs`` is imported, ``Composition._project`` (the TNF projection, row N2) is rebound too.
 
     import vamb, vamb_amd.dropin
     vamb_amd.dropin.install()          # or: install(vamb)
@@ -34,7 +35,28 @@ def install(vamb_module=None):
     enc.set_batchsize = _encode.set_batchsize
     clu.ClusterGenerator = _cluster.ClusterGenerator
     clu.Cluster = _cluster.Cluster
+    # row N2: Composition._project (vamb/parsecontigs.py:140-150) is looked up on the class by _convert at call time
+    # (parsecontigs.py:155): every 1000 contigs' worth of raw 4-mer counts is projected on the GPU
+    pc = getattr(vamb_module, "parsecontigs", None)
+    if pc is not None and hasattr(pc, "Composition"):
+        original["_project"] = pc.Composition.__dict__["_project"]
+        pc.Composition._project = staticmethod(_make_project(pc._KERNEL))
     return original
+
+
+def _make_project(default_kernel):
+    """Composition._project with the reference's signature ``(fourmers, kernel=_KERNEL)``; one device projector per kernel."""
+    from . import composition as _composition
+
+    projectors = {}
+
+    def _project(fourmers, kernel=default_kernel):
+        key = id(kernel)
+        if key not in projectors:
+            projectors[key] = _composition.TnfProjector(kernel)
+        return projectors[key].project(fourmers)
+
+    return _project
 
 
 def uninstall(original, vamb_module=None):
@@ -44,3 +66,5 @@ def uninstall(original, vamb_module=None):
     enc.VAE, enc.make_dataloader, enc.set_batchsize = (original["VAE"], original["make_dataloader"],
                                                        original["set_batchsize"])
     clu.ClusterGenerator, clu.Cluster = original["ClusterGenerator"], original["Cluster"]
+    if "_project" in original:
+        vamb_module.parsecontigs.Composition._project = original["_project"]
