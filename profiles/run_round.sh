@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 
 if has tests; then
-  (cd $R && timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log)
+  (cd $R && timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log)
   tail -3 $O/pytest_gpu.log
 fi
 if has bench; then
