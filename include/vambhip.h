@@ -154,6 +154,12 @@ typedef struct {
     double radius;         /* valid for kind 0 and 2 */
     int64_t successes;
     int64_t attempts;
+    /* the generator's state AFTER this cluster (what the reference's attributes show to a caller between two
+     * __next__ calls: peak_valley_ratio, successes, len(attempts), order_index) */
+    double pvr_after;
+    int64_t successes_after;
+    int64_t attempts_after;
+    int64_t order_index_after;
 } vh_cluster_info;
 
 int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, int windowsize, int minsuccesses,

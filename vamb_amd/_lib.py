@@ -33,7 +33,8 @@ class ClusterInfo(ctypes.Structure):                                    # vh_clu
     _fields_ = [("medoid", ctypes.c_int64), ("seed", ctypes.c_int64), ("n_members", ctypes.c_int64),
                 ("kind", ctypes.c_int32), ("pad_", ctypes.c_int32), ("maximal_pvr", ctypes.c_double),
                 ("observed_pvr", ctypes.c_double), ("radius", ctypes.c_double), ("successes", ctypes.c_int64),
-                ("attempts", ctypes.c_int64)]
+                ("attempts", ctypes.c_int64), ("pvr_after", ctypes.c_double), ("successes_after", ctypes.c_int64),
+                ("attempts_after", ctypes.c_int64), ("order_index_after", ctypes.c_int64)]
 
 
 _lib = None

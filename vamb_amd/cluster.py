@@ -446,12 +446,10 @@ class ClusterGenerator:
         self.n_emitted_clusters += 1
         self.n_remaining_points -= int(info.n_members)
         # the attributes the reference exposes (repr, callers inspecting the search state) AFTER update_successes
-        pvr, succ, att, oi = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-        _lib.check(lib.vh_gen_state(self._gen, ctypes.byref(pvr), ctypes.byref(succ), ctypes.byref(att), ctypes.byref(oi)))
-        self.peak_valley_ratio = pvr.value
-        self.successes = succ.value
-        self._native_attempts = att.value
-        self.order_index = oi.value
+        self.peak_valley_ratio = info.pvr_after
+        self.successes = info.successes_after
+        self._native_attempts = info.attempts_after
+        self.order_index = info.order_index_after
         self._counters_stale = True
         return Cluster(int(info.medoid), int(info.seed), members, info.maximal_pvr, observed, radius,
                        int(info.successes), int(info.attempts))
