@@ -263,6 +263,8 @@ __device__ __forceinline__ void scan_flush(int tid, const unsigned long long* __
     }
 }
 
+// (Requesting the first row block before the prologue -- LDS initialisation, query gather, barrier -- to overlap the two
+// memory round trips of a small pass measured neutral at 10^5 rows and 25 % slower at 2 M x 32, k = 8: +25 VGPRs.)
 // LC: latent width known at compile time (0 = runtime L4).  With LC every column load of a lane's rows is issued
 // before the first fmaf, so a wavefront pays one memory round trip per row block instead of L4/4 dependent ones:
 // the matrices the generator scans late in a sweep (10^5 rows, ~1 workgroup per CU) are latency-bound.
@@ -287,23 +289,6 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     float4* hq = hq_s + (tid >> 6) * kHitCap;
-    // Unrolled-load variants: the rows of the FIRST row block are requested before the prologue (LDS initialisation, the
-    // dependent gather of the query vectors, the barrier), so the two memory round trips of a small pass overlap -- most
-    // passes of a sweep stream 10^5 rows, one row block per lane, and are latency-bound.
-    const int64_t base_first = ((int64_t)blockIdx.x * kBlock + tid) * RPT;
-    constexpr int LCX = LC > 0 ? LC : 1;
-    float x[LCX][RPT], len[RPT];     // ONE register set: filled here for the first row block, in the loop for later ones
-    unsigned char live[RPT];
-    if constexpr (LC > 0) {
-        if (base_first < n) {
-            const uint32_t boff = (uint32_t)base_first * 4u;
-            load_live<RPT>(kept + base_first, live);
-#pragma unroll
-            for (int c = 0; c < LC; ++c)
-                load_rows<RPT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mt + (int64_t)c * ld) + boff), x[c]);
-            load_rows<RPT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(lengths) + boff), len);
-        }
-    }
     for (int i = tid; i < KM; i += kBlock) med_s[i] = (int32_t)medoid.row[i];
     for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
     for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
@@ -320,9 +305,10 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
     const float edge_hi = edges_s[VH_NBINS];
     int qn = 0;   // hits queued by this wavefront (uniform)
 
-    for (int64_t base = base_first; base < n; base += (int64_t)gridDim.x * kBlock * RPT) {
-        const bool preloaded = LC > 0 && base == base_first;
-        if (!preloaded) load_live<RPT>(kept + base, live);
+    for (int64_t base = ((int64_t)blockIdx.x * kBlock + tid) * RPT; base < n;
+         base += (int64_t)gridDim.x * kBlock * RPT) {
+        unsigned char live[RPT];
+        load_live<RPT>(kept + base, live);
         bool any = false;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) any = any || (live[r] != 0);
@@ -331,6 +317,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
 
         const float* col = Mt + base;
         (void)col;
+        float len[RPT];
         // Liveness (and the timing switch) folded into a per-row threshold: a pair is of interest iff d <= thr[r]
         // (beyond the last histogram edge, 0.3 > radius, there is nothing to record)
         float thr[RPT];
@@ -386,12 +373,11 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
             // scalar column base + one 32-bit byte offset per lane (n < 2^30 rows, checked at creation): the
             // 32 x RPT loads in flight do not need 32 address pairs
             const uint32_t boff = (uint32_t)base * 4u;
-            if (!preloaded) {
+            float x[LC][RPT];
 #pragma unroll
-                for (int c = 0; c < LC; ++c)
-                    load_rows<RPT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mt + (int64_t)c * ld) + boff), x[c]);
-                load_rows<RPT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(lengths) + boff), len);
-            }
+            for (int c = 0; c < LC; ++c)
+                load_rows<RPT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mt + (int64_t)c * ld) + boff), x[c]);
+            load_rows<RPT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(lengths) + boff), len);
             __builtin_amdgcn_sched_barrier(0);   // every load is issued before the first fmaf ...
             float acc[KM][RPT];
 #pragma unroll
