@@ -205,6 +205,7 @@ __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn
                                            const int32_t* __restrict__ med_s, int dbg,
                                            const float* __restrict__ lengths = nullptr) {
     const float radius = 0.05f;
+    if (dbg & 8) return;   // timing experiment: queued pairs are dropped
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int e = lane; e < qn; e += 64) {
         const float4 v = hq[e];
@@ -243,9 +244,10 @@ __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn
 template <int KM>
 __device__ __forceinline__ void scan_flush(int tid, const unsigned long long* __restrict__ acc_s,
                                            const unsigned int* __restrict__ lcnt_s, const int32_t* __restrict__ llist_s,
-                                           unsigned long long* __restrict__ results, int32_t* __restrict__ lists) {
+                                           unsigned long long* __restrict__ results, int32_t* __restrict__ lists, int dbg = 0) {
     __shared__ unsigned int start_s;
     __syncthreads();
+    if (dbg & 4) return;   // timing experiment: no flush
     for (int i = tid; i < KM * kResultWords; i += kBlock) {
         const unsigned long long v = acc_s[i];
         if (v != 0ull) atomicAdd(&results[i], v);
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
     }
     drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg);
 
-    scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists);
+    scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists, dbg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_mfma_kernel(const float* __re
         }
     }
     drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, lengths);
-    scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists);
+    scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists, dbg);
 }
 
 // Query vectors of a many-medoid pass in quad-major order [L4 / 4][km][4] for the scalar loads of the pipelined scan
