@@ -67,6 +67,12 @@ constexpr int kMaxMedoids = 32;
 constexpr int kListCap = 2048;    // rows within the medoid radius kept per medoid by the scan itself
 constexpr int64_t kMinScanBlocks = 768;   // workgroups wanted before lanes are given more than one row
 constexpr int kListRing = 16;     // scans whose lists stay readable (one cluster search rarely needs more)
+// The pass accumulators exist in kResultReplicas copies: a workgroup flushes its non-zero LDS accumulators into copy
+// blockIdx.x % kResultReplicas, the publish kernel adds the copies up.  With ONE copy every workgroup of a pass added
+// into the same ~25 addresses (density, two counts, the populated histogram bins) and the serialised same-address
+// device atomics were 40 % of the kernel time of a small pass (100 k rows, 1 medoid: 13.1 us with the flush, 7.0 us without;
+// profiles/r02q_scan_ablation.txt).  The list cursor (word 63) lives in copy 0 only.
+constexpr int kResultReplicas = 8;    // (the publish kernel reads and zeroes every copy: more copies cost it more than they save)
 constexpr int kLocalCap = 128;    // per-block, per-medoid staging of list entries in LDS
 constexpr int kSpecWindow = 8;   // speculative seed scans kept ahead of the walk by the native state machine
 
@@ -248,9 +254,10 @@ __device__ __forceinline__ void scan_flush(int tid, const unsigned long long* __
     __shared__ unsigned int start_s;
     __syncthreads();
     if (dbg & 4) return;   // timing experiment: no flush
+    unsigned long long* copy = results + (size_t)(blockIdx.x % kResultReplicas) * kMaxMedoids * kResultWords;
     for (int i = tid; i < KM * kResultWords; i += kBlock) {
         const unsigned long long v = acc_s[i];
-        if (v != 0ull) atomicAdd(&results[i], v);
+        if (v != 0ull) atomicAdd(&copy[i], v);
     }
     for (int j = 0; j < KM; ++j) {
         const unsigned int cnt = lcnt_s[j];
@@ -651,6 +658,18 @@ __global__ __launch_bounds__(kBlock) void clu_gather_quads_kernel(const float* _
     }
 }
 
+// Row-sharded execution: the accumulator copies of a pass are folded into copy 0 before the all-reduce over the ranks
+__global__ __launch_bounds__(kBlock) void clu_fold_replicas_kernel(int km, unsigned long long* __restrict__ results) {
+    for (int i = threadIdx.x; i < km * kResultWords; i += kBlock) {
+        unsigned long long v = results[i];
+        for (int r = 1; r < kResultReplicas; ++r) {
+            v += results[(size_t)r * kMaxMedoids * kResultWords + i];
+            results[(size_t)r * kMaxMedoids * kResultWords + i] = 0ull;
+        }
+        results[i] = v;
+    }
+}
+
 // Row-sharded execution: query vectors of the medoids THIS rank owns (medoid.row[j] >= 0), zeros for the others; the sum
 // all-reduce over the ranks distributes every vector exactly (x + 0 + ... + 0).
 __global__ __launch_bounds__(kBlock) void clu_gather_owned_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
@@ -675,10 +694,25 @@ __global__ __launch_bounds__(kBlock) void clu_publish_kernel(int km, unsigned lo
                                                              unsigned long long* __restrict__ host_flag,
                                                              unsigned long long seq) {
     const int tid = threadIdx.x;
+    // the accumulator copies of the pass are added up first (and zeroed for the next pass)
+    __shared__ unsigned long long red_s[kMaxMedoids * kResultWords];
+#pragma unroll 2
+    for (int i = tid; i < km * kResultWords; i += kBlock) {   // 2 x 8 independent loads in flight per thread
+        unsigned long long part[kResultReplicas];
+#pragma unroll
+        for (int r = 0; r < kResultReplicas; ++r) part[r] = results[(size_t)r * kMaxMedoids * kResultWords + i];
+        unsigned long long v = 0ull;
+#pragma unroll
+        for (int r = 0; r < kResultReplicas; ++r) v += part[r];
+        red_s[i] = v;
+#pragma unroll
+        for (int r = 0; r < kResultReplicas; ++r) results[(size_t)r * kMaxMedoids * kResultWords + i] = 0ull;
+    }
+    __syncthreads();
     // list lengths first (one parallel load), then the copies: 8 lanes per medoid, no dependent load per medoid
     __shared__ int len_s[kMaxMedoids];
     if (tid < km) {
-        const unsigned long long cnt = results[tid * kResultWords + 3 + VH_NBINS];
+        const unsigned long long cnt = red_s[tid * kResultWords + 3 + VH_NBINS];
         len_s[tid] = cnt <= (unsigned long long)kListCap ? (int)cnt : 0;
     }
     __syncthreads();
@@ -691,14 +725,12 @@ __global__ __launch_bounds__(kBlock) void clu_publish_kernel(int km, unsigned lo
     // their own: the host reads 32 bytes per medoid instead of 512 (host reads of this memory are expensive)
     for (int i = tid; i < km * 4; i += kBlock) {
         const int j = i >> 2, w = i & 3;
-        host_summary[i] = results[j * kResultWords + (w == 0 ? 0 : VH_NBINS + w)];
+        host_summary[i] = red_s[j * kResultWords + (w == 0 ? 0 : VH_NBINS + w)];
     }
     for (int i = tid; i < km * VH_NBINS; i += kBlock) {
         const int j = i / VH_NBINS, b = i - j * VH_NBINS;
-        host_hist[i] = results[j * kResultWords + 1 + b];
+        host_hist[i] = red_s[j * kResultWords + 1 + b];
     }
-    __syncthreads();
-    for (int i = tid; i < km * kResultWords; i += kBlock) results[i] = 0ull;
     __threadfence_system();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1180,7 +1212,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->scan_lc = (int)option("scan.column_loop", 1);
         h->use_mfma = option("scan.mfma", 1) != 0;
         h->scan_dbg = (int)option("scan.debug", 0);
-        h->results.alloc((size_t)kMaxMedoids * kResultWords);
+        h->results.alloc((size_t)kResultReplicas * kMaxMedoids * kResultWords);
         h->lists_dev.alloc((size_t)kMaxMedoids * kListCap);
         VH_HIP(hipHostMalloc((void**)&h->lists, (size_t)kListRing * kMaxMedoids * kListCap * sizeof(int32_t),
                              hipHostMallocMapped | hipHostMallocCoherent));
@@ -1297,7 +1329,11 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
     dispatch_scan(h, km, med, q_ext);
     h->timer.stop(h->stream);
     // the exact integer accumulators of all shards: order-free sums, so the result does not depend on the sharding
-    if (sharded) rccl_allreduce_sum_u64(h->comm, h->results.p, (size_t)km * kResultWords, h->stream);
+    if (sharded) {
+        hipLaunchKernelGGL(clu_fold_replicas_kernel, dim3(1), dim3(kBlock), 0, h->stream, km, h->results.p);
+        VH_HIP(hipGetLastError());
+        rccl_allreduce_sum_u64(h->comm, h->results.p, (size_t)km * kResultWords, h->stream);
+    }
     hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->mfma_pass ? k : km, h->results.p, h->lists_dev.p, lists,
                        h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1));
     VH_HIP(hipGetLastError());
