@@ -35,8 +35,8 @@ def test_device_prep_matches_reference_tensors(name):
         if key in ("depths", "tnf"):
             assert np.array_equal(d, g[key]), key
         else:
-            # total_abundance and weights go through numpy's float32 log, whose SIMD kernel (AVX512F / AVX2 dispatch)
-            # differs in the last ulp between the CPU the goldens were made on and this host; everything else is exact
+            # total_abundance and weights go through numpy's float32 log, whose SIMD kernel is chosen per host CPU
+            # (AVX512F / AVX2 dispatch): robust against a last-ulp difference between the golden's CPU and this host
             assert np.allclose(d, g[key], rtol=2e-6, atol=2e-6), key
 
 
