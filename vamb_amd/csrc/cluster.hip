@@ -686,18 +686,21 @@ __global__ __launch_bounds__(kBlock) void clu_gather_owned_kernel(const float* _
 // the host spins on.  (A separate launch, not a last-block-done tail of the scan: the kernel boundary is the
 // cheap way to make the other XCDs' L2 contents visible -- a per-block agent-scope fence writes L2 back and
 // made the scan 5x slower.)
-__global__ __launch_bounds__(kBlock) void clu_publish_kernel(int km, unsigned long long* __restrict__ results,
-                                                             const int32_t* __restrict__ lists,
-                                                             int32_t* __restrict__ host_lists,
-                                                             unsigned long long* __restrict__ host_summary,
-                                                             unsigned long long* __restrict__ host_hist,
-                                                             unsigned long long* __restrict__ host_flag,
-                                                             unsigned long long seq) {
+constexpr int kPublishThreads = 1024;   // ONE workgroup (the flag must follow every write), but a wide one: the kernel is
+                                        // a chain of memory round trips -- measured 8.4 us per pass with 256 threads
+                                        // and 8 lanes per candidate list (profiles/r02t_kernel_stats_bench_c1_full.csv)
+__global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, unsigned long long* __restrict__ results,
+                                                                      const int32_t* __restrict__ lists,
+                                                                      int32_t* __restrict__ host_lists,
+                                                                      unsigned long long* __restrict__ host_summary,
+                                                                      unsigned long long* __restrict__ host_hist,
+                                                                      unsigned long long* __restrict__ host_flag,
+                                                                      unsigned long long seq) {
     const int tid = threadIdx.x;
     // the accumulator copies of the pass are added up first (and zeroed for the next pass)
     __shared__ unsigned long long red_s[kMaxMedoids * kResultWords];
 #pragma unroll 2
-    for (int i = tid; i < km * kResultWords; i += kBlock) {   // 2 x 8 independent loads in flight per thread
+    for (int i = tid; i < km * kResultWords; i += kPublishThreads) {   // 2 x 8 independent loads in flight per thread
         unsigned long long part[kResultReplicas];
 #pragma unroll
         for (int r = 0; r < kResultReplicas; ++r) part[r] = results[(size_t)r * kMaxMedoids * kResultWords + i];
@@ -706,28 +709,33 @@ __global__ __launch_bounds__(kBlock) void clu_publish_kernel(int km, unsigned lo
         for (int r = 0; r < kResultReplicas; ++r) v += part[r];
         red_s[i] = v;
 #pragma unroll
-        for (int r = 0; r < kResultReplicas; ++r) results[(size_t)r * kMaxMedoids * kResultWords + i] = 0ull;
+        for (int r = 0; r < kResultReplicas; ++r)
+            if (part[r] != 0ull) results[(size_t)r * kMaxMedoids * kResultWords + i] = 0ull;
     }
     __syncthreads();
-    // list lengths first (one parallel load), then the copies: 8 lanes per medoid, no dependent load per medoid
-    __shared__ int len_s[kMaxMedoids];
-    if (tid < km) {
-        const unsigned long long cnt = red_s[tid * kResultWords + 3 + VH_NBINS];
-        len_s[tid] = cnt <= (unsigned long long)kListCap ? (int)cnt : 0;
-    }
-    __syncthreads();
+    // candidate lists: 32 lanes per medoid, four independent loads in flight per lane
     {
-        const int j = tid >> 3, l = tid & 7;   // 256 threads = 32 medoids x 8 lanes
-        if (j < km)
-            for (int i = l; i < len_s[j]; i += 8) host_lists[j * kListCap + i] = lists[j * kListCap + i];
+        const int j = tid >> 5, l = tid & 31;   // 1024 threads = 32 medoids x 32 lanes
+        if (j < km) {
+            const unsigned long long cnt = red_s[j * kResultWords + 3 + VH_NBINS];
+            const int len = cnt <= (unsigned long long)kListCap ? (int)cnt : 0;
+            const int32_t* src = lists + j * kListCap;
+            int32_t* dst = host_lists + j * kListCap;
+            int i = l;
+            for (; i + 96 < len; i += 128) {
+                const int32_t v0 = src[i], v1 = src[i + 32], v2 = src[i + 64], v3 = src[i + 96];
+                dst[i] = v0; dst[i + 32] = v1; dst[i + 64] = v2; dst[i + 96] = v3;
+            }
+            for (; i < len; i += 32) dst[i] = src[i];
+        }
     }
     // the four words every candidate needs (density, n_within, n_lt, list cursor) go to a compact block of
     // their own: the host reads 32 bytes per medoid instead of 512 (host reads of this memory are expensive)
-    for (int i = tid; i < km * 4; i += kBlock) {
+    for (int i = tid; i < km * 4; i += kPublishThreads) {
         const int j = i >> 2, w = i & 3;
         host_summary[i] = red_s[j * kResultWords + (w == 0 ? 0 : VH_NBINS + w)];
     }
-    for (int i = tid; i < km * VH_NBINS; i += kBlock) {
+    for (int i = tid; i < km * VH_NBINS; i += kPublishThreads) {
         const int j = i / VH_NBINS, b = i - j * VH_NBINS;
         host_hist[i] = red_s[j * kResultWords + 1 + b];
     }
@@ -1334,7 +1342,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
         VH_HIP(hipGetLastError());
         rccl_allreduce_sum_u64(h->comm, h->results.p, (size_t)km * kResultWords, h->stream);
     }
-    hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->mfma_pass ? k : km, h->results.p, h->lists_dev.p, lists,
+    hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, h->mfma_pass ? k : km, h->results.p, h->lists_dev.p, lists,
                        h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1));
     VH_HIP(hipGetLastError());
     wait_for_scan(h, h->scan_seq + 1);
