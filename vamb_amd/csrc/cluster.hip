@@ -695,7 +695,7 @@ __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, un
                                                                       unsigned long long* __restrict__ host_summary,
                                                                       unsigned long long* __restrict__ host_hist,
                                                                       unsigned long long* __restrict__ host_flag,
-                                                                      unsigned long long seq) {
+                                                                      unsigned long long seq, int dbg) {
     const int tid = threadIdx.x;
     // the accumulator copies of the pass are added up first (and zeroed for the next pass)
     __shared__ unsigned long long red_s[kMaxMedoids * kResultWords];
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, un
     // candidate lists: 32 lanes per medoid, four independent loads in flight per lane
     {
         const int j = tid >> 5, l = tid & 31;   // 1024 threads = 32 medoids x 32 lanes
-        if (j < km) {
+        if (j < km && !(dbg & 16)) {   // (16 / 32: timing experiments -- no list copy / no histogram publication)
             const unsigned long long cnt = red_s[j * kResultWords + 3 + VH_NBINS];
             const int len = cnt <= (unsigned long long)kListCap ? (int)cnt : 0;
             const int32_t* src = lists + j * kListCap;
@@ -735,10 +735,11 @@ __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, un
         const int j = i >> 2, w = i & 3;
         host_summary[i] = red_s[j * kResultWords + (w == 0 ? 0 : VH_NBINS + w)];
     }
-    for (int i = tid; i < km * VH_NBINS; i += kPublishThreads) {
-        const int j = i / VH_NBINS, b = i - j * VH_NBINS;
-        host_hist[i] = red_s[j * kResultWords + 1 + b];
-    }
+    if (!(dbg & 32))
+        for (int i = tid; i < km * VH_NBINS; i += kPublishThreads) {
+            const int j = i / VH_NBINS, b = i - j * VH_NBINS;
+            host_hist[i] = red_s[j * kResultWords + 1 + b];
+        }
     __threadfence_system();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1343,7 +1344,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
         rccl_allreduce_sum_u64(h->comm, h->results.p, (size_t)km * kResultWords, h->stream);
     }
     hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, h->mfma_pass ? k : km, h->results.p, h->lists_dev.p, lists,
-                       h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1));
+                       h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1), h->scan_dbg);
     VH_HIP(hipGetLastError());
     wait_for_scan(h, h->scan_seq + 1);
     if (h->timer.enabled) {
