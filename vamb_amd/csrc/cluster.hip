@@ -690,8 +690,6 @@ constexpr int kPublishThreads = 1024;   // ONE workgroup (the flag must follow e
                                         // a chain of memory round trips -- measured 8.4 us per pass with 256 threads
                                         // and 8 lanes per candidate list (profiles/r02t_kernel_stats_bench_c1_full.csv)
 __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, unsigned long long* __restrict__ results,
-                                                                      const int32_t* __restrict__ lists,
-                                                                      int32_t* __restrict__ host_lists,
                                                                       unsigned long long* __restrict__ host_summary,
                                                                       unsigned long long* __restrict__ host_hist,
                                                                       unsigned long long* __restrict__ host_flag,
@@ -713,22 +711,7 @@ __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, un
             if (part[r] != 0ull) results[(size_t)r * kMaxMedoids * kResultWords + i] = 0ull;
     }
     __syncthreads();
-    // candidate lists: 32 lanes per medoid, four independent loads in flight per lane
-    {
-        const int j = tid >> 5, l = tid & 31;   // 1024 threads = 32 medoids x 32 lanes
-        if (j < km && !(dbg & 16)) {   // (16 / 32: timing experiments -- no list copy / no histogram publication)
-            const unsigned long long cnt = red_s[j * kResultWords + 3 + VH_NBINS];
-            const int len = cnt <= (unsigned long long)kListCap ? (int)cnt : 0;
-            const int32_t* src = lists + j * kListCap;
-            int32_t* dst = host_lists + j * kListCap;
-            int i = l;
-            for (; i + 96 < len; i += 128) {
-                const int32_t v0 = src[i], v1 = src[i + 32], v2 = src[i + 64], v3 = src[i + 96];
-                dst[i] = v0; dst[i + 32] = v1; dst[i + 64] = v2; dst[i + 96] = v3;
-            }
-            for (; i < len; i += 32) dst[i] = src[i];
-        }
-    }
+    // (the candidate lists are already in the host-mapped ring: the scan kernels append them there)
     // the four words every candidate needs (density, n_within, n_lt, list cursor) go to a compact block of
     // their own: the host reads 32 bytes per medoid instead of 512 (host reads of this memory are expensive)
     for (int i = tid; i < km * 4; i += kPublishThreads) {
@@ -964,7 +947,9 @@ struct vh_clu {
     DevBuf<unsigned long long> results;
     // host-mapped (pinned, coherent) publication buffers written by the scan kernel itself
     int32_t* lists = nullptr;     // [kListRing][kMaxMedoids][kListCap] rows within the medoid radius, per scan
-    DevBuf<int32_t> lists_dev;    // [kMaxMedoids][kListCap] staging of the running scan (its last block copies out)
+    int32_t* lists_pass = nullptr;   // ring slot of the running pass: the scan kernels append the candidate lists straight into
+                                     // host-mapped memory (posted PCIe writes spread over the scan; the publish kernel's
+                                     // copy of them was 4.5 of its 10 us, profiles/run_publish_ablation.sh)
     unsigned long long* host_results = nullptr;   // [kListRing][kMaxMedoids][4] summaries, [kListRing][kMaxMedoids]
                                                   // [VH_NBINS] histograms, 1 flag word (offsets below)
     unsigned long long* summary(int slot) { return host_results + (size_t)slot * kMaxMedoids * 4; }
@@ -1055,7 +1040,7 @@ void launch_scan_lc(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     const int64_t blocks = ceil_div(h->ld, (int64_t)kBlock * RPT);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
     hipLaunchKernelGGL((clu_scan_kernel<KM, RPT, LC, PIPE>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
-                       h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_dev.p, h->scan_dbg);
+                       h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_pass, h->scan_dbg);
 }
 
 template <int KM, int RPT>
@@ -1107,7 +1092,7 @@ void launch_scan_mfma(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     // three workgroups per CU are resident (LDS): one resident set, every wavefront strides over its tiles
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(tiles, kBlock / 64), 256 * 3));
     hipLaunchKernelGGL((clu_scan_mfma_kernel<NK>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
-                       h->lengths.p, h->kept.p, q_ext, med, h->mfma_k, h->results.p, h->lists_dev.p, h->scan_dbg);
+                       h->lengths.p, h->kept.p, q_ext, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg);
 }
 
 // more than 8 medoids and a latent width the B operand registers hold: the matrix-pipe kernel (always 32 medoid slots)
@@ -1222,7 +1207,6 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->use_mfma = option("scan.mfma", 1) != 0;
         h->scan_dbg = (int)option("scan.debug", 0);
         h->results.alloc((size_t)kResultReplicas * kMaxMedoids * kResultWords);
-        h->lists_dev.alloc((size_t)kMaxMedoids * kListCap);
         VH_HIP(hipHostMalloc((void**)&h->lists, (size_t)kListRing * kMaxMedoids * kListCap * sizeof(int32_t),
                              hipHostMallocMapped | hipHostMallocCoherent));
         const size_t host_words = (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS) + 1;
@@ -1334,6 +1318,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
     }
     const int slot = (int)(h->scan_seq % kListRing);
     int32_t* lists = h->lists + (size_t)slot * kMaxMedoids * kListCap;
+    h->lists_pass = lists;
     h->timer.start(h->stream);
     dispatch_scan(h, km, med, q_ext);
     h->timer.stop(h->stream);
@@ -1343,7 +1328,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
         VH_HIP(hipGetLastError());
         rccl_allreduce_sum_u64(h->comm, h->results.p, (size_t)km * kResultWords, h->stream);
     }
-    hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, h->mfma_pass ? k : km, h->results.p, h->lists_dev.p, lists,
+    hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, h->mfma_pass ? k : km, h->results.p,
                        h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1), h->scan_dbg);
     VH_HIP(hipGetLastError());
     wait_for_scan(h, h->scan_seq + 1);
