@@ -686,9 +686,9 @@ __global__ __launch_bounds__(kBlock) void clu_gather_owned_kernel(const float* _
 // the host spins on.  (A separate launch, not a last-block-done tail of the scan: the kernel boundary is the
 // cheap way to make the other XCDs' L2 contents visible -- a per-block agent-scope fence writes L2 back and
 // made the scan 5x slower.)
-constexpr int kPublishThreads = 1024;   // ONE workgroup (the flag must follow every write), but a wide one: the kernel is
-                                        // a chain of memory round trips -- measured 8.4 us per pass with 256 threads
-                                        // and 8 lanes per candidate list (profiles/r02t_kernel_stats_bench_c1_full.csv)
+constexpr int kPublishThreads = 256;    // ONE workgroup (the flag must follow every write).  Measured, C1 sweep under rocprofv3:
+                                        // 256 threads + list copy 8.4 us average / 2.9 us minimum per pass; 1024 threads 9.1 /
+                                        // 5.4 us (a 16-wavefront workgroup starts later and 1024 threads sit in the system fence)
 __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, unsigned long long* __restrict__ results,
                                                                       unsigned long long* __restrict__ host_summary,
                                                                       unsigned long long* __restrict__ host_hist,
@@ -697,8 +697,8 @@ __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, un
     const int tid = threadIdx.x;
     // the accumulator copies of the pass are added up first (and zeroed for the next pass)
     __shared__ unsigned long long red_s[kMaxMedoids * kResultWords];
-#pragma unroll 2
-    for (int i = tid; i < km * kResultWords; i += kPublishThreads) {   // 2 x 8 independent loads in flight per thread
+#pragma unroll 4
+    for (int i = tid; i < km * kResultWords; i += kPublishThreads) {   // up to 4 x 8 independent loads in flight per thread
         unsigned long long part[kResultReplicas];
 #pragma unroll
         for (int r = 0; r < kResultReplicas; ++r) part[r] = results[(size_t)r * kMaxMedoids * kResultWords + i];
