@@ -101,3 +101,32 @@ def test_header_is_plain_c(tmp_path):
         out = tmp_path / "use_all"
         subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(out), lib,
                                "-Wl,-rpath," + os.path.dirname(lib), "-Wl,--allow-shlib-undefined"])
+
+
+def test_options_replace_environment_variables(monkeypatch):
+    """The library reads no environment variable: options are set through vh_set_option, and the Python layer forwards the
+    VAMBHIP_* variables when a handle is created (_lib.sync_env_options)."""
+    from vamb_amd import _lib
+
+    lib = _lib.load()
+    assert _lib.get_option("scan.column_loop", 1) == 1          # unset: the caller's default comes back
+    _lib.check(lib.vh_set_option(b"scan.column_loop", 0))
+    assert _lib.get_option("scan.column_loop", 1) == 0
+    _lib.check(lib.vh_unset_option(b"scan.column_loop"))
+    assert _lib.get_option("scan.column_loop", 7) == 7
+    monkeypatch.setenv("VAMBHIP_SPEC_WINDOW", "12")
+    monkeypatch.setenv("VAMBHIP_NO_SPECULATION", "1")
+    monkeypatch.delenv("VAMBHIP_SCAN_MFMA", raising=False)
+    _lib.sync_env_options()
+    assert _lib.get_option("gen.spec_window", -1) == 12 and _lib.get_option("gen.speculate", 1) == 0
+    assert _lib.get_option("scan.mfma", 1) == 1
+    monkeypatch.delenv("VAMBHIP_SPEC_WINDOW")
+    monkeypatch.delenv("VAMBHIP_NO_SPECULATION")
+    _lib.sync_env_options()
+    assert _lib.get_option("gen.spec_window", -1) == -1 and _lib.get_option("gen.speculate", 1) == 1
+    # no getenv left in the native sources
+    import glob, os
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vamb_amd", "csrc")
+    for path in glob.glob(os.path.join(root, "*.h*")):
+        assert "getenv" not in open(path).read(), path
