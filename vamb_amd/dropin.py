@@ -41,6 +41,13 @@ def install(vamb_module=None):
     if pc is not None and hasattr(pc, "Composition"):
         original["_project"] = pc.Composition.__dict__["_project"]
         pc.Composition._project = staticmethod(_make_project(pc._KERNEL))
+    # row N3: the output loop of `vamb bin default` (vamb/__main__.py:1254-1404); its callers look the name up in the module
+    main = sys.modules.get(vamb_module.__name__ + ".__main__")
+    if main is not None and hasattr(main, "cluster_and_write_files"):
+        from . import output as _output
+
+        original["cluster_and_write_files"] = main.cluster_and_write_files
+        main.cluster_and_write_files = _output.cluster_and_write_files
     return original
 
 
@@ -68,3 +75,5 @@ def uninstall(original, vamb_module=None):
     clu.ClusterGenerator, clu.Cluster = original["ClusterGenerator"], original["Cluster"]
     if "_project" in original:
         vamb_module.parsecontigs.Composition._project = original["_project"]
+    if "cluster_and_write_files" in original:
+        sys.modules[vamb_module.__name__ + ".__main__"].cluster_and_write_files = original["cluster_and_write_files"]
