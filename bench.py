@@ -441,6 +441,13 @@ def main():
                                        "(bias + leaky-relu + dropout + BatchNorm batch sums in the epilogue)", peak)
         if roof is not None:
             roof["traffic"] = pmc_traffic(cfg_name.lower())
+            if roof["traffic"]:
+                # the same launches against the other roofline: at C2 the kernel's arithmetic intensity (flops / PMC bytes)
+                # is below the ridge of 2.5 PFLOP/s : 8 TB/s = 312 flop/B, i.e. it is the HBM side that binds there
+                gbps = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9
+                roof["hbm_side"] = {"achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                                    "flop_per_byte": roof["flops_per_launch"] / roof["traffic"], "ridge_flop_per_byte":
+                                    peak * 1e12 / (PEAK_HBM_GBPS * 1e9)}
         line = {
             "metric": "contigs/sec through VAE-train+encode+cluster; VAE epoch step time",
             "value": job_contigs * K / elapsed,
