@@ -162,6 +162,7 @@ _ENV_OPTIONS = {
     "VAMBHIP_SCAN_LC": ("scan.column_loop", int),
     "VAMBHIP_SCAN_MFMA": ("scan.mfma", int),
     "VAMBHIP_SCAN_WIDE": ("scan.wide_rows", lambda v: 1),
+    "VAMBHIP_SCAN_MIN_BLOCKS": ("scan.min_blocks", int),
     "VAMBHIP_SCAN_DBG": ("scan.debug", int),
     "VAMBHIP_GEN_PROFILE": ("gen.profile", lambda v: 1),
     "VAMBHIP_NO_SPECULATION": ("gen.speculate", lambda v: 0),

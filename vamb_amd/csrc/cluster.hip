@@ -967,6 +967,7 @@ struct vh_clu {
     int mfma_k = 0;               // its medoid count
     int scan_lc = 1;              // column-loop variant (VAMBHIP_SCAN_LC, A/B measurements): 0 runtime-width loop everywhere,
                                   // 1 unrolled loads up to 8 medoids + pipelined query / row fetches from 12 medoids
+    int64_t min_blocks = kMinScanBlocks;   // option scan.min_blocks: workgroups wanted before lanes take more than one row
     bool small_rpt = true;        // VAMBHIP_SCAN_WIDE=1 disables the narrow variant (A/B measurements)
     uint64_t scan_seq = 0;        // number of scans issued; scan s wrote ring slot s % kListRing
     int last_k = 0;
@@ -1073,7 +1074,7 @@ void launch_scan(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     constexpr int RPT = (KM >= 12) ? 2 : 4;
     int rpt = RPT;
     if (h->small_rpt)
-        while (rpt > 1 && ceil_div(h->n_rows, (int64_t)kBlock * rpt) < kMinScanBlocks) rpt >>= 1;
+        while (rpt > 1 && ceil_div(h->n_rows, (int64_t)kBlock * rpt) < h->min_blocks) rpt >>= 1;
     if (rpt == 1) launch_scan_rpt<KM, 1>(h, med, q_ext);
     else if (rpt == 2) launch_scan_rpt<KM, 2>(h, med, q_ext);
     else launch_scan_rpt<KM, RPT>(h, med, q_ext);
@@ -1203,6 +1204,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
             VH_REQUIRE(h->max_k >= 1, "latent width %d does not fit the scan kernel's LDS", L);
         }
         h->small_rpt = option("scan.wide_rows", 0) == 0;
+        h->min_blocks = option("scan.min_blocks", kMinScanBlocks);
         h->scan_lc = (int)option("scan.column_loop", 1);
         h->use_mfma = option("scan.mfma", 1) != 0;
         h->scan_dbg = (int)option("scan.debug", 0);
