@@ -251,7 +251,7 @@ template <int KM>
 __device__ __forceinline__ void scan_flush(int tid, const unsigned long long* __restrict__ acc_s,
                                            const unsigned int* __restrict__ lcnt_s, const int32_t* __restrict__ llist_s,
                                            unsigned long long* __restrict__ results, int32_t* __restrict__ lists, int dbg = 0) {
-    __shared__ unsigned int start_s;
+    __shared__ unsigned int start_s[kMaxMedoids];
     __syncthreads();
     if (dbg & 4) return;   // timing experiment: no flush
     unsigned long long* copy = results + (size_t)(blockIdx.x % kResultReplicas) * kMaxMedoids * kResultWords;
@@ -259,16 +259,22 @@ __device__ __forceinline__ void scan_flush(int tid, const unsigned long long* __
         const unsigned long long v = acc_s[i];
         if (v != 0ull) atomicAdd(&copy[i], v);
     }
+    // The cursor atomics of ALL medoids with local entries go out together (thread j owns medoid j): one round trip.
+    // (They used to be issued one medoid at a time between two barriers -- a returning device atomic each, ~1 us -- which made
+    // the flush of a workgroup holding members of many medoids the longest part of a dense pass.)
+    if (tid < KM) {
+        const unsigned int cnt = lcnt_s[tid];
+        if (cnt != 0u) {
+            unsigned int* cursor = reinterpret_cast<unsigned int*>(&results[tid * kResultWords + 3 + VH_NBINS]);
+            start_s[tid] = cnt > (unsigned int)kLocalCap ? atomicOr(cursor, 0x80000000u) | 0x80000000u : atomicAdd(cursor, cnt);
+        }
+    }
+    __syncthreads();
     for (int j = 0; j < KM; ++j) {
         const unsigned int cnt = lcnt_s[j];
         if (cnt == 0u) continue;
-        unsigned int* cursor = reinterpret_cast<unsigned int*>(&results[j * kResultWords + 3 + VH_NBINS]);
-        if (tid == 0) start_s = cnt > (unsigned int)kLocalCap ? atomicOr(cursor, 0x80000000u) | 0x80000000u
-                                                              : atomicAdd(cursor, cnt);
-        __syncthreads();
-        const unsigned int start = start_s;
+        const unsigned int start = start_s[j];
         if (start + cnt <= (unsigned int)kListCap && tid < (int)cnt) lists[j * kListCap + start + tid] = llist_s[j * kLocalCap + tid];
-        __syncthreads();
     }
 }
 
