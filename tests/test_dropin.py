@@ -58,3 +58,43 @@ def test_state_dict_spec_matches_reference():
         assert names == list(ref.keys())
         for k in names:
             assert tuple(ve.VAE._shape_of(me, k)) == tuple(ref[k].shape), k
+
+
+@pytest.mark.skipif(not ref_harness.reference_available(), reason="reference tree not present")
+def test_install_rebinds_the_output_writer_and_the_tnf_projection():
+    """dropin.install also rebinds vamb.__main__.cluster_and_write_files (row N3: every binner of the reference -- default,
+    taxvamb, avamb -- writes its clusters through that one function, vamb/__main__.py:1266,1523,2050) and
+    Composition._project (row N2) when those modules are loaded.  vamb/__main__.py cannot be imported in this image, so a
+    stand-in module object carries the attribute."""
+    import importlib.util
+    import os
+    import sys
+    import types
+
+    ref_harness.load_reference()
+    vamb = sys.modules["vamb"]
+    from vamb_amd import dropin, output
+
+    spec = importlib.util.spec_from_file_location("vamb.parsecontigs",
+                                                  os.path.join(ref_harness.REFERENCE_ROOT, "vamb", "parsecontigs.py"))
+    pc = importlib.util.module_from_spec(spec)
+    sys.modules["vamb.parsecontigs"] = pc
+    spec.loader.exec_module(pc)
+    vamb.parsecontigs = pc
+    main = types.ModuleType("vamb.__main__")
+    main.cluster_and_write_files = object()
+    sys.modules["vamb.__main__"] = main
+    ref_project = pc.Composition.__dict__["_project"]
+    saved = dropin.install(vamb)
+    try:
+        assert main.cluster_and_write_files is output.cluster_and_write_files
+        assert pc.Composition.__dict__["_project"] is not ref_project
+        import inspect
+
+        ours = [(p.name, p.default) for p in inspect.signature(pc.Composition._project).parameters.values()]
+        theirs = [(p.name, p.default is not inspect.Parameter.empty) for p in inspect.signature(ref_project.__func__).parameters.values()]
+        assert [n for n, _ in ours] == [n for n, _ in theirs] == ["fourmers", "kernel"]
+    finally:
+        dropin.uninstall(saved, vamb)
+        del sys.modules["vamb.__main__"]
+    assert pc.Composition.__dict__["_project"] is ref_project
