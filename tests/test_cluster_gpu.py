@@ -33,7 +33,10 @@ def test_normalize_bit_exact(oracle_lib, n, L):
 
 
 @pytest.mark.parametrize("n,L,k", [(1, 8, 1), (700, 32, 1), (5000, 32, 3), (5000, 40, 8), (20000, 32, 12),
-                                   (20000, 64, 25), (3000, 3, 32), (2049, 15, 17)])
+                                   (20000, 64, 25), (3000, 3, 32), (2049, 15, 17),
+                                   # latent spaces wider than the matrix-pipe kernel's operand registers (L > 64): more than 8
+                                   # medoids take the VALU kernel with scalar-cache queries (quad-major gather)
+                                   (5000, 96, 25), (4000, 132, 12), (3000, 72, 9)])
 def test_scan_accumulators_bit_exact(oracle_lib, n, L, k):
     lat, _ = synth.blob_latent(n, L, 0.2, seed=n + k, k=max(2, n // 300))
     lens = synth.lengths(n, 3)
