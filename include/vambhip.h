@@ -40,7 +40,9 @@ const char* vh_version(void);
  *   scan.column_loop (1)   0: runtime-width column loop in every scan kernel; 1: unrolled loads up to 8 medoids
  *   scan.mfma (1)          passes with more than 8 medoids on the matrix-pipe kernel
  *   scan.wide_rows (0)     fixed 4 / 2 rows per lane (no narrow variants for small matrices)
- *   scan.debug (0)         timing experiments only (wrong results): 1 no pair of interest, 2 no histogram
+ *   scan.min_blocks (768)  workgroups wanted before lanes take more than one row (measured neutral between 384 and 1536)
+ *   scan.debug (0)         timing experiments only (wrong results): 1 no pair of interest, 2 no histogram, 4 no flush,
+ *                          8 no drain, 32 no histogram publication
  *   gen.profile (0)        wall-clock breakdown of the native cluster state machine on stderr
  *   gen.speculate (1), gen.spec_window (40), gen.spec_big_target (0)   speculative seed scans
  *   vae.single_stream (0)  weight-gradient GEMMs on the main stream
