@@ -84,8 +84,8 @@ __global__ __launch_bounds__(kSumThreads) void prep_column_sums_kernel(const flo
         if (tid < kColsPerBlock) {
             const int64_t rows = min((int64_t)kTileRows, n - t * kTileRows);
             int r = 0;
-            if (t == 0) {   // the reduction starts from the first row (not from +0: a column of -0.0 sums to -0.0)
-                acc = tile[buf][0][tid];
+            if (t == 0) {   // numpy's add.reduce starts from its identity +0.0: a column of -0.0 sums to +0.0 (0.0f + -0.0f)
+                acc = 0.0f + tile[buf][0][tid];
                 r = 1;
             }
             // batches of 16 LDS reads in flight, then the 16 dependent adds (the order of the adds is the row order)

@@ -455,7 +455,7 @@ void prepare_batch(vh_vae* h, int bs) {
         if (!t.dsrc) t.slab = h->slabs.p + reinterpret_cast<size_t>(t.slab);
         TensorDesc& d = tab.d[tab.n];
         d.dsrc = t.dsrc;
-        d.dscale = t.dsrc_allrank && h->comm && h->syncbn && h->comm->world > 1 ? 1.0f / (float)h->comm->world : 1.0f;
+        d.dscale = t.dsrc_allrank && h->comm && h->comm->world > 1 ? 1.0f / (float)h->comm->world : 1.0f;
         d.slab = t.slab;
         d.nslab = t.nslab;
         d.stride = t.stride;
@@ -591,6 +591,10 @@ void join_side(vh_vae* h) {
 // like the single-process reference (encode.py:238,246,264).
 bool syncbn_active(const vh_vae* h) { return h->comm != nullptr && h->syncbn && h->global_bs > 0; }
 int stat_bs(const vh_vae* h) { return syncbn_active(h) ? h->global_bs : h->bs; }
+// 1 when this step's BatchNorm sums really are all-rank sums: only then are the gamma / beta gradient accumulators scaled
+// by 1 / world before the gradient all-reduce (same predicate as sync_stats; a step without a global batch keeps
+// per-rank statistics and per-rank gradients)
+int allrank_stats(const vh_vae* h) { return syncbn_active(h) && h->comm->world > 1 ? 1 : 0; }
 void sync_stats(vh_vae* h, double* stats, int n_p) {
     if (syncbn_active(h) && h->comm->world > 1) rccl_allreduce_sum_f64(h->comm, stats, (size_t)2 * n_p, h->stream);
 }
@@ -888,7 +892,8 @@ void optimizer_step(vh_vae* h) {
     if (h->comm) {
         // sum this rank's slabs into the flat buffer, all-reduce it over the ranks (RCCL, same stream,
         // no host synchronisation), then every rank applies the identical update
-        hipLaunchKernelGGL(vae_reduce_slabs_kernel, dim3(h->opt_blocks), dim3(256), 0, h->stream, h->opt_tab, h->G.p);
+        hipLaunchKernelGGL(vae_reduce_slabs_kernel, dim3(h->opt_blocks), dim3(256), 0, h->stream, h->opt_tab, h->G.p,
+                           allrank_stats(h));
         VH_HIP(hipGetLastError());
         rccl_allreduce_sum_f32(h->comm, h->G.p, h->flat_elems, h->stream);
         tab = &h->opt_tab_flat;
@@ -1144,7 +1149,7 @@ int vh_vae_get_grad(vh_vae* h, const char* name, float* data, int64_t n) {
         if (h->bf16) {
             // the complete gradient (slab sums + BatchNorm completion) as the optimiser forms it, through the flat buffer
             hipLaunchKernelGGL(vae_grad16_kernel, dim3(h->opt16_blocks), dim3(256), 0, h->stream, h->opt16_tab.p, h->opt16_n,
-                               stat_bs(h), h->G.p, 0);
+                               stat_bs(h), h->G.p, 0, allrank_stats(h));
             VH_HIP(hipGetLastError());
             std::vector<float> buf((size_t)t.padded());
             VH_HIP(hipMemcpyAsync(buf.data(), h->G.p + t.off, sizeof(float) * buf.size(), hipMemcpyDeviceToHost, h->stream));

@@ -537,7 +537,8 @@ __global__ __launch_bounds__(256) void vae_latent_bwd_kernel(const float* __rest
 // ---- D-Adapt-Adam (dadaptation==3.2 DAdaptAdam.step as Vamb configures it, encode.py:578) ----------
 struct TensorDesc {
     const double* dsrc;   // if non-null the gradient is this fp64 accumulator (bias / gamma / beta of hidden layers)
-    float dscale;         // factor on dsrc: 1, or 1 / world for accumulators that are already all-rank sums (SyncBN)
+    float dscale;         // 1 / world for accumulators that SyncBN turns into all-rank sums (applied only in a step that
+                          // really all-reduced the statistics: the kernels' `allrank` argument), 1 otherwise
     const float* slab;    // gradient slabs; g[i] = sum_s slab[s*stride + i]
     int nslab;
     int64_t stride;
@@ -560,11 +561,12 @@ __device__ __forceinline__ int opt_find_tensor(const OptTable& tab, int blk) {
     return t;
 }
 
-__device__ __forceinline__ float4 fetch_grad(const TensorDesc& td, int64_t local) {
+__device__ __forceinline__ float4 fetch_grad(const TensorDesc& td, int64_t local, int allrank = 0) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (td.dsrc) {
-        g.x = (float)td.dsrc[local + 0] * td.dscale; g.y = (float)td.dsrc[local + 1] * td.dscale;
-        g.z = (float)td.dsrc[local + 2] * td.dscale; g.w = (float)td.dsrc[local + 3] * td.dscale;
+        const float sc = allrank ? td.dscale : 1.0f;
+        g.x = (float)td.dsrc[local + 0] * sc; g.y = (float)td.dsrc[local + 1] * sc;
+        g.z = (float)td.dsrc[local + 2] * sc; g.w = (float)td.dsrc[local + 3] * sc;
         return g;
     }
     // eight slab loads in flight per round (same ascending summation order as before)
@@ -590,12 +592,12 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 // data-parallel path: G[flat] = sum of this rank's gradient slabs (then all-reduced over the ranks)
-__global__ __launch_bounds__(256) void vae_reduce_slabs_kernel(const OptTable tab, float* __restrict__ G) {
+__global__ __launch_bounds__(256) void vae_reduce_slabs_kernel(const OptTable tab, float* __restrict__ G, int allrank) {
     const int t = opt_find_tensor(tab, blockIdx.x);
     const TensorDesc& td = tab.d[t];
     const int64_t local = (int64_t)(blockIdx.x - tab.blk_start[t]) * 1024 + threadIdx.x * 4;
     if (local >= td.size) return;
-    *reinterpret_cast<float4*>(G + td.p_off + local) = fetch_grad(td, local);
+    *reinterpret_cast<float4*>(G + td.p_off + local) = fetch_grad(td, local, allrank);
 }
 
 __global__ void vae_scale_kernel(float* __restrict__ v, int64_t n, float f) {

@@ -479,7 +479,7 @@ __global__ void vae_latent_bwd16_kernel(const float* __restrict__ slabs, int nsl
 // gradient of a weight that consumes BatchNorm-ed activations is completed here:  dW = G diag(s) + dbias t^T.
 struct Opt16Tensor {
     const double* dsrc;   // fp64 accumulator gradient (vectors), or nullptr
-    float dscale;         // factor on dsrc: 1, or 1 / world for accumulators that are already all-rank sums (SyncBN)
+    float dscale;         // 1 / world for accumulators that SyncBN turns into all-rank sums (see TensorDesc::dscale)
     const float* slab;    // split-K slabs (matrices)
     int nslab;
     int rows_p, cols_p;   // padded shape (vectors: rows_p == 1)
@@ -499,11 +499,12 @@ constexpr int kMaxOpt16 = 4 * 2 * 8 + 4;
 
 // gradient of 4 consecutive elements (tensor-local index `local` = row * cols_p + col): slab sum or fp64 accumulator,
 // completed for weights that consume BatchNorm-ed activations:  dW = G diag(s) + dbias t^T
-__device__ __forceinline__ float4 opt16_grad(const Opt16Tensor& td, int64_t local, int row, int col, int bs) {
+__device__ __forceinline__ float4 opt16_grad(const Opt16Tensor& td, int64_t local, int row, int col, int bs, int allrank = 0) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (td.dsrc) {
-        g.x = (float)td.dsrc[local + 0] * td.dscale; g.y = (float)td.dsrc[local + 1] * td.dscale;
-        g.z = (float)td.dsrc[local + 2] * td.dscale; g.w = (float)td.dsrc[local + 3] * td.dscale;
+        const float sc = allrank ? td.dscale : 1.0f;
+        g.x = (float)td.dsrc[local + 0] * sc; g.y = (float)td.dsrc[local + 1] * sc;
+        g.z = (float)td.dsrc[local + 2] * sc; g.w = (float)td.dsrc[local + 3] * sc;
         return g;
     }
     int s = 0;
@@ -550,7 +551,7 @@ __device__ __forceinline__ bool opt16_locate(const Opt16Tensor& td, int lb, int&
 
 // data-parallel path: G[flat] = this rank's complete gradient (then all-reduced over the ranks)
 __global__ __launch_bounds__(256) void vae_grad16_kernel(const Opt16Tensor* __restrict__ tab, int ntensors, int bs,
-                                                         float* __restrict__ G, int blk0) {
+                                                         float* __restrict__ G, int blk0, int allrank) {
     const int blk = (int)blockIdx.x + blk0;   // the launch covers the table's workgroups [blk0, blk0 + gridDim.x)
     int t = 0;
     while (t + 1 < ntensors && blk >= tab[t + 1].blk_start) ++t;
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(256) void vae_grad16_kernel(const Opt16Tensor* __re
     int row, col;
     int64_t local;
     if (!opt16_locate(td, blk - td.blk_start, row, col, local)) return;
-    *reinterpret_cast<float4*>(G + td.p_off + local) = opt16_grad(td, local, row, col, bs);
+    *reinterpret_cast<float4*>(G + td.p_off + local) = opt16_grad(td, local, row, col, bs, allrank);
 }
 
 __global__ __launch_bounds__(256) void vae_dadapt16_kernel(const Opt16Tensor* __restrict__ tab, int ntensors, int bs,

@@ -163,7 +163,7 @@ void build_opt16_table(vh_vae* h) {
         d.rows_p = t.rows_p; d.cols_p = t.cols_p;
         d.p_off = (int64_t)t.off;
         d.blk_start = nblk;
-        d.dscale = t.dsrc_allrank && h->comm && h->syncbn && h->comm->world > 1 ? 1.0f / (float)h->comm->world : 1.0f;
+        d.dscale = t.dsrc_allrank && h->comm && h->comm->world > 1 ? 1.0f / (float)h->comm->world : 1.0f;
         if (!t.matrix) {
             d.dsrc = t.dsrc;
             nblk += (int)ceil_div(t.cols_p, 1024);
@@ -445,7 +445,7 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
             q.add([h](hipStream_t st) {
                 const int nb = h->opt16_blocks - h->opt16_bucketA_blk0;
                 hipLaunchKernelGGL(vae_grad16_kernel, dim3(nb), dim3(256), 0, st, h->opt16_tab.p, h->opt16_n, stat_bs(h), h->G.p,
-                                   h->opt16_bucketA_blk0);
+                                   h->opt16_bucketA_blk0, allrank_stats(h));
                 VH_HIP(hipGetLastError());
                 rccl_allreduce_sum_f32(h->comm, h->G.p + h->opt16_bucketA_off, h->flat_elems - h->opt16_bucketA_off, st);
             });
@@ -500,7 +500,7 @@ void optimizer_step16(vh_vae* h) {
     if (h->comm) {
         // bucket B (encoder + mu; bucket A went out on the side stream during the encoder's backward, joined by now)
         hipLaunchKernelGGL(vae_grad16_kernel, dim3(h->opt16_bucketA_blk0), dim3(256), 0, h->stream, h->opt16_tab.p, h->opt16_n,
-                           stat_bs(h), h->G.p, 0);
+                           stat_bs(h), h->G.p, 0, allrank_stats(h));
         VH_HIP(hipGetLastError());
         rccl_allreduce_sum_f32(h->comm, h->G.p, h->opt16_bucketA_off, h->stream);
         tab = h->opt16_tab_flat.p;

@@ -5,7 +5,8 @@
 (``vamb/__main__.py:1075,1277,1458``), so replacing the attributes is enough for ``vamb bin default`` to
 run on the GPU path unchanged.  The reference's own classes stay importable under ``*_reference`` names;
 ``vamb.semisupervised_encode`` captured the original ``VAE`` base class at import time and is unaffected.
-When ``vamb.parsecontigs`` is imported, ``Composition._project`` (the TNF projection, row N2) is rebound too.
+``Composition._project`` (the TNF projection, row N2) and ``cluster_and_write_files`` (row N3) are rebound too; the
+submodules are imported on demand and a hook that cannot be installed is reported with a ``RuntimeWarning``.
 
     import vamb, vamb_amd.dropin
     vamb_amd.dropin.install()          # or: install(vamb)
@@ -36,33 +37,102 @@ def install(vamb_module=None):
     clu.ClusterGenerator = _cluster.ClusterGenerator
     clu.Cluster = _cluster.Cluster
     # row N2: Composition._project (vamb/parsecontigs.py:140-150) is looked up on the class by _convert at call time
-    # (parsecontigs.py:155): every 1000 contigs' worth of raw 4-mer counts is projected on the GPU
-    pc = getattr(vamb_module, "parsecontigs", None)
+    # (parsecontigs.py:155): every 1000 contigs' worth of raw 4-mer counts is projected on the GPU.  The submodule is
+    # imported here if the caller has not done so yet (a hook that is silently skipped leaves the slow path running).
+    pc = _submodule(vamb_module, "parsecontigs")
     if pc is not None and hasattr(pc, "Composition"):
         original["_project"] = pc.Composition.__dict__["_project"]
         pc.Composition._project = staticmethod(_make_project(pc._KERNEL))
-    # row N3: the output loop of `vamb bin default` (vamb/__main__.py:1254-1404); its callers look the name up in the module
-    main = sys.modules.get(vamb_module.__name__ + ".__main__")
-    if main is not None and hasattr(main, "cluster_and_write_files"):
-        from . import output as _output
+    else:
+        _warn("vamb.parsecontigs.Composition not found: the TNF projection stays on the reference's numpy path")
+    # row N3: the output loop of `vamb bin default` (vamb/__main__.py:1254-1404); its callers look the name up in the
+    # module.  Under `python -m vamb` that module is registered as `__main__`, under an entry-point script as
+    # `vamb.__main__`: every module object that is vamb's __main__ is patched.
+    from . import output as _output
 
-        original["cluster_and_write_files"] = main.cluster_and_write_files
-        main.cluster_and_write_files = _output.cluster_and_write_files
+    mains = _main_modules(vamb_module)
+    original["cluster_and_write_files"] = [(m, m.cluster_and_write_files) for m in mains]
+    for m in mains:
+        m.cluster_and_write_files = _output.cluster_and_write_files
+    if not mains:
+        _warn("vamb.__main__ is not importable: cluster_and_write_files stays the reference's")
     return original
 
 
+def _warn(msg: str) -> None:
+    import warnings
+
+    warnings.warn("vamb_amd.dropin: " + msg, RuntimeWarning, stacklevel=3)
+
+
+def _submodule(vamb_module, name: str):
+    """``vamb.<name>``, imported on demand (None if it cannot be imported, e.g. a stub package in the tests)."""
+    mod = getattr(vamb_module, name, None)
+    if mod is None:
+        import importlib
+
+        try:
+            mod = importlib.import_module(vamb_module.__name__ + "." + name)
+        except Exception:
+            return None
+    return mod
+
+
+def _main_modules(vamb_module):
+    """Every module object that is vamb's ``__main__``: ``vamb.__main__`` (imported on demand) and, under
+    ``python -m vamb``, the running ``__main__`` itself (importing ``vamb.__main__`` then would run the CLI twice)."""
+    import os
+
+    pkg_dirs = {os.path.abspath(str(p)) for p in getattr(vamb_module, "__path__", [])}
+
+    def is_vambs_main(m) -> bool:
+        f = getattr(m, "__file__", None)
+        return bool(f) and os.path.basename(f).startswith("__main__") and os.path.dirname(os.path.abspath(f)) in pkg_dirs
+
+    found = []
+    running = sys.modules.get("__main__")
+    if running is not None and is_vambs_main(running):
+        found.append(running)
+    named = sys.modules.get(vamb_module.__name__ + ".__main__")
+    if named is None and not found:
+        named = _submodule(vamb_module, "__main__")
+    if named is not None and named not in found:
+        found.append(named)
+    return [m for m in found if hasattr(m, "cluster_and_write_files")]
+
+
+_MAX_PROJECTORS = 4
+
+
 def _make_project(default_kernel):
-    """Composition._project with the reference's signature ``(fourmers, kernel=_KERNEL)``; one device projector per kernel."""
+    """Composition._project with the reference's signature ``(fourmers, kernel=_KERNEL)``.
+
+    One device projector per kernel CONTENT (shape + bytes): ``id(kernel)`` is reused by CPython once an array is
+    collected and says nothing about an in-place edit.  The cache is bounded; an evicted projector releases its stream
+    and device buffers."""
+    import collections
+
+    import numpy as _np
+
     from . import composition as _composition
 
-    projectors = {}
+    projectors = collections.OrderedDict()
 
     def _project(fourmers, kernel=default_kernel):
-        key = id(kernel)
-        if key not in projectors:
-            projectors[key] = _composition.TnfProjector(kernel)
-        return projectors[key].project(fourmers)
+        k = _np.ascontiguousarray(kernel, dtype=_np.float32)
+        key = (k.shape, k.tobytes())   # 105 KB: negligible next to the [n x 256] counts of a call
+        proj = projectors.get(key)
+        if proj is None:
+            proj = _composition.TnfProjector(k)
+            projectors[key] = proj
+            while len(projectors) > _MAX_PROJECTORS:
+                _, old = projectors.popitem(last=False)
+                old.close()
+        else:
+            projectors.move_to_end(key)
+        return proj.project(fourmers)
 
+    _project._projectors = projectors   # introspection (tests)
     return _project
 
 
@@ -75,5 +145,5 @@ def uninstall(original, vamb_module=None):
     clu.ClusterGenerator, clu.Cluster = original["ClusterGenerator"], original["Cluster"]
     if "_project" in original:
         vamb_module.parsecontigs.Composition._project = original["_project"]
-    if "cluster_and_write_files" in original:
-        sys.modules[vamb_module.__name__ + ".__main__"].cluster_and_write_files = original["cluster_and_write_files"]
+    for m, fn in original.get("cluster_and_write_files", []):
+        m.cluster_and_write_files = fn

@@ -204,10 +204,65 @@ def _device_prep_possible(abundance: _np.ndarray, tnf: _np.ndarray, required: bo
     return False
 
 
+class _LazyHostTensor:
+    """Stand-in for one tensor of a device-prepared dataset.  ``.shape`` / ``len()`` / ``.size()`` / ``.dtype`` -- all the
+    reference's drivers ever read (``data_loader.dataset.tensors[0].shape``, vamb/__main__.py:1073-1074,1119,1135) --
+    cost nothing; anything that needs the VALUES (indexing, ``.numpy()``, any torch function) downloads the dataset from
+    HBM once and behaves like the real ``torch.Tensor`` from then on."""
+
+    __slots__ = ("_owner", "_index", "shape")
+
+    def __init__(self, owner, index: int, shape):
+        self._owner = owner
+        self._index = index
+        self.shape = _torch.Size(shape)
+
+    dtype = _torch.float32
+    device = _torch.device("cpu")
+
+    def _real(self):
+        return self._owner._materialise()[self._index]
+
+    def __len__(self) -> int:
+        return self.shape[0]
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self) -> int:
+        return len(self.shape)
+
+    ndim = property(dim)
+
+    def __getitem__(self, index):
+        return self._real()[index]
+
+    def __iter__(self):
+        return iter(self._real())
+
+    def __getattr__(self, name):   # only reached for names not defined above
+        return getattr(self._real(), name)
+
+    def __repr__(self) -> str:
+        return f"<device-resident float32 tensor of shape {tuple(self.shape)} (host copy made on first element access)>"
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def real(x):
+            if isinstance(x, _LazyHostTensor):
+                return x._real()
+            if isinstance(x, (list, tuple)):
+                return type(x)(real(y) for y in x)
+            return x
+
+        return func(*real(args), **{k: real(v) for k, v in (kwargs or {}).items()})
+
+
 class _PreparedDataset(_torch.utils.data.Dataset):
     """The TensorDataset of make_dataloader when the features were normalised on the device: the four tensors live
-    in HBM (``vh_dataset``); ``.tensors`` materialises host copies on first use (the reference's callers only hand
-    the loader to VAE.trainmodel / VAE.encode, which never need them)."""
+    in HBM (``vh_dataset``).  ``.tensors`` is a tuple of shape-only proxies (``_LazyHostTensor``): reading a shape never
+    moves data; host copies are made on the first access to an element (the reference's callers only hand the loader to
+    VAE.trainmodel / VAE.encode, which never need them)."""
 
     def __init__(self, lib, handle, n: int, nsamples: int):
         self._lib = lib
@@ -215,13 +270,14 @@ class _PreparedDataset(_torch.utils.data.Dataset):
         self.n = int(n)
         self.nsamples = int(nsamples)
         self._tensors = None
+        shapes = ((self.n, self.nsamples), (self.n, NTNF), (self.n, 1), (self.n, 1))
+        self._proxies = tuple(_LazyHostTensor(self, i, sh) for i, sh in enumerate(shapes))
 
     @property
     def _vambhip_prepared(self):
         return self
 
-    @property
-    def tensors(self):
+    def _materialise(self):
         if self._tensors is None:
             d = _np.empty((self.n, self.nsamples), _np.float32)
             t = _np.empty((self.n, NTNF), _np.float32)
@@ -231,11 +287,15 @@ class _PreparedDataset(_torch.utils.data.Dataset):
             self._tensors = tuple(_torch.from_numpy(x) for x in (d, t, a, w))
         return self._tensors
 
+    @property
+    def tensors(self):
+        return self._tensors if self._tensors is not None else self._proxies
+
     def __len__(self) -> int:
         return self.n
 
     def __getitem__(self, index):
-        return tuple(t[index] for t in self.tensors)
+        return tuple(t[index] for t in self._materialise())
 
     def __del__(self):
         try:

@@ -16,8 +16,11 @@ Two planes
 Training semantics under data parallelism: every rank holds a contiguous row shard and contributes
 ``global_batch / world`` rows to each step; the loss of a step is normalised by the ALL-RANK batch so
 the summed gradients equal the single-GPU gradient of the same global batch.  BatchNorm batch
-statistics are per-rank (as in torch DDP without SyncBatchNorm); running statistics are averaged over
-ranks after every epoch so that all ranks encode with the same network.
+statistics are synchronised by default (``syncbn=True``: the fp64 sums of every BatchNorm layer are
+all-reduced in stream order, forward and backward, so a step computes what the single-process
+reference computes on the global batch, vamb/encode.py:238,246); ``syncbn=False`` keeps per-rank
+statistics (torch DDP without SyncBatchNorm) and averages the running statistics over the ranks after
+every epoch so that all ranks encode with the same network.
 """
 from __future__ import annotations
 
