@@ -209,3 +209,52 @@ def tnf_sequences(seed=21, n=40):
     seqs.append(b"ACG")                 # shorter than one 4-mer
     seqs.append(b"NNNNNNNNNN")          # no countable 4-mer
     return seqs
+
+
+# ------------------------------------------------------------------------------------------------
+# End-to-end statistical parity: free-running training + clustering on synthetic
+# features; compared through loss curves and bin quality, never bit for bit
+# ------------------------------------------------------------------------------------------------
+E2E_CASES = {
+    # the CLI schedule (vamb/__main__.py:2412-2431: 300 epochs, batch 256 doubling at 25/75/150/225) at a tenth of the epochs
+    "e2e_n20k_s50_cli": dict(n=20000, nsamples=50, data_seed=1, nepochs=30, batchsize=256, batchsteps=[3, 8, 15, 22],
+                             model_seeds=[0, 1, 2, 3, 4]),
+}
+
+
+def bin_quality(labels, members, kinds=None, big=10):
+    """Agreement of a clustering with the synthetic genomes.  ``labels``: int [n] genome of every contig; ``members``: list of
+    index arrays (one per cluster, covering every contig exactly once).  Returns plain python numbers:
+    n_clusters, kind counts, ARI over all contigs, number of clusters with >= ``big`` members, the fraction of contigs in such
+    clusters, their (size-weighted) purity, and how many genomes are recovered (>= 90 % of the genome in one cluster that is
+    >= 95 % pure)."""
+    from sklearn.metrics import adjusted_rand_score
+
+    labels = np.asarray(labels)
+    n = len(labels)
+    pred = np.full(n, -1, np.int64)
+    for i, m in enumerate(members):
+        pred[np.asarray(m)] = i
+    assert (pred >= 0).all(), "clusters do not cover every contig"
+    sizes = np.array([len(m) for m in members])
+    genome_size = np.bincount(labels)
+    in_big = 0
+    pure_w = 0.0
+    recovered = 0
+    for i, m in enumerate(members):
+        if sizes[i] < big:
+            continue
+        lab = labels[np.asarray(m)]
+        counts = np.bincount(lab)
+        top = int(counts.argmax())
+        in_big += sizes[i]
+        pure_w += counts[top]
+        if counts[top] >= 0.95 * sizes[i] and counts[top] >= 0.9 * genome_size[top]:
+            recovered += 1
+    out = dict(n_clusters=int(len(members)), n_big=int((sizes >= big).sum()), frac_in_big=float(in_big / n),
+               purity_big=float(pure_w / max(in_big, 1)), genomes_recovered=int(recovered),
+               n_genomes=int((genome_size > 0).sum()), ari=float(adjusted_rand_score(labels, pred)))
+    if kinds is not None:
+        for k in ("normal", "loner", "fallback"):
+            out["kind_" + k] = int(sum(1 for x in kinds if x == k))
+    return out

@@ -7,7 +7,7 @@ vambcore.overwrite_matrix and dadaptation.DAdaptAdam -- the latter restated, PAR
 The GPU box never runs this; tests read the committed .npz files.
 
     python tests/golden/make_golden.py            # regenerate everything
-    python tests/golden/make_golden.py cluster    # only one family (cluster | cluster_large | prep | vae | tnf)
+    python tests/golden/make_golden.py cluster    # only one family (cluster | cluster_large | prep | vae | tnf | e2e)
 
 Environment recorded in golden_manifest.json (torch / numpy versions, thread count).
 """
@@ -166,6 +166,26 @@ def gen_vae(en):
     return out
 
 
+def gen_e2e():
+    """End-to-end runs of the real reference over several model seeds: loss curves + bin quality.  Free-running
+    RNG, 8 threads (the CLI default, vamb/__main__.py:27-28): the stored numbers are a SPREAD to land in, not values to match."""
+    import e2e_reference as e2e
+
+    out = {}
+    for name, c in fd.E2E_CASES.items():
+        runs = [e2e.run_reference(c["n"], c["nsamples"], c["nepochs"], c["batchsize"], c["batchsteps"], seed,
+                                  c["data_seed"], threads=8) for seed in c["model_seeds"]]
+        rec = dict(losses=np.stack([r["losses"] for r in runs]), model_seeds=np.array(c["model_seeds"], np.int64))
+        for k in runs[0]:
+            if k != "losses":
+                rec[k] = np.array([r[k] for r in runs], np.float64)
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+        out[name] = {k: [float(x) for x in rec[k]] for k in ("n_clusters", "n_big", "ari", "purity_big", "genomes_recovered")}
+        out[name]["loss_last"] = [float(x) for x in rec["losses"][:, -1, 0]]
+        print("e2e", name, out[name])
+    return out
+
+
 def main():
     which = sys.argv[1:] or ["cluster", "prep", "vae"]
     import torch
@@ -205,6 +225,8 @@ def main():
         manifest["prep"] = gen_prep(en)
     if "vae" in which:
         manifest["vae"] = gen_vae(en)
+    if "e2e" in which:   # minutes of reference CPU time; 8 threads, free-running RNG
+        manifest["e2e"] = gen_e2e()
     json.dump(manifest, open(manifest_path, "w"), indent=1, sort_keys=True)
 
 

@@ -746,7 +746,7 @@ void loss_and_seed(vh_vae* h) {
     // the scalar reduction (loss means, sum of weights) is only needed by the optimiser: side stream; the
     // output layer's weight gradient (backward) forks off the same point
     launch_forking(h, vae_loss_kernel, dim3(h->loss_blocks), dim3(256), 0, a);
-    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, h->side, h->loss_part.p, h->loss_blocks,
+    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(kLossFinThreads), 0, h->side, h->loss_part.p, h->loss_blocks,
                        h->Wb.p, h->bs, h->gwsum_src, bs_global, h->state.p);
     VH_HIP(hipGetLastError());
 }

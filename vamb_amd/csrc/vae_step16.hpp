@@ -374,7 +374,7 @@ void loss_and_seed16(vh_vae* h, SideQueue& q) {
     // the scalar reduction (loss means, sum of weights) is only needed by the optimiser
     const float* gw = h->gwsum_src;
     q.add([h, bs_global, gw](hipStream_t st) {
-        hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, st, h->loss_part.p, h->loss_blocks, h->Wb.p,
+        hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(kLossFinThreads), 0, st, h->loss_part.p, h->loss_blocks, h->Wb.p,
                            h->bs, gw, bs_global, h->state.p);
         VH_HIP(hipGetLastError());
     });
