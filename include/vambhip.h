@@ -48,6 +48,8 @@ const char* vh_version(void);
  *   vae.single_stream (0)  weight-gradient GEMMs on the main stream
  *   vae.fork_events (0)    forks as event records instead of kernel completion signals
  *   vae.big_tiles (0), vae.xcd_remap (1), vae.dw_workgroups (256), vae.debug_timing (0)
+ *   vae.gemm_pipeline (2)  K loop of the bf16 GEMMs: 2 = three LDS buffers, DMA issue interleaved with the MFMAs; 0 = two buffers
+ *   vae.dw_row_major (1)   bf16 weight gradients contract row-major tensors (transposing LDS reads); 0 = transposed bf16 copies
  * String options: comm.rccl_library (path of librccl), comm.rocm_path (default /opt/rocm). */
 int vh_set_option(const char* name, int64_t value);
 int vh_unset_option(const char* name);
@@ -374,6 +376,15 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
  * *ms = average duration of `reps` back-to-back launches. */
 int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, float* C, float* CT, double* stats, int M,
                     int N, int K, int splits, int reps, int variant, float* ms);
+
+/* Diagnostic: the row-major weight-gradient GEMM (gemm_bf16_tn.hpp; reference shape: dW = dZ^T In of a Linear layer's
+ * backward, vamb/encode.py:226-249,419) on host data.  A [K][M] and B [K][N] are rounded to bf16 on the host;
+ * C[m][n] = sum_k A[k][m] B[k][n] (split-K slabs summed on return); colsum (optional) [M] = sum over k < k_real of the
+ * rounded A[k][m] (the fused bias gradient).  tile: 0 = by output shape as in the training step, 1 = 128x128 / 8 waves,
+ * 3 = 64x128 / 4 waves; pipeline: 0 = two LDS buffers, 2 = three buffers with interleaved DMA issue.
+ * *ms = average duration of `reps` back-to-back launches. */
+int vh_debug_gemm16_tn(const float* A, const float* B, float* C, double* colsum, int M, int N, int K, int k_real, int splits,
+                       int reps, int tile, int pipeline, float* ms);
 
 #ifdef __cplusplus
 }

@@ -142,8 +142,63 @@ def test_gemm16_hidden_epilogue(shape):
     assert rel(C, want) < 2.0 ** -8                      # one bf16 rounding of the output
     assert np.array_equal(CT, C.T)                       # both copies carry the same bits
     assert np.array_equal(bf16_round(C), C)              # ... which are bf16 values
-    assert np.allclose(stats[0], C.astype(np.float64).sum(axis=0), rtol=1e-5, atol=1e-3)
-    assert np.allclose(stats[1], (C.astype(np.float64) ** 2).sum(axis=0), rtol=1e-5, atol=1e-3)
+    # the batch sums are taken from the fp32 values BEFORE the bf16 rounding of the stored copy
+    assert np.allclose(stats[0], want.sum(axis=0), rtol=1e-5, atol=1e-3)
+    assert np.allclose(stats[1], (want ** 2).sum(axis=0), rtol=1e-5, atol=1e-3)
+
+
+# every K-tile count from 1 to 8 plus the C3 encoder's 17.5 (prologue / steady triple / tail of the three-buffer loop), ragged
+# M and N; 21 / 23 / 27 = 128x128 (8 waves), 64x128, 128x128 (4 waves) with the interleaved DMA issue; 1 / 3 / 7 = the same
+# tiles on the two-buffer loop
+@pytest.mark.parametrize("variant", [21, 23, 27, 1, 3, 7])
+@pytest.mark.parametrize("K", [64, 128, 136, 192, 256, 320, 384, 448, 512, 1120])
+def test_gemm16_pipelines(K, variant):
+    M, N = 264, 136
+    rng = np.random.RandomState(K + variant)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = (rng.standard_normal((N, K)) + 0.25 * np.arange(N)[:, None] / N).astype(np.float32)
+    want = bf16_round(A).astype(np.float64) @ bf16_round(B).astype(np.float64).T
+    C, _, _ = _gemm16(0, A, B, variant=variant)
+    assert rel(C, want) < 2e-6 * np.sqrt(K)
+    if K >= 256:   # split-K slabs of uneven length
+        C, _, _ = _gemm16(0, A, B, splits=3, variant=variant)
+        assert rel(C, want) < 2e-6 * np.sqrt(K)
+
+
+def _gemm16_tn(A, B, splits=1, tile=0, pipeline=2, colsum=False, k_real=None):
+    K, M = A.shape
+    N = B.shape[1]
+    C = np.zeros((M, N), np.float32)
+    cs = np.zeros(M, np.float64) if colsum else None
+    ms = ctypes.c_float()
+    _lib.check(_lib.load().vh_debug_gemm16_tn(_lib.ptr(np.ascontiguousarray(A)), _lib.ptr(np.ascontiguousarray(B)), _lib.ptr(C),
+                                              _lib.ptr(cs), M, N, K, K if k_real is None else k_real, splits, 1, tile, pipeline,
+                                              ctypes.byref(ms)))
+    return C, cs
+
+
+# (M, N, K, splits): one tile; ragged everywhere; the weight-gradient shapes of the default network at batch 2048 (hidden x
+# hidden, D_p x hidden, latent-tall, latent-wide) with their split-K slabs; K not a multiple of the K-tile
+@pytest.mark.parametrize("pipeline", [2, 0])
+@pytest.mark.parametrize("shape", [(64, 128, 64, 1), (128, 128, 192, 1), (96, 136, 200, 1), (512, 512, 2048, 4), (320, 512, 1024, 2),
+                                   (32, 512, 2048, 4), (512, 32, 2048, 4), (512, 320, 2048, 3), (40, 24, 72, 1)])
+def test_gemm16_row_major_weight_gradient(shape, pipeline):
+    """gemm_bf16_tn.hpp: C = A^T B from ROW-major [K][M], [K][N] operands (transposing LDS reads): exact against float64 of
+    the bf16-rounded operands up to fp32 accumulation; asymmetric operands (a transposed fragment, a wrong swizzle, a stale
+    buffer or a mis-assigned lane cannot pass); the fused column sums of A over the real rows."""
+    M, N, K, splits = shape
+    rng = np.random.RandomState(M + N + K + 3)
+    A = (rng.standard_normal((K, M)) + 0.5 * np.arange(M)[None, :] / M).astype(np.float32)
+    B = (rng.standard_normal((K, N)) + 0.25 * np.arange(N)[None, :] / N).astype(np.float32)
+    Ar, Br = bf16_round(A).astype(np.float64), bf16_round(B).astype(np.float64)
+    want = Ar.T @ Br
+    k_real = K - 5
+    for tile in ((0, 1, 3) if min(M, N) >= 64 else (0,)):
+        C, cs = _gemm16_tn(A, B, splits=splits, tile=tile, pipeline=pipeline, colsum=True, k_real=k_real)
+        assert rel(C, want) < 2e-6 * np.sqrt(K), (tile, pipeline)
+        assert np.allclose(cs, Ar[:k_real].sum(axis=0), rtol=1e-5, atol=1e-3), (tile, pipeline)
+    C, _ = _gemm16_tn(A, B, splits=splits, pipeline=pipeline)
+    assert rel(C, want) < 2e-6 * np.sqrt(K)
 
 
 @pytest.mark.parametrize("name", ["vae_small_drop", "vae_default_arch"])

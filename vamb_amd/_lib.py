@@ -134,6 +134,7 @@ SIGNATURES = {
                              ctypes.POINTER(_f32)]),
     "vh_debug_gemm16": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,
                                ctypes.POINTER(_f32)]),
+    "vh_debug_gemm16_tn": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
 }
 
 
@@ -174,6 +175,8 @@ _ENV_OPTIONS = {
     "VAMBHIP_SINGLE_STREAM": ("vae.single_stream", lambda v: 1),
     "VAMBHIP_FORK_EVENTS": ("vae.fork_events", lambda v: 1),
     "VAMBHIP_DEBUG_TIMING": ("vae.debug_timing", lambda v: 1),
+    "VAMBHIP_VAE_GEMM_PIPELINE": ("vae.gemm_pipeline", int),
+    "VAMBHIP_VAE_DW_ROW_MAJOR": ("vae.dw_row_major", int),
 }
 _ENV_STRING_OPTIONS = {"VAMBHIP_RCCL": "comm.rccl_library", "ROCM_PATH": "comm.rocm_path"}
 _explicit_options: dict = {}

@@ -25,8 +25,8 @@
 //   E16_SPLITK      C32[slab z] = acc                                   (dW, latent-wide outputs)
 //   E16_BIAS        C32 = acc + bias[n]                                 (reconstruction)
 //   E16_LATENT_MASK C32 = bits(acc + bias) & ~0xFFF, compact [M][N]     (encode, vambtools.py:324-330)
-//   E16_HIDDEN_TRAIN h = dropout(leaky_relu(acc + bias)) rounded to bf16; C16 = h, C16T = h^T; fp64 batch sums
-//                   of h and h^2 (of the ROUNDED values: the statistics every consumer of C16 sees)
+//   E16_HIDDEN_TRAIN h = dropout(leaky_relu(acc + bias)) rounded to bf16; C16 = h, C16T = h^T (if wanted); fp64 batch
+//                   sums of h and h^2 taken from the fp32 values before rounding
 //   E16_HIDDEN_EVAL C16 = bf16(leaky_relu(acc + bias) * scale[n] + shift[n])
 //   E16_STORE_BNRED C16 = bf16(acc) (= dA of the layer below) + fp64 batch sums of dA and dA * xhat(Hbelow)
 // bf16 outputs leave through LDS images of the tile (row-major and, for the hidden-train epilogue, transposed) and
@@ -102,8 +102,16 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_wav
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// STG: how a K-tile reaches the LDS.  0 = LDS-DMA (global_load_lds_dwordx4), 1 = through registers
-// (global_load_dwordx4 issued before the MFMAs of the current tile, ds_write_b128 after them; same LDS image).
+// STG: how a K-tile reaches the LDS.
+//   0 = LDS-DMA (global_load_lds_dwordx4), two buffers, the whole next tile requested in front of the current tile's MFMAs
+//   1 = through registers (global_load_dwordx4 issued before the MFMAs of the current tile, ds_write_b128 after them)
+//   2 = LDS-DMA, THREE buffers, the pieces of tile t + 2 issued one by one BETWEEN the MFMA groups of tile t, counted
+//       vmcnt + raw s_barrier.  Why (profiles/r03a_loadpath_*.json, tests/micro/loadpath.hip): the DMA path alone moves a
+//       32 KB K-tile in 0.39 us with a drain per tile and in 0.25 us with two tiles in flight (54 B/clk/CU = the L2's rate),
+//       yet the STG = 0 loop needs 0.84 us per tile: a global_load_lds occupies its wave until the texture addresser takes
+//       it (~17-27 clk per 1 KiB piece, 32 pieces per tile and CU), all waves run in lockstep, so "issue 4 pieces, then
+//       12 ds_reads + 8 MFMAs, then drain" is a DMA phase FOLLOWED by a matrix phase.  Spreading the pieces over the MFMA
+//       groups puts the issue stalls under matrix-pipe time, and the third buffer takes the landing latency off the barrier.
 template <int BM, int BN, int WM, int WN, int EPI, int STG = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Args g) {
     constexpr int NWAVE = WM * WN;
@@ -114,12 +122,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;   // one buffer of each operand
     constexpr int PA = BM / 8, PB = BN / 8;                 // 1 KiB DMA pieces per K-tile
     constexpr int RA = PA / NWAVE, RB = PB / NWAVE;         // pieces per wave
+    constexpr int NBUF = STG == 2 ? 3 : 2;
     static_assert(TM >= 1 && TN >= 1 && PA % NWAVE == 0 && PB % NWAVE == 0, "tile / wave layout");
     // ALL LDS of the kernel is this one array (a second __shared__ object makes hipcc drain the DMA queue
     // in front of every fragment read)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
-    unsigned char* const As = smem16;                  // [2][A_BYTES]
-    unsigned char* const Bs = smem16 + 2 * A_BYTES;    // [2][B_BYTES]
+    unsigned char* const As = smem16;                     // [NBUF][A_BYTES]
+    unsigned char* const Bs = smem16 + NBUF * A_BYTES;    // [NBUF][B_BYTES]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -248,6 +257,80 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
             compute(As, Bs);
             __syncthreads();
         }
+    } else if constexpr (STG == 2) {
+        // one DMA piece of the tile starting at k0 (q < RA: A piece q, else B piece q - RA)
+        auto piece = [&](unsigned char* abuf, unsigned char* bbuf, int k0, int q) {
+            const int room = kend - k0;
+            if (q < RA) glds16(a_k[q] < room ? a_src[q] + k0 : g.zeros, abuf + (wave + NWAVE * q) * 1024);
+            else glds16(b_k[q - RA] < room ? b_src[q - RA] + k0 : g.zeros, bbuf + (wave + NWAVE * (q - RA)) * 1024);
+        };
+        constexpr int NP = RA + RB;   // pieces per wave and tile
+        // MFMA groups of tile `cur`, the pieces of the tile two ahead in between; fragments two k-steps ahead as in compute()
+        auto compute_stage = [&](const unsigned char* abuf, const unsigned char* bbuf, unsigned char* anext, unsigned char* bnext,
+                                 int knext, bool prefetch) {
+            bf16x8 a8[BK / 16][TM], b8[BK / 16][TN];
+            auto frags = [&](int t) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a8[t][i] = *reinterpret_cast<const bf16x8*>(abuf + a_off[i] + 16 * ((2 * t + frag_h) ^ a_swz[i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b8[t][j] = *reinterpret_cast<const bf16x8*>(bbuf + b_off[j] + 16 * ((2 * t + frag_h) ^ b_swz[j]));
+            };
+            frags(0);
+            frags(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < BK / 16; ++t) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[t][i], b8[t][j], acc[i][j], 0, 0, 0);
+                if (prefetch) {   // workgroup-uniform
+#pragma unroll
+                    for (int q = (NP * t) / 4; q < (NP * (t + 1)) / 4; ++q) piece(anext, bnext, knext, q);
+                }
+                if (t + 2 < BK / 16) frags(t + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto abuf = [&](int b) { return As + b * A_BYTES; };
+        auto bbuf = [&](int b) { return Bs + b * B_BYTES; };
+        // prologue: tiles 0 and 1 requested; tile 0 awaited (tile 1's NP pieces may stay in flight)
+        if (nk > 0) stage(abuf(0), bbuf(0), kbeg);
+        if (nk > 1) {
+            stage(abuf(1), bbuf(1), kbeg + BK);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // iteration kt computes buffer kt % 3 and requests tile kt + 2 into buffer (kt + 2) % 3 -- the buffer every wave
+        // finished reading before the barrier that ended iteration kt - 1.  At its end the pieces of tile kt + 1 (requested
+        // during iteration kt - 1) must have landed: all but the NP newest DMAs of this wave, then the workgroup barrier.
+        auto iteration = [&](int kt, int cur, auto steady) {
+            // steady: tile kt + 2 exists for sure (no branch in the loop body)
+            const bool pre = decltype(steady)::value ? true : kt + 2 < nk;
+            const int nxt = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
+            compute_stage(abuf(cur), bbuf(cur), abuf(nxt), bbuf(nxt), kbeg + (kt + 2) * BK, pre);
+            if (pre) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int kt = 0;
+        for (; kt + 4 < nk; kt += 3) {   // all three iterations prefetch: kt + 2 + 2 < nk
+            iteration(kt, 0, std::true_type{});
+            iteration(kt + 1, 1, std::true_type{});
+            iteration(kt + 2, 2, std::true_type{});
+        }
+        // at most four tiles left, starting in buffer 0
+        if (kt < nk) iteration(kt, 0, std::false_type{});
+        if (kt + 1 < nk) iteration(kt + 1, 1, std::false_type{});
+        if (kt + 2 < nk) iteration(kt + 2, 2, std::false_type{});
+        if (kt + 3 < nk) iteration(kt + 3, 0, std::false_type{});
     } else {
         uint4 ra[RA], rb[RB];
         auto fetch = [&](int k0) {
@@ -327,6 +410,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
         if constexpr (EPI == E16_HIDDEN_TRAIN) drop_key = step_key(g.drop_key, g.step_ptr);
         // phase 1 (accumulator layout): transform, round, write the image (+ the transposed copy, + the sums).
         // DROP = 0: no dropout, 1: counter-based hash, 2: injected keep-masks -- chosen once per workgroup
+        const bool want_t = g.C16T != nullptr && !(g.dbg & 2);   // the transposed copy exists only in the round-2 dataflow
         auto phase1 = [&](auto drop_mode) {
             constexpr int DROP = decltype(drop_mode)::value;
 #pragma unroll
@@ -380,21 +464,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                             }
                             const bf16_t b = col_ok ? f2bf(v) : (bf16_t)0;
                             if constexpr (EPI == E16_HIDDEN_TRAIN) {
+                                // BatchNorm batch sums from the fp32 value, before it is rounded for storage (the rounding
+                                // error of an activation is unbiased and 2^-9 relative: the statistics are those of the
+                                // exact activations to first order, and one conversion per element is saved)
                                 if (row < g.m_real && col_ok) {
-                                    const float vr = bf2f(b);
-                                    s1[j] += vr;
-                                    s2[j] += vr * vr;
+                                    s1[j] += v;
+                                    s2[j] += v * v;
                                 }
                             }
                             hb[e] = b;
                             ct[rl * CP + cl] = b;
                         }
                         if constexpr (EPI == E16_HIDDEN_TRAIN) {
-                            // transposed image: 4 consecutive rows of this lane's column are 8 contiguous bytes
-                            uint2 w;
-                            w.x = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16);
-                            w.y = (uint32_t)hb[2] | ((uint32_t)hb[3] << 16);
-                            *reinterpret_cast<uint2*>(ctT + cl * CPT + rl4) = w;
+                            if (want_t) {   // uniform: transposed image, 4 consecutive rows of this lane's column = 8 bytes
+                                uint2 w;
+                                w.x = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16);
+                                w.y = (uint32_t)hb[2] | ((uint32_t)hb[3] << 16);
+                                *reinterpret_cast<uint2*>(ctT + cl * CPT + rl4) = w;
+                            }
                         }
                     }
                 }
@@ -486,7 +573,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
             }
             if constexpr (EPI == E16_HIDDEN_TRAIN) {
                 // transposed copy: 16-byte chunks of 8 rows, consecutive threads along the rows of one column
-                if (g.C16T != nullptr && !(g.dbg & 2)) {
+                if (want_t) {
                     constexpr int CPC = BM / 8;   // chunks per column
                     for (int idx = tid; idx < BN * CPC; idx += NT) {
                         const int c = idx / CPC, mc = idx % CPC;
@@ -508,9 +595,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
 }
 
 // dynamic LDS bytes of an instantiation: the operand buffers, or the output image + reduction scratch if larger
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int STG = 0>
 constexpr size_t gemm16_smem_bytes() {
-    size_t ops = 2 * (size_t)(BM + BN) * 128;
+    size_t ops = (STG == 2 ? 3 : 2) * (size_t)(BM + BN) * 128;
     if (EPI == E16_SPLITK || EPI == E16_BIAS || EPI == E16_LATENT_MASK) return ops;
     const size_t img = (size_t)BM * (BN + 8) * 2 + (EPI == E16_HIDDEN_TRAIN ? (size_t)BN * (BM + 8) * 2 : 0);
     const size_t nt = (size_t)WM * WN * 64, rpp = nt / (BN / 8);

@@ -17,6 +17,7 @@
 #include <hip/hip_ext.h>
 #include "gemm.hpp"
 #include "gemm_bf16.hpp"
+#include "gemm_bf16_tn.hpp"
 #include "vae_kernels.hpp"
 #include "vae_kernels16.hpp"
 
@@ -156,12 +157,18 @@ struct VaeTuning {
     bool big_tiles = false;   // vae.big_tiles
     int xcd_remap = 1;        // vae.xcd_remap
     int dw_workgroups = 256;  // vae.dw_workgroups: workgroups wanted per weight-gradient GEMM (split-K target)
+    int pipeline = 2;         // vae.gemm_pipeline: K loop of the bf16 GEMMs.  2 = three LDS buffers, DMA pieces of tile t + 2 issued
+                              // between the MFMA groups of tile t; 0 = the round-2 loop (two buffers, tile t + 1 requested up front)
+    bool dw_row_major = true; // vae.dw_row_major: bf16 weight gradients contract ROW-major tensors (gemm_bf16_tn.hpp); 0 = the
+                              // round-2 dataflow with a transposed bf16 copy of every contracted tensor (A/B measurements)
 } g_tuning;
 
 void refresh_tuning() {
     g_tuning.big_tiles = option("vae.big_tiles", 0) != 0;
     g_tuning.xcd_remap = (int)option("vae.xcd_remap", 1);
     g_tuning.dw_workgroups = (int)option("vae.dw_workgroups", 256);
+    g_tuning.dw_row_major = option("vae.dw_row_major", 1) != 0;
+    g_tuning.pipeline = option("vae.gemm_pipeline", 2) == 0 ? 0 : 2;
 }
 
 int fwd_tile(int M, int N) {
@@ -1773,6 +1780,77 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
     });
 }
 
+int vh_debug_gemm16_tn(const float* A, const float* B, float* C, double* colsum, int M, int N, int K, int k_real, int splits,
+                       int reps, int tile, int pipeline, float* ms) {
+    return guarded([&] {
+        VH_REQUIRE(A && B && C, "NULL argument");
+        VH_REQUIRE(M >= 8 && N >= 8 && K >= 1 && M % 8 == 0 && N % 8 == 0, "need M, N multiples of 8");
+        VH_REQUIRE(splits >= 1 && reps >= 1, "bad split / repetition count");
+        VH_REQUIRE(tile == 0 || tile == 1 || tile == 3, "tile: 0 (by shape), 1 (128x128) or 3 (64x128)");
+        VH_REQUIRE(pipeline == 0 || pipeline == 2, "pipeline: 0 or 2");
+        auto to_bf16 = [](const float* src, size_t n) {
+            std::vector<bf16_t> out(n);
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t u;
+                memcpy(&u, &src[i], 4);
+                u += 0x7FFFu + ((u >> 16) & 1u);
+                out[i] = (bf16_t)(u >> 16);
+            }
+            return out;
+        };
+        hipStream_t s;
+        VH_HIP(hipStreamCreate(&s));
+        DevBuf<bf16_t> dA, dB, dz;
+        DevBuf<float> dC;
+        DevBuf<double> dsum;
+        const std::vector<bf16_t> hA = to_bf16(A, (size_t)K * M), hB = to_bf16(B, (size_t)K * N);
+        dA.alloc(hA.size()); dB.alloc(hB.size()); dz.alloc(128);
+        VH_HIP(hipMemcpy(dA.p, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+        VH_HIP(hipMemcpy(dB.p, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+        VH_HIP(hipMemset(dz.p, 0, dz.bytes()));
+        const int k_per = splits == 1 ? K : (int)round_up(ceil_div(K, splits), 64);
+        const int nsplit = (int)ceil_div(K, k_per);
+        dC.alloc((size_t)nsplit * M * N);
+        dsum.alloc((size_t)M);
+        Gemm16TnArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A = dA.p; g.lda = M; g.B = dB.p; g.ldb = N; g.M = M; g.N = N; g.K = K; g.k_real = k_real;
+        g.k_per_split = k_per; g.slab_stride = (int64_t)M * N; g.zeros = dz.p;
+        g.C32 = dC.p; g.ldc = N; g.colsum = colsum ? dsum.p : nullptr; g.xcd_remap = 1;
+        auto run = [&] {
+            if (colsum) step16::gemm16_tn<1>(s, g, nsplit, tile, pipeline);
+            else step16::gemm16_tn<0>(s, g, nsplit, tile, pipeline);
+        };
+        run();   // warm-up (sets the LDS attribute)
+        VH_HIP(hipMemsetAsync(dsum.p, 0, dsum.bytes(), s));
+        hipEvent_t e0, e1;
+        VH_HIP(hipEventCreate(&e0));
+        VH_HIP(hipEventCreate(&e1));
+        VH_HIP(hipEventRecord(e0, s));
+        for (int r = 0; r < reps; ++r) run();
+        VH_HIP(hipEventRecord(e1, s));
+        VH_HIP(hipStreamSynchronize(s));
+        float t = 0.f;
+        VH_HIP(hipEventElapsedTime(&t, e0, e1));
+        if (ms) *ms = t / (float)reps;
+        std::vector<float> hc((size_t)nsplit * M * N);
+        VH_HIP(hipMemcpy(hc.data(), dC.p, sizeof(float) * hc.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < (size_t)M * N; ++i) {
+            float acc = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) acc += hc[(size_t)sp * M * N + i];
+            C[i] = acc;
+        }
+        if (colsum) {
+            std::vector<double> hs((size_t)M);
+            VH_HIP(hipMemcpy(hs.data(), dsum.p, hs.size() * 8, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < hs.size(); ++i) colsum[i] = hs[i] / (double)reps;   // accumulated once per timed launch
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(s);
+    });
+}
+
 int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, float* C, float* CT, double* stats, int M,
                     int N, int K, int splits, int reps, int variant, float* ms) {
     return guarded([&] {
@@ -1816,8 +1894,9 @@ int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, 
         g.bias = dbias.p; g.m_real = M; g.fstat_out = dstat.p; g.drop_scale = 1.0f; g.xcd_remap = 1;
         const int tile = variant & 0xFF;
         g.dbg = variant >> 8;
-        VH_REQUIRE(tile == 0 || tile == 1 || tile == 3 || tile == 4 || tile == 7 || tile == 11 || tile == 13 || tile == 17,
-                   "variant: tile 0, 1, 3, 4, 7 or 11, 13, 17 (register-staged) (+ 256 * timing-experiment flags)");
+        VH_REQUIRE(tile == 0 || tile == 1 || tile == 3 || tile == 4 || tile == 7 || tile == 11 || tile == 13 || tile == 17 ||
+                       tile == 21 || tile == 23 || tile == 27,
+                   "variant: tile 0, 1, 3, 4, 7; 11, 13, 17 (register-staged); 21, 23, 27 (interleaved DMA) (+ 256 * timing-experiment flags)");
         auto run = [&] {
             if (epi == E16_SPLITK) step16::gemm16_variant<E16_SPLITK>(s, tile, g, nsplit);
             else if (epi == E16_BIAS) step16::gemm16_variant<E16_BIAS>(s, tile, g, 1);

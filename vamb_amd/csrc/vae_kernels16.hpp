@@ -418,15 +418,15 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
             }
         }
         const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-        *reinterpret_cast<uint4*>(&tile[rl][c8]) = o;
+        if (a.DZT) *reinterpret_cast<uint4*>(&tile[rl][c8]) = o;
         if (r < a.bs_p && col < a.n_p) *reinterpret_cast<uint4*>(a.DZ + (int64_t)r * a.n_p + col) = o;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[rt][c8 + e] = s[e];
     __syncthreads();
-    // transposed copy: chunk = (column c, 8 consecutive rows); lanes of a wave take consecutive columns
+    // transposed copy (round-2 dataflow only): chunk = (column c, 8 consecutive rows); lanes of a wave take consecutive columns
 #pragma unroll
-    for (int p = 0; p < (kDz16Cols * (kDz16Rows / 8)) / 256; ++p) {
+    for (int p = 0; p < (a.DZT ? (kDz16Cols * (kDz16Rows / 8)) / 256 : 0); ++p) {
         const int id = tid + 256 * p;
         const int c = id % kDz16Cols, rg = id / kDz16Cols;
         bf16_t e[8];

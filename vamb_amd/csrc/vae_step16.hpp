@@ -18,7 +18,7 @@ constexpr int kDwTargetWgs = 256;   // workgroups wanted per weight-gradient GEM
 template <int BM, int BN, int WM, int WN, int EPI, int STG = 0>
 void launch_gemm16(hipStream_t stream, const Gemm16Args& g, int splits) {
     static bool attr_set = false;
-    constexpr size_t smem = gemm16_smem_bytes<BM, BN, WM, WN, EPI>();
+    constexpr size_t smem = gemm16_smem_bytes<BM, BN, WM, WN, EPI, STG>();
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STG>;
     if (!attr_set) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -39,20 +39,66 @@ void launch_gemm16(hipStream_t stream, const Gemm16Args& g, int splits) {
     VH_HIP(hipGetLastError());
 }
 
+template <int BM, int BN, int WM, int WN, int COLSUM, int STG>
+void launch_gemm16_tn(hipStream_t stream, const Gemm16TnArgs& g, int splits) {
+    static bool attr_set = false;
+    constexpr size_t smem = gemm16_tn_smem_bytes<BM, BN, STG>();
+    auto kern = gemm_bf16_tn_kernel<BM, BN, WM, WN, COLSUM, STG>;
+    if (!attr_set) {
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kMaxDynLds));
+        attr_set = true;
+    }
+    static_assert(smem <= kMaxDynLds, "tile does not fit the LDS budget");
+    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits);
+    if (t_probe_start) {
+        hipExtLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, t_probe_start, t_probe_stop, 0, g);
+        t_probe_start = t_probe_stop = nullptr;
+    } else if (t_fork_stop) {
+        hipExtLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, nullptr, t_fork_stop, 0, g);
+        t_fork_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g);
+    }
+    VH_HIP(hipGetLastError());
+}
+
+// weight-gradient tile by output shape (same rule as the K-contiguous kernel; dw_splits16 plans the slabs for it):
+// tile 0 = by shape, 1 = 128x128 / 8 waves, 3 = 64x128 / 4 waves (A/B measurements through vh_debug_gemm16_tn)
+template <int COLSUM, int STG>
+void gemm16_tn_stg(hipStream_t s, const Gemm16TnArgs& g, int splits, int tile) {
+    if (tile == 1) launch_gemm16_tn<128, 128, 2, 4, COLSUM, STG>(s, g, splits);
+    else if (tile == 3) launch_gemm16_tn<64, 128, 2, 2, COLSUM, STG>(s, g, splits);
+    else if (g.N <= 32) launch_gemm16_tn<128, 32, 4, 1, COLSUM, STG>(s, g, splits);
+    else if (g.M <= 32) launch_gemm16_tn<32, 128, 1, 4, COLSUM, STG>(s, g, splits);
+    else launch_gemm16_tn<64, 128, 2, 2, COLSUM, STG>(s, g, splits);
+}
+template <int COLSUM>
+void gemm16_tn(hipStream_t s, const Gemm16TnArgs& g, int splits, int tile = 0, int pipeline = -1) {
+    if (pipeline < 0) pipeline = g_tuning.pipeline;
+    if (pipeline == 2) gemm16_tn_stg<COLSUM, 2>(s, g, splits, tile);
+    else gemm16_tn_stg<COLSUM, 0>(s, g, splits, tile);
+}
+
 // Tile by output shape (measured, profiles/r02_gemm16_variants.json): batch-tall outputs take 128x128 tiles with 8 waves
 // (2x4, two per SIMD: one wave's DMA issue and fragment reads overlap the other's MFMAs), weight gradients 64x128 tiles
 // (twice the workgroups per split), 128x32 / 32x128 for latent-wide / latent-tall outputs.
+template <int EPI, int STG>
+void gemm16_stg(hipStream_t s, const Gemm16Args& g, int splits) {
+    if constexpr (EPI == E16_SPLITK) {
+        if (g.N <= 32) launch_gemm16<128, 32, 4, 1, EPI, STG>(s, g, splits);
+        else if (g.M <= 32) launch_gemm16<32, 128, 1, 4, EPI, STG>(s, g, splits);
+        else launch_gemm16<64, 128, 2, 2, EPI, STG>(s, g, splits);
+    } else if constexpr (EPI == E16_LATENT_MASK) {
+        launch_gemm16<128, 32, 4, 1, EPI, STG>(s, g, splits);
+    } else {
+        launch_gemm16<128, 128, 2, 4, EPI, STG>(s, g, splits);
+    }
+}
 template <int EPI>
 void gemm16(hipStream_t s, const Gemm16Args& g, int splits) {
-    if constexpr (EPI == E16_SPLITK) {
-        if (g.N <= 32) launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
-        else if (g.M <= 32) launch_gemm16<32, 128, 1, 4, EPI>(s, g, splits);
-        else launch_gemm16<64, 128, 2, 2, EPI>(s, g, splits);
-    } else if constexpr (EPI == E16_LATENT_MASK) {
-        launch_gemm16<128, 32, 4, 1, EPI>(s, g, splits);
-    } else {
-        launch_gemm16<128, 128, 2, 4, EPI>(s, g, splits);
-    }
+    if (g_tuning.pipeline == 2) gemm16_stg<EPI, 2>(s, g, splits);
+    else gemm16_stg<EPI, 0>(s, g, splits);
 }
 
 // every tile / pipeline variant of one epilogue (vh_debug_gemm16): 0 = the production choice by output shape,
@@ -70,6 +116,9 @@ void gemm16_variant(hipStream_t s, int tile, const Gemm16Args& g, int splits) {
         case 11: launch_gemm16<128, 128, 2, 4, EPI, 1>(s, g, splits); break;
         case 13: launch_gemm16<64, 128, 2, 2, EPI, 1>(s, g, splits); break;
         case 17: launch_gemm16<128, 128, 2, 2, EPI, 1>(s, g, splits); break;
+        case 21: launch_gemm16<128, 128, 2, 4, EPI, 2>(s, g, splits); break;   // interleaved DMA, three buffers
+        case 23: launch_gemm16<64, 128, 2, 2, EPI, 2>(s, g, splits); break;
+        case 27: launch_gemm16<128, 128, 2, 2, EPI, 2>(s, g, splits); break;
         default: gemm16<EPI>(s, g, splits); break;
     }
 }
@@ -130,17 +179,21 @@ void refresh_shadows(vh_vae* h, int only) {
 // everything of the bf16 step that depends on the batch size (called from prepare_batch)
 void prepare_batch16(vh_vae* h) {
     const int bs_p = h->bs_p;
+    const bool tcopies = !g_tuning.dw_row_major;   // transposed bf16 copies: only the round-2 dataflow needs them
     h->Xb16.ensure((size_t)bs_p * h->D_p);
-    h->Xb16T.ensure((size_t)bs_p * h->D_p);
     h->Z16.ensure((size_t)bs_p * h->L_p);
-    h->Z16T.ensure((size_t)bs_p * h->L_p);
     h->dR16.ensure((size_t)bs_p * h->D_p);
-    h->dR16T.ensure((size_t)bs_p * h->D_p);
     h->dMU16.ensure((size_t)bs_p * h->L_p);
-    h->dMU16T.ensure((size_t)bs_p * h->L_p);
+    if (tcopies) {
+        h->Xb16T.ensure((size_t)bs_p * h->D_p);
+        h->Z16T.ensure((size_t)bs_p * h->L_p);
+        h->dR16T.ensure((size_t)bs_p * h->D_p);
+        h->dMU16T.ensure((size_t)bs_p * h->L_p);
+    }
     for (auto& hl : h->hidden) {
         const size_t n = (size_t)bs_p * hl.nout_p;
-        hl.H16.ensure(n); hl.H16T.ensure(n); hl.DA16.ensure(n); hl.DZ16.ensure(n); hl.DZ16T.ensure(n);
+        hl.H16.ensure(n); hl.DA16.ensure(n); hl.DZ16.ensure(n);
+        if (tcopies) { hl.H16T.ensure(n); hl.DZ16T.ensure(n); }
         hl.Wf16.ensure((size_t)hl.nout_p * hl.nin_p);
         hl.biasf.ensure((size_t)hl.nout_p);
     }
@@ -260,7 +313,7 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
                 g.B = w16(h, hl.tW); g.bias = h->pptr(hl.tb);
             }
             g.ldb = hl.nin_p;
-            g.C16T = hl.H16T.p; g.ldc16t = bs_p;
+            g.C16T = g_tuning.dw_row_major ? nullptr : hl.H16T.p; g.ldc16t = bs_p;
             g.fstat_out = hl.fstat;
             g.drop_scale = dc.scale; g.drop_thresh = dc.thresh; g.drop_key = layer_key(h, li);
             g.step_ptr = step_ptr(h);
@@ -308,7 +361,8 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
                            layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z16.p, bs, h->L, h->L_p, bs_p);
         VH_HIP(hipGetLastError());
         // the transposed latent code feeds the first decoder layer's weight gradient
-        if (defer) defer->add([h, bs_p](hipStream_t st) { transpose16(h, st, h->Z16.p, bs_p, h->L_p, h->Z16T.p, nullptr, 0); });
+        if (defer && !g_tuning.dw_row_major)
+            defer->add([h, bs_p](hipStream_t st) { transpose16(h, st, h->Z16.p, bs_p, h->L_p, h->Z16T.p, nullptr, 0); });
     }
     in = h->Z16.p;
     in_w = h->L_p;
@@ -396,6 +450,29 @@ void grad_weight16(vh_vae* h, int tW, const bf16_t* dZT, int out_p, const bf16_t
     gemm16<E16_SPLITK>(st, g, splits);
 }
 
+// dW slabs = dZ^T In straight from the ROW-major tensors dZ [bs_p][out_p], In [bs_p][in_p] (gemm_bf16_tn.hpp); dbias: the
+// fp64 column sums of dZ over the real rows, for the layers whose bias gradient no other kernel produces (output, mu)
+void grad_weight16_rm(vh_vae* h, int tW, const bf16_t* dZ, int out_p, const bf16_t* In, int in_p, double* dbias,
+                      hipStream_t st) {
+    Tensor& t = h->tensors[tW];
+    Gemm16TnArgs g;
+    memset(&g, 0, sizeof(g));
+    g.zeros = h->zeros16.p;
+    g.xcd_remap = 1;
+    g.A = dZ; g.lda = out_p;
+    g.B = In; g.ldb = in_p;
+    g.C32 = t.slab; g.ldc = in_p;
+    g.M = out_p; g.N = in_p; g.K = h->bs_p; g.k_real = h->bs;
+    g.k_per_split = (int)round_up(ceil_div(h->bs_p, t.nslab), 64);
+    g.slab_stride = t.stride;
+    g.colsum = dbias;
+    const int splits = (int)ceil_div(h->bs_p, g.k_per_split);
+    if (splits < t.nslab)
+        VH_HIP(hipMemsetAsync(t.slab + (int64_t)splits * t.stride, 0, sizeof(float) * (t.nslab - splits) * t.stride, st));
+    if (dbias) gemm16_tn<1>(st, g, splits);
+    else gemm16_tn<0>(st, g, splits);
+}
+
 // dIn16 = dZ16 [bs_p][out] x W16T [in][out]; the epilogue leaves the BatchNorm-backward sums of the layer below
 void grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidden& below) {
     Gemm16Args g = args16(h);
@@ -417,8 +494,12 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
     {   // output layer: dR16 is ready
         Hidden& last = h->hidden[2 * nl - 1];
         q.add([h, bs_p, bs, &last](hipStream_t st) {
-            transpose16(h, st, h->dR16.p, bs_p, h->D_p, h->dR16T.p, h->dbias_out, bs);
-            grad_weight16(h, h->tWo, h->dR16T.p, h->D_p, last.H16T.p, last.nout_p, st);
+            if (g_tuning.dw_row_major) {
+                grad_weight16_rm(h, h->tWo, h->dR16.p, h->D_p, last.H16.p, last.nout_p, h->dbias_out, st);
+            } else {
+                transpose16(h, st, h->dR16.p, bs_p, h->D_p, h->dR16T.p, h->dbias_out, bs);
+                grad_weight16(h, h->tWo, h->dR16T.p, h->D_p, last.H16T.p, last.nout_p, st);
+            }
         });
         grad_input16(h, h->dR16.p, h->D_p, h->tWo, last.nout_p, last);
     }
@@ -426,19 +507,25 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
     auto hidden_bwd = [&](int li) {
         Hidden& hl = h->hidden[li];
         Dz16Args a;
-        a.DA = hl.DA16.p; a.H = hl.H16.p; a.DZ = hl.DZ16.p; a.DZT = hl.DZ16T.p; a.ldt = bs_p;
+        a.DA = hl.DA16.p; a.H = hl.H16.p; a.DZ = hl.DZ16.p; a.DZT = g_tuning.dw_row_major ? nullptr : hl.DZ16T.p; a.ldt = bs_p;
         a.n_p = hl.nout_p; a.bs = bs; a.bs_p = bs_p;
         a.bn = bn_src(h, hl);
         a.bstat = hl.bstat;
         a.drop_scale = dc.scale;
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
         a.dbias = hl.dbias;
-        const bf16_t* InT = li == 0 ? h->Xb16T.p : (li == nl ? h->Z16T.p : h->hidden[li - 1].H16T.p);
+        const bool rm = g_tuning.dw_row_major;
+        const bf16_t* InT = rm ? (li == 0 ? h->Xb16.p : (li == nl ? h->Z16.p : h->hidden[li - 1].H16.p))     // row-major input
+                               : (li == 0 ? h->Xb16T.p : (li == nl ? h->Z16T.p : h->hidden[li - 1].H16T.p));
         const int in_p = li == 0 ? h->D_p : (li == nl ? h->L_p : h->hidden[li - 1].nout_p);
+        auto dw = [h, &hl, InT, in_p, rm](hipStream_t st) {
+            if (rm) grad_weight16_rm(h, hl.tW, hl.DZ16.p, hl.nout_p, InT, in_p, nullptr, st);
+            else grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, st);
+        };
         // Fork points: the top decoder layer and encoder layer 1 (and layer 0 when something is still queued): each
         // hands everything queued so far to the side stream.  The first layer's weight gradient is the end of the
         // chain -- nothing is left on the main stream for it to hide behind -- so it runs there.
-        if (li > 0) q.add([h, &hl, InT, in_p](hipStream_t st) { grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, st); });
+        if (li > 0) q.add(dw);
         if (li == nl && h->comm) {
             // data parallel: every decoder-side gradient is now queued -- materialise that bucket of the flat gradient and
             // all-reduce it on the side stream while the encoder's backward still runs on the main stream
@@ -460,7 +547,7 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
             VH_HIP(hipGetLastError());
         }
         if (li == 0) {
-            grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, h->stream);
+            dw(h->stream);
         } else if (li == nl) {
             // first decoder layer -> latent: latent-wide output, split-K slabs summed by the latent kernel
             Gemm16Args g = args16(h);
@@ -486,8 +573,12 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
                            h->dMU16.p, h->L_p, bs, bs_p);
         VH_HIP(hipGetLastError());
         q.add([h, bs_p, bs, &enc_last](hipStream_t st) {
-            transpose16(h, st, h->dMU16.p, bs_p, h->L_p, h->dMU16T.p, h->dbias_mu, bs);
-            grad_weight16(h, h->tWmu, h->dMU16T.p, h->L_p, enc_last.H16T.p, enc_last.nout_p, st);
+            if (g_tuning.dw_row_major) {
+                grad_weight16_rm(h, h->tWmu, h->dMU16.p, h->L_p, enc_last.H16.p, enc_last.nout_p, h->dbias_mu, st);
+            } else {
+                transpose16(h, st, h->dMU16.p, bs_p, h->L_p, h->dMU16T.p, h->dbias_mu, bs);
+                grad_weight16(h, h->tWmu, h->dMU16T.p, h->L_p, enc_last.H16T.p, enc_last.nout_p, st);
+            }
         });
         grad_input16(h, h->dMU16.p, h->L_p, h->tWmu, enc_last.nout_p, enc_last);
     }
@@ -519,8 +610,8 @@ void gather_rows16(vh_vae* h, const int64_t* dev_idx, SideQueue& q) {
                        (const float*)h->X.p, (int64_t)h->D_p, (const float*)h->w.p, dev_idx, h->shuffle,
                        (const long long*)&h->state.p->batch, h->bs, h->bs_p, h->Xb.p, h->Xb16.p, h->Wb.p);
     VH_HIP(hipGetLastError());
-    // transposed copy of the batch for the first layer's weight gradient (needed last)
-    q.add([h](hipStream_t st) { transpose16(h, st, h->Xb16.p, h->bs_p, h->D_p, h->Xb16T.p, nullptr, 0); });
+    // round-2 dataflow only: transposed copy of the batch for the first layer's weight gradient (needed last)
+    if (!g_tuning.dw_row_major) q.add([h](hipStream_t st) { transpose16(h, st, h->Xb16.p, h->bs_p, h->D_p, h->Xb16T.p, nullptr, 0); });
 }
 
 void train_step16(vh_vae* h, const int64_t* dev_idx, bool eps_injected, bool masks_injected) {
