@@ -386,6 +386,13 @@ int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, 
 int vh_debug_gemm16_tn(const float* A, const float* B, float* C, double* colsum, int M, int N, int K, int k_real, int splits,
                        int reps, int tile, int pipeline, float* ms);
 
+/* Diagnostic: one launch of the bf16-storage GEMM on device-generated data with in-kernel time stamps (s_memtime ticks,
+ * 100 MHz constant clock or shader clock -- compare differences only).  stamps[b][0..4] of workgroup b = kernel entry,
+ * first K-tile landed, K loop done, epilogue phase 1 done (image in LDS), stores issued.  epi / variant as vh_debug_gemm16
+ * (variant < 256).  Returns the number of workgroups in *n_blocks (<= cap_blocks rows are written). */
+int vh_debug_gemm16_timeline(int epi, int M, int N, int K, int variant, unsigned long long* stamps, int cap_blocks,
+                             int* n_blocks, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

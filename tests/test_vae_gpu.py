@@ -145,6 +145,13 @@ def test_gemm16_hidden_epilogue(shape):
     # the batch sums are taken from the fp32 values BEFORE the bf16 rounding of the stored copy
     assert np.allclose(stats[0], want.sum(axis=0), rtol=1e-5, atol=1e-3)
     assert np.allclose(stats[1], (want ** 2).sum(axis=0), rtol=1e-5, atol=1e-3)
+    # without the transposed copy (the round-3 dataflow) interior tiles take the lean epilogue (transposed LDS image,
+    # transposing reads): the same bits
+    for variant in (0, 21, 23, 27, 4):
+        C2, _, stats2 = _gemm16(3, A, B, bias=bias, want_t=False, want_stats=True, variant=variant)
+        assert np.array_equal(C2, C), variant
+        assert np.allclose(stats2[0], want.sum(axis=0), rtol=1e-5, atol=1e-3)
+        assert np.allclose(stats2[1], (want ** 2).sum(axis=0), rtol=1e-5, atol=1e-3)
 
 
 # every K-tile count from 1 to 8 plus the C3 encoder's 17.5 (prologue / steady triple / tail of the three-buffer loop), ragged

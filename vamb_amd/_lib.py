@@ -134,6 +134,7 @@ SIGNATURES = {
                              ctypes.POINTER(_f32)]),
     "vh_debug_gemm16": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,
                                ctypes.POINTER(_f32)]),
+    "vh_debug_gemm16_timeline": (_int, [_int, _int, _int, _int, _int, _vp, _int, _vp, _vp]),
     "vh_debug_gemm16_tn": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
 }
 

@@ -86,6 +86,8 @@ struct Gemm16Args {
     double* bstat_out;     // [2][N]
     int xcd_remap;
     int dbg;               // timing experiments (vh_debug_gemm16): 1 no fp64 atomics, 2 no transposed copy, 4 no row-major copy
+    unsigned long long* tstamps;   // diagnostic (vh_debug_gemm16, variant flag 8): [workgroup][8] s_memtime stamps -- entry, first tile
+                                   // landed, K loop done, epilogue phase 1 done, stores issued, exit
 };
 
 __device__ __forceinline__ bf16_t f2bf(float x) {
@@ -100,6 +102,22 @@ __device__ __forceinline__ int swz16(int row) { return ((row >> 1) ^ (row >> 4))
 __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ds_read_b64_tr_b16: sixteen lanes address a [4][16] block of 16-bit elements (lane s: row s / 4, elements 4 (s % 4) .. + 3 of
+// it, 8 contiguous bytes; the row stride is free); lane c of the group receives element c of the four rows (measured mapping:
+// profiles/r03a_tr16_probe.txt).
+typedef short tr_v4s __attribute__((ext_vector_type(4)));
+typedef short tr_v8s __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ tr_v4s lds_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p));
+}
+
+__device__ __forceinline__ void gemm16_stamp(const Gemm16Args& g, int slot) {
+    if (g.tstamps != nullptr && threadIdx.x == 0) {
+        const unsigned nb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        g.tstamps[(size_t)nb * 8 + slot] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 // STG: how a K-tile reaches the LDS.
@@ -130,6 +148,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
     unsigned char* const As = smem16;                     // [NBUF][A_BYTES]
     unsigned char* const Bs = smem16 + NBUF * A_BYTES;    // [NBUF][B_BYTES]
 
+    gemm16_stamp(g, 0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,6 +263,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
     if constexpr (STG == 0) {
         if (nk > 0) stage(As, Bs, kbeg);
         __syncthreads();   // (hipcc drains the DMA queue in front of this barrier)
+        gemm16_stamp(g, 1);
         int kt = 0;
         for (; kt + 1 < nk; kt += 2) {
             stage(As + A_BYTES, Bs + B_BYTES, kbeg + (kt + 1) * BK);
@@ -307,6 +327,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        gemm16_stamp(g, 1);
         // iteration kt computes buffer kt % 3 and requests tile kt + 2 into buffer (kt + 2) % 3 -- the buffer every wave
         // finished reading before the barrier that ended iteration kt - 1.  At its end the pieces of tile kt + 1 (requested
         // during iteration kt - 1) must have landed: all but the NP newest DMAs of this wave, then the workgroup barrier.
@@ -368,6 +389,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
         }
     }
 
+    gemm16_stamp(g, 2);
     // ---------------------------------------------------------------------------------------------------
     // epilogue.  acc[i][j][reg] is C[row][col] with
     //   row = m0 + (wm*TM + i)*32 + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5),   col = n0 + (wn*TN + j)*32 + (lane & 31)
@@ -392,8 +414,176 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                     Cout[(int64_t)row * g.ldc32 + col] = v;
                 }
         }
+        gemm16_stamp(g, 4);
         return;
     } else {
+        // ---- lean epilogue: tiles that lie completely inside the batch and the matrix (all of them at the BASELINE shapes), no
+        // injected dropout masks.  The round-2 epilogue below spent 9 500 clk per 128 x 128 tile in its accumulator-layout pass
+        // (profiles/r03c_gemm16_timeline.txt: twice the K loop of the C2 encoder GEMM) -- ~31 instructions per element: a
+        // predicate and a branch per element for the matrix edges, two integer-multiply hashes per four elements, one
+        // ds_write_b16 per element.  Here: no edge tests; dropout bits from a per-lane xorshift32 stream seeded once per launch
+        // by the counter hash (6 full-rate VALU per 32 bits); the image is written TRANSPOSED, [BN][BM + 8], four consecutive
+        // rows of the lane's column per ds_write_b64 (8 stores per lane instead of 32), and the row-major 16-byte chunks of
+        // the global stores are assembled by the transposing LDS read.
+        bool lean = m0 + BM <= g.m_real && m0 + BM <= g.M && n0 + BN <= g.N && !(g.dbg & 16);
+        if constexpr (EPI == E16_HIDDEN_TRAIN) lean = lean && g.drop_mask == nullptr && (g.C16T == nullptr || (g.dbg & 2));
+        if constexpr (NWAVE % (BN / 32) != 0 || BM % 16 != 0) lean = false;
+        if (lean) {
+            constexpr int IP = BM + 8;                         // elements per image row (one output COLUMN)
+            constexpr int IMG_BYTES = BN * IP * 2;
+            bf16_t* const img = reinterpret_cast<bf16_t*>(smem16);
+            float* const lred = reinterpret_cast<float*>(smem16 + IMG_BYTES);
+            float s1[TN], s2[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+            uint32_t rng = 1u;
+            float dsa = 1.0f, dsb = kLeakySlopeF;
+            bool hashed = false;
+            uint32_t thresh16 = 0;
+            if constexpr (EPI == E16_HIDDEN_TRAIN) {
+                hashed = g.drop_scale != 1.0f;
+                dsa = g.drop_scale;
+                dsb = g.drop_scale * kLeakySlopeF;
+                thresh16 = g.drop_thresh >> 16;
+                if (hashed) rng = hash_drop(step_key(g.drop_key, g.step_ptr), (uint32_t)(by * (int)gridDim.x + bx) * NT + tid) | 1u;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cl = (wn * TN + j) * 32 + frag_r;
+                float bias = 0.f, sc = 1.f, sh = 0.f;
+                if constexpr (EPI == E16_HIDDEN_TRAIN || EPI == E16_HIDDEN_EVAL) bias = g.bias[n0 + cl];
+                if constexpr (EPI == E16_HIDDEN_EVAL) { sc = g.scale[n0 + cl]; sh = g.shift[n0 + cl]; }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                        if constexpr (EPI == E16_HIDDEN_TRAIN) {
+                            uint32_t r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
+                            if (hashed) {   // uniform; two 32-bit draws = four 16-bit uniforms
+                                rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; r0 = rng;
+                                rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; r1 = rng;
+                            }
+                            const uint32_t u[4] = {r0 & 0xFFFFu, r0 >> 16, r1 & 0xFFFFu, r1 >> 16};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float x = v[e] + bias;
+                                float y = fmaxf(x * dsa, x * dsb);       // drop_scale * leaky_relu(x)
+                                y = u[e] >= thresh16 ? y : 0.f;
+                                s1[j] += y;
+                                s2[j] = fmaf(y, y, s2[j]);
+                                v[e] = y;
+                            }
+                        } else if constexpr (EPI == E16_HIDDEN_EVAL) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float x = v[e] + bias;
+                                v[e] = fmaxf(x, x * kLeakySlopeF) * sc + sh;
+                            }
+                        }
+                        const int rl4 = (wm * TM + i) * 32 + 8 * q + 4 * frag_h;
+                        uint2 w;
+                        w.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                        w.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(img + cl * IP + rl4) = w;
+                    }
+            }
+            if constexpr (EPI == E16_HIDDEN_TRAIN) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    s1[j] += __shfl_xor(s1[j], 32);
+                    s2[j] += __shfl_xor(s2[j], 32);
+                    if (lane < 32) {
+                        const int cl = (wn * TN + j) * 32 + lane;
+                        lred[(0 * WM + wm) * BN + cl] = s1[j];
+                        lred[(1 * WM + wm) * BN + cl] = s2[j];
+                    }
+                }
+            }
+            __syncthreads();
+            gemm16_stamp(g, 3);
+            // row-major stores: a wave instruction covers 16 rows x 32 columns (lane = 16 g4 + r16: row r16 of the block, columns
+            // 8 g4 .. + 7: two transposing reads of [4 columns][16 rows] blocks of the image)
+            constexpr int UC = BN / 32, UR = BM / 16, WG = NWAVE / UC;   // column passes, row blocks, waves per column pass
+            const int g4 = lane >> 4, r16 = lane & 15;
+            const int cp = wave % UC;
+            const int c0 = cp * 32 + 8 * g4;
+            const bf16_t* const isrc = img + (c0 + (r16 >> 2)) * IP + 4 * (r16 & 3);
+            float mean8[8], istd8[8], t1[8], t2[8];
+            if constexpr (EPI == E16_STORE_BNRED) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float sc, sh;
+                    bn_column(g.bnC, n0 + c0 + e, mean8[e], istd8[e], sc, sh);
+                    t1[e] = 0.f; t2[e] = 0.f;
+                }
+            }
+            constexpr int NU = UR / WG;    // row blocks per wave
+            static_assert(UR % WG == 0, "row blocks per wave");
+            uint4 hv[NU];
+            if constexpr (EPI == E16_STORE_BNRED) {
+#pragma unroll
+                for (int k = 0; k < NU; ++k) {
+                    const int row = m0 + (wave / UC + WG * k) * 16 + r16;
+                    hv[k] = *reinterpret_cast<const uint4*>(g.Hbelow + (int64_t)row * g.ldh + n0 + c0);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+                const int rb = wave / UC + WG * k;
+                const tr_v4s lo = lds_tr16(isrc + rb * 16);
+                const tr_v4s hi = lds_tr16(isrc + 4 * IP + rb * 16);
+                uint4 o;
+                o.x = (uint32_t)(unsigned short)lo[0] | ((uint32_t)(unsigned short)lo[1] << 16);
+                o.y = (uint32_t)(unsigned short)lo[2] | ((uint32_t)(unsigned short)lo[3] << 16);
+                o.z = (uint32_t)(unsigned short)hi[0] | ((uint32_t)(unsigned short)hi[1] << 16);
+                o.w = (uint32_t)(unsigned short)hi[2] | ((uint32_t)(unsigned short)hi[3] << 16);
+                const int row = m0 + rb * 16 + r16;
+                if (!(g.dbg & 4)) *reinterpret_cast<uint4*>(g.C16 + (int64_t)row * g.ldc16 + n0 + c0) = o;
+                if constexpr (EPI == E16_STORE_BNRED) {
+                    const uint32_t dw[4] = {o.x, o.y, o.z, o.w};
+                    const uint32_t hw[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = __uint_as_float((e & 1) ? (dw[e >> 1] & 0xFFFF0000u) : (dw[e >> 1] << 16));
+                        const float hh = __uint_as_float((e & 1) ? (hw[e >> 1] & 0xFFFF0000u) : (hw[e >> 1] << 16));
+                        t1[e] += d;
+                        t2[e] = fmaf(d, (hh - mean8[e]) * istd8[e], t2[e]);
+                    }
+                }
+            }
+            if constexpr (EPI == E16_STORE_BNRED) {
+                // the 16 row-lanes of a group and the WG waves of a column pass hold partial sums of the same 8 columns
+                float* const bred = reinterpret_cast<float*>(smem16 + IMG_BYTES);   // [2][WG * 16][BN]
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    bred[(0 * WG * 16 + (wave / UC) * 16 + r16) * BN + c0 + e] = t1[e];
+                    bred[(1 * WG * 16 + (wave / UC) * 16 + r16) * BN + c0 + e] = t2[e];
+                }
+                __syncthreads();
+                for (int t = tid; t < 2 * BN; t += NT) {
+                    const int stat = t / BN, cb = t % BN;
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WG * 16; ++w) s += bred[(stat * WG * 16 + w) * BN + cb];
+                    atomicAdd(&g.bstat_out[(int64_t)stat * g.N + n0 + cb], (double)s);
+                }
+            }
+            if constexpr (EPI == E16_HIDDEN_TRAIN) {
+                for (int t = tid; t < 2 * BN; t += NT) {
+                    const int stat = t / BN, cb = t % BN;
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) s += lred[(stat * WM + w) * BN + cb];
+                    if (!(g.dbg & 1)) atomicAdd(&g.fstat_out[(int64_t)stat * g.N + n0 + cb], (double)s);
+                }
+            }
+            gemm16_stamp(g, 4);
+            return;
+        }
+        // ---- general epilogue (edge tiles, injected dropout masks, the transposed copy of the round-2 dataflow)
         // bf16 image of the output tile in LDS: [BM][CP] (operand buffers are free: every wave is past the last barrier)
         constexpr int CP = BN + 8;                         // elements per image row (keeps 16-byte alignment)
         constexpr int CT_BYTES = BM * CP * 2;
@@ -507,6 +697,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
             }
         }
         __syncthreads();
+        gemm16_stamp(g, 3);
         // row-major pass over the image: 16-byte chunks (8 columns), CPR chunks per row
         constexpr int CPR = BN / 8;
         constexpr int RPP = NT / CPR;         // rows covered by one pass of the workgroup
@@ -591,6 +782,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                 }
             }
         }
+        gemm16_stamp(g, 4);
     }
 }
 
@@ -602,7 +794,11 @@ constexpr size_t gemm16_smem_bytes() {
     const size_t img = (size_t)BM * (BN + 8) * 2 + (EPI == E16_HIDDEN_TRAIN ? (size_t)BN * (BM + 8) * 2 : 0);
     const size_t nt = (size_t)WM * WN * 64, rpp = nt / (BN / 8);
     const size_t red = EPI == E16_STORE_BNRED ? 2 * rpp * BN * 4 : 2 * (size_t)WM * BN * 4;
-    return ops > img + red ? ops : img + red;
+    // lean epilogue: transposed image [BN][BM + 8] + reduction scratch [2][16 * waves per column pass][BN]
+    const size_t wg = nt / 64 / (BN / 32 > 0 ? BN / 32 : 1);
+    const size_t lean = (size_t)BN * (BM + 8) * 2 + (EPI == E16_STORE_BNRED ? 2 * (wg > 0 ? wg : 1) * 16 * BN * 4 : 2 * (size_t)WM * BN * 4);
+    size_t need = ops > img + red ? ops : img + red;
+    return need > lean ? need : lean;
 }
 
 }  // namespace vh

@@ -46,8 +46,6 @@ struct Gemm16TnArgs {
     int xcd_remap;
 };
 
-typedef short tr_v4s __attribute__((ext_vector_type(4)));
-typedef short tr_v8s __attribute__((ext_vector_type(8)));
 
 // 64-byte-chunk permutation of a tile row (in 16-byte slot units), by row width
 template <int SPR>
@@ -55,10 +53,6 @@ __device__ __forceinline__ int tn_swz(int k) {
     if constexpr (SPR >= 16) return 4 * (k & 3);          // 256-byte rows: rows k .. k + 3 would share all banks
     else if constexpr (SPR == 8) return 4 * ((k >> 1) & 1);   // 128-byte rows: rows k and k + 2 would
     else return 0;                                        // 64-byte rows: four rows are 256 contiguous bytes
-}
-
-__device__ __forceinline__ tr_v4s lds_tr16(const unsigned char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p));
 }
 
 // STG: 0 = two LDS buffers, the next tile requested in front of the current tile's MFMAs; 2 = three buffers, the pieces of

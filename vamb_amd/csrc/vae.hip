@@ -1780,6 +1780,74 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
     });
 }
 
+int vh_debug_gemm16_timeline(int epi, int M, int N, int K, int variant, unsigned long long* stamps, int cap_blocks,
+                             int* n_blocks, float* ms) {
+    return guarded([&] {
+        VH_REQUIRE(stamps && n_blocks, "NULL argument");
+        VH_REQUIRE(epi == E16_SPLITK || epi == E16_BIAS || epi == E16_HIDDEN_TRAIN, "epi in {0 split-K, 1 bias, 3 hidden}");
+        VH_REQUIRE(M >= 8 && N >= 8 && K >= 8 && K % 8 == 0 && N % 8 == 0 && M % 8 == 0, "need M, N, K multiples of 8");
+        hipStream_t s;
+        VH_HIP(hipStreamCreate(&s));
+        DevBuf<bf16_t> dA, dB, dC16, dz;
+        DevBuf<float> dC32, dbias;
+        DevBuf<double> dstat;
+        DevBuf<unsigned long long> dts;
+        std::vector<bf16_t> hA((size_t)M * K), hB((size_t)N * K);
+        uint32_t x = 12345u;
+        auto rnd = [&] { x = x * 1664525u + 1013904223u; return (bf16_t)(0x3C00u + ((x >> 9) & 0x3FFu) + ((x >> 3) & 0x8000u)); };
+        for (auto& v : hA) v = rnd();
+        for (auto& v : hB) v = rnd();
+        dA.alloc(hA.size()); dB.alloc(hB.size()); dz.alloc(128);
+        VH_HIP(hipMemcpy(dA.p, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+        VH_HIP(hipMemcpy(dB.p, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+        VH_HIP(hipMemset(dz.p, 0, dz.bytes()));
+        dC32.alloc((size_t)M * N); dC16.alloc((size_t)M * N); dstat.alloc((size_t)2 * N); dbias.alloc(N);
+        VH_HIP(hipMemset(dbias.p, 0, dbias.bytes()));
+        VH_HIP(hipMemset(dstat.p, 0, dstat.bytes()));
+        const int max_blocks = (int)(ceil_div(M, 32) * ceil_div(N, 32));
+        dts.alloc((size_t)max_blocks * 8);
+        VH_HIP(hipMemset(dts.p, 0, dts.bytes()));
+        Gemm16Args g;
+        memset(&g, 0, sizeof(g));
+        g.A = dA.p; g.lda = K; g.B = dB.p; g.ldb = K; g.M = M; g.N = N; g.K = K;
+        g.k_per_split = K; g.slab_stride = (int64_t)M * N; g.zeros = dz.p;
+        g.C32 = dC32.p; g.ldc32 = N; g.C16 = dC16.p; g.ldc16 = N;
+        g.bias = dbias.p; g.m_real = M; g.fstat_out = dstat.p; g.drop_scale = 1.25f; g.drop_thresh = 858993459u; g.drop_key = 77;
+        g.xcd_remap = 1;
+        const int tile = variant & 0xFF;
+        auto run = [&] {
+            if (epi == E16_SPLITK) step16::gemm16_variant<E16_SPLITK>(s, tile, g, 1);
+            else if (epi == E16_BIAS) step16::gemm16_variant<E16_BIAS>(s, tile, g, 1);
+            else step16::gemm16_variant<E16_HIDDEN_TRAIN>(s, tile, g, 1);
+        };
+        for (int i = 0; i < 3; ++i) run();   // warm-up: attributes, caches
+        hipEvent_t e0, e1;
+        VH_HIP(hipEventCreate(&e0));
+        VH_HIP(hipEventCreate(&e1));
+        VH_HIP(hipEventRecord(e0, s));
+        for (int r = 0; r < 20; ++r) run();
+        VH_HIP(hipEventRecord(e1, s));
+        VH_HIP(hipStreamSynchronize(s));
+        float t = 0.f;
+        VH_HIP(hipEventElapsedTime(&t, e0, e1));
+        if (ms) *ms = t / 20.0f;
+        g.tstamps = dts.p;
+        run();
+        VH_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h((size_t)max_blocks * 8);
+        VH_HIP(hipMemcpy(h.data(), dts.p, h.size() * 8, hipMemcpyDeviceToHost));
+        int nb = 0;
+        for (int b = 0; b < max_blocks; ++b)
+            if (h[(size_t)b * 8] != 0) nb = b + 1;
+        *n_blocks = nb;
+        for (int b = 0; b < std::min(nb, cap_blocks); ++b)
+            for (int k = 0; k < 8; ++k) stamps[(size_t)b * 8 + k] = h[(size_t)b * 8 + k];
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(s);
+    });
+}
+
 int vh_debug_gemm16_tn(const float* A, const float* B, float* C, double* colsum, int M, int N, int K, int k_real, int splits,
                        int reps, int tile, int pipeline, float* ms) {
     return guarded([&] {
@@ -1890,7 +1958,7 @@ int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, 
         memset(&g, 0, sizeof(g));
         g.A = dA.p; g.lda = K; g.B = dB.p; g.ldb = K; g.M = M; g.N = N; g.K = K;
         g.k_per_split = k_per; g.slab_stride = (int64_t)M * N; g.zeros = dz.p;
-        g.C32 = dC32.p; g.ldc32 = N; g.C16 = dC16.p; g.ldc16 = N; g.C16T = dC16T.p; g.ldc16t = M;
+        g.C32 = dC32.p; g.ldc32 = N; g.C16 = dC16.p; g.ldc16 = N; g.C16T = CT ? dC16T.p : nullptr; g.ldc16t = M;   // without CT: the lean epilogue
         g.bias = dbias.p; g.m_real = M; g.fstat_out = dstat.p; g.drop_scale = 1.0f; g.xcd_remap = 1;
         const int tile = variant & 0xFF;
         g.dbg = variant >> 8;

@@ -75,7 +75,7 @@ void gemm16_tn_stg(hipStream_t s, const Gemm16TnArgs& g, int splits, int tile) {
 }
 template <int COLSUM>
 void gemm16_tn(hipStream_t s, const Gemm16TnArgs& g, int splits, int tile = 0, int pipeline = -1) {
-    if (pipeline < 0) pipeline = g_tuning.pipeline;
+    if (pipeline < 0) pipeline = 0;   // 4-wave tiles: the two-buffer loop (see gemm16)
     if (pipeline == 2) gemm16_tn_stg<COLSUM, 2>(s, g, splits, tile);
     else gemm16_tn_stg<COLSUM, 0>(s, g, splits, tile);
 }
@@ -95,10 +95,17 @@ void gemm16_stg(hipStream_t s, const Gemm16Args& g, int splits) {
         launch_gemm16<128, 128, 2, 4, EPI, STG>(s, g, splits);
     }
 }
+// The interleaved three-buffer loop pays on the 8-wave 128 x 128 tiles (two waves per SIMD: one wave's DMA issue hides under the
+// other's MFMAs); on the 4-wave split-K tiles it measured slower (profiles/r03b_gemm16_variants.txt, r03c_step_timeline_*.txt:
+// 64x128 weight gradients 16.8 -> 22.6 us, latent-wide 6.3 -> 10.8 us), so those stay on the two-buffer loop.
 template <int EPI>
 void gemm16(hipStream_t s, const Gemm16Args& g, int splits) {
-    if (g_tuning.pipeline == 2) gemm16_stg<EPI, 2>(s, g, splits);
-    else gemm16_stg<EPI, 0>(s, g, splits);
+    if constexpr (EPI == E16_SPLITK || EPI == E16_LATENT_MASK) {
+        gemm16_stg<EPI, 0>(s, g, splits);
+    } else {
+        if (g_tuning.pipeline == 2) gemm16_stg<EPI, 2>(s, g, splits);
+        else gemm16_stg<EPI, 0>(s, g, splits);
+    }
 }
 
 // every tile / pipeline variant of one epilogue (vh_debug_gemm16): 0 = the production choice by output shape,
