@@ -44,7 +44,8 @@ const char* vh_version(void);
  *   scan.debug (0)         timing experiments only (wrong results): 1 no pair of interest, 2 no histogram, 4 no flush,
  *                          8 no drain, 32 no histogram publication
  *   gen.profile (0)        wall-clock breakdown of the native cluster state machine on stderr
- *   gen.speculate (1), gen.spec_window (40), gen.spec_big_target (0)   speculative seed scans
+ *   gen.speculate (1), gen.spec_window (8), gen.spec_big_target (0)   medoid statistics scanned ahead of need in the free slots of a pass
+ *   gen.spec_neighbours (1)  ... including the within-radius rows of cached upcoming seeds (their first candidate round)
  *   vae.single_stream (0)  weight-gradient GEMMs on the main stream
  *   vae.fork_events (0)    forks as event records instead of kernel completion signals
  *   vae.big_tiles (0), vae.xcd_remap (1), vae.dw_workgroups (256), vae.debug_timing (0)

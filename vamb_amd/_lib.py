@@ -169,6 +169,7 @@ _ENV_OPTIONS = {
     "VAMBHIP_GEN_PROFILE": ("gen.profile", lambda v: 1),
     "VAMBHIP_NO_SPECULATION": ("gen.speculate", lambda v: 0),
     "VAMBHIP_SPEC_WINDOW": ("gen.spec_window", int),
+    "VAMBHIP_SPEC_NEIGHBOURS": ("gen.spec_neighbours", int),
     "VAMBHIP_SPEC_BIG_TARGET": ("gen.spec_big_target", int),
     "VAMBHIP_BIG_TILES": ("vae.big_tiles", int),
     "VAMBHIP_XCD_REMAP": ("vae.xcd_remap", int),

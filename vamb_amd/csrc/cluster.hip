@@ -74,7 +74,9 @@ constexpr int kListRing = 16;     // scans whose lists stay readable (one cluste
 // profiles/r02q_scan_ablation.txt).  The list cursor (word 63) lives in copy 0 only.
 constexpr int kResultReplicas = 8;    // (the publish kernel reads and zeroes every copy: more copies cost it more than they save)
 constexpr int kLocalCap = 128;    // per-block, per-medoid staging of list entries in LDS
-constexpr int kSpecWindow = 8;   // speculative seed scans kept ahead of the walk by the native state machine
+constexpr int kSpecWindow = 8;   // upcoming seeds the native state machine looks at when it fills the free medoid slots of a pass
+constexpr int kKeepList = 32;    // within-radius lists up to this length are copied out of the ring when a row is scanned ahead
+constexpr size_t kMaxCached = 192;   // medoid statistics kept across emissions (every emission re-validates all of them)
 
 // medoid rows travel in the kernel arguments (no upload, no gather launch)
 struct MedoidRows {
@@ -1752,7 +1754,9 @@ struct GenStats {
     uint64_t seq = 0;              // scan that produced the statistics; its results sit in ring slot seq % kListRing
     int slot_j = 0;
     unsigned int list_count = 0;   // > kListCap: the device list is incomplete
-    bool spec = false;             // scanned ahead of time (an upcoming seed): survives cluster emissions while provably valid
+    bool spec = false;             // scanned ahead of need (an upcoming seed or a neighbour of one) and not used yet
+    int64_t born = 0;              // emission count at its scan (age-based eviction)
+    std::vector<float> vec;        // the row itself (host copy): the per-emission validity check reads it from here
     bool hist_stale = false;       // rows were removed since the scan: the histogram (range 0.3) must be taken again
 };
 
@@ -1796,11 +1800,16 @@ struct vh_gen {
     int64_t spec_scanned = 0, spec_used = 0, spec_dropped = 0;
     bool speculate = true;
     int spec_window = kSpecWindow;
+    bool spec_neighbours = true;   // option gen.spec_neighbours: within-radius rows of cached upcoming seeds are scanned ahead too
     int spec_big_target = 0;      // experiment: widening target of passes over matrices above 600 k rows (0 = bucket fill)
     // optional wall-clock breakdown (VAMBHIP_GEN_PROFILE=1): scan calls, select calls, seed walk, logical index
     bool profile = false;
     double t_scan = 0, t_select = 0, t_seed = 0, t_logical = 0, t_total = 0;
     double t_km[33] = {0};          // scan wall time by medoid count of the pass (profile)
+    int64_t pass_seed = 0, pass_cand = 0, pass_hist = 0, pass_select = 0, pass_listsel = 0;   // passes by purpose (profile)
+    int64_t cand_rounds = 0, cand_rounds_cached = 0, cand_needed = 0, seeds_total = 0, seeds_cached = 0, wander_moves = 0;
+    int64_t kept_entries = 0, kept_emissions = 0, full_checks = 0;
+    int pass_purpose = 0;           // what the next scan pass is for: 0 seed, 1 candidate round
     int64_t n_km[33] = {0}, rows_km[33] = {0};
 };
 
@@ -1834,19 +1843,42 @@ void gen_remove_live(vh_gen* g, const int64_t* rows, int64_t n) {
     h->n_live -= n;
 }
 
-// The next live seeds of the length-ordered walk (cluster.py:342-384) after order_index, without touching the walk's
-// state: physical rows not scanned yet.  Bounded look-ahead (dead stretches are not tombstoned by a peek).
-void gen_upcoming_seeds(vh_gen* g, size_t want, const std::vector<int64_t>& exclude, std::vector<int64_t>& out) {
+// What to put into the free medoid slots of a pass that has to run anyway.  sample_medoid is a pure function of the live
+// matrix (cluster.py:606-637), so anything scanned now is exactly what a scan at the time of use returns -- as long as no
+// row removed in between lies inside the medoid radius of the scanned row (vh_gen_next re-validates every cached entry at
+// every emission).  In the order the walk will want them: the next live seeds (cluster.py:342-384, peeked at without
+// touching the walk's state: dead stretches are not tombstoned), and for a seed whose statistics are already cached with
+// its within-radius list, the rows of that list -- the pool wander_medoid draws its first candidates from
+// (cluster.py:415-450).  A C2 sweep spent 446 k of its 586 k passes on candidate rounds (profiles/r03g_sweep_pass_purposes.txt);
+// a round whose candidates were all scanned ahead needs no pass at all.
+void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& exclude, std::vector<int64_t>& out) {
     const int64_t n_order = (int64_t)g->order.size();
+    auto taken = [&](int64_t row) {
+        return g->stats.count(row) != 0 || std::find(exclude.begin(), exclude.end(), row) != exclude.end() ||
+               std::find(out.begin(), out.end(), row) != out.end();
+    };
+    // the upcoming live seeds, in walk order
+    std::vector<int64_t> upcoming;
     int64_t looked = 0;
-    for (int64_t i = g->order_index; i < n_order && out.size() < want && looked < 4096; ++i, ++looked) {
+    for (int64_t i = g->order_index; i < n_order && (int)upcoming.size() < g->spec_window && looked < 4096; ++i, ++looked) {
         const int64_t o = g->order[(size_t)i];
         if (o == -1 || !g->alive[(size_t)o]) continue;
-        const int64_t row = (int64_t)(std::lower_bound(g->indices.begin(), g->indices.end(), o) - g->indices.begin());
-        if (g->stats.count(row)) continue;
-        if (std::find(exclude.begin(), exclude.end(), row) != exclude.end()) continue;
-        if (std::find(out.begin(), out.end(), row) != out.end()) continue;
-        out.push_back(row);
+        upcoming.push_back((int64_t)(std::lower_bound(g->indices.begin(), g->indices.end(), o) - g->indices.begin()));
+    }
+    // seeds first (most of them turn out to be loners: their scan is all they need) ...
+    for (int64_t row : upcoming) {
+        if (out.size() >= want) return;
+        if (!taken(row)) out.push_back(row);
+    }
+    // ... then the candidate pools of the seeds whose statistics are already there
+    if (!g->spec_neighbours) return;
+    for (int64_t row : upcoming) {
+        const auto it = g->stats.find(row);
+        if (it == g->stats.end() || !it->second.have_list) continue;
+        for (int64_t r : it->second.within) {
+            if (out.size() >= want) return;
+            if (r != row && !taken(r)) out.push_back(r);
+        }
     }
 }
 
@@ -1864,21 +1896,22 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
     // in the same pass (free slots of the medoid-count bucket; a lone seed scan is widened).  They are used only while no
     // row removed since lies within the histogram range of the seed (vh_gen_next), i.e. while they are exactly what a
     // scan at the time of use would return.
+    // requested entries that were scanned ahead are in use from now on
+    for (size_t i = 0; i < n; ++i) {
+        const auto it = g->stats.find(medoids[i]);
+        if (it != g->stats.end() && it->second.spec) { it->second.spec = false; g->spec_used++; }
+    }
     size_t n_needed = missing.size();
     if (g->speculate) {
         size_t target = (size_t)pick_km((int)std::min<size_t>(missing.size(), kMaxMedoids));
         if (g->clu->max_k < kMaxMedoids) target = std::min(missing.size(), (size_t)g->clu->max_k);   // wide latents: no widening
         else if (scan_uses_mfma(g->clu, (int)std::min<size_t>(missing.size(), kMaxMedoids))) target = kMaxMedoids;   // matrix-pipe pass: 32 medoids cost what 9 cost
-        else if (missing.size() <= 8 && g->clu->n_rows <= 600000) target = kMaxMedoids;  // latency-bound pass: extra medoids are free
+        else if (g->clu->n_rows <= 600000) target = kMaxMedoids;  // latency-bound pass: extra medoids are free
         else if (g->spec_big_target > 0 && missing.size() <= 8) target = std::max(target, (size_t)g->spec_big_target);
         else if (missing.size() == 1) target = 8;
-        // look-ahead window: at most kSpecWindow unused speculative entries at any time (every emission re-validates them)
-        size_t n_spec = 0;
-        for (const auto& kv : g->stats) n_spec += kv.second.spec ? 1 : 0;
-        const size_t room = n_spec < (size_t)g->spec_window ? (size_t)g->spec_window - n_spec : 0;
-        if (missing.size() < target && missing.size() < (size_t)kMaxMedoids && room > 0) {
+        if (missing.size() < target && missing.size() < (size_t)kMaxMedoids && g->stats.size() < kMaxCached) {
             std::vector<int64_t> extra;
-            gen_upcoming_seeds(g, std::min(target - missing.size(), room), missing, extra);
+            gen_speculative_fill(g, std::min(target - missing.size(), kMaxCached - g->stats.size()), missing, extra);
             missing.insert(missing.end(), extra.begin(), extra.end());
         }
     }
@@ -1894,6 +1927,7 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         }
         g->n_km[k]++;
         g->rows_km[k] += g->clu->n_rows;
+        (g->pass_purpose == 0 ? g->pass_seed : g->pass_cand)++;
         g->scan_passes++;
         g->scan_medoids += k;
         g->rows_streamed += g->clu->n_rows;
@@ -1913,10 +1947,16 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
             st.list_count = g->clu->last_counts[slot][j];
             st.have_list = false;
             st.spec = lo + (size_t)j >= n_needed;
+            st.born = g->n_emitted;
+            {   // the row itself, for the validity checks of the emissions to come
+                const float* v = g->clu->host_rows.data() + (size_t)g->indices[(size_t)missing[lo + j]] * g->clu->L;
+                st.vec.assign(v, v + g->clu->L);
+            }
             if (st.spec) {
                 g->spec_scanned++;
-                // a speculative entry may be used after its scan has left the ring: keep its (short) list now
-                if (st.list_count <= 8u) {
+                // an entry scanned ahead may be used after its scan has left the ring, and its list names the rows to scan
+                // ahead next (gen_speculative_fill): keep it now if it is short
+                if (st.list_count <= (unsigned int)kKeepList) {
                     const int32_t* src = g->clu->lists + ((size_t)slot * kMaxMedoids + j) * kListCap;
                     st.within.assign(src, src + st.list_count);
                     std::sort(st.within.begin(), st.within.end());
@@ -1931,6 +1971,7 @@ int64_t gen_select(vh_gen* g, int64_t medoid, float threshold, bool remove) {
     int64_t n = 0;
     g->sel.resize((size_t)std::max<int64_t>(1, g->clu->n_rows));
     GenTimer t(&g->t_select);
+    (remove ? g->pass_select : g->pass_listsel)++;
     gen_check(vh_clu_select(g->clu, medoid, nullptr, threshold, remove ? 1 : 0, g->sel.data(), (int64_t)g->sel.size(), &n));
     g->scan_passes++;
     g->rows_streamed += g->clu->n_rows;
@@ -2000,10 +2041,9 @@ void gen_update_successes(vh_gen* g, bool success) {
 int64_t gen_wander(vh_gen* g, int64_t seed) {
     int64_t medoid = seed;
     std::vector<int64_t> tried{medoid};
-    {
-        const auto it = g->stats.find(seed);
-        if (it != g->stats.end() && it->second.spec) { g->spec_used++; it->second.spec = false; }
-    }
+    g->seeds_total++;
+    if (g->stats.count(seed)) g->seeds_cached++;
+    g->pass_purpose = 0;
     gen_ensure_stats(g, &seed, 1);
     double local_density = g->stats.at(seed).density;
     auto untried = [&](const std::vector<int64_t>& rows) {
@@ -2017,6 +2057,14 @@ int64_t gen_wander(vh_gen* g, int64_t seed) {
     size_t i = 0;
     while (i < candidates.size()) {
         // look ahead: every not-yet-scanned candidate of this round shares one matrix pass
+        if (i == 0) {
+            size_t miss = 0;
+            for (int64_t c : candidates) miss += g->stats.count(c) ? 0 : 1;
+            g->cand_rounds++;
+            g->cand_needed += (int64_t)miss;
+            g->cand_rounds_cached += miss == 0 ? 1 : 0;
+        }
+        g->pass_purpose = 1;
         gen_ensure_stats(g, candidates.data() + i, candidates.size() - i);
         const int64_t sampled = candidates[i];
         tried.push_back(sampled);
@@ -2024,6 +2072,7 @@ int64_t gen_wander(vh_gen* g, int64_t seed) {
         if (d > local_density) {
             medoid = sampled;
             local_density = d;
+            g->wander_moves++;
             pool = untried(gen_within(g, sampled));
             g->rng.sample(pool, (int)std::min<size_t>(pool.size(), (size_t)g->maxsteps), candidates);
             i = 0;
@@ -2045,6 +2094,7 @@ void gen_fetch_hist(vh_gen* g, int64_t medoid, GenStats& st) {
             (void)scan_core(g->clu, 1, &medoid, nullptr);
         }
         g->scan_passes++;
+        g->pass_hist++;
         g->scan_medoids += 1;
         g->rows_streamed += g->clu->n_rows;
         gen_collect_ms(g);
@@ -2156,6 +2206,7 @@ int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, in
         g->profile = option("gen.profile", 0) != 0;
         g->speculate = option("gen.speculate", 1) != 0;
         g->spec_window = (int)option("gen.spec_window", kSpecWindow);
+        g->spec_neighbours = option("gen.spec_neighbours", 1) != 0;
         g->spec_big_target = (int)option("gen.spec_big_target", 0);
         g->order.assign(order, order + n);
         g->indices.resize((size_t)n);
@@ -2176,6 +2227,13 @@ int vh_gen_destroy(vh_gen* g) {
                 g->t_total - g->t_scan - g->t_select - g->t_seed - g->t_logical, (long long)g->scan_passes,
                 (long long)g->scan_medoids, (long long)g->spec_scanned, (long long)g->spec_used, (long long)g->spec_dropped);
     if (g && g->profile) {
+        fprintf(stderr, "[vambhip]   passes by purpose: seed scans %lld, candidate rounds %lld, histogram re-scans %lld, selects %lld (+ %lld list selects); "
+                "seeds %lld (cached at arrival %lld), candidate rounds %lld (fully cached %lld, %lld candidates to scan), medoid moves %lld; "
+                "cached entries per emission %.1f, row-by-row validity checks %lld\n",
+                (long long)g->pass_seed, (long long)g->pass_cand, (long long)g->pass_hist, (long long)g->pass_select, (long long)g->pass_listsel,
+                (long long)g->seeds_total, (long long)g->seeds_cached, (long long)g->cand_rounds, (long long)g->cand_rounds_cached,
+                (long long)g->cand_needed, (long long)g->wander_moves,
+                g->kept_emissions ? (double)g->kept_entries / (double)g->kept_emissions : 0.0, (long long)g->full_checks);
         for (int k = 1; k <= 32; ++k)
             if (g->n_km[k])
                 fprintf(stderr, "[vambhip]   passes with %2d medoids: %8lld, %7.1f ms, avg %6.1f us, avg rows %9.0f\n", k,
@@ -2195,6 +2253,8 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
         GenTimer t_all(&g->t_total);
         int64_t n_points = 0;
         std::vector<int64_t> points;
+        int64_t emitted_medoid = -1;   // physical row and radius of the cluster being emitted (validity check below)
+        double emitted_radius = 0.0;
         while (true) {
             const int64_t seed = gen_next_seed(g);
             const int64_t medoid = gen_wander(g, seed);
@@ -2212,6 +2272,8 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
                 info->attempts = (int64_t)g->attempts.size();
                 points.assign(1, medoid);
                 gen_remove_live(g, points.data(), 1);
+                emitted_medoid = medoid;
+                emitted_radius = 0.0;
                 break;
             }
             if (kind == kNoThreshold) {
@@ -2223,6 +2285,8 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
                     info->attempts = (int64_t)g->attempts.size();
                     n_points = gen_select(g, medoid, (float)0.06, true);
                     points.assign(g->sel.begin(), g->sel.begin() + n_points);
+                    emitted_medoid = medoid;
+                    emitted_radius = 0.06;
                     break;
                 }
                 gen_update_successes(g, false);
@@ -2236,53 +2300,69 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
             info->attempts = (int64_t)g->attempts.size();
             n_points = gen_select(g, medoid, (float)threshold, true);
             points.assign(g->sel.begin(), g->sel.begin() + n_points);
+            emitted_medoid = medoid;
+            emitted_radius = threshold;
             if (g->pvr < 0.55) gen_update_successes(g, true);
             break;
         }
         VH_REQUIRE((int64_t)points.size() <= cap, "members buffer too small");
         for (size_t i = 0; i < points.size(); ++i) members[i] = g->indices[(size_t)points[i]];
         info->n_members = (int64_t)points.size();
-        // __next__ bookkeeping.  The reference clears its sample_medoid cache here because a removal may change any
-        // cached result.  Of a speculative seed scan the NEAR-FIELD results (density, counts and the list of rows within
-        // the medoid radius 0.05: everything wander_medoid and the loner test read) stay exact as long as no removed row
-        // lies within that radius of the seed (checked with a margin that covers any float32 summation order); its
-        // histogram reaches out to 0.3 and is simply taken again if the seed ends up as the medoid of a cluster.
+        // __next__ bookkeeping.  The reference clears its sample_medoid cache here because a removal may change any cached
+        // result (cluster.py:298-316).  What wander_medoid and the loner test read of a cached entry -- density, the two counts
+        // and the list of rows within the medoid radius 0.05 -- is a function of the live rows INSIDE that radius only, so an
+        // entry stays exact as long as no removed row lies within the radius of its row (checked with a margin that covers any
+        // float32 summation order); its histogram reaches out to 0.3 and is simply taken again if the row ends up as the
+        // medoid of a cluster.  Every cached entry is checked, whether it was scanned ahead or for the search that just ended
+        // (its neighbours are the next seeds' candidates more often than not).
+        // Cost control: an entry carries a host copy of its row (no random access into the 256 MB host matrix); entries whose
+        // angle to the cluster's medoid exceeds angle(cluster radius) + angle(medoid radius) cannot be near any removed row
+        // (triangle inequality on the sphere) and take ONE dot product per emission; the rest is compared row by row.
         {
-            // (The dot products are summed in eight interleaved partial sums -- the compiler vectorises that -- instead of
-            // one scalar chain of L dependent adds, which made this check the largest host-side term of a sweep: ~0.3 us
-            // per (emission, speculative entry).  The margin covers any summation order.  Entries are filtered in place.)
             const int L = g->clu->L;
             const float* hm = g->clu->host_rows.data();
             for (int64_t r : points) __builtin_prefetch(hm + (size_t)g->indices[(size_t)r] * L);
-            size_t n_keep = 0;
+            auto dot8 = [L](const float* a, const float* b) {
+                float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int c = 0;
+                for (; c + 8 <= L; c += 8)
+                    for (int k = 0; k < 8; ++k) part[k] += a[c + k] * b[c + k];
+                float dot = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+                for (; c < L; ++c) dot += a[c] * b[c];
+                return dot;
+            };
+            // rows are scaled to norm 1 / sqrt(2): cos(angle) = 2 <x, y> = 1 - 2 d
+            const float* vmed = hm + (size_t)g->indices[(size_t)emitted_medoid] * L;
+            const double t_cluster = std::min(0.5, std::max(0.0, emitted_radius) + 2e-3);
+            const double ang_limit = std::acos(1.0 - 2.0 * t_cluster) + std::acos(1.0 - 2.0 * (0.05 + 2e-3)) + 1e-3;
+            const float cos_limit = ang_limit < 3.14 ? (float)std::cos(ang_limit) : -2.0f;   // entries with 2 <e, m> < cos_limit are safe
+            const bool all_zero_medoid = dot8(vmed, vmed) < 0.25f;   // (an all-zero row has no direction: no shortcut)
             for (auto it = g->stats.begin(); it != g->stats.end();) {
                 GenStats& st = it->second;
-                bool valid = st.spec;
-                if (valid) {
-                    const float* vm = hm + (size_t)g->indices[(size_t)it->first] * L;
+                bool valid = true;
+                const float* vm = st.vec.data();
+                // entries that served the search that just ended are dropped like the reference's cache (their rows are mostly
+                // members of the emitted cluster); entries scanned ahead stay until used, invalidated or clearly overtaken
+                if (!st.spec || g->n_emitted - st.born > 96) valid = false;
+                if (valid && (all_zero_medoid || 2.0f * dot8(vm, vmed) >= cos_limit - 1e-4f)) {
+                    g->full_checks++;
                     for (int64_t r : points) {
                         if (r == it->first) { valid = false; break; }
                         const float* vr = hm + (size_t)g->indices[(size_t)r] * L;
-                        float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                        int c = 0;
-                        for (; c + 8 <= L; c += 8)
-                            for (int k = 0; k < 8; ++k) part[k] += vm[c + k] * vr[c + k];
-                        float dot = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-                        for (; c < L; ++c) dot += vm[c] * vr[c];
-                        if (0.5f - dot <= 0.05f + 2e-3f) { valid = false; break; }
+                        if (0.5f - dot8(vm, vr) <= 0.05f + 2e-3f) { valid = false; break; }
                     }
-                    if (!valid) g->spec_dropped++;
+                    if (!valid && st.spec) g->spec_dropped++;
                 }
                 if (valid) {
                     st.hist_stale = true;
                     st.have_hist = false;
-                    ++n_keep;
                     ++it;
                 } else {
                     it = g->stats.erase(it);
                 }
             }
-            if (n_keep > 256) { g->spec_dropped += (int64_t)n_keep; g->stats.clear(); }   // bounded validity work per emission
+            g->kept_entries += (int64_t)g->stats.size();
+            g->kept_emissions++;
         }
         g->n_emitted++;
         g->n_remaining -= (int64_t)points.size();
