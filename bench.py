@@ -74,7 +74,7 @@ def parse():
                    help="PROFILING ONLY: leave the cluster sweep out of a step (a rocprofv3 trace of a short training "
                         "run; with few epochs the latents are unstructured and the sweep degenerates).  The line is "
                         "marked as such and is not a valid headline")
-    p.add_argument("--c3-epochs", type=int, default=3)
+    p.add_argument("--c3-epochs", type=int, default=300, help="training epochs of the C3-shape whole-job leg")
     p.add_argument("--deadline", type=float, default=1650.0,
                    help="seconds from process start the whole run should fit in (the driver allows 1800): only the "
                         "UNTIMED parts adapt to it (later warm-up steps run fewer epochs, the C3 leg may be skipped)")
@@ -137,7 +137,7 @@ def run_step(ve, vc, lib, _lib, dl, lens, args, seed, comm=None, probe_layer=0, 
         _lib.check(lib.vh_vae_probe_result(vae._h, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl)))
         return dict(setup_s=t1 - t0, train_s=t2 - t1, encode_s=t3 - t2, cluster_s=0.0, total_s=t3 - t0, clusters=0,
                     probe_ms=ms.value, probe_launches=nl.value, probe_flops=fl.value, scan_passes=0, scan_medoids=0,
-                    scan_kernel_ms=0.0, scan_bytes=0, loss=vae.last_epoch_losses["loss"], latent=latent)
+                    scan_kernel_ms=0.0, scan_bytes=0, scan_resident_bytes=0, loss=vae.last_epoch_losses["loss"], latent=latent)
     if sharded is not None:
         gen = sharded(latent, lens, seed)
         backend = gen._backend
@@ -160,10 +160,14 @@ def run_step(ve, vc, lib, _lib, dl, lens, args, seed, comm=None, probe_layer=0, 
     _lib.check(lib.vh_vae_probe_result(vae._h, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl)))
     b = backend
     L4 = (args.latent + 3) // 4 * 4
+    # algorithmic bytes of a pass = N_LIVE x (4 L4 + 4 + 1): live rows at the time of the pass, not the
+    # resident (dead-but-uncompacted) rows the kernels actually stream -- those are reported beside it
+    live_rows = getattr(b, "live_rows_streamed", b.rows_streamed)
     out = dict(setup_s=t1 - t0, train_s=t2 - t1, encode_s=t3 - t2, cluster_s=t4 - t3, total_s=t4 - t0,
                clusters=n_clusters, probe_ms=ms.value, probe_launches=nl.value, probe_flops=fl.value,
                scan_passes=b.scan_passes, scan_medoids=b.scan_medoids, scan_kernel_ms=b.kernel_ms,
-               scan_bytes=b.rows_streamed * (4 * L4 + 5), loss=vae.last_epoch_losses["loss"], latent=latent)
+               scan_bytes=live_rows * (4 * L4 + 5), scan_resident_bytes=b.rows_streamed * (4 * L4 + 5),
+               loss=vae.last_epoch_losses["loss"], latent=latent)
     b.close()
     return out
 
@@ -180,6 +184,28 @@ def probe_roofline(steps, what, peak):
             "timing": "kernel begin/end timestamps (hipExtLaunchKernelGGL start/stop events on the launching stream)"}
 
 
+def scan_summary(timed, wall, measured_in):
+    """cluster_scan object: `timed` = steps that ran with HIP-event timing of every scan / select kernel (kernel-time
+    fraction), `wall` = steps whose sweep ran untimed, as a user runs it (fraction over the sweep's wall time)."""
+    kms = sum(r["scan_kernel_ms"] for r in timed)
+    kbytes = sum(r["scan_bytes"] for r in timed)
+    wbytes = sum(r["scan_bytes"] for r in wall)
+    wres = sum(r["scan_resident_bytes"] for r in wall)
+    wsec = sum(r["cluster_s"] for r in wall)
+    return {
+        "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBPS,
+        "bytes": "algorithmic: live rows at the time of each pass x (4 L4 + 4 + 1) B (SURVEY.md 8d)",
+        "achieved": kbytes / (kms * 1e-3) / 1e9 if kms else None,
+        "frac": kbytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBPS if kms else None,
+        "achieved_over_sweep_wall_time": wbytes / wsec / 1e9 if wsec else None,
+        "frac_over_sweep_wall_time": wbytes / wsec / 1e9 / PEAK_HBM_GBPS if wsec else None,
+        "resident_over_live_bytes": wres / wbytes if wbytes else None,
+        "passes": sum(r["scan_passes"] for r in (wall or timed)), "medoids": sum(r["scan_medoids"] for r in (wall or timed)),
+        "kernel_ms_total": kms, "sweep_wall_s": wsec,
+        "measured_in": measured_in,
+    }
+
+
 def pmc_traffic(tag):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", f"r02_pmc_roofline_{tag}.json")
@@ -190,10 +216,13 @@ def pmc_traffic(tag):
         return None
 
 
-def c3_shape_leg(args, ve, lib, _lib, synth):
-    """Training + encode at the C3 shape (2 M contigs x 1000 samples: 8.8 GB of features) on ONE GPU: the shape
-    BASELINE's 10x target is quoted on.  A few epochs only (the epoch time does not depend on the epoch count)."""
+def c3_shape_leg(args, ve, vc, lib, _lib, synth):
+    """The WHOLE job at the C3 shape (2 M contigs x 1000 samples: 8.8 GB of features) on ONE GPU -- the shape BASELINE's 10x
+    target is quoted on: VAE.trainmodel (args.c3_epochs, default the CLI's 300) -> encode -> full cluster sweep, one timed
+    step; then the sweep once more on the same latents with HIP-event timing of every pass (its kernel-time roofline)."""
     n, S, bs = CONFIGS["C3"][0], CONFIGS["C3"][1], CONFIGS["C3"][2]
+    a3 = argparse.Namespace(**vars(args))
+    a3.contigs, a3.samples, a3.batch, a3.latent, a3.epochs, a3.no_cluster = n, S, bs, 32, args.c3_epochs, False
     t0 = time.perf_counter()
     ab, tnf, lens, _ = synth.features(n, S, seed=3)
     t_synth = time.perf_counter() - t0
@@ -201,36 +230,44 @@ def c3_shape_leg(args, ve, lib, _lib, synth):
     dl = ve.make_dataloader(ab, tnf, lens, batchsize=bs, destroy=True)
     t_prep = time.perf_counter() - t0
     prep_on_device = getattr(dl.dataset, "_vambhip_prepared", None) is not None
-    vae = ve.VAE(S, nlatent=32, seed=3)
-    _lib.check(lib.vh_vae_set_probe(vae._h, 1, 0))
+    del ab, tnf
+    # allocations / kernel attributes of this shape, outside the timed step
+    run_step(ve, vc, lib, _lib, dl, lens, argparse.Namespace(**dict(vars(a3), no_cluster=True)), seed=1003, epochs=1)
     t0 = time.perf_counter()
-    vae._ensure_dataset(dl)
-    t_up = time.perf_counter() - t0
-    vae.trainmodel(dl, nepochs=1, batchsteps=None)     # allocations, kernel attributes
-    _lib.check(lib.vh_vae_set_probe(vae._h, 1, 0))
-    t0 = time.perf_counter()
-    vae.trainmodel(dl, nepochs=args.c3_epochs, batchsteps=None)
-    t_epoch = (time.perf_counter() - t0) / args.c3_epochs
-    t0 = time.perf_counter()
-    vae.encode(dl)
-    t_enc = time.perf_counter() - t0
-    ms, nl, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-    _lib.check(lib.vh_vae_probe_result(vae._h, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl)))
+    r = run_step(ve, vc, lib, _lib, dl, lens, a3, seed=3, probe_layer=0, time_scans=False)
+    t_job = time.perf_counter() - t0
+    latent = r.pop("latent")
+    # the same sweep with per-pass kernel timing (a stream synchronisation per pass: not part of the timed job)
+    gen = vc.ClusterGenerator(latent.copy(), lens, destroy=True, rng_seed=3)
+    gen._backend.set_timing(True)
+    tt = time.perf_counter()
+    n_clusters2 = sum(1 for _ in gen)
+    t_sweep2 = time.perf_counter() - tt
+    gen._sync_native_counters()
+    bk = gen._backend
+    timed = dict(scan_kernel_ms=bk.kernel_ms, scan_bytes=getattr(bk, "live_rows_streamed", bk.rows_streamed) * (4 * 32 + 5),
+                 scan_resident_bytes=bk.rows_streamed * (4 * 32 + 5), scan_passes=bk.scan_passes, scan_medoids=bk.scan_medoids,
+                 cluster_s=t_sweep2)
+    bk.close()
     D = S + NTNF + 1
     flops_contig = 12 * HIDDEN * (D + HIDDEN + 32) - 2 * D * HIDDEN
-    peak = PEAK_BF16_MFMA_TFLOPS if vae.compute_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-    ach = fl.value / (ms.value / max(nl.value, 1) * 1e-3) / 1e12 if nl.value else None
-    return {"workload": f"C3 shape on one GPU: {n} contigs x {S} samples (D={D}), batch {bs}, {vae.compute_dtype}; "
-                        f"{args.c3_epochs} epochs timed + encode, no cluster sweep",
+    bf16 = args.dtype == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    t_epoch = r["train_s"] / a3.epochs
+    roof = probe_roofline([r], f"first encoder layer, M={bs}, K=D={D} (padded 1120), N=512", peak)
+    return {"workload": f"C3 shape on one GPU: {n} contigs x {S} samples (D={D}), batch {bs}, {args.dtype}; whole job = "
+                        f"{a3.epochs} train epochs + encode + full cluster sweep, ONE timed step",
+            "value": n / t_job, "unit": "contigs/s", "job_s": t_job,
+            "train_s": r["train_s"], "encode_s": r["encode_s"], "cluster_s": r["cluster_s"], "setup_s": r["setup_s"],
+            "clusters": r["clusters"], "clusters_second_sweep": n_clusters2, "final_loss": r["loss"],
             "epoch_ms": t_epoch * 1e3, "us_per_step": t_epoch / (n // bs) * 1e6,
             "train_contigs_per_s_per_epoch": n / t_epoch, "train_tflops_algorithmic": flops_contig * n / t_epoch / 1e12,
-            "encode_ms": t_enc * 1e3, "synthetic_input_s": t_synth,
-            "make_dataloader_s": t_prep, "make_dataloader_on": "device (csrc/prep.hip: one upload of the raw matrices + "
-            "normalisation kernels, PCIe-inclusive)" if prep_on_device else "host (numpy)", "upload_s": t_up,
-            "roofline_encoder_gemm": None if ach is None else {
-                "kernel": f"first encoder layer, M={bs}, K=D={D} (padded 1120), N=512", "bound": "mfma", "achieved": ach,
-                "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "avg_launch_ms": ms.value / nl.value,
-                "launches": nl.value, "flops_per_launch": fl.value}}
+            "synthetic_input_s": t_synth, "make_dataloader_s": t_prep,
+            "make_dataloader_on": "device (csrc/prep.hip: one upload of the raw matrices + normalisation kernels, "
+                                  "PCIe-inclusive)" if prep_on_device else "host (numpy)",
+            "roofline_encoder_gemm": roof,
+            "cluster_scan": scan_summary([timed], [r], "kernel time: a second, event-timed sweep over the same latents; "
+                                                          "wall time: the sweep of the timed job")}
 
 
 def cpu_baseline(args, latent, lens):
@@ -441,6 +478,8 @@ def main():
                                        "(bias + leaky-relu + dropout + BatchNorm batch sums in the epilogue)", peak)
         if roof is not None:
             roof["traffic"] = pmc_traffic(cfg_name.lower())
+            roof["traffic_source"] = (f"static: profiles/r02_pmc_roofline_{cfg_name.lower()}.json (rocprofv3 --pmc passes of this kernel "
+                                      "at this shape, FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE); NOT counted in this run")
             if roof["traffic"]:
                 # the same launches against the other roofline: at C2 the kernel's arithmetic intensity (flops / PMC bytes)
                 # is below the ridge of 2.5 PFLOP/s : 8 TB/s = 312 flop/B, i.e. it is the HBM side that binds there
@@ -483,14 +522,7 @@ def main():
             "encode_ms": float(np.mean([r["encode_s"] for r in results]) * 1e3),
             "cluster_ms": float(np.mean([r["cluster_s"] for r in results]) * 1e3),
             "clusters_per_step": int(np.mean([r["clusters"] for r in results])),
-            "cluster_scan": {
-                "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBPS,
-                "achieved": scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else None,
-                "frac": scan_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS if scan_ms else None,
-                "passes": sum(r["scan_passes"] for r in scan_src), "medoids": sum(r["scan_medoids"] for r in scan_src),
-                "kernel_ms_total": scan_ms,
-                "measured_in": "first warm-up step" if warm else "timed steps",
-            },
+            "cluster_scan": scan_summary(scan_src, results, ("kernel time: first warm-up step (HIP-event timing of every pass); " if warm else "kernel time: timed steps; ") + "wall time: the timed steps"),
             "make_dataloader": None if strong else {
                 "seconds": prep_s, "on": "device" if prep_on_device else "host",
                 "note": "outside the timed region; on the device it is ONE upload of the raw abundance / TNF matrices "
@@ -507,12 +539,12 @@ def main():
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None
         if world == 1 and not args.no_c3 and cfg_name != "C3":
-            if args.deadline - (time.perf_counter() - T_START) < 240.0:
+            if args.deadline - (time.perf_counter() - T_START) < 330.0:   # synthetic input 35 s + job ~60 s + timed sweep ~30 s + margin
                 line["c3_shape"] = {"skipped": "not enough of --deadline left for the extra leg"}
             else:
                 del dl, ab, tnf      # free the C2 dataset first (host arrays + the device copy cached on the loader)
                 try:
-                    line["c3_shape"] = c3_shape_leg(args, ve, lib, _lib, synth)
+                    line["c3_shape"] = c3_shape_leg(args, ve, vc, lib, _lib, synth)
                 except Exception as e:   # never lose the headline because of the extra leg
                     line["c3_shape"] = {"error": repr(e)}
         emit_result(line)

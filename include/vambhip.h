@@ -183,6 +183,9 @@ int vh_debug_pyrandom_sample(uint64_t seed, int n_calls, const int64_t* ns, cons
  * len(attempts) / order_index, cluster.py:282-283, 386-413): what repr() and callers inspecting the attributes see */
 int vh_gen_state(vh_gen* g, double* peak_valley_ratio, int64_t* successes, int64_t* attempts, int64_t* order_index);
 /* accounting: passes over the matrix, medoids scanned, rows streamed, summed kernel time (when timing is on) */
+/* Sum over all scan / select passes so far of the LIVE rows at the time of the pass (vh_gen_counters' rows_streamed counts
+ * the resident rows, dead-but-uncompacted ones included): the N_live of SURVEY.md section 8d's algorithmic bytes. */
+int vh_gen_live_rows(vh_gen* g, int64_t* live_rows_streamed);
 int vh_gen_counters(vh_gen* g, int64_t* scan_passes, int64_t* scan_medoids, int64_t* rows_streamed,
                     double* kernel_ms, int64_t* n_emitted, int64_t* n_remaining);
 

@@ -210,6 +210,27 @@ def test_c2_sized_sweep_properties(oracle_lib):
     assert len(gen.matrix) < n // 4          # order-preserving compaction ran (rows are dropped as they are emitted)
 
 
+def test_c4_sized_sweep_properties(oracle_lib):
+    """BASELINE config C4's latent matrix on ONE GPU: 10 M x 64 (2.6 GB, resident in HBM), 2 000 genomes: every contig emitted
+    exactly once, members ascending, >= 95 % pure clusters, physical compaction on the way."""
+    n, k = 10_000_000, 2000
+    lat, labels = synth.blob_latent(n, 64, 0.08, seed=4, k=k)
+    lens = synth.lengths(n, 4)
+    seen = np.zeros(n, np.int8)
+    pure = clusters = 0
+    gen = vc.ClusterGenerator(lat, lens, destroy=True, rng_seed=4)
+    for c in gen:
+        seen[c.members] += 1
+        assert c.members[0] >= 0 and np.all(np.diff(c.members) > 0)
+        lab = labels[c.members]
+        pure += np.bincount(lab).max() == len(lab)
+        clusters += 1
+    assert (seen == 1).all()
+    assert clusters >= k * 0.9
+    assert pure >= 0.95 * clusters
+    assert len(gen.matrix) < n // 4
+
+
 def _stream_prefix(st, n):
     """The first n clusters of a packed stream."""
     m = int(st["sizes"][:n].sum())

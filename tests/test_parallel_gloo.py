@@ -39,7 +39,13 @@ def _worker(rank, world, port, fn_name, queue):
         from vamb_amd import parallel
 
         comm = parallel.Communicator(dist, rccl=False)
-        result = globals()[fn_name](comm)
+        if ":" in fn_name:   # "module:function" -- a per-rank body defined in another test module
+            import importlib
+
+            mod, fn = fn_name.split(":")
+            result = getattr(importlib.import_module(mod), fn)(comm)
+        else:
+            result = globals()[fn_name](comm)
         dist.barrier()
         dist.destroy_process_group()
         queue.put((rank, "ok", result))

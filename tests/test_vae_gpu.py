@@ -503,8 +503,8 @@ def test_baseline_shapes_match_oracle(cfg, S, batch, dtype, monkeypatch):
     (S = 1000, D_p = 1120, batch 8192; bf16 as prescribed and fp32 as the exact check of the same shape) against the
     fp64 numpy oracle with injected dropout masks and noise.  Tolerances: SURVEY.md section 8(c) -- fp32: losses 2e-5,
     gradients 2e-3 of the tensor norm (and element-wise 2e-4 of its largest entry), latents 2^-10; bf16-MFMA: losses
-    1e-3, gradients 20 % Frobenius with cosine > 0.98 (see test_training_steps_bf16_within_tolerance for why), latents
-    2e-2 of the largest latent."""
+    1e-3, gradients within 1.6 x the error the bf16 ARITHMETIC MODEL of the step predicts for this batch (see below), cosine
+    > 0.99, latents 2e-2 of the largest latent."""
     monkeypatch.setenv("VAMBHIP_PRECISION", dtype)
     hid, L = [512, 512], 32
     ab, tnf, lens, _ = synth.features(batch, S, seed=31)
@@ -523,13 +523,29 @@ def test_baseline_shapes_match_oracle(cfg, S, batch, dtype, monkeypatch):
     want = oracle.train_step(d, t, a, w, eps, masks)
     bf16 = dtype == "bf16"
     assert rel(losses, want) < (1e-3 if bf16 else 2e-5), (losses, want)
+    model_err = None
+    if bf16:
+        # What "bf16 operands, fp32 accumulate" (BASELINE configs[2]) costs BY ITSELF: the fp64 restatement of the step's
+        # dataflow with every stored tensor rounded to bf16 where the GPU rounds it (oracle/bf16_error_budget.py) on this very
+        # batch.  The gradient error is dominated by the rounding of the FORWARD operands (weights 3e-2, activations 3e-2;
+        # the backward tensors and the place the sums are taken: 1e-3, profiles/r03_bf16_error_budget.txt), i.e. it is a
+        # property of the prescribed arithmetic: the GPU has to stay within that model, not within SURVEY 8c's 2e-2 guess.
+        import bf16_error_budget as budget
+
+        flow = budget.Flow(st0, S, hid, L, vae.alpha, vae.beta, 0.2,
+                           ["x", "w", "h", "z", "dR", "dA", "dZ", "dMU", "bstat", "dbias"])
+        gm = flow.step(d.astype(np.float64), t.astype(np.float64), a.astype(np.float64), w.astype(np.float64),
+                       eps.astype(np.float64), [m.astype(np.float64) for m in masks])
+        model_err = {n: np.linalg.norm(gm[n] - oracle.grads[n]) / max(np.linalg.norm(oracle.grads[n]), 1e-30) for n in oracle.names}
     for name in oracle.names:
         got = vae.parameters_gradient(name).astype(np.float64)
         ref = np.asarray(oracle.grads[name], dtype=np.float64)
         nr = max(np.linalg.norm(ref), 1e-30)
         if bf16:
-            assert np.linalg.norm(got - ref) / nr < 0.2, name
-            assert float(got.ravel() @ ref.ravel()) / (max(np.linalg.norm(got), 1e-30) * nr) > 0.98, name
+            err = np.linalg.norm(got - ref) / nr
+            assert err < 1.6 * model_err[name] + 3e-3, (name, err, model_err[name])
+            assert err < 0.15, (name, err)
+            assert float(got.ravel() @ ref.ravel()) / (max(np.linalg.norm(got), 1e-30) * nr) > 0.99, name
         else:
             assert np.linalg.norm(got - ref) <= 2e-3 * nr, name
             # element-wise per output unit; a handful of units (measured: 5-16 of 512 at C1 / C3) sit on a LeakyReLU kink where
@@ -590,3 +606,36 @@ def test_large_batch_tiles_match_oracle(batch, big, monkeypatch):
     lat = vae.encode(dl)
     ref = oracle.encode(d, t, a)
     assert np.abs(lat - ref).max() <= np.abs(ref).max() * 2.0 ** -10
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_latent_64_step_matches_oracle(dtype, monkeypatch):
+    """BASELINE config C4 names a 64-dimensional latent space: one oracle-checked training step + encode of
+    VAE(nlatent=64) at S = 1000 (D_p = 1120), batch 2048, fp32 and bf16 -- the latent-wide GEMM tiles, the split-K slabs of
+    mu / the first decoder layer and the latent kernels at twice the default width."""
+    monkeypatch.setenv("VAMBHIP_PRECISION", dtype)
+    S, batch, hid, L = 1000, 2048, [512, 512], 64
+    ab, tnf, lens, _ = synth.features(batch, S, seed=41)
+    dl = ve.make_dataloader(ab, tnf, lens, batchsize=batch, destroy=True)
+    d, t, a, w = (x.numpy() for x in dl.dataset.tensors)
+    st0 = vo.init_state(S, hid, L, 9)
+    vae = ve.VAE(S, nhiddens=hid, nlatent=L, dropout=0.2, seed=0)
+    vae.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st0.items()})
+    vae._ensure_dataset(dl)
+    oracle = vo.OracleVAE(S, hid, L, vae.alpha, vae.beta, 0.2, state=st0)
+    rng = np.random.RandomState(3)
+    eps = rng.standard_normal((batch, L)).astype(np.float32)
+    masks = [(rng.random_sample((batch, 512)) >= 0.2).astype(np.uint8) for _ in range(4)]
+    losses = vae.train_batch(np.arange(batch), eps=eps, masks=masks)
+    want = oracle.train_step(d, t, a, w, eps, masks)
+    bf16 = dtype == "bf16"
+    assert rel(losses, want) < (1e-3 if bf16 else 2e-5), (losses, want)
+    for name in oracle.names:
+        got = vae.parameters_gradient(name).astype(np.float64)
+        ref = np.asarray(oracle.grads[name], dtype=np.float64)
+        nr = max(np.linalg.norm(ref), 1e-30)
+        assert np.linalg.norm(got - ref) <= (0.15 if bf16 else 2e-3) * nr, name
+    lat = vae.encode(dl)
+    assert lat.shape == (batch, L)
+    ref = oracle.encode(d, t, a)
+    assert np.abs(lat - ref).max() <= (2e-2 if bf16 else 2.0 ** -10) * np.abs(ref).max()

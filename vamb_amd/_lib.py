@@ -75,6 +75,7 @@ SIGNATURES = {
     "vh_debug_pyrandom_sample": (_int, [ctypes.c_uint64, _int, _vp, _vp, _vp]),
     "vh_gen_state": (_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                             ctypes.POINTER(_i64)]),
+    "vh_gen_live_rows": (_int, [_vp, ctypes.POINTER(_i64)]),
     "vh_gen_counters": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "vh_clu_select": (_int, [_vp, _i64, _vp, _f32, _int, _vp, _i64, ctypes.POINTER(_i64)]),

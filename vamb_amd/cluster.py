@@ -140,9 +140,15 @@ class HipScanBackend:
         # accounting for bench.py / DESIGN.md roofline: rows streamed by scan and select passes
         self.scan_passes = 0
         self.scan_medoids = 0
-        self.rows_streamed = 0
+        self.rows_streamed = 0          # resident rows per pass (what the kernels read)
+        self.live_rows_streamed = 0     # live rows per pass (algorithmic bytes)
         self.kernel_ms = 0.0
         self.timing = False
+
+    def _n_live(self) -> int:
+        n_live = ctypes.c_int64()
+        _lib.check(self.lib.vh_clu_rows(self.h, None, ctypes.byref(n_live)))
+        return n_live.value
 
     def close(self):
         if self.h is not None and self.h.value:
@@ -180,6 +186,7 @@ class HipScanBackend:
         self.scan_passes += 1
         self.scan_medoids += k
         self.rows_streamed += self.n_rows
+        self.live_rows_streamed += self._n_live()
         self._collect_ms()
         return _np.frombuffer(self._res, dtype=_np.int64, count=k * (_NBINS + 3)).reshape(k, _NBINS + 3).copy()
 
@@ -218,6 +225,7 @@ class HipScanBackend:
         _lib.check(self.lib.vh_clu_select(self.h, int(row), _lib.ptr(q), thr, int(remove), _lib.ptr(self._sel),
                                           len(self._sel), ctypes.byref(n)))
         self.rows_streamed += self.n_rows
+        self.live_rows_streamed += self._n_live() + (n.value if remove else 0)
         self.scan_passes += 1
         self._collect_ms()
         return self._sel[: n.value].copy()
@@ -464,6 +472,9 @@ class ClusterGenerator:
         _lib.check(lib.vh_gen_counters(self._gen, ctypes.byref(passes), ctypes.byref(medoids), ctypes.byref(rows),
                                        ctypes.byref(ms), ctypes.byref(emitted), ctypes.byref(remaining)))
         b.scan_passes, b.scan_medoids, b.rows_streamed, b.kernel_ms = passes.value, medoids.value, rows.value, ms.value
+        live = ctypes.c_int64()
+        _lib.check(lib.vh_gen_live_rows(self._gen, ctypes.byref(live)))
+        b.live_rows_streamed = live.value
         n_rows, n_live = ctypes.c_int64(), ctypes.c_int64()
         _lib.check(lib.vh_clu_rows(b.h, ctypes.byref(n_rows), ctypes.byref(n_live)))
         b.n_rows = n_rows.value

@@ -1793,7 +1793,8 @@ struct vh_gen {
     int successes = 0;
     std::unordered_map<int64_t, GenStats> stats;
     // counters (bench accounting)
-    int64_t scan_passes = 0, scan_medoids = 0, rows_streamed = 0;
+    int64_t scan_passes = 0, scan_medoids = 0, rows_streamed = 0;   // rows_streamed: RESIDENT rows per pass (what the kernels read)
+    int64_t live_rows_streamed = 0;   // live rows per pass (algorithmic bytes count N_live, not the uncompacted matrix)
     double kernel_ms = 0.0;
     std::vector<int64_t> sel;       // scratch
     // speculative seed scans: upcoming seeds share the pass of whatever has to be scanned anyway
@@ -1931,6 +1932,7 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         g->scan_passes++;
         g->scan_medoids += k;
         g->rows_streamed += g->clu->n_rows;
+        g->live_rows_streamed += g->clu->n_live;
         gen_collect_ms(g);
         const std::vector<unsigned long long>& sm = g->clu->last_summary[slot];
         for (int j = 0; j < k; ++j) {
@@ -1975,6 +1977,7 @@ int64_t gen_select(vh_gen* g, int64_t medoid, float threshold, bool remove) {
     gen_check(vh_clu_select(g->clu, medoid, nullptr, threshold, remove ? 1 : 0, g->sel.data(), (int64_t)g->sel.size(), &n));
     g->scan_passes++;
     g->rows_streamed += g->clu->n_rows;
+    g->live_rows_streamed += g->clu->n_live + (remove ? n : 0);   // the rows that were live when the pass ran
     gen_collect_ms(g);
     return n;
 }
@@ -2097,6 +2100,7 @@ void gen_fetch_hist(vh_gen* g, int64_t medoid, GenStats& st) {
         g->pass_hist++;
         g->scan_medoids += 1;
         g->rows_streamed += g->clu->n_rows;
+        g->live_rows_streamed += g->clu->n_live;
         gen_collect_ms(g);
         if (!st.hist_stale) {   // (a stale entry keeps its own list: identical rows, already copied or still in the ring)
             st.seq = seq;
@@ -2431,6 +2435,13 @@ int vh_gen_state(vh_gen* g, double* peak_valley_ratio, int64_t* successes, int64
         if (successes) *successes = g->successes;
         if (attempts) *attempts = (int64_t)g->attempts.size();
         if (order_index) *order_index = g->order_index;
+    });
+}
+
+int vh_gen_live_rows(vh_gen* g, int64_t* live_rows_streamed) {
+    return guarded([&] {
+        VH_REQUIRE(g != nullptr && live_rows_streamed != nullptr, "NULL argument");
+        *live_rows_streamed = g->live_rows_streamed;
     });
 }
 
