@@ -34,6 +34,7 @@ class Capture(logging.Handler):
 
 def run(n, S, nepochs, bs, steps, dtype, seed, dseed=1):
     ab, tnf, lens, labels = synth.features(n, S, seed=dseed)
+    previous = ve._COMPUTE_DTYPE
     ve.set_compute_dtype(dtype)
     cap = Capture()
     log = logging.getLogger("vamb_amd.encode")
@@ -48,6 +49,7 @@ def run(n, S, nepochs, bs, steps, dtype, seed, dseed=1):
         latent = vae.encode(dl)
     finally:
         log.removeHandler(cap)
+        ve.set_compute_dtype(previous)   # a module setting: do not leak it into whatever runs next in this process
     t0 = time.perf_counter()
     clusters = list(vc.ClusterGenerator(latent.copy(), lens))
     t_cluster = time.perf_counter() - t0

@@ -387,9 +387,12 @@ def test_free_running_training_learns():
     assert np.isfinite(lat).all() and lat.std() > 1e-3
 
 
-def test_step_scheduling_variants_are_bit_identical(monkeypatch):
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_step_scheduling_variants_are_bit_identical(dtype, monkeypatch):
     """The scheduling of a step (weight-gradient GEMMs on a second stream, forks riding on kernel completion signals)
-    must not change a single bit: train the same model on one stream with event-record forks and with the defaults."""
+    must not change a single bit: train the same model on one stream with event-record forks and with the defaults.
+    (Also the run-to-run determinism check of each precision: same seed, same data, same bits.)"""
+    monkeypatch.setenv("VAMBHIP_PRECISION", dtype)
     n, S = 5000, 6
     ab, tnf, lens, _ = synth.features(n, S, seed=11)
     states = []
@@ -411,10 +414,13 @@ def test_step_scheduling_variants_are_bit_identical(monkeypatch):
     assert np.array_equal(la, lb)
 
 
-def test_generated_dropout_statistics():
-    """The device-generated keep mask (two decisions per 32-bit hash): drop rate p within 4 sigma on every hidden
-    layer, decisions of vertically adjacent elements (which share a hash) and of horizontally adjacent ones
-    independent, and a different mask every step."""
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_generated_dropout_statistics(dtype, monkeypatch):
+    """The device-generated keep mask (fp32 step: two decisions per 32-bit counter hash; bf16 step: 16-bit fields of a
+    per-lane xorshift32 stream seeded by that hash): drop rate p within 4 sigma on every hidden layer, decisions of
+    vertically adjacent elements (which share a 32-bit draw) and of horizontally adjacent ones independent, and a different
+    mask every step."""
+    monkeypatch.setenv("VAMBHIP_PRECISION", dtype)
     n, S, B, p = 4096, 8, 2048, 0.2
     ab, tnf, lens, _ = synth.features(n, S, seed=9)
     dl = ve.make_dataloader(ab, tnf, lens, batchsize=B, destroy=True)

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void vae_fold_bn_kernel(const float* __restric
                                                           const float* __restrict__ bias, const BnSrc bn,
                                                           const float* __restrict__ scale_in,
                                                           const float* __restrict__ shift_in,
-                                                          bf16_t* __restrict__ W16, float* __restrict__ bias_out) {
+                                                          bf16_t* __restrict__ W16, float* __restrict__ bias_out,
+                                                          float* __restrict__ scale_out, float* __restrict__ shift_out) {
     extern __shared__ __attribute__((aligned(16))) float fold_st[];   // [2][K]
     float* s_s = fold_st;
     float* t_s = fold_st + K;
@@ -148,6 +149,9 @@ __global__ __launch_bounds__(256) void vae_fold_bn_kernel(const float* __restric
         }
         s_s[k] = sc;
         t_s[k] = sh;
+        // the coefficients this step's forward pass uses, kept for the optimiser (dW = G diag(s) + dbias t^T must be completed
+        // with THESE s, t: re-deriving them from gamma / beta inside the kernel that updates gamma / beta is a race)
+        if (blockIdx.x == 0 && scale_out != nullptr) { scale_out[k] = sc; shift_out[k] = sh; }
     }
     __syncthreads();
     if (n >= n_rows) return;
@@ -487,12 +491,11 @@ struct Opt16Tensor {
     int64_t p_off;        // offset in the flat parameter / moment buffers
     bf16_t* w16;          // [rows_p][cols_p] shadow (matrices) or nullptr
     bf16_t* w16t;         // [cols_p][rows_p] shadow or nullptr
-    // BatchNorm of the layer that produced this weight's input (nullptr: the input is not normalised)
-    const double* bn_fstat;
-    const float* bn_gamma;
-    const float* bn_beta;
-    int bn_np;
-    const double* dbias;  // [rows_p] fp64 column sums of this layer's dZ (needed with bn_fstat)
+    // BatchNorm of the layer that produced this weight's input (nullptr: the input is not normalised): the scale / shift
+    // vectors s, t the forward pass of THIS step folded into the weights (written by vae_fold_bn_kernel)
+    const float* bn_scale;
+    const float* bn_shift;
+    const double* dbias;  // [rows_p] fp64 column sums of this layer's dZ (needed with bn_scale)
     int blk_start;        // first workgroup of the tensor
 };
 constexpr int kMaxOpt16 = 4 * 2 * 8 + 4;
@@ -519,17 +522,12 @@ __device__ __forceinline__ float4 opt16_grad(const Opt16Tensor& td, int64_t loca
         const float4 v = *reinterpret_cast<const float4*>(td.slab + (int64_t)s * td.stride + local);
         g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
     }
-    if (td.bn_fstat) {
-        BnSrc bn;
-        bn.fstat = td.bn_fstat; bn.gamma = td.bn_gamma; bn.beta = td.bn_beta; bn.n_p = td.bn_np; bn.bs = bs;
+    if (td.bn_scale) {
         const float db = (float)td.dbias[row];
-        float* pg = &g.x;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float mean, istd, sc, sh;
-            bn_column(bn, col + e, mean, istd, sc, sh);
-            pg[e] = pg[e] * sc + db * sh;
-        }
+        const float4 s4 = *reinterpret_cast<const float4*>(td.bn_scale + col);
+        const float4 t4 = *reinterpret_cast<const float4*>(td.bn_shift + col);
+        g.x = g.x * s4.x + db * t4.x; g.y = g.y * s4.y + db * t4.y;
+        g.z = g.z * s4.z + db * t4.z; g.w = g.w * s4.w + db * t4.w;
     }
     return g;
 }

@@ -231,10 +231,8 @@ void build_opt16_table(vh_vae* h) {
             d.slab = t.slab; d.nslab = t.nslab; d.stride = t.stride;
             d.w16 = w16(h, ti); d.w16t = w16t(h, ti);
             if (prev_bn) {
-                d.bn_fstat = prev_bn->fstat;
-                d.bn_gamma = h->pptr(prev_bn->tG);
-                d.bn_beta = h->pptr(prev_bn->tB);
-                d.bn_np = prev_bn->nout_p;
+                d.bn_scale = prev_bn->scale.p;
+                d.bn_shift = prev_bn->shift.p;
                 d.dbias = dbias;
             }
             nblk += (t.rows_p / 32) * (t.cols_p / 32);
@@ -269,7 +267,7 @@ void build_opt16_table(vh_vae* h) {
     for (auto& d : tab) {
         d.dsrc = nullptr;
         d.slab = h->G.p + d.p_off; d.nslab = 1; d.stride = 0;
-        d.bn_fstat = nullptr; d.dbias = nullptr;
+        d.bn_scale = nullptr; d.bn_shift = nullptr; d.dbias = nullptr;
     }
     h->opt16_tab_flat.ensure(tab.size());
     VH_HIP(hipMemcpy(h->opt16_tab_flat.p, tab.data(), tab.size() * sizeof(Opt16Tensor), hipMemcpyHostToDevice));
@@ -281,7 +279,8 @@ void fold_bn(vh_vae* h, hipStream_t s, int tW, int tb, int n_rows, int K, const 
     BnSrc bn = bn_src(h, prev);
     hipLaunchKernelGGL(vae_fold_bn_kernel, dim3((unsigned)ceil_div(n_rows, 4 * kFoldRowsPerWave)), dim3(256), (size_t)2 * K * sizeof(float), s,
                        h->pptr(tW), (int64_t)K, n_rows, K, h->pptr(tb), bn, training ? nullptr : prev.scale.p,
-                       training ? nullptr : prev.shift.p, Wf16, biasf);
+                       training ? nullptr : prev.shift.p, Wf16, biasf, training ? prev.scale.p : nullptr,
+                       training ? prev.shift.p : nullptr);
     VH_HIP(hipGetLastError());
 }
 
