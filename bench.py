@@ -208,7 +208,7 @@ def scan_summary(timed, wall, measured_in):
 
 def pmc_traffic(tag):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_roofline_{tag}.json")
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_roofline_{tag}.json")
     try:
         with open(path) as fh:
             return json.load(fh).get("hbm_bytes_per_launch")
@@ -479,7 +479,7 @@ def main():
                                        "(bias + leaky-relu + dropout + BatchNorm batch sums in the epilogue)", peak)
         if roof is not None:
             roof["traffic"] = pmc_traffic(cfg_name.lower())
-            roof["traffic_source"] = (f"static: profiles/r02_pmc_roofline_{cfg_name.lower()}.json (rocprofv3 --pmc passes of this kernel "
+            roof["traffic_source"] = (f"static: profiles/r03_pmc_roofline_{cfg_name.lower()}.json (rocprofv3 --pmc passes of this kernel "
                                       "at this shape, FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE); NOT counted in this run")
             if roof["traffic"]:
                 # the same launches against the other roofline: at C2 the kernel's arithmetic intensity (flops / PMC bytes)
