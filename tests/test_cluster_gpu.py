@@ -69,7 +69,7 @@ def test_scan_accumulators_bit_exact(oracle_lib, n, L, k):
 
 
 def test_scan_list_overflow_and_ring_expiry(oracle_lib):
-    """Lists longer than the device capacity (2048) and scans that left the 16-deep ring report None, and the
+    """Lists longer than the device capacity (2048) and scans that left the 64-deep ring report None, and the
     generator then falls back to a select pass with the same result."""
     n, L = 6000, 32
     rng = np.random.RandomState(4)
@@ -87,7 +87,7 @@ def test_scan_list_overflow_and_ring_expiry(oracle_lib):
     gen._ensure_stats([100])
     assert np.array_equal(gen._within(100), co.select(m, kept, 100, 0.05))
     old = b.scan([7])[0]
-    for _ in range(16):
+    for _ in range(64):
         b.scan([8])
     assert b.scan_list(old.list_ref) is None
     assert np.array_equal(b.scan_list(b.scan([7])[0].list_ref), co.select(m, kept, 7, 0.05))

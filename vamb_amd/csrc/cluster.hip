@@ -66,7 +66,7 @@ constexpr int kResultWords = VH_NBINS + 4;              // density, hist[60], n_
 constexpr int kMaxMedoids = 32;
 constexpr int kListCap = 2048;    // rows within the medoid radius kept per medoid by the scan itself
 constexpr int64_t kMinScanBlocks = 768;   // workgroups wanted before lanes are given more than one row
-constexpr int kListRing = 16;     // scans whose lists stay readable (one cluster search rarely needs more)
+constexpr int kListRing = 64;     // scans whose lists / histograms stay readable in host-mapped memory (17 MB)
 // The pass accumulators exist in kResultReplicas copies: a workgroup flushes its non-zero LDS accumulators into copy
 // blockIdx.x % kResultReplicas, the publish kernel adds the copies up.  With ONE copy every workgroup of a pass added
 // into the same ~25 addresses (density, two counts, the populated histogram bins) and the serialised same-address
@@ -76,7 +76,8 @@ constexpr int kResultReplicas = 8;    // (the publish kernel reads and zeroes ev
 constexpr int kLocalCap = 128;    // per-block, per-medoid staging of list entries in LDS
 constexpr int kSpecWindow = 8;   // upcoming seeds the native state machine looks at when it fills the free medoid slots of a pass
 constexpr int kKeepList = 32;    // within-radius lists up to this length are copied out of the ring when a row is scanned ahead
-constexpr size_t kMaxCached = 192;   // medoid statistics kept across emissions (every emission re-validates all of them)
+constexpr int64_t kMaxEntryAgeDefault = 32;   // measured at C2 (profiles/r03r_*): 8 -> 15.9 s, 32 -> 14.9 s, 128 -> 15.3 s, 512 -> 22.4 s   // emissions a cached entry may lag behind before it is dropped unseen (its lazy check walks the log)
+constexpr size_t kMaxCached = 16384; // cached medoid statistics (hard cap; the age rule keeps it far below)
 
 // medoid rows travel in the kernel arguments (no upload, no gather launch)
 struct MedoidRows {
@@ -1756,6 +1757,8 @@ struct GenStats {
     unsigned int list_count = 0;   // > kListCap: the device list is incomplete
     bool spec = false;             // scanned ahead of need (an upcoming seed or a neighbour of one) and not used yet
     int64_t born = 0;              // emission count at its scan (age-based eviction)
+    int64_t checked = 0;           // the near-field statistics are known to be exact as of this emission count (lazy validation)
+    int64_t hist_checked = 0;      // ... and the histogram (range 0.3)
     std::vector<float> vec;        // the row itself (host copy): the per-emission validity check reads it from here
     bool hist_stale = false;       // rows were removed since the scan: the histogram (range 0.3) must be taken again
 };
@@ -1792,6 +1795,18 @@ struct vh_gen {
     std::deque<bool> attempts;
     int successes = 0;
     std::unordered_map<int64_t, GenStats> stats;
+    // Removal log: one record per emitted cluster (index = emission count at the time), the rows it removed by ORIGINAL index.
+    // Cached statistics are validated against it lazily, when they are looked at (gen_lookup), instead of eagerly at every
+    // emission.
+    struct Removal {
+        int64_t first, count;     // into removed_orig
+        float cos_near, cos_far;  // 2 <e, medoid> below this: no removed row can lie within 0.05 / 0.3 of e
+    };
+    std::vector<Removal> rlog;
+    std::vector<float> rlog_medoid;   // [emission][L]: the emitted medoids (pivots of the triangle-inequality filter), contiguous --
+                                      // a lazy check walks consecutive records, never the 256 MB host matrix
+    std::vector<int64_t> removed_orig;
+    int64_t lazy_checks = 0, lazy_cluster_tests = 0, lazy_point_tests = 0, lazy_invalid = 0, hist_kept = 0;
     // counters (bench accounting)
     int64_t scan_passes = 0, scan_medoids = 0, rows_streamed = 0;   // rows_streamed: RESIDENT rows per pass (what the kernels read)
     int64_t live_rows_streamed = 0;   // live rows per pass (algorithmic bytes count N_live, not the uncompacted matrix)
@@ -1801,6 +1816,9 @@ struct vh_gen {
     int64_t spec_scanned = 0, spec_used = 0, spec_dropped = 0;
     bool speculate = true;
     int spec_window = kSpecWindow;
+    int64_t max_entry_age = kMaxEntryAgeDefault;   // option gen.max_entry_age
+    int spec_depth = 2;             // option gen.spec_depth: 1 = within-radius rows of upcoming seeds, 2 = also THEIR within-radius rows
+    double t_validate = 0, t_fill = 0, t_book = 0, t_emit = 0;   // profile: lazy validation, speculative fill, post-scan bookkeeping, emission
     bool spec_neighbours = true;   // option gen.spec_neighbours: within-radius rows of cached upcoming seeds are scanned ahead too
     int spec_big_target = 0;      // experiment: widening target of passes over matrices above 600 k rows (0 = bucket fill)
     // optional wall-clock breakdown (VAMBHIP_GEN_PROFILE=1): scan calls, select calls, seed walk, logical index
@@ -1831,6 +1849,67 @@ void gen_collect_ms(vh_gen* g) {
     if (g->clu->timer.enabled) g->kernel_ms += g->clu->timer.last_ms;
 }
 
+float gen_dot(const float* a, const float* b, int L) {
+    float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int c = 0;
+    for (; c + 8 <= L; c += 8)
+        for (int k = 0; k < 8; ++k) part[k] += a[c + k] * b[c + k];
+    float dot = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    for (; c < L; ++c) dot += a[c] * b[c];
+    return dot;
+}
+
+// Has any row removed by the emissions [from, n_emitted) come within `radius` (+ margin) of the row `vm`?  Per emitted cluster
+// one dot product against its medoid decides whether the cluster can matter at all (triangle inequality on the sphere: rows are
+// scaled to norm 1 / sqrt(2), cos(angle) = 2 <x, y>; the margins cover any float32 summation order); only then row by row.
+bool gen_touched_since(vh_gen* g, const float* vm, int64_t from, bool far) {
+    const int L = g->clu->L;
+    const float* hm = g->clu->host_rows.data();
+    const float limit = (far ? 0.3f : 0.05f) + 2e-3f;
+    const float* piv = g->rlog_medoid.data() + (size_t)from * L;
+    for (int64_t e = from; e < (int64_t)g->rlog.size(); ++e, piv += L) {
+        const vh_gen::Removal& R = g->rlog[(size_t)e];
+        g->lazy_cluster_tests++;
+        if (2.0f * gen_dot(vm, piv, L) < (far ? R.cos_far : R.cos_near) - 1e-4f) continue;
+        const int64_t* rows = g->removed_orig.data() + R.first;
+        for (int64_t k = 0; k < R.count; ++k) __builtin_prefetch(hm + (size_t)rows[k] * L);
+        for (int64_t k = 0; k < R.count; ++k) {
+            g->lazy_point_tests++;
+            if (0.5f - gen_dot(vm, hm + (size_t)rows[k] * L, L) <= limit) return true;
+        }
+    }
+    return false;
+}
+
+// The cached statistics of a row, or nullptr.  What wander_medoid and the loner test read of an entry -- density, the two
+// counts and the list of rows within the medoid radius 0.05 -- is a function of the live rows INSIDE that radius only
+// (sample_medoid is pure, cluster.py:606-637), so an entry is exact as long as no row removed since its scan lies within the
+// radius of its row.  The reference clears its cache at every emission (cluster.py:298-316); here every entry is checked
+// against the removal log when it is looked at, once per emission it has not seen yet.
+GenStats* gen_lookup(vh_gen* g, int64_t row) {
+    const auto it = g->stats.find(row);
+    if (it == g->stats.end()) return nullptr;
+    GenStats& st = it->second;
+    if (st.checked == g->n_emitted) return &st;
+    GenTimer tv(&g->t_validate);
+    g->lazy_checks++;
+    if (g->n_emitted - st.born > g->max_entry_age || gen_touched_since(g, st.vec.data(), st.checked, false)) {
+        if (st.spec) g->spec_dropped++;
+        g->lazy_invalid++;
+        g->stats.erase(it);
+        return nullptr;
+    }
+    st.checked = g->n_emitted;
+    // an entry that outlives its emission will be asked for its list sooner or later: take it while its scan is in the ring
+    if (!st.have_list && st.list_count <= (unsigned int)kListCap && g->clu->scan_seq - st.seq <= (uint64_t)kListRing) {
+        const int32_t* src = g->clu->lists + ((size_t)(st.seq % kListRing) * kMaxMedoids + st.slot_j) * kListCap;
+        st.within.assign(src, src + st.list_count);
+        std::sort(st.within.begin(), st.within.end());
+        st.have_list = true;
+    }
+    return &st;
+}
+
 // kept[row] = 0 for rows the state machine knows to be live: stream-ordered launch, no read-back, no wait
 void gen_remove_live(vh_gen* g, const int64_t* rows, int64_t n) {
     vh_clu* h = g->clu;
@@ -1855,7 +1934,7 @@ void gen_remove_live(vh_gen* g, const int64_t* rows, int64_t n) {
 void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& exclude, std::vector<int64_t>& out) {
     const int64_t n_order = (int64_t)g->order.size();
     auto taken = [&](int64_t row) {
-        return g->stats.count(row) != 0 || std::find(exclude.begin(), exclude.end(), row) != exclude.end() ||
+        return gen_lookup(g, row) != nullptr || std::find(exclude.begin(), exclude.end(), row) != exclude.end() ||
                std::find(out.begin(), out.end(), row) != out.end();
     };
     // the upcoming live seeds, in walk order
@@ -1871,14 +1950,32 @@ void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& ex
         if (out.size() >= want) return;
         if (!taken(row)) out.push_back(row);
     }
-    // ... then the candidate pools of the seeds whose statistics are already there
+    // ... then the candidate pools of the seeds whose statistics are already there (the first round of their hill climb), and
+    // the pools of those candidates (where the climb can move to)
     if (!g->spec_neighbours) return;
-    for (int64_t row : upcoming) {
-        const auto it = g->stats.find(row);
-        if (it == g->stats.end() || !it->second.have_list) continue;
-        for (int64_t r : it->second.within) {
-            if (out.size() >= want) return;
-            if (r != row && !taken(r)) out.push_back(r);
+    auto absent = [&](int64_t r) {   // (presence only: a stale entry is simply not refreshed ahead of time)
+        return g->stats.count(r) == 0 && std::find(exclude.begin(), exclude.end(), r) == exclude.end() &&
+               std::find(out.begin(), out.end(), r) == out.end();
+    };
+    for (int depth = 1; depth <= g->spec_depth; ++depth) {
+        for (int64_t row : upcoming) {
+            const GenStats* seed_st = gen_lookup(g, row);
+            if (seed_st == nullptr || !seed_st->have_list) continue;
+            const std::vector<int64_t> pool = seed_st->within;   // (copy: gen_lookup may erase entries)
+            for (int64_t r : pool) {
+                if (out.size() >= want) return;
+                if (r == row) continue;
+                if (depth == 1) {
+                    if (absent(r)) out.push_back(r);
+                    continue;
+                }
+                const auto it = g->stats.find(r);
+                if (it == g->stats.end() || !it->second.have_list) continue;
+                for (int64_t r2 : it->second.within) {
+                    if (out.size() >= want) return;
+                    if (r2 != r && r2 != row && absent(r2)) out.push_back(r2);
+                }
+            }
         }
     }
 }
@@ -1888,7 +1985,7 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
     std::vector<int64_t> missing;
     for (size_t i = 0; i < n; ++i) {
         const int64_t m = medoids[i];
-        if (g->stats.count(m)) continue;
+        if (gen_lookup(g, m) != nullptr) continue;
         if (std::find(missing.begin(), missing.end(), m) != missing.end()) continue;
         missing.push_back(m);
     }
@@ -1899,7 +1996,7 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
     // scan at the time of use would return.
     // requested entries that were scanned ahead are in use from now on
     for (size_t i = 0; i < n; ++i) {
-        const auto it = g->stats.find(medoids[i]);
+        const auto it = g->stats.find(medoids[i]);   // (validated by the loop above)
         if (it != g->stats.end() && it->second.spec) { it->second.spec = false; g->spec_used++; }
     }
     size_t n_needed = missing.size();
@@ -1910,9 +2007,10 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         else if (g->clu->n_rows <= 600000) target = kMaxMedoids;  // latency-bound pass: extra medoids are free
         else if (g->spec_big_target > 0 && missing.size() <= 8) target = std::max(target, (size_t)g->spec_big_target);
         else if (missing.size() == 1) target = 8;
-        if (missing.size() < target && missing.size() < (size_t)kMaxMedoids && g->stats.size() < kMaxCached) {
+        if (missing.size() < target && missing.size() < (size_t)kMaxMedoids) {
             std::vector<int64_t> extra;
-            gen_speculative_fill(g, std::min(target - missing.size(), kMaxCached - g->stats.size()), missing, extra);
+            GenTimer tf(&g->t_fill);
+            gen_speculative_fill(g, target - missing.size(), missing, extra);
             missing.insert(missing.end(), extra.begin(), extra.end());
         }
     }
@@ -1935,6 +2033,7 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         g->live_rows_streamed += g->clu->n_live;
         gen_collect_ms(g);
         const std::vector<unsigned long long>& sm = g->clu->last_summary[slot];
+        GenTimer tb(&g->t_book);
         for (int j = 0; j < k; ++j) {
             GenStats& st = g->stats[missing[lo + j]];
             // the python float the reference gets from `.sum().item()` on a float32 tensor (cluster.py:629)
@@ -1949,7 +2048,8 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
             st.list_count = g->clu->last_counts[slot][j];
             st.have_list = false;
             st.spec = lo + (size_t)j >= n_needed;
-            st.born = g->n_emitted;
+            st.born = st.checked = st.hist_checked = g->n_emitted;
+            st.hist_stale = false;
             {   // the row itself, for the validity checks of the emissions to come
                 const float* v = g->clu->host_rows.data() + (size_t)g->indices[(size_t)missing[lo + j]] * g->clu->L;
                 st.vec.assign(v, v + g->clu->L);
@@ -2045,7 +2145,7 @@ int64_t gen_wander(vh_gen* g, int64_t seed) {
     int64_t medoid = seed;
     std::vector<int64_t> tried{medoid};
     g->seeds_total++;
-    if (g->stats.count(seed)) g->seeds_cached++;
+    if (gen_lookup(g, seed) != nullptr) g->seeds_cached++;
     g->pass_purpose = 0;
     gen_ensure_stats(g, &seed, 1);
     double local_density = g->stats.at(seed).density;
@@ -2062,7 +2162,7 @@ int64_t gen_wander(vh_gen* g, int64_t seed) {
         // look ahead: every not-yet-scanned candidate of this round shares one matrix pass
         if (i == 0) {
             size_t miss = 0;
-            for (int64_t c : candidates) miss += g->stats.count(c) ? 0 : 1;
+            for (int64_t c : candidates) miss += gen_lookup(g, c) != nullptr ? 0 : 1;
             g->cand_rounds++;
             g->cand_needed += (int64_t)miss;
             g->cand_rounds_cached += miss == 0 ? 1 : 0;
@@ -2088,9 +2188,15 @@ int64_t gen_wander(vh_gen* g, int64_t seed) {
 
 // cluster.py:452-543 on the exact histogram of the scan
 void gen_fetch_hist(vh_gen* g, int64_t medoid, GenStats& st) {
+    // the histogram reaches out to 0.3: it is the scan's as long as no row removed since lies within that range of the medoid
+    if (st.hist_checked != g->n_emitted) {
+        if (!st.hist_stale && gen_touched_since(g, st.vec.data(), st.hist_checked, true)) st.hist_stale = true;
+        if (st.hist_stale) st.have_hist = false;
+        st.hist_checked = g->n_emitted;
+    }
     if (st.have_hist) return;
     if (st.hist_stale || g->clu->scan_seq - st.seq > (uint64_t)kListRing) {
-        // its scan has left the ring: one more pass for this medoid alone (same exact accumulators)
+        // rows in range were removed, or the scan has left the ring: one more pass for this medoid alone
         const uint64_t seq = g->clu->scan_seq;
         {
             GenTimer t(&g->t_scan);
@@ -2102,7 +2208,7 @@ void gen_fetch_hist(vh_gen* g, int64_t medoid, GenStats& st) {
         g->rows_streamed += g->clu->n_rows;
         g->live_rows_streamed += g->clu->n_live;
         gen_collect_ms(g);
-        if (!st.hist_stale) {   // (a stale entry keeps its own list: identical rows, already copied or still in the ring)
+        if (!st.have_list) {   // (the near field is unchanged: the new scan's list is the same list, and it is in the ring)
             st.seq = seq;
             st.slot_j = 0;
             st.list_count = g->clu->last_counts[(int)(seq % kListRing)][0];
@@ -2114,6 +2220,7 @@ void gen_fetch_hist(vh_gen* g, int64_t medoid, GenStats& st) {
         st.hist_stale = false;
         return;
     }
+    if (st.born != g->n_emitted) g->hist_kept++;
     unsigned long long tmp[VH_NBINS];
     memcpy(tmp, g->clu->hist((int)(st.seq % kListRing)) + (size_t)st.slot_j * VH_NBINS, sizeof(tmp));
     for (int b = 0; b < VH_NBINS; ++b) st.hist_fx[b] = (int64_t)tmp[b];
@@ -2211,6 +2318,8 @@ int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, in
         g->speculate = option("gen.speculate", 1) != 0;
         g->spec_window = (int)option("gen.spec_window", kSpecWindow);
         g->spec_neighbours = option("gen.spec_neighbours", 1) != 0;
+        g->max_entry_age = option("gen.max_entry_age", kMaxEntryAgeDefault);
+        g->spec_depth = (int)option("gen.spec_depth", 2);
         g->spec_big_target = (int)option("gen.spec_big_target", 0);
         g->order.assign(order, order + n);
         g->indices.resize((size_t)n);
@@ -2231,13 +2340,16 @@ int vh_gen_destroy(vh_gen* g) {
                 g->t_total - g->t_scan - g->t_select - g->t_seed - g->t_logical, (long long)g->scan_passes,
                 (long long)g->scan_medoids, (long long)g->spec_scanned, (long long)g->spec_used, (long long)g->spec_dropped);
     if (g && g->profile) {
+        fprintf(stderr, "[vambhip]   host time inside 'rest': lazy validation %.1f ms (part of it inside the fill), speculative fill %.1f ms, "
+                "post-scan bookkeeping %.1f ms, removal log + eviction %.1f ms\n", g->t_validate, g->t_fill, g->t_book, g->t_emit);
         fprintf(stderr, "[vambhip]   passes by purpose: seed scans %lld, candidate rounds %lld, histogram re-scans %lld, selects %lld (+ %lld list selects); "
                 "seeds %lld (cached at arrival %lld), candidate rounds %lld (fully cached %lld, %lld candidates to scan), medoid moves %lld; "
-                "cached entries per emission %.1f, row-by-row validity checks %lld\n",
+                "cached entries per emission %.1f; lazy validations %lld (%lld cluster tests, %lld row tests, %lld invalid), histograms reused %lld\n",
                 (long long)g->pass_seed, (long long)g->pass_cand, (long long)g->pass_hist, (long long)g->pass_select, (long long)g->pass_listsel,
                 (long long)g->seeds_total, (long long)g->seeds_cached, (long long)g->cand_rounds, (long long)g->cand_rounds_cached,
                 (long long)g->cand_needed, (long long)g->wander_moves,
-                g->kept_emissions ? (double)g->kept_entries / (double)g->kept_emissions : 0.0, (long long)g->full_checks);
+                g->kept_emissions ? (double)g->kept_entries / (double)g->kept_emissions : 0.0, (long long)g->lazy_checks,
+                (long long)g->lazy_cluster_tests, (long long)g->lazy_point_tests, (long long)g->lazy_invalid, (long long)g->hist_kept);
         for (int k = 1; k <= 32; ++k)
             if (g->n_km[k])
                 fprintf(stderr, "[vambhip]   passes with %2d medoids: %8lld, %7.1f ms, avg %6.1f us, avg rows %9.0f\n", k,
@@ -2313,60 +2425,33 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
         for (size_t i = 0; i < points.size(); ++i) members[i] = g->indices[(size_t)points[i]];
         info->n_members = (int64_t)points.size();
         // __next__ bookkeeping.  The reference clears its sample_medoid cache here because a removal may change any cached
-        // result (cluster.py:298-316).  What wander_medoid and the loner test read of a cached entry -- density, the two counts
-        // and the list of rows within the medoid radius 0.05 -- is a function of the live rows INSIDE that radius only, so an
-        // entry stays exact as long as no removed row lies within the radius of its row (checked with a margin that covers any
-        // float32 summation order); its histogram reaches out to 0.3 and is simply taken again if the row ends up as the
-        // medoid of a cluster.  Every cached entry is checked, whether it was scanned ahead or for the search that just ended
-        // (its neighbours are the next seeds' candidates more often than not).
-        // Cost control: an entry carries a host copy of its row (no random access into the 256 MB host matrix); entries whose
-        // angle to the cluster's medoid exceeds angle(cluster radius) + angle(medoid radius) cannot be near any removed row
-        // (triangle inequality on the sphere) and take ONE dot product per emission; the rest is compared row by row.
+        // result (cluster.py:298-316).  Here the removal goes into a log and cached entries are validated against it when they
+        // are looked at (gen_lookup / gen_fetch_hist): an entry nobody asks for again costs nothing, one that is asked for pays
+        // one dot product per emission since its last check (+ a row-by-row comparison for the few clusters near it).
         {
-            const int L = g->clu->L;
-            const float* hm = g->clu->host_rows.data();
-            for (int64_t r : points) __builtin_prefetch(hm + (size_t)g->indices[(size_t)r] * L);
-            auto dot8 = [L](const float* a, const float* b) {
-                float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                int c = 0;
-                for (; c + 8 <= L; c += 8)
-                    for (int k = 0; k < 8; ++k) part[k] += a[c + k] * b[c + k];
-                float dot = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-                for (; c < L; ++c) dot += a[c] * b[c];
-                return dot;
-            };
-            // rows are scaled to norm 1 / sqrt(2): cos(angle) = 2 <x, y> = 1 - 2 d
-            const float* vmed = hm + (size_t)g->indices[(size_t)emitted_medoid] * L;
+            GenTimer te(&g->t_emit);
             const double t_cluster = std::min(0.5, std::max(0.0, emitted_radius) + 2e-3);
-            const double ang_limit = std::acos(1.0 - 2.0 * t_cluster) + std::acos(1.0 - 2.0 * (0.05 + 2e-3)) + 1e-3;
-            const float cos_limit = ang_limit < 3.14 ? (float)std::cos(ang_limit) : -2.0f;   // entries with 2 <e, m> < cos_limit are safe
-            const bool all_zero_medoid = dot8(vmed, vmed) < 0.25f;   // (an all-zero row has no direction: no shortcut)
-            for (auto it = g->stats.begin(); it != g->stats.end();) {
-                GenStats& st = it->second;
-                bool valid = true;
-                const float* vm = st.vec.data();
-                // entries that served the search that just ended are dropped like the reference's cache (their rows are mostly
-                // members of the emitted cluster); entries scanned ahead stay until used, invalidated or clearly overtaken
-                if (!st.spec || g->n_emitted - st.born > 96) valid = false;
-                if (valid && (all_zero_medoid || 2.0f * dot8(vm, vmed) >= cos_limit - 1e-4f)) {
-                    g->full_checks++;
-                    for (int64_t r : points) {
-                        if (r == it->first) { valid = false; break; }
-                        const float* vr = hm + (size_t)g->indices[(size_t)r] * L;
-                        if (0.5f - dot8(vm, vr) <= 0.05f + 2e-3f) { valid = false; break; }
-                    }
-                    if (!valid && st.spec) g->spec_dropped++;
-                }
-                if (valid) {
-                    st.hist_stale = true;
-                    st.have_hist = false;
-                    ++it;
-                } else {
-                    it = g->stats.erase(it);
-                }
+            const double a_t = std::acos(1.0 - 2.0 * t_cluster);
+            const double a_near = a_t + std::acos(1.0 - 2.0 * (0.05 + 2e-3)) + 1e-3;
+            const double a_far = a_t + std::acos(1.0 - 2.0 * (0.3 + 2e-3)) + 1e-3;
+            vh_gen::Removal R;
+            R.first = (int64_t)g->removed_orig.size();
+            R.count = (int64_t)points.size();
+            {
+                const float* mv = g->clu->host_rows.data() + (size_t)g->indices[(size_t)emitted_medoid] * g->clu->L;
+                g->rlog_medoid.insert(g->rlog_medoid.end(), mv, mv + g->clu->L);
             }
+            R.cos_near = a_near < 3.14 ? (float)std::cos(a_near) : -3.0f;
+            R.cos_far = a_far < 3.14 ? (float)std::cos(a_far) : -3.0f;
+            for (int64_t r : points) g->removed_orig.push_back(g->indices[(size_t)r]);
+            g->rlog.push_back(R);   // rlog.size() == n_emitted + 1 from here on
             g->kept_entries += (int64_t)g->stats.size();
             g->kept_emissions++;
+            // entries the walk has left behind: dropped in bulk now and then (their lazy check would walk a long log)
+            if ((g->n_emitted & 63) == 63 || g->stats.size() > kMaxCached) {
+                for (auto it = g->stats.begin(); it != g->stats.end();)
+                    it = (g->n_emitted - it->second.born > g->max_entry_age || g->stats.size() > 2 * kMaxCached) ? g->stats.erase(it) : std::next(it);
+            }
         }
         g->n_emitted++;
         g->n_remaining -= (int64_t)points.size();
