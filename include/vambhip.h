@@ -216,6 +216,35 @@ typedef struct {
 int vh_vae_create(const vh_vae_config* cfg, vh_vae** out);
 int vh_vae_destroy(vh_vae* h);
 
+/* The two subclasses of VAE the semi-supervised / TaxVamb workflows train: the same stack of layers on
+ * other input / reconstruction columns, with a label cross-entropy term.
+ *   VH_VAE_CONCAT  semisupervised_encode.py:438-698 VAEConcat: columns depths | TNF | abundance | one-hot labels; calc_loss
+ *                  (:515-569) = VAE.calc_loss + CrossEntropyLoss(label logits, class) with weight 1; trained by the inherited
+ *                  VAE.trainmodel, i.e. D-Adapt-Adam.
+ *   VH_VAE_LABELS  semisupervised_encode.py:189-436 VAELabels: the one-hot labels are the ONLY columns; calc_loss (:248-257) =
+ *                  CrossEntropyLoss + KLD / (nlatent * beta), no per-contig weights; trainmodel (:362-436) uses
+ *                  torch.optim.Adam(lr = lrate).  cfg->nsamples only documents the reference's `nlabels - 104`. */
+enum { VH_VAE_PLAIN = 0, VH_VAE_CONCAT = 1, VH_VAE_LABELS = 2 };
+enum { VH_OPT_DADAPT_ADAM = 0, VH_OPT_ADAM = 1 };
+typedef struct {
+    int32_t kind;        /* VH_VAE_* */
+    int32_t nlabels;     /* width of the one-hot block: max(number of classes, 105), semisupervised_encode.py:25-47 */
+    int32_t optimizer;   /* VH_OPT_* */
+    float lrate;         /* Adam only */
+} vh_vae_labels_config;
+int vh_vae_create_labelled(const vh_vae_config* cfg, const vh_vae_labels_config* lab, vh_vae** out);
+/* number of input (= reconstruction) columns of the model */
+int vh_vae_row_width(vh_vae* h, int32_t* width);
+/* forward() on rows given in the model's own column order ([batch][width], one-hot labels included): R = what `_decode`
+ * returns, concatenated (softmax on the depths block when nsamples > 1, raw label logits), mu [batch][nlatent].
+ * eps / masks as vh_vae_forward. */
+int vh_vae_forward_rows(vh_vae* h, const float* X, int64_t batch, int training, const float* eps, const uint8_t* masks,
+                        float* R_out, float* mu_out);
+/* Label statistics of the most recent vh_vae_train_step / _epoch / _epochs call, per epoch: the mean over the batches of
+ * CrossEntropyLoss (`ce_labels`) and the number of rows whose argmax(label logits) is their class (`correct_labels`,
+ * semisupervised_encode.py:257, 563-569).  n_epochs must equal the epochs of that call (1 for a step / an epoch). */
+int vh_vae_label_stats(vh_vae* h, int64_t n_epochs, double* out /* [n_epochs][2] */);
+
 /* Parameters and buffers by their torch state_dict names (encode.py:226-249): e.g.
  * "encoderlayers.0.weight" [nh0][D], "encodernorms.1.running_var" [nh1], "mu.bias" [L],
  * "outputlayer.weight" [D][nh0], "...num_batches_tracked" [1] (as float).  n is the logical element
@@ -267,6 +296,10 @@ int vh_vae_opt_set_state(vh_vae* h, double d, double numerator_weighted, int64_t
 /* a fresh optimiser, as `DAdaptAdam(self.parameters(), decouple=True)` at the top of trainmodel (encode.py:578):
  * exp_avg = exp_avg_sq = s = 0, d = 1e-6, numerator_weighted = 0, k = 0 */
 int vh_vae_reset_optimizer(vh_vae* h);
+/* the optimiser of the following steps: VH_OPT_DADAPT_ADAM (VAE.trainmodel, encode.py:578) or VH_OPT_ADAM =
+ * torch.optim.Adam(lr = lrate) with its default betas / eps (VAELabels.trainmodel, semisupervised_encode.py:405).  Both use
+ * the exp_avg / exp_avg_sq buffers and the step count k; call vh_vae_reset_optimizer for a fresh state. */
+int vh_vae_set_optimizer(vh_vae* h, int optimizer, float lrate);
 /* per-parameter optimiser state by state_dict name: which = 0 exp_avg, 1 exp_avg_sq, 2 s */
 int vh_vae_get_opt_moment(vh_vae* h, const char* name, int which, float* data, int64_t n);
 int vh_vae_set_opt_moment(vh_vae* h, const char* name, int which, const float* data, int64_t n);
@@ -278,6 +311,12 @@ int vh_dataset_create(const float* depths, const float* tnf, const float* abunda
                       int nsamples, vh_dataset** out);
 int vh_dataset_destroy(vh_dataset* d);
 int vh_vae_use_dataset(vh_vae* h, vh_dataset* d);
+/* Labels of the semi-supervised loaders (semisupervised_encode.py:111-175: `np.unique(labels, return_inverse=True)[1]`,
+ * one-hot to `nlabels` = max(classes, 105) columns by the collate functions): one int32 class per row.  The one-hot block
+ * is produced by the batch gather on the device and never stored.  vh_dataset_set_labels adds them to a feature dataset
+ * (make_dataloader_concat), vh_dataset_create_labels makes the labels-only dataset of make_dataloader_labels. */
+int vh_dataset_set_labels(vh_dataset* d, const int32_t* labels, int64_t n, int32_t nlabels);
+int vh_dataset_create_labels(const int32_t* labels, int64_t n, int32_t nlabels, vh_dataset** out);
 
 /* ---- make_dataloader on the device -------------------------------------------------
  * The matrix passes of vamb/encode.py:98-119 and vamb/vambtools.py:250-288 (column sums of the abundances, per-row

@@ -121,3 +121,18 @@ def load_reference():
         mods.append(mod)
     _cached = tuple(mods)
     return _cached
+
+
+def load_reference_module(name: str):
+    """One more module of the reference package, executed unmodified (after load_reference()): e.g.
+    ``semisupervised_encode`` (imports only vamb.encode, vamb.vambtools, torch and loguru)."""
+    load_reference()
+    full = f"vamb.{name}"
+    if full in sys.modules:
+        return sys.modules[full]
+    spec = importlib.util.spec_from_file_location(full, os.path.join(REFERENCE_ROOT, "vamb", f"{name}.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[full] = mod
+    spec.loader.exec_module(mod)
+    setattr(sys.modules["vamb"], name, mod)
+    return mod

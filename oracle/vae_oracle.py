@@ -32,8 +32,8 @@ BN_MOMENTUM = 0.1
 LRELU_SLOPE = 0.01
 
 
-def layer_dims(nsamples, nhiddens, nlatent):
-    d = nsamples + NTNF + 1
+def layer_dims(nsamples, nhiddens, nlatent, width=None):
+    d = nsamples + NTNF + 1 if width is None else width   # width: the subclasses' input columns (semisup_oracle.py)
     enc = list(zip([d] + list(nhiddens), nhiddens))
     dec = list(zip([nlatent] + list(nhiddens[::-1]), nhiddens[::-1]))
     return d, enc, dec
@@ -55,12 +55,12 @@ def param_names(nhiddens):
     return names
 
 
-def init_state(nsamples, nhiddens, nlatent, seed):
+def init_state(nsamples, nhiddens, nlatent, seed, width=None):
     """Deterministic numpy initialisation with torch's default Linear scheme
     (U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias; BN weight 1, bias 0, rm 0, rv 1).
     Used by fixtures so that weights never have to be stored."""
     rng = np.random.RandomState(seed)
-    d, enc, dec = layer_dims(nsamples, nhiddens, nlatent)
+    d, enc, dec = layer_dims(nsamples, nhiddens, nlatent, width)
     st = {}
 
     def lin(prefix, nin, nout):
@@ -226,6 +226,10 @@ class OracleVAE:
         dab = g * ab_w * 2.0 * (L["ab_out"] - L["ab_in"])
         drecon = np.concatenate([dlogit, dtnf, dab], axis=1)
         dmu_kld = g * kld_w * L["mu"]
+        return self._backprop(drecon, dmu_kld)
+
+    def _backprop(self, drecon, dmu_kld):
+        """Chain rule from d loss / d reconstruction and the KLD part of d loss / d mu down to every parameter."""
         grads = {}
         st = self.state
         nl = len(self.nhiddens)

@@ -191,6 +191,53 @@ def load(name):
 
 
 # ------------------------------------------------------------------------------------------------
+# VAEConcat / VAELabels cases (/root/reference/vamb/semisupervised_encode.py:189,438)
+# nclasses distinct labels -> a one-hot block of max(nclasses, 105) columns (collate functions, :25-47)
+# ------------------------------------------------------------------------------------------------
+SEMISUP_CASES = {
+    "semisup_concat_drop": dict(kind="concat", n=48, batch=24, nsamples=6, nclasses=7, nhiddens=[48, 40], nlatent=8,
+                                dropout=0.2, alpha=None, beta=200.0, seed=31, steps=3),
+    # more classes than 105, ragged batch, no dropout
+    "semisup_concat_wide": dict(kind="concat", n=150, batch=37, nsamples=5, nclasses=130, nhiddens=[33, 17], nlatent=5,
+                                dropout=0.0, alpha=0.3, beta=50.0, seed=32, steps=3),
+    "semisup_labels_drop": dict(kind="labels", n=48, batch=24, nsamples=6, nclasses=7, nhiddens=[48, 40], nlatent=8,
+                                dropout=0.2, alpha=None, beta=200.0, seed=33, steps=4, lrate=1e-3),
+    # (dropout > 0 on purpose: without it a hidden unit that is active for every row of the batch has a bias gradient that is
+    # mathematically ZERO -- BatchNorm's backward sums to zero over the batch -- so torch's fp32 value is rounding noise and Adam,
+    # which normalises each element by its own magnitude, turns that noise into full +-lr steps nobody else can reproduce)
+    "semisup_labels_wide": dict(kind="labels", n=160, batch=29, nsamples=4, nclasses=150, nhiddens=[64, 32], nlatent=6,
+                                dropout=0.1, alpha=None, beta=100.0, seed=34, steps=4, lrate=1e-2),
+}
+
+
+def semisup_width(name):
+    return max(SEMISUP_CASES[name]["nclasses"], 105)
+
+
+def semisup_inputs(name):
+    """Raw features + one string label per contig (every class occurs at least once)."""
+    c = SEMISUP_CASES[name]
+    ab, tnf, lens, _ = synth.features(c["n"], c["nsamples"], c["seed"], k=4)
+    rng = np.random.RandomState(c["seed"] + 500)
+    assert c["n"] >= c["nclasses"]
+    cls = np.concatenate([np.arange(c["nclasses"]), rng.randint(0, c["nclasses"], size=c["n"] - c["nclasses"])])
+    rng.shuffle(cls)
+    labels = np.array([f"taxon_{i:04d}" for i in cls])
+    return ab, tnf, lens, labels
+
+
+def semisup_randomness(name):
+    c = SEMISUP_CASES[name]
+    rng = np.random.RandomState(c["seed"] + 1000)
+    widths = list(c["nhiddens"]) + list(c["nhiddens"][::-1])
+    masks, eps = [], []
+    for _ in range(c["steps"]):
+        masks.append([rng.random_sample((c["batch"], w)) >= c["dropout"] for w in widths])
+        eps.append(rng.standard_normal((c["batch"], c["nlatent"])).astype(np.float32))
+    return masks, eps
+
+
+# ------------------------------------------------------------------------------------------------
 # TNF case (row N2): seeded random sequences over the alphabet of the reference's own k-mer test
 # (test/testtools.py:75-86) plus U / u, lengths 4 .. 6000 and two degenerate ones
 # ------------------------------------------------------------------------------------------------

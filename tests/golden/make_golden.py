@@ -7,7 +7,7 @@ vambcore.overwrite_matrix and dadaptation.DAdaptAdam -- the latter restated, PAR
 The GPU box never runs this; tests read the committed .npz files.
 
     python tests/golden/make_golden.py            # regenerate everything
-    python tests/golden/make_golden.py cluster    # only one family (cluster | cluster_large | prep | vae | tnf | e2e)
+    python tests/golden/make_golden.py cluster    # only one family (cluster | cluster_large | prep | vae | semisup | tnf | e2e)
 
 Environment recorded in golden_manifest.json (torch / numpy versions, thread count).
 """
@@ -166,6 +166,88 @@ def gen_vae(en):
     return out
 
 
+def gen_semisup():
+    """VAEConcat / VAELabels of the real reference (semisupervised_encode.py) with injected dropout masks and noise."""
+    import torch
+    import dadaptation  # the stub installed by ref_harness (oracle/dadapt_restated.py)
+
+    ss = ref_harness.load_reference_module("semisupervised_encode")
+    out = {}
+    for name, c in fd.SEMISUP_CASES.items():
+        ab, tnf, lens, labels = fd.semisup_inputs(name)
+        B, NL = c["batch"], fd.semisup_width(name)
+        masks, eps = fd.semisup_randomness(name)
+        mask_q, eps_q = [], []
+
+        class InjectedDropout(torch.nn.Module):
+            def forward(self, x):
+                if not self.training or c["dropout"] == 0:
+                    return x
+                m = mask_q.pop(0)
+                scale = np.float32(1.0) / (np.float32(1.0) - np.float32(c["dropout"]))
+                return x * torch.from_numpy(m.astype(np.float32) * scale)
+
+        rec = {}
+        if c["kind"] == "concat":
+            dl = ss.make_dataloader_concat(ab.copy(), tnf.copy(), lens, labels, batchsize=B)
+            depths, tnfz, totab, weights, lab_int = dl.dataset.tensors
+            vae = ss.VAEConcat(c["nsamples"], NL, nhiddens=list(c["nhiddens"]), nlatent=c["nlatent"], alpha=c["alpha"],
+                               beta=c["beta"], dropout=c["dropout"])
+            width = c["nsamples"] + 104 + NL
+            rec.update(depths=depths.numpy().copy(), tnf=tnfz.numpy().copy(), total_abundance=totab.numpy().copy(),
+                       weights=weights.numpy().copy())
+            opt = dadaptation.DAdaptAdam(vae.parameters(), decouple=True)
+        else:
+            dl = ss.make_dataloader_labels(ab.copy(), tnf.copy(), lens, labels, batchsize=B)
+            (lab_int,) = dl.dataset.tensors
+            vae = ss.VAELabels(NL, nhiddens=list(c["nhiddens"]), nlatent=c["nlatent"], alpha=c["alpha"], beta=c["beta"],
+                               dropout=c["dropout"])
+            width = NL
+            opt = torch.optim.Adam(vae.parameters(), lr=c["lrate"])
+        rec["labels"] = lab_int.numpy().astype(np.int64)
+        rec["alpha"] = np.array(vae.alpha)
+        st0 = vae_oracle.init_state(0, c["nhiddens"], c["nlatent"], c["seed"], width=width)
+        vae.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st0.items()})
+        vae.dropoutlayer = InjectedDropout()
+        vae.reparameterize = lambda mu: (mu + torch.from_numpy(eps_q.pop(0))) if eps_q else mu
+        onehot = torch.nn.functional.one_hot(lab_int[:B], num_classes=NL).float()
+        losses = []
+        vae.train()
+        for step in range(c["steps"]):
+            mask_q[:] = list(masks[step])
+            eps_q[:] = [eps[step]]
+            opt.zero_grad()
+            if c["kind"] == "concat":
+                d_in, t_in, a_in, w_in = depths[:B], tnfz[:B], totab[:B], weights[:B]
+                do, to, ao, lo, mu, logsigma = vae(d_in, t_in, a_in, onehot)
+                loss, ce, sse, cel, kld, correct = vae.calc_loss(d_in, do, t_in, to, a_in, ao, onehot, lo, mu, logsigma, w_in)
+                loss.mean().backward()
+                losses.append([loss.mean().item(), ce.mean().item(), sse.mean().item(), cel.item(), kld.mean().item(),
+                               float(correct.item())])
+                outs = dict(depths_out=do, tnf_out=to, ab_out=ao, labels_out=lo, mu=mu)
+            else:
+                lo, mu, logsigma = vae(onehot)
+                loss, cel, kld, correct = vae.calc_loss(onehot, lo, mu, logsigma)
+                loss.backward()
+                losses.append([loss.item(), 0.0, 0.0, cel.item(), kld.item(), float(correct.item())])
+                outs = dict(labels_out=lo, mu=mu)
+            if step == 0:
+                for k, v in outs.items():
+                    rec["step0_" + k] = v.detach().numpy().copy()
+                for pname, p in vae.named_parameters():
+                    rec["grad0/" + pname] = p.grad.detach().numpy().copy()
+            opt.step()
+        rec["losses"] = np.array(losses, np.float64)   # loss, ce (raw mean), sse (raw mean), ce_labels, kld (raw mean), correct
+        for k, v in vae.state_dict().items():
+            rec["final/" + k] = v.numpy().copy()
+        vae.eval()
+        rec["latent"] = vae.encode(dl)
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+        out[name] = dict(loss0=losses[0][0], loss_last=losses[-1][0], correct_last=losses[-1][5])
+        print("semisup", name, out[name])
+    return out
+
+
 def gen_e2e():
     """End-to-end runs of the real reference over several model seeds: loss curves + bin quality.  Free-running
     RNG, 8 threads (the CLI default, vamb/__main__.py:27-28): the stored numbers are a SPREAD to land in, not values to match."""
@@ -225,6 +307,8 @@ def main():
         manifest["prep"] = gen_prep(en)
     if "vae" in which:
         manifest["vae"] = gen_vae(en)
+    if "semisup" in which:
+        manifest["semisup"] = gen_semisup()
     if "e2e" in which:   # minutes of reference CPU time; 8 threads, free-running RNG
         manifest["e2e"] = gen_e2e()
     json.dump(manifest, open(manifest_path, "w"), indent=1, sort_keys=True)

@@ -37,6 +37,49 @@ def test_install_and_uninstall():
     assert vamb.encode.VAE is ref_vae and vamb.cluster.ClusterGenerator is ref_cg
 
 
+@pytest.mark.skipif(not ref_harness.reference_available(), reason="reference tree not present")
+def test_semisupervised_classes_mirror_the_reference():
+    """Row N4: VAELabels / VAEConcat and their loaders keep the reference's signatures (names and defaults;
+    semisupervised_encode.py:111-175, 189-436, 438-698), write state_dicts of the reference's names and shapes, and
+    dropin.install(semisupervised=True) binds them."""
+    import inspect
+    import sys
+    import types
+
+    ss = ref_harness.load_reference_module("semisupervised_encode")
+    vamb = sys.modules["vamb"]
+    from vamb_amd import dropin, semisupervised_encode as vs
+
+    def sig(f):
+        return [(p.name, p.default) for p in inspect.signature(f).parameters.values() if not p.name.startswith("_")]
+
+    for cls in ("VAELabels", "VAEConcat"):
+        for meth in ("__init__", "forward", "calc_loss", "trainepoch", "trainmodel", "encode"):
+            assert sig(getattr(getattr(vs, cls), meth)) == sig(getattr(getattr(ss, cls), meth)), (cls, meth)
+    for fn in ("make_dataloader_labels", "make_dataloader_concat", "collate_fn_labels", "collate_fn_concat"):
+        assert sig(getattr(vs, fn)) == sig(getattr(ss, fn)), fn
+    # state_dict names / shapes
+    ref = ss.VAEConcat(6, 130, nhiddens=[48, 40], nlatent=8).state_dict()
+    me = types.SimpleNamespace(nsamples=6, _native_nsamples=6, nlabels=130, nhiddens=[48, 40], nlatent=8)
+    me._row_width = lambda: vs.VAEConcat._row_width(me)
+    assert vs.VAEConcat._state_names(me) == list(ref.keys())
+    for k in ref:
+        assert tuple(vs.VAEConcat._shape_of(me, k)) == tuple(ref[k].shape), k
+    ref = ss.VAELabels(150, nhiddens=[64, 32], nlatent=6).state_dict()
+    me = types.SimpleNamespace(nsamples=46, nlabels=150, nhiddens=[64, 32], nlatent=6)
+    me._row_width = lambda: vs.VAELabels._row_width(me)
+    for k in ref:
+        assert tuple(vs.VAELabels._shape_of(me, k)) == tuple(ref[k].shape), k
+    theirs = ss.VAELabels
+    saved = dropin.install(vamb, semisupervised=True)
+    try:
+        assert ss.VAELabels is vs.VAELabels and ss.VAEConcat is vs.VAEConcat
+        assert ss.make_dataloader_concat is vs.make_dataloader_concat
+    finally:
+        dropin.uninstall(saved, vamb)
+    assert ss.VAELabels is theirs
+
+
 @pytest.mark.reference
 def test_state_dict_spec_matches_reference():
     """The names, order and shapes our VAE.state_dict()/save() writes (VAE._state_names / _shape_of) are exactly those
@@ -54,6 +97,7 @@ def test_state_dict_spec_matches_reference():
     for nsamples, nhiddens, nlatent in [(6, [48, 40], 8), (1, [24, 24], 4), (7, [32, 24, 16], 6), (50, [512, 512], 32)]:
         ref = ref_encode.VAE(nsamples, nhiddens=list(nhiddens), nlatent=nlatent).state_dict()
         me = types.SimpleNamespace(nsamples=nsamples, nhiddens=list(nhiddens), nlatent=nlatent)
+        me._row_width = lambda: ve.VAE._row_width(me)
         names = ve.VAE._state_names(me)
         assert names == list(ref.keys())
         for k in names:

@@ -136,6 +136,13 @@ SIGNATURES = {
     "vh_debug_gemm16": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,
                                ctypes.POINTER(_f32)]),
     "vh_debug_gemm16_timeline": (_int, [_int, _int, _int, _int, _int, _vp, _int, _vp, _vp]),
+    "vh_vae_create_labelled": (_int, [_vp, _vp, _pp]),
+    "vh_vae_set_optimizer": (_int, [_vp, _int, _f32]),
+    "vh_vae_row_width": (_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
+    "vh_vae_forward_rows": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
+    "vh_vae_label_stats": (_int, [_vp, _i64, _vp]),
+    "vh_dataset_set_labels": (_int, [_vp, _vp, _i64, ctypes.c_int32]),
+    "vh_dataset_create_labels": (_int, [_vp, _i64, ctypes.c_int32, ctypes.POINTER(_vp)]),
     "vh_debug_gemm16_tn": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
 }
 

@@ -198,6 +198,16 @@ struct vh_vae {
     int nl = 0;       // hidden layers per side
     int S = 0, D = 0, D_p = 0, L = 0, L_p = 0;
     float ce_w = 0, ab_w = 0, sse_w = 0, kld_w = 0;
+    // input / reconstruction columns: S depths | ntnf TNF | nab total abundance | NL label logits (semisupervised_encode.py:
+    // VAEConcat 438-698 appends the one-hot labels, VAELabels 189-436 has ONLY the label block)
+    int kind = VH_VAE_PLAIN;
+    int NL = 0, lab0 = 0, ntnf = VH_NTNF, nab = 1;
+    float adam_lr = 0.0f;             // > 0: torch.optim.Adam(lr) instead of D-Adapt-Adam (VAELabels.trainmodel, :405)
+    int64_t ld_src = 0;               // row width of the dataset in use (0: labels-only dataset)
+    const int32_t* labels = nullptr;  // labels of the dataset in use
+    DevBuf<int32_t> Lb;               // labels of the batch rows
+    DevBuf<float> lab_part;           // per loss workgroup: label cross-entropy sum, correct predictions
+    std::vector<double> label_stats;  // (mean label cross-entropy, correct predictions) per epoch of the last training call
     hipStream_t stream = nullptr;
     // weight-gradient GEMMs are off the critical path of backward (only the optimiser needs them): they
     // run on a second stream, forked after each layer's dZ is ready and joined before the update
@@ -391,6 +401,8 @@ void prepare_batch(vh_vae* h, int bs) {
     const int nrb = bs_p / kRB;
     h->loss_blocks = bs_p / 4;
     h->loss_part.ensure((size_t)h->loss_blocks * 4);
+    h->Lb.ensure(bs_p);
+    if (h->NL > 0) h->lab_part.ensure((size_t)h->loss_blocks * 2);
     h->out_sm.ensure((size_t)bs_p * std::max(1, h->S));
     h->skinny.ensure((size_t)kSkinnySplits * bs_p * h->L_p);
     for (auto& hl : h->hidden) {
@@ -750,11 +762,13 @@ void loss_and_seed(vh_vae* h) {
     a.bs = h->bs; a.bs_p = h->bs_p; a.S = h->S; a.L = h->L;
     a.ce_w = h->ce_w; a.ab_w = h->ab_w; a.sse_w = h->sse_w; a.kld_w = h->kld_w;
     a.dR = h->dR.p; a.dMUk = h->dMUk.p; a.part = h->loss_part.p;
+    a.NL = h->NL; a.lab0 = h->lab0; a.ntnf = h->ntnf; a.nab = h->nab; a.Lb = h->Lb.p;
+    a.lab_part = h->NL > 0 ? h->lab_part.p : nullptr;
     // the scalar reduction (loss means, sum of weights) is only needed by the optimiser: side stream; the
     // output layer's weight gradient (backward) forks off the same point
     launch_forking(h, vae_loss_kernel, dim3(h->loss_blocks), dim3(256), 0, a);
     hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(kLossFinThreads), 0, h->side, h->loss_part.p, h->loss_blocks,
-                       h->Wb.p, h->bs, h->gwsum_src, bs_global, h->state.p);
+                       h->Wb.p, h->bs, h->gwsum_src, bs_global, h->state.p, (const float*)a.lab_part);
     VH_HIP(hipGetLastError());
 }
 
@@ -908,19 +922,19 @@ void optimizer_step(vh_vae* h) {
     const int nblk = h->opt_blocks;
     if (nblk > 0) {
         hipLaunchKernelGGL(vae_dadapt_kernel, dim3(nblk), dim3(256), 0, h->stream, *tab, h->P.p, h->M1.p, h->M2.p,
-                           h->Sv.p, h->state.p, h->opt_part.p, 0);
+                           h->Sv.p, h->state.p, h->opt_part.p, 0, h->adam_lr);
         VH_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(vae_dadapt_finalize_kernel, dim3(1), dim3(256), 0, h->stream, h->opt_part.p, h->opt_blocks,
-                       h->state.p, h->statbuf.p, h->keep_grads ? 0 : (int)h->statbuf.n);
+                       h->state.p, h->statbuf.p, h->keep_grads ? 0 : (int)h->statbuf.n, h->adam_lr > 0.f ? 1 : 0);
     VH_HIP(hipGetLastError());
     h->stat_clean = !h->keep_grads;
 }
 
 void gather_rows(vh_vae* h, const int64_t* dev_idx) {
     hipLaunchKernelGGL(vae_gather_kernel, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, h->stream, h->X.p,
-                       (int64_t)h->D_p, h->w.p, dev_idx, h->shuffle, &h->state.p->batch, h->bs, h->bs_p, h->Xb.p,
-                       h->Wb.p);
+                       h->ld_src, (int64_t)h->D_p, h->w.p, dev_idx, h->shuffle, &h->state.p->batch, (int64_t)0, h->bs,
+                       h->bs_p, h->Xb.p, h->Wb.p, LabelSrc{h->labels, h->lab0}, h->Lb.p);
     VH_HIP(hipGetLastError());
 }
 
@@ -984,12 +998,19 @@ int find_tensor(vh_vae* h, const char* name) {
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
+// VAE.__init__ (encode.py:171-257) and its two subclasses (semisupervised_encode.py:207-226, 457-478): same stack of layers,
+// different input / reconstruction columns, loss terms and optimiser
+int create_vae(const vh_vae_config* cfg, const vh_vae_labels_config* lab, vh_vae** out) {
     return guarded([&] {
         VH_REQUIRE(cfg != nullptr && out != nullptr, "NULL argument");
         *out = nullptr;
+        const int kind = lab ? lab->kind : VH_VAE_PLAIN;
+        VH_REQUIRE(kind == VH_VAE_PLAIN || kind == VH_VAE_CONCAT || kind == VH_VAE_LABELS, "unknown model kind %d", kind);
+        VH_REQUIRE(kind == VH_VAE_PLAIN || lab->nlabels >= 1, "nlabels must be > 0, not %d", lab ? lab->nlabels : 0);
+        VH_REQUIRE(!lab || lab->optimizer == VH_OPT_DADAPT_ADAM || (lab->optimizer == VH_OPT_ADAM && lab->lrate > 0),
+                   "optimizer must be D-Adapt-Adam or Adam with a positive learning rate");
         // encode.py:182-208
         VH_REQUIRE(cfg->nlatent >= 1, "Minimum 1 latent neuron, not %d", cfg->nlatent);
         VH_REQUIRE(cfg->nsamples >= 1, "nsamples must be > 0, not %d", cfg->nsamples);
@@ -1005,7 +1026,16 @@ int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
         h->cfg = *cfg;
         h->nl = cfg->nlayers;
         h->S = cfg->nsamples;
-        h->D = cfg->nsamples + VH_NTNF + 1;
+        h->kind = kind;
+        if (kind == VH_VAE_LABELS) {   // VAELabels: the network sees nothing but the one-hot labels
+            h->S = 0; h->ntnf = 0; h->nab = 0;
+        }
+        if (kind != VH_VAE_PLAIN) {
+            h->NL = lab->nlabels;
+            h->lab0 = h->S + h->ntnf + h->nab;
+            if (lab->optimizer == VH_OPT_ADAM) h->adam_lr = lab->lrate;
+        }
+        h->D = h->S + h->ntnf + h->nab + h->NL;
         h->D_p = (int)round_up(h->D, kColPad);
         h->L = cfg->nlatent;
         h->L_p = (int)round_up(h->L, kColPad);
@@ -1014,6 +1044,7 @@ int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
         h->ce_w = cfg->nsamples == 1 ? 0.0f : (float)(((1 - a) * (S - 1)) / (S * std::log(S)));
         h->ab_w = (float)((1 - a) * (1 / S));
         h->sse_w = (float)(a / VH_NTNF);
+        if (kind == VH_VAE_LABELS) h->ce_w = h->ab_w = h->sse_w = 0.0f;   // semisupervised_encode.py:248-257: CE(labels) + KLD
         h->kld_w = (float)(1.0 / ((double)cfg->nlatent * cfg->beta));
         // the main stream carries the critical path of a step (forward chain, dX chain, optimiser): highest
         // priority, so that its workgroups are dispatched ahead of the side stream's weight-gradient GEMMs
@@ -1078,6 +1109,17 @@ int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) {
         init_parameters(h.get());
         *out = h.release();
     });
+}
+
+}  // namespace
+
+extern "C" {
+
+int vh_vae_create(const vh_vae_config* cfg, vh_vae** out) { return create_vae(cfg, nullptr, out); }
+
+int vh_vae_create_labelled(const vh_vae_config* cfg, const vh_vae_labels_config* lab, vh_vae** out) {
+    if (lab == nullptr) return guarded([&] { VH_REQUIRE(false, "NULL argument"); });
+    return create_vae(cfg, lab, out);
 }
 
 int vh_vae_destroy(vh_vae* h) {
@@ -1251,10 +1293,48 @@ int vh_vae_set_dataset(vh_vae* h, const float* depths, const float* tnf, const f
                        int64_t n) {
     return guarded([&] {
         VH_REQUIRE(h != nullptr, "NULL argument");
+        VH_REQUIRE(h->kind == VH_VAE_PLAIN, "models with a label block take a shared dataset (vh_dataset_set_labels + vh_vae_use_dataset)");
         upload_dataset(&h->own, h->S, h->D_p, depths, tnf, abundance, weights, n);
         h->n = n;
         h->X.p = h->own.X.p;
         h->w.p = h->own.w.p;
+        h->ld_src = h->D_p;
+        h->labels = nullptr;
+    });
+}
+
+namespace {
+void upload_labels(vh_dataset* d, const int32_t* labels, int64_t n, int32_t nlabels) {
+    VH_REQUIRE(labels != nullptr, "NULL argument");
+    VH_REQUIRE(nlabels >= 1, "nlabels must be > 0, not %d", nlabels);
+    for (int64_t i = 0; i < n; ++i)
+        VH_REQUIRE(labels[i] >= 0 && labels[i] < nlabels, "label %d of row %lld is outside [0, %d)", labels[i], (long long)i, nlabels);
+    d->labels.alloc((size_t)n);
+    VH_HIP(hipMemcpy(d->labels.p, labels, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    d->NL = nlabels;
+}
+}  // namespace
+
+int vh_dataset_set_labels(vh_dataset* d, const int32_t* labels, int64_t n, int32_t nlabels) {
+    return guarded([&] {
+        VH_REQUIRE(d != nullptr, "NULL argument");
+        VH_REQUIRE(n == d->n, "%lld labels for a dataset of %lld rows", (long long)n, (long long)d->n);
+        upload_labels(d, labels, n, nlabels);
+    });
+}
+
+int vh_dataset_create_labels(const int32_t* labels, int64_t n, int32_t nlabels, vh_dataset** out) {
+    return guarded([&] {
+        VH_REQUIRE(out != nullptr, "NULL argument");
+        VH_REQUIRE(n >= 1, "empty dataset");
+        std::unique_ptr<vh_dataset> d(new vh_dataset());
+        d->n = n;
+        upload_labels(d.get(), labels, n, nlabels);
+        // VAELabels.calc_loss (semisupervised_encode.py:248-257) has no per-contig weights: unit weights
+        std::vector<float> ones((size_t)n, 1.0f);
+        d->w.alloc((size_t)n);
+        VH_HIP(hipMemcpy(d->w.p, ones.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+        *out = d.release();
     });
 }
 
@@ -1277,13 +1357,17 @@ int vh_dataset_destroy(vh_dataset* d) {
 int vh_vae_use_dataset(vh_vae* h, vh_dataset* d) {
     return guarded([&] {
         VH_REQUIRE(h != nullptr && d != nullptr, "NULL argument");
-        VH_REQUIRE(d->S == h->S && d->D_p == h->D_p, "dataset has %d samples, the model %d", d->S, h->S);
+        VH_REQUIRE(d->S == h->S, "dataset has %d samples, the model %d", d->S, h->S);
+        if (h->kind == VH_VAE_PLAIN) VH_REQUIRE(d->D_p == h->D_p, "dataset rows are %d wide, the model's %d", d->D_p, h->D_p);
+        else VH_REQUIRE(d->labels.p != nullptr && d->NL == h->NL, "the model has %d label columns, the dataset %d", h->NL, d->NL);
         VH_HIP(hipStreamSynchronize(h->stream));
         h->own.X.release();
         h->own.w.release();
         h->n = d->n;
         h->X.p = d->X.p;
         h->w.p = d->w.p;
+        h->ld_src = d->D_p;
+        h->labels = h->kind == VH_VAE_PLAIN ? nullptr : d->labels.p;
     });
 }
 
@@ -1322,6 +1406,7 @@ int vh_vae_train_step(vh_vae* h, const int64_t* rows, int64_t batch, const float
         probe_collect(h);
         if (losses)
             for (int i = 0; i < 5; ++i) losses[i] = st.step_loss[i];
+        h->label_stats.assign({st.step_label[0], st.step_label[1]});
     });
 }
 
@@ -1416,6 +1501,7 @@ void enqueue_epoch(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t ba
             // epoch log line: every rank holds local_sum / B_global, the sum over ranks is the global mean
             StepState* st = h->state.p;
             rccl_allreduce_sum_f64(h->comm, st->epoch_loss, 5, h->stream);
+            if (h->NL > 0) rccl_allreduce_sum_f64(h->comm, st->epoch_label, 2, h->stream);
             // BatchNorm running statistics are per-rank (local batch statistics): average them so that
             // every rank encodes with the same eval-mode network
             rccl_allreduce_sum_f32(h->comm, h->bnbuf.p, h->bn_elems, h->stream);
@@ -1439,6 +1525,7 @@ int vh_vae_train_epoch_dp(vh_vae* h, const int64_t* perm, int64_t n_batches, int
         probe_collect(h);
         if (loss_means)
             for (int i = 0; i < 5; ++i) loss_means[i] = st.epoch_loss[i] / (double)n_batches;
+        h->label_stats.assign({st.epoch_label[0] / (double)n_batches, st.epoch_label[1]});
     });
 }
 
@@ -1450,16 +1537,25 @@ int vh_vae_train_epochs(vh_vae* h, int64_t n_epochs, int64_t n_batches, int64_t 
     return guarded([&] {
         VH_REQUIRE(h != nullptr && loss_means != nullptr, "NULL argument");
         VH_REQUIRE(n_epochs >= 1, "no epochs");
-        h->h_epoch_loss.ensure((size_t)n_epochs * 5);
+        h->h_epoch_loss.ensure((size_t)n_epochs * 7);   // per epoch: the five loss sums, then (label cross-entropy, correct)
+        double* lab_sums = h->h_epoch_loss.p + 5 * n_epochs;
         for (int64_t e = 0; e < n_epochs; ++e) {
             enqueue_epoch(h, nullptr, n_batches, batch, global_batch, nullptr);
             VH_HIP(hipMemcpyAsync(h->h_epoch_loss.p + 5 * e, h->state.p->epoch_loss, 5 * sizeof(double),
                                   hipMemcpyDeviceToHost, h->stream));
+            if (h->NL > 0)
+                VH_HIP(hipMemcpyAsync(lab_sums + 2 * e, h->state.p->epoch_label, 2 * sizeof(double), hipMemcpyDeviceToHost,
+                                      h->stream));
             probe_collect_ready(h);
         }
         VH_HIP(hipStreamSynchronize(h->stream));
         probe_collect(h);
         for (int64_t i = 0; i < n_epochs * 5; ++i) loss_means[i] = h->h_epoch_loss.p[i] / (double)n_batches;
+        h->label_stats.clear();
+        for (int64_t e = 0; e < n_epochs && h->NL > 0; ++e) {
+            h->label_stats.push_back(lab_sums[2 * e] / (double)n_batches);
+            h->label_stats.push_back(lab_sums[2 * e + 1]);
+        }
     });
 }
 
@@ -1494,6 +1590,7 @@ int vh_vae_forward(vh_vae* h, const float* depths, const float* tnf, const float
                    float* abundance_out, float* mu_out) {
     return guarded([&] {
         VH_REQUIRE(h != nullptr && depths && tnf && abundance, "NULL argument");
+        VH_REQUIRE(h->kind == VH_VAE_PLAIN, "models with a label block go through vh_vae_forward_rows");
         VH_REQUIRE(batch >= 1 && batch <= (1 << 24), "bad batch size");
         VH_REQUIRE(!training || batch >= 2, "Expected more than 1 value per channel when training");
         prepare_batch(h, (int)batch);
@@ -1550,6 +1647,80 @@ int vh_vae_forward(vh_vae* h, const float* depths, const float* tnf, const float
     });
 }
 
+int vh_vae_label_stats(vh_vae* h, int64_t n_epochs, double* out) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && out != nullptr, "NULL argument");
+        VH_REQUIRE(h->NL > 0, "the model has no label block");
+        VH_REQUIRE((int64_t)h->label_stats.size() == 2 * n_epochs, "the last training call covered %lld epochs, not %lld",
+                   (long long)(h->label_stats.size() / 2), (long long)n_epochs);
+        memcpy(out, h->label_stats.data(), sizeof(double) * h->label_stats.size());
+    });
+}
+
+int vh_vae_row_width(vh_vae* h, int32_t* width) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && width != nullptr, "NULL argument");
+        *width = h->D;
+    });
+}
+
+// forward() on explicit input rows in the model's own column order; R = the reconstruction with the softmax applied to the
+// depths block (what `_decode` returns, encode.py:283-304 / semisupervised_encode.py:228-237, 480-502)
+int vh_vae_forward_rows(vh_vae* h, const float* X, int64_t batch, int training, const float* eps, const uint8_t* masks,
+                        float* R_out, float* mu_out) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && X != nullptr, "NULL argument");
+        VH_REQUIRE(batch >= 1 && batch <= (1 << 24), "bad batch size");
+        VH_REQUIRE(!training || batch >= 2, "Expected more than 1 value per channel when training");
+        prepare_batch(h, (int)batch);
+        std::vector<float> xb((size_t)h->bs_p * h->D_p, 0.f);
+        for (int64_t r = 0; r < batch; ++r) memcpy(xb.data() + (size_t)r * h->D_p, X + (size_t)r * h->D, sizeof(float) * h->D);
+        VH_HIP(hipMemcpyAsync(h->Xb.p, xb.data(), sizeof(float) * xb.size(), hipMemcpyHostToDevice, h->stream));
+        std::vector<float> e;
+        if (eps) {
+            e.assign((size_t)h->bs_p * h->L_p, 0.f);
+            for (int r = 0; r < batch; ++r) memcpy(e.data() + (size_t)r * h->L_p, eps + (size_t)r * h->L, sizeof(float) * h->L);
+            VH_HIP(hipMemcpyAsync(h->EPS.p, e.data(), sizeof(float) * e.size(), hipMemcpyHostToDevice, h->stream));
+        }
+        VH_HIP(hipStreamSynchronize(h->stream));
+        const bool inj_masks = training && masks != nullptr && h->cfg.dropout > 0;
+        if (inj_masks) upload_masks(h, masks, (int)batch);
+        if (h->bf16) {
+            const int64_t n4 = (int64_t)h->bs_p * h->D_p / 4;
+            hipLaunchKernelGGL(vae_cast16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n4, 256), 4096)), dim3(256), 0,
+                               h->stream, h->Xb.p, h->Xb16.p, n4);
+            VH_HIP(hipGetLastError());
+            step16::forward16(h, training != 0, eps != nullptr, inj_masks, true, nullptr);
+        } else {
+            forward(h, training != 0, eps != nullptr, inj_masks, true);
+        }
+        if (training) { join_side(h); count_batches(h, 1); }
+        hipLaunchKernelGGL(vae_advance_step_kernel, dim3(1), dim3(1), 0, h->stream, h->state.p);
+        VH_HIP(hipGetLastError());
+        std::vector<float> r((size_t)batch * h->D_p), sm, mu;
+        VH_HIP(hipMemcpyAsync(r.data(), h->R.p, sizeof(float) * r.size(), hipMemcpyDeviceToHost, h->stream));
+        if (R_out && h->S > 1) {
+            sm.resize((size_t)batch * h->S);
+            hipLaunchKernelGGL(vae_softmax_out_kernel, dim3((unsigned)ceil_div(batch, 4)), dim3(256), 0, h->stream,
+                               h->R.p, (int64_t)h->D_p, (int)batch, h->S, h->out_sm.p);
+            VH_HIP(hipGetLastError());
+            VH_HIP(hipMemcpyAsync(sm.data(), h->out_sm.p, sizeof(float) * sm.size(), hipMemcpyDeviceToHost, h->stream));
+        }
+        if (mu_out) {
+            mu.resize((size_t)batch * h->L_p);
+            VH_HIP(hipMemcpyAsync(mu.data(), h->MU.p, sizeof(float) * mu.size(), hipMemcpyDeviceToHost, h->stream));
+        }
+        VH_HIP(hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < batch; ++i) {
+            if (R_out) {
+                memcpy(R_out + (size_t)i * h->D, r.data() + (size_t)i * h->D_p, sizeof(float) * h->D);
+                if (!sm.empty()) memcpy(R_out + (size_t)i * h->D, sm.data() + (size_t)i * h->S, sizeof(float) * h->S);
+            }
+            if (mu_out) memcpy(mu_out + (size_t)i * h->L, mu.data() + (size_t)i * h->L_p, sizeof(float) * h->L);
+        }
+    });
+}
+
 int vh_vae_encode(vh_vae* h, float* latent) {
     return guarded([&] {
         VH_REQUIRE(h != nullptr && latent != nullptr, "NULL argument");
@@ -1559,10 +1730,11 @@ int vh_vae_encode(vh_vae* h, float* latent) {
         const int64_t chunk = 16384;
         int maxw = 0;
         for (int li = 0; li < h->nl; ++li) maxw = std::max(maxw, h->hidden[li].nout_p);
-        DevBuf<float> a0, a1, lat;
+        DevBuf<float> a0, a1, lat, xin;
         a0.alloc((size_t)chunk * maxw);
         a1.alloc((size_t)chunk * maxw);
         lat.alloc((size_t)chunk * h->L);
+        if (h->kind != VH_VAE_PLAIN) xin.alloc((size_t)chunk * h->D_p);   // rows with their one-hot label block
         for (int li = 0; li < h->nl; ++li) {
             Hidden& hl = h->hidden[li];
             hipLaunchKernelGGL(vae_bn_eval_coeff_kernel, dim3((unsigned)ceil_div(hl.nout_p, 256)), dim3(256), 0, s,
@@ -1573,6 +1745,14 @@ int vh_vae_encode(vh_vae* h, float* latent) {
         for (int64_t lo = 0; lo < h->n; lo += chunk) {
             const int m = (int)std::min<int64_t>(chunk, h->n - lo);
             const float* in = h->X.p + (size_t)lo * h->D_p;
+            if (h->kind != VH_VAE_PLAIN) {
+                hipLaunchKernelGGL(vae_gather_kernel, dim3((unsigned)ceil_div(m, 4)), dim3(64, 4), 0, s, h->X.p, h->ld_src,
+                                   (int64_t)h->D_p, h->w.p, (const int64_t*)nullptr, ShuffleSpec{0, 0, 1},
+                                   (const long long*)nullptr, lo, m, m, xin.p, (float*)nullptr, LabelSrc{h->labels, h->lab0},
+                                   (int32_t*)nullptr);
+                VH_HIP(hipGetLastError());
+                in = xin.p;
+            }
             int in_w = h->D_p;
             float* bufs[2] = {a0.p, a1.p};
             for (int li = 0; li < h->nl; ++li) {
@@ -1639,6 +1819,16 @@ int vh_vae_reset_optimizer(vh_vae* h) {
         st.k = 0;
         VH_HIP(hipMemcpyAsync(h->state.p, &st, offsetof(StepState, step), hipMemcpyHostToDevice, h->stream));
         VH_HIP(hipStreamSynchronize(h->stream));
+    });
+}
+
+int vh_vae_set_optimizer(vh_vae* h, int optimizer, float lrate) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr, "NULL argument");
+        VH_REQUIRE(optimizer == VH_OPT_DADAPT_ADAM || optimizer == VH_OPT_ADAM, "unknown optimizer %d", optimizer);
+        VH_REQUIRE(optimizer == VH_OPT_DADAPT_ADAM || lrate > 0, "Learning rate must be positive, not %g", (double)lrate);
+        VH_HIP(hipStreamSynchronize(h->stream));
+        h->adam_lr = optimizer == VH_OPT_ADAM ? lrate : 0.0f;
     });
 }
 

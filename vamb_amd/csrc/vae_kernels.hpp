@@ -62,29 +62,44 @@ __host__ __device__ __forceinline__ unsigned long long shuffle_index(const Shuff
     return x;
 }
 
+// Label block of the semi-supervised models (semisupervised_encode.py:25-47: the collate functions one-hot the integer label
+// of every row).  The dataset keeps the int32 label per row; the batch row gets a 1.0 at column col0 + label.
+struct LabelSrc {
+    const int32_t* labels;   // [n] or nullptr (no label block)
+    int col0;                // first label column of the batch row
+};
+
 // Xb[r][:] = X[src(r)][:], Wb[r] = w[src(r)] for r < bs; zero rows for the padding.  blockDim (64,4).
-// src(r) = idx[first + r] when an explicit row list is given, else shuffle(first + r); first = batch * bs
+// src(r) = idx[first + r] when an explicit row list is given, else shuffle(first + r); first = base + batch * bs
 // with the batch index read from device memory (advanced by the optimiser's finalize kernel).
-__global__ void vae_gather_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ w_all,
+// The dataset row is ld_src wide (0: the dataset has no feature columns), the batch row ldx; Lb[r] = label of the row.
+__global__ void vae_gather_kernel(const float* __restrict__ X, int64_t ld_src, int64_t ldx, const float* __restrict__ w_all,
                                   const int64_t* __restrict__ idx, const ShuffleSpec shuffle,
-                                  const long long* __restrict__ batch_ptr, int bs, int bs_p,
-                                  float* __restrict__ Xb, float* __restrict__ Wb) {
+                                  const long long* __restrict__ batch_ptr, int64_t base, int bs, int bs_p,
+                                  float* __restrict__ Xb, float* __restrict__ Wb, const LabelSrc lab,
+                                  int32_t* __restrict__ Lb) {
     const int r = blockIdx.x * 4 + threadIdx.y;
     if (r >= bs_p) return;
     const bool real = r < bs;
-    const int64_t first = batch_ptr ? (int64_t)(*batch_ptr) * bs : 0;
+    const int64_t first = base + (batch_ptr ? (int64_t)(*batch_ptr) * bs : 0);
     int64_t src = 0;
     if (real) src = idx ? idx[first + r] : (int64_t)shuffle_index(shuffle, (unsigned long long)(first + r));
-    const float4* s = reinterpret_cast<const float4*>(X + src * ldx);
+    const float4* s = reinterpret_cast<const float4*>(X + src * ld_src);
     float4* d = reinterpret_cast<float4*>(Xb + (int64_t)r * ldx);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int dq = (int)(ldx / 4);
+    const int dq = (int)(ldx / 4), sq = (int)(ld_src / 4);
+    int hot = -1;
+    if (lab.labels && real) hot = lab.col0 + lab.labels[src];
     for (int c = threadIdx.x; c < dq; c += 64) {
         float4 v = z;
-        if (real) v = s[c];
+        if (real && c < sq) v = s[c];
+        if ((hot >> 2) == c && hot >= 0) (&v.x)[hot & 3] = 1.0f;
         d[c] = v;
     }
-    if (threadIdx.x == 0) Wb[r] = real ? w_all[src] : 0.f;
+    if (threadIdx.x == 0) {
+        if (Wb) Wb[r] = real ? w_all[src] : 0.f;
+        if (Lb) Lb[r] = hot >= 0 ? hot - lab.col0 : 0;
+    }
 }
 
 // data-parallel planning on the device: out[b] = sum of the weights of this rank's rows of batch b
@@ -208,13 +223,49 @@ struct LossArgs {
     float* dR;           // [bs_p][ld]
     float* dMUk;         // [bs_p][ldl]
     float* part;         // [gridDim.x][4] : ab, ce, sse, kld (already multiplied by their weights)
+    // label block (semisupervised_encode.py:248-257, 515-569): NL logits at columns lab0.. of R, the row's class in Lb;
+    // cross-entropy of the row (the reference's CrossEntropyLoss is the batch mean of these) with weight 1 and
+    // argmax(logits) == class.  ntnf / nab: 103 / 1, or 0 / 0 for the labels-only model.
+    int NL, lab0, ntnf, nab;
+    const int32_t* Lb;
+    float* lab_part;     // [gridDim.x][2] : cross-entropy sum, correct predictions
 };
 
+// Cross-entropy of one row's label logits and its gradient (softmax - onehot) * g; returns (ce, correct) on every lane.
+// torch.max(dim=1) returns the FIRST maximal index: ties go to the lowest column.
+template <class Store>
+__device__ __forceinline__ void label_block(const float* __restrict__ r, int NL, int y, float g, Store&& store, float& ce_out,
+                                            float& correct_out) {
+    const int lane = threadIdx.x & 63;
+    float mx = -3.0e38f;
+    int arg = 0x7fffffff;
+    for (int c = lane; c < NL; c += 64) {
+        const float v = r[c];
+        if (v > mx) { mx = v; arg = c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float om = __shfl_xor(mx, off);
+        const int oa = __shfl_xor(arg, off);
+        if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
+    }
+    float se = 0.f;
+    for (int c = lane; c < NL; c += 64) se += expf(r[c] - mx);
+    se = wave_sum(se);
+    const float inv = 1.0f / se;
+    for (int c = lane; c < NL; c += 64) {
+        const float p = expf(r[c] - mx) * inv;
+        store(c, g * (p - (c == y ? 1.0f : 0.0f)));
+    }
+    ce_out = (logf(se) + mx) - r[y];
+    correct_out = arg == y ? 1.0f : 0.0f;
+}
+
 __global__ __launch_bounds__(256) void vae_loss_kernel(const LossArgs a) {
-    __shared__ float red[4][4];
+    __shared__ float red[4][6];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
-    float ab_t = 0.f, ce_t = 0.f, sse_t = 0.f, kld_t = 0.f;
+    float ab_t = 0.f, ce_t = 0.f, sse_t = 0.f, kld_t = 0.f, cel_t = 0.f, hit_t = 0.f;
     if (row < a.bs_p) {
         float* dr = a.dR + (int64_t)row * a.ld;
         float* dm = a.dMUk + (int64_t)row * a.ldl;
@@ -226,14 +277,14 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const LossArgs a) {
             const float* x = a.X + (int64_t)row * a.ld;
             const float g = a.inv_b2;
             const int S = a.S;
-            // softmax over the S abundance logits
+            // softmax over the S abundance logits (S = 0: the labels-only model has none; every loop below is empty)
             float mx = -3.0e38f;
             for (int c = lane; c < S; c += 64) mx = fmaxf(mx, r[c]);
             mx = wave_max(mx);
             float se = 0.f;
             for (int c = lane; c < S; c += 64) se += expf(r[c] - mx);
             se = wave_sum(se);
-            const float inv = 1.0f / se;
+            const float inv = S > 0 ? 1.0f / se : 0.0f;
             float ce = 0.f, pdp = 0.f;
             for (int c = lane; c < S; c += 64) {
                 const float p = expf(r[c] - mx) * inv;
@@ -252,22 +303,25 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const LossArgs a) {
             // TNF sum of squared errors
             float sse = 0.f;
             const float gsse = g * a.sse_w * 2.0f;
-            for (int c = S + lane; c < S + 103; c += 64) {
+            for (int c = S + lane; c < S + a.ntnf; c += 64) {
                 const float diff = r[c] - x[c];
                 sse += diff * diff;
                 dr[c] = gsse * diff;
             }
             sse = wave_sum(sse);
-            // total-abundance squared error (one column) + zero the padding columns
+            // total-abundance squared error (one column)
             float ab = 0.f;
-            if (lane == 0) {
-                const int c = S + 103;
+            if (lane == 0 && a.nab) {
+                const int c = S + a.ntnf;
                 const float diff = r[c] - x[c];
                 ab = diff * diff;
                 dr[c] = g * a.ab_w * 2.0f * diff;
             }
             ab = wave_sum(ab);
-            for (int c = S + 104 + lane; c < a.ld; c += 64) dr[c] = 0.f;
+            // label logits
+            if (a.NL > 0) label_block(r + a.lab0, a.NL, a.Lb[row], g, [&](int c, float v) { dr[a.lab0 + c] = v; }, cel_t, hit_t);
+            // zero the padding columns
+            for (int c = S + a.ntnf + a.nab + a.NL + lane; c < a.ld; c += 64) dr[c] = 0.f;
             // KLD = 0.5 * sum(mu^2)
             const float* mu = a.MU + (int64_t)row * a.ldl;
             float kld = 0.f;
@@ -284,11 +338,17 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const LossArgs a) {
             kld_t = kld * a.kld_w;
         }
     }
-    if (lane == 0) { red[wave][0] = ab_t; red[wave][1] = ce_t; red[wave][2] = sse_t; red[wave][3] = kld_t; }
+    if (lane == 0) {
+        red[wave][0] = ab_t; red[wave][1] = ce_t; red[wave][2] = sse_t; red[wave][3] = kld_t;
+        red[wave][4] = cel_t; red[wave][5] = hit_t;
+    }
     __syncthreads();
     if (threadIdx.x < 4) {
         const int t = threadIdx.x;
         a.part[(int64_t)blockIdx.x * 4 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    } else if (threadIdx.x < 6 && a.lab_part) {
+        const int t = threadIdx.x;
+        a.lab_part[(int64_t)blockIdx.x * 2 + (t - 4)] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
     }
 }
 
@@ -303,6 +363,8 @@ struct StepState {
     double step_loss[5];       // loss, ab, ce, sse, kld of the last step (calc_loss order)
     double epoch_loss[5];      // running sums over the epoch's batches
     long long epoch_batches;
+    double epoch_label[2];     // label block: sums over the epoch of the batch-mean cross-entropy / of the correct predictions
+    double step_label[2];      // ... of the last step
 };
 
 // reduce the loss partials, produce the five means (encode.py:350-356), add them to the epoch sums and
@@ -316,9 +378,15 @@ constexpr int kLossFinThreads = 1024;
 __global__ __launch_bounds__(kLossFinThreads) void vae_loss_finalize_kernel(const float* __restrict__ part, int nblocks,
                                                                             const float* __restrict__ Wb, int bs,
                                                                             const float* __restrict__ gwsum, int bs_global,
-                                                                            StepState* __restrict__ st) {
-    __shared__ double red[5][kLossFinThreads / 64];
-    double s[5] = {0, 0, 0, 0, 0};
+                                                                            StepState* __restrict__ st,
+                                                                            const float* __restrict__ lab_part) {
+    __shared__ double red[7][kLossFinThreads / 64];
+    double s[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (lab_part)   // [nblocks][2]: cross-entropy sums, correct predictions
+        for (int b = threadIdx.x; b < nblocks; b += kLossFinThreads) {
+            const float2 v = reinterpret_cast<const float2*>(lab_part)[b];
+            s[5] += (double)v.x; s[6] += (double)v.y;
+        }
     const float4* p4 = reinterpret_cast<const float4*>(part);   // one float4 (ab, ce, sse, kld) per loss workgroup
     for (int b0 = threadIdx.x; b0 < nblocks; b0 += 4 * kLossFinThreads) {
         float4 v[4];
@@ -347,7 +415,7 @@ __global__ __launch_bounds__(kLossFinThreads) void vae_loss_finalize_kernel(cons
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < 7; ++t) {
         double v = s[t];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -355,8 +423,8 @@ __global__ __launch_bounds__(kLossFinThreads) void vae_loss_finalize_kernel(cons
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double tot[5];
-        for (int t = 0; t < 5; ++t) {
+        double tot[7];
+        for (int t = 0; t < 7; ++t) {
             double v = 0.0;
             for (int w = 0; w < kLossFinThreads / 64; ++w) v += red[t][w];
             tot[t] = v;
@@ -365,9 +433,14 @@ __global__ __launch_bounds__(kLossFinThreads) void vae_loss_finalize_kernel(cons
         const double wsum = gwsum ? (double)gwsum[st->batch] : (double)(float)tot[4];
         const double ab = tot[0] / bsg, ce = tot[1] / bsg, sse = tot[2] / bsg, kld = tot[3] / bsg;
         const double wmean = wsum / bsg;
-        const double loss = ((ce + ab + sse) + kld) * wmean;
+        // the label cross-entropy (weight 1) joins the reconstruction terms (semisupervised_encode.py:553-556; a model without
+        // a label block adds exactly 0.0)
+        const double cel = tot[5] / bsg;
+        const double loss = lab_part ? (((ce + ab + sse) + cel) + kld) * wmean : ((ce + ab + sse) + kld) * wmean;
         const double v[5] = {loss, ab, ce, sse, kld};
         for (int t = 0; t < 5; ++t) { st->step_loss[t] = v[t]; st->epoch_loss[t] += v[t]; }
+        st->step_label[0] = cel; st->step_label[1] = tot[6];
+        st->epoch_label[0] += cel; st->epoch_label[1] += tot[6];
         st->epoch_batches += 1;
         st->wsum = wsum;
     }
@@ -644,7 +717,8 @@ __global__ void vae_scale_kernel(float* __restrict__ v, int64_t n, float f) {
 __global__ __launch_bounds__(256) void vae_dadapt_kernel(const OptTable tab, float* __restrict__ P,
                                                          float* __restrict__ M1, float* __restrict__ M2,
                                                          float* __restrict__ Sv, const StepState* __restrict__ st,
-                                                         double* __restrict__ partials /*[all blocks][2]*/, int blk0) {
+                                                         double* __restrict__ partials /*[all blocks][2]*/, int blk0,
+                                                         float adam_lr) {
     __shared__ double red[2][4];
     const int blk = blockIdx.x + blk0;   // the launch covers the table's workgroups [blk0, blk0 + gridDim.x)
     const int t = opt_find_tensor(tab, blk);
@@ -659,7 +733,29 @@ __global__ __launch_bounds__(256) void vae_dadapt_kernel(const OptTable tab, flo
     const float sqrt_b2 = (float)sqrt_b2d;
     const float one_m_b2 = (float)(1.0 - 0.999);
     float num = 0.f, sk = 0.f;
-    if (local < td.size) {
+    if (local < td.size && adam_lr > 0.f) {
+        // torch.optim.Adam(lr) with its defaults (semisupervised_encode.py:405: betas 0.9 / 0.999, eps 1e-8, no weight decay):
+        //   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+        float4 g = fetch_grad(td, local);
+        g.x *= gscale; g.y *= gscale; g.z *= gscale; g.w *= gscale;
+        const int64_t o = td.p_off + local;
+        float4 p = *reinterpret_cast<float4*>(P + o), m = *reinterpret_cast<float4*>(M1 + o),
+               v = *reinterpret_cast<float4*>(M2 + o);
+        const double t = (double)(st->k + 1);
+        const float step_size = (float)((double)adam_lr / (1.0 - pow(0.9, t)));
+        const float bc2_sqrt = (float)sqrt(1.0 - pow(0.999, t));
+        float* pg = &g.x; float* pp = &p.x; float* pm = &m.x; float* pv = &v.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = pg[e];
+            pm[e] = pm[e] + (gi - pm[e]) * (1.0f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
+            pv[e] = pv[e] * b2 + one_m_b2 * gi * gi;
+            pp[e] -= step_size * (pm[e] / (sqrtf(pv[e]) / bc2_sqrt + eps));
+        }
+        *reinterpret_cast<float4*>(P + o) = p;
+        *reinterpret_cast<float4*>(M1 + o) = m;
+        *reinterpret_cast<float4*>(M2 + o) = v;
+    } else if (local < td.size) {
         float4 g = fetch_grad(td, local);
         g.x *= gscale; g.y *= gscale; g.z *= gscale; g.w *= gscale;
         const int64_t o = td.p_off + local;
@@ -695,7 +791,7 @@ __global__ __launch_bounds__(256) void vae_dadapt_kernel(const OptTable tab, flo
 // ... and clears the hidden layers' fp64 batch accumulators for the next step (every reader has finished).
 __global__ __launch_bounds__(256) void vae_dadapt_finalize_kernel(const double* __restrict__ partials, int nblocks,
                                                                   StepState* __restrict__ st,
-                                                                  double* __restrict__ statbuf, int nstat) {
+                                                                  double* __restrict__ statbuf, int nstat, int adam) {
     for (int i = threadIdx.x; i < nstat; i += 256) statbuf[i] = 0.0;
     __shared__ double red[2][256];
     double a = 0.0, b = 0.0;
@@ -719,7 +815,9 @@ __global__ __launch_bounds__(256) void vae_dadapt_finalize_kernel(const double* 
         const double numerator_acum = d * red[0][0];  // dlr * sum of the per-tensor dots
         const double sk_l1 = red[1][0];
         const double nw = sqrt_b2 * st->numerator_weighted + (1.0 - sqrt_b2) * numerator_acum;
-        if (sk_l1 != 0.0) {
+        if (adam) {
+            st->k += 1;   // Adam's step count
+        } else if (sk_l1 != 0.0) {
             const double d_hat = nw / ((1.0 - sqrt_b2) * sk_l1);
             st->d = d_hat > d ? d_hat : d;  // growth_rate = inf
             st->numerator_weighted = nw;

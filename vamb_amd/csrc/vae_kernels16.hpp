@@ -26,27 +26,34 @@ __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 
 
 // ---- batch assembly: Xb (fp32, the loss targets), Xb16 (the first GEMM's operand), Wb ----------------------------
 // blockDim (64, 4): one wavefront per row, float4 per lane.
-__global__ void vae_gather16_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ w_all,
+__global__ void vae_gather16_kernel(const float* __restrict__ X, int64_t ld_src, int64_t ldx, const float* __restrict__ w_all,
                                     const int64_t* __restrict__ idx, const ShuffleSpec shuffle,
-                                    const long long* __restrict__ batch_ptr, int bs, int bs_p,
-                                    float* __restrict__ Xb, bf16_t* __restrict__ Xb16, float* __restrict__ Wb) {
+                                    const long long* __restrict__ batch_ptr, int64_t base, int bs, int bs_p,
+                                    float* __restrict__ Xb, bf16_t* __restrict__ Xb16, float* __restrict__ Wb,
+                                    const LabelSrc lab, int32_t* __restrict__ Lb) {
     const int r = blockIdx.x * 4 + threadIdx.y;
     if (r >= bs_p) return;
     const bool real = r < bs;
-    const int64_t first = batch_ptr ? (int64_t)(*batch_ptr) * bs : 0;
+    const int64_t first = base + (batch_ptr ? (int64_t)(*batch_ptr) * bs : 0);
     int64_t src = 0;
     if (real) src = idx ? idx[first + r] : (int64_t)shuffle_index(shuffle, (unsigned long long)(first + r));
-    const float4* s = reinterpret_cast<const float4*>(X + src * ldx);
-    float4* d = reinterpret_cast<float4*>(Xb + (int64_t)r * ldx);
+    const float4* s = reinterpret_cast<const float4*>(X + src * ld_src);
+    float4* d = Xb ? reinterpret_cast<float4*>(Xb + (int64_t)r * ldx) : nullptr;   // (encode pass: only the bf16 operand)
     uint2* d16 = reinterpret_cast<uint2*>(Xb16 + (int64_t)r * ldx);
-    const int dq = (int)(ldx / 4);
+    const int dq = (int)(ldx / 4), sq = (int)(ld_src / 4);
+    int hot = -1;   // one-hot label column (see vae_gather_kernel)
+    if (lab.labels && real) hot = lab.col0 + lab.labels[src];
     for (int c = threadIdx.x; c < dq; c += 64) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (real) v = s[c];
-        d[c] = v;
+        if (real && c < sq) v = s[c];
+        if ((hot >> 2) == c && hot >= 0) (&v.x)[hot & 3] = 1.0f;
+        if (d) d[c] = v;
         d16[c] = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
     }
-    if (threadIdx.x == 0) Wb[r] = real ? w_all[src] : 0.f;
+    if (threadIdx.x == 0) {
+        if (Wb) Wb[r] = real ? w_all[src] : 0.f;
+        if (Lb) Lb[r] = hot >= 0 ? hot - lab.col0 : 0;
+    }
 }
 
 // rows of an fp32 matrix -> bf16 (encode pass: the resident feature matrix is fp32)
@@ -236,16 +243,19 @@ struct Loss16Args {
     bf16_t* dR16;
     float* dMUk;
     float* part;
+    int NL, lab0, ntnf, nab;   // label block, see LossArgs
+    const int32_t* Lb;
+    float* lab_part;
 };
 
 __global__ __launch_bounds__(256) void vae_loss16_kernel(const Loss16Args a) {
     // dynamic LDS: per wave the reconstruction row and the target row, read from HBM once with 16-byte loads (the
     // softmax / CE / SSE passes below re-read them four times)
     extern __shared__ __attribute__((aligned(16))) float loss_rows[];   // [4 waves][2][ld]
-    __shared__ float red[4][4];
+    __shared__ float red[4][6];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
-    float ab_t = 0.f, ce_t = 0.f, sse_t = 0.f, kld_t = 0.f;
+    float ab_t = 0.f, ce_t = 0.f, sse_t = 0.f, kld_t = 0.f, cel_t = 0.f, hit_t = 0.f;
     if (row < a.bs_p) {
         bf16_t* dr = a.dR16 + (int64_t)row * a.ld;
         float* dm = a.dMUk + (int64_t)row * a.ldl;
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(256) void vae_loss16_kernel(const Loss16Args a) {
                 se += e;
             }
             se = wave_sum(se);
-            const float inv = 1.0f / se;
+            const float inv = S > 0 ? 1.0f / se : 0.0f;
             float ce = 0.f, pdp = 0.f;
             for (int c = lane; c < S; c += 64) {
                 const float p = r[c] * inv;
@@ -296,21 +306,23 @@ __global__ __launch_bounds__(256) void vae_loss16_kernel(const Loss16Args a) {
             for (int c = lane; c < S; c += 64) dr[c] = f2bf(gce * r[c] * (-x[c] - pdp));
             float sse = 0.f;
             const float gsse = g * a.sse_w * 2.0f;
-            for (int c = S + lane; c < S + 103; c += 64) {
+            for (int c = S + lane; c < S + a.ntnf; c += 64) {
                 const float diff = r[c] - x[c];
                 sse += diff * diff;
                 dr[c] = f2bf(gsse * diff);
             }
             sse = wave_sum(sse);
             float ab = 0.f;
-            if (lane == 0) {
-                const int c = S + 103;
+            if (lane == 0 && a.nab) {
+                const int c = S + a.ntnf;
                 const float diff = r[c] - x[c];
                 ab = diff * diff;
                 dr[c] = f2bf(g * a.ab_w * 2.0f * diff);
             }
             ab = wave_sum(ab);
-            for (int c = S + 104 + lane; c < a.ld; c += 64) dr[c] = 0;
+            if (a.NL > 0)
+                label_block(r + a.lab0, a.NL, a.Lb[row], g, [&](int c, float v) { dr[a.lab0 + c] = f2bf(v); }, cel_t, hit_t);
+            for (int c = S + a.ntnf + a.nab + a.NL + lane; c < a.ld; c += 64) dr[c] = 0;
             const float* mu = a.MU + (int64_t)row * a.ldl;
             float kld = 0.f;
             const float gk = g * a.kld_w;
@@ -326,11 +338,17 @@ __global__ __launch_bounds__(256) void vae_loss16_kernel(const Loss16Args a) {
             kld_t = kld * a.kld_w;
         }
     }
-    if (lane == 0) { red[wave][0] = ab_t; red[wave][1] = ce_t; red[wave][2] = sse_t; red[wave][3] = kld_t; }
+    if (lane == 0) {
+        red[wave][0] = ab_t; red[wave][1] = ce_t; red[wave][2] = sse_t; red[wave][3] = kld_t;
+        red[wave][4] = cel_t; red[wave][5] = hit_t;
+    }
     __syncthreads();
     if (threadIdx.x < 4) {
         const int t = threadIdx.x;
         a.part[(int64_t)blockIdx.x * 4 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    } else if (threadIdx.x < 6 && a.lab_part) {
+        const int t = threadIdx.x;
+        a.lab_part[(int64_t)blockIdx.x * 2 + (t - 4)] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
     }
 }
 
@@ -564,7 +582,7 @@ __global__ __launch_bounds__(256) void vae_dadapt16_kernel(const Opt16Tensor* __
                                                            float* __restrict__ P, float* __restrict__ M1,
                                                            float* __restrict__ M2, float* __restrict__ Sv,
                                                            const StepState* __restrict__ st,
-                                                           double* __restrict__ partials) {
+                                                           double* __restrict__ partials, float adam_lr) {
     __shared__ double red[2][4];
     __shared__ bf16_t wt[32][32 + 2];
     const int blk = blockIdx.x;
@@ -586,7 +604,27 @@ __global__ __launch_bounds__(256) void vae_dadapt16_kernel(const Opt16Tensor* __
     const float one_m_b2 = (float)(1.0 - 0.999);
     float num = 0.f, sk = 0.f;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) {
+    if (live && adam_lr > 0.f) {   // torch.optim.Adam, see vae_dadapt_kernel
+        float4 g = opt16_grad(td, local, row, col, bs);
+        g.x *= gscale; g.y *= gscale; g.z *= gscale; g.w *= gscale;
+        const int64_t o = td.p_off + local;
+        p = *reinterpret_cast<float4*>(P + o);
+        float4 m = *reinterpret_cast<float4*>(M1 + o), v = *reinterpret_cast<float4*>(M2 + o);
+        const double tt = (double)(st->k + 1);
+        const float step_size = (float)((double)adam_lr / (1.0 - pow(0.9, tt)));
+        const float bc2_sqrt = (float)sqrt(1.0 - pow(0.999, tt));
+        float* pg = &g.x; float* pp = &p.x; float* pm = &m.x; float* pv = &v.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = pg[e];
+            pm[e] = pm[e] + (gi - pm[e]) * (1.0f - b1);
+            pv[e] = pv[e] * b2 + one_m_b2 * gi * gi;
+            pp[e] -= step_size * (pm[e] / (sqrtf(pv[e]) / bc2_sqrt + eps));
+        }
+        *reinterpret_cast<float4*>(P + o) = p;
+        *reinterpret_cast<float4*>(M1 + o) = m;
+        *reinterpret_cast<float4*>(M2 + o) = v;
+    } else if (live) {
         float4 g = opt16_grad(td, local, row, col, bs);
         g.x *= gscale; g.y *= gscale; g.z *= gscale; g.w *= gscale;
         const int64_t o = td.p_off + local;

@@ -421,8 +421,10 @@ void loss_and_seed16(vh_vae* h, SideQueue& q) {
     a.bs = h->bs; a.bs_p = h->bs_p; a.S = h->S; a.L = h->L;
     a.ce_w = h->ce_w; a.ab_w = h->ab_w; a.sse_w = h->sse_w; a.kld_w = h->kld_w;
     a.dR16 = h->dR16.p; a.dMUk = h->dMUk.p; a.part = h->loss_part.p;
+    a.NL = h->NL; a.lab0 = h->lab0; a.ntnf = h->ntnf; a.nab = h->nab; a.Lb = h->Lb.p;
+    a.lab_part = h->NL > 0 ? h->lab_part.p : nullptr;
     const size_t loss_lds = (size_t)8 * h->D_p * sizeof(float);   // 4 waves x (reconstruction row + target row)
-    VH_REQUIRE(loss_lds <= 160 * 1024 - 256, "nsamples = %d is too wide for the bf16 step's loss kernel (fp32 mode has no limit)", h->S);
+    VH_REQUIRE(loss_lds <= 160 * 1024 - 256, "%d input columns are too wide for the bf16 step's loss kernel (fp32 mode has no limit)", h->D);
     static bool loss_attr = false;
     if (!loss_attr) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_loss16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -433,9 +435,10 @@ void loss_and_seed16(vh_vae* h, SideQueue& q) {
     VH_HIP(hipGetLastError());
     // the scalar reduction (loss means, sum of weights) is only needed by the optimiser
     const float* gw = h->gwsum_src;
-    q.add([h, bs_global, gw](hipStream_t st) {
+    const float* lab_part = a.lab_part;
+    q.add([h, bs_global, gw, lab_part](hipStream_t st) {
         hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(kLossFinThreads), 0, st, h->loss_part.p, h->loss_blocks, h->Wb.p,
-                           h->bs, gw, bs_global, h->state.p);
+                           h->bs, gw, bs_global, h->state.p, lab_part);
         VH_HIP(hipGetLastError());
     });
 }
@@ -603,18 +606,19 @@ void optimizer_step16(vh_vae* h) {
         tab = h->opt16_tab_flat.p;
     }
     hipLaunchKernelGGL(vae_dadapt16_kernel, dim3(h->opt16_blocks), dim3(256), 0, h->stream, tab, h->opt16_n, stat_bs(h), h->P.p,
-                       h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p);
+                       h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p, h->adam_lr);
     VH_HIP(hipGetLastError());
     hipLaunchKernelGGL(vae_dadapt_finalize_kernel, dim3(1), dim3(256), 0, h->stream, h->opt_part.p, h->opt16_blocks,
-                       h->state.p, h->statbuf.p, h->keep_grads ? 0 : (int)h->statbuf.n);
+                       h->state.p, h->statbuf.p, h->keep_grads ? 0 : (int)h->statbuf.n, h->adam_lr > 0.f ? 1 : 0);
     VH_HIP(hipGetLastError());
     h->stat_clean = !h->keep_grads;
 }
 
 void gather_rows16(vh_vae* h, const int64_t* dev_idx, SideQueue& q) {
     hipLaunchKernelGGL(vae_gather16_kernel, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, h->stream,
-                       (const float*)h->X.p, (int64_t)h->D_p, (const float*)h->w.p, dev_idx, h->shuffle,
-                       (const long long*)&h->state.p->batch, h->bs, h->bs_p, h->Xb.p, h->Xb16.p, h->Wb.p);
+                       (const float*)h->X.p, h->ld_src, (int64_t)h->D_p, (const float*)h->w.p, dev_idx, h->shuffle,
+                       (const long long*)&h->state.p->batch, (int64_t)0, h->bs, h->bs_p, h->Xb.p, h->Xb16.p, h->Wb.p,
+                       LabelSrc{h->labels, h->lab0}, h->Lb.p);
     VH_HIP(hipGetLastError());
     // round-2 dataflow only: transposed copy of the batch for the first layer's weight gradient (needed last)
     if (!g_tuning.dw_row_major) q.add([h](hipStream_t st) { transpose16(h, st, h->Xb16.p, h->bs_p, h->D_p, h->Xb16T.p, nullptr, 0); });
@@ -648,9 +652,16 @@ void encode16(vh_vae* h, float* latent) {
     }
     for (int64_t lo = 0; lo < h->n; lo += chunk) {
         const int m = (int)std::min<int64_t>(chunk, h->n - lo);
-        const int64_t n4 = (int64_t)m * h->D_p / 4;
-        hipLaunchKernelGGL(vae_cast16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n4, 256), 4096)), dim3(256), 0, s,
-                           h->X.p + (size_t)lo * h->D_p, a1.p, n4);
+        if (h->kind == VH_VAE_PLAIN) {
+            const int64_t n4 = (int64_t)m * h->D_p / 4;
+            hipLaunchKernelGGL(vae_cast16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n4, 256), 4096)), dim3(256), 0, s,
+                               h->X.p + (size_t)lo * h->D_p, a1.p, n4);
+        } else {   // rows with their one-hot label block, straight to bf16
+            hipLaunchKernelGGL(vae_gather16_kernel, dim3((unsigned)ceil_div(m, 4)), dim3(64, 4), 0, s, (const float*)h->X.p,
+                               h->ld_src, (int64_t)h->D_p, (const float*)h->w.p, (const int64_t*)nullptr, ShuffleSpec{0, 0, 1},
+                               (const long long*)nullptr, lo, m, m, (float*)nullptr, a1.p, (float*)nullptr,
+                               LabelSrc{h->labels, h->lab0}, (int32_t*)nullptr);
+        }
         VH_HIP(hipGetLastError());
         const bf16_t* in = a1.p;
         int in_w = h->D_p;

@@ -17,9 +17,16 @@ from __future__ import annotations
 import sys
 
 
-def install(vamb_module=None):
+def install(vamb_module=None, semisupervised: bool = False):
     """Replace the hot-path entry points of ``vamb`` by the ``vamb_amd`` ones.  Returns the dict of
-    original objects (pass it to ``uninstall``)."""
+    original objects (pass it to ``uninstall``).
+
+    ``semisupervised=True`` also rebinds ``vamb.semisupervised_encode.{VAELabels, VAEConcat, make_dataloader_labels,
+    make_dataloader_concat}`` (row N4) for callers that train those models on their own.  Off by default: the reference's
+    joint trainer ``VAEVAE`` / ``VAEVAEHLoss`` (semisupervised_encode.py:700, taxvamb_encode.py:551) builds the two classes
+    through the same module attributes and then drives them as torch modules (``.parameters()``, ``._encode``), which the
+    GPU classes are not -- with the flag set, that trainer no longer works.  TaxVamb's clustering is on the GPU either way
+    (``cluster_and_write_files`` below)."""
     from . import cluster as _cluster
     from . import encode as _encode
 
@@ -56,6 +63,17 @@ def install(vamb_module=None):
         m.cluster_and_write_files = _output.cluster_and_write_files
     if not mains:
         _warn("vamb.__main__ is not importable: cluster_and_write_files stays the reference's")
+    if semisupervised:
+        ss = _submodule(vamb_module, "semisupervised_encode")
+        if ss is None:
+            _warn("vamb.semisupervised_encode is not importable: VAELabels / VAEConcat stay the reference's")
+        else:
+            from . import semisupervised_encode as _ss
+
+            names = ("VAELabels", "VAEConcat", "make_dataloader_labels", "make_dataloader_concat")
+            original["semisupervised"] = {n: getattr(ss, n) for n in names}
+            for n in names:
+                setattr(ss, n, getattr(_ss, n))
     return original
 
 
@@ -147,3 +165,5 @@ def uninstall(original, vamb_module=None):
         vamb_module.parsecontigs.Composition._project = original["_project"]
     for m, fn in original.get("cluster_and_write_files", []):
         m.cluster_and_write_files = fn
+    for n, obj in original.get("semisupervised", {}).items():
+        setattr(vamb_module.semisupervised_encode, n, obj)

@@ -441,14 +441,13 @@ class VAE:
         self._lib = _lib.load()
         _lib.require_gpu()
         cfg = _Config()
-        cfg.nsamples, cfg.nlatent, cfg.nlayers = nsamples, nlatent, len(nhiddens)
+        # (a subclass whose super().__init__ argument is not the number of samples sets _native_nsamples first)
+        cfg.nsamples, cfg.nlatent, cfg.nlayers = getattr(self, "_native_nsamples", nsamples), nlatent, len(nhiddens)
         for i, n in enumerate(nhiddens):
             cfg.nhiddens[i] = n
         cfg.alpha, cfg.beta, cfg.dropout, cfg.seed = alpha, beta, dropout, seed & 0xFFFFFFFFFFFFFFFF
-        h = ctypes.c_void_p()
         _lib.sync_env_options()   # VAMBHIP_* variables -> library options (the .so reads no environment)
-        _lib.check(self._lib.vh_vae_create(ctypes.byref(cfg), ctypes.byref(h)))
-        self._h = h
+        self._h = self._create_handle(cfg)
         self._dataset_key = None
         self._dataset_ref = None
         self._n_rows = 0
@@ -457,6 +456,15 @@ class VAE:
         if self.compute_dtype not in ("fp32", "bf16"):
             raise ValueError(f"compute dtype must be 'fp32' or 'bf16', not {self.compute_dtype!r}")
         _lib.check(self._lib.vh_vae_set_precision(self._h, int(self.compute_dtype == "bf16")))
+
+    def _create_handle(self, cfg) -> ctypes.c_void_p:
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.vh_vae_create(ctypes.byref(cfg), ctypes.byref(h)))
+        return h
+
+    def _row_width(self) -> int:
+        """Input (= reconstruction) columns: depths | TNF | total abundance."""
+        return self.nsamples + NTNF + 1
 
     def attach_communicator(self, comm, syncbn: bool = True) -> None:
         """Data-parallel training over ``comm`` (``vamb_amd.parallel.Communicator``): this process holds
@@ -499,7 +507,7 @@ class VAE:
         return names
 
     def _shape_of(self, name: str):
-        d = self.nsamples + NTNF + 1
+        d = self._row_width()
         enc_in = [d] + self.nhiddens[:-1]
         dec_w = self.nhiddens[::-1]
         dec_in = [self.nlatent] + dec_w[:-1]
