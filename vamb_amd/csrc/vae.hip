@@ -159,6 +159,10 @@ struct VaeTuning {
     int dw_workgroups = 256;  // vae.dw_workgroups: workgroups wanted per weight-gradient GEMM (split-K target)
     int pipeline = 2;         // vae.gemm_pipeline: K loop of the bf16 GEMMs.  2 = three LDS buffers, DMA pieces of tile t + 2 issued
                               // between the MFMA groups of tile t; 0 = the round-2 loop (two buffers, tile t + 1 requested up front)
+    int fork_at_loss = 0;     // vae.fork_at_loss: the side stream (running statistics, loss reduction, weight gradients) starts when the
+                              // loss kernel ends instead of after the first BatchNorm-backward kernel of the decoder (one more fork =
+                              // ~5 us on the main stream: 296 vs 286 us per step at C2, profiles/r03zc_fork_at_loss.txt; it only paid
+                              // while the loss reduction on the side stream still took 14 us)
     bool dw_row_major = true; // vae.dw_row_major: bf16 weight gradients contract ROW-major tensors (gemm_bf16_tn.hpp); 0 = the
                               // round-2 dataflow with a transposed bf16 copy of every contracted tensor (A/B measurements)
 } g_tuning;
@@ -168,6 +172,7 @@ void refresh_tuning() {
     g_tuning.xcd_remap = (int)option("vae.xcd_remap", 1);
     g_tuning.dw_workgroups = (int)option("vae.dw_workgroups", 256);
     g_tuning.dw_row_major = option("vae.dw_row_major", 1) != 0;
+    g_tuning.fork_at_loss = (int)option("vae.fork_at_loss", 0);
     g_tuning.pipeline = option("vae.gemm_pipeline", 2) == 0 ? 0 : 2;
 }
 

@@ -93,7 +93,10 @@ __global__ void vae_gather_kernel(const float* __restrict__ X, int64_t ld_src, i
     for (int c = threadIdx.x; c < dq; c += 64) {
         float4 v = z;
         if (real && c < sq) v = s[c];
-        if ((hot >> 2) == c && hot >= 0) (&v.x)[hot & 3] = 1.0f;
+        if ((hot >> 2) == c && hot >= 0) {   // (selects, not an indexed write: the compiler moves an indexed float4 into LDS)
+            const int e = hot & 3;
+            v.x = e == 0 ? 1.0f : v.x; v.y = e == 1 ? 1.0f : v.y; v.z = e == 2 ? 1.0f : v.z; v.w = e == 3 ? 1.0f : v.w;
+        }
         d[c] = v;
     }
     if (threadIdx.x == 0) {
@@ -374,7 +377,7 @@ struct StepState {
 // One workgroup of kLossFinThreads threads.  The loads are 16 bytes wide and issued in batches of four per thread before
 // the first add (the 256-thread scalar version walked 8 + 32 DEPENDENT load round trips per thread: 17 us for 40 KB);
 // fp64 wavefront reductions, one LDS exchange.
-constexpr int kLossFinThreads = 1024;
+constexpr int kLossFinThreads = 512;   // (1024 threads left 128 VGPRs per thread: the seven fp64 sums and the batched loads spilled to scratch)
 __global__ __launch_bounds__(kLossFinThreads) void vae_loss_finalize_kernel(const float* __restrict__ part, int nblocks,
                                                                             const float* __restrict__ Wb, int bs,
                                                                             const float* __restrict__ gwsum, int bs_global,

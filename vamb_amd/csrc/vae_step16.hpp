@@ -431,8 +431,12 @@ void loss_and_seed16(vh_vae* h, SideQueue& q) {
                                    160 * 1024 - 256));
         loss_attr = true;
     }
-    hipLaunchKernelGGL(vae_loss16_kernel, dim3(h->loss_blocks), dim3(256), loss_lds, h->stream, a);
-    VH_HIP(hipGetLastError());
+    if (g_tuning.fork_at_loss) {   // the side stream's first items (see backward16) only need what this kernel leaves
+        launch_forking(h, vae_loss16_kernel, dim3(h->loss_blocks), dim3(256), loss_lds, a);
+    } else {
+        hipLaunchKernelGGL(vae_loss16_kernel, dim3(h->loss_blocks), dim3(256), loss_lds, h->stream, a);
+        VH_HIP(hipGetLastError());
+    }
     // the scalar reduction (loss means, sum of weights) is only needed by the optimiser
     const float* gw = h->gwsum_src;
     const float* lab_part = a.lab_part;
@@ -510,6 +514,9 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
                 grad_weight16(h, h->tWo, h->dR16T.p, h->D_p, last.H16T.p, last.nout_p, st);
             }
         });
+        // running statistics, the loss reduction and the output layer's weight gradient depend on nothing later than the
+        // loss kernel: hand them to the side stream now (forked on that kernel's completion, loss_and_seed16)
+        if (g_tuning.fork_at_loss) q.flush(h->side);
         grad_input16(h, h->dR16.p, h->D_p, h->tWo, last.nout_p, last);
     }
     int latent_slabs = 1;
@@ -546,6 +553,11 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
                 rccl_allreduce_sum_f32(h->comm, h->G.p + h->opt16_bucketA_off, h->flat_elems - h->opt16_bucketA_off, st);
             });
         }
+        // Fork points: the top decoder layer and encoder layer 1 (and layer 0 when something is still queued): each hands
+        // everything queued so far to the side stream (vae.fork_at_loss adds one at the loss kernel, loss_and_seed16).  A fork
+        // costs the main stream ~5 us before its next kernel (the producing kernel's completion signal).  Variants measured at
+        // C2 (profiles/r03w_*, r03zb_*, r03zc_*): these two 286 us per step; + the loss kernel 296; loss + LAST decoder layer +
+        // encoder layer 1 299 against 297 on the box of that run.
         const bool fork = li == 2 * nl - 1 || li == 1 || (li == 0 && !q.items.empty());
         const dim3 grid((unsigned)ceil_div(hl.nout_p, kDz16Cols), (unsigned)ceil_div(bs_p, kDz16Rows));
         if (fork) {
@@ -615,7 +627,8 @@ void optimizer_step16(vh_vae* h) {
 }
 
 void gather_rows16(vh_vae* h, const int64_t* dev_idx, SideQueue& q) {
-    hipLaunchKernelGGL(vae_gather16_kernel, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, h->stream,
+    auto kern = h->kind == VH_VAE_PLAIN ? vae_gather16_kernel<false> : vae_gather16_kernel<true>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, h->stream,
                        (const float*)h->X.p, h->ld_src, (int64_t)h->D_p, (const float*)h->w.p, dev_idx, h->shuffle,
                        (const long long*)&h->state.p->batch, (int64_t)0, h->bs, h->bs_p, h->Xb.p, h->Xb16.p, h->Wb.p,
                        LabelSrc{h->labels, h->lab0}, h->Lb.p);
@@ -657,7 +670,7 @@ void encode16(vh_vae* h, float* latent) {
             hipLaunchKernelGGL(vae_cast16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n4, 256), 4096)), dim3(256), 0, s,
                                h->X.p + (size_t)lo * h->D_p, a1.p, n4);
         } else {   // rows with their one-hot label block, straight to bf16
-            hipLaunchKernelGGL(vae_gather16_kernel, dim3((unsigned)ceil_div(m, 4)), dim3(64, 4), 0, s, (const float*)h->X.p,
+            hipLaunchKernelGGL(vae_gather16_kernel<true>, dim3((unsigned)ceil_div(m, 4)), dim3(64, 4), 0, s, (const float*)h->X.p,
                                h->ld_src, (int64_t)h->D_p, (const float*)h->w.p, (const int64_t*)nullptr, ShuffleSpec{0, 0, 1},
                                (const long long*)nullptr, lo, m, m, (float*)nullptr, a1.p, (float*)nullptr,
                                LabelSrc{h->labels, h->lab0}, (int32_t*)nullptr);
