@@ -937,7 +937,8 @@ void optimizer_step(vh_vae* h) {
 }
 
 void gather_rows(vh_vae* h, const int64_t* dev_idx) {
-    hipLaunchKernelGGL(vae_gather_kernel, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, h->stream, h->X.p,
+    auto kern = h->kind == VH_VAE_PLAIN ? vae_gather_kernel<false> : vae_gather_kernel<true>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, h->stream, h->X.p,
                        h->ld_src, (int64_t)h->D_p, h->w.p, dev_idx, h->shuffle, &h->state.p->batch, (int64_t)0, h->bs,
                        h->bs_p, h->Xb.p, h->Wb.p, LabelSrc{h->labels, h->lab0}, h->Lb.p);
     VH_HIP(hipGetLastError());
@@ -1751,7 +1752,7 @@ int vh_vae_encode(vh_vae* h, float* latent) {
             const int m = (int)std::min<int64_t>(chunk, h->n - lo);
             const float* in = h->X.p + (size_t)lo * h->D_p;
             if (h->kind != VH_VAE_PLAIN) {
-                hipLaunchKernelGGL(vae_gather_kernel, dim3((unsigned)ceil_div(m, 4)), dim3(64, 4), 0, s, h->X.p, h->ld_src,
+                hipLaunchKernelGGL(vae_gather_kernel<true>, dim3((unsigned)ceil_div(m, 4)), dim3(64, 4), 0, s, h->X.p, h->ld_src,
                                    (int64_t)h->D_p, h->w.p, (const int64_t*)nullptr, ShuffleSpec{0, 0, 1},
                                    (const long long*)nullptr, lo, m, m, xin.p, (float*)nullptr, LabelSrc{h->labels, h->lab0},
                                    (int32_t*)nullptr);

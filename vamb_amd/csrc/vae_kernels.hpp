@@ -73,6 +73,8 @@ struct LabelSrc {
 // src(r) = idx[first + r] when an explicit row list is given, else shuffle(first + r); first = base + batch * bs
 // with the batch index read from device memory (advanced by the optimiser's finalize kernel).
 // The dataset row is ld_src wide (0: the dataset has no feature columns), the batch row ldx; Lb[r] = label of the row.
+// LABELS = false: the plain VAE's kernel as it was before the label block existed (see vae_gather16_kernel).
+template <bool LABELS>
 __global__ void vae_gather_kernel(const float* __restrict__ X, int64_t ld_src, int64_t ldx, const float* __restrict__ w_all,
                                   const int64_t* __restrict__ idx, const ShuffleSpec shuffle,
                                   const long long* __restrict__ batch_ptr, int64_t base, int bs, int bs_p,
@@ -84,24 +86,35 @@ __global__ void vae_gather_kernel(const float* __restrict__ X, int64_t ld_src, i
     const int64_t first = base + (batch_ptr ? (int64_t)(*batch_ptr) * bs : 0);
     int64_t src = 0;
     if (real) src = idx ? idx[first + r] : (int64_t)shuffle_index(shuffle, (unsigned long long)(first + r));
-    const float4* s = reinterpret_cast<const float4*>(X + src * ld_src);
     float4* d = reinterpret_cast<float4*>(Xb + (int64_t)r * ldx);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int dq = (int)(ldx / 4), sq = (int)(ld_src / 4);
-    int hot = -1;
-    if (lab.labels && real) hot = lab.col0 + lab.labels[src];
-    for (int c = threadIdx.x; c < dq; c += 64) {
-        float4 v = z;
-        if (real && c < sq) v = s[c];
-        if ((hot >> 2) == c && hot >= 0) {   // (selects, not an indexed write: the compiler moves an indexed float4 into LDS)
-            const int e = hot & 3;
-            v.x = e == 0 ? 1.0f : v.x; v.y = e == 1 ? 1.0f : v.y; v.z = e == 2 ? 1.0f : v.z; v.w = e == 3 ? 1.0f : v.w;
+    const int dq = (int)(ldx / 4);
+    if constexpr (!LABELS) {
+        const float4* s = reinterpret_cast<const float4*>(X + src * ldx);
+        for (int c = threadIdx.x; c < dq; c += 64) {
+            float4 v = z;
+            if (real) v = s[c];
+            d[c] = v;
         }
-        d[c] = v;
-    }
-    if (threadIdx.x == 0) {
-        if (Wb) Wb[r] = real ? w_all[src] : 0.f;
-        if (Lb) Lb[r] = hot >= 0 ? hot - lab.col0 : 0;
+        if (threadIdx.x == 0) Wb[r] = real ? w_all[src] : 0.f;
+    } else {
+        const float4* s = reinterpret_cast<const float4*>(X + src * ld_src);
+        const int sq = (int)(ld_src / 4);
+        int hot = -1;
+        if (lab.labels && real) hot = lab.col0 + lab.labels[src];
+        for (int c = threadIdx.x; c < dq; c += 64) {
+            float4 v = z;
+            if (real && c < sq) v = s[c];
+            if ((hot >> 2) == c && hot >= 0) {   // (selects, not an indexed write: the compiler moves an indexed float4 into LDS)
+                const int e = hot & 3;
+                v.x = e == 0 ? 1.0f : v.x; v.y = e == 1 ? 1.0f : v.y; v.z = e == 2 ? 1.0f : v.z; v.w = e == 3 ? 1.0f : v.w;
+            }
+            d[c] = v;
+        }
+        if (threadIdx.x == 0) {
+            if (Wb) Wb[r] = real ? w_all[src] : 0.f;
+            if (Lb) Lb[r] = hot >= 0 ? hot - lab.col0 : 0;
+        }
     }
 }
 
