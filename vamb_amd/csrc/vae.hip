@@ -163,6 +163,10 @@ struct VaeTuning {
                               // loss kernel ends instead of after the first BatchNorm-backward kernel of the decoder (one more fork =
                               // ~5 us on the main stream: 296 vs 286 us per step at C2, profiles/r03zc_fork_at_loss.txt; it only paid
                               // while the loss reduction on the side stream still took 14 us)
+    bool dz_colsum = true;    // vae.dz_colsum: 1 = the elementwise BatchNorm-backward kernel sums its own output for the bias gradient
+                              // (fp64 atomics from every row block); 0 = the weight-gradient GEMM does it on the way.  Measured at C2
+                              // (profiles/r03zd_dz_colsum.txt): the dz kernel 12.1 -> 10.2 us, the dW GEMMs 16.9 -> 20.4 us, step 291 ->
+                              // 293 us: stays where it was
     bool dw_row_major = true; // vae.dw_row_major: bf16 weight gradients contract ROW-major tensors (gemm_bf16_tn.hpp); 0 = the
                               // round-2 dataflow with a transposed bf16 copy of every contracted tensor (A/B measurements)
 } g_tuning;
@@ -173,6 +177,7 @@ void refresh_tuning() {
     g_tuning.dw_workgroups = (int)option("vae.dw_workgroups", 256);
     g_tuning.dw_row_major = option("vae.dw_row_major", 1) != 0;
     g_tuning.fork_at_loss = (int)option("vae.fork_at_loss", 0);
+    g_tuning.dz_colsum = option("vae.dz_colsum", 1) != 0;
     g_tuning.pipeline = option("vae.gemm_pipeline", 2) == 0 ? 0 : 2;
 }
 

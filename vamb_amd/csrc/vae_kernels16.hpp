@@ -463,9 +463,11 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
         if (a.DZT) *reinterpret_cast<uint4*>(&tile[rl][c8]) = o;
         if (r < a.bs_p && col < a.n_p) *reinterpret_cast<uint4*>(a.DZ + (int64_t)r * a.n_p + col) = o;
     }
+    if (a.dbias) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[rt][c8 + e] = s[e];
-    __syncthreads();
+        for (int e = 0; e < 8; ++e) red[rt][c8 + e] = s[e];
+    }
+    if (a.dbias || a.DZT) __syncthreads();   // (kernel-argument uniform)
     // transposed copy (round-2 dataflow only): chunk = (column c, 8 consecutive rows); lanes of a wave take consecutive columns
 #pragma unroll
     for (int p = 0; p < (a.DZT ? (kDz16Cols * (kDz16Rows / 8)) / 256 : 0); ++p) {
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
             *reinterpret_cast<uint4*>(a.DZT + (int64_t)(col0 + c) * a.ldt + row0 + rg * 8) = v;
         }
     }
-    if (tid < kDz16Cols) {
+    if (a.dbias && tid < kDz16Cols) {
         const int c = col0 + tid;
         float t = 0.f;
 #pragma unroll

@@ -529,13 +529,17 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         a.bstat = hl.bstat;
         a.drop_scale = dc.scale;
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
-        a.dbias = hl.dbias;
         const bool rm = g_tuning.dw_row_major;
+        // bias gradient = column sums of dZ: with row-major weight gradients the dW GEMM of this layer streams dZ anyway and
+        // sums it on the way (COLSUM, a few atomics per column); the elementwise kernel's own sums cost it one fp64 atomic per
+        // column from each of its bs_p / 64 row blocks (vae.dz_colsum = 1: keep them there, A/B)
+        const bool colsum_in_gemm = rm && !g_tuning.dz_colsum;
+        a.dbias = colsum_in_gemm ? nullptr : hl.dbias;
         const bf16_t* InT = rm ? (li == 0 ? h->Xb16.p : (li == nl ? h->Z16.p : h->hidden[li - 1].H16.p))     // row-major input
                                : (li == 0 ? h->Xb16T.p : (li == nl ? h->Z16T.p : h->hidden[li - 1].H16T.p));
         const int in_p = li == 0 ? h->D_p : (li == nl ? h->L_p : h->hidden[li - 1].nout_p);
-        auto dw = [h, &hl, InT, in_p, rm](hipStream_t st) {
-            if (rm) grad_weight16_rm(h, hl.tW, hl.DZ16.p, hl.nout_p, InT, in_p, nullptr, st);
+        auto dw = [h, &hl, InT, in_p, rm, colsum_in_gemm](hipStream_t st) {
+            if (rm) grad_weight16_rm(h, hl.tW, hl.DZ16.p, hl.nout_p, InT, in_p, colsum_in_gemm ? hl.dbias : nullptr, st);
             else grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, st);
         };
         // Fork points: the top decoder layer and encoder layer 1 (and layer 0 when something is still queued): each
