@@ -48,6 +48,7 @@ const char* vh_version(void);
  *   gen.spec_neighbours (1)  ... including the within-radius rows of cached upcoming seeds (their first candidate round)
  *   gen.spec_depth (2)       ... and the within-radius rows of those rows (1: first ring only)
  *   gen.max_entry_age (32)   emissions a cached medoid statistic may outlive (validated lazily against the removal log)
+ *   gen.defer_bookkeeping (1) cache entries of speculative results are built while the next pass runs
  *   vae.single_stream (0)  weight-gradient GEMMs on the main stream
  *   vae.fork_events (0)    forks as event records instead of kernel completion signals
  *   vae.big_tiles (0), vae.xcd_remap (1), vae.dw_workgroups (256), vae.debug_timing (0)

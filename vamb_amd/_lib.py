@@ -180,6 +180,7 @@ _ENV_OPTIONS = {
     "VAMBHIP_SPEC_NEIGHBOURS": ("gen.spec_neighbours", int),
     "VAMBHIP_MAX_ENTRY_AGE": ("gen.max_entry_age", int),
     "VAMBHIP_SPEC_DEPTH": ("gen.spec_depth", int),
+    "VAMBHIP_DEFER_BOOKKEEPING": ("gen.defer_bookkeeping", int),
     "VAMBHIP_SPEC_BIG_TARGET": ("gen.spec_big_target", int),
     "VAMBHIP_BIG_TILES": ("vae.big_tiles", int),
     "VAMBHIP_XCD_REMAP": ("vae.xcd_remap", int),

@@ -1296,7 +1296,8 @@ namespace {
 // Launch one pass for k medoids and wait for its publication; returns the ring slot of the results.
 // The accumulators were zeroed by the publish kernel of the previous pass, the medoid rows travel in the
 // kernel arguments and the query vectors are gathered by the scan kernel itself.
-int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries, bool sharded = false) {
+int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries, bool sharded = false,
+              const std::function<void()>* while_waiting = nullptr) {
     VH_REQUIRE(h != nullptr && medoid_rows != nullptr, "NULL argument");
     VH_REQUIRE(!sharded || (h->comm != nullptr && queries == nullptr), "sharded scan needs vh_clu_attach_comm and no explicit queries");
     VH_REQUIRE(k >= 1 && k <= h->max_k, "k=%d outside [1, %d] (vh_clu_max_medoids)", k, h->max_k);
@@ -1342,6 +1343,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
     hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, h->mfma_pass ? k : km, h->results.p,
                        h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1), h->scan_dbg);
     VH_HIP(hipGetLastError());
+    if (while_waiting) (*while_waiting)();   // host work that does not depend on this pass, under the pass
     wait_for_scan(h, h->scan_seq + 1);
     if (h->timer.enabled) {
         VH_HIP(hipStreamSynchronize(h->stream));
@@ -1795,6 +1797,12 @@ struct vh_gen {
     std::deque<bool> attempts;
     int successes = 0;
     std::unordered_map<int64_t, GenStats> stats;
+    // speculative results of the last pass that have not been turned into `stats` entries yet: that host work (a copy of the
+    // row, of its list, a map insert per medoid; 1.2 s of a C2 sweep) runs while the GPU executes the NEXT pass, or at once for
+    // an entry somebody asks for
+    struct Pending { int64_t row; int slot; int j; uint64_t seq; int64_t born; };
+    std::vector<Pending> pending;
+    bool defer_book = true;         // option gen.defer_bookkeeping
     // Removal log: one record per emitted cluster (index = emission count at the time), the rows it removed by ORIGINAL index.
     // Cached statistics are validated against it lazily, when they are looked at (gen_lookup), instead of eagerly at every
     // emission.
@@ -1818,7 +1826,7 @@ struct vh_gen {
     int spec_window = kSpecWindow;
     int64_t max_entry_age = kMaxEntryAgeDefault;   // option gen.max_entry_age
     int spec_depth = 2;             // option gen.spec_depth: 1 = within-radius rows of upcoming seeds, 2 = also THEIR within-radius rows
-    double t_validate = 0, t_fill = 0, t_book = 0, t_emit = 0;   // profile: lazy validation, speculative fill, post-scan bookkeeping, emission
+    double t_validate = 0, t_fill = 0, t_book = 0, t_emit = 0, t_book_hidden = 0;   // profile: lazy validation, speculative fill, post-scan bookkeeping, emission
     bool spec_neighbours = true;   // option gen.spec_neighbours: within-radius rows of cached upcoming seeds are scanned ahead too
     int spec_big_target = 0;      // experiment: widening target of passes over matrices above 600 k rows (0 = bucket fill)
     // optional wall-clock breakdown (VAMBHIP_GEN_PROFILE=1): scan calls, select calls, seed walk, logical index
@@ -1886,7 +1894,64 @@ bool gen_touched_since(vh_gen* g, const float* vm, int64_t from, bool far) {
 // (sample_medoid is pure, cluster.py:606-637), so an entry is exact as long as no row removed since its scan lies within the
 // radius of its row.  The reference clears its cache at every emission (cluster.py:298-316); here every entry is checked
 // against the removal log when it is looked at, once per emission it has not seen yet.
+GenStats* gen_lookup(vh_gen* g, int64_t row);
+// The cached entry of one scanned medoid (from the pass's summary, its ring slot and the host copy of the row)
+GenStats& gen_materialise(vh_gen* g, int64_t row, int slot, int j, uint64_t seq, int64_t born, bool spec) {
+    const std::vector<unsigned long long>& sm = g->clu->last_summary[slot];
+    GenStats& st = g->stats[row];
+    // the python float the reference gets from `.sum().item()` on a float32 tensor (cluster.py:629)
+    st.density = (double)(float)((double)(int64_t)sm[4 * j] / VH_DENSITY_SCALE);
+    st.n_within = (int64_t)sm[4 * j + 1];
+    st.n_lt = (int64_t)sm[4 * j + 2];
+    st.have_hist = false;
+    // histogram and candidate list stay in the host-mapped ring; they are fetched only for the few
+    // medoids that need them (host reads of that memory are slow: one bulk copy, on demand)
+    st.seq = seq;
+    st.slot_j = j;
+    st.list_count = g->clu->last_counts[slot][j];
+    st.have_list = false;
+    st.within.clear();
+    st.spec = spec;
+    st.born = st.checked = st.hist_checked = born;
+    st.hist_stale = false;
+    {   // the row itself, for the validity checks of the emissions to come
+        const float* v = g->clu->host_rows.data() + (size_t)g->indices[(size_t)row] * g->clu->L;
+        st.vec.assign(v, v + g->clu->L);
+    }
+    if (spec) {
+        g->spec_scanned++;
+        // an entry scanned ahead may be used after its scan has left the ring, and its list names the rows to scan
+        // ahead next (gen_speculative_fill): keep it now if it is short
+        if (st.list_count <= (unsigned int)kKeepList) {
+            const int32_t* src = g->clu->lists + ((size_t)slot * kMaxMedoids + j) * kListCap;
+            st.within.assign(src, src + st.list_count);
+            std::sort(st.within.begin(), st.within.end());
+            st.have_list = true;
+        }
+    }
+    return st;
+}
+
+void gen_flush_pending(vh_gen* g) {
+    for (const vh_gen::Pending& p : g->pending) gen_materialise(g, p.row, p.slot, p.j, p.seq, p.born, true);
+    g->pending.clear();
+}
+
+bool gen_is_pending(const vh_gen* g, int64_t row) {
+    for (const vh_gen::Pending& p : g->pending)
+        if (p.row == row) return true;
+    return false;
+}
+
 GenStats* gen_lookup(vh_gen* g, int64_t row) {
+    for (size_t i = 0; i < g->pending.size(); ++i) {   // scanned by the last pass, not turned into an entry yet
+        if (g->pending[i].row != row) continue;
+        const vh_gen::Pending p = g->pending[i];
+        g->pending[i] = g->pending.back();
+        g->pending.pop_back();
+        gen_materialise(g, p.row, p.slot, p.j, p.seq, p.born, true);
+        break;
+    }
     const auto it = g->stats.find(row);
     if (it == g->stats.end()) return nullptr;
     GenStats& st = it->second;
@@ -1954,7 +2019,7 @@ void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& ex
     // the pools of those candidates (where the climb can move to)
     if (!g->spec_neighbours) return;
     auto absent = [&](int64_t r) {   // (presence only: a stale entry is simply not refreshed ahead of time)
-        return g->stats.count(r) == 0 && std::find(exclude.begin(), exclude.end(), r) == exclude.end() &&
+        return g->stats.count(r) == 0 && !gen_is_pending(g, r) && std::find(exclude.begin(), exclude.end(), r) == exclude.end() &&
                std::find(out.begin(), out.end(), r) == out.end();
     };
     for (int depth = 1; depth <= g->spec_depth; ++depth) {
@@ -2022,7 +2087,11 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         {
             GenTimer t(&g->t_scan);
             GenTimer t2(&g->t_km[k]);
-            slot = scan_core(g->clu, k, missing.data() + lo, nullptr);
+            const std::function<void()> under_the_pass = [g] {
+                GenTimer th(&g->t_book_hidden);
+                gen_flush_pending(g);
+            };
+            slot = scan_core(g->clu, k, missing.data() + lo, nullptr, false, &under_the_pass);
         }
         g->n_km[k]++;
         g->rows_km[k] += g->clu->n_rows;
@@ -2032,39 +2101,13 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         g->rows_streamed += g->clu->n_rows;
         g->live_rows_streamed += g->clu->n_live;
         gen_collect_ms(g);
-        const std::vector<unsigned long long>& sm = g->clu->last_summary[slot];
         GenTimer tb(&g->t_book);
         for (int j = 0; j < k; ++j) {
-            GenStats& st = g->stats[missing[lo + j]];
-            // the python float the reference gets from `.sum().item()` on a float32 tensor (cluster.py:629)
-            st.density = (double)(float)((double)(int64_t)sm[4 * j] / VH_DENSITY_SCALE);
-            st.n_within = (int64_t)sm[4 * j + 1];
-            st.n_lt = (int64_t)sm[4 * j + 2];
-            st.have_hist = false;
-            // histogram and candidate list stay in the host-mapped ring; they are fetched only for the few
-            // medoids that need them (host reads of that memory are slow: one bulk copy, on demand)
-            st.seq = seq;
-            st.slot_j = j;
-            st.list_count = g->clu->last_counts[slot][j];
-            st.have_list = false;
-            st.spec = lo + (size_t)j >= n_needed;
-            st.born = st.checked = st.hist_checked = g->n_emitted;
-            st.hist_stale = false;
-            {   // the row itself, for the validity checks of the emissions to come
-                const float* v = g->clu->host_rows.data() + (size_t)g->indices[(size_t)missing[lo + j]] * g->clu->L;
-                st.vec.assign(v, v + g->clu->L);
-            }
-            if (st.spec) {
-                g->spec_scanned++;
-                // an entry scanned ahead may be used after its scan has left the ring, and its list names the rows to scan
-                // ahead next (gen_speculative_fill): keep it now if it is short
-                if (st.list_count <= (unsigned int)kKeepList) {
-                    const int32_t* src = g->clu->lists + ((size_t)slot * kMaxMedoids + j) * kListCap;
-                    st.within.assign(src, src + st.list_count);
-                    std::sort(st.within.begin(), st.within.end());
-                    st.have_list = true;
-                }
-            }
+            const bool spec = lo + (size_t)j >= n_needed;
+            // what the caller asked for becomes an entry now; what was scanned ahead waits for the next pass (gen_lookup
+            // materialises the ones that are wanted before that)
+            if (spec && g->defer_book) g->pending.push_back(vh_gen::Pending{missing[lo + j], slot, j, seq, g->n_emitted});
+            else gen_materialise(g, missing[lo + j], slot, j, seq, g->n_emitted, spec);
         }
     }
 }
@@ -2200,7 +2243,11 @@ void gen_fetch_hist(vh_gen* g, int64_t medoid, GenStats& st) {
         const uint64_t seq = g->clu->scan_seq;
         {
             GenTimer t(&g->t_scan);
-            (void)scan_core(g->clu, 1, &medoid, nullptr);
+            const std::function<void()> under_the_pass = [g] {   // (entries are never moved by an insert: `st` stays valid)
+                GenTimer th(&g->t_book_hidden);
+                gen_flush_pending(g);
+            };
+            (void)scan_core(g->clu, 1, &medoid, nullptr, false, &under_the_pass);
         }
         g->scan_passes++;
         g->pass_hist++;
@@ -2320,6 +2367,7 @@ int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, in
         g->spec_neighbours = option("gen.spec_neighbours", 1) != 0;
         g->max_entry_age = option("gen.max_entry_age", kMaxEntryAgeDefault);
         g->spec_depth = (int)option("gen.spec_depth", 2);
+        g->defer_book = option("gen.defer_bookkeeping", 1) != 0;
         g->spec_big_target = (int)option("gen.spec_big_target", 0);
         g->order.assign(order, order + n);
         g->indices.resize((size_t)n);
@@ -2341,7 +2389,7 @@ int vh_gen_destroy(vh_gen* g) {
                 (long long)g->scan_medoids, (long long)g->spec_scanned, (long long)g->spec_used, (long long)g->spec_dropped);
     if (g && g->profile) {
         fprintf(stderr, "[vambhip]   host time inside 'rest': lazy validation %.1f ms (part of it inside the fill), speculative fill %.1f ms, "
-                "post-scan bookkeeping %.1f ms, removal log + eviction %.1f ms\n", g->t_validate, g->t_fill, g->t_book, g->t_emit);
+                "post-scan bookkeeping %.1f ms (+ %.1f ms under the next pass), removal log + eviction %.1f ms\n", g->t_validate, g->t_fill, g->t_book, g->t_book_hidden, g->t_emit);
         fprintf(stderr, "[vambhip]   passes by purpose: seed scans %lld, candidate rounds %lld, histogram re-scans %lld, selects %lld (+ %lld list selects); "
                 "seeds %lld (cached at arrival %lld), candidate rounds %lld (fully cached %lld, %lld candidates to scan), medoid moves %lld; "
                 "cached entries per emission %.1f; lazy validations %lld (%lld cluster tests, %lld row tests, %lld invalid), histograms reused %lld\n",
@@ -2465,6 +2513,7 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
             int64_t new_n = 0;
             gen_check(vh_clu_pack(g->clu, &new_n));
             g->stats.clear();   // physical row numbers change
+            g->pending.clear();
             size_t w = 0;
             for (size_t r = 0; r < g->kept.size(); ++r)
                 if (g->kept[r]) g->indices[w++] = g->indices[r];
