@@ -80,6 +80,41 @@ def test_semisupervised_classes_mirror_the_reference():
     assert ss.VAELabels is theirs
 
 
+@pytest.mark.skipif(not ref_harness.reference_available(), reason="reference tree not present")
+def test_semisupervised_loaders_yield_the_reference_batches():
+    """make_dataloader_concat / make_dataloader_labels (semisupervised_encode.py:111-175): same dataset tensors, same one-hot
+    batches from the collate functions, same batch size / drop_last as the reference's loaders on the same inputs."""
+    import numpy as np
+    import torch
+
+    ss = ref_harness.load_reference_module("semisupervised_encode")
+    from vamb_amd import encode as ve, semisupervised_encode as vs, synth
+
+    ab, tnf, lens, genome = synth.features(300, 5, seed=11, k=7)
+    labels = np.array([f"g{int(i)}" for i in genome])
+    ve.set_prep_mode("host")
+    try:
+        ours = vs.make_dataloader_concat(ab.copy(), tnf.copy(), lens, labels, batchsize=64)
+    finally:
+        ve.set_prep_mode("auto")
+    theirs = ss.make_dataloader_concat(ab.copy(), tnf.copy(), lens, labels, batchsize=64)
+    assert ours.batch_size == theirs.batch_size and ours.drop_last == theirs.drop_last
+    for a, b in zip(ours.dataset.tensors, theirs.dataset.tensors):
+        assert torch.equal(a, b)
+    rows = [ours.dataset[i] for i in range(10)]
+    got, want = ours.collate_fn(rows), theirs.collate_fn([theirs.dataset[i] for i in range(10)])
+    assert len(got) == len(want) == 5
+    for a, b in zip(got, want):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    assert got[4].shape == (10, 105)
+    ours_l = vs.make_dataloader_labels(ab, tnf, lens, labels, batchsize=64)
+    theirs_l = ss.make_dataloader_labels(ab.copy(), tnf.copy(), lens, labels, batchsize=64)
+    assert torch.equal(ours_l.dataset.tensors[0], theirs_l.dataset.tensors[0])
+    a = ours_l.collate_fn([ours_l.dataset[i] for i in range(7)])
+    b = theirs_l.collate_fn([theirs_l.dataset[i] for i in range(7)])
+    assert len(a) == len(b) == 1 and torch.equal(a[0], b[0])
+
+
 @pytest.mark.reference
 def test_state_dict_spec_matches_reference():
     """The names, order and shapes our VAE.state_dict()/save() writes (VAE._state_names / _shape_of) are exactly those

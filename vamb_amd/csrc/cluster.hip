@@ -1802,6 +1802,7 @@ struct vh_gen {
     // an entry somebody asks for
     struct Pending { int64_t row; int slot; int j; uint64_t seq; int64_t born; };
     std::vector<Pending> pending;
+    std::vector<uint8_t> pending_mark;   // [current rows]: 1 while the row is in `pending`
     bool defer_book = true;         // option gen.defer_bookkeeping
     // Removal log: one record per emitted cluster (index = emission count at the time), the rows it removed by ORIGINAL index.
     // Cached statistics are validated against it lazily, when they are looked at (gen_lookup), instead of eagerly at every
@@ -1933,24 +1934,28 @@ GenStats& gen_materialise(vh_gen* g, int64_t row, int slot, int j, uint64_t seq,
 }
 
 void gen_flush_pending(vh_gen* g) {
-    for (const vh_gen::Pending& p : g->pending) gen_materialise(g, p.row, p.slot, p.j, p.seq, p.born, true);
+    for (const vh_gen::Pending& p : g->pending) {
+        g->pending_mark[(size_t)p.row] = 0;
+        gen_materialise(g, p.row, p.slot, p.j, p.seq, p.born, true);
+    }
     g->pending.clear();
 }
 
 bool gen_is_pending(const vh_gen* g, int64_t row) {
-    for (const vh_gen::Pending& p : g->pending)
-        if (p.row == row) return true;
-    return false;
+    return (size_t)row < g->pending_mark.size() && g->pending_mark[(size_t)row] != 0;
 }
 
 GenStats* gen_lookup(vh_gen* g, int64_t row) {
-    for (size_t i = 0; i < g->pending.size(); ++i) {   // scanned by the last pass, not turned into an entry yet
-        if (g->pending[i].row != row) continue;
-        const vh_gen::Pending p = g->pending[i];
-        g->pending[i] = g->pending.back();
-        g->pending.pop_back();
-        gen_materialise(g, p.row, p.slot, p.j, p.seq, p.born, true);
-        break;
+    if (gen_is_pending(g, row)) {   // scanned by the last pass, not turned into an entry yet
+        for (size_t i = 0; i < g->pending.size(); ++i) {
+            if (g->pending[i].row != row) continue;
+            const vh_gen::Pending p = g->pending[i];
+            g->pending[i] = g->pending.back();
+            g->pending.pop_back();
+            g->pending_mark[(size_t)row] = 0;
+            gen_materialise(g, p.row, p.slot, p.j, p.seq, p.born, true);
+            break;
+        }
     }
     const auto it = g->stats.find(row);
     if (it == g->stats.end()) return nullptr;
@@ -2106,7 +2111,11 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
             const bool spec = lo + (size_t)j >= n_needed;
             // what the caller asked for becomes an entry now; what was scanned ahead waits for the next pass (gen_lookup
             // materialises the ones that are wanted before that)
-            if (spec && g->defer_book) g->pending.push_back(vh_gen::Pending{missing[lo + j], slot, j, seq, g->n_emitted});
+            if (spec && g->defer_book) {
+                if (g->pending_mark.size() < g->kept.size()) g->pending_mark.assign(g->kept.size(), 0);
+                g->pending_mark[(size_t)missing[lo + j]] = 1;
+                g->pending.push_back(vh_gen::Pending{missing[lo + j], slot, j, seq, g->n_emitted});
+            }
             else gen_materialise(g, missing[lo + j], slot, j, seq, g->n_emitted, spec);
         }
     }
@@ -2514,6 +2523,7 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
             gen_check(vh_clu_pack(g->clu, &new_n));
             g->stats.clear();   // physical row numbers change
             g->pending.clear();
+            g->pending_mark.assign(g->pending_mark.size(), 0);
             size_t w = 0;
             for (size_t r = 0; r < g->kept.size(); ++r)
                 if (g->kept[r]) g->indices[w++] = g->indices[r];
