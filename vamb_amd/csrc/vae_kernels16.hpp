@@ -268,7 +268,9 @@ struct Loss16Args {
     float* lab_part;
 };
 
-__global__ __launch_bounds__(256) void vae_loss16_kernel(const Loss16Args a) {
+// 8 waves per SIMD: the compiler's own choice was 95 VGPRs (5 waves per SIMD, 1280 of the 2048 workgroups of a batch of 8192
+// resident at once); with 50 VGPRs every row's wavefront is resident from the start: 14.4 -> 12.8 us (profiles/r03zf_*)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void vae_loss16_kernel(const Loss16Args a) {
     // dynamic LDS: per wave the reconstruction row and the target row, read from HBM once with 16-byte loads (the
     // softmax / CE / SSE passes below re-read them four times)
     extern __shared__ __attribute__((aligned(16))) float loss_rows[];   // [4 waves][2][ld]
@@ -393,7 +395,7 @@ struct Dz16Args {
 // (Two register-transposing variants without LDS -- a thread owning an 8 x 8 block, 128 x 128 tiles with 4 waves or
 // 64 x 64 tiles with one wave -- measured 18 and 37 us against 13.7 us for this kernel at 8192 x 512: profiles/README.md.)
 constexpr int kDz16Cols = 128;
-constexpr int kDz16Rows = 64;
+constexpr int kDz16Rows = 64;   // (32-row tiles, twice the workgroups: the same 12.1 us per launch at C2, profiles/r03zg_*)
 
 __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
     __shared__ __attribute__((aligned(16))) bf16_t tile[kDz16Rows][kDz16Cols + 8];
