@@ -54,6 +54,8 @@ const char* vh_version(void);
  *   vae.big_tiles (0), vae.xcd_remap (1), vae.dw_workgroups (256), vae.debug_timing (0)
  *   vae.gemm_pipeline (2)  K loop of the bf16 GEMMs: 2 = three LDS buffers, DMA issue interleaved with the MFMAs; 0 = two buffers
  *   vae.dw_row_major (1)   bf16 weight gradients contract row-major tensors (transposing LDS reads); 0 = transposed bf16 copies
+ *   vae.fork_at_loss (0)   the side stream also forks at the loss kernel (one more fork: measured slower)
+ *   vae.dz_colsum (1)      bias-gradient column sums in the BatchNorm-backward kernel; 0 = inside the weight-gradient GEMM (measured slower)
  * String options: comm.rccl_library (path of librccl), comm.rocm_path (default /opt/rocm). */
 int vh_set_option(const char* name, int64_t value);
 int vh_unset_option(const char* name);
