@@ -396,22 +396,27 @@ def test_step_scheduling_variants_are_bit_identical(dtype, monkeypatch):
     n, S = 5000, 6
     ab, tnf, lens, _ = synth.features(n, S, seed=11)
     states = []
-    for plain in (True, False):
-        for var in ("VAMBHIP_FORK_EVENTS", "VAMBHIP_SINGLE_STREAM"):
+    knobs = ("VAMBHIP_FORK_EVENTS", "VAMBHIP_SINGLE_STREAM", "VAMBHIP_VAE_OPT_SPLIT", "VAMBHIP_VAE_FORK_AT_LOSS")
+    # one stream + event-record forks; the defaults; half of the optimiser on the side stream during the backward; one more fork
+    for setting in ({"VAMBHIP_FORK_EVENTS": "1", "VAMBHIP_SINGLE_STREAM": "1"}, {}, {"VAMBHIP_VAE_OPT_SPLIT": "1"},
+                    {"VAMBHIP_VAE_FORK_AT_LOSS": "1"}):
+        for var in knobs:
             monkeypatch.delenv(var, raising=False)
-        if plain:
-            monkeypatch.setenv("VAMBHIP_FORK_EVENTS", "1")
-            monkeypatch.setenv("VAMBHIP_SINGLE_STREAM", "1")
+        for var, val in setting.items():
+            monkeypatch.setenv(var, val)
         dl = ve.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=512, destroy=True)
         vae = ve.VAE(S, seed=4)
         vae.trainmodel(dl, nepochs=4, batchsteps=[2])
         sd = {k: v.numpy().copy() for k, v in vae.state_dict().items()}
         states.append((sd, vae.optimizer_state(), vae.encode(dl)))
-    (a, oa, la), (b, ob, lb) = states
-    assert oa == ob
-    for k in a:
-        assert np.array_equal(a[k], b[k]), k
-    assert np.array_equal(la, lb)
+    for var in knobs:
+        monkeypatch.delenv(var, raising=False)
+    a, oa, la = states[0]
+    for b, ob, lb in states[1:]:
+        assert oa == ob
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(la, lb)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

@@ -192,6 +192,7 @@ _ENV_OPTIONS = {
     "VAMBHIP_VAE_DW_ROW_MAJOR": ("vae.dw_row_major", int),
     "VAMBHIP_VAE_FORK_AT_LOSS": ("vae.fork_at_loss", int),
     "VAMBHIP_VAE_DZ_COLSUM": ("vae.dz_colsum", int),
+    "VAMBHIP_VAE_OPT_SPLIT": ("vae.opt_split", int),
 }
 _ENV_STRING_OPTIONS = {"VAMBHIP_RCCL": "comm.rccl_library", "ROCM_PATH": "comm.rocm_path"}
 _explicit_options: dict = {}

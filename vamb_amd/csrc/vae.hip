@@ -163,6 +163,10 @@ struct VaeTuning {
                               // loss kernel ends instead of after the first BatchNorm-backward kernel of the decoder (one more fork =
                               // ~5 us on the main stream: 296 vs 286 us per step at C2, profiles/r03zc_fork_at_loss.txt; it only paid
                               // while the loss reduction on the side stream still took 14 us)
+    bool opt_split = false;   // vae.opt_split: bf16 step, one GPU: the optimiser's decoder-side half runs on the side stream during the
+                              // encoder's backward instead of at the end of the step.  Bit-identical, but measured SLOWER at C2 (300 vs
+                              // 290 us per step, profiles/r03zj_opt_split.txt): the update streams 30 MB of gradient slabs and moments
+                              // against the main stream's GEMMs
     bool dz_colsum = true;    // vae.dz_colsum: 1 = the elementwise BatchNorm-backward kernel sums its own output for the bias gradient
                               // (fp64 atomics from every row block); 0 = the weight-gradient GEMM does it on the way.  Measured at C2
                               // (profiles/r03zd_dz_colsum.txt): the dz kernel 12.1 -> 10.2 us, the dW GEMMs 16.9 -> 20.4 us, step 291 ->
@@ -178,6 +182,7 @@ void refresh_tuning() {
     g_tuning.dw_row_major = option("vae.dw_row_major", 1) != 0;
     g_tuning.fork_at_loss = (int)option("vae.fork_at_loss", 0);
     g_tuning.dz_colsum = option("vae.dz_colsum", 1) != 0;
+    g_tuning.opt_split = option("vae.opt_split", 0) != 0;
     g_tuning.pipeline = option("vae.gemm_pipeline", 2) == 0 ? 0 : 2;
 }
 
@@ -269,6 +274,7 @@ struct vh_vae {
     // data parallelism (one process per GPU; gradients all-reduced over RCCL on `stream`)
     vh_comm* comm = nullptr;
     bool syncbn = true;              // BatchNorm batch statistics over the ALL-RANK batch (reference semantics, encode.py:238,246)
+    bool opt16_decoder_done = false; // bf16 step: the decoder-side tensors were updated on the side stream during this step's backward
     int opt16_bucketA_blk0 = 0;      // bf16 step: first optimiser workgroup / flat offset of the decoder-side tensors
     size_t opt16_bucketA_off = 0;    // (gradient bucket that is all-reduced while the encoder's backward still runs)
     DevBuf<float> G, gwsum;          // flat gradient buffer; per-batch global weight sums

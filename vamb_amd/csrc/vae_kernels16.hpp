@@ -606,10 +606,10 @@ __global__ __launch_bounds__(256) void vae_dadapt16_kernel(const Opt16Tensor* __
                                                            float* __restrict__ P, float* __restrict__ M1,
                                                            float* __restrict__ M2, float* __restrict__ Sv,
                                                            const StepState* __restrict__ st,
-                                                           double* __restrict__ partials, float adam_lr) {
+                                                           double* __restrict__ partials, float adam_lr, int blk0) {
     __shared__ double red[2][4];
     __shared__ bf16_t wt[32][32 + 2];
-    const int blk = blockIdx.x;
+    const int blk = (int)blockIdx.x + blk0;   // the launch covers the table's workgroups [blk0, blk0 + gridDim.x)
     int t = 0;
     while (t + 1 < ntensors && blk >= tab[t + 1].blk_start) ++t;
     const Opt16Tensor td = tab[t];

@@ -546,6 +546,21 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         // hands everything queued so far to the side stream.  The first layer's weight gradient is the end of the
         // chain -- nothing is left on the main stream for it to hide behind -- so it runs there.
         if (li > 0) q.add(dw);
+        if (li == nl && !h->comm && nl >= 2 && g_tuning.opt_split) {
+            // Every decoder-side gradient is queued now (output layer, decoder layers; their bias / gamma / beta sums are
+            // complete on the main stream).  The update of those tensors -- half of the parameters -- does not need this
+            // step's D-Adapt reductions (it steps with the d of the previous step), so it runs on the side stream under the
+            // encoder's backward instead of at the end of the step.  The batch is handed over at encoder layer 1's fork: by
+            // then the main stream has read the decoder's weights for the last time (nl >= 2).
+            q.add([h](hipStream_t st) {
+                const int nb = h->opt16_blocks - h->opt16_bucketA_blk0;
+                hipLaunchKernelGGL(vae_dadapt16_kernel, dim3(nb), dim3(256), 0, st, (const Opt16Tensor*)h->opt16_tab.p, h->opt16_n,
+                                   stat_bs(h), h->P.p, h->M1.p, h->M2.p, h->Sv.p, (const StepState*)h->state.p, h->opt_part.p,
+                                   h->adam_lr, h->opt16_bucketA_blk0);
+                VH_HIP(hipGetLastError());
+            });
+            h->opt16_decoder_done = true;
+        }
         if (li == nl && h->comm) {
             // data parallel: every decoder-side gradient is now queued -- materialise that bucket of the flat gradient and
             // all-reduce it on the side stream while the encoder's backward still runs on the main stream
@@ -621,8 +636,11 @@ void optimizer_step16(vh_vae* h) {
         rccl_allreduce_sum_f32(h->comm, h->G.p, h->opt16_bucketA_off, h->stream);
         tab = h->opt16_tab_flat.p;
     }
-    hipLaunchKernelGGL(vae_dadapt16_kernel, dim3(h->opt16_blocks), dim3(256), 0, h->stream, tab, h->opt16_n, stat_bs(h), h->P.p,
-                       h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p, h->adam_lr);
+    // (the decoder-side half may already have been updated on the side stream: backward16)
+    const int nblk = h->opt16_decoder_done ? h->opt16_bucketA_blk0 : h->opt16_blocks;
+    h->opt16_decoder_done = false;
+    hipLaunchKernelGGL(vae_dadapt16_kernel, dim3(nblk), dim3(256), 0, h->stream, tab, h->opt16_n, stat_bs(h), h->P.p,
+                       h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p, h->adam_lr, 0);
     VH_HIP(hipGetLastError());
     hipLaunchKernelGGL(vae_dadapt_finalize_kernel, dim3(1), dim3(256), 0, h->stream, h->opt_part.p, h->opt16_blocks,
                        h->state.p, h->statbuf.p, h->keep_grads ? 0 : (int)h->statbuf.n, h->adam_lr > 0.f ? 1 : 0);
