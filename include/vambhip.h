@@ -39,6 +39,9 @@ const char* vh_version(void);
  * variables (the Python layer forwards its VAMBHIP_* variables through these calls, vamb_amd/_lib.py).  Integer options:
  *   scan.column_loop (1)   0: runtime-width column loop in every scan kernel; 1: unrolled loads up to 8 medoids
  *   scan.mfma (1)          passes with more than 8 medoids on the matrix-pipe kernel
+ *   scan.reference_order (0)  distances and row normalisation in the evaluation order of the reference's torch / oneMKL AVX-512
+ *                          CPU build (measured: oracle/probe_reference_order.py) instead of the ascending fmaf chain: the cluster
+ *                          stream then equals the reference's own on every golden fixture; a plain scan kernel, not the tuned ones
  *   scan.wide_rows (0)     fixed 4 / 2 rows per lane (no narrow variants for small matrices)
  *   scan.min_blocks (768)  workgroups wanted before lanes take more than one row (measured neutral between 384 and 1536)
  *   scan.debug (0)         timing experiments only (wrong results): 1 no pair of interest, 2 no histogram, 4 no flush,

@@ -54,6 +54,8 @@ def lib():
         L = ctypes.CDLL(path)
         i64, vp, f32 = ctypes.c_int64, ctypes.c_void_p, ctypes.c_float
         L.vo_normalize.argtypes = [vp, i64, ctypes.c_int]
+        L.vo_set_order.argtypes = [ctypes.c_int]
+        L.vo_get_order.restype = ctypes.c_int
         L.vo_distances.argtypes = [vp, i64, ctypes.c_int, i64, vp]
         L.vo_scan.argtypes = [vp, vp, vp, i64, ctypes.c_int, i64, vp, vp, vp, vp, vp, vp, i64]
         L.vo_select.argtypes = [vp, vp, i64, ctypes.c_int, i64, f32, vp, i64]
@@ -72,6 +74,17 @@ def lib():
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def set_order(order: int) -> None:
+    """0: the ascending fmaf chain (default; what the HIP kernels compute), 1: the evaluation order of the reference's own
+    torch CPU build for `matmul` and `norm` (cluster_scan.c header) -- distances and normalisation then equal the real
+    reference's bit for bit."""
+    lib().vo_set_order(int(order))
+
+
+def get_order() -> int:
+    return int(lib().vo_get_order())
 
 
 def normalize(matrix: np.ndarray) -> np.ndarray:

@@ -19,6 +19,18 @@
  *              torch.linspace produces it (== torch.histogram's searchsorted-right-minus-one rule)
  * The reference sums density / histogram in fp32 in an unspecified (MKL / vectorised) order; the
  * integer accumulation here is the correctly rounded version of the same sum.
+ *
+ * vo_set_order(1) -- the REFERENCE's own order, measured (round 3; oracle/probe_reference_order.py): the evaluation order of
+ * `matrix.matmul(matrix[index])` and of `matrix.norm(dim=1)` on the torch 2.10 / oneMKL 2024.2 / AVX-512 CPU build of this
+ * container, identified by probing which partial sums meet first and then confirmed bit for bit on 10^5-row random matrices for
+ * every latent width from 1 to 257, 1 and 8 threads:
+ *   dot(i)   : s = a0 x0;  16 lanes {s, 0, ...}; every full block of 16 columns from column 1 on is accumulated lane-wise with
+ *              fma; halving tree (p + 8, p + 4, p + 2, p + 1); the (L - 1) % 16 remaining columns form one more 16-lane block
+ *              whose lane 0 starts from the running sum, reduced by the same tree
+ *   norm(i)  : 8 lanes accumulated with fma over full blocks of 8 columns, lanes summed 0..7 in order; of the L % 8 remaining
+ *              columns the first four (if there are four) add their rounded squares one by one, the last <= 3 are fused
+ *              multiply-adds; sqrtf;  row / (norm * 1.41421354f)
+ * With this order the defined arithmetic IS the reference's arithmetic for distances and normalisation on that build.
  */
 #include <math.h>
 #include <stdint.h>
@@ -68,6 +80,56 @@ int vo_bin(float d) {
     return b;
 }
 
+static int g_order = 0;   /* 0: ascending fmaf chain (the HIP kernels' default), 1: the reference build's order (see header) */
+void vo_set_order(int order) { g_order = order; }
+int vo_get_order(void) { return g_order; }
+
+static inline float tree16(const float* v) {
+    float a[8], b[4], c[2];
+    for (int p = 0; p < 8; ++p) a[p] = v[p] + v[p + 8];
+    for (int p = 0; p < 4; ++p) b[p] = a[p] + a[p + 4];
+    for (int p = 0; p < 2; ++p) c[p] = b[p] + b[p + 2];
+    return c[0] + c[1];
+}
+
+/* <row, q> as torch CPU (oneMKL sgemv, AVX-512) evaluates it */
+static inline float dot_ref(const float* row, const float* q, int L) {
+    float s = row[0] * q[0];
+    const int nfull = (L - 1) / 16, rem = (L - 1) % 16;
+    int k = 1;
+    float acc[16];
+    if (nfull) {
+        acc[0] = s;
+        for (int p = 1; p < 16; ++p) acc[p] = 0.0f;
+        for (int b = 0; b < nfull; ++b, k += 16)
+            for (int p = 0; p < 16; ++p) acc[p] = fmaf(row[k + p], q[k + p], acc[p]);
+        s = tree16(acc);
+    }
+    if (rem) {
+        acc[0] = s;
+        for (int p = 1; p < 16; ++p) acc[p] = 0.0f;
+        for (int p = 0; p < rem; ++p) acc[p] = fmaf(row[k + p], q[k + p], acc[p]);
+        s = tree16(acc);
+    }
+    return s;
+}
+
+/* ||row|| as torch's norm(dim=1) evaluates it (ATen norm_reduce, 8-lane vectors) */
+static inline float norm_ref(const float* row, int L) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int d = 0;
+    for (; d + 8 <= L; d += 8)
+        for (int p = 0; p < 8; ++p) acc[p] = fmaf(row[d + p], row[d + p], acc[p]);
+    float s = acc[0];
+    for (int p = 1; p < 8; ++p) s = s + acc[p];
+    if (L - d >= 4) {   /* four remaining columns: their ROUNDED squares are added one after the other */
+        for (int p = 0; p < 4; ++p) { const float sq = row[d + p] * row[d + p]; s = s + sq; }
+        d += 4;
+    }
+    for (; d < L; ++d) s = fmaf(row[d], row[d], s);   /* the last <= 3 columns: fused */
+    return sqrtf(s);
+}
+
 /* cluster.py:653-669.  Row-major [n][L], in place. */
 void vo_normalize(float* m, int64_t n, int L) {
     const float inv_l = (float)(1.0 / (double)L);
@@ -77,14 +139,21 @@ void vo_normalize(float* m, int64_t n, int L) {
         int allzero = 1;
         for (int k = 0; k < L; ++k) if (row[k] != 0.0f) { allzero = 0; break; }
         if (allzero) for (int k = 0; k < L; ++k) row[k] = inv_l;
-        float ss = 0.0f;
-        for (int k = 0; k < L; ++k) ss = fmaf(row[k], row[k], ss);
-        const float denom = sqrtf(ss) * sqrt2;
+        float nrm;
+        if (g_order == 1) {
+            nrm = norm_ref(row, L);
+        } else {
+            float ss = 0.0f;
+            for (int k = 0; k < L; ++k) ss = fmaf(row[k], row[k], ss);
+            nrm = sqrtf(ss);
+        }
+        const float denom = nrm * sqrt2;
         for (int k = 0; k < L; ++k) row[k] = row[k] / denom;
     }
 }
 
 static inline float dist_to(const float* row, const float* q, int L) {
+    if (g_order == 1) return 0.5f - dot_ref(row, q, L);
     float acc = 0.0f;
     for (int k = 0; k < L; ++k) acc = fmaf(row[k], q[k], acc);
     return 0.5f - acc;

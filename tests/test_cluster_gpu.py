@@ -350,3 +350,73 @@ def test_one_rank_sharded_backend_stream_matches_golden(name):
         pytest.skip("np.argsort tie order differs on this CPU (unstable sort, cluster.py:275)")
     ok, msg = fd.streams_equal(got, golden)
     assert ok, msg
+
+
+# ---- the reference's own evaluation order (option scan.reference_order; oracle: cluster_oracle.set_order(1)) -----------------
+@pytest.fixture
+def reference_order(monkeypatch, oracle_lib):
+    """Distances and row normalisation in the order of the reference's torch / oneMKL AVX-512 CPU build, on both sides: the HIP
+    library (VAMBHIP_REFERENCE_ORDER -> scan.reference_order) and the C oracle, which in that mode equals torch bit for bit
+    (tests/test_oracle_cluster.py, oracle/probe_reference_order.py)."""
+    monkeypatch.setenv("VAMBHIP_REFERENCE_ORDER", "1")
+    co.set_order(1)
+    yield
+    co.set_order(0)
+
+
+@pytest.mark.parametrize("n,L", [(1, 32), (5, 3), (1023, 32), (1025, 40), (4096, 64), (3000, 15), (777, 130), (500, 12), (600, 29)])
+def test_reference_order_normalize_bit_exact(reference_order, n, L):
+    rng = np.random.RandomState(n + L)
+    m = rng.standard_normal((n, L)).astype(np.float32)
+    if n > 3:
+        m[2] = 0
+    want = co.normalize(m.copy())
+    got = m.copy()
+    b = _mk(m, np.ones(n), False, got)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(b.matrix().view(np.uint32), want.view(np.uint32))
+    b.close()
+
+
+@pytest.mark.parametrize("n,L,k", [(700, 32, 1), (5000, 32, 3), (5000, 40, 8), (20000, 32, 12), (20000, 64, 25), (3000, 3, 32),
+                                   (2049, 15, 17), (4000, 132, 12), (3000, 17, 9), (3000, 33, 5), (2500, 1, 2), (2500, 16, 4)])
+def test_reference_order_scan_accumulators_bit_exact(reference_order, n, L, k):
+    lat, _ = synth.blob_latent(n, L, 0.2, seed=n + k, k=max(2, n // 300))
+    lens = synth.lengths(n, 3)
+    m = co.normalize(lat.copy())
+    lf = lens.astype(np.float32)
+    kept = np.ones(n, np.uint8)
+    rng = np.random.RandomState(1)
+    dead = rng.choice(n, size=n // 5, replace=False)
+    kept[dead] = 0
+    b = _mk(m, lens, True)
+    b.remove(dead)
+    live = np.flatnonzero(kept)
+    meds = [int(x) for x in rng.choice(live, size=min(k, len(live)), replace=False)]
+    for med, g in zip(meds, b.scan(meds)):
+        w = co.scan(m, lf, kept, med, want_dist=False)
+        assert g.n_within == w["n_within"] and g.n_lt == w["n_lt"], med
+        assert np.array_equal(g.hist_fx, w["hist_fx"]), med
+        assert g.density == co.density_value(w["density_fx"]), med
+        lst = b.scan_list(g.list_ref)
+        if lst is not None:
+            assert np.array_equal(lst, co.select(m, kept, med, 0.05)), med
+        for thr in (0.05, 0.06, 0.123456, 0.3):
+            assert np.array_equal(b.select(med, thr, remove=False), co.select(m, kept, med, thr)), (med, thr)
+    b.close()
+
+
+@pytest.mark.parametrize("name", list(fd.CLUSTER_CASES) + list(fd.CLUSTER_CASES_LARGE))
+def test_reference_order_stream_equals_the_reference(reference_order, name):
+    """In the reference's own evaluation order the GPU stream IS the real reference's stream on every golden fixture -- all
+    31 583 clusters of the 100 k sigma = 0.5 case included, which the ascending chain leaves at cluster 10 697 over one row
+    0.00000009 away from the medoid radius (test_100k_stream_matches_reference_golden)."""
+    mat, lens, kw = fd.cluster_inputs(name)
+    golden = fd.load("cluster_" + name)
+    order_hash = hashlib.sha256(np.argsort(lens)[::-1].astype(np.int64).tobytes()).hexdigest()
+    if "order_sha256" in golden and str(golden["order_sha256"]) != order_hash:
+        pytest.skip("np.argsort tie order differs on this CPU (unstable sort, cluster.py:275)")
+    got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
+    # (reported observed_pvr only: a ratio of torch.histogram's order-dependent float32 bin sums, see streams_equal)
+    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-2)
+    assert ok, "vs the reference's golden stream: " + msg

@@ -78,3 +78,54 @@ def test_bad_params(oracle_lib):
         co.OracleClusterGenerator(mat.astype(np.float64), lens)
     with pytest.raises(ValueError):
         co.OracleClusterGenerator(mat[:0], lens[:0])
+
+
+@pytest.mark.parametrize("name", list(fd.CLUSTER_CASES))
+def test_reference_order_oracle_stream_equals_the_reference(name):
+    """oracle.set_order(1): distances and normalisation in the evaluation order measured on the reference's own torch / oneMKL
+    CPU build (oracle/probe_reference_order.py: equal to torch bit for bit for every latent width).  The restated state machine
+    then reproduces the real reference's golden streams (the two 100 k fixtures take minutes on the CPU: checked by
+    oracle/check_reference_order_streams.py -> profiles/r03_reference_order_streams.txt, and on the GPU by
+    tests/test_cluster_gpu.py::test_reference_order_stream_equals_the_reference)."""
+    co.set_order(1)
+    try:
+        mat, lens, kw = fd.cluster_inputs(name)
+        got = fd.pack_stream(list(co.OracleClusterGenerator(mat.copy(), lens, **kw)))
+    finally:
+        co.set_order(0)
+    golden = fd.load("cluster_" + name)
+    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-2)
+    assert ok, msg
+
+
+def test_reference_order_equals_torch_bit_for_bit():
+    """The pin of oracle.set_order(1): on an AVX-512 host the restated order IS what torch computes for the reference's two
+    reductions -- `matrix.matmul(matrix[index])` (cluster.py:674) and `matrix.norm(dim=1)` in `_normalize` (cluster.py:668) --
+    for the latent widths of every fixture and of BASELINE's configs (32, 64) and a few awkward ones."""
+    import torch
+
+    if torch.backends.cpu.get_cpu_capability() != "AVX512":
+        pytest.skip("the measured order is that of torch / oneMKL on an AVX-512 host")
+    rng = np.random.RandomState(11)
+    co.set_order(1)
+    try:
+        for threads in (1, 4):
+            torch.set_num_threads(threads)
+            for L in (1, 3, 12, 16, 17, 29, 32, 33, 40, 48, 49, 64, 65):
+                n = 6000
+                raw = (rng.standard_normal((n, L)) * rng.uniform(0.1, 3, (n, 1))).astype(np.float32)
+                raw[5] = 0
+                t = torch.from_numpy(raw.copy())
+                zero = (t == 0).all(dim=1)
+                t[zero] = 1 / L
+                t /= t.norm(dim=1).reshape(-1, 1) * (2 ** 0.5)                      # cluster.py:664-668
+                ours = co.normalize(raw.copy())
+                assert np.array_equal(ours.view(np.uint32), t.numpy().view(np.uint32)), (threads, L)
+                for idx in (0, 5, n // 2, n - 1):
+                    want = (0.5 - t.matmul(t[idx])).numpy()                          # cluster.py:674
+                    want[idx] = 0.0
+                    got = co.scan(ours, np.ones(n, np.float32), None, idx)["dist"]
+                    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (threads, L, idx)
+    finally:
+        co.set_order(0)
+        torch.set_num_threads(1)

@@ -100,11 +100,94 @@ __constant__ uint32_t c_edge_bits[VH_NBINS + 1] = {
     0x3e99999au};
 
 // ---------------------------------------------------------------------------------------------
+// The REFERENCE's evaluation order (option scan.reference_order).  `matrix.matmul(matrix[index])` (cluster.py:674) and
+// `matrix.norm(dim=1)` (cluster.py:668) are float32 reductions whose order the reference does not define; on the torch 2.10 /
+// oneMKL 2024.2 / AVX-512 CPU build they were measured (oracle/probe_reference_order.py, profiles/r03_reference_order_probe.txt)
+// and restated in oracle/cluster_scan.c (dot_ref / norm_ref), which then equals torch bit for bit for every latent width.
+// With these two functions the distances and the normalised matrix ARE the reference's on that build, and the near-tie of
+// the 100 k sigma = 0.5 fixture (0.04999998 vs 0.05000007 at the medoid radius) falls on the reference's side.
+//   dot : s = a0 x0;  16 lanes {s, 0, ...}; every full block of 16 columns from column 1 on accumulated lane-wise with fma;
+//         halving tree (p + 8, p + 4, p + 2, p + 1); the (L - 1) % 16 columns left form one more block whose lane 0 starts
+//         from the running sum
+//   norm: 8 lanes of fma over the full blocks of 8 columns, lanes added 0..7 in order; of the L % 8 columns left the first
+//         four (if there are four) add their ROUNDED squares one by one, the last <= 3 are fused; sqrtf
+// (this file is compiled with -ffp-contract=off: a * b + c below is a rounded product and a rounded sum)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ref_tree16(const float (&v)[16]) {
+    float a[8], b[4];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) a[p] = v[p] + v[p + 8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) b[p] = a[p] + a[p + 4];
+    const float c0 = b[0] + b[2], c1 = b[1] + b[3];
+    return c0 + c1;
+}
+
+template <class FX, class FQ>
+__device__ __forceinline__ float ref_dot(int L, FX x, FQ q) {
+    float s = x(0) * q(0);
+    const int nfull = (L - 1) / 16, rem = (L - 1) % 16;
+    int k = 1;
+    float acc[16];
+    if (nfull > 0) {
+        acc[0] = s;
+#pragma unroll
+        for (int p = 1; p < 16; ++p) acc[p] = 0.0f;
+        for (int b = 0; b < nfull; ++b, k += 16) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc[p] = __builtin_fmaf(x(k + p), q(k + p), acc[p]);
+        }
+        s = ref_tree16(acc);
+    }
+    if (rem > 0) {
+        acc[0] = s;
+#pragma unroll
+        for (int p = 1; p < 16; ++p) acc[p] = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+            if (p < rem) acc[p] = __builtin_fmaf(x(k + p), q(k + p), acc[p]);
+        s = ref_tree16(acc);
+    }
+    return s;
+}
+
+template <class FX>
+__device__ __forceinline__ float ref_norm(int L, FX x) {
+    float acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = 0.0f;
+    int d = 0;
+    for (; d + 8 <= L; d += 8) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float v = x(d + p);
+            acc[p] = __builtin_fmaf(v, v, acc[p]);
+        }
+    }
+    float s = acc[0];
+#pragma unroll
+    for (int p = 1; p < 8; ++p) s = s + acc[p];
+    if (L - d >= 4) {
+        for (int p = 0; p < 4; ++p) {
+            const float v = x(d + p);
+            const float sq = v * v;
+            s = s + sq;
+        }
+        d += 4;
+    }
+    for (; d < L; ++d) {
+        const float v = x(d);
+        s = __builtin_fmaf(v, v, s);
+    }
+    return __builtin_sqrtf(s);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K9: normalise rows (cluster.py:653-669) and transpose to the SoA layout.  One thread per row.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void clu_normalize_transpose_kernel(float* __restrict__ rowmajor, int64_t n, int L,
                                                                      int do_normalize, float* __restrict__ Mt,
-                                                                     int64_t ld) {
+                                                                     int64_t ld, int ref_order) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
     float* r = rowmajor + row * (int64_t)L;
@@ -125,7 +208,9 @@ __global__ __launch_bounds__(64) void clu_normalize_transpose_kernel(float* __re
         for (int k = 0; k < L; ++k) ss = __builtin_fmaf(inv_l, inv_l, ss);
     }
     const float sqrt2 = (float)1.4142135623730951;
-    const float denom = __builtin_sqrtf(ss) * sqrt2;  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+    float nrm = __builtin_sqrtf(ss);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+    if (ref_order) nrm = ref_norm(L, [&](int k) { return allzero ? inv_l : r[k]; });
+    const float denom = nrm * sqrt2;
     for (int k = 0; k < L; ++k) {
         const float x = allzero ? inv_l : r[k];
         const float y = x / denom;
@@ -208,12 +293,35 @@ __device__ __forceinline__ void load_live(const uint8_t* __restrict__ p, unsigne
 // with all lanes busy: one hit per lane.  All accumulators are integers, so the order of accumulation is free.
 constexpr int kHitCap = 256;      // queued hits per wavefront (drained when fewer than 64 slots remain)
 
+// One (row, medoid) pair inside the histogram range: what sample_medoid / find_threshold record for it (all integer, order-free)
+__device__ __forceinline__ void record_pair(float d, float len, int32_t row, int j, unsigned long long* __restrict__ acc_s,
+                                            unsigned int* __restrict__ lcnt_s, int32_t* __restrict__ llist_s,
+                                            const float* __restrict__ edges_s, int dbg) {
+    const float radius = 0.05f;
+    // rows inside the medoid radius: exact integer accumulation and the medoid's candidate list
+    // (sample_medoid's `cluster`, cluster.py:621-626)
+    if (d <= radius) {
+        // len * (radius - d) in float32 as the reference computes it, then * 2^16 (exact) and RNE
+        const float p = len * (radius - d);
+        atomicAdd(&acc_s[j * kResultWords + 0], rn_u64(p * (float)VH_DENSITY_SCALE));
+        atomicAdd(&acc_s[j * kResultWords + 1 + VH_NBINS], 1ull);
+        if (d < radius) atomicAdd(&acc_s[j * kResultWords + 2 + VH_NBINS], 1ull);
+        // appended block-locally in LDS, flushed once per block -- per-row global atomics on one cursor
+        // serialise in L2 for dense medoids
+        const unsigned int lp = atomicAdd(&lcnt_s[j], 1u);
+        if (lp < (unsigned int)kLocalCap) llist_s[j * kLocalCap + lp] = row;
+    }
+    if (dbg & 2) return;       // timing experiment: no histogram
+    // fixed-point histogram weight: len * 2^8 is exact in float32
+    if (d >= edges_s[0])
+        atomicAdd(&acc_s[j * kResultWords + 1 + bin_of_in_range(d, edges_s)], rn_u64(len * (float)VH_HIST_SCALE));
+}
+
 __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn, int lane,
                                            unsigned long long* __restrict__ acc_s, unsigned int* __restrict__ lcnt_s,
                                            int32_t* __restrict__ llist_s, const float* __restrict__ edges_s,
                                            const int32_t* __restrict__ med_s, int dbg,
                                            const float* __restrict__ lengths = nullptr) {
-    const float radius = 0.05f;
     if (dbg & 8) return;   // timing experiment: queued pairs are dropped
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int e = lane; e < qn; e += 64) {
@@ -226,23 +334,7 @@ __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn
         // the distance of a medoid to itself is 0 by definition (cluster.py:619), not 0.5 - <q, q>: decided here, once
         // per queued pair, instead of once per (row, medoid) pair in the scan loop
         const float d = row == med_s[j] ? 0.0f : v.x;
-        // rows inside the medoid radius: exact integer accumulation and the medoid's candidate list
-        // (sample_medoid's `cluster`, cluster.py:621-626)
-        if (d <= radius) {
-            // len * (radius - d) in float32 as the reference computes it, then * 2^16 (exact) and RNE
-            const float p = len * (radius - d);
-            atomicAdd(&acc_s[j * kResultWords + 0], rn_u64(p * (float)VH_DENSITY_SCALE));
-            atomicAdd(&acc_s[j * kResultWords + 1 + VH_NBINS], 1ull);
-            if (d < radius) atomicAdd(&acc_s[j * kResultWords + 2 + VH_NBINS], 1ull);
-            // appended block-locally in LDS, flushed once per block -- per-row global atomics on one cursor
-            // serialise in L2 for dense medoids
-            const unsigned int lp = atomicAdd(&lcnt_s[j], 1u);
-            if (lp < (unsigned int)kLocalCap) llist_s[j * kLocalCap + lp] = row;
-        }
-        if (dbg & 2) continue;       // timing experiment: no histogram
-        // fixed-point histogram weight: len * 2^8 is exact in float32
-        if (d >= edges_s[0])
-            atomicAdd(&acc_s[j * kResultWords + 1 + bin_of_in_range(d, edges_s)], rn_u64(len * (float)VH_HIST_SCALE));
+        record_pair(d, len, row, j, acc_s, lcnt_s, llist_s, edges_s, dbg);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
@@ -503,6 +595,56 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// K6r: the scan in the REFERENCE's evaluation order (option scan.reference_order).  One row per lane, the distance of every
+// (row, medoid) pair evaluated by ref_dot; 32 medoid slots like the matrix-pipe kernel (slots >= k_real are empty).  A plain
+// kernel: this mode exists to be bit-identical with the reference's own distances, the tuned kernels above keep the
+// ascending chain.  Same LDS layout, accumulators, candidate lists and flush as clu_scan_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void clu_scan_ref_kernel(const float* __restrict__ Mt, int64_t ld, int L, int L4,
+                                                              const float* __restrict__ lengths,
+                                                              const uint8_t* __restrict__ kept, int64_t n,
+                                                              const float* __restrict__ q_ext, const MedoidRows medoid,
+                                                              int k_real, unsigned long long* __restrict__ results,
+                                                              int32_t* __restrict__ lists, int dbg) {
+    constexpr int KM = kMaxMedoids;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* hq_s = reinterpret_cast<float4*>(smem_raw);                                  // (unused here; keeps the layout)
+    unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(hq_s + (kBlock / 64) * kHitCap);   // [KM][kResultWords]
+    float* edges_s = reinterpret_cast<float*>(acc_s + KM * kResultWords);               // [64]
+    float* q_s = edges_s + 64;                                                          // [KM][L4]
+    unsigned int* lcnt_s = reinterpret_cast<unsigned int*>(q_s + KM * L4);              // [KM]
+    int32_t* llist_s = reinterpret_cast<int32_t*>(lcnt_s + KM);                         // [KM][kLocalCap]
+    int32_t* med_s = llist_s + KM * kLocalCap;                                          // [KM]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KM; i += kBlock) med_s[i] = (int32_t)medoid.row[i];
+    for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
+    for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
+    for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
+    for (int i = tid; i < KM * L4; i += kBlock) {
+        const int j = i / L4, c = i - j * L4;
+        float v = 0.0f;
+        if (j < k_real) v = q_ext ? q_ext[i] : Mt[(int64_t)c * ld + medoid.row[j]];
+        q_s[i] = v;
+    }
+    __syncthreads();
+    const float edge_hi = edges_s[VH_NBINS];
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + tid; row < n; row += (int64_t)gridDim.x * kBlock) {
+        if (kept[row] == 0) continue;
+        const float len = lengths[row];
+        const float* col = Mt + row;
+        for (int j = 0; j < k_real; ++j) {
+            float d = 0.0f;
+            if ((int32_t)row != med_s[j]) {
+                const float* qj = q_s + j * L4;
+                d = 0.5f - ref_dot(L, [&](int c) { return col[(int64_t)c * ld]; }, [&](int c) { return qj[c]; });
+            }
+            if (d <= edge_hi && !(dbg & 1)) record_pair(d, len, (int32_t)row, j, acc_s, lcnt_s, llist_s, edges_s, dbg);
+        }
+    }
+    scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists, dbg);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K6m: passes with more than 8 medoids on the matrix pipe.  The VALU issues one wavefront fmaf per 4 cycles (PMC of the
 // many-medoid VALU kernel, profiles/r02f_pmc_scan_*.txt: SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU quad-cycles, VALU ~70 % busy at
 // 2 wavefronts per SIMD, 114 us for 32 medoids over 2 M x 32 with no pair of interest at all), i.e. 16 fmaf lanes per clock
@@ -746,7 +888,7 @@ __global__ __launch_bounds__(kBlock) void clu_select_kernel(const float* __restr
                                                             const float* __restrict__ q_ext, int64_t medoid,
                                                             float threshold, int remove,
                                                             int32_t* __restrict__ out_rows,
-                                                            unsigned int* __restrict__ out_count) {
+                                                            unsigned int* __restrict__ out_count, int ref_L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* q_s = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x;
@@ -782,6 +924,11 @@ __global__ __launch_bounds__(kBlock) void clu_select_kernel(const float* __restr
             acc[1] = __builtin_fmaf(x3.y, qq.w, acc[1]);
             acc[2] = __builtin_fmaf(x3.z, qq.w, acc[2]);
             acc[3] = __builtin_fmaf(x3.w, qq.w, acc[3]);
+        }
+        if (ref_L > 0) {   // scan.reference_order: the dot products in the reference build's order (ref_L = latent width)
+#pragma unroll
+            for (int r = 0; r < kRowsPerThread; ++r)
+                acc[r] = ref_dot(ref_L, [&](int c) { return col[(int64_t)c * ld + r]; }, [&](int c) { return q_s[c]; });
         }
         const unsigned char live[4] = {kp.x, kp.y, kp.z, kp.w};
         unsigned char newlive[4] = {kp.x, kp.y, kp.z, kp.w};
@@ -971,6 +1118,8 @@ struct vh_clu {
     vh_comm* comm = nullptr;      // row-sharded execution (vh_clu_attach_comm): the ranks holding the other shards
     int64_t max_shard_ld = 0;     // largest padded shard over the ranks (size of the select exchange buffers)
     DevBuf<uint32_t> xch_counts, xch_rows;
+    bool ref_order = false;       // scan.reference_order = 1: distances and normalisation in the reference build's evaluation order
+                                  // (ref_dot / ref_norm; the scan runs on clu_scan_ref_kernel)
     bool use_mfma = true;         // scan.mfma = 0: passes with more than 8 medoids stay on the VALU kernels (A/B)
     bool mfma_pass = false;       // set by scan_core for the pass being launched
     int mfma_k = 0;               // its medoid count
@@ -1110,7 +1259,26 @@ bool scan_uses_mfma(const vh_clu* h, int k) {
     return h->use_mfma && k > 8 && h->L4 <= 64 && h->max_k >= kMaxMedoids && h->ld < ((int64_t)1 << 28);   // 32-bit byte offsets
 }
 
+void launch_scan_ref(vh_clu* h, const MedoidRows& med, const float* q_ext) {
+    const size_t smem = scan_smem_bytes(kMaxMedoids, h->L4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_ref_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kScanLdsBudget));
+        attr_set = true;
+    }
+    VH_REQUIRE(smem <= kScanLdsBudget, "internal: %d latent columns do not fit the LDS", h->L4);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(h->ld, (int64_t)kBlock), 256 * 8));
+    hipLaunchKernelGGL(clu_scan_ref_kernel, dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L, h->L4, h->lengths.p,
+                       h->kept.p, h->ld, q_ext, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg);
+}
+
 void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext) {
+    if (h->ref_order) {
+        launch_scan_ref(h, med, q_ext);
+        VH_HIP(hipGetLastError());
+        return;
+    }
     if (h->mfma_pass) {
         if (h->L4 <= 32) launch_scan_mfma<16>(h, med, q_ext);
         else launch_scan_mfma<32>(h, med, q_ext);
@@ -1216,6 +1384,8 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->min_blocks = option("scan.min_blocks", kMinScanBlocks);
         h->scan_lc = (int)option("scan.column_loop", 1);
         h->use_mfma = option("scan.mfma", 1) != 0;
+        h->ref_order = option("scan.reference_order", 0) != 0;
+        VH_REQUIRE(!h->ref_order || h->max_k >= kMaxMedoids, "scan.reference_order: latent width %d is too wide", L);
         h->scan_dbg = (int)option("scan.debug", 0);
         h->results.alloc((size_t)kResultReplicas * kMaxMedoids * kResultWords);
         VH_HIP(hipHostMalloc((void**)&h->lists, (size_t)kListRing * kMaxMedoids * kListCap * sizeof(int32_t),
@@ -1241,7 +1411,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         VH_HIP(hipMemcpyAsync(staging.p, matrix, (size_t)n * L * sizeof(float), hipMemcpyHostToDevice, h->stream));
         VH_HIP(hipMemcpyAsync(h->lengths.p, lengths, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(clu_normalize_transpose_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64), 0, h->stream,
-                           staging.p, n, L, normalized ? 0 : 1, h->Mt.p, h->ld);
+                           staging.p, n, L, normalized ? 0 : 1, h->Mt.p, h->ld, h->ref_order ? 1 : 0);
         VH_HIP(hipGetLastError());
         hipLaunchKernelGGL(clu_fill_kept_kernel, dim3(1024), dim3(256), 0, h->stream, h->kept.p, n, h->ld);
         VH_HIP(hipGetLastError());
@@ -1301,7 +1471,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
     VH_REQUIRE(h != nullptr && medoid_rows != nullptr, "NULL argument");
     VH_REQUIRE(!sharded || (h->comm != nullptr && queries == nullptr), "sharded scan needs vh_clu_attach_comm and no explicit queries");
     VH_REQUIRE(k >= 1 && k <= h->max_k, "k=%d outside [1, %d] (vh_clu_max_medoids)", k, h->max_k);
-    h->mfma_pass = scan_uses_mfma(h, k);
+    h->mfma_pass = h->ref_order || scan_uses_mfma(h, k);   // (both kernels take 32 medoid slots, the unused ones empty)
     const int km = h->mfma_pass ? kMaxMedoids : pick_km(k);
     MedoidRows med;
     h->mfma_k = k;
@@ -1438,7 +1608,7 @@ int vh_clu_select_sharded(vh_clu* h, int64_t local_row, float threshold, int rem
         // local select (counts[0] is zero on entry), then the counts of all ranks
         hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
                            h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, h->q.p, local_row, threshold, remove,
-                           h->sel_rows.p, h->counts.p);
+                           h->sel_rows.p, h->counts.p, h->ref_order ? h->L : 0);
         VH_HIP(hipGetLastError());
         h->xch_counts.ensure((size_t)world + 1);
         rccl_allgather_u32(comm, h->counts.p, h->xch_counts.p, 1, h->stream);
@@ -1515,7 +1685,7 @@ int vh_clu_select(vh_clu* h, int64_t medoid_row, const float* query, float thres
         h->timer.start(h->stream);
         hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
                            h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, q_ext, medoid_row, threshold, remove,
-                           h->sel_rows.p, h->counts.p);
+                           h->sel_rows.p, h->counts.p, h->ref_order ? h->L : 0);
         VH_HIP(hipGetLastError());
         h->timer.stop(h->stream);
         // count and (short) row list travel through host-mapped memory; the host spins on the sequence flag
