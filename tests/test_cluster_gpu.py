@@ -254,8 +254,9 @@ def test_100k_stream_matches_reference_golden(name):
       radius (cluster.py:621): the reference offers rng.sample 13 candidates instead of 12, the shared random stream is
       consumed differently from there on and 8 559 clusters later a different candidate order first changes a medoid
       (oracle/analyze_near_tie.py -> profiles/r02_near_tie_100k_s050.txt).  The reference's own result depends on
-      its BLAS kernel and thread count (doc/how_to_run.md:108), so this is the resolution limit of ANY
-      re-implementation, not a defect of the exact accumulators."""
+      its BLAS kernel (doc/how_to_run.md:108): this is the limit of the DEFAULT arithmetic (ascending chain); in the
+      evaluation order measured on the reference's own build the whole stream is reproduced
+      (test_reference_order_stream_equals_the_reference)."""
     mat, lens, kw = fd.cluster_inputs(name)
     golden = fd.load("cluster_" + name)
     defined = fd.load("cluster_" + name + ".defined_order")
