@@ -10,7 +10,7 @@ n = int(sys.argv[1])
 cap = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 60
 lat, _ = synth.blob_latent(n, 32, 0.5, seed=3)
 lens = synth.lengths(n, 3)
-for mode in ("0", "1"):
+for mode in ("0", "2", "1"):
     os.environ["VAMBHIP_REFERENCE_ORDER"] = mode
     gen = vc.ClusterGenerator(lat.copy(), lens, destroy=True, rng_seed=0)
     t0 = time.perf_counter()

@@ -354,12 +354,13 @@ def test_one_rank_sharded_backend_stream_matches_golden(name):
 
 
 # ---- the reference's own evaluation order (option scan.reference_order; oracle: cluster_oracle.set_order(1)) -----------------
-@pytest.fixture
-def reference_order(monkeypatch, oracle_lib):
+@pytest.fixture(params=["1", "2"], ids=["plain-kernel", "tuned-kernels-as-filter"])
+def reference_order(request, monkeypatch, oracle_lib):
     """Distances and row normalisation in the order of the reference's torch / oneMKL AVX-512 CPU build, on both sides: the HIP
-    library (VAMBHIP_REFERENCE_ORDER -> scan.reference_order) and the C oracle, which in that mode equals torch bit for bit
+    library (VAMBHIP_REFERENCE_ORDER -> scan.reference_order; 1 = the plain scan kernel, 2 = the tuned kernels as a filter with
+    the reference-order evaluation in their drain) and the C oracle, which in that mode equals torch bit for bit
     (tests/test_oracle_cluster.py, oracle/probe_reference_order.py)."""
-    monkeypatch.setenv("VAMBHIP_REFERENCE_ORDER", "1")
+    monkeypatch.setenv("VAMBHIP_REFERENCE_ORDER", request.param)
     co.set_order(1)
     yield
     co.set_order(0)

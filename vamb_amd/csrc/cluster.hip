@@ -317,10 +317,23 @@ __device__ __forceinline__ void record_pair(float d, float len, int32_t row, int
         atomicAdd(&acc_s[j * kResultWords + 1 + bin_of_in_range(d, edges_s)], rn_u64(len * (float)VH_HIST_SCALE));
 }
 
+// scan.reference_order = 2: the tuned kernels act as a FILTER -- a pair is queued when its ascending-chain distance is within
+// kRefSlack of the histogram range -- and the drain evaluates the queued pair in the reference's order (ref_dot) from the
+// resident matrix.  Two float32 evaluations of the same dot product of unit-scale vectors differ by < 1e-5 for any latent width
+// the kernels accept, so no pair the reference order would record is missed; the hot loops are untouched.
+struct RefSrc {
+    const float* Mt;       // resident matrix [L4][ld]
+    int64_t ld;
+    int L, L4;
+    const float* q_rows;   // explicit query vectors [km][L4] (row-sharded execution / vh_clu_scan with queries) or nullptr
+};
+constexpr float kRefSlack = 1.0e-4f;
+
+template <bool REF = false>
 __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn, int lane,
                                            unsigned long long* __restrict__ acc_s, unsigned int* __restrict__ lcnt_s,
                                            int32_t* __restrict__ llist_s, const float* __restrict__ edges_s,
-                                           const int32_t* __restrict__ med_s, int dbg,
+                                           const int32_t* __restrict__ med_s, int dbg, const RefSrc& ro,
                                            const float* __restrict__ lengths = nullptr) {
     if (dbg & 8) return;   // timing experiment: queued pairs are dropped
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -333,7 +346,18 @@ __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn
         const int j = __float_as_int(v.w);
         // the distance of a medoid to itself is 0 by definition (cluster.py:619), not 0.5 - <q, q>: decided here, once
         // per queued pair, instead of once per (row, medoid) pair in the scan loop
-        const float d = row == med_s[j] ? 0.0f : v.x;
+        float d = row == med_s[j] ? 0.0f : v.x;
+        if constexpr (REF) {
+            if (row != med_s[j]) {
+                const float* x = ro.Mt + row;
+                const float* qr = ro.q_rows ? ro.q_rows + (size_t)j * ro.L4 : nullptr;
+                const float* qm = ro.Mt + med_s[j];
+                const int64_t ld = ro.ld;
+                d = 0.5f - ref_dot(ro.L, [&](int c) { return x[(int64_t)c * ld]; },
+                                   [&](int c) { return qr ? qr[c] : qm[(int64_t)c * ld]; });
+                if (!(d <= edges_s[VH_NBINS])) continue;   // passed the filter only
+            }
+        }
         record_pair(d, len, row, j, acc_s, lcnt_s, llist_s, edges_s, dbg);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -379,14 +403,14 @@ __device__ __forceinline__ void scan_flush(int tid, const unsigned long long* __
 // before the first fmaf, so a wavefront pays one memory round trip per row block instead of L4/4 dependent ones:
 // the matrices the generator scans late in a sweep (10^5 rows, ~1 workgroup per CU) are latency-bound.
 // PIPE: (runtime-width loop, many medoids) software pipeline, see the kernel body.
-template <int KM, int RPT, int LC, int PIPE = 0>
+template <int KM, int RPT, int LC, int PIPE = 0, bool REF = false>
 __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
                                                           const float* __restrict__ lengths,
                                                           const uint8_t* __restrict__ kept, int64_t n,
                                                           const float* __restrict__ q_ext,
                                                           const MedoidRows medoid,
                                                           unsigned long long* __restrict__ results,
-                                                          int32_t* __restrict__ lists, int dbg) {
+                                                          int32_t* __restrict__ lists, int dbg, const RefSrc ro) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* hq_s = reinterpret_cast<float4*>(smem_raw);                                  // [kBlock/64][kHitCap]
     unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(hq_s + (kBlock / 64) * kHitCap);   // [KM][kResultWords]
@@ -432,7 +456,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
         // (beyond the last histogram edge, 0.3 > radius, there is nothing to record)
         float thr[RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) thr[r] = (live[r] != 0 && !(dbg & 1)) ? edge_hi : -__builtin_inff();
+        for (int r = 0; r < RPT; ++r) thr[r] = (live[r] != 0 && !(dbg & 1)) ? (REF ? edge_hi + kRefSlack : edge_hi) : -__builtin_inff();
         // Evaluation of the finished dot products of medoids j0 .. j0 + NJ - 1.  Pairs of interest are rare (a medoid's
         // neighbourhood is a few hundred of 10^6 rows), so the common path is kept to two VALU instructions per pair --
         // d = 0.5 - dot and one compare whose lane mask is OR-ed on the scalar unit -- and ONE branch per group of four
@@ -471,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                             }
                             qn += __popcll(m);
                             if (qn > kHitCap - 64) {
-                                drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg);
+                                drain_hits<REF>(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, ro);
                                 qn = 0;
                             }
                         }
@@ -589,7 +613,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
             evaluate(acc, 0);
         }
     }
-    drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg);
+    drain_hits<REF>(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, ro);
 
     scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists, dbg);
 }
@@ -683,13 +707,13 @@ __device__ __forceinline__ void scan_tile_load(ScanTile<NK>& t, const float* __r
         t.xa[s] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mt + (int64_t)(2 * min(s, nk - 1)) * ld + base) + off);
 }
 
-template <int NK>
+template <int NK, bool REF = false>
 __global__ __launch_bounds__(kBlock) void clu_scan_mfma_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
                                                                const float* __restrict__ lengths,
                                                                const uint8_t* __restrict__ kept,
                                                                const float* __restrict__ q_ext, const MedoidRows medoid,
                                                                int k_real, unsigned long long* __restrict__ results,
-                                                               int32_t* __restrict__ lists, int dbg) {
+                                                               int32_t* __restrict__ lists, int dbg, const RefSrc ro) {
     constexpr int KM = kMaxMedoids;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* hq_s = reinterpret_cast<float4*>(smem_raw);                                  // [kBlock/64][kHitCap]
@@ -722,6 +746,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_mfma_kernel(const float* __re
     float dot_min = 0.5f - edge_hi;
     while (0.5f - __uint_as_float(__float_as_uint(dot_min) - 1u) <= edge_hi) dot_min = __uint_as_float(__float_as_uint(dot_min) - 1u);
     while (!(0.5f - dot_min <= edge_hi)) dot_min = __uint_as_float(__float_as_uint(dot_min) + 1u);
+    if constexpr (REF) dot_min -= kRefSlack;   // filter only: the drain decides in the reference's order
     if (dbg & 1) dot_min = __builtin_inff();   // timing experiment: no pair of interest
     int qn = 0;   // hits queued by this wavefront (uniform)
 
@@ -777,7 +802,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_mfma_kernel(const float* __re
                     }
                     qn += __popcll(m);
                     if (qn > kHitCap - 64) {
-                        drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, lengths);
+                        drain_hits<REF>(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, ro, lengths);
                         qn = 0;
                     }
                 }
@@ -793,7 +818,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_mfma_kernel(const float* __re
             }
         }
     }
-    drain_hits(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, lengths);
+    drain_hits<REF>(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, ro, lengths);
     scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists, dbg);
 }
 
@@ -1118,6 +1143,8 @@ struct vh_clu {
     vh_comm* comm = nullptr;      // row-sharded execution (vh_clu_attach_comm): the ranks holding the other shards
     int64_t max_shard_ld = 0;     // largest padded shard over the ranks (size of the select exchange buffers)
     DevBuf<uint32_t> xch_counts, xch_rows;
+    bool ref_filter = false;      // scan.reference_order = 2: the same arithmetic, the tuned kernels as a filter + ref_dot in their drain
+    const float* q_rows_pass = nullptr;   // explicit row-major query vectors of the running pass (or nullptr)
     bool ref_order = false;       // scan.reference_order = 1: distances and normalisation in the reference build's evaluation order
                                   // (ref_dot / ref_norm; the scan runs on clu_scan_ref_kernel)
     bool use_mfma = true;         // scan.mfma = 0: passes with more than 8 medoids stay on the VALU kernels (A/B)
@@ -1186,20 +1213,27 @@ size_t scan_smem_bytes(int km, int L4) {
            (size_t)km * 4 * (2 + kLocalCap);
 }
 
-template <int KM, int RPT, int LC, int PIPE = 0>
-void launch_scan_lc(vh_clu* h, const MedoidRows& med, const float* q_ext) {
+RefSrc ref_src(const vh_clu* h) { return RefSrc{h->Mt.p, h->ld, h->L, h->L4, h->q_rows_pass}; }
+
+template <int KM, int RPT, int LC, int PIPE, bool REF>
+void launch_scan_lc_impl(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     const size_t smem = scan_smem_bytes(KM, h->L4);
     static bool attr_set = false;
     if (!attr_set) {   // wide latent spaces need more than the default 64 KiB of dynamic LDS (query vectors live there)
-        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_kernel<KM, RPT, LC, PIPE>),
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_kernel<KM, RPT, LC, PIPE, REF>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScanLdsBudget));
         attr_set = true;
     }
     VH_REQUIRE(smem <= kScanLdsBudget, "internal: %d medoids x %d latent columns do not fit the LDS", KM, h->L4);
     const int64_t blocks = ceil_div(h->ld, (int64_t)kBlock * RPT);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
-    hipLaunchKernelGGL((clu_scan_kernel<KM, RPT, LC, PIPE>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
-                       h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_pass, h->scan_dbg);
+    hipLaunchKernelGGL((clu_scan_kernel<KM, RPT, LC, PIPE, REF>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
+                       h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_pass, h->scan_dbg, ref_src(h));
+}
+template <int KM, int RPT, int LC, int PIPE = 0>
+void launch_scan_lc(vh_clu* h, const MedoidRows& med, const float* q_ext) {
+    if (h->ref_filter) launch_scan_lc_impl<KM, RPT, LC, PIPE, true>(h, med, q_ext);
+    else launch_scan_lc_impl<KM, RPT, LC, PIPE, false>(h, med, q_ext);
 }
 
 template <int KM, int RPT>
@@ -1238,20 +1272,25 @@ void launch_scan(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     else launch_scan_rpt<KM, RPT>(h, med, q_ext);
 }
 
-template <int NK>
-void launch_scan_mfma(vh_clu* h, const MedoidRows& med, const float* q_ext) {
+template <int NK, bool REF>
+void launch_scan_mfma_impl(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     const size_t smem = scan_smem_bytes(kMaxMedoids, 0);
     static bool attr_set = false;
     if (!attr_set) {
-        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_mfma_kernel<NK>),
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_mfma_kernel<NK, REF>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScanLdsBudget));
         attr_set = true;
     }
     const int64_t tiles = h->ld >> 5;
     // three workgroups per CU are resident (LDS): one resident set, every wavefront strides over its tiles
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(tiles, kBlock / 64), 256 * 3));
-    hipLaunchKernelGGL((clu_scan_mfma_kernel<NK>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
-                       h->lengths.p, h->kept.p, q_ext, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg);
+    hipLaunchKernelGGL((clu_scan_mfma_kernel<NK, REF>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
+                       h->lengths.p, h->kept.p, q_ext, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg, ref_src(h));
+}
+template <int NK>
+void launch_scan_mfma(vh_clu* h, const MedoidRows& med, const float* q_ext) {
+    if (h->ref_filter) launch_scan_mfma_impl<NK, true>(h, med, q_ext);
+    else launch_scan_mfma_impl<NK, false>(h, med, q_ext);
 }
 
 // more than 8 medoids and a latent width the B operand registers hold: the matrix-pipe kernel (always 32 medoid slots)
@@ -1274,7 +1313,7 @@ void launch_scan_ref(vh_clu* h, const MedoidRows& med, const float* q_ext) {
 }
 
 void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext) {
-    if (h->ref_order) {
+    if (h->ref_order && !h->ref_filter) {
         launch_scan_ref(h, med, q_ext);
         VH_HIP(hipGetLastError());
         return;
@@ -1384,8 +1423,13 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->min_blocks = option("scan.min_blocks", kMinScanBlocks);
         h->scan_lc = (int)option("scan.column_loop", 1);
         h->use_mfma = option("scan.mfma", 1) != 0;
-        h->ref_order = option("scan.reference_order", 0) != 0;
-        VH_REQUIRE(!h->ref_order || h->max_k >= kMaxMedoids, "scan.reference_order: latent width %d is too wide", L);
+        {
+            const int64_t mode = option("scan.reference_order", 0);
+            VH_REQUIRE(mode >= 0 && mode <= 2, "scan.reference_order: 0, 1 or 2");
+            h->ref_order = mode != 0;          // normalisation + select in the reference's order
+            h->ref_filter = mode == 2;         // scans: the tuned kernels (filter) instead of the plain kernel
+        }
+        VH_REQUIRE(!h->ref_order || h->ref_filter || h->max_k >= kMaxMedoids, "scan.reference_order = 1: latent width %d is too wide", L);
         h->scan_dbg = (int)option("scan.debug", 0);
         h->results.alloc((size_t)kResultReplicas * kMaxMedoids * kResultWords);
         VH_HIP(hipHostMalloc((void**)&h->lists, (size_t)kListRing * kMaxMedoids * kListCap * sizeof(int32_t),
@@ -1471,7 +1515,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
     VH_REQUIRE(h != nullptr && medoid_rows != nullptr, "NULL argument");
     VH_REQUIRE(!sharded || (h->comm != nullptr && queries == nullptr), "sharded scan needs vh_clu_attach_comm and no explicit queries");
     VH_REQUIRE(k >= 1 && k <= h->max_k, "k=%d outside [1, %d] (vh_clu_max_medoids)", k, h->max_k);
-    h->mfma_pass = h->ref_order || scan_uses_mfma(h, k);   // (both kernels take 32 medoid slots, the unused ones empty)
+    h->mfma_pass = (h->ref_order && !h->ref_filter) || scan_uses_mfma(h, k);   // (both kernels take 32 medoid slots, the unused ones empty)
     const int km = h->mfma_pass ? kMaxMedoids : pick_km(k);
     MedoidRows med;
     h->mfma_k = k;
@@ -1501,6 +1545,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
     const int slot = (int)(h->scan_seq % kListRing);
     int32_t* lists = h->lists + (size_t)slot * kMaxMedoids * kListCap;
     h->lists_pass = lists;
+    h->q_rows_pass = q_ext;   // row-major [km][L4] or nullptr (the quad-major copy some kernels take is made from it)
     h->timer.start(h->stream);
     dispatch_scan(h, km, med, q_ext);
     h->timer.stop(h->stream);
