@@ -41,7 +41,8 @@ const char* vh_version(void);
  *   scan.mfma (1)          passes with more than 8 medoids on the matrix-pipe kernel
  *   scan.reference_order (0)  distances and row normalisation in the evaluation order of the reference's torch / oneMKL AVX-512
  *                          CPU build (measured: oracle/probe_reference_order.py) instead of the ascending fmaf chain: the cluster
- *                          stream then equals the reference's own on every golden fixture; a plain scan kernel, not the tuned ones
+ *                          stream then equals the reference's own on every golden fixture.  1: a plain scan kernel; 2: the tuned kernels as a
+ *                          filter, the reference-order evaluation in their drain
  *   scan.wide_rows (0)     fixed 4 / 2 rows per lane (no narrow variants for small matrices)
  *   scan.min_blocks (768)  workgroups wanted before lanes take more than one row (measured neutral between 384 and 1536)
  *   scan.debug (0)         timing experiments only (wrong results): 1 no pair of interest, 2 no histogram, 4 no flush,
