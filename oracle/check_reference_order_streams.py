@@ -18,6 +18,6 @@ for order in (1, 0):
         ref = fd.load("cluster_" + name)
         n = min(len(packed["medoid"]), len(ref["medoid"]))
         diff = np.flatnonzero(packed["medoid"][:n] != ref["medoid"][:n])
-        ok, msg = fd.streams_equal(packed, ref, pvr_rtol=1e-5)
+        ok, msg = fd.streams_equal(packed, ref, pvr_rtol=0.0 if order == 1 else 1e-2)   # reference order: EVERY field exact
         print(f"order {order} {name:24s} clusters {len(packed['medoid']):6d} (reference {len(ref['medoid']):6d}) identical prefix {int(diff[0]) if len(diff) else n:6d} equal={ok} {'' if ok else msg[:100]}  [{time.time()-t0:.0f}s]", flush=True)
 co.set_order(0)

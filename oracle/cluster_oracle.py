@@ -55,6 +55,9 @@ def lib():
         i64, vp, f32 = ctypes.c_int64, ctypes.c_void_p, ctypes.c_float
         L.vo_normalize.argtypes = [vp, i64, ctypes.c_int]
         L.vo_set_order.argtypes = [ctypes.c_int]
+        L.vo_torch_sum.argtypes = [vp, i64]
+        L.vo_torch_sum.restype = f32
+        L.vo_reference_sums.argtypes = [vp, vp, vp, i64, vp, vp, vp]
         L.vo_get_order.restype = ctypes.c_int
         L.vo_distances.argtypes = [vp, i64, ctypes.c_int, i64, vp]
         L.vo_scan.argtypes = [vp, vp, vp, i64, ctypes.c_int, i64, vp, vp, vp, vp, vp, vp, i64]
@@ -137,6 +140,23 @@ def select(matrix, kept, medoid, threshold):
     out = np.empty(n, np.int64)
     cnt = lib().vo_select(_p(matrix), _p(kept), n, L, int(medoid), float(np.float32(threshold)), _p(out), n)
     return out[:cnt].copy()
+
+
+def torch_sum(x: np.ndarray) -> float:
+    """``torch.sum`` of a contiguous float32 vector in ATen's evaluation order (cluster_scan.c vo_torch_sum)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return float(lib().vo_torch_sum(_p(x), len(x)))
+
+
+def reference_sums(dist, lengths_f32, kept):
+    """(local_density, histogram) as the reference itself computes them from these distances: torch.sum's order for the density,
+    torch.histogram's one-thread order for the bins (cluster_scan.c vo_reference_sums)."""
+    n = len(dist)
+    scratch = np.empty(max(n, 1), np.float32)
+    dens = np.zeros(1, np.float32)
+    hist = np.zeros(NBINS, np.float32)
+    lib().vo_reference_sums(_p(dist), _p(lengths_f32), _p(kept), n, _p(scratch), _p(dens), _p(hist))
+    return float(dens[0]), hist
 
 
 def density_value(density_fx: int) -> float:
@@ -314,7 +334,14 @@ class OracleClusterGenerator:
         r = scan(self._live(), self.lengths, None, medoid)
         self.n_scans += 1
         self.scan_rows += self.n
-        res = (r["within"], r, density_value(r["density_fx"]))
+        if get_order() == 1:
+            # the reference's own float32 sums (torch.sum / one-thread torch.histogram order) instead of the exact ones: with
+            # them every reported field of the stream, observed_pvr included, is the reference's bit for bit
+            dens, hist = reference_sums(r["dist"], self.lengths, None)
+            r["hist_ref"] = hist
+            res = (r["within"], r, dens)
+        else:
+            res = (r["within"], r, density_value(r["density_fx"]))
         if len(self.cache) == MAX_CACHED:
             self.cache.popitem(last=False)
         self.cache[medoid] = res
@@ -345,7 +372,7 @@ class OracleClusterGenerator:
     def _threshold(self, result):
         if result["n_lt"] == 1:
             return "loner"
-        dens = smooth(histogram_value(result["hist_fx"]))
+        dens = smooth(result["hist_ref"] if "hist_ref" in result else histogram_value(result["hist_fx"]))
         t = pick_threshold(dens, self.peak_valley_ratio)
         return "none" if t is None else t
 

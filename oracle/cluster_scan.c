@@ -31,6 +31,7 @@
  *              columns the first four (if there are four) add their rounded squares one by one, the last <= 3 are fused
  *              multiply-adds; sqrtf;  row / (norm * 1.41421354f)
  * With this order the defined arithmetic IS the reference's arithmetic for distances and normalisation on that build.
+ * vo_torch_sum / vo_reference_sums add the two float32 sums the reference reports (density, histogram bins) in ITS order.
  */
 #include <math.h>
 #include <stdint.h>
@@ -130,6 +131,59 @@ static inline float norm_ref(const float* row, int L) {
     return sqrtf(s);
 }
 
+/* torch.sum of a contiguous float32 vector as ATen evaluates it on the same build (SumKernel.cpp cascade_sum ->
+ * vectorized_inner_sum / scalar_inner_sum; measured with the same probe and confirmed on random vectors of 1..20000 elements):
+ * items are 8-lane vectors (n >= 8) or scalars (n < 8); four interleaved rows of items (item i -> row i % 4) are accumulated by
+ * a cascade (sixteen items into level 0, level 0 into level 1, ...; levels added up at the end), the items left over by the
+ * interleave go into row 0, rows are added 0..3; the n % 8 trailing scalars are summed first, then lanes 0..7 are added to that. */
+#define VO_W 8
+static int ceil_log2_i64(int64_t x) { int b = 0; while (((int64_t)1 << b) < x) ++b; return b; }
+static void vo_row_sum(const float* x, int64_t size, int W, float* out /* [W] */) {
+    const int ilp = 4, num_levels = 4;
+    const int64_t size_ilp = size / ilp;
+    int level_power = ceil_log2_i64(size_ilp) / num_levels;
+    if (level_power < 4) level_power = 4;
+    const int64_t level_step = (int64_t)1 << level_power, level_mask = level_step - 1;
+    float acc[4][4][VO_W];
+    memset(acc, 0, sizeof(acc));
+    int64_t i = 0;
+    while (i + level_step <= size_ilp) {
+        for (int64_t j = 0; j < level_step; ++j, ++i)
+            for (int k = 0; k < ilp; ++k)
+                for (int p = 0; p < W; ++p) acc[0][k][p] = acc[0][k][p] + x[((i * ilp + k) * W) + p];
+        for (int j = 1; j < num_levels; ++j) {
+            for (int k = 0; k < ilp; ++k)
+                for (int p = 0; p < W; ++p) { acc[j][k][p] = acc[j][k][p] + acc[j - 1][k][p]; acc[j - 1][k][p] = 0.0f; }
+            const int64_t mask = level_mask << (j * level_power);
+            if ((i & mask) != 0) break;
+        }
+    }
+    for (; i < size_ilp; ++i)
+        for (int k = 0; k < ilp; ++k)
+            for (int p = 0; p < W; ++p) acc[0][k][p] = acc[0][k][p] + x[((i * ilp + k) * W) + p];
+    for (int j = 1; j < num_levels; ++j)
+        for (int k = 0; k < ilp; ++k)
+            for (int p = 0; p < W; ++p) acc[0][k][p] = acc[0][k][p] + acc[j][k][p];
+    for (int64_t t = size_ilp * ilp; t < size; ++t)
+        for (int p = 0; p < W; ++p) acc[0][0][p] = acc[0][0][p] + x[t * W + p];
+    for (int k = 1; k < ilp; ++k)
+        for (int p = 0; p < W; ++p) acc[0][0][p] = acc[0][0][p] + acc[0][k][p];
+    for (int p = 0; p < W; ++p) out[p] = acc[0][0][p];
+}
+float vo_torch_sum(const float* x, int64_t n) {
+    float v[VO_W];
+    if (n < VO_W) {
+        vo_row_sum(x, n, 1, v);
+        return v[0];
+    }
+    const int64_t nb = n / VO_W;
+    vo_row_sum(x, nb, VO_W, v);
+    float s = 0.0f;
+    for (int64_t k = nb * VO_W; k < n; ++k) s = s + x[k];
+    for (int p = 0; p < VO_W; ++p) s = s + v[p];
+    return s;
+}
+
 /* cluster.py:653-669.  Row-major [n][L], in place. */
 void vo_normalize(float* m, int64_t n, int L) {
     const float inv_l = (float)(1.0 / (double)L);
@@ -197,6 +251,24 @@ void vo_scan_q(const float* m, const float* lengths, const uint8_t* kept, int64_
     *density_fx = dens;
     *n_within = nw;
     *n_lt = nlt;
+}
+
+/* What the reference itself reports for one scan when its distances are `dist` (live rows only): local_density =
+ * (lengths[within] * (0.05f - dist[within])).sum() (cluster.py:628-629, torch.sum's order above) and the histogram as
+ * torch.histogram with ONE thread accumulates it (cluster.py:475-481: float32, rows in ascending order).  scratch: n floats. */
+void vo_reference_sums(const float* dist, const float* lengths, const uint8_t* kept, int64_t n, float* scratch,
+                       float* density, float* hist /* [VO_NBINS] */) {
+    if (!g_edges_ready) make_edges();
+    int64_t m = 0;
+    for (int b = 0; b < VO_NBINS; ++b) hist[b] = 0.0f;
+    for (int64_t i = 0; i < n; ++i) {
+        if (kept && !kept[i]) continue;
+        const float d = dist[i];
+        if (d <= 0.05f) scratch[m++] = lengths[i] * (0.05f - d);
+        const int b = vo_bin(d);
+        if (b >= 0) hist[b] = hist[b] + lengths[i];
+    }
+    *density = vo_torch_sum(scratch, m);
 }
 
 void vo_scan(const float* m, const float* lengths, const uint8_t* kept, int64_t n, int L,

@@ -82,11 +82,12 @@ def test_bad_params(oracle_lib):
 
 @pytest.mark.parametrize("name", list(fd.CLUSTER_CASES))
 def test_reference_order_oracle_stream_equals_the_reference(name):
-    """oracle.set_order(1): distances and normalisation in the evaluation order measured on the reference's own torch / oneMKL
-    CPU build (oracle/probe_reference_order.py: equal to torch bit for bit for every latent width).  The restated state machine
-    then reproduces the real reference's golden streams (the two 100 k fixtures take minutes on the CPU: checked by
-    oracle/check_reference_order_streams.py -> profiles/r03_reference_order_streams.txt, and on the GPU by
-    tests/test_cluster_gpu.py::test_reference_order_stream_equals_the_reference)."""
+    """oracle.set_order(1): the evaluation orders measured on the reference's own torch / oneMKL CPU build
+    (oracle/probe_reference_order.py) -- `matmul` and `norm` (equal to torch bit for bit for every latent width), and the two
+    float32 sums the reference reports: torch.sum of the density terms and torch.histogram's one-thread bin sums.  The restated
+    state machine then reproduces the real reference's golden streams EXACTLY, every field, observed_pvr included (the two
+    100 k fixtures take minutes on the CPU: oracle/check_reference_order_streams.py ->
+    profiles/r03_reference_order_streams.txt; on the GPU: tests/test_cluster_gpu.py::test_reference_order_*)."""
     co.set_order(1)
     try:
         mat, lens, kw = fd.cluster_inputs(name)
@@ -94,8 +95,33 @@ def test_reference_order_oracle_stream_equals_the_reference(name):
     finally:
         co.set_order(0)
     golden = fd.load("cluster_" + name)
-    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-2)
+    ok, msg = fd.streams_equal(got, golden, pvr_rtol=0.0)
     assert ok, msg
+
+
+def test_reference_sums_equal_torch_bit_for_bit():
+    """vo_torch_sum == torch.sum and vo_reference_sums' histogram == torch.histogram (one thread), bit for bit."""
+    import torch
+
+    if torch.backends.cpu.get_cpu_capability() != "AVX512":
+        pytest.skip("measured on an AVX-512 host")
+    torch.set_num_threads(1)
+    rng = np.random.RandomState(3)
+    for n in list(range(0, 70)) + [127, 128, 129, 255, 256, 257, 511, 512, 1000, 1024, 2047, 4096, 9000, 33000]:
+        for _ in range(8):
+            x = (rng.standard_normal(n) * rng.uniform(0.1, 100)).astype(np.float32)
+            assert co.torch_sum(x) == float(torch.from_numpy(x).sum().item()), n
+    for n in (10, 1000, 20000):
+        d = rng.uniform(0, 0.35, n).astype(np.float32)
+        w = rng.randint(2000, 100000, n).astype(np.float32)
+        sel = d <= np.float32(0.3)
+        hist, edges = torch.zeros(60), torch.zeros(61)
+        torch.histogram(input=torch.from_numpy(d[sel]), bins=60, range=(0.0, 0.3), out=(hist, edges), weight=torch.from_numpy(w[sel]))
+        dens, h = co.reference_sums(d, w, None)
+        assert np.array_equal(h.view(np.uint32), hist.numpy().view(np.uint32))
+        close = (np.float32(0.05) - d[d <= np.float32(0.05)]).astype(np.float32)
+        want = float((torch.from_numpy(w[d <= np.float32(0.05)]) * torch.from_numpy(close)).sum().item())
+        assert dens == want
 
 
 def test_reference_order_equals_torch_bit_for_bit():
