@@ -335,6 +335,18 @@ def cpu_baseline(args, latent, lens):
                 reference_estimate_contigs_per_s=ref_est)
 
 
+def _cluster_order(_lib):
+    """Which arithmetic the timed sweeps ran in (library option scan.reference_order)."""
+    _lib.sync_env_options()
+    mode = _lib.get_option("scan.reference_order", 2)
+    what = {2: "reference order (default): matmul / norm evaluated as the reference's own torch / oneMKL AVX-512 CPU build does; the "
+               "tuned scan kernels filter with the ascending fmaf chain and re-evaluate pairs at decision boundaries in that order. "
+               "Bit-exact cluster streams against the real reference on every golden fixture (tests/test_cluster_gpu.py)",
+            1: "reference order on the plain one-pair-per-lane kernel (cross-check mode)",
+            0: "ascending fmaf chain (default of rounds 1-3; NOT the bit-exact mode)"}[int(mode)]
+    return {"scan.reference_order": int(mode), "meaning": what}
+
+
 _RESULT_FD = None
 
 
@@ -524,6 +536,7 @@ def main():
             "cluster_ms": float(np.mean([r["cluster_s"] for r in results]) * 1e3),
             "clusters_per_step": int(np.mean([r["clusters"] for r in results])),
             "cluster_scan": scan_summary(scan_src, results, ("kernel time: first warm-up step (HIP-event timing of every pass); " if warm else "kernel time: timed steps; ") + "wall time: the timed steps"),
+            "cluster_order": _cluster_order(_lib),
             "make_dataloader": None if strong else {
                 "seconds": prep_s, "on": "device" if prep_on_device else "host",
                 "note": "outside the timed region; on the device it is ONE upload of the raw abundance / TNF matrices "

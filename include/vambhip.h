@@ -39,10 +39,13 @@ const char* vh_version(void);
  * variables (the Python layer forwards its VAMBHIP_* variables through these calls, vamb_amd/_lib.py).  Integer options:
  *   scan.column_loop (1)   0: runtime-width column loop in every scan kernel; 1: unrolled loads up to 8 medoids
  *   scan.mfma (1)          passes with more than 8 medoids on the matrix-pipe kernel
- *   scan.reference_order (0)  distances and row normalisation in the evaluation order of the reference's torch / oneMKL AVX-512
- *                          CPU build (measured: oracle/probe_reference_order.py) instead of the ascending fmaf chain: the cluster
- *                          stream then equals the reference's own on every golden fixture.  1: a plain scan kernel; 2: the tuned kernels as a
- *                          filter, the reference-order evaluation in their drain
+ *   scan.reference_order (2)  evaluation order of the two float32 reductions behind every cluster decision, `matrix.matmul` and
+ *                          `matrix.norm` (cluster.py:668, 674).  2 (default): the order measured on the reference's own torch /
+ *                          oneMKL AVX-512 CPU build (oracle/probe_reference_order.py) -- the cluster stream equals the reference's
+ *                          on every golden fixture; the tuned kernels evaluate the ascending fmaf chain as a filter and
+ *                          re-evaluate in the reference's order only the pairs within the rounding slack of a decision boundary.
+ *                          1: the same order on a plain one-pair-per-lane kernel (cross-check, ~3x the time per pass).
+ *                          0: the ascending fmaf chain (the default of rounds 1-3; differs from the reference at near-ties)
  *   scan.wide_rows (0)     fixed 4 / 2 rows per lane (no narrow variants for small matrices)
  *   scan.min_blocks (768)  workgroups wanted before lanes take more than one row (measured neutral between 384 and 1536)
  *   scan.debug (0)         timing experiments only (wrong results): 1 no pair of interest, 2 no histogram, 4 no flush,

@@ -79,10 +79,17 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
+DEFAULT_ORDER = 2
+
+
 def set_order(order: int) -> None:
-    """0: the ascending fmaf chain (default; what the HIP kernels compute), 1: the evaluation order of the reference's own
-    torch CPU build for `matmul` and `norm` (cluster_scan.c header) -- distances and normalisation then equal the real
-    reference's bit for bit."""
+    """Evaluation order of the two float32 reductions behind every decision (cluster_scan.c header):
+    2 (default; == libvambhip's default, scan.reference_order = 2): `matmul` and `norm` as the reference's own torch / oneMKL
+      AVX-512 CPU build evaluates them -- distances and normalisation equal the real reference's bit for bit -- with the exact
+      integer density / histogram sums;
+    1: the same, and the density / histogram sums in float32 in the reference's own order (torch.sum / one-thread
+      torch.histogram): every reported field of the stream, observed_pvr included, is the reference's;
+    0: the ascending fmaf chain (libvambhip: scan.reference_order = 0)."""
     lib().vo_set_order(int(order))
 
 

@@ -20,10 +20,13 @@
  * The reference sums density / histogram in fp32 in an unspecified (MKL / vectorised) order; the
  * integer accumulation here is the correctly rounded version of the same sum.
  *
- * vo_set_order(1) -- the REFERENCE's own order, measured (round 3; oracle/probe_reference_order.py): the evaluation order of
+ * vo_set_order(1 | 2) -- the REFERENCE's own order, measured (round 3; oracle/probe_reference_order.py): the evaluation order of
  * `matrix.matmul(matrix[index])` and of `matrix.norm(dim=1)` on the torch 2.10 / oneMKL 2024.2 / AVX-512 CPU build of this
  * container, identified by probing which partial sums meet first and then confirmed bit for bit on 10^5-row random matrices for
- * every latent width from 1 to 257, 1 and 8 threads:
+ * every latent width from 1 to 257, 1 and 8 threads.  Order 2 (the DEFAULT since round 4, and the default of libvambhip's
+ * scan.reference_order) keeps the exact integer density / histogram sums; order 1 additionally makes cluster_oracle.py sum them in
+ * float32 in the reference's own order (vo_torch_sum / vo_reference_sums), which reproduces even the reported observed_pvr bit
+ * for bit.  Order 0 is the ascending fmaf chain of the "defined order" paragraph above (libvambhip: scan.reference_order = 0).
  *   dot(i)   : s = a0 x0;  16 lanes {s, 0, ...}; every full block of 16 columns from column 1 on is accumulated lane-wise with
  *              fma; halving tree (p + 8, p + 4, p + 2, p + 1); the (L - 1) % 16 remaining columns form one more 16-lane block
  *              whose lane 0 starts from the running sum, reduced by the same tree
@@ -81,7 +84,9 @@ int vo_bin(float d) {
     return b;
 }
 
-static int g_order = 0;   /* 0: ascending fmaf chain (the HIP kernels' default), 1: the reference build's order (see header) */
+static int g_order = 2;   /* 0: ascending fmaf chain, 1 / 2: the reference build's order for matmul and norm (see header); 1 also selects
+                            * the reference's float32 density / histogram sums in cluster_oracle.py, 2 (default = what libvambhip
+                            * computes by default) keeps the exact integer sums */
 void vo_set_order(int order) { g_order = order; }
 int vo_get_order(void) { return g_order; }
 
@@ -194,7 +199,7 @@ void vo_normalize(float* m, int64_t n, int L) {
         for (int k = 0; k < L; ++k) if (row[k] != 0.0f) { allzero = 0; break; }
         if (allzero) for (int k = 0; k < L; ++k) row[k] = inv_l;
         float nrm;
-        if (g_order == 1) {
+        if (g_order != 0) {
             nrm = norm_ref(row, L);
         } else {
             float ss = 0.0f;
@@ -207,7 +212,7 @@ void vo_normalize(float* m, int64_t n, int L) {
 }
 
 static inline float dist_to(const float* row, const float* q, int L) {
-    if (g_order == 1) return 0.5f - dot_ref(row, q, L);
+    if (g_order != 0) return 0.5f - dot_ref(row, q, L);
     float acc = 0.0f;
     for (int k = 0; k < L; ++k) acc = fmaf(row[k], q[k], acc);
     return 0.5f - acc;

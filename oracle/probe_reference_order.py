@@ -84,7 +84,7 @@ def main():
                 tot_d += int((got.view(np.uint32) != want.view(np.uint32)).sum())
                 cnt += N
         print(f"  threads {threads}: latent widths 1..69, 80..257: normalised elements differing {tot_n}, distances differing {tot_d} of {cnt}")
-    co.set_order(0)
+    co.set_order(co.DEFAULT_ORDER)
 
 
 if __name__ == "__main__":

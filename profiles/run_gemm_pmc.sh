@@ -9,12 +9,12 @@ run() {  # name, counter set, command...
   rm -rf /tmp/pmcx
   timeout 300 rocprofv3 --pmc $set_ --kernel-trace --output-format csv -d /tmp/pmcx -o pmc -- "$@" > $O/$name.out 2>&1
   f=$(find /tmp/pmcx -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && python $R/tests/gpu_pmc_summary.py $f > $O/$name.txt 2>&1
+  [ -n "$f" ] && python $R/tools/gpu/gpu_pmc_summary.py $f > $O/$name.txt 2>&1
   grep -E "gemm|scan" $O/$name.txt
 }
-run pmc_gemm16_c3_set1 "$SET" python $R/tests/gpu_gemm16_one.py 3 8192 512 1120 30
-run pmc_gemm16_c3_set2 "$SET2" python $R/tests/gpu_gemm16_one.py 3 8192 512 1120 30
-run pmc_gemm16_c2_set1 "$SET" python $R/tests/gpu_gemm16_one.py 3 8192 512 320 30
-run pmc_gemm16_sq4096_set1 "$SET" python $R/tests/gpu_gemm16_one.py 0 4096 4096 4096 10
-VAMBHIP_SCAN_DBG=1 run pmc_scan_mfma_k32_set1 "$SET" python $R/tests/gpu_scan_one.py 2000000 32 32 20
-VAMBHIP_SCAN_DBG=1 run pmc_scan_mfma_k32_set2 "$SET2" python $R/tests/gpu_scan_one.py 2000000 32 32 20
+run pmc_gemm16_c3_set1 "$SET" python $R/tools/gpu/gpu_gemm16_one.py 3 8192 512 1120 30
+run pmc_gemm16_c3_set2 "$SET2" python $R/tools/gpu/gpu_gemm16_one.py 3 8192 512 1120 30
+run pmc_gemm16_c2_set1 "$SET" python $R/tools/gpu/gpu_gemm16_one.py 3 8192 512 320 30
+run pmc_gemm16_sq4096_set1 "$SET" python $R/tools/gpu/gpu_gemm16_one.py 0 4096 4096 4096 10
+VAMBHIP_SCAN_DBG=1 run pmc_scan_mfma_k32_set1 "$SET" python $R/tools/gpu/gpu_scan_one.py 2000000 32 32 20
+VAMBHIP_SCAN_DBG=1 run pmc_scan_mfma_k32_set2 "$SET2" python $R/tools/gpu/gpu_scan_one.py 2000000 32 32 20

@@ -5,5 +5,5 @@ O=$R/gpurun_out/r03q
 mkdir -p $O
 cd $R
 (timeout 900 python -m pytest tests/test_cluster_gpu.py tests/test_parallel_gpu.py tests/test_dp_gpu.py -m gpu -x -q > $O/pytest_cluster.log 2>&1; echo "rc=$?" >> $O/pytest_cluster.log); tail -5 $O/pytest_cluster.log
-timeout 1500 python tests/gpu_cluster_sweep_ab.py 2000000 200 8192 bf16 300 "VAMBHIP_GEN_PROFILE=1;VAMBHIP_SPEC_NEIGHBOURS=0,VAMBHIP_GEN_PROFILE=1;VAMBHIP_SPEC_WINDOW=16,VAMBHIP_GEN_PROFILE=1" $O/sweep_ab.json 2> $O/sweep_ab.err | tee $O/sweep_ab.txt
+timeout 1500 python tools/gpu/gpu_cluster_sweep_ab.py 2000000 200 8192 bf16 300 "VAMBHIP_GEN_PROFILE=1;VAMBHIP_SPEC_NEIGHBOURS=0,VAMBHIP_GEN_PROFILE=1;VAMBHIP_SPEC_WINDOW=16,VAMBHIP_GEN_PROFILE=1" $O/sweep_ab.json 2> $O/sweep_ab.err | tee $O/sweep_ab.txt
 grep "vambhip\] generator\|passes by purpose" $O/sweep_ab.err | cut -c1-900

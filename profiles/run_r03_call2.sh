@@ -6,7 +6,7 @@ O=$R/gpurun_out/r03b
 mkdir -p $O
 cd $R
 (timeout 600 python -m pytest tests/test_vae_gpu.py -m gpu -x -q -k "gemm16" > $O/pytest_gemm16.log 2>&1; echo "rc=$?" >> $O/pytest_gemm16.log); tail -5 $O/pytest_gemm16.log
-timeout 600 python tests/gpu_gemm16_variants.py $O/gemm16_variants.json > $O/gemm16_variants.txt 2>&1; cat $O/gemm16_variants.txt
+timeout 600 python tools/gpu/gpu_gemm16_variants.py $O/gemm16_variants.json > $O/gemm16_variants.txt 2>&1; cat $O/gemm16_variants.txt
 (timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log); tail -5 $O/pytest_gpu.log
 for opt in "" "VAMBHIP_VAE_GEMM_PIPELINE=0" "VAMBHIP_VAE_DW_ROW_MAJOR=0" "VAMBHIP_VAE_GEMM_PIPELINE=0 VAMBHIP_VAE_DW_ROW_MAJOR=0"; do
   echo "== options: $opt"

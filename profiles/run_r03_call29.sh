@@ -6,5 +6,5 @@ mkdir -p $O
 cd $R
 for rep in 1 2; do
 for v in 1 0; do
-  VAMBHIP_VAE_FORK_AT_LOSS=$v timeout 300 python tests/gpu_epoch_time.py 2000000 200 8192 12 bf16 2>&1 | tail -1 | sed "s/^/fork_at_loss=$v: /" | tee -a $O/fork_at_loss.txt
+  VAMBHIP_VAE_FORK_AT_LOSS=$v timeout 300 python tools/gpu/gpu_epoch_time.py 2000000 200 8192 12 bf16 2>&1 | tail -1 | sed "s/^/fork_at_loss=$v: /" | tee -a $O/fork_at_loss.txt
 done; done

@@ -289,6 +289,7 @@ def main():
         # the reference stream up to the documented divergence.
         import cluster_oracle as co
 
+        co.set_order(0)   # the ascending fmaf chain (libvambhip: scan.reference_order = 0); the oracle's default is the reference's order
         out = {}
         for name in fd.CLUSTER_CASES_LARGE:
             mat, lens, kw = fd.cluster_inputs(name)
@@ -300,6 +301,7 @@ def main():
             out[name] = dict(n_clusters=len(packed["medoid"]),
                              identical_prefix_with_reference=int(diff[0]) if len(diff) else n)
             print("defined-order", name, out[name])
+        co.set_order(co.DEFAULT_ORDER)
         manifest["cluster_large_defined_order"] = out
     if "tnf" in which:
         manifest["tnf"] = gen_tnf()

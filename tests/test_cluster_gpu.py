@@ -1,6 +1,13 @@
 """GPU parity tests of the cluster path: libvambhip (HIP kernels through the C ABI) against the
 oracle on the same seeded inputs -- bit-exact for every integer accumulator and for the emitted
-cluster stream -- and against the reference's golden streams."""
+cluster stream -- and against the reference's golden streams.
+
+Evaluation order.  The DEFAULT configuration of the library (scan.reference_order = 2) and of the oracle
+(cluster_oracle.DEFAULT_ORDER = 2) evaluates `matmul` / `norm` in the order measured on the reference's own torch / oneMKL
+AVX-512 CPU build: every test below that does not say otherwise runs in it, and in it the GPU stream IS the real reference's
+stream on every golden fixture, both 100 k ones in full.  The `order_mode` fixture re-runs the arithmetic tests in the two
+other modes: the plain one-pair-per-lane kernel in the same order (scan.reference_order = 1, a cross-check of the tuned
+kernels' filter) and the ascending fmaf chain (scan.reference_order = 0, the default of rounds 1-3)."""
 import ctypes
 import hashlib
 
@@ -137,7 +144,9 @@ def test_stream_matches_oracle_and_reference(oracle_lib, name):
     if "order_sha256" in golden and str(golden["order_sha256"]) != order_hash:
         pytest.skip("np.argsort tie order differs on this CPU (unstable sort, cluster.py:275); "
                     "oracle comparison passed")
-    ok, msg = fd.streams_equal(got, golden)
+    # (reported observed_pvr only: a ratio of smoothed densities the reference forms from torch.histogram's order-dependent
+    # float32 bin sums; the library's sums are the exact ones.  Every decision -- medoid, seed, radius, members -- is compared exactly.)
+    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-2)
     assert ok, "vs reference golden: " + msg
 
 
@@ -242,31 +251,36 @@ def _stream_prefix(st, n):
 @pytest.mark.parametrize("name", list(fd.CLUSTER_CASES_LARGE))
 def test_100k_stream_matches_reference_golden(name):
     """100 000-point streams (N in {1 k, 10 k, 100 k}) recorded from the REAL reference
-    (tests/golden/make_golden.py cluster_large) and from the defined-order restatement (cluster_large_defined_order).
+    (tests/golden/make_golden.py cluster_large), in the library's DEFAULT configuration: the GPU stream equals the
+    reference's in full -- all 500 clusters of the sigma = 0.08 fixture and all 31 583 of the sigma = 0.5 one (loner /
+    NoThreshold / fallback / PVR relaxation), every medoid, seed, radius, member list, success window.  (Rounds 1-3 evaluated
+    the distances as an ascending fmaf chain and left the second stream at cluster 10 697, where one row is 0.04999998 from a
+    candidate medoid by the reference's summation order and 0.05000007 by the chain: test_100k_stream_ascending_chain.)
+    Only the REPORTED observed_pvr is compared with a tolerance: the reference forms it from torch.histogram's
+    order-dependent float32 bin sums, the library from the exact sums."""
+    mat, lens, kw = fd.cluster_inputs(name)
+    golden = fd.load("cluster_" + name)
+    order_hash = hashlib.sha256(np.argsort(lens)[::-1].astype(np.int64).tobytes()).hexdigest()
+    assert str(golden["order_sha256"]) == order_hash      # lengths are unique: the seed order cannot depend on the CPU
+    assert _lib.get_option("scan.reference_order", 2) == 2
+    got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
+    assert len(got["medoid"]) == len(golden["medoid"]) == {"blob_s008_n100000": 500, "blob_s050_n100000": 31583}[name]
+    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-2)
+    assert ok, "vs the reference's golden stream: " + msg
 
-    * The GPU stream equals the defined-order stream EXACTLY, every field of all 500 / 31 576 clusters.
-    * sigma 0.08 (500 clusters of ~200 members, thousands of members per density / histogram sum): every decision of
-      the reference stream is reproduced; the only disagreement is the REPORTED observed_pvr of 2 clusters (relative
-      9e-8, the last bit of a valley density of ~2e-12 built from torch.histogram's order-dependent float32 bin sums).
-    * sigma 0.5 (31 583 clusters: loner / NoThreshold / fallback / PVR relaxation): identical to the reference for the
-      first 10 697 clusters.  The streams then part because in cluster #2138 one row's distance to a candidate medoid
-      is 0.04999998 by torch's MKL sgemv and 0.05000007 by the ascending fmaf chain, on either side of the medoid
-      radius (cluster.py:621): the reference offers rng.sample 13 candidates instead of 12, the shared random stream is
-      consumed differently from there on and 8 559 clusters later a different candidate order first changes a medoid
-      (oracle/analyze_near_tie.py -> profiles/r02_near_tie_100k_s050.txt).  The reference's own result depends on
-      its BLAS kernel (doc/how_to_run.md:108): this is the limit of the DEFAULT arithmetic (ascending chain); in the
-      evaluation order measured on the reference's own build the whole stream is reproduced
-      (test_reference_order_stream_equals_the_reference)."""
+
+@pytest.mark.parametrize("name", list(fd.CLUSTER_CASES_LARGE))
+def test_100k_stream_ascending_chain(name, monkeypatch):
+    """scan.reference_order = 0 (the arithmetic of rounds 1-3): the GPU stream equals the defined-order restatement's stream
+    (tests/golden/*.defined_order.npz) exactly, and the real reference's up to the documented near-tie -- cluster 10 697 of the
+    sigma = 0.5 fixture (oracle/analyze_near_tie.py -> profiles/r02_near_tie_100k_s050.txt)."""
+    monkeypatch.setenv("VAMBHIP_REFERENCE_ORDER", "0")
     mat, lens, kw = fd.cluster_inputs(name)
     golden = fd.load("cluster_" + name)
     defined = fd.load("cluster_" + name + ".defined_order")
-    order_hash = hashlib.sha256(np.argsort(lens)[::-1].astype(np.int64).tobytes()).hexdigest()
-    assert str(golden["order_sha256"]) == order_hash      # lengths are unique: the seed order cannot depend on the CPU
     got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
     ok, msg = fd.streams_equal(got, defined)
     assert ok, "vs defined-order restatement: " + msg
-    # reported observed_pvr only: 2 of 500 (sigma 0.08, <= 9e-8 relative) and 7 of the 549 normal clusters of the sigma-0.5
-    # prefix (<= 5.4e-3 relative) differ from torch.histogram's order-dependent float32 bin sums
     prefix, rtol = {"blob_s008_n100000": (500, 1e-6), "blob_s050_n100000": (10697, 1e-2)}[name]
     ok, msg = fd.streams_equal(_stream_prefix(got, prefix), _stream_prefix(golden, prefix), pvr_rtol=rtol)
     assert ok, f"vs reference golden (first {prefix} clusters): " + msg
@@ -279,7 +293,7 @@ def test_100k_stream_python_state_machine(monkeypatch):
     name = "blob_s008_n100000"
     mat, lens, kw = fd.cluster_inputs(name)
     got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
-    ok, msg = fd.streams_equal(got, fd.load("cluster_" + name), pvr_rtol=1e-6)
+    ok, msg = fd.streams_equal(got, fd.load("cluster_" + name), pvr_rtol=1e-2)
     assert ok, msg
 
 
@@ -349,25 +363,24 @@ def test_one_rank_sharded_backend_stream_matches_golden(name):
     order_hash = hashlib.sha256(np.argsort(lens)[::-1].astype(np.int64).tobytes()).hexdigest()
     if str(golden["order_sha256"]) != order_hash:
         pytest.skip("np.argsort tie order differs on this CPU (unstable sort, cluster.py:275)")
-    ok, msg = fd.streams_equal(got, golden)
+    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-2)
     assert ok, msg
 
 
-# ---- the reference's own evaluation order (option scan.reference_order; oracle: cluster_oracle.set_order(1)) -----------------
-@pytest.fixture(params=["1", "2"], ids=["plain-kernel", "tuned-kernels-as-filter"])
-def reference_order(request, monkeypatch, oracle_lib):
-    """Distances and row normalisation in the order of the reference's torch / oneMKL AVX-512 CPU build, on both sides: the HIP
-    library (VAMBHIP_REFERENCE_ORDER -> scan.reference_order; 1 = the plain scan kernel, 2 = the tuned kernels as a filter with
-    the reference-order evaluation in their drain) and the C oracle, which in that mode equals torch bit for bit
-    (tests/test_oracle_cluster.py, oracle/probe_reference_order.py)."""
+# ---- the other two evaluation modes (option scan.reference_order; oracle: cluster_oracle.set_order) ---------------------------
+@pytest.fixture(params=["1", "0"], ids=["plain-kernel", "ascending-chain"])
+def order_mode(request, monkeypatch, oracle_lib):
+    """scan.reference_order = 1: the reference build's order on the plain one-pair-per-lane scan kernel (every distance evaluated
+    by ref_dot; an independent check of the default's filter-and-re-evaluate kernels); = 0: the ascending fmaf chain.  The oracle
+    follows (order 2 = the reference's order with exact sums, order 0 = the chain)."""
     monkeypatch.setenv("VAMBHIP_REFERENCE_ORDER", request.param)
-    co.set_order(1)
-    yield
-    co.set_order(0)
+    co.set_order(0 if request.param == "0" else 2)
+    yield request.param
+    co.set_order(co.DEFAULT_ORDER)
 
 
 @pytest.mark.parametrize("n,L", [(1, 32), (5, 3), (1023, 32), (1025, 40), (4096, 64), (3000, 15), (777, 130), (500, 12), (600, 29)])
-def test_reference_order_normalize_bit_exact(reference_order, n, L):
+def test_other_orders_normalize_bit_exact(order_mode, n, L):
     rng = np.random.RandomState(n + L)
     m = rng.standard_normal((n, L)).astype(np.float32)
     if n > 3:
@@ -380,10 +393,12 @@ def test_reference_order_normalize_bit_exact(reference_order, n, L):
     b.close()
 
 
-@pytest.mark.parametrize("n,L,k", [(700, 32, 1), (5000, 32, 3), (5000, 40, 8), (20000, 32, 12), (20000, 64, 25), (3000, 3, 32),
-                                   (2049, 15, 17), (4000, 132, 12), (3000, 17, 9), (3000, 33, 5), (2500, 1, 2), (2500, 16, 4)])
-def test_reference_order_scan_accumulators_bit_exact(reference_order, n, L, k):
-    lat, _ = synth.blob_latent(n, L, 0.2, seed=n + k, k=max(2, n // 300))
+_ORDER_SHAPES = [(700, 32, 1), (5000, 32, 3), (5000, 40, 8), (20000, 32, 12), (20000, 64, 25), (3000, 3, 32),
+                 (2049, 15, 17), (4000, 132, 12), (3000, 17, 9), (3000, 33, 5), (2500, 1, 2), (2500, 16, 4)]
+
+
+def _check_scan_against_oracle(n, L, k, sigma=0.2):
+    lat, _ = synth.blob_latent(n, L, sigma, seed=n + k, k=max(2, n // 300))
     lens = synth.lengths(n, 3)
     m = co.normalize(lat.copy())
     lf = lens.astype(np.float32)
@@ -408,17 +423,91 @@ def test_reference_order_scan_accumulators_bit_exact(reference_order, n, L, k):
     b.close()
 
 
-@pytest.mark.parametrize("name", list(fd.CLUSTER_CASES) + list(fd.CLUSTER_CASES_LARGE))
-def test_reference_order_stream_equals_the_reference(reference_order, name):
-    """In the reference's own evaluation order the GPU stream IS the real reference's stream on every golden fixture -- all
-    31 583 clusters of the 100 k sigma = 0.5 case included, which the ascending chain leaves at cluster 10 697 over one row
-    0.00000009 away from the medoid radius (test_100k_stream_matches_reference_golden)."""
+@pytest.mark.parametrize("n,L,k", _ORDER_SHAPES)
+def test_other_orders_scan_accumulators_bit_exact(order_mode, n, L, k):
+    _check_scan_against_oracle(n, L, k)
+
+
+@pytest.mark.parametrize("n,L,k", _ORDER_SHAPES)
+def test_default_order_scan_accumulators_more_shapes(oracle_lib, n, L, k):
+    """The default mode on the shapes of the order tests (odd latent widths: remainder blocks of the reference's 16-lane order)."""
+    _check_scan_against_oracle(n, L, k)
+
+
+@pytest.mark.parametrize("n,L,k,sigma", [(6000, 32, 25, 0.01), (6000, 32, 8, 0.01), (4000, 64, 32, 0.02), (3000, 20, 4, 0.005)])
+def test_default_order_dense_neighbourhoods(oracle_lib, n, L, k, sigma):
+    """Tight blobs: most (row, medoid) pairs lie INSIDE the medoid radius, where the default mode re-evaluates every pair in the
+    reference's order (sixteen pairs per wavefront round) -- the path that is rare on ordinary data is the common one here."""
+    _check_scan_against_oracle(n, L, k, sigma)
+
+
+def test_default_order_pairs_at_the_decision_boundaries(oracle_lib):
+    """Rows placed ON the decision boundaries of one medoid -- the medoid radius 0.05 and histogram bin edges -- to within a few
+    ulp, where the ascending chain and the reference's order land on different sides for a good fraction of them: the default
+    mode must agree with the oracle (reference order) on every count, bin and density bit."""
+    n, L = 40000, 32
+    rng = np.random.RandomState(7)
+    q = rng.standard_normal(L)
+    q /= np.linalg.norm(q)
+    targets = np.concatenate([np.full(n // 4, 0.05), rng.choice(np.arange(1, 61) * 0.005, n - n // 4)])
+    rows = np.empty((n, L), np.float64)
+    for i, d in enumerate(targets):
+        cosv = 1.0 - 2.0 * d                      # d = 0.5 - <x, q> / 2 for unit vectors
+        u = rng.standard_normal(L)
+        u -= u.dot(q) * q
+        u /= np.linalg.norm(u)
+        rows[i] = cosv * q + np.sqrt(max(0.0, 1.0 - cosv * cosv)) * u
+    rows[0] = q
+    lat = (rows * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    lens = synth.lengths(n, 5)
+    m = co.normalize(lat.copy())
+    lf = lens.astype(np.float32)
+    kept = np.ones(n, np.uint8)
+    b = _mk(m, lens, True)
+    # how often the two orders disagree here (the test is vacuous if they never do)
+    co.set_order(0)
+    chain = co.scan(m, lf, kept, 0)["dist"]
+    co.set_order(co.DEFAULT_ORDER)
+    ref = co.scan(m, lf, kept, 0)["dist"]
+    edges = np.concatenate([[np.float32(0.05)], np.linspace(0, 0.3, 61, dtype=np.float32)])
+    flips = sum(int(((chain <= e) != (ref <= e)).sum()) for e in edges)
+    assert flips > 20, flips
+    for meds in ([0], [0, 5, 9], list(range(0, 24, 2)), list(range(25))):
+        for med, g in zip(meds, b.scan(meds)):
+            w = co.scan(m, lf, kept, med, want_dist=False)
+            assert g.n_within == w["n_within"] and g.n_lt == w["n_lt"], (len(meds), med)
+            assert np.array_equal(g.hist_fx, w["hist_fx"]), (len(meds), med)
+            assert g.density == co.density_value(w["density_fx"]), (len(meds), med)
+    for thr in [0.05] + [float(e) for e in edges[3::7]]:
+        assert np.array_equal(b.select(0, thr, remove=False), co.select(m, kept, 0, thr)), thr
+    b.close()
+
+
+@pytest.mark.parametrize("name", list(fd.CLUSTER_CASES) + ["blob_s050_n100000"])
+def test_plain_kernel_stream_equals_the_reference(monkeypatch, name):
+    """scan.reference_order = 1 (every distance by ref_dot on the plain kernel): the same stream as the default mode, i.e. the
+    real reference's, on every fixture."""
+    monkeypatch.setenv("VAMBHIP_REFERENCE_ORDER", "1")
     mat, lens, kw = fd.cluster_inputs(name)
     golden = fd.load("cluster_" + name)
     order_hash = hashlib.sha256(np.argsort(lens)[::-1].astype(np.int64).tobytes()).hexdigest()
     if "order_sha256" in golden and str(golden["order_sha256"]) != order_hash:
         pytest.skip("np.argsort tie order differs on this CPU (unstable sort, cluster.py:275)")
     got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
-    # (reported observed_pvr only: a ratio of torch.histogram's order-dependent float32 bin sums, see streams_equal)
     ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-2)
     assert ok, "vs the reference's golden stream: " + msg
+
+
+@pytest.mark.parametrize("name", list(fd.CLUSTER_CASES))
+def test_ascending_chain_stream_matches_its_oracle(monkeypatch, oracle_lib, name):
+    """scan.reference_order = 0 against the oracle in the same (ascending-chain) order, exactly."""
+    monkeypatch.setenv("VAMBHIP_REFERENCE_ORDER", "0")
+    co.set_order(0)
+    try:
+        mat, lens, kw = fd.cluster_inputs(name)
+        got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
+        want = fd.pack_stream(list(co.OracleClusterGenerator(mat.copy(), lens, **kw)))
+    finally:
+        co.set_order(co.DEFAULT_ORDER)
+    ok, msg = fd.streams_equal(got, want)
+    assert ok, "vs oracle: " + msg

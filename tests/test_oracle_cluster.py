@@ -93,7 +93,7 @@ def test_reference_order_oracle_stream_equals_the_reference(name):
         mat, lens, kw = fd.cluster_inputs(name)
         got = fd.pack_stream(list(co.OracleClusterGenerator(mat.copy(), lens, **kw)))
     finally:
-        co.set_order(0)
+        co.set_order(co.DEFAULT_ORDER)
     golden = fd.load("cluster_" + name)
     ok, msg = fd.streams_equal(got, golden, pvr_rtol=0.0)
     assert ok, msg
@@ -153,5 +153,5 @@ def test_reference_order_equals_torch_bit_for_bit():
                     got = co.scan(ours, np.ones(n, np.float32), None, idx)["dist"]
                     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (threads, L, idx)
     finally:
-        co.set_order(0)
+        co.set_order(co.DEFAULT_ORDER)
         torch.set_num_threads(1)

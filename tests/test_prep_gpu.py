@@ -107,3 +107,65 @@ def test_training_from_a_prepared_loader_is_identical():
         out.append((vae.last_epoch_losses["loss"], vae.encode(dl)))
     assert out[0][0] == out[1][0]
     assert np.array_equal(out[0][1], out[1][1])
+
+
+# ---- the reference's own make_dataloader tests (test/test_encode.py:47-95) with a GPU visible and prep mode "auto" ---------
+def _ref_fixture():
+    rng = np.random.RandomState(0)
+    tnfs = rng.random_sample((111, 103)).astype(np.float32)
+    rpkm = rng.random_sample((111, 14)).astype(np.float32)
+    lens = rng.randint(2000, 5000, size=111)
+    return tnfs, rpkm, lens
+
+
+def _nearly_same(a, b):
+    return bool(np.all(np.abs(a - b) < 1e-5))
+
+
+def test_reference_test_destroy_on_the_device_path():
+    """test_encode.py:47-58 (test_destroy): destroy=False leaves the caller's arrays alone, destroy=True normalises them in
+    place -- on the DEVICE path (prep mode auto, GPU visible), where the normalised blocks are written back."""
+    assert ve.get_prep_mode() == "auto"
+    tnfs, rpkm, lens = _ref_fixture()
+    copy_rpkm, copy_tnfs = rpkm.copy(), tnfs.copy()
+    dl = ve.make_dataloader(rpkm, tnfs, lens, batchsize=32)
+    assert getattr(dl.dataset, "_vambhip_prepared", None) is not None
+    assert _nearly_same(rpkm, copy_rpkm) and _nearly_same(tnfs, copy_tnfs)
+    dl = ve.make_dataloader(copy_rpkm, copy_tnfs, lens, batchsize=32, destroy=True)
+    assert getattr(dl.dataset, "_vambhip_prepared", None) is not None
+    assert not _nearly_same(rpkm, copy_rpkm) and not _nearly_same(tnfs, copy_tnfs)
+    # the dataset's host tensors ARE the caller's arrays (torch.from_numpy in the reference, encode.py:128-133)
+    assert dl.dataset.tensors[0].numpy().ctypes.data == copy_rpkm.ctypes.data
+    assert dl.dataset.tensors[1].numpy().ctypes.data == copy_tnfs.ctypes.data
+    # and they hold exactly what the host path writes into them
+    ve.set_prep_mode("host")
+    try:
+        h_rpkm, h_tnfs = rpkm.copy(), tnfs.copy()
+        ve.make_dataloader(h_rpkm, h_tnfs, lens, batchsize=32, destroy=True)
+    finally:
+        ve.set_prep_mode("auto")
+    assert np.array_equal(h_rpkm, copy_rpkm) and np.array_equal(h_tnfs, copy_tnfs)
+
+
+def test_reference_test_normalized_on_the_device_path():
+    """test_encode.py:60-75 (test_normalized)."""
+    tnfs, rpkm, lens = _ref_fixture()
+    copy_rpkm, copy_tnfs = rpkm.copy(), tnfs.copy()
+    ve.make_dataloader(copy_rpkm, copy_tnfs, lens, batchsize=32, destroy=True)
+    assert _nearly_same(np.mean(copy_tnfs, axis=0), np.zeros(copy_tnfs.shape[1]))
+    assert _nearly_same(np.std(copy_tnfs, axis=0), np.ones(copy_tnfs.shape[1]))
+    assert _nearly_same(np.sum(copy_rpkm, axis=1), np.ones(copy_rpkm.shape[0]))
+    assert np.all(copy_rpkm >= 0.0)
+
+
+def test_reference_test_single_sample_on_the_device_path():
+    """test_encode.py:77-95 (test_single_sample)."""
+    tnfs, rpkm, lens = _ref_fixture()
+    single_rpkm = rpkm[:, [0]]
+    copy_single = single_rpkm.copy()
+    dl = ve.make_dataloader(single_rpkm, tnfs.copy(), lens, batchsize=32, destroy=True)
+    assert getattr(dl.dataset, "_vambhip_prepared", None) is not None
+    assert abs(abs(np.mean(single_rpkm)) - 1.0) < 1e-6
+    assert abs(np.std(single_rpkm)) < 1e-6
+    assert (torch.argsort(dl.dataset.tensors[2], dim=0, stable=True)
+            == torch.argsort(torch.from_numpy(copy_single), dim=0, stable=True)).all().item()

@@ -1,10 +1,9 @@
 """Diagnostic: per-tensor gradient / loss / latent errors of the bf16-operand path against the fp64 oracle."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
 os.environ["VAMBHIP_PRECISION"] = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 import fixture_defs as fd
 import vae_oracle as vo

@@ -2,7 +2,7 @@
 """Diagnostic (not a test): the whole job at a BASELINE shape for several epoch counts on ONE dataset --
 train time, encode time, cluster sweep time / cluster count / purity -- to size bench.py's default workload.
 
-    python tests/gpu_c2_probe.py N S batch precision epochs[,epochs...] [out.json]
+    python tools/gpu/gpu_c2_probe.py N S batch precision epochs[,epochs...] [out.json]
 """
 import json
 import os
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 n, S, bs = (int(x) for x in sys.argv[1:4])
 os.environ["VAMBHIP_PRECISION"] = sys.argv[4]

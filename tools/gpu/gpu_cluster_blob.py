@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Diagnostic (not a test): one cluster sweep over blob latents (sigma 0.08), for rocprofv3 runs of the cluster kernels.
 With VAMBHIP_SCAN_DBG timing switches the results are wrong by design (the sweep is cut after 3000 clusters).
-    python tests/gpu_cluster_blob.py n"""
+    python tools/gpu/gpu_cluster_blob.py n"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vamb_amd import cluster as vc, synth  # noqa: E402
 n = int(sys.argv[1])

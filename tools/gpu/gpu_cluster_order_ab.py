@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Diagnostic (not a test): the same blob latents (sigma 0.5: many small clusters, a pass-bound sweep) clustered with the tuned
 kernels (ascending chain) and in the reference's evaluation order (scan.reference_order: the plain kernel).
-    python tests/gpu_cluster_order_ab.py n [max_clusters]"""
+    python tools/gpu/gpu_cluster_order_ab.py n [max_clusters]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vamb_amd import cluster as vc, synth  # noqa: E402
 n = int(sys.argv[1])

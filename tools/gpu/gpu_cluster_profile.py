@@ -1,5 +1,5 @@
 """Diagnostic (not a test): cProfile of the host side of the cluster sweep on C1-shaped latents.
-Usage on the GPU box: python tests/gpu_cluster_profile.py [contigs] [epochs]"""
+Usage on the GPU box: python tools/gpu/gpu_cluster_profile.py [contigs] [epochs]"""
 import cProfile
 import io
 import pstats

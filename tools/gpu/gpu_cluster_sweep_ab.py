@@ -2,14 +2,14 @@
 """Diagnostic (not a test): ONE trained latent matrix at a BASELINE shape, clustered several times under different
 generator settings (environment switches read when the generator is created) -- A/B of the sweep policy.
 
-    python tests/gpu_cluster_sweep_ab.py N S batch precision epochs "K1=V1,K2=V2;K1=V3;..." [out.json]
+    python tools/gpu/gpu_cluster_sweep_ab.py N S batch precision epochs "K1=V1,K2=V2;K1=V3;..." [out.json]
 """
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 n, S, bs = (int(x) for x in sys.argv[1:4])
 os.environ["VAMBHIP_PRECISION"] = sys.argv[4]

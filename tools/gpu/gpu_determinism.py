@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Diagnostic (not a test): run-to-run determinism of free-running training.
-    python tests/gpu_determinism.py dtype reps mode[epochs|steps] nsteps dropout"""
+    python tools/gpu/gpu_determinism.py dtype reps mode[epochs|steps] nsteps dropout"""
 import hashlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["VAMBHIP_PRECISION"] = sys.argv[1]
 reps = int(sys.argv[2]); mode = sys.argv[3]; nsteps = int(sys.argv[4]); drop = float(sys.argv[5])

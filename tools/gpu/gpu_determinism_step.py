@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Diagnostic (not a test): ONE free-running training step on identical fresh models, repeated; which tensors differ between
-repetitions?   python tests/gpu_determinism_step.py dtype reps [batch] [nsamples]"""
+repetitions?   python tools/gpu/gpu_determinism_step.py dtype reps [batch] [nsamples]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 os.environ["VAMBHIP_PRECISION"] = sys.argv[1]
 reps = int(sys.argv[2]); B = int(sys.argv[3]) if len(sys.argv) > 3 else 512; S = int(sys.argv[4]) if len(sys.argv) > 4 else 6

@@ -1,7 +1,7 @@
 """Diagnostic (GPU box): free-running training -> encode -> clustering through the product path on synthetic features,
 with the agreement of the bins with the synthetic genomes (tests/golden/fixture_defs.bin_quality) and the loss curve.
 
-    python tests/gpu_e2e_quality.py N S nepochs batchsize '[batchsteps]' dtype model_seed [data_seed] [out.json]
+    python tools/gpu/gpu_e2e_quality.py N S nepochs batchsize '[batchsteps]' dtype model_seed [data_seed] [out.json]
 """
 import json
 import logging
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 import fixture_defs as fd  # noqa: E402

@@ -2,7 +2,7 @@
 """Where does an epoch's wall time go? (host permutation, enqueue, GPU)"""
 import ctypes, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vamb_amd import _lib, encode as ve, synth
 lib = _lib.load()

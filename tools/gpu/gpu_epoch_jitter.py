@@ -2,7 +2,7 @@
 """Per-epoch wall time of vh_vae_train_epoch over many epochs (looking for sporadic stalls)."""
 import ctypes, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vamb_amd import _lib, encode as ve, synth
 lib = _lib.load()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Epoch time of VAE.trainmodel at a given shape / precision: python tests/gpu_epoch_time.py N S batch epochs [fp32|bf16]"""
+"""Epoch time of VAE.trainmodel at a given shape / precision: python tools/gpu/gpu_epoch_time.py N S batch epochs [fp32|bf16]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 n, S, bs, E = (int(x) for x in sys.argv[1:5])
 os.environ["VAMBHIP_PRECISION"] = sys.argv[5] if len(sys.argv) > 5 else "fp32"

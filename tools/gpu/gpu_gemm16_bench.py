@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Diagnostic (not a test): duration / TFLOP/s of the bf16-storage GEMM at the shapes of the C2 / C3 training step.
-    python tests/gpu_gemm16_bench.py [out.json]"""
+    python tools/gpu/gpu_gemm16_bench.py [out.json]"""
 import ctypes
 import json
 import os
@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vamb_amd import _lib  # noqa: E402
 

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Diagnostic (not a test): `reps` launches of ONE bf16 GEMM shape through vh_debug_gemm16, for rocprofv3 --pmc runs.
-    python tests/gpu_gemm16_one.py epi M N K reps [t]"""
+    python tools/gpu/gpu_gemm16_one.py epi M N K reps [t]"""
 import ctypes, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vamb_amd import _lib  # noqa: E402
 lib = _lib.load(); _lib.require_gpu()

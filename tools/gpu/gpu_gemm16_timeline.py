@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Diagnostic (not a test): where the time of one bf16 GEMM launch goes, from in-kernel s_memtime stamps of every workgroup.
-    python tests/gpu_gemm16_timeline.py [out.txt]"""
+    python tools/gpu/gpu_gemm16_timeline.py [out.txt]"""
 import ctypes, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vamb_amd import _lib  # noqa: E402
 lib = _lib.load(); _lib.require_gpu()

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Diagnostic (not a test): correctness + duration of every tile / pipeline variant of the bf16 GEMM, and the cost of
-the parts of the hidden-layer epilogue.   python tests/gpu_gemm16_variants.py [out.json]"""
+the parts of the hidden-layer epilogue.   python tools/gpu/gpu_gemm16_variants.py [out.json]"""
 import ctypes, json, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vamb_amd import _lib  # noqa: E402
 lib = _lib.load(); _lib.require_gpu()

@@ -2,7 +2,7 @@
 """Run one GEMM instantiation repeatedly (for rocprofv3 --pmc / --kernel-trace runs)."""
 import ctypes, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vamb_amd import _lib
 lib = _lib.load()

@@ -1,4 +1,4 @@
-"""Diagnostic: per-tensor gradient error against the fp64 oracle at a large batch (python tests/gpu_large_batch_errors.py 16384)."""
+"""Diagnostic: per-tensor gradient error against the fp64 oracle at a large batch (python tools/gpu/gpu_large_batch_errors.py 16384)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

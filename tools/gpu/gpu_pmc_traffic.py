@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """HBM-side traffic of one kernel from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass).
 
-    python tests/gpu_pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <kernel substring> <out.json>
+    python tools/gpu/gpu_pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <kernel substring> <out.json>
 
 Corrections follow /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are reported in KiB;
 on gfx950 FETCH_SIZE tallies the 128-byte requests of 16 B/lane streaming reads at 64 bytes, so it is doubled.

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Summarise a rocprofv3 kernel_stats.csv per training step: python tests/gpu_prof_summary.py stats.csv nsteps"""
+"""Summarise a rocprofv3 kernel_stats.csv per training step: python tools/gpu/gpu_prof_summary.py stats.csv nsteps"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 nsteps = float(sys.argv[2])

@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """Diagnostic: train a small model on the GPU, save it with VAE.save (encode.py:486-502 format) and store the latents
 our encode pass produces, so that oracle/check_model_pt.py can load the file with the REFERENCE's VAE.load in the build
-container and compare.   python tests/gpu_save_model.py gpurun_out/model_small.pt gpurun_out/model_small_check.npz"""
+container and compare.   python tools/gpu/gpu_save_model.py gpurun_out/model_small.pt gpurun_out/model_small_check.npz"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vamb_amd import encode as ve, synth  # noqa: E402
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Diagnostic (not a test): duration of one scan pass by matrix size and medoid count, unrolled-load kernel vs runtime-width kernel
-(VAMBHIP_SCAN_LC=1 / 0).   python tests/gpu_scan_bench.py [out.json]"""
+(VAMBHIP_SCAN_LC=1 / 0).   python tools/gpu/gpu_scan_bench.py [out.json]"""
 import json
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vamb_amd import cluster as vc, synth  # noqa: E402
 

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Diagnostic (not a test): `reps` scan passes of ONE shape, for rocprofv3 --pmc runs.
-    python tests/gpu_scan_one.py n L k reps [sigma]"""
+    python tools/gpu/gpu_scan_one.py n L k reps [sigma]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vamb_amd import cluster as vc, synth  # noqa: E402
 n, L, k, reps = (int(x) for x in sys.argv[1:5])

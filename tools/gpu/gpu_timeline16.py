@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel timeline of one bf16 training step + per-kernel totals from a rocprofv3 kernel_trace.csv:
-    python tests/gpu_timeline16.py kernel_trace.csv [k-th step]"""
+    python tools/gpu/gpu_timeline16.py kernel_trace.csv [k-th step]"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))

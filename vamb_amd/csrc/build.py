@@ -28,7 +28,11 @@ SOURCES = {
     # -fno-slp-vectorize: the SLP vectoriser pairs the fmaf chains of two rows into v_pk_fma_f32, which gfx950 issues at
     # a quarter of the v_fma_f32 rate per lane-op (measured: 17 cycles per v_pk_fma_f32 in the scan kernel); plain
     # v_fmac_f32 with a scalar query operand runs the chains at the VALU's 2 cycles per wavefront instruction
-    "cluster.hip": ["-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
+    # -pragma-unroll-threshold: the evaluation loops of the scan kernels (one drain site per (medoid, row slot) pair, up to 32 per
+    # kernel, each with the reference-order re-evaluation inlined) exceed the default budget of `#pragma unroll` (16 K
+    # instructions); left rolled they index their accumulators dynamically and spill to scratch
+    "cluster.hip": ["-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
+                    "-mllvm", "-pragma-unroll-threshold=400000"],
     "vae.hip": [],
     # prep.hip reproduces numpy's float32 results bit for bit: no fused multiply-add
     "prep.hip": ["-ffp-contract=off"],

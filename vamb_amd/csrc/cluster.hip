@@ -151,6 +151,83 @@ __device__ __forceinline__ float ref_dot(int L, FX x, FQ q) {
     return s;
 }
 
+// d = 0.5f - <x, q> in the reference's order, FOUR LANES PER PAIR.  The reference's order is a 16-lane SIMD program (AVX-512);
+// lane p = lane & 3 of a group of four plays its lanes p, p + 4, p + 8, p + 12, so the halving tree's first two levels are
+// in-lane adds and the last two are xor-2 / xor-1 exchanges.  A wavefront re-evaluates 16 pairs per call with ~12 registers and
+// one round trip to memory.  (Round 3 evaluated one pair per lane with ref_dot inlined at every drain site: 32 accumulators and 64
+// loads in flight raised the register count of EVERY scan kernel -- 56 -> 115 VGPRs for the one-medoid kernel, scratch spills in
+// the matrix-pipe kernel -- which was the 1.6x of that round's filter mode.)  x, q: strided vectors in global memory; every lane
+// of the wavefront must be active (cross-lane exchanges); all four lanes of a group return the distance.
+__device__ __forceinline__ float ref_g4_tree(float a0, float a1, float a2, float a3) {
+    const float t0 = a0 + a2;   // v[p] + v[p + 8]
+    const float t1 = a1 + a3;   // v[p + 4] + v[p + 12]
+    const float b = t0 + t1;    // a[p] + a[p + 4]
+    const float c = b + __shfl_xor(b, 2);
+    return c + __shfl_xor(c, 1);
+}
+__device__ __forceinline__ float ref_distance_g4(const float* __restrict__ x, int64_t xs, const float* __restrict__ q, int64_t qs,
+                                                 int L, int p) {
+    float s = x[0] * q[0];
+    const int nfull = (L - 1) >> 4, rem = (L - 1) & 15;
+    int k = 1;
+    if (nfull > 0) {
+        float a0 = p == 0 ? s : 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (int b = 0; b < nfull; ++b, k += 16) {
+            const int64_t c = k + p;
+            a0 = __builtin_fmaf(x[c * xs], q[c * qs], a0);
+            a1 = __builtin_fmaf(x[(c + 4) * xs], q[(c + 4) * qs], a1);
+            a2 = __builtin_fmaf(x[(c + 8) * xs], q[(c + 8) * qs], a2);
+            a3 = __builtin_fmaf(x[(c + 12) * xs], q[(c + 12) * qs], a3);
+        }
+        s = ref_g4_tree(a0, a1, a2, a3);
+    }
+    if (rem > 0) {
+        float a0 = p == 0 ? s : 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        const int64_t c = k + p;
+        if (p < rem) a0 = __builtin_fmaf(x[c * xs], q[c * qs], a0);
+        if (p + 4 < rem) a1 = __builtin_fmaf(x[(c + 4) * xs], q[(c + 4) * qs], a1);
+        if (p + 8 < rem) a2 = __builtin_fmaf(x[(c + 8) * xs], q[(c + 8) * qs], a2);
+        if (p + 12 < rem) a3 = __builtin_fmaf(x[(c + 12) * xs], q[(c + 12) * qs], a3);
+        s = ref_g4_tree(a0, a1, a2, a3);
+    }
+    return 0.5f - s;
+}
+
+// Reference-order distances for the lanes of a wavefront that `need` one (all 64 lanes must be active): sixteen pairs per round,
+// the g-th needy lane of a round served by lane group g.  xrow(r): the row vector of matrix row r (stride xs); qptr(j, &qs): the
+// query vector of medoid slot j.  Returns the lane's own new distance (d unchanged where !need).
+// Query vector of slot j: q_rows + j * q_stride_j (unit stride) when q_rows != nullptr, else column `med[j]` of Mt (stride ld).
+// (Inlined at every drain site -- up to 32 in one kernel; cluster.hip is compiled with a raised -pragma-unroll-threshold so that
+// the evaluation loops around those sites still unroll.  As a real call it would cost every kernel ~60 VGPRs: arguments of device
+// functions travel in vector registers.)
+__device__ __forceinline__ float ref_recheck_wave(bool need, float d, int32_t row, int j, const float* __restrict__ Mt,
+                                                            int64_t ld, int L, const float* __restrict__ q_rows, int q_stride_j,
+                                                            const int32_t* __restrict__ med) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+    const int g = lane >> 2;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    while (m != 0ull) {   // (uniform)
+        const unsigned long long m0 = m;
+        int src = -1;
+        for (int i = 0; i < 16 && m != 0ull; ++i) {   // (uniform) the i-th needy lane goes to group i
+            const int b = __builtin_ctzll(m);
+            m &= m - 1ull;
+            if (g == i) src = b;
+        }
+        const int from = src < 0 ? lane : src;
+        const int32_t srow = __shfl(row, from);
+        const int sj = src < 0 ? 0 : __shfl(j, from);
+        const float* q = q_rows ? q_rows + (size_t)sj * q_stride_j : Mt + med[sj];
+        const int64_t qs = q_rows ? 1 : ld;
+        const float dd = ref_distance_g4(Mt + (src < 0 ? 0 : srow), ld, q, qs, L, lane & 3);   // idle groups re-read row 0: harmless
+        const int rank = __popcll(m0 & below);
+        const float got = __shfl(dd, 4 * (rank & 15));
+        if (((m0 >> lane) & 1ull) != 0ull && rank < 16) d = got;
+    }
+    return d;
+}
+
 template <class FX>
 __device__ __forceinline__ float ref_norm(int L, FX x) {
     float acc[8];
@@ -317,17 +394,30 @@ __device__ __forceinline__ void record_pair(float d, float len, int32_t row, int
         atomicAdd(&acc_s[j * kResultWords + 1 + bin_of_in_range(d, edges_s)], rn_u64(len * (float)VH_HIST_SCALE));
 }
 
-// scan.reference_order = 2: the tuned kernels act as a FILTER -- a pair is queued when its ascending-chain distance is within
-// kRefSlack of the histogram range -- and the drain evaluates the queued pair in the reference's order (ref_dot) from the
-// resident matrix.  Two float32 evaluations of the same dot product of unit-scale vectors differ by < 1e-5 for any latent width
-// the kernels accept, so no pair the reference order would record is missed; the hot loops are untouched.
+// scan.reference_order = 2 (the default): the tuned kernels act as a FILTER -- a pair is queued when its ascending-chain
+// distance is within the slack of the histogram range -- and the drain re-evaluates a queued pair in the reference's order
+// (ref_dot, from the resident matrix) only where the two orders can decide differently: inside the medoid radius, where the
+// distance's value is recorded, and next to a bin edge.  Two float32 evaluations of the same dot product of rows of norm
+// 1 / sqrt(2) differ by less than ref_slack(L), so no pair the reference order would record is missed and every recorded
+// quantity is the reference order's, bit for bit (tests: test_scan_accumulators_bit_exact against the oracle in that order);
+// the hot loops are untouched.
 struct RefSrc {
     const float* Mt;       // resident matrix [L4][ld]
     int64_t ld;
     int L, L4;
     const float* q_rows;   // explicit query vectors [km][L4] (row-sharded execution / vh_clu_scan with queries) or nullptr
+    float slack;           // bound on |d(ascending chain) - d(reference order)| for this latent width (ref_slack below)
 };
-constexpr float kRefSlack = 1.0e-4f;
+// Two float32 evaluations of the same dot product differ by at most 2 gamma_L sum|x_i q_i| <= 2 L 2^-24 * 0.5 (rows have norm
+// 1 / sqrt(2)) plus the two roundings of 0.5f - dot: 6e-8 (L + 1).  Five times that, never below 1e-5.
+inline float ref_slack(int L) { return std::max(1.0e-5f, 3.0e-7f * (float)L); }
+
+// Can a distance within `slack` of the ascending-chain distance d fall into another histogram bin, or on the other side of the
+// last edge?  The edges are float32 linspace(0, 0.3, 61): within 1.5e-8 of i * 0.005, and d * 200 rounds by < 4e-6.
+__device__ __forceinline__ bool near_bin_edge(float d, float slack) {
+    const float t = d * 200.0f;
+    return __builtin_fabsf(t - __builtin_rintf(t)) <= slack * 200.0f + 2.0e-5f;
+}
 
 template <bool REF = false>
 __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn, int lane,
@@ -337,27 +427,29 @@ __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn
                                            const float* __restrict__ lengths = nullptr) {
     if (dbg & 8) return;   // timing experiment: queued pairs are dropped
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int e = lane; e < qn; e += 64) {
-        const float4 v = hq[e];
+    for (int e0 = 0; e0 < qn; e0 += 64) {   // (uniform trip count: the reference-order re-evaluation exchanges data across lanes)
+        const int e = e0 + lane;
+        const bool valid = e < qn;
+        const float4 v = hq[valid ? e : 0];
         const int32_t row = __float_as_int(v.z);
-        // the matrix-pipe kernel queues (d, row, medoid) only and leaves the length to this loop: a global load in its
-        // tile loop would make every tile with a pair of interest wait for the prefetched tiles behind it
-        const float len = lengths ? lengths[row] : v.y;
         const int j = __float_as_int(v.w);
         // the distance of a medoid to itself is 0 by definition (cluster.py:619), not 0.5 - <q, q>: decided here, once
         // per queued pair, instead of once per (row, medoid) pair in the scan loop
-        float d = row == med_s[j] ? 0.0f : v.x;
+        const bool self = row == med_s[j];
+        float d = self ? 0.0f : v.x;
         if constexpr (REF) {
-            if (row != med_s[j]) {
-                const float* x = ro.Mt + row;
-                const float* qr = ro.q_rows ? ro.q_rows + (size_t)j * ro.L4 : nullptr;
-                const float* qm = ro.Mt + med_s[j];
-                const int64_t ld = ro.ld;
-                d = 0.5f - ref_dot(ro.L, [&](int c) { return x[(int64_t)c * ld]; },
-                                   [&](int c) { return qr ? qr[c] : qm[(int64_t)c * ld]; });
-                if (!(d <= edges_s[VH_NBINS])) continue;   // passed the filter only
-            }
+            // The reference-order distance is within ro.slack of the chain distance.  Inside the medoid radius (+ slack) its VALUE
+            // is recorded (density), elsewhere only its histogram bin: the pair is re-evaluated in the reference's order only
+            // if it is that close to the radius or to a bin edge (0.4 % of the queued pairs at L = 32) -- everywhere else the
+            // chain distance decides exactly what the reference-order distance would.
+            const bool need = valid && !self && (d <= 0.05f + ro.slack || near_bin_edge(d, ro.slack));
+            if (__builtin_amdgcn_ballot_w64(need) != 0ull)
+                d = ref_recheck_wave(need, d, row, j, ro.Mt, ro.ld, ro.L, ro.q_rows, ro.L4, med_s);
         }
+        if (!valid || !(d <= edges_s[VH_NBINS])) continue;   // (beyond the last edge: passed the filter's slack only)
+        // the matrix-pipe kernel queues (d, row, medoid) only and leaves the length to this loop: a global load in its
+        // tile loop would make every tile with a pair of interest wait for the prefetched tiles behind it
+        const float len = lengths ? lengths[row] : v.y;
         record_pair(d, len, row, j, acc_s, lcnt_s, llist_s, edges_s, dbg);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -456,7 +548,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
         // (beyond the last histogram edge, 0.3 > radius, there is nothing to record)
         float thr[RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) thr[r] = (live[r] != 0 && !(dbg & 1)) ? (REF ? edge_hi + kRefSlack : edge_hi) : -__builtin_inff();
+        for (int r = 0; r < RPT; ++r) thr[r] = (live[r] != 0 && !(dbg & 1)) ? (REF ? edge_hi + ro.slack : edge_hi) : -__builtin_inff();
         // Evaluation of the finished dot products of medoids j0 .. j0 + NJ - 1.  Pairs of interest are rare (a medoid's
         // neighbourhood is a few hundred of 10^6 rows), so the common path is kept to two VALU instructions per pair --
         // d = 0.5 - dot and one compare whose lane mask is OR-ed on the scalar unit -- and ONE branch per group of four
@@ -708,7 +800,7 @@ __device__ __forceinline__ void scan_tile_load(ScanTile<NK>& t, const float* __r
 }
 
 template <int NK, bool REF = false>
-__global__ __launch_bounds__(kBlock) void clu_scan_mfma_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(REF && NK <= 16 ? 3 : 1, REF && NK <= 16 ? 3 : 8))) void clu_scan_mfma_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
                                                                const float* __restrict__ lengths,
                                                                const uint8_t* __restrict__ kept,
                                                                const float* __restrict__ q_ext, const MedoidRows medoid,
@@ -746,7 +838,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_mfma_kernel(const float* __re
     float dot_min = 0.5f - edge_hi;
     while (0.5f - __uint_as_float(__float_as_uint(dot_min) - 1u) <= edge_hi) dot_min = __uint_as_float(__float_as_uint(dot_min) - 1u);
     while (!(0.5f - dot_min <= edge_hi)) dot_min = __uint_as_float(__float_as_uint(dot_min) + 1u);
-    if constexpr (REF) dot_min -= kRefSlack;   // filter only: the drain decides in the reference's order
+    if constexpr (REF) dot_min -= 2.0f * ro.slack;   // filter only (slack + the rounding of 0.5f - dot): the drain decides in the reference's order
     if (dbg & 1) dot_min = __builtin_inff();   // timing experiment: no pair of interest
     int qn = 0;   // hits queued by this wavefront (uniform)
 
@@ -913,11 +1005,14 @@ __global__ __launch_bounds__(kBlock) void clu_select_kernel(const float* __restr
                                                             const float* __restrict__ q_ext, int64_t medoid,
                                                             float threshold, int remove,
                                                             int32_t* __restrict__ out_rows,
-                                                            unsigned int* __restrict__ out_count, int ref_L) {
+                                                            unsigned int* __restrict__ out_count, int ref_L, float ref_slack,
+                                                            int ref_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* q_s = reinterpret_cast<float*>(smem_raw);
+    __shared__ int32_t med_one[1];   // (the reference-order re-evaluation takes medoid rows from an array)
     const int tid = threadIdx.x;
     for (int i = tid; i < L4; i += kBlock) q_s[i] = q_ext ? q_ext[i] : Mt[(int64_t)i * ld + medoid];
+    if (tid == 0) med_one[0] = (int32_t)medoid;
     __syncthreads();
     const int lane = tid & 63;
 
@@ -950,17 +1045,25 @@ __global__ __launch_bounds__(kBlock) void clu_select_kernel(const float* __restr
             acc[2] = __builtin_fmaf(x3.z, qq.w, acc[2]);
             acc[3] = __builtin_fmaf(x3.w, qq.w, acc[3]);
         }
-        if (ref_L > 0) {   // scan.reference_order: the dot products in the reference build's order (ref_L = latent width)
+        float dist[kRowsPerThread];
 #pragma unroll
-            for (int r = 0; r < kRowsPerThread; ++r)
-                acc[r] = ref_dot(ref_L, [&](int c) { return col[(int64_t)c * ld + r]; }, [&](int c) { return q_s[c]; });
+        for (int r = 0; r < kRowsPerThread; ++r) dist[r] = 0.5f - acc[r];
+        if (ref_L > 0) {
+            // scan.reference_order: the decision d <= threshold in the reference build's order (ref_L = latent width).  The two
+            // orders differ by less than ref_slack: only a row that close to the threshold is evaluated again.
+#pragma unroll
+            for (int r = 0; r < kRowsPerThread; ++r) {
+                const bool need = ref_all || __builtin_fabsf(dist[r] - threshold) <= ref_slack;
+                if (__builtin_amdgcn_ballot_w64(need) != 0ull)   // (uniform: every lane of the wavefront is in this loop)
+                    dist[r] = ref_recheck_wave(need, dist[r], (int32_t)(base + r), 0, Mt, ld, ref_L, q_ext, 0, med_one);
+            }
         }
         const unsigned char live[4] = {kp.x, kp.y, kp.z, kp.w};
         unsigned char newlive[4] = {kp.x, kp.y, kp.z, kp.w};
         bool any_removed = false;
 #pragma unroll
         for (int r = 0; r < kRowsPerThread; ++r) {
-            float d = 0.5f - acc[r];
+            float d = dist[r];
             if (base + r == medoid) d = 0.0f;
             const bool hit = live[r] && (d <= threshold);
             const unsigned long long ball = __ballot(hit);
@@ -1213,7 +1316,7 @@ size_t scan_smem_bytes(int km, int L4) {
            (size_t)km * 4 * (2 + kLocalCap);
 }
 
-RefSrc ref_src(const vh_clu* h) { return RefSrc{h->Mt.p, h->ld, h->L, h->L4, h->q_rows_pass}; }
+RefSrc ref_src(const vh_clu* h) { return RefSrc{h->Mt.p, h->ld, h->L, h->L4, h->q_rows_pass, ref_slack(h->L)}; }
 
 template <int KM, int RPT, int LC, int PIPE, bool REF>
 void launch_scan_lc_impl(vh_clu* h, const MedoidRows& med, const float* q_ext) {
@@ -1282,8 +1385,9 @@ void launch_scan_mfma_impl(vh_clu* h, const MedoidRows& med, const float* q_ext)
         attr_set = true;
     }
     const int64_t tiles = h->ld >> 5;
-    // three workgroups per CU are resident (LDS): one resident set, every wavefront strides over its tiles
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(tiles, kBlock / 64), 256 * 3));
+    // three workgroups per CU are resident (LDS; two for latent widths above 32, whose operand registers allow two wavefronts
+    // per SIMD): one resident set, every wavefront strides over its tiles
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(tiles, kBlock / 64), 256 * (NK <= 16 ? 3 : 2)));
     hipLaunchKernelGGL((clu_scan_mfma_kernel<NK, REF>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
                        h->lengths.p, h->kept.p, q_ext, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg, ref_src(h));
 }
@@ -1424,7 +1528,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->scan_lc = (int)option("scan.column_loop", 1);
         h->use_mfma = option("scan.mfma", 1) != 0;
         {
-            const int64_t mode = option("scan.reference_order", 0);
+            const int64_t mode = option("scan.reference_order", 2);
             VH_REQUIRE(mode >= 0 && mode <= 2, "scan.reference_order: 0, 1 or 2");
             h->ref_order = mode != 0;          // normalisation + select in the reference's order
             h->ref_filter = mode == 2;         // scans: the tuned kernels (filter) instead of the plain kernel
@@ -1653,7 +1757,7 @@ int vh_clu_select_sharded(vh_clu* h, int64_t local_row, float threshold, int rem
         // local select (counts[0] is zero on entry), then the counts of all ranks
         hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
                            h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, h->q.p, local_row, threshold, remove,
-                           h->sel_rows.p, h->counts.p, h->ref_order ? h->L : 0);
+                           h->sel_rows.p, h->counts.p, h->ref_order ? h->L : 0, ref_slack(h->L), h->ref_filter ? 0 : 1);
         VH_HIP(hipGetLastError());
         h->xch_counts.ensure((size_t)world + 1);
         rccl_allgather_u32(comm, h->counts.p, h->xch_counts.p, 1, h->stream);
@@ -1730,7 +1834,7 @@ int vh_clu_select(vh_clu* h, int64_t medoid_row, const float* query, float thres
         h->timer.start(h->stream);
         hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
                            h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, q_ext, medoid_row, threshold, remove,
-                           h->sel_rows.p, h->counts.p, h->ref_order ? h->L : 0);
+                           h->sel_rows.p, h->counts.p, h->ref_order ? h->L : 0, ref_slack(h->L), h->ref_filter ? 0 : 1);
         VH_HIP(hipGetLastError());
         h->timer.stop(h->stream);
         // count and (short) row list travel through host-mapped memory; the host spins on the sequence flag
@@ -2026,10 +2130,13 @@ struct vh_gen {
         int64_t first, count;     // into removed_orig
         float cos_near, cos_far;  // 2 <e, medoid> below this: no removed row can lie within 0.05 / 0.3 of e
     };
-    std::vector<Removal> rlog;
-    std::vector<float> rlog_medoid;   // [emission][L]: the emitted medoids (pivots of the triangle-inequality filter), contiguous --
-                                      // a lazy check walks consecutive records, never the 256 MB host matrix
-    std::vector<int64_t> removed_orig;
+    std::vector<Removal> rlog;        // record of emission e is rlog[e - rlog_base]
+    std::vector<float> rlog_medoid;   // [emission - rlog_base][L]: the emitted medoids (pivots of the triangle-inequality filter),
+                                      // contiguous -- a lazy check walks consecutive records, never the 256 MB host matrix
+    std::vector<int64_t> removed_orig;   // rows of record R: removed_orig[R.first - removed_base ...]
+    // Records older than max_entry_age emissions are never read again (entries that old are dropped unseen), so the log is
+    // trimmed now and then: a 10 M-row sweep that emits millions of clusters would otherwise hold ~1 GB of host memory for nothing.
+    int64_t rlog_base = 0, removed_base = 0;
     int64_t lazy_checks = 0, lazy_cluster_tests = 0, lazy_point_tests = 0, lazy_invalid = 0, hist_kept = 0;
     // counters (bench accounting)
     int64_t scan_passes = 0, scan_medoids = 0, rows_streamed = 0;   // rows_streamed: RESIDENT rows per pass (what the kernels read)
@@ -2090,12 +2197,13 @@ bool gen_touched_since(vh_gen* g, const float* vm, int64_t from, bool far) {
     const int L = g->clu->L;
     const float* hm = g->clu->host_rows.data();
     const float limit = (far ? 0.3f : 0.05f) + 2e-3f;
-    const float* piv = g->rlog_medoid.data() + (size_t)from * L;
-    for (int64_t e = from; e < (int64_t)g->rlog.size(); ++e, piv += L) {
+    VH_REQUIRE(from >= g->rlog_base, "internal: the removal log was trimmed past an entry that is still in use");
+    const float* piv = g->rlog_medoid.data() + (size_t)(from - g->rlog_base) * L;
+    for (int64_t e = from - g->rlog_base; e < (int64_t)g->rlog.size(); ++e, piv += L) {
         const vh_gen::Removal& R = g->rlog[(size_t)e];
         g->lazy_cluster_tests++;
         if (2.0f * gen_dot(vm, piv, L) < (far ? R.cos_far : R.cos_near) - 1e-4f) continue;
-        const int64_t* rows = g->removed_orig.data() + R.first;
+        const int64_t* rows = g->removed_orig.data() + (R.first - g->removed_base);
         for (int64_t k = 0; k < R.count; ++k) __builtin_prefetch(hm + (size_t)rows[k] * L);
         for (int64_t k = 0; k < R.count; ++k) {
             g->lazy_point_tests++;
@@ -2238,9 +2346,10 @@ void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& ex
     // ... then the candidate pools of the seeds whose statistics are already there (the first round of their hill climb), and
     // the pools of those candidates (where the climb can move to)
     if (!g->spec_neighbours) return;
-    auto absent = [&](int64_t r) {   // (presence only: a stale entry is simply not refreshed ahead of time)
-        return g->stats.count(r) == 0 && !gen_is_pending(g, r) && std::find(exclude.begin(), exclude.end(), r) == exclude.end() &&
-               std::find(out.begin(), out.end(), r) == out.end();
+    auto absent = [&](int64_t r) {   // (presence only: a stale entry is simply not refreshed ahead of time; a row removed since
+                                     // the scan that listed it is never scheduled)
+        return g->kept[(size_t)r] != 0 && g->stats.count(r) == 0 && !gen_is_pending(g, r) &&
+               std::find(exclude.begin(), exclude.end(), r) == exclude.end() && std::find(out.begin(), out.end(), r) == out.end();
     };
     for (int depth = 1; depth <= g->spec_depth; ++depth) {
         for (int64_t row : upcoming) {
@@ -2254,9 +2363,11 @@ void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& ex
                     if (absent(r)) out.push_back(r);
                     continue;
                 }
-                const auto it = g->stats.find(r);
-                if (it == g->stats.end() || !it->second.have_list) continue;
-                for (int64_t r2 : it->second.within) {
+                if (g->kept[(size_t)r] == 0) continue;
+                const GenStats* nb = gen_lookup(g, r);   // (validated against the removal log: a stale list would name dead rows)
+                if (nb == nullptr || !nb->have_list) continue;
+                const std::vector<int64_t> pool2 = nb->within;   // (copy: gen_lookup may erase entries)
+                for (int64_t r2 : pool2) {
                     if (out.size() >= want) return;
                     if (r2 != r && r2 != row && absent(r2)) out.push_back(r2);
                 }
@@ -2707,7 +2818,7 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
             const double a_near = a_t + std::acos(1.0 - 2.0 * (0.05 + 2e-3)) + 1e-3;
             const double a_far = a_t + std::acos(1.0 - 2.0 * (0.3 + 2e-3)) + 1e-3;
             vh_gen::Removal R;
-            R.first = (int64_t)g->removed_orig.size();
+            R.first = g->removed_base + (int64_t)g->removed_orig.size();
             R.count = (int64_t)points.size();
             {
                 const float* mv = g->clu->host_rows.data() + (size_t)g->indices[(size_t)emitted_medoid] * g->clu->L;
@@ -2716,13 +2827,27 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
             R.cos_near = a_near < 3.14 ? (float)std::cos(a_near) : -3.0f;
             R.cos_far = a_far < 3.14 ? (float)std::cos(a_far) : -3.0f;
             for (int64_t r : points) g->removed_orig.push_back(g->indices[(size_t)r]);
-            g->rlog.push_back(R);   // rlog.size() == n_emitted + 1 from here on
+            g->rlog.push_back(R);   // rlog_base + rlog.size() == n_emitted + 1 from here on
             g->kept_entries += (int64_t)g->stats.size();
             g->kept_emissions++;
             // entries the walk has left behind: dropped in bulk now and then (their lazy check would walk a long log)
             if ((g->n_emitted & 63) == 63 || g->stats.size() > kMaxCached) {
                 for (auto it = g->stats.begin(); it != g->stats.end();)
                     it = (g->n_emitted - it->second.born > g->max_entry_age || g->stats.size() > 2 * kMaxCached) ? g->stats.erase(it) : std::next(it);
+            }
+            // ... and the log records nobody can ask for any more (every surviving entry was born, hence last checked, at most
+            // max_entry_age emissions ago; pending entries are younger still)
+            if ((g->n_emitted & 8191) == 8191) {
+                const int64_t keep_from = g->n_emitted - g->max_entry_age - 64;
+                if (keep_from > g->rlog_base) {
+                    const size_t drop = (size_t)(keep_from - g->rlog_base);
+                    const int64_t first_kept = g->rlog[drop].first;
+                    g->removed_orig.erase(g->removed_orig.begin(), g->removed_orig.begin() + (first_kept - g->removed_base));
+                    g->removed_base = first_kept;
+                    g->rlog.erase(g->rlog.begin(), g->rlog.begin() + drop);
+                    g->rlog_medoid.erase(g->rlog_medoid.begin(), g->rlog_medoid.begin() + drop * (size_t)g->clu->L);
+                    g->rlog_base = keep_from;
+                }
             }
         }
         g->n_emitted++;

@@ -1886,6 +1886,11 @@ int vh_vae_set_precision(vh_vae* h, int bf16_operands) {
         VH_REQUIRE(h != nullptr, "NULL handle");
         const bool on = bf16_operands != 0;
         if (on == h->bf16) return;
+        // the bf16 step's loss kernel stages 4 x (reconstruction row + target row) in LDS: checked HERE (VH_ERR_INVALID), not at
+        // the first training step -- VAEConcat / VAELabels with a few thousand classes reach this width (step16::loss_and_seed16)
+        VH_REQUIRE(!on || (size_t)8 * h->D_p * sizeof(float) <= 160 * 1024 - 256,
+                   "%d input columns are too wide for the bf16 step (its loss kernel holds 8 rows in LDS: at most 5112 columns); "
+                   "use the fp32 step", h->D);
         VH_HIP(hipStreamSynchronize(h->stream));
         h->bf16 = on;
         h->bs = 0;   // the per-batch plan (gradient slabs, optimiser table, workspaces) depends on the mode

@@ -17,7 +17,7 @@ from __future__ import annotations
 import sys
 
 
-def install(vamb_module=None, semisupervised: bool = False):
+def install(vamb_module=None, semisupervised: bool = False, strict: bool = False):
     """Replace the hot-path entry points of ``vamb`` by the ``vamb_amd`` ones.  Returns the dict of
     original objects (pass it to ``uninstall``).
 
@@ -26,7 +26,12 @@ def install(vamb_module=None, semisupervised: bool = False):
     joint trainer ``VAEVAE`` / ``VAEVAEHLoss`` (semisupervised_encode.py:700, taxvamb_encode.py:551) builds the two classes
     through the same module attributes and then drives them as torch modules (``.parameters()``, ``._encode``), which the
     GPU classes are not -- with the flag set, that trainer no longer works.  TaxVamb's clustering is on the GPU either way
-    (``cluster_and_write_files`` below)."""
+    (``cluster_and_write_files`` below).
+
+    ``strict=True``: a submodule of ``vamb`` that cannot be imported (``vamb.parsecontigs`` needs ``vambcore``, say) raises
+    instead of leaving that hook on the reference's path with a ``RuntimeWarning`` naming the cause."""
+    global _STRICT
+    _STRICT = bool(strict)
     from . import cluster as _cluster
     from . import encode as _encode
 
@@ -83,15 +88,23 @@ def _warn(msg: str) -> None:
     warnings.warn("vamb_amd.dropin: " + msg, RuntimeWarning, stacklevel=3)
 
 
+_STRICT = False
+
+
 def _submodule(vamb_module, name: str):
-    """``vamb.<name>``, imported on demand (None if it cannot be imported, e.g. a stub package in the tests)."""
+    """``vamb.<name>``, imported on demand.  Only a failed IMPORT (a missing dependency such as vambcore, a stub package in the
+    tests) is tolerated, and its cause is reported; any other exception raised while the module executes is a bug and
+    propagates.  ``install(strict=True)`` re-raises the ImportError as well."""
     mod = getattr(vamb_module, name, None)
     if mod is None:
         import importlib
 
         try:
             mod = importlib.import_module(vamb_module.__name__ + "." + name)
-        except Exception:
+        except ImportError as exc:
+            if _STRICT:
+                raise
+            _warn(f"{vamb_module.__name__}.{name} could not be imported ({exc!r})")
             return None
     return mod
 

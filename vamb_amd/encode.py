@@ -140,7 +140,7 @@ def make_dataloader(abundance: _np.ndarray, tnf: _np.ndarray, lengths: _np.ndarr
         raise ValueError("TNF and abundance must be Numpy arrays of dtype float32")
     mode = get_prep_mode()
     if mode != "host" and _device_prep_possible(abundance, tnf, required=(mode == "device")):
-        return _make_dataloader_device(abundance, tnf, lengths, batchsize)
+        return _make_dataloader_device(abundance, tnf, lengths, batchsize, destroy)
     if not destroy:
         abundance = abundance.copy()
         tnf = tnf.copy()
@@ -277,10 +277,13 @@ class _PreparedDataset(_torch.utils.data.Dataset):
     def _vambhip_prepared(self):
         return self
 
-    def _materialise(self):
+    def _materialise(self, into=None):
+        """Host copies of the four tensors (one download).  ``into`` = (abundance, tnf): the caller's own C-contiguous arrays
+        receive the normalised blocks (make_dataloader(destroy=True)) and back the host tensors, as torch.from_numpy does in
+        the reference."""
         if self._tensors is None:
-            d = _np.empty((self.n, self.nsamples), _np.float32)
-            t = _np.empty((self.n, NTNF), _np.float32)
+            d = into[0] if into is not None else _np.empty((self.n, self.nsamples), _np.float32)
+            t = into[1] if into is not None else _np.empty((self.n, NTNF), _np.float32)
             a = _np.empty((self.n, 1), _np.float32)
             w = _np.empty((self.n, 1), _np.float32)
             _lib.check(self._lib.vh_dataset_download(self.handle, _lib.ptr(d), _lib.ptr(t), _lib.ptr(a), _lib.ptr(w)))
@@ -306,11 +309,15 @@ class _PreparedDataset(_torch.utils.data.Dataset):
             pass
 
 
-def _make_dataloader_device(abundance: _np.ndarray, tnf: _np.ndarray, lengths: _np.ndarray, batchsize: int) -> _DataLoader:
+def _make_dataloader_device(abundance: _np.ndarray, tnf: _np.ndarray, lengths: _np.ndarray, batchsize: int,
+                            destroy: bool = False) -> _DataLoader:
     """make_dataloader (encode.py:98-126) with the O(N x columns) passes on the GPU.  The statements below are the
     reference's, in its order; wherever it reduces or rescales a whole matrix the vector comes from / goes to a kernel
     of csrc/prep.hip that reproduces numpy's float32 summation order, so the tensors are bit-identical to the host
-    path (tests/test_prep_gpu.py).  The raw arrays are uploaded once and never modified (``destroy`` is moot)."""
+    path (tests/test_prep_gpu.py).  The raw arrays are uploaded once.  ``destroy=False``: they are never modified.
+    ``destroy=True`` (encode.py:86-89: "mutate abundance and tnf array in-place"): the normalised blocks are written back
+    into the caller's arrays and the dataset's host tensors ARE those arrays, as in the reference
+    (test/test_encode.py:47-95: test_destroy, test_normalized, test_single_sample)."""
     lib = _lib.load()
     n, n_samples = abundance.shape
     h = ctypes.c_void_p()
@@ -353,6 +360,8 @@ def _make_dataloader_device(abundance: _np.ndarray, tnf: _np.ndarray, lengths: _
     finally:
         lib.vh_prep_destroy(h)
     dataset = _PreparedDataset(lib, d, n, n_samples)
+    if destroy:
+        dataset._materialise(into=(abundance, tnf))
     return _DataLoader(dataset=dataset, batch_size=batchsize, drop_last=(n > batchsize), shuffle=True, num_workers=0,
                        pin_memory=False)
 
@@ -455,7 +464,15 @@ class VAE:
         self.compute_dtype = get_compute_dtype()
         if self.compute_dtype not in ("fp32", "bf16"):
             raise ValueError(f"compute dtype must be 'fp32' or 'bf16', not {self.compute_dtype!r}")
-        _lib.check(self._lib.vh_vae_set_precision(self._h, int(self.compute_dtype == "bf16")))
+        try:
+            _lib.check(self._lib.vh_vae_set_precision(self._h, int(self.compute_dtype == "bf16")))
+        except ValueError as e:
+            # too wide for the bf16 step (a label block of several thousand classes): the fp32 step has no such limit
+            import warnings
+
+            warnings.warn(f"vamb_amd: {e}; this model runs the fp32 step", RuntimeWarning, stacklevel=2)
+            self.compute_dtype = "fp32"
+            _lib.check(self._lib.vh_vae_set_precision(self._h, 0))
 
     def _create_handle(self, cfg) -> ctypes.c_void_p:
         h = ctypes.c_void_p()

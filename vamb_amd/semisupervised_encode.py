@@ -122,6 +122,14 @@ class _LabelledMixin:
         _lib.check(self._lib.vh_vae_create_labelled(ctypes.byref(cfg), ctypes.byref(lab), ctypes.byref(h)))
         return h
 
+    def attach_communicator(self, comm, syncbn: bool = True) -> None:
+        """The label models train on one GPU: refused HERE, not after the dataset has been uploaded (VAE.attach_communicator
+        would succeed and the first epoch would fail)."""
+        if comm is not None:
+            raise NotImplementedError("data-parallel training of VAELabels / VAEConcat is not wired into the host mirror; "
+                                      "train them on one GPU")
+        super().attach_communicator(None, syncbn)
+
     def _forward_rows(self, x: _np.ndarray, eps, masks):
         b = len(x)
         r = _np.empty((b, self._row_width()), _np.float32)
@@ -156,8 +164,6 @@ class _LabelledMixin:
             data_loader = _DataLoader(dataset=data_loader.dataset, batch_size=new_bs, shuffle=True, drop_last=n_seq > new_bs,
                                       num_workers=0, pin_memory=False, collate_fn=data_loader.collate_fn)
         bs = data_loader.batch_size
-        if self._comm is not None:
-            raise NotImplementedError("data-parallel training of the label models is not wired into the host mirror yet")
         n_batches, batch = (n_seq // bs, bs) if n_seq > bs else (1, n_seq)
         means = (ctypes.c_double * (5 * count))()
         _lib.check(self._lib.vh_vae_train_epochs(self._h, count, n_batches, batch, 0, means))
