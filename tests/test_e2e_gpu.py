@@ -13,6 +13,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools", "gpu"))
 import fixture_defs as fd  # noqa: E402
 import gpu_e2e_quality as e2e  # noqa: E402
 

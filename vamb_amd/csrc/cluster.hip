@@ -216,8 +216,10 @@ __device__ __forceinline__ float ref_recheck_wave(bool need, float d, int32_t ro
             if (g == i) src = b;
         }
         const int from = src < 0 ? lane : src;
+        // (both exchanges unconditional: a bpermute executed by a subset of the lanes reads 0 from every lane outside it)
         const int32_t srow = __shfl(row, from);
-        const int sj = src < 0 ? 0 : __shfl(j, from);
+        const int sj_any = __shfl(j, from);
+        const int sj = src < 0 ? 0 : sj_any;
         const float* q = q_rows ? q_rows + (size_t)sj * q_stride_j : Mt + med[sj];
         const int64_t qs = q_rows ? 1 : ld;
         const float dd = ref_distance_g4(Mt + (src < 0 ? 0 : srow), ld, q, qs, L, lane & 3);   // idle groups re-read row 0: harmless
