@@ -15,7 +15,9 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                     GEMM BASELINE's >= 50 % target names) over the timed steps, against the dtype's MFMA peak
   roofline_hidden : the same for a 512x512 hidden layer (the GEMM shape that dominates the step's time), warm-up steps
   cluster_scan    : algorithmic bytes / kernel time of the scan + select passes (HBM bound), warm-up steps
-  c3_shape        : a short training + encode leg at the C3 shape (2 M x 1000, D = 1104) on this GPU
+  c1, c3_shape    : the WHOLE job (300 epochs + encode + sweep, one timed step each) at configs[1] (200 k x 50, fp32) and at the
+                    C3 shape (2 M x 1000, D = 1104) on this GPU
+  cluster_order   : which arithmetic the sweeps ran in (library option scan.reference_order; default = the reference's order)
   cpu_baseline    : the CPU oracle ("port") timed on a bounded sample, with its calibration against the real
                     reference measured in the build container (oracle/cpu_calibration.json)
 
@@ -68,7 +70,7 @@ def parse():
     p.add_argument("--dtype", choices=["fp32", "bf16"], default=None)
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample", type=int, default=20_000)
+    p.add_argument("--cpu-sample", type=int, default=24_000, help="contigs of the larger CPU-baseline sample (a second one of a third of it runs beside it)")
     p.add_argument("--no-c3", action="store_true", help="skip the C3-shape leg")
     p.add_argument("--no-cluster", action="store_true",
                    help="PROFILING ONLY: leave the cluster sweep out of a step (a rocprofv3 trace of a short training "
@@ -216,26 +218,32 @@ def pmc_traffic(tag):
         return None
 
 
-def c3_shape_leg(args, ve, vc, lib, _lib, synth):
-    """The WHOLE job at the C3 shape (2 M contigs x 1000 samples: 8.8 GB of features) on ONE GPU -- the shape BASELINE's 10x
-    target is quoted on: VAE.trainmodel (args.c3_epochs, default the CLI's 300) -> encode -> full cluster sweep, one timed
-    step; then the sweep once more on the same latents with HIP-event timing of every pass (its kernel-time roofline)."""
-    n, S, bs = CONFIGS["C3"][0], CONFIGS["C3"][1], CONFIGS["C3"][2]
+def config_leg(args, name, ve, vc, lib, _lib, synth, epochs):
+    """The WHOLE job at another BASELINE configuration on this GPU, as ONE timed step: VAE.trainmodel (`epochs`, default the
+    CLI's 300) -> encode -> full cluster sweep; then the sweep once more on the same latents with HIP-event timing of every
+    pass (its kernel-time roofline).  "C3": 2 M contigs x 1000 samples (8.8 GB of features), the shape BASELINE's 10x target is
+    quoted on, in the headline's dtype.  "C1": configs[1], 200 k x 50, batch 4096, fp32 MFMA."""
+    n, S, bs, lat_w, cfg_dtype = CONFIGS[name]
+    dtype = cfg_dtype if name == "C1" else args.dtype
     a3 = argparse.Namespace(**vars(args))
-    a3.contigs, a3.samples, a3.batch, a3.latent, a3.epochs, a3.no_cluster = n, S, bs, 32, args.c3_epochs, False
-    t0 = time.perf_counter()
-    ab, tnf, lens, _ = synth.features(n, S, seed=3)
-    t_synth = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    dl = ve.make_dataloader(ab, tnf, lens, batchsize=bs, destroy=True)
-    t_prep = time.perf_counter() - t0
-    prep_on_device = getattr(dl.dataset, "_vambhip_prepared", None) is not None
-    del ab, tnf
-    # allocations / kernel attributes of this shape, outside the timed step
-    run_step(ve, vc, lib, _lib, dl, lens, argparse.Namespace(**dict(vars(a3), no_cluster=True)), seed=1003, epochs=1)
-    t0 = time.perf_counter()
-    r = run_step(ve, vc, lib, _lib, dl, lens, a3, seed=3, probe_layer=0, time_scans=False)
-    t_job = time.perf_counter() - t0
+    a3.contigs, a3.samples, a3.batch, a3.latent, a3.epochs, a3.no_cluster, a3.dtype = n, S, bs, lat_w, epochs, False, dtype
+    ve.set_compute_dtype(dtype)
+    try:
+        t0 = time.perf_counter()
+        ab, tnf, lens, _ = synth.features(n, S, seed=3)
+        t_synth = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        dl = ve.make_dataloader(ab, tnf, lens, batchsize=bs, destroy=True)
+        t_prep = time.perf_counter() - t0
+        prep_on_device = getattr(dl.dataset, "_vambhip_prepared", None) is not None
+        del ab, tnf
+        # allocations / kernel attributes of this shape, outside the timed step
+        run_step(ve, vc, lib, _lib, dl, lens, argparse.Namespace(**dict(vars(a3), no_cluster=True)), seed=1003, epochs=1)
+        t0 = time.perf_counter()
+        r = run_step(ve, vc, lib, _lib, dl, lens, a3, seed=3, probe_layer=0, time_scans=False)
+        t_job = time.perf_counter() - t0
+    finally:
+        ve.set_compute_dtype(args.dtype)
     latent = r.pop("latent")
     # the same sweep with per-pass kernel timing (a stream synchronisation per pass: not part of the timed job)
     # (the timed job's generator normalised `latent` in place: destroy=True -- normalising twice is not bit-idempotent)
@@ -246,18 +254,21 @@ def c3_shape_leg(args, ve, vc, lib, _lib, synth):
     t_sweep2 = time.perf_counter() - tt
     gen._sync_native_counters()
     bk = gen._backend
-    timed = dict(scan_kernel_ms=bk.kernel_ms, scan_bytes=getattr(bk, "live_rows_streamed", bk.rows_streamed) * (4 * 32 + 5),
-                 scan_resident_bytes=bk.rows_streamed * (4 * 32 + 5), scan_passes=bk.scan_passes, scan_medoids=bk.scan_medoids,
+    L4 = (lat_w + 3) // 4 * 4
+    timed = dict(scan_kernel_ms=bk.kernel_ms, scan_bytes=getattr(bk, "live_rows_streamed", bk.rows_streamed) * (4 * L4 + 5),
+                 scan_resident_bytes=bk.rows_streamed * (4 * L4 + 5), scan_passes=bk.scan_passes, scan_medoids=bk.scan_medoids,
                  cluster_s=t_sweep2)
     bk.close()
     D = S + NTNF + 1
-    flops_contig = 12 * HIDDEN * (D + HIDDEN + 32) - 2 * D * HIDDEN
-    bf16 = args.dtype == "bf16"
+    flops_contig = 12 * HIDDEN * (D + HIDDEN + lat_w) - 2 * D * HIDDEN
+    bf16 = dtype == "bf16"
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     t_epoch = r["train_s"] / a3.epochs
-    roof = probe_roofline([r], f"first encoder layer, M={bs}, K=D={D} (padded 1120), N=512", peak)
-    return {"workload": f"C3 shape on one GPU: {n} contigs x {S} samples (D={D}), batch {bs}, {args.dtype}; whole job = "
+    roof = probe_roofline([r], f"first encoder layer, M={bs}, K=D={D} (padded {(D + 31) // 32 * 32}), N=512, "
+                               f"{'bf16 MFMA' if bf16 else 'fp32 MFMA'}", peak)
+    return {"workload": f"{name} on one GPU: {n} contigs x {S} samples (D={D}), batch {bs}, {'bf16' if bf16 else 'f32'}; whole job = "
                         f"{a3.epochs} train epochs + encode + full cluster sweep, ONE timed step",
+            "dtype": "bf16" if bf16 else "f32",
             "value": n / t_job, "unit": "contigs/s", "job_s": t_job,
             "train_s": r["train_s"], "encode_s": r["encode_s"], "cluster_s": r["cluster_s"], "setup_s": r["setup_s"],
             "clusters": r["clusters"], "clusters_second_sweep": n_clusters2, "final_loss": r["loss"],
@@ -271,21 +282,9 @@ def c3_shape_leg(args, ve, vc, lib, _lib, synth):
                                                           "wall time: the sweep of the timed job")}
 
 
-def cpu_baseline(args, latent, lens):
-    """The oracle (numpy VAE restatement + C cluster restatement) on a bounded sample of the workload, with the
-    reference's default thread count (min(cores, 8), vamb/__main__.py:27-28)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import cluster_oracle as co
-    import vae_oracle as vo
-    from vamb_amd import encode as ve, synth
-
-    threads = min(8, os.cpu_count() or 1)
-    try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=threads)
-    except Exception:
-        limiter = None
-    n = min(args.cpu_sample, args.contigs)
+def _cpu_sample(args, n, latent, lens, threads, co, vo, ve, synth, cpu_epochs=3):
+    """The oracle port on the first n contigs of the workload: seconds per training epoch, for the encode pass and for the
+    full cluster sweep of the first n GPU latents."""
     ab, tnf, ln, _ = synth.features(n, args.samples, seed=101)
     ve.set_prep_mode("host")     # the CPU baseline never touches the GPU
     dl = ve.make_dataloader(ab, tnf, ln, batchsize=args.batch, destroy=True)
@@ -296,7 +295,9 @@ def cpu_baseline(args, latent, lens):
     rng = np.random.RandomState(0)
     bs = min(args.batch, n)
     nb = max(1, n // bs)
-    cpu_epochs = 3
+    wrows = np.arange(bs)    # one untimed step: BLAS thread pool, page faults of the work arrays
+    m.train_step(d[wrows], t[wrows], a[wrows], w[wrows], rng.standard_normal((bs, args.latent)).astype(np.float32),
+                 [rng.random_sample((bs, HIDDEN)) >= 0.2 for _ in range(4)])
     t0 = time.perf_counter()
     for _ in range(cpu_epochs):
         perm = rng.permutation(n)
@@ -312,9 +313,41 @@ def cpu_baseline(args, latent, lens):
     t0 = time.perf_counter()
     nclu = sum(1 for _ in co.OracleClusterGenerator(np.ascontiguousarray(latent[:n]), lens[:n], rng_seed=1))
     t_clu = time.perf_counter() - t0
+    return dict(contigs=n, batch=bs, epoch_s=t_epoch, encode_s=t_enc, cluster_s=t_clu, clusters=nclu,
+                job_s=args.epochs * t_epoch + t_enc + t_clu, epochs_timed=cpu_epochs)
+
+
+def cpu_baseline(args, latent, lens):
+    """The oracle (numpy VAE restatement + C cluster restatement) on TWO bounded samples of the workload, with the
+    reference's default thread count (min(cores, 8), vamb/__main__.py:27-28).  Training and encoding cost is linear in the
+    number of contigs; the cluster sweep is not (every cluster costs passes over all remaining contigs), so its exponent is
+    read off the two samples and the extrapolation to the full workload is stated explicitly.  `value` is the measured
+    throughput of the LARGER sample (no extrapolation)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cluster_oracle as co
+    import vae_oracle as vo
+    from vamb_amd import encode as ve, synth
+
+    cores = os.cpu_count() or 1
+    threads = min(8, cores)
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
+    except Exception:
+        limiter = None
+    n_big = min(args.cpu_sample, args.contigs, len(latent))
+    n_small = max(1000, n_big // 3)
+    small = _cpu_sample(args, n_small, latent, lens, threads, co, vo, ve, synth)
+    big = _cpu_sample(args, n_big, latent, lens, threads, co, vo, ve, synth)
     if limiter is not None:
         limiter.restore_original_limits()
-    total = args.epochs * t_epoch + t_enc + t_clu
+    # cluster sweep: t = c n^p through the two samples; training / encoding: linear through the larger sample
+    p_clu = float(np.log(big["cluster_s"] / small["cluster_s"]) / np.log(n_big / n_small)) if n_big > n_small else 1.0
+    scale = args.contigs / n_big
+    full = dict(contigs=args.contigs, train_s=args.epochs * big["epoch_s"] * scale, encode_s=big["encode_s"] * scale,
+                cluster_s=big["cluster_s"] * scale ** p_clu)
+    full["job_s"] = full["train_s"] + full["encode_s"] + full["cluster_s"]
+    full["contigs_per_s"] = args.contigs / full["job_s"]
     calib = None
     try:
         with open(os.path.join(ROOT, "oracle", "cpu_calibration.json")) as fh:
@@ -322,17 +355,29 @@ def cpu_baseline(args, latent, lens):
         calib = {"reference_over_port": c["reference_over_port"], "measured_on": f"{c['cpu']}, {c['threads']} threads",
                  "sample": c["sample"],
                  "note": "the real reference (vamb/{encode,cluster}.py, torch CPU) and this port timed on the same sample "
-                         "in the build container (oracle/calibrate_cpu_baseline.py); > 1 means the reference is slower"}
+                         "in the build container (oracle/calibrate_cpu_baseline.py: a DIFFERENT machine from the one this "
+                         "line was measured on); > 1 means the reference is slower"}
     except (OSError, ValueError, KeyError):
         pass
-    ref_est = None if calib is None else n / (total * calib["reference_over_port"]["job_300_epochs"])
-    return dict(value=n / total, unit="contigs/s", cores=int(threads), kind="port",
-                sample=(f"{n} contigs x {args.samples} samples, batch {bs}: {cpu_epochs} oracle epochs timed "
-                        f"({t_epoch:.3f} s/epoch, numpy fp32 BLAS, {threads} threads) extrapolated to {args.epochs}, + encode "
-                        f"{t_enc:.3f} s + full cluster sweep of the first {n} GPU latents {t_clu:.3f} s "
-                        f"({nclu} clusters, scalar C, 1 thread)"),
-                epoch_s=t_epoch, encode_s=t_enc, cluster_s=t_clu, calibration_vs_reference=calib,
-                reference_estimate_contigs_per_s=ref_est)
+    ref_est = None if calib is None else n_big / (big["job_s"] * calib["reference_over_port"]["job_300_epochs"])
+    cpu_model = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), None)
+    except OSError:
+        pass
+    return dict(value=n_big / big["job_s"], unit="contigs/s", cores=int(threads), kind="port",
+                sample=(f"{n_big} contigs x {args.samples} samples, batch {big['batch']}: {big['epochs_timed']} oracle epochs timed "
+                        f"({big['epoch_s']:.3f} s/epoch, numpy fp32 BLAS, {threads} threads) extrapolated to {args.epochs}, + encode "
+                        f"{big['encode_s']:.3f} s + full cluster sweep of the first {n_big} GPU latents {big['cluster_s']:.3f} s "
+                        f"({big['clusters']} clusters, scalar C, 1 thread); second sample of {n_small} contigs beside it"),
+                epoch_s=big["epoch_s"], encode_s=big["encode_s"], cluster_s=big["cluster_s"],
+                samples=[small, big], cluster_time_exponent=p_clu,
+                host={"cpu": cpu_model, "cores_visible": int(cores), "threads_used": int(threads)},
+                extrapolated_to_workload={**full, "how": f"training and encode linear in contigs from the {n_big}-contig sample; cluster "
+                                          f"sweep t = c n^p with p = {p_clu:.2f} from the two samples (a sweep is super-linear: every "
+                                          "cluster costs passes over all remaining contigs); an estimate, not a measurement"},
+                calibration_vs_reference=calib, reference_estimate_contigs_per_s=ref_est)
 
 
 def _cluster_order(_lib):
@@ -553,13 +598,21 @@ def main():
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None
         if world == 1 and not args.no_c3 and cfg_name != "C3":
+            del dl, ab, tnf      # free the headline's dataset first (host arrays + the device copy cached on the loader)
+            if cfg_name != "C1":     # configs[1] (200 k x 50, batch 4096, fp32): ~3 s of input + ~6 s job + ~1 s timed sweep
+                if args.deadline - (time.perf_counter() - T_START) < 60.0:
+                    line["c1"] = {"skipped": "not enough of --deadline left for the extra leg"}
+                else:
+                    try:
+                        line["c1"] = config_leg(args, "C1", ve, vc, lib, _lib, synth, args.c3_epochs)
+                    except Exception as e:   # never lose the headline because of an extra leg
+                        line["c1"] = {"error": repr(e)}
             if args.deadline - (time.perf_counter() - T_START) < 330.0:   # synthetic input 35 s + job ~60 s + timed sweep ~30 s + margin
                 line["c3_shape"] = {"skipped": "not enough of --deadline left for the extra leg"}
             else:
-                del dl, ab, tnf      # free the C2 dataset first (host arrays + the device copy cached on the loader)
                 try:
-                    line["c3_shape"] = c3_shape_leg(args, ve, vc, lib, _lib, synth)
-                except Exception as e:   # never lose the headline because of the extra leg
+                    line["c3_shape"] = config_leg(args, "C3", ve, vc, lib, _lib, synth, args.c3_epochs)
+                except Exception as e:
                     line["c3_shape"] = {"error": repr(e)}
         emit_result(line)
     if comm is not None:
