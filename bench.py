@@ -22,10 +22,12 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                     reference measured in the build container (oracle/cpu_calibration.json)
 
 N > 1: `python bench.py --gpus N` launches N ranks itself (one process per GPU; the driver's
-`python -m torch.distributed.run ... bench.py --gpus N` form works too).  weak scaling (default): every rank holds its
-own shard of `--contigs` contigs, training is data-parallel (RCCL all-reduce of the flat gradient inside the library),
-encode and the cluster sweep are shard-local.  --scaling strong: ONE dataset of `--contigs` contigs is row-sharded over
-the ranks and clustered through the sharded scan (vamb_amd.parallel.sharded_cluster_generator).
+`python -m torch.distributed.run ... bench.py --gpus N` form works too).  Default (--scaling strong, --config C3 = BASELINE's
+8-GPU configuration): ONE dataset of 2 M contigs x 1000 samples row-sharded over the ranks -- data-parallel training with
+synchronised BatchNorm (RCCL all-reduce of the flat gradient and of the BatchNorm sums inside the library), shard-local encode,
+and the cluster sweep through the NATIVE sharded state machine (vh_gen_create_sharded: every rank scans its shard, one
+all-gather of exact integer accumulators per pass); on one GPU the same workload is the `c3_shape` object of the N = 1 line.
+--scaling weak: every rank holds its own dataset of `--contigs` contigs and sweeps it locally (N independent jobs).
 """
 from __future__ import annotations
 
@@ -61,14 +63,19 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--config", choices=sorted(CONFIGS), default="C2")
+    p.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                   help="default: C2 on one GPU (the largest single-GPU configuration); C3 -- BASELINE's 8-GPU configuration, "
+                        "ONE 2 M x 1000 dataset row-sharded over the ranks -- on more than one")
     p.add_argument("--epochs", type=int, default=300, help="training epochs per step (reference CLI default 300)")
     p.add_argument("--contigs", type=int, default=None, help="contigs per GPU (weak) / in total (strong)")
     p.add_argument("--samples", type=int, default=None)
     p.add_argument("--batch", type=int, default=None, help="rows per GPU and optimisation step")
     p.add_argument("--latent", type=int, default=None)
     p.add_argument("--dtype", choices=["fp32", "bf16"], default=None)
-    p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    p.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                   help="N > 1: strong (default) = ONE dataset row-sharded over the ranks -- data-parallel training with SyncBN, the "
+                        "cluster sweep through the native sharded state machine (BASELINE.json north_star's partition); weak = "
+                        "every rank holds its own dataset of --contigs contigs, shard-local sweeps")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=24_000, help="contigs of the larger CPU-baseline sample (a second one of a third of it runs beside it)")
     p.add_argument("--no-c3", action="store_true", help="skip the C3-shape leg")
@@ -83,6 +90,11 @@ def parse():
     p.add_argument("--force-dist", action="store_true",
                    help="take the multi-GPU code path (process group + RCCL communicator) even with one rank")
     a = p.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", a.gpus))
+    if a.config is None:
+        a.config = "C3" if world > 1 else "C2"
+    if a.scaling is None:
+        a.scaling = "strong" if world > 1 else "weak"
     c = CONFIGS[a.config]
     a.contigs = c[0] if a.contigs is None else a.contigs
     a.samples = c[1] if a.samples is None else a.samples
@@ -157,6 +169,7 @@ def run_step(ve, vc, lib, _lib, dl, lens, args, seed, comm=None, probe_layer=0, 
     t4 = time.perf_counter()
     if sharded is None:
         assert n_points == len(lens)
+    if getattr(gen, "_gen", None) is not None:     # native state machine (one GPU, or sharded over the ranks): its counters
         gen._sync_native_counters()
     ms, nl, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
     _lib.check(lib.vh_vae_probe_result(vae._h, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl)))
@@ -441,19 +454,25 @@ def main():
 
         comm = parallel.Communicator.from_torch_distributed(dist)
 
-    strong = args.scaling == "strong" and world > 1
+    strong = args.scaling == "strong" and (world > 1 or args.force_dist)   # (--force-dist: the multi-GPU code path on one rank)
     if strong:
         # ONE dataset, row-sharded: rank r holds rows [r n / world, (r + 1) n / world)
         ab, tnf, lens_all, _ = synth.features(args.contigs, args.samples, seed=1)
         lo, hi = rank * args.contigs // world, (rank + 1) * args.contigs // world
         ve.set_prep_mode("host")     # the normalised tensors are sliced on the host below
-        dl_full = ve.make_dataloader(ab, tnf, lens_all, batchsize=args.batch * world, destroy=True)
+        # strong scaling = the SAME job on more GPUs: the optimisation batch stays --batch rows in total (every rank contributes
+        # batch / N rows per step, north_star: "training mini-batches ... partition across the 8 GPUs"), so an epoch has the
+        # same number of optimiser steps as on one GPU
+        if args.batch % world != 0:
+            raise SystemExit(f"--batch {args.batch} is not divisible by {world} GPUs")
+        dl_full = ve.make_dataloader(ab, tnf, lens_all, batchsize=args.batch, destroy=True)
         ve.set_prep_mode("auto")
         import torch
 
         tens = [t[lo:hi].contiguous() for t in dl_full.dataset.tensors]
-        dl = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(*tens), batch_size=args.batch * world,
+        dl = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(*tens), batch_size=args.batch,
                                          shuffle=True, drop_last=True)
+        del dl_full, ab, tnf
         lens = lens_all[lo:hi]
         from vamb_amd import parallel as _par
 
@@ -468,6 +487,7 @@ def main():
         dl = ve.make_dataloader(ab, tnf, lens, batchsize=args.batch * world, destroy=True)
         prep_s = time.perf_counter() - t_prep0
         prep_on_device = getattr(dl.dataset, "_vambhip_prepared", None) is not None
+        del ab, tnf
         sharded = None
 
     def barrier():
@@ -561,12 +581,12 @@ def main():
             "config": {
                 "workload": (f"{cfg_name}: {args.contigs} contigs x {args.samples} samples "
                              f"{'in total' if strong else 'per GPU'} (D={D}), hidden 512-512, latent {args.latent}, "
-                             f"batch {args.batch} per GPU, {arith}; {args.epochs} train epochs"
+                             f"batch {str(args.batch) + ' in total (' + str(args.batch // world) + ' per GPU)' if strong else str(args.batch) + ' per GPU'}, {arith}; {args.epochs} train epochs"
                              f"{' (reference CLI default)' if args.epochs == 300 else ' (reference CLI default is 300)'}"
                              f" + encode + {'NO cluster sweep (--no-cluster: profiling run, not a headline)' if args.no_cluster else 'full cluster sweep'} per step; features resident in HBM before the clock starts "
                              "(make_dataloader -- one H2D upload + normalisation -- outside the timed region)"),
                 "contigs_per_gpu": args.contigs if not strong else args.contigs // world, "samples": args.samples,
-                "batch": args.batch, "epochs": args.epochs,
+                "batch": args.batch, "batch_per_gpu": args.batch // world if strong else args.batch, "epochs": args.epochs,
                 "parallelism": (f"dp{world}" + ("+sharded-cluster" if strong else "")) if world > 1 else "single",
             },
             "roofline": roof,
@@ -574,7 +594,7 @@ def main():
                                                     "(the GEMM shape that dominates the step), warm-up steps", peak),
             "epoch_ms": float(np.mean([r["train_s"] for r in results]) / args.epochs * 1e3),
             "us_per_train_step": float(np.mean([r["train_s"] for r in results]) / args.epochs /
-                                       max(1, (args.contigs if not strong else args.contigs // world) // args.batch) * 1e6),
+                                       max(1, args.contigs // args.batch) * 1e6),
             "train_contigs_per_s_per_epoch": float(job_contigs / (np.mean([r["train_s"] for r in results]) / args.epochs)),
             "train_s": float(np.mean([r["train_s"] for r in results])),
             "encode_ms": float(np.mean([r["encode_s"] for r in results]) * 1e3),
@@ -582,6 +602,17 @@ def main():
             "clusters_per_step": int(np.mean([r["clusters"] for r in results])),
             "cluster_scan": scan_summary(scan_src, results, ("kernel time: first warm-up step (HIP-event timing of every pass); " if warm else "kernel time: timed steps; ") + "wall time: the timed steps"),
             "cluster_order": _cluster_order(_lib),
+            "multi_gpu": None if comm is None else {
+                **comm.info(),
+                "rccl_ranks": comm.info()["reported_ranks"] if comm.info()["data_plane"] == "rccl" else None,
+                "training": "data parallel: every rank holds a row shard and contributes batch / N rows per step; loss normalised by "
+                            "the all-rank batch, BatchNorm statistics synchronised (fp64 sums all-reduced), flat gradient all-reduced "
+                            "over RCCL in two buckets (decoder side under the encoder's backward)",
+                "cluster": ("ONE latent matrix row-sharded over the ranks, the native sharded state machine (vh_gen_create_sharded): "
+                            "every rank scans its shard, one all-gather of exact integer accumulators + list parts per pass"
+                            if strong else "shard-local sweeps (weak scaling: N independent datasets)"),
+                "n1_reference": ("the c3_shape object of the N = 1 line is this workload on one GPU" if cfg_name == "C3" and strong
+                                 else None)},
             "make_dataloader": None if strong else {
                 "seconds": prep_s, "on": "device" if prep_on_device else "host",
                 "note": "outside the timed region; on the device it is ONE upload of the raw abundance / TNF matrices "
@@ -598,7 +629,7 @@ def main():
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None
         if world == 1 and not args.no_c3 and cfg_name != "C3":
-            del dl, ab, tnf      # free the headline's dataset first (host arrays + the device copy cached on the loader)
+            del dl      # free the headline's dataset first (the device copy cached on the loader)
             if cfg_name != "C1":     # configs[1] (200 k x 50, batch 4096, fp32): ~3 s of input + ~6 s job + ~1 s timed sweep
                 if args.deadline - (time.perf_counter() - T_START) < 60.0:
                     line["c1"] = {"skipped": "not enough of --deadline left for the extra leg"}

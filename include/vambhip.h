@@ -182,6 +182,15 @@ typedef struct {
 
 int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, int windowsize, int minsuccesses,
                   uint64_t rng_seed, double pack_fraction, int64_t pack_min_rows, vh_gen** out);
+/* The same state machine over a ROW-SHARDED matrix (BASELINE.json north_star: "the cluster seed search partitions across the 8
+ * GPUs"; the reference has one process).  `clu` = this rank's shard with a communicator attached (vh_clu_attach_comm; rank
+ * order = global row order); `order` = np.argsort(lengths)[::-1] of the GLOBAL lengths (n_global entries, identical on every
+ * rank).  Collective: every rank calls it and then vh_gen_next in lock step, and receives the same clusters with GLOBAL
+ * contig indices.  A pass = the shard's scan with explicit query vectors (every rank keeps a host copy of the whole normalised
+ * matrix) + ONE all-gather of the exact integer accumulators and the within-radius list parts; the sums are order-free, so
+ * the stream is bit-identical for any number of shards.  No control-plane traffic: all ranks take the same decisions. */
+int vh_gen_create_sharded(vh_clu* clu, const int64_t* order, int64_t n_global, int maxsteps, int windowsize, int minsuccesses,
+                          uint64_t rng_seed, double pack_fraction, int64_t pack_min_rows, vh_gen** out);
 int vh_gen_destroy(vh_gen* g);
 /* one Cluster (cluster.py:298-316, 545-604); members = original contig indices, ascending */
 int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap);
@@ -396,6 +405,18 @@ int vh_comm_unique_id(unsigned char* out128);
 /* collective over all ranks: ncclCommInitRank on the calling process' current device */
 int vh_comm_create(int rank, int world, const unsigned char* id128, vh_comm** out);
 int vh_comm_destroy(vh_comm* c);
+/* Host data plane: a communicator whose collectives are two caller-supplied functions on HOST memory (what a
+ * torch.distributed gloo group offers); the library stages device buffers through pinned memory around them.  For running
+ * and checking the multi-rank paths with several processes on ONE GPU (RCCL refuses two ranks per device) or where RCCL
+ * cannot be loaded -- slow by construction.  allreduce(ctx, buf, count, dtype): in-place sum, dtype 0 = float32,
+ * 1 = float64, 2 = uint64; allgather(ctx, send, recv, bytes): the ranks' blocks in rank order.  Both return 0 on success. */
+typedef int (*vh_comm_allreduce_fn)(void* ctx, void* buf, int64_t count, int dtype);
+typedef int (*vh_comm_allgather_fn)(void* ctx, const void* send, void* recv, int64_t bytes);
+int vh_comm_create_host(int rank, int world, vh_comm_allreduce_fn allreduce, vh_comm_allgather_fn allgather, void* ctx,
+                        vh_comm** out);
+/* rank / world of a communicator, the rank count the collective library itself reports (ncclCommCount; = world on the host
+ * plane) and whether it is an RCCL communicator.  Any output pointer may be NULL. */
+int vh_comm_info(vh_comm* c, int* rank, int* world, int* reported_ranks, int* is_rccl);
 /* hipDeviceSynchronize of the library's HIP runtime (the timing fence used by bench.py) */
 int vh_device_synchronize(void);
 /* Synchronised BatchNorm under data parallelism (default ON): the BatchNorm batch sums (forward: sum h, sum h^2;

@@ -89,25 +89,30 @@ def test_global_batch_normalisation(comm):
     assert np.allclose(np.array(res[1][1:]), np.array(res[0][1:]) / 2, rtol=1e-3)
 
 
+@pytest.mark.parametrize("state_machine", ["native", "python"])
 @pytest.mark.parametrize("name", ["blob_s008_n2000", "blob_s050_n3000", "blob_s008_n10000"])
-def test_rccl_sharded_cluster_stream_matches_golden(comm, name):
-    """The row-sharded cluster path on its DEVICE data plane (vh_clu_scan_sharded / vh_clu_select_sharded: query
-    exchange, int64 accumulator all-reduce and select gather over RCCL on the scan stream) with a 1-rank communicator:
-    the stream must equal the reference golden, exactly as the single-GPU path does."""
+def test_rccl_sharded_cluster_stream_matches_golden(comm, name, state_machine, monkeypatch):
+    """The row-sharded cluster path on its RCCL data plane with a 1-rank communicator: the stream must equal the reference
+    golden, exactly as the single-GPU path does.  "native": vh_gen_create_sharded (the state machine in the library, ONE
+    all-gather of accumulators + list parts per pass over RCCL); "python": the Python state machine over
+    vh_clu_scan_sharded / vh_clu_select_sharded (query exchange, int64 accumulator all-reduce, select gather)."""
     import hashlib
+
+    if state_machine == "python":
+        monkeypatch.setenv("VAMBHIP_PY_GENERATOR", "1")
 
     import fixture_defs as fd
 
     mat, lens, kw = fd.cluster_inputs(name)
     gen = parallel.sharded_cluster_generator(comm, mat.copy(), lens, rng_seed=kw.get("rng_seed", 0),
                                              **{k: v for k, v in kw.items() if k != "rng_seed"})
-    assert gen._backend.device_plane
+    assert gen._backend.device_plane and gen._sharded_native == (state_machine == "native")
     got = fd.pack_stream(list(gen))
     golden = fd.load("cluster_" + name)
     order_hash = hashlib.sha256(np.argsort(lens)[::-1].astype(np.int64).tobytes()).hexdigest()
     if str(golden["order_sha256"]) != order_hash:
         pytest.skip("np.argsort tie order differs on this CPU (unstable sort, cluster.py:275)")
-    ok, msg = fd.streams_equal(got, golden)
+    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-2)
     assert ok, msg
 
 

@@ -29,9 +29,105 @@ def _sharded_cluster_hip(comm):
         gen = parallel.sharded_cluster_generator(comm, mat[lo:hi].copy(), lens[lo:hi], **kw)   # default factory: HipScanBackend
         assert type(gen._backend.local).__name__ == "HipScanBackend"
         got = fd.pack_stream(list(gen))
-        out[name] = fd.streams_equal(got, fd.load("cluster_" + name))
+        out[name] = fd.streams_equal(got, fd.load("cluster_" + name), pvr_rtol=1e-2)
         gen._backend.local.close()
     return out
+
+
+def _sharded_cluster_native(comm_control):
+    """The NATIVE sharded state machine (vh_gen_create_sharded) on two uneven HIP shards of one GPU: its collectives (ONE
+    all-gather of accumulators + list parts per pass, the select gathers, the one-off gather of the normalised matrix) run
+    over the library's HOST data plane, i.e. over this gloo group -- RCCL refuses two ranks on one device."""
+    import fixture_defs as fd
+    from vamb_amd import _lib, cluster as vc, parallel
+
+    _lib.require_gpu()
+    vc.ClusterGenerator.PACK_MIN_ROWS = 64   # make the lazy packing happen on small fixtures
+    comm = parallel.Communicator(comm_control.dist, rccl="host")
+    assert comm.info() == {"rank": comm.rank, "world": 2, "reported_ranks": 2, "data_plane": "host"}
+    out = {}
+    for name in ("blob_s008_n2000", "blob_s050_window", "blob_zero_dup", "blob_s050_n3000", "blob_s008_n10000", "test_cluster_py"):
+        mat, lens, kw = fd.cluster_inputs(name)
+        cut = [0, int(len(mat) * 0.37), len(mat)]       # uneven shards
+        lo, hi = cut[comm.rank], cut[comm.rank + 1]
+        gen = parallel.sharded_cluster_generator(comm, mat[lo:hi].copy(), lens[lo:hi], **kw)
+        assert gen._sharded_native and gen._gen is not None
+        got = fd.pack_stream(list(gen))
+        out[name] = fd.streams_equal(got, fd.load("cluster_" + name), pvr_rtol=1e-2)
+        gen._backend.local.close()
+    comm.close()
+    return out
+
+
+def _dp_training_host_plane(comm_control):
+    """Data-parallel training of two processes on one GPU over the host data plane: two epochs of the DP path (gradient
+    all-reduce, SyncBN sums, all-rank loss normalisation) must reproduce the single-process epoch on the concatenated batch
+    -- both ranks end with the same parameters, equal to the serial run's within float32 summation-order tolerance."""
+    import ctypes
+
+    import numpy as np
+
+    from vamb_amd import _lib, encode as ve, parallel, synth
+
+    _lib.require_gpu()
+    comm = parallel.Communicator(comm_control.dist, rccl="host")
+    lib = _lib.load()
+    n, S, gb = 2048, 6, 256
+    ab, tnf, lens, _ = synth.features(n, S, seed=5)
+    ve.set_prep_mode("host")
+    dl = ve.make_dataloader(ab, tnf, lens, batchsize=gb, destroy=True)
+    ve.set_prep_mode("auto")
+    tens = [t.numpy() for t in dl.dataset.tensors]
+    w_all = tens[3].reshape(-1).astype(np.float64)
+    nb = n // gb
+    perm = np.random.RandomState(0).permutation(n)[: nb * gb].astype(np.int64).reshape(nb, gb)
+    import torch
+
+    def run_serial(rows_per_batch, dataset):
+        vae = ve.VAE(S, nhiddens=[64, 48], nlatent=8, dropout=0.0, seed=3)   # no dropout: the masks depend on the rank
+        ds = torch.utils.data.TensorDataset(*(torch.from_numpy(np.ascontiguousarray(x)) for x in dataset))
+        vae._ensure_dataset(torch.utils.data.DataLoader(ds, batch_size=rows_per_batch.shape[1], shuffle=True, drop_last=True))
+        means = (ctypes.c_double * 5)()
+        flat = np.ascontiguousarray(rows_per_batch.reshape(-1))
+        for _ in range(2):
+            _lib.check(lib.vh_vae_train_epoch(vae._h, _lib.ptr(flat), nb, rows_per_batch.shape[1], means))
+        return {k: v.numpy().copy() for k, v in vae.state_dict().items()}, list(means)
+
+    # this rank's half of every global batch: rows of its own shard (global rows [rank n / 2, (rank + 1) n / 2))
+    half = n // 2
+    lo = comm.rank * half
+    mine = [np.sort(b[(b >= lo) & (b < lo + half)]) for b in perm]
+    k = min(len(m) for m in mine)
+    k = int(comm_control.all_reduce_min(np.array([k], np.int64))[0])
+    local_rows = np.stack([m[:k] for m in mine]) - lo
+    # the serial reference trains on exactly the rows the two ranks use
+    used = comm_control.all_gather_arrays(np.stack([m[:k] for m in mine]))
+    serial_rows = np.concatenate(used, axis=1)
+    shard = [x[lo:lo + half] for x in tens]
+    # (the all-rank weight sums must be those of the rows actually used)
+    w_used = w_all[serial_rows].sum(axis=1).astype(np.float32)
+
+    def run_dp():
+        v = ve.VAE(S, nhiddens=[64, 48], nlatent=8, dropout=0.0, seed=3)
+        ds = torch.utils.data.TensorDataset(*(torch.from_numpy(np.ascontiguousarray(x)) for x in shard))
+        v._ensure_dataset(torch.utils.data.DataLoader(ds, batch_size=k, shuffle=True, drop_last=True))
+        v.attach_communicator(comm)
+        means = (ctypes.c_double * 5)()
+        flat = np.ascontiguousarray(local_rows.reshape(-1))
+        for _ in range(2):
+            _lib.check(lib.vh_vae_train_epoch_dp(v._h, _lib.ptr(flat), nb, k, 2 * k, _lib.ptr(w_used), means))
+        return {kk: vv.numpy().copy() for kk, vv in v.state_dict().items()}, list(means)
+
+    sd_dp, m_dp = run_dp()
+    sd_serial, m_serial = run_serial(serial_rows, tens)
+    worst = 0.0
+    for key in sd_serial:
+        a, b = sd_dp[key], sd_serial[key]
+        if a.dtype.kind != "f":
+            continue
+        worst = max(worst, float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12)))
+    comm.close()
+    return {"worst_rel_param_diff": worst, "means_dp": m_dp, "means_serial": m_serial}
 
 
 def test_two_processes_one_gpu_sharded_stream_equals_reference():
@@ -39,3 +135,19 @@ def test_two_processes_one_gpu_sharded_stream_equals_reference():
     for rank in (0, 1):
         for name, (ok, msg) in results[rank].items():
             assert ok, (rank, name, msg)
+
+
+def test_two_processes_one_gpu_native_sharded_state_machine_equals_reference():
+    """vh_gen_create_sharded / vh_gen_next on two ranks: both ranks emit the real reference's golden stream."""
+    results = pg._run("test_parallel_gpu:_sharded_cluster_native", world=2)
+    for rank in (0, 1):
+        for name, (ok, msg) in results[rank].items():
+            assert ok, (rank, name, msg)
+
+
+def test_two_processes_one_gpu_data_parallel_training_equals_serial():
+    results = pg._run("test_parallel_gpu:_dp_training_host_plane", world=2)
+    for rank in (0, 1):
+        r = results[rank]
+        assert r["worst_rel_param_diff"] < 2e-3, r
+        assert max(abs(a - b) for a, b in zip(r["means_dp"], r["means_serial"])) < 1e-3 * max(1.0, abs(r["means_serial"][0])), r

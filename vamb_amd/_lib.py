@@ -68,6 +68,8 @@ SIGNATURES = {
     "vh_clu_scan_list": (_int, [_vp, _i64, _int, _vp, _i64, ctypes.POINTER(_i64)]),
     "vh_gen_create": (_int, [_vp, _vp, _i64, _int, _int, _int, ctypes.c_uint64, ctypes.c_double, _i64,
                              ctypes.POINTER(_vp)]),
+    "vh_gen_create_sharded": (_int, [_vp, _vp, _i64, _int, _int, _int, ctypes.c_uint64, ctypes.c_double, _i64,
+                                     ctypes.POINTER(_vp)]),
     "vh_gen_destroy": (_int, [_vp]),
     "vh_gen_next": (_int, [_vp, ctypes.POINTER(ClusterInfo), _vp, _i64]),
     "vh_debug_find_threshold": (_int, [_vp, _i64, ctypes.c_double, ctypes.POINTER(_int), ctypes.POINTER(ctypes.c_double),
@@ -127,6 +129,8 @@ SIGNATURES = {
     "vh_comm_unique_id": (_int, [_vp]),
     "vh_comm_create": (_int, [_int, _int, _vp, _pp]),
     "vh_comm_destroy": (_int, [_vp]),
+    "vh_comm_create_host": (_int, [_int, _int, _vp, _vp, _vp, _pp]),
+    "vh_comm_info": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "vh_device_synchronize": (_int, []),
     "vh_vae_attach_comm": (_int, [_vp, _vp]),
     "vh_vae_set_syncbn": (_int, [_vp, _int]),

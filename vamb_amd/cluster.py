@@ -399,7 +399,7 @@ class ClusterGenerator:
             raise ValueError("N sequences in lengths and matrix do not match")
         self = cls.__new__(cls)
         self._backend = backend
-        self._setup(lengths, maxsteps, windowsize, minsuccesses, rng_seed)
+        self._setup(lengths, maxsteps, windowsize, minsuccesses, rng_seed, native=True)
         return self
 
     def _setup(self, lengths, maxsteps, windowsize, minsuccesses, rng_seed, native=False):
@@ -428,8 +428,10 @@ class ClusterGenerator:
         self._gen = None
         self._members_buf = None
         self._native_attempts = 0
-        if (native and isinstance(self._backend, HipScanBackend) and isinstance(rng_seed, int)
-                and abs(rng_seed) < 2 ** 64 and not _os.environ.get("VAMBHIP_PY_GENERATOR")):
+        self._sharded_native = False
+        seed_ok = isinstance(rng_seed, int) and abs(rng_seed) < 2 ** 64 and not _os.environ.get("VAMBHIP_PY_GENERATOR")
+        local = getattr(self._backend, "local", None)      # vamb_amd.parallel.ShardedScanBackend: this rank's shard
+        if native and seed_ok and isinstance(self._backend, HipScanBackend):
             handle = ctypes.c_void_p()
             order = _np.ascontiguousarray(self.order, dtype=_np.int64)
             _lib.sync_env_options()   # VAMBHIP_* variables -> library options (the .so reads no environment)
@@ -440,6 +442,19 @@ class ClusterGenerator:
             self._gen = handle
             self._backend.gen_handle = handle      # destroyed by the backend, before the handle it borrows
             self._members_buf = _np.empty(n, _np.int64)
+        elif (native and seed_ok and isinstance(local, HipScanBackend) and getattr(self._backend, "device_plane", False)):
+            # row-sharded matrix, HIP shards, a device data plane: the native state machine over all shards (collective:
+            # every rank creates it and iterates in lock step); n = GLOBAL rows
+            handle = ctypes.c_void_p()
+            order = _np.ascontiguousarray(self.order, dtype=_np.int64)
+            _lib.sync_env_options()
+            _lib.check(local.lib.vh_gen_create_sharded(local.h, _lib.ptr(order), n, int(maxsteps), int(windowsize),
+                                                       int(minsuccesses), abs(rng_seed), float(self.PACK_FRACTION),
+                                                       int(self.PACK_MIN_ROWS), ctypes.byref(handle)))
+            self._gen = handle
+            local.gen_handle = handle
+            self._members_buf = _np.empty(n, _np.int64)
+            self._sharded_native = True
 
     def _next_native(self) -> Cluster:
         info = _lib.ClusterInfo()
@@ -475,9 +490,10 @@ class ClusterGenerator:
         live = ctypes.c_int64()
         _lib.check(lib.vh_gen_live_rows(self._gen, ctypes.byref(live)))
         b.live_rows_streamed = live.value
-        n_rows, n_live = ctypes.c_int64(), ctypes.c_int64()
-        _lib.check(lib.vh_clu_rows(b.h, ctypes.byref(n_rows), ctypes.byref(n_live)))
-        b.n_rows = n_rows.value
+        if not self._sharded_native:   # (a sharded backend's n_rows is the GLOBAL row count: left to its own bookkeeping)
+            n_rows, n_live = ctypes.c_int64(), ctypes.c_int64()
+            _lib.check(lib.vh_clu_rows(b.h, ctypes.byref(n_rows), ctypes.byref(n_live)))
+            b.n_rows = n_rows.value
         self._counters_stale = False
 
     def __iter__(self):

@@ -951,14 +951,88 @@ __global__ __launch_bounds__(kBlock) void clu_gather_owned_kernel(const float* _
     }
 }
 
+constexpr int kPublishThreads = 256;    // ONE workgroup (the flag must follow every write).  Measured, C1 sweep under rocprofv3:
+                                        // 256 threads + list copy 8.4 us average / 2.9 us minimum per pass; 1024 threads 9.1 /
+                                        // 5.4 us (a 16-wavefront workgroup starts later and 1024 threads sit in the system fence)
+// ---- row-sharded pass of the NATIVE state machine: ONE collective per pass --------------------------------------------------
+// Every rank scans its shard with explicit query vectors (each rank holds a host copy of the whole normalised matrix for
+// the generator's validity checks, so no query exchange is needed) and then contributes ONE block to an all-gather:
+//   [k][63] u64   the exact integer accumulators of its shard (density, 60 bins, n_within, n_lt), replica copies folded
+//   [k][1 + kXListCap] u32   its part of every medoid's within-radius list as GLOBAL physical rows (count, rows), or the
+//                            count 0xFFFFFFFF when the part is incomplete / longer than kXListCap (the caller then selects)
+// The publishing kernel adds the accumulators of all ranks (integer sums: order-free, so the result does not depend on the
+// sharding) and hands accumulators and list parts to the host through mapped memory.
+constexpr int kXListCap = 64;
+constexpr int kXAccWords = 2 * (kResultWords - 1);              // u32 words of one medoid's 63 accumulators
+constexpr int kXMedWords = kXAccWords + 1 + kXListCap;         // u32 words of one medoid in a block
+// k: medoids of the pass (the block holds these); k_slots >= k: medoid slots the scan kernel accumulated into (a VALU pass
+// pads its medoid-count bucket with copies of medoid 0): all of them are re-zeroed for the next pass.
+__global__ __launch_bounds__(kBlock) void clu_xblock_kernel(int k, int k_slots, unsigned long long* __restrict__ results,
+                                                            const int32_t* __restrict__ lists, uint32_t row_offset,
+                                                            uint32_t* __restrict__ block) {
+    __shared__ unsigned long long nwithin_s[kMaxMedoids];
+    __shared__ unsigned int cursor_s[kMaxMedoids];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < k_slots * kResultWords; i += kBlock) {
+        const int j = i / kResultWords, w = i - j * kResultWords;
+        unsigned long long v = 0ull;
+        for (int r = 0; r < kResultReplicas; ++r) {
+            const size_t at = (size_t)r * kMaxMedoids * kResultWords + i;
+            const unsigned long long x = results[at];
+            v += x;
+            if (x != 0ull) results[at] = 0ull;
+        }
+        if (j >= k) continue;
+        if (w == kResultWords - 1) { cursor_s[j] = (unsigned int)v; continue; }   // (the list cursor lives in copy 0 only)
+        if (w == 1 + VH_NBINS) nwithin_s[j] = v;
+        block[(size_t)j * kXMedWords + 2 * w] = (uint32_t)v;
+        block[(size_t)j * kXMedWords + 2 * w + 1] = (uint32_t)(v >> 32);
+    }
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        uint32_t* out = block + (size_t)j * kXMedWords + kXAccWords;
+        const unsigned long long nw = nwithin_s[j];
+        const bool ok = (unsigned long long)cursor_s[j] == nw && nw <= (unsigned long long)kXListCap;
+        if (tid == 0) out[0] = ok ? (uint32_t)nw : 0xFFFFFFFFu;
+        if (ok && tid < (int)nw) out[1 + tid] = (uint32_t)lists[j * kListCap + tid] + row_offset;
+    }
+}
+
+__global__ __launch_bounds__(kPublishThreads) void clu_publish_sharded_kernel(int k, int world, const uint32_t* __restrict__ gathered,
+                                                                              size_t block_words,
+                                                                              unsigned long long* __restrict__ host_summary,
+                                                                              unsigned long long* __restrict__ host_hist,
+                                                                              uint32_t* __restrict__ host_lists,
+                                                                              unsigned long long* __restrict__ host_flag,
+                                                                              unsigned long long seq) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < k * (kResultWords - 1); i += kPublishThreads) {
+        const int j = i / (kResultWords - 1), w = i - j * (kResultWords - 1);
+        unsigned long long v = 0ull;
+        for (int r = 0; r < world; ++r) {
+            const uint32_t* b = gathered + (size_t)r * block_words + (size_t)j * kXMedWords + 2 * w;
+            v += (unsigned long long)b[0] | ((unsigned long long)b[1] << 32);
+        }
+        if (w == 0) host_summary[4 * j + 0] = v;
+        else if (w <= VH_NBINS) host_hist[(size_t)j * VH_NBINS + (w - 1)] = v;
+        else host_summary[4 * j + (w - VH_NBINS)] = v;   // n_within -> 1, n_lt -> 2
+    }
+    // list parts: [rank][medoid][1 + kXListCap]
+    for (int i = tid; i < world * k * (1 + kXListCap); i += kPublishThreads) {
+        const int e = i % (1 + kXListCap), rj = i / (1 + kXListCap);
+        const int j = rj % k, r = rj / k;
+        host_lists[i] = gathered[(size_t)r * block_words + (size_t)j * kXMedWords + kXAccWords + e];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // K6b: publication without a copy-engine round trip.  One block moves the accumulators and the candidate
 // lists into host-mapped memory, zeroes the accumulators for the next scan and then raises the sequence flag
 // the host spins on.  (A separate launch, not a last-block-done tail of the scan: the kernel boundary is the
 // cheap way to make the other XCDs' L2 contents visible -- a per-block agent-scope fence writes L2 back and
 // made the scan 5x slower.)
-constexpr int kPublishThreads = 256;    // ONE workgroup (the flag must follow every write).  Measured, C1 sweep under rocprofv3:
-                                        // 256 threads + list copy 8.4 us average / 2.9 us minimum per pass; 1024 threads 9.1 /
-                                        // 5.4 us (a 16-wavefront workgroup starts later and 1024 threads sit in the system fence)
 __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, unsigned long long* __restrict__ results,
                                                                       unsigned long long* __restrict__ host_summary,
                                                                       unsigned long long* __restrict__ host_hist,
@@ -1248,6 +1322,10 @@ struct vh_clu {
     vh_comm* comm = nullptr;      // row-sharded execution (vh_clu_attach_comm): the ranks holding the other shards
     int64_t max_shard_ld = 0;     // largest padded shard over the ranks (size of the select exchange buffers)
     DevBuf<uint32_t> xch_counts, xch_rows;
+    // one-collective sharded pass (native state machine): scan lists stay on the device, blocks are exchanged
+    DevBuf<int32_t> lists_dev;        // [kMaxMedoids][kListCap] local rows within the radius, appended by the scan kernels
+    DevBuf<uint32_t> xsend, xrecv;    // this rank's block / all ranks' blocks
+    uint32_t* xlists_host = nullptr;  // host-mapped [world][k][1 + kXListCap] list parts of the last sharded pass
     bool ref_filter = false;      // scan.reference_order = 2: the same arithmetic, the tuned kernels as a filter + ref_dot in their drain
     const float* q_rows_pass = nullptr;   // explicit row-major query vectors of the running pass (or nullptr)
     bool ref_order = false;       // scan.reference_order = 1: distances and normalisation in the reference build's evaluation order
@@ -1286,6 +1364,7 @@ struct vh_clu {
         if (host_results) (void)hipHostFree(host_results);
         if (sel_host) (void)hipHostFree(sel_host);
         if (sel_meta) (void)hipHostFree(sel_meta);
+        if (xlists_host) (void)hipHostFree(xlists_host);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -1616,10 +1695,15 @@ namespace {
 // Launch one pass for k medoids and wait for its publication; returns the ring slot of the results.
 // The accumulators were zeroed by the publish kernel of the previous pass, the medoid rows travel in the
 // kernel arguments and the query vectors are gathered by the scan kernel itself.
-int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries, bool sharded = false,
-              const std::function<void()>* while_waiting = nullptr) {
+// sharded: 0 = this handle alone; 1 = row-sharded, the owners' query vectors and the accumulators all-reduced (vh_clu_scan_sharded,
+// driven by the Python state machine); 2 = row-sharded with explicit queries and ONE all-gather of accumulators + list parts
+// (the native state machine; row_offset = first global physical row of this shard)
+int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries, int sharded = 0,
+              const std::function<void()>* while_waiting = nullptr, int64_t row_offset = 0) {
     VH_REQUIRE(h != nullptr && medoid_rows != nullptr, "NULL argument");
-    VH_REQUIRE(!sharded || (h->comm != nullptr && queries == nullptr), "sharded scan needs vh_clu_attach_comm and no explicit queries");
+    VH_REQUIRE(sharded == 0 || h->comm != nullptr, "sharded scan needs vh_clu_attach_comm");
+    VH_REQUIRE(sharded != 1 || queries == nullptr, "vh_clu_scan_sharded takes no explicit queries");
+    VH_REQUIRE(sharded != 2 || queries != nullptr, "internal: the one-collective sharded pass needs explicit queries");
     VH_REQUIRE(k >= 1 && k <= h->max_k, "k=%d outside [1, %d] (vh_clu_max_medoids)", k, h->max_k);
     h->mfma_pass = (h->ref_order && !h->ref_filter) || scan_uses_mfma(h, k);   // (both kernels take 32 medoid slots, the unused ones empty)
     const int km = h->mfma_pass ? kMaxMedoids : pick_km(k);
@@ -1641,7 +1725,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
         VH_HIP(hipMemcpyAsync(h->q.p, h->h_q.p, (size_t)km * h->L4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
         q_ext = h->q.p;
     }
-    if (sharded) {
+    if (sharded == 1) {
         // owners contribute their medoids' vectors, RCCL sums them on this stream: no host round trip
         hipLaunchKernelGGL(clu_gather_owned_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->Mt.p, h->ld, h->L4, med, km, h->q.p);
         VH_HIP(hipGetLastError());
@@ -1651,19 +1735,41 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
     const int slot = (int)(h->scan_seq % kListRing);
     int32_t* lists = h->lists + (size_t)slot * kMaxMedoids * kListCap;
     h->lists_pass = lists;
+    if (sharded == 2) {   // the list parts travel in the exchange block: the kernels append them on the device
+        h->lists_dev.ensure((size_t)kMaxMedoids * kListCap);
+        h->lists_pass = h->lists_dev.p;
+    }
     h->q_rows_pass = q_ext;   // row-major [km][L4] or nullptr (the quad-major copy some kernels take is made from it)
     h->timer.start(h->stream);
     dispatch_scan(h, km, med, q_ext);
     h->timer.stop(h->stream);
     // the exact integer accumulators of all shards: order-free sums, so the result does not depend on the sharding
-    if (sharded) {
+    if (sharded == 1) {
         hipLaunchKernelGGL(clu_fold_replicas_kernel, dim3(1), dim3(kBlock), 0, h->stream, km, h->results.p);
         VH_HIP(hipGetLastError());
         rccl_allreduce_sum_u64(h->comm, h->results.p, (size_t)km * kResultWords, h->stream);
     }
-    hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, h->mfma_pass ? k : km, h->results.p,
-                       h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1), h->scan_dbg);
-    VH_HIP(hipGetLastError());
+    const int world = h->comm ? h->comm->world : 1;
+    if (sharded == 2) {
+        const size_t block_words = (size_t)k * kXMedWords;
+        h->xsend.ensure(block_words);
+        h->xrecv.ensure(block_words * (size_t)world);
+        if (!h->xlists_host)
+            VH_HIP(hipHostMalloc((void**)&h->xlists_host, (size_t)world * kMaxMedoids * (1 + kXListCap) * sizeof(uint32_t),
+                                 hipHostMallocMapped | hipHostMallocCoherent));
+        hipLaunchKernelGGL(clu_xblock_kernel, dim3(1), dim3(kBlock), 0, h->stream, k, h->mfma_pass ? k : km, h->results.p,
+                           h->lists_dev.p, (uint32_t)row_offset, h->xsend.p);
+        VH_HIP(hipGetLastError());
+        rccl_allgather_bytes(h->comm, h->xsend.p, h->xrecv.p, block_words * 4, h->stream);
+        hipLaunchKernelGGL(clu_publish_sharded_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, k, world, h->xrecv.p,
+                           block_words, h->summary(slot), h->hist(slot), h->xlists_host, h->flag(),
+                           (unsigned long long)(h->scan_seq + 1));
+        VH_HIP(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, h->mfma_pass ? k : km, h->results.p,
+                           h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1), h->scan_dbg);
+        VH_HIP(hipGetLastError());
+    }
     if (while_waiting) (*while_waiting)();   // host work that does not depend on this pass, under the pass
     wait_for_scan(h, h->scan_seq + 1);
     if (h->timer.enabled) {
@@ -1673,13 +1779,35 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
     // one bulk copy of the compact summaries into ordinary memory
     unsigned long long sm[kMaxMedoids * 4];
     memcpy(sm, h->summary(slot), (size_t)k * 4 * 8);
-    h->last_summary[slot].assign(sm, sm + (size_t)k * 4);
     h->last_counts[slot].assign(kMaxMedoids, 0u);
-    for (int j = 0; j < k; ++j) {
-        const unsigned long long n_within = sm[4 * j + 1], cursor = sm[4 * j + 3];
-        // the list is complete iff every within-radius row was appended: cursor == n_within <= capacity
-        h->last_counts[slot][j] = (cursor == n_within && n_within <= (unsigned long long)kListCap)
-                                      ? (unsigned int)n_within : (unsigned int)kListCap + 1u;
+    if (sharded == 2) {
+        // merge the ranks' list parts (global rows; rank order = global row order, every part sorted here) into the ring
+        // slot the rest of the code reads lists from; a medoid with an incomplete part has no list (the caller selects)
+        for (int j = 0; j < k; ++j) {
+            int32_t* dst = lists + (size_t)j * kListCap;
+            size_t total = 0;
+            bool complete = true;
+            for (int r = 0; r < world && complete; ++r) {
+                const uint32_t* part = h->xlists_host + ((size_t)r * k + j) * (1 + kXListCap);
+                const uint32_t cnt = part[0];
+                if (cnt == 0xFFFFFFFFu || total + cnt > (size_t)kListCap) { complete = false; break; }
+                for (uint32_t i = 0; i < cnt; ++i) dst[total + i] = (int32_t)part[1 + i];
+                std::sort(dst + total, dst + total + cnt);
+                total += cnt;
+            }
+            sm[4 * j + 3] = complete ? (unsigned long long)total : ~0ull;
+            VH_REQUIRE(!complete || total == sm[4 * j + 1], "internal: sharded list parts do not add up to n_within");
+            h->last_counts[slot][j] = complete ? (unsigned int)total : (unsigned int)kListCap + 1u;
+        }
+        h->last_summary[slot].assign(sm, sm + (size_t)k * 4);
+    } else {
+        h->last_summary[slot].assign(sm, sm + (size_t)k * 4);
+        for (int j = 0; j < k; ++j) {
+            const unsigned long long n_within = sm[4 * j + 1], cursor = sm[4 * j + 3];
+            // the list is complete iff every within-radius row was appended: cursor == n_within <= capacity
+            h->last_counts[slot][j] = (cursor == n_within && n_within <= (unsigned long long)kListCap)
+                                          ? (unsigned int)n_within : (unsigned int)kListCap + 1u;
+        }
     }
     h->last_k = k;
     h->scan_seq++;
@@ -1727,7 +1855,7 @@ int vh_clu_attach_comm(vh_clu* h, vh_comm* comm) {
 int vh_clu_scan_sharded(vh_clu* h, int k, const int64_t* local_rows, vh_scan_result* out) {
     return guarded([&] {
         VH_REQUIRE(out != nullptr, "NULL argument");
-        const int slot = scan_core(h, k, local_rows, nullptr, true);
+        const int slot = scan_core(h, k, local_rows, nullptr, 1);
         const std::vector<unsigned long long>& sm = h->last_summary[slot];
         std::vector<unsigned long long> hist((size_t)k * VH_NBINS);
         memcpy(hist.data(), h->hist(slot), hist.size() * 8);
@@ -1740,54 +1868,102 @@ int vh_clu_scan_sharded(vh_clu* h, int k, const int64_t* local_rows, vh_scan_res
     });
 }
 
-int vh_clu_select_sharded(vh_clu* h, int64_t local_row, float threshold, int remove, const int64_t* row_offsets,
-                          int64_t* out_rows, int64_t cap, int64_t* n_out) {
-    return guarded([&] {
-        VH_REQUIRE(h != nullptr && n_out != nullptr && row_offsets != nullptr, "NULL argument");
-        VH_REQUIRE(h->comm != nullptr, "vh_clu_attach_comm has not been called");
-        VH_REQUIRE(local_row >= -1 && local_row < h->n_rows, "medoid row out of range");
-        VH_REQUIRE(cap >= 0 && (cap == 0 || out_rows != nullptr), "bad output buffer");
-        vh_comm* comm = h->comm;
-        const int world = comm->world;
-        h->sel_rows.ensure((size_t)std::max<int64_t>(h->ld, h->max_shard_ld));
-        // query vector from its owner
+}  // extern "C"
+
+namespace {
+
+// count + the first kSelXCap rows of a local select into one block (and the select counter re-armed): the common case -- a
+// cluster of fewer than kSelXCap members per shard -- then needs ONE all-gather
+constexpr int kSelXCap = 1023;
+__global__ __launch_bounds__(kBlock) void clu_sel_block_kernel(unsigned int* __restrict__ count, const int32_t* __restrict__ rows,
+                                                               uint32_t* __restrict__ block) {
+    const unsigned int cnt = *count;
+    const unsigned int ncopy = cnt < (unsigned int)kSelXCap ? cnt : (unsigned int)kSelXCap;
+    for (unsigned int i = threadIdx.x; i < ncopy; i += kBlock) block[1 + i] = (uint32_t)rows[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block[0] = cnt;
+        *count = 0u;
+    }
+}
+
+// sharded cluster.py:_smaller_indices.  query == nullptr: the owner of the medoid contributes its vector (all-reduce);
+// otherwise `query` is a host [L] vector every rank passes.  Returns the GLOBAL rows, ascending, in h->h_sel64.
+int64_t select_sharded_core(vh_clu* h, int64_t local_row, const float* query, float threshold, int remove,
+                            const int64_t* row_offsets, std::vector<int64_t>& out) {
+    VH_REQUIRE(h->comm != nullptr, "vh_clu_attach_comm has not been called");
+    VH_REQUIRE(local_row >= -1 && local_row < h->n_rows, "medoid row out of range");
+    vh_comm* comm = h->comm;
+    const int world = comm->world;
+    h->sel_rows.ensure((size_t)std::max<int64_t>(h->ld, h->max_shard_ld));
+    if (query) {
+        for (int c = 0; c < h->L4; ++c) h->h_q.p[c] = c < h->L ? query[c] : 0.0f;
+        VH_HIP(hipMemcpyAsync(h->q.p, h->h_q.p, (size_t)h->L4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    } else {   // query vector from its owner
         MedoidRows med;
         for (int j = 0; j < kMaxMedoids; ++j) med.row[j] = j == 0 ? local_row : -1;
         hipLaunchKernelGGL(clu_gather_owned_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->Mt.p, h->ld, h->L4, med, 1, h->q.p);
         VH_HIP(hipGetLastError());
         rccl_allreduce_sum_f32(comm, h->q.p, (size_t)h->L4, h->stream);
-        // local select (counts[0] is zero on entry), then the counts of all ranks
-        hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
-                           h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, h->q.p, local_row, threshold, remove,
-                           h->sel_rows.p, h->counts.p, h->ref_order ? h->L : 0, ref_slack(h->L), h->ref_filter ? 0 : 1);
-        VH_HIP(hipGetLastError());
-        h->xch_counts.ensure((size_t)world + 1);
-        rccl_allgather_u32(comm, h->counts.p, h->xch_counts.p, 1, h->stream);
-        std::vector<uint32_t> counts((size_t)world);
-        VH_HIP(hipMemcpyAsync(counts.data(), h->xch_counts.p, 4 * counts.size(), hipMemcpyDeviceToHost, h->stream));
-        VH_HIP(hipMemsetAsync(h->counts.p, 0, 4, h->stream));   // re-arm the select counter
+    }
+    // local select (counts[0] is zero on entry)
+    h->timer.start(h->stream);
+    hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
+                       h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, h->q.p, local_row, threshold, remove,
+                       h->sel_rows.p, h->counts.p, h->ref_order ? h->L : 0, ref_slack(h->L), h->ref_filter ? 0 : 1);
+    VH_HIP(hipGetLastError());
+    h->timer.stop(h->stream);
+    const size_t bw = 1 + (size_t)kSelXCap;
+    h->xsend.ensure(bw);
+    h->xrecv.ensure(bw * (size_t)world);
+    hipLaunchKernelGGL(clu_sel_block_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->counts.p, h->sel_rows.p, h->xsend.p);
+    VH_HIP(hipGetLastError());
+    rccl_allgather_bytes(comm, h->xsend.p, h->xrecv.p, bw * 4, h->stream);
+    std::vector<uint32_t> blocks(bw * (size_t)world);
+    VH_HIP(hipMemcpyAsync(blocks.data(), h->xrecv.p, 4 * blocks.size(), hipMemcpyDeviceToHost, h->stream));
+    VH_HIP(hipStreamSynchronize(h->stream));
+    if (h->timer.enabled) h->timer.collect();
+    uint32_t maxc = 0;
+    int64_t total = 0;
+    for (int r = 0; r < world; ++r) {
+        maxc = std::max(maxc, blocks[(size_t)r * bw]);
+        total += blocks[(size_t)r * bw];
+    }
+    std::vector<uint32_t> gathered;
+    if (maxc > (uint32_t)kSelXCap) {   // a long member list somewhere: the full lists in a second exchange
+        VH_REQUIRE((int64_t)maxc <= std::max<int64_t>(h->ld, h->max_shard_ld), "internal: select count exceeds the shard size");
+        h->xch_rows.ensure((size_t)world * maxc);
+        rccl_allgather_u32(comm, reinterpret_cast<const uint32_t*>(h->sel_rows.p), h->xch_rows.p, maxc, h->stream);
+        gathered.resize((size_t)world * maxc);
+        VH_HIP(hipMemcpyAsync(gathered.data(), h->xch_rows.p, 4 * gathered.size(), hipMemcpyDeviceToHost, h->stream));
         VH_HIP(hipStreamSynchronize(h->stream));
-        const uint32_t maxc = *std::max_element(counts.begin(), counts.end());
-        int64_t total = 0;
-        for (uint32_t c : counts) total += c;
-        std::vector<uint32_t> gathered;
-        if (maxc > 0) {
-            VH_REQUIRE((int64_t)maxc <= std::max<int64_t>(h->ld, h->max_shard_ld), "internal: select count exceeds the shard size");
-            h->xch_rows.ensure((size_t)world * maxc);
-            rccl_allgather_u32(comm, reinterpret_cast<const uint32_t*>(h->sel_rows.p), h->xch_rows.p, maxc, h->stream);
-            gathered.resize((size_t)world * maxc);
-            VH_HIP(hipMemcpyAsync(gathered.data(), h->xch_rows.p, 4 * gathered.size(), hipMemcpyDeviceToHost, h->stream));
-            VH_HIP(hipStreamSynchronize(h->stream));
-        }
-        // rank order is global row order: sort every rank's local rows, shift them by its offset
-        int64_t w = 0;
-        for (int r = 0; r < world; ++r) {
-            uint32_t* part = gathered.data() + (size_t)r * maxc;
-            std::sort(part, part + counts[(size_t)r]);
-            for (uint32_t i = 0; i < counts[(size_t)r] && w < cap; ++i) out_rows[w++] = row_offsets[r] + (int64_t)part[i];
-        }
+    }
+    // rank order is global row order: sort every rank's local rows, shift them by its offset
+    out.clear();
+    out.reserve((size_t)total);
+    for (int r = 0; r < world; ++r) {
+        const uint32_t cnt = blocks[(size_t)r * bw];
+        uint32_t* part = gathered.empty() ? blocks.data() + (size_t)r * bw + 1 : gathered.data() + (size_t)r * maxc;
+        std::sort(part, part + cnt);
+        for (uint32_t i = 0; i < cnt; ++i) out.push_back(row_offsets[r] + (int64_t)part[i]);
+    }
+    if (remove) h->n_live -= blocks[(size_t)comm->rank * bw];
+    return total;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vh_clu_select_sharded(vh_clu* h, int64_t local_row, float threshold, int remove, const int64_t* row_offsets,
+                          int64_t* out_rows, int64_t cap, int64_t* n_out) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && n_out != nullptr && row_offsets != nullptr, "NULL argument");
+        VH_REQUIRE(cap >= 0 && (cap == 0 || out_rows != nullptr), "bad output buffer");
+        std::vector<int64_t> rows;
+        const int64_t total = select_sharded_core(h, local_row, nullptr, threshold, remove, row_offsets, rows);
+        for (int64_t i = 0; i < std::min<int64_t>(cap, total); ++i) out_rows[i] = rows[(size_t)i];
         *n_out = total;
-        if (remove) h->n_live -= counts[(size_t)comm->rank];
     });
 }
 
@@ -2102,6 +2278,13 @@ enum ThresholdKind { kLoner = 0, kNoThreshold = 1, kThreshold = 2 };
 
 struct vh_gen {
     vh_clu* clu = nullptr;          // borrowed
+    // Row-sharded execution (vh_gen_create_sharded): `clu` holds this rank's shard and every rank runs this same state machine
+    // in lock step on GLOBAL physical rows (rank order = global row order; offsets[r] = first global row of rank r).  All
+    // inputs of a decision are identical on every rank -- the pass results are exact integer sums over the shards -- so the
+    // ranks take the same decisions and emit the same stream; no control-plane traffic is needed between them.
+    vh_comm* comm = nullptr;
+    std::vector<int64_t> offsets;   // [world + 1] (sharded only)
+    std::vector<float> rows_global; // the whole normalised matrix by ORIGINAL row (sharded only; clu->host_rows is the shard's)
     int maxsteps = 25, minsuccesses = 15;
     size_t windowsize = 300;
     double pack_fraction = 0.5;
@@ -2182,6 +2365,31 @@ void gen_collect_ms(vh_gen* g) {
     if (g->clu->timer.enabled) g->kernel_ms += g->clu->timer.last_ms;
 }
 
+// host copy of the normalised matrix, row-major by ORIGINAL (global) row
+const float* gen_host_rows(const vh_gen* g) { return g->comm ? g->rows_global.data() : g->clu->host_rows.data(); }
+
+// global physical row -> row of this rank's shard, or -1
+int64_t gen_local_row(const vh_gen* g, int64_t row) {
+    if (!g->comm) return row;
+    const int64_t lo = g->offsets[(size_t)g->comm->rank], hi = g->offsets[(size_t)g->comm->rank + 1];
+    return row >= lo && row < hi ? row - lo : -1;
+}
+
+// one scan pass for k medoids given by (global) physical row
+int gen_scan(vh_gen* g, int k, const int64_t* rows, const std::function<void()>* while_waiting) {
+    if (!g->comm) return scan_core(g->clu, k, rows, nullptr, 0, while_waiting);
+    const int L = g->clu->L;
+    int64_t local[kMaxMedoids];
+    std::vector<float> q((size_t)k * L);
+    const float* hm = gen_host_rows(g);
+    for (int j = 0; j < k; ++j) {
+        local[j] = gen_local_row(g, rows[j]);
+        const float* v = hm + (size_t)g->indices[(size_t)rows[j]] * L;
+        std::copy(v, v + L, q.begin() + (size_t)j * L);
+    }
+    return scan_core(g->clu, k, local, q.data(), 2, while_waiting, g->offsets[(size_t)g->comm->rank]);
+}
+
 float gen_dot(const float* a, const float* b, int L) {
     float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int c = 0;
@@ -2197,7 +2405,7 @@ float gen_dot(const float* a, const float* b, int L) {
 // scaled to norm 1 / sqrt(2), cos(angle) = 2 <x, y>; the margins cover any float32 summation order); only then row by row.
 bool gen_touched_since(vh_gen* g, const float* vm, int64_t from, bool far) {
     const int L = g->clu->L;
-    const float* hm = g->clu->host_rows.data();
+    const float* hm = gen_host_rows(g);
     const float limit = (far ? 0.3f : 0.05f) + 2e-3f;
     VH_REQUIRE(from >= g->rlog_base, "internal: the removal log was trimmed past an entry that is still in use");
     const float* piv = g->rlog_medoid.data() + (size_t)(from - g->rlog_base) * L;
@@ -2241,7 +2449,7 @@ GenStats& gen_materialise(vh_gen* g, int64_t row, int slot, int j, uint64_t seq,
     st.born = st.checked = st.hist_checked = born;
     st.hist_stale = false;
     {   // the row itself, for the validity checks of the emissions to come
-        const float* v = g->clu->host_rows.data() + (size_t)g->indices[(size_t)row] * g->clu->L;
+        const float* v = gen_host_rows(g) + (size_t)g->indices[(size_t)row] * g->clu->L;
         st.vec.assign(v, v + g->clu->L);
     }
     if (spec) {
@@ -2306,8 +2514,19 @@ GenStats* gen_lookup(vh_gen* g, int64_t row) {
 }
 
 // kept[row] = 0 for rows the state machine knows to be live: stream-ordered launch, no read-back, no wait
-void gen_remove_live(vh_gen* g, const int64_t* rows, int64_t n) {
+void gen_remove_live(vh_gen* g, const int64_t* rows_in, int64_t n_in) {
     vh_clu* h = g->clu;
+    std::vector<int64_t> mine;   // sharded: the rows of this rank's shard, as local rows
+    const int64_t* rows = rows_in;
+    int64_t n = n_in;
+    if (g->comm) {
+        for (int64_t i = 0; i < n_in; ++i) {
+            const int64_t l = gen_local_row(g, rows_in[i]);
+            if (l >= 0) mine.push_back(l);
+        }
+        rows = mine.data();
+        n = (int64_t)mine.size();
+    }
     for (int64_t lo = 0; lo < n; lo += kMaxMedoids) {
         const int k = (int)std::min<int64_t>(kMaxMedoids, n - lo);
         MedoidRows mr;
@@ -2424,7 +2643,7 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
                 GenTimer th(&g->t_book_hidden);
                 gen_flush_pending(g);
             };
-            slot = scan_core(g->clu, k, missing.data() + lo, nullptr, false, &under_the_pass);
+            slot = gen_scan(g, k, missing.data() + lo, &under_the_pass);
         }
         g->n_km[k]++;
         g->rows_km[k] += g->clu->n_rows;
@@ -2451,10 +2670,15 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
 
 int64_t gen_select(vh_gen* g, int64_t medoid, float threshold, bool remove) {
     int64_t n = 0;
-    g->sel.resize((size_t)std::max<int64_t>(1, g->clu->n_rows));
     GenTimer t(&g->t_select);
     (remove ? g->pass_select : g->pass_listsel)++;
-    gen_check(vh_clu_select(g->clu, medoid, nullptr, threshold, remove ? 1 : 0, g->sel.data(), (int64_t)g->sel.size(), &n));
+    if (g->comm) {
+        const float* q = gen_host_rows(g) + (size_t)g->indices[(size_t)medoid] * g->clu->L;
+        n = select_sharded_core(g->clu, gen_local_row(g, medoid), q, threshold, remove ? 1 : 0, g->offsets.data(), g->sel);
+    } else {
+        g->sel.resize((size_t)std::max<int64_t>(1, g->clu->n_rows));
+        gen_check(vh_clu_select(g->clu, medoid, nullptr, threshold, remove ? 1 : 0, g->sel.data(), (int64_t)g->sel.size(), &n));
+    }
     g->scan_passes++;
     g->rows_streamed += g->clu->n_rows;
     g->live_rows_streamed += g->clu->n_live + (remove ? n : 0);   // the rows that were live when the pass ran
@@ -2584,7 +2808,7 @@ void gen_fetch_hist(vh_gen* g, int64_t medoid, GenStats& st) {
                 GenTimer th(&g->t_book_hidden);
                 gen_flush_pending(g);
             };
-            (void)scan_core(g->clu, 1, &medoid, nullptr, false, &under_the_pass);
+            (void)gen_scan(g, 1, &medoid, &under_the_pass);
         }
         g->scan_passes++;
         g->pass_hist++;
@@ -2681,38 +2905,100 @@ int64_t gen_logical_index(vh_gen* g, int64_t row) {
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+
+vh_gen* gen_create_common(vh_clu* clu, vh_comm* comm, const int64_t* order, int64_t n, int maxsteps, int windowsize, int minsuccesses,
+                          uint64_t rng_seed, double pack_fraction, int64_t pack_min_rows) {
+    VH_REQUIRE(maxsteps >= 1, "maxsteps must be a positive integer, not %d", maxsteps);
+    VH_REQUIRE(windowsize >= 1, "windowsize must be at least 1, not %d", windowsize);
+    VH_REQUIRE(minsuccesses >= 1 && minsuccesses <= windowsize, "minsuccesses must be between 1 and windowsize, not %d",
+               minsuccesses);
+    std::unique_ptr<vh_gen> g(new vh_gen());
+    g->clu = clu;
+    g->comm = comm;
+    g->maxsteps = maxsteps;
+    g->windowsize = (size_t)windowsize;
+    g->minsuccesses = minsuccesses;
+    g->pack_fraction = pack_fraction;
+    g->pack_min_rows = pack_min_rows;
+    g->rng.seed(rng_seed);
+    g->profile = option("gen.profile", 0) != 0;
+    g->speculate = option("gen.speculate", 1) != 0;
+    g->spec_window = (int)option("gen.spec_window", kSpecWindow);
+    g->spec_neighbours = option("gen.spec_neighbours", 1) != 0;
+    g->max_entry_age = option("gen.max_entry_age", kMaxEntryAgeDefault);
+    g->spec_depth = (int)option("gen.spec_depth", 2);
+    g->defer_book = option("gen.defer_bookkeeping", 1) != 0;
+    g->spec_big_target = (int)option("gen.spec_big_target", 0);
+    g->order.assign(order, order + n);
+    g->indices.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) g->indices[(size_t)i] = i;
+    g->kept.assign((size_t)n, 1);
+    g->alive.assign((size_t)n, 1);
+    gen_bit_build(g.get());
+    g->n_remaining = n;
+    return g.release();
+}
+
+}  // namespace
+
+extern "C" {
+
 int vh_gen_create(vh_clu* clu, const int64_t* order, int64_t n, int maxsteps, int windowsize, int minsuccesses,
                   uint64_t rng_seed, double pack_fraction, int64_t pack_min_rows, vh_gen** out) {
     return guarded([&] {
         VH_REQUIRE(clu != nullptr && order != nullptr && out != nullptr, "NULL argument");
         VH_REQUIRE(n == clu->n_rows && n >= 1, "order length does not match the matrix");
-        VH_REQUIRE(maxsteps >= 1, "maxsteps must be a positive integer, not %d", maxsteps);
-        VH_REQUIRE(windowsize >= 1, "windowsize must be at least 1, not %d", windowsize);
-        VH_REQUIRE(minsuccesses >= 1 && minsuccesses <= windowsize, "minsuccesses must be between 1 and windowsize, not %d",
-                   minsuccesses);
-        std::unique_ptr<vh_gen> g(new vh_gen());
-        g->clu = clu;
-        g->maxsteps = maxsteps;
-        g->windowsize = (size_t)windowsize;
-        g->minsuccesses = minsuccesses;
-        g->pack_fraction = pack_fraction;
-        g->pack_min_rows = pack_min_rows;
-        g->rng.seed(rng_seed);
-        g->profile = option("gen.profile", 0) != 0;
-        g->speculate = option("gen.speculate", 1) != 0;
-        g->spec_window = (int)option("gen.spec_window", kSpecWindow);
-        g->spec_neighbours = option("gen.spec_neighbours", 1) != 0;
-        g->max_entry_age = option("gen.max_entry_age", kMaxEntryAgeDefault);
-        g->spec_depth = (int)option("gen.spec_depth", 2);
-        g->defer_book = option("gen.defer_bookkeeping", 1) != 0;
-        g->spec_big_target = (int)option("gen.spec_big_target", 0);
-        g->order.assign(order, order + n);
-        g->indices.resize((size_t)n);
-        for (int64_t i = 0; i < n; ++i) g->indices[(size_t)i] = i;
-        g->kept.assign((size_t)n, 1);
-        g->alive.assign((size_t)n, 1);
-        gen_bit_build(g.get());
-        g->n_remaining = n;
+        *out = gen_create_common(clu, nullptr, order, n, maxsteps, windowsize, minsuccesses, rng_seed, pack_fraction, pack_min_rows);
+    });
+}
+
+// The state machine over a ROW-SHARDED matrix: `clu` is this rank's shard with a communicator attached (vh_clu_attach_comm);
+// `order` = np.argsort(lengths)[::-1] of the GLOBAL lengths (n_global entries, identical on every rank).  Collective: every
+// rank calls it, and afterwards vh_gen_next, in lock step; every rank receives the same clusters with GLOBAL row indices.
+int vh_gen_create_sharded(vh_clu* clu, const int64_t* order, int64_t n_global, int maxsteps, int windowsize, int minsuccesses,
+                          uint64_t rng_seed, double pack_fraction, int64_t pack_min_rows, vh_gen** out) {
+    return guarded([&] {
+        VH_REQUIRE(clu != nullptr && order != nullptr && out != nullptr, "NULL argument");
+        VH_REQUIRE(clu->comm != nullptr, "vh_clu_attach_comm has not been called");
+        VH_REQUIRE(clu->n_rows == clu->n_live && (int64_t)clu->host_rows.size() == clu->n_rows * clu->L,
+                   "the sharded state machine needs a freshly created handle");
+        vh_comm* comm = clu->comm;
+        const int world = comm->world, L = clu->L;
+        // shard sizes -> offsets
+        clu->xch_counts.ensure((size_t)world + 1);
+        const uint32_t mine = (uint32_t)clu->n_rows;
+        VH_HIP(hipMemcpyAsync(clu->xch_counts.p + world, &mine, 4, hipMemcpyHostToDevice, clu->stream));
+        rccl_allgather_u32(comm, clu->xch_counts.p + world, clu->xch_counts.p, 1, clu->stream);
+        std::vector<uint32_t> sizes((size_t)world);
+        VH_HIP(hipMemcpyAsync(sizes.data(), clu->xch_counts.p, 4 * sizes.size(), hipMemcpyDeviceToHost, clu->stream));
+        VH_HIP(hipStreamSynchronize(clu->stream));
+        std::vector<int64_t> off((size_t)world + 1, 0);
+        for (int r = 0; r < world; ++r) off[(size_t)r + 1] = off[(size_t)r] + sizes[(size_t)r];
+        VH_REQUIRE(off.back() == n_global, "order length %lld does not match the %lld rows of all shards", (long long)n_global,
+                   (long long)off.back());
+        VH_REQUIRE(n_global < ((int64_t)1 << 31) - 4096, "more than 2^31 rows in total are not supported");
+        std::unique_ptr<vh_gen> g(gen_create_common(clu, comm, order, n_global, maxsteps, windowsize, minsuccesses, rng_seed,
+                                                    pack_fraction, pack_min_rows));
+        g->offsets = off;
+        // the whole normalised matrix on every rank (validity checks of cached statistics, query vectors of foreign medoids):
+        // equal-sized padded blocks through one all-gather
+        const size_t max_rows = *std::max_element(sizes.begin(), sizes.end());
+        const size_t block = max_rows * (size_t)L;
+        DevBuf<float> send, recv;
+        send.alloc(block);
+        recv.alloc(block * (size_t)world);
+        VH_HIP(hipMemsetAsync(send.p, 0, block * sizeof(float), clu->stream));
+        VH_HIP(hipMemcpyAsync(send.p, clu->host_rows.data(), clu->host_rows.size() * sizeof(float), hipMemcpyHostToDevice, clu->stream));
+        rccl_allgather_bytes(comm, send.p, recv.p, block * sizeof(float), clu->stream);
+        g->rows_global.resize((size_t)n_global * L);
+        for (int r = 0; r < world; ++r)
+            if (sizes[(size_t)r])
+                VH_HIP(hipMemcpyAsync(g->rows_global.data() + (size_t)off[(size_t)r] * L, recv.p + (size_t)r * block,
+                                      (size_t)sizes[(size_t)r] * L * sizeof(float), hipMemcpyDeviceToHost, clu->stream));
+        VH_HIP(hipStreamSynchronize(clu->stream));
         *out = g.release();
     });
 }
@@ -2823,7 +3109,7 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
             R.first = g->removed_base + (int64_t)g->removed_orig.size();
             R.count = (int64_t)points.size();
             {
-                const float* mv = g->clu->host_rows.data() + (size_t)g->indices[(size_t)emitted_medoid] * g->clu->L;
+                const float* mv = gen_host_rows(g) + (size_t)g->indices[(size_t)emitted_medoid] * g->clu->L;
                 g->rlog_medoid.insert(g->rlog_medoid.end(), mv, mv + g->clu->L);
             }
             R.cos_near = a_near < 3.14 ? (float)std::cos(a_near) : -3.0f;
@@ -2863,6 +3149,17 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
         if (g->n_remaining > 0 && n_rows >= g->pack_min_rows && (double)g->n_remaining < g->pack_fraction * (double)n_rows) {
             int64_t new_n = 0;
             gen_check(vh_clu_pack(g->clu, &new_n));
+            if (g->comm) {   // every rank packed its own shard: the new offsets follow from the (replicated) live mask
+                std::vector<int64_t> off(g->offsets.size(), 0);
+                for (size_t r = 0; r + 1 < g->offsets.size(); ++r) {
+                    int64_t live = 0;
+                    for (int64_t i = g->offsets[r]; i < g->offsets[r + 1]; ++i) live += g->kept[(size_t)i] != 0;
+                    off[r + 1] = off[r] + live;
+                }
+                VH_REQUIRE(off[(size_t)g->comm->rank + 1] - off[(size_t)g->comm->rank] == new_n, "pack bookkeeping mismatch (shard)");
+                g->offsets = off;
+                new_n = off.back();
+            }
             g->stats.clear();   // physical row numbers change
             g->pending.clear();
             g->pending_mark.assign(g->pending_mark.size(), 0);

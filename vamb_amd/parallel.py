@@ -37,14 +37,23 @@ class Communicator:
     """A torch.distributed group (control plane) plus, optionally, an RCCL communicator owned by
     libvambhip (data plane)."""
 
-    def __init__(self, dist, group=None, rccl: bool = True):
+    def __init__(self, dist, group=None, rccl=True):
+        """``rccl``: True = an RCCL communicator inside libvambhip (one rank per GPU); ``"host"`` = the library's HOST data
+        plane: its collectives are carried out by this process group through two callbacks (``vh_comm_create_host``) --
+        for running the multi-rank device paths with several processes on one GPU, where RCCL refuses to start; False = no
+        device data plane at all (the exchanges of the sharded scan run in Python on the control plane)."""
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.handle = None
         self._lib = None
-        if rccl:
+        self.data_plane = "rccl" if rccl is True else ("host" if rccl == "host" else None)
+        if rccl == "host":
+            self._lib = _lib.load()
+            _lib.sync_env_options()
+            self._make_host_plane()
+        elif rccl:
             self._lib = _lib.load()
             _lib.sync_env_options()
             ident = (ctypes.c_ubyte * 128)()
@@ -58,8 +67,54 @@ class Communicator:
             self.handle = h
 
     @classmethod
-    def from_torch_distributed(cls, dist, group=None, rccl: bool = True) -> "Communicator":
+    def from_torch_distributed(cls, dist, group=None, rccl=True) -> "Communicator":
         return cls(dist, group, rccl)
+
+    def _make_host_plane(self):
+        import traceback
+
+        import torch
+
+        dist, group, world = self.dist, self.group, self.world
+        np_types = {0: (_np.float32, ctypes.c_float), 1: (_np.float64, ctypes.c_double), 2: (_np.int64, ctypes.c_int64)}
+
+        def allreduce(_ctx, buf, count, dtype):
+            try:
+                _, ct = np_types[int(dtype)]   # (uint64 sums as int64: the same bits)
+                arr = _np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ct)), shape=(int(count),))
+                dist.all_reduce(torch.from_numpy(arr), op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except Exception:   # an exception must not unwind through the C caller
+                traceback.print_exc()
+                return 1
+
+        def allgather(_ctx, send, recv, nbytes):
+            try:
+                nbytes = int(nbytes)
+                s_arr = _np.ctypeslib.as_array(ctypes.cast(send, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,))
+                r_arr = _np.ctypeslib.as_array(ctypes.cast(recv, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes * world,))
+                parts = [torch.from_numpy(r_arr[i * nbytes:(i + 1) * nbytes]) for i in range(world)]
+                dist.all_gather(parts, torch.from_numpy(s_arr.copy()), group=group)
+                return 0
+            except Exception:
+                traceback.print_exc()
+                return 1
+
+        ar_t = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int)
+        ag_t = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+        self._callbacks = (ar_t(allreduce), ag_t(allgather))   # kept alive as long as the communicator
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.vh_comm_create_host(self.rank, self.world, ctypes.cast(self._callbacks[0], ctypes.c_void_p),
+                                                 ctypes.cast(self._callbacks[1], ctypes.c_void_p), None, ctypes.byref(h)))
+        self.handle = h
+
+    def info(self) -> dict:
+        """rank / world, the rank count the collective library itself reports (ncclCommCount) and the kind of data plane."""
+        if self.handle is None:
+            return {"rank": self.rank, "world": self.world, "reported_ranks": None, "data_plane": None}
+        r, w, n, is_rccl = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self._lib.vh_comm_info(self.handle, ctypes.byref(r), ctypes.byref(w), ctypes.byref(n), ctypes.byref(is_rccl)))
+        return {"rank": r.value, "world": w.value, "reported_ranks": n.value, "data_plane": "rccl" if is_rccl.value else "host"}
 
     def close(self):
         if self.handle is not None and self._lib is not None:
@@ -145,6 +200,7 @@ class ShardedScanBackend:
             _lib.check(local_backend.lib.vh_clu_attach_comm(local_backend.h, comm.handle))
             self._res = (_lib.ScanResult * _MAX_MEDOIDS_PER_PASS)()
             self._sel = _np.empty(1, _np.int64)
+            self.lib, self.h = local_backend.lib, local_backend.h   # (the native sharded state machine drives the shard's handle)
         self._refresh_offsets()
         self.scan_passes = 0
         self.scan_medoids = 0
@@ -257,5 +313,8 @@ def sharded_cluster_generator(comm: Communicator, local_matrix: _np.ndarray, loc
     out = local_matrix if (destroy and not normalized) else None
     local = factory(local_matrix, lf, normalized, out)
     backend = ShardedScanBackend(comm, local)
+    # HIP shards + a device data plane (RCCL, or the host plane of the tests): the NATIVE sharded state machine
+    # (vh_gen_create_sharded: same speculation and lazy validation as on one GPU, one collective per pass, no Python between
+    # the passes); otherwise the Python state machine on this backend (the CPU oracle backend of the tests, rccl=False)
     return ClusterGenerator.from_backend(backend, lengths_global, maxsteps=maxsteps, windowsize=windowsize,
                                          minsuccesses=minsuccesses, rng_seed=rng_seed)
