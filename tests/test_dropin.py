@@ -39,6 +39,7 @@ def test_install_and_uninstall():
 
 @pytest.mark.skipif(not ref_harness.reference_available(), reason="reference tree not present")
 def test_semisupervised_classes_mirror_the_reference():
+    import torch
     """Row N4: VAELabels / VAEConcat and their loaders keep the reference's signatures (names and defaults;
     semisupervised_encode.py:111-175, 189-436, 438-698), write state_dicts of the reference's names and shapes, and
     dropin.install(semisupervised=True) binds them."""
@@ -75,9 +76,15 @@ def test_semisupervised_classes_mirror_the_reference():
     try:
         assert ss.VAELabels is vs.VAELabels and ss.VAEConcat is vs.VAEConcat
         assert ss.make_dataloader_concat is vs.make_dataloader_concat
+        # the reference's joint trainer (semisupervised_encode.py:700-770) still builds -- and gets -- its own torch networks
+        joint = ss.VAEVAE(6, 130, nhiddens=[48, 40], nlatent=8)
+        assert type(joint.VAELabels) is theirs and isinstance(joint.VAEJoint, torch.nn.Module)
+        assert isinstance(joint.VAEVamb, torch.nn.Module) and len(list(joint.VAEVamb.parameters())) > 0
+        assert ss.VAELabels is vs.VAELabels      # ... and the module attributes point at the GPU classes again
     finally:
         dropin.uninstall(saved, vamb)
     assert ss.VAELabels is theirs
+    assert not getattr(ss.VAEVAE.__init__, "_vamb_amd_wrapped", False)
 
 
 @pytest.mark.skipif(not ref_harness.reference_available(), reason="reference tree not present")
