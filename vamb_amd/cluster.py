@@ -404,6 +404,8 @@ class ClusterGenerator:
 
     def _setup(self, lengths, maxsteps, windowsize, minsuccesses, rng_seed, native=False):
         self._gen = None
+        if _os.environ.get("VAMBHIP_PACK_FRACTION"):     # A/B runs of the packing policy (results do not depend on it)
+            self.PACK_FRACTION = float(_os.environ["VAMBHIP_PACK_FRACTION"])
         self.maxsteps: int = maxsteps
         self.minsuccesses: int = minsuccesses
         self.cuda: bool = True

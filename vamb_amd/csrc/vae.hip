@@ -288,6 +288,9 @@ struct vh_vae {
     int probe_layer = 0;
     std::vector<hipEvent_t> ev_a, ev_b;
     int probe_used = 0, probe_head = 0;   // armed pairs form the circular range [head, head + used)
+    int64_t probe_calls = 0;              // launches of the probed GEMM seen; every probe_every-th one is timed
+    int probe_every = 16;                 // option vae.probe_every: a timed launch carries a start AND a stop event (two barrier
+                                          // packets around the kernel); timing every step taxes the step it measures
     PinnedBuf<double> h_epoch_loss;        // per-epoch loss sums of vh_vae_train_epochs
     double probe_ms = 0.0;
     int64_t probe_launches = 0;
@@ -557,6 +560,7 @@ void upload_masks(vh_vae* h, const uint8_t* masks, int bs) {
 // simply not sampled while the ring is full)
 void probe_arm(vh_vae* h) {
     if (!h->probe_on || h->probe_used >= kProbeRing) return;
+    if ((h->probe_calls++ % h->probe_every) != 0) return;
     if ((int)h->ev_a.size() < kProbeRing) {
         hipEvent_t a, b;
         VH_HIP(hipEventCreate(&a));
@@ -1917,6 +1921,8 @@ int vh_vae_set_probe(vh_vae* h, int enable, int layer) {
         h->probe_launches = 0;
         h->probe_used = 0;
         h->probe_head = 0;
+        h->probe_calls = 0;
+        h->probe_every = (int)std::max<int64_t>(1, option("vae.probe_every", 16));
     });
 }
 
