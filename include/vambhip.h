@@ -196,6 +196,10 @@ int vh_gen_create_sharded(vh_clu* clu, const int64_t* order, int64_t n_global, i
 int vh_gen_destroy(vh_gen* g);
 /* one Cluster (cluster.py:298-316, 545-604); members = original contig indices, ascending */
 int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap);
+/* up to max_clusters consecutive clusters in one call (the same state machine; it saves the binding's per-call overhead):
+ * infos[i] describes cluster i, its members follow those of cluster i - 1 in `members` (a buffer of the generator's row count
+ * always holds whatever is left).  *n_out < max_clusters: exhausted. */
+int vh_gen_next_batch(vh_gen* g, int max_clusters, vh_cluster_info* infos, int64_t* members, int64_t cap, int* n_out);
 /* test hook (host only): find_threshold (cluster.py:452-543) on exact histogram accumulators; kind 0 loner,
  * 1 no threshold, 2 threshold (then *threshold and *observed_pvr are set) */
 int vh_debug_find_threshold(const int64_t* hist_fx, int64_t n_lt, double pvr, int* kind, double* threshold,

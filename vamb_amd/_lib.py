@@ -72,6 +72,7 @@ SIGNATURES = {
                                      ctypes.POINTER(_vp)]),
     "vh_gen_destroy": (_int, [_vp]),
     "vh_gen_next": (_int, [_vp, ctypes.POINTER(ClusterInfo), _vp, _i64]),
+    "vh_gen_next_batch": (_int, [_vp, _int, ctypes.POINTER(ClusterInfo), _vp, _i64, ctypes.POINTER(_int)]),
     "vh_debug_find_threshold": (_int, [_vp, _i64, ctypes.c_double, ctypes.POINTER(_int), ctypes.POINTER(ctypes.c_double),
                                        ctypes.POINTER(ctypes.c_double)]),
     "vh_debug_pyrandom_sample": (_int, [ctypes.c_uint64, _int, _vp, _vp, _vp]),

@@ -326,7 +326,9 @@ class ClusterGenerator:
         rng_seed: seed of the candidate sampler
     """
 
-    PACK_FRACTION = 0.5   # compact the resident matrix when fewer than this fraction of rows are live
+    # compact the resident matrix when fewer than this fraction of rows are live.  Measured at C2 (profiles/r04e_*, cached
+    # statistics survive a pack since round 4): 0.5 -> 14.6 s, 0.75 -> 14.2 s, 0.85 -> 13.6 s, 0.92 -> 13.3 s per sweep
+    PACK_FRACTION = 0.9
     PACK_MIN_ROWS = 8192
 
     def __repr__(self) -> str:
@@ -430,6 +432,7 @@ class ClusterGenerator:
         self._gen = None
         self._members_buf = None
         self._native_attempts = 0
+        self._native_queue = _deque()     # clusters the native state machine has produced ahead of the iteration
         self._sharded_native = False
         seed_ok = isinstance(rng_seed, int) and abs(rng_seed) < 2 ** 64 and not _os.environ.get("VAMBHIP_PY_GENERATOR")
         local = getattr(self._backend, "local", None)      # vamb_amd.parallel.ShardedScanBackend: this rank's shard
@@ -458,26 +461,39 @@ class ClusterGenerator:
             self._members_buf = _np.empty(n, _np.int64)
             self._sharded_native = True
 
+    _NATIVE_BATCH = 64     # clusters fetched per call of the native state machine (vh_gen_next_batch)
+
     def _next_native(self) -> Cluster:
-        info = _lib.ClusterInfo()
-        lib = self._backend.lib
-        _lib.check(lib.vh_gen_next(self._gen, ctypes.byref(info), _lib.ptr(self._members_buf), len(self._members_buf)))
-        if info.n_members == 0:
-            self._sync_native_counters()
-            raise StopIteration
-        members = self._members_buf[: info.n_members].copy()
-        observed = info.observed_pvr if info.kind == 0 else None
-        radius = None if info.kind == 1 else info.radius
+        if not self._native_queue:
+            lib = self._backend.lib
+            infos = (_lib.ClusterInfo * self._NATIVE_BATCH)()
+            n = ctypes.c_int(0)
+            _lib.check(lib.vh_gen_next_batch(self._gen, self._NATIVE_BATCH, infos, _lib.ptr(self._members_buf),
+                                             len(self._members_buf), ctypes.byref(n)))
+            if n.value == 0:
+                self._sync_native_counters()
+                raise StopIteration
+            off = 0
+            for i in range(n.value):
+                info = infos[i]
+                k = int(info.n_members)
+                self._native_queue.append((int(info.medoid), int(info.seed), self._members_buf[off:off + k].copy(), info.kind,
+                                           info.maximal_pvr, info.observed_pvr, info.radius, int(info.successes),
+                                           int(info.attempts), info.pvr_after, info.successes_after, info.attempts_after,
+                                           info.order_index_after))
+                off += k
+            self._counters_stale = True
+        (medoid, seed, members, kind, maximal_pvr, observed_pvr, radius, successes, attempts, pvr_after, successes_after,
+         attempts_after, order_index_after) = self._native_queue.popleft()
         self.n_emitted_clusters += 1
-        self.n_remaining_points -= int(info.n_members)
+        self.n_remaining_points -= len(members)
         # the attributes the reference exposes (repr, callers inspecting the search state) AFTER update_successes
-        self.peak_valley_ratio = info.pvr_after
-        self.successes = info.successes_after
-        self._native_attempts = info.attempts_after
-        self.order_index = info.order_index_after
-        self._counters_stale = True
-        return Cluster(int(info.medoid), int(info.seed), members, info.maximal_pvr, observed, radius,
-                       int(info.successes), int(info.attempts))
+        self.peak_valley_ratio = pvr_after
+        self.successes = successes_after
+        self._native_attempts = attempts_after
+        self.order_index = order_index_after
+        return Cluster(medoid, seed, members, maximal_pvr, observed_pvr if kind == 0 else None,
+                       None if kind == 1 else radius, successes, attempts)
 
     def _sync_native_counters(self):
         """Mirror the native counters on the Python objects (bench accounting, repr, len(matrix))."""

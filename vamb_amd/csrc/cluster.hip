@@ -2301,6 +2301,7 @@ struct vh_gen {
     std::deque<bool> attempts;
     int successes = 0;
     std::unordered_map<int64_t, GenStats> stats;
+    uint64_t ring_rows_valid_from = 0;   // lists of scans older than this (clu->scan_seq at the last pack) name pre-pack rows
     // speculative results of the last pass that have not been turned into `stats` entries yet: that host work (a copy of the
     // row, of its list, a map insert per medoid; 1.2 s of a C2 sweep) runs while the GPU executes the NEXT pass, or at once for
     // an entry somebody asks for
@@ -2504,7 +2505,8 @@ GenStats* gen_lookup(vh_gen* g, int64_t row) {
     }
     st.checked = g->n_emitted;
     // an entry that outlives its emission will be asked for its list sooner or later: take it while its scan is in the ring
-    if (!st.have_list && st.list_count <= (unsigned int)kListCap && g->clu->scan_seq - st.seq <= (uint64_t)kListRing) {
+    if (!st.have_list && st.list_count <= (unsigned int)kListCap && g->clu->scan_seq - st.seq <= (uint64_t)kListRing &&
+        st.seq >= g->ring_rows_valid_from) {
         const int32_t* src = g->clu->lists + ((size_t)(st.seq % kListRing) * kMaxMedoids + st.slot_j) * kListCap;
         st.within.assign(src, src + st.list_count);
         std::sort(st.within.begin(), st.within.end());
@@ -2689,7 +2691,7 @@ int64_t gen_select(vh_gen* g, int64_t medoid, float threshold, bool remove) {
 const std::vector<int64_t>& gen_within(vh_gen* g, int64_t medoid) {
     GenStats& st = g->stats.at(medoid);
     if (!st.have_list) {
-        const bool in_ring = g->clu->scan_seq - st.seq <= (uint64_t)kListRing;
+        const bool in_ring = g->clu->scan_seq - st.seq <= (uint64_t)kListRing && st.seq >= g->ring_rows_valid_from;
         if (in_ring && st.list_count <= (unsigned int)kListCap) {
             const int slot = (int)(st.seq % kListRing);
             g->clu->h_sel.resize(st.list_count);
@@ -2901,6 +2903,21 @@ int64_t gen_logical_index(vh_gen* g, int64_t row) {
     return c;
 }
 
+// Before the resident matrix is compacted: everything that still refers to the ring of the scans (pending speculative results,
+// within-radius lists not copied to the host yet) is brought to the host while the ring's row numbers are still the current ones.
+void gen_prepare_pack(vh_gen* g) {
+    gen_flush_pending(g);
+    for (auto& kv : g->stats) {
+        GenStats& st = kv.second;
+        if (st.have_list || st.list_count > (unsigned int)kListCap) continue;
+        if (g->clu->scan_seq - st.seq > (uint64_t)kListRing || st.seq < g->ring_rows_valid_from) continue;
+        const int32_t* src = g->clu->lists + ((size_t)(st.seq % kListRing) * kMaxMedoids + st.slot_j) * kListCap;
+        st.within.assign(src, src + st.list_count);
+        std::sort(st.within.begin(), st.within.end());
+        st.have_list = true;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -3031,9 +3048,13 @@ int vh_gen_destroy(vh_gen* g) {
     return VH_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
 // __next__ (cluster.py:298-316) + find_cluster (cluster.py:545-604).  info->n_members == 0: StopIteration.
-int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap) {
-    return guarded([&] {
+void gen_next_impl(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap) {
+    {
         VH_REQUIRE(g != nullptr && info != nullptr && members != nullptr, "NULL argument");
         memset(info, 0, sizeof(*info));
         if (g->n_remaining == 0) return;
@@ -3148,6 +3169,7 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
         const int64_t n_rows = (int64_t)g->kept.size();
         if (g->n_remaining > 0 && n_rows >= g->pack_min_rows && (double)g->n_remaining < g->pack_fraction * (double)n_rows) {
             int64_t new_n = 0;
+            gen_prepare_pack(g);
             gen_check(vh_clu_pack(g->clu, &new_n));
             if (g->comm) {   // every rank packed its own shard: the new offsets follow from the (replicated) live mask
                 std::vector<int64_t> off(g->offsets.size(), 0);
@@ -3160,8 +3182,31 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
                 g->offsets = off;
                 new_n = off.back();
             }
-            g->stats.clear();   // physical row numbers change
-            g->pending.clear();
+            // Physical row numbers change.  The cached statistics survive the renumbering (a row's new number is its rank among
+            // the live rows: the Fenwick tree still describes the old numbering here): an entry is kept if its row and every
+            // row of its within-radius list are live -- a dead row in the list means a neighbour was removed since the scan,
+            // which the lazy validation would have found -- and its list is translated; lists that are not on the host yet
+            // were fetched from the ring before the pack (gen_prepare_pack), the rest fall back to a select pass.
+            {
+                std::unordered_map<int64_t, GenStats> kept_stats;
+                kept_stats.reserve(g->stats.size());
+                for (auto& kv : g->stats) {
+                    GenStats& st = kv.second;
+                    if (!g->kept[(size_t)kv.first]) continue;
+                    bool ok = true;
+                    if (st.have_list) {
+                        for (int64_t& r : st.within) {
+                            if (!g->kept[(size_t)r]) { ok = false; break; }
+                            r = gen_logical_index(g, r);
+                        }
+                    } else {
+                        st.list_count = (unsigned int)kListCap + 1u;   // no list: the caller selects
+                    }
+                    if (ok) kept_stats.emplace(gen_logical_index(g, kv.first), std::move(st));
+                }
+                g->stats.swap(kept_stats);
+            }
+            g->ring_rows_valid_from = g->clu->scan_seq;
             g->pending_mark.assign(g->pending_mark.size(), 0);
             size_t w = 0;
             for (size_t r = 0; r < g->kept.size(); ++r)
@@ -3175,6 +3220,33 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
         info->successes_after = g->successes;
         info->attempts_after = (int64_t)g->attempts.size();
         info->order_index_after = g->order_index;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap) {
+    return guarded([&] { gen_next_impl(g, info, members, cap); });
+}
+
+// Up to max_clusters consecutive clusters in one call: infos[i] describes cluster i, whose members follow those of cluster
+// i - 1 in `members`.  A members buffer of the generator's row count always holds whatever is left.  *n_out < max_clusters:
+// the generator is exhausted (or the buffer was too small for the next cluster).  The state machine is exactly vh_gen_next's;
+// the batch only saves the per-cluster call overhead of the binding (~3 us of a ctypes round trip, 0.2 M times per C2 sweep).
+int vh_gen_next_batch(vh_gen* g, int max_clusters, vh_cluster_info* infos, int64_t* members, int64_t cap, int* n_out) {
+    return guarded([&] {
+        VH_REQUIRE(g != nullptr && infos != nullptr && members != nullptr && n_out != nullptr && max_clusters >= 1, "bad argument");
+        *n_out = 0;
+        int64_t used = 0;
+        for (int i = 0; i < max_clusters; ++i) {
+            if (g->n_remaining == 0 || g->n_remaining > cap - used) break;   // (a cluster never has more members than are left)
+            gen_next_impl(g, &infos[i], members + used, cap - used);
+            if (infos[i].n_members == 0) break;
+            used += infos[i].n_members;
+            ++*n_out;
+        }
     });
 }
 
