@@ -511,41 +511,3 @@ def test_ascending_chain_stream_matches_its_oracle(monkeypatch, oracle_lib, name
         co.set_order(co.DEFAULT_ORDER)
     ok, msg = fd.streams_equal(got, want)
     assert ok, "vs oracle: " + msg
-
-
-# ---- the pair-of-tiles matrix-pipe kernel (option scan.mfma_tiles = 2) ----------------------------------------------------
-@pytest.fixture
-def pair_tiles(monkeypatch, oracle_lib):
-    monkeypatch.setenv("VAMBHIP_SCAN_MFMA_TILES", "2")
-    yield
-
-
-@pytest.mark.parametrize("n,L,k,sigma", [(20000, 32, 12, 0.2), (20000, 32, 25, 0.2), (3000, 3, 32, 0.2), (2049, 15, 17, 0.2),
-                                         (3000, 17, 9, 0.2), (6000, 32, 25, 0.01), (70000, 32, 32, 0.3), (5000, 29, 20, 0.05)])
-def test_pair_tiles_scan_accumulators_bit_exact(pair_tiles, n, L, k, sigma):
-    """More than 8 medoids, latent width <= 32: clu_scan_mfma2_kernel (two interleaved chains over the even / odd rows of a
-    64-row block, live flags looked up in the drain) against the oracle, default (reference) order."""
-    _check_scan_against_oracle(n, L, k, sigma)
-
-
-@pytest.mark.parametrize("mode", ["0", "2"])
-@pytest.mark.parametrize("name", ["blob_s008_n10000", "blob_s050_n3000", "blob_zero_dup", "blob_s050_window"])
-def test_pair_tiles_stream(pair_tiles, monkeypatch, name, mode):
-    monkeypatch.setenv("VAMBHIP_REFERENCE_ORDER", mode)
-    co.set_order(0 if mode == "0" else 2)
-    try:
-        mat, lens, kw = fd.cluster_inputs(name)
-        got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
-        want = fd.pack_stream(list(co.OracleClusterGenerator(mat.copy(), lens, **kw)))
-    finally:
-        co.set_order(co.DEFAULT_ORDER)
-    ok, msg = fd.streams_equal(got, want)
-    assert ok, msg
-
-
-def test_pair_tiles_100k_reference_stream(pair_tiles):
-    name = "blob_s050_n100000"
-    mat, lens, kw = fd.cluster_inputs(name)
-    got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
-    ok, msg = fd.streams_equal(got, fd.load("cluster_" + name), pvr_rtol=1e-2)
-    assert ok, msg

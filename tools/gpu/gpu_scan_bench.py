@@ -14,12 +14,12 @@ from vamb_amd import cluster as vc, synth  # noqa: E402
 
 mode = os.environ.get("VAMBHIP_SCAN_LC", "1")
 rows = []
-for (n, L) in ([(250_000, 32), (700_000, 32), (2_000_000, 32)] if os.environ.get("SCAN_BENCH_MANY") else [(100_000, 32), (400_000, 32), (2_000_000, 32), (2_000_000, 64)]):
+for (n, L) in [(100_000, 32), (400_000, 32), (2_000_000, 32), (2_000_000, 64)]:
     lat, _ = synth.blob_latent(n, L, 0.3, seed=1)      # sigma 0.3: a few percent of the pairs fall inside the histogram range
     lens = synth.lengths(n, 1)
     b = vc.HipScanBackend(lat, lens.astype(np.float32), False, None)
     rng = np.random.RandomState(0)
-    for k in ((9, 16, 25, 32) if os.environ.get("SCAN_BENCH_MANY") else (1, 4, 8, 9, 16, 25, 32)):
+    for k in (1, 4, 8, 9, 16, 25, 32):
         med = rng.choice(n, k, replace=False)
         b.scan_raw(med)          # warm-up
         b.set_timing(True)

@@ -426,8 +426,7 @@ __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn
                                            unsigned long long* __restrict__ acc_s, unsigned int* __restrict__ lcnt_s,
                                            int32_t* __restrict__ llist_s, const float* __restrict__ edges_s,
                                            const int32_t* __restrict__ med_s, int dbg, const RefSrc& ro,
-                                           const float* __restrict__ lengths = nullptr,
-                                           const uint8_t* __restrict__ kept_g = nullptr) {
+                                           const float* __restrict__ lengths = nullptr) {
     if (dbg & 8) return;   // timing experiment: queued pairs are dropped
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int e0 = 0; e0 < qn; e0 += 64) {   // (uniform trip count: the reference-order re-evaluation exchanges data across lanes)
@@ -440,8 +439,6 @@ __device__ __forceinline__ void drain_hits(const float4* __restrict__ hq, int qn
         // per queued pair, instead of once per (row, medoid) pair in the scan loop
         const bool self = row == med_s[j];
         float d = self ? 0.0f : v.x;
-        // (the pair-of-tiles matrix-pipe kernel queues pairs without looking at the live mask: looked up here, with the length)
-        if (kept_g != nullptr && valid && kept_g[row] == 0) d = __builtin_inff();
         if constexpr (REF) {
             // The reference-order distance is within ro.slack of the chain distance.  Inside the medoid radius (+ slack) its VALUE
             // is recorded (density), elsewhere only its histogram bin: the pair is re-evaluated in the reference's order only
@@ -919,143 +916,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(REF && N
     scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists, dbg);
 }
 
-// ---------------------------------------------------------------------------------------------
-// K6m2: the matrix-pipe scan on PAIRS of tiles (latent widths up to 32).  Two findings of rounds 2-4 meet here: the kernel
-// above runs its matrix pipe 37 % of the time because a wavefront's chain of 16 dependent MFMAs leaves issue slots empty
-// (profiles/r02s_pmc_scan_mfma_k32_set1.txt), and its 4-byte loads fetch the matrix in 128-byte pieces that lie 4 ld bytes
-// apart.  Here a lane loads a float2 -- rows base + 2 r and base + 2 r + 1 of its column -- so a wave instruction covers two
-// 256-byte runs, and the two tiles (even rows / odd rows of a 64-row block) are multiplied as two INTERLEAVED chains: the pipe
-// always has an independent MFMA to issue.  Three 64-row buffers per wavefront, 2 wavefronts per SIMD (184 VGPRs).  Same
-// arithmetic (each (row, medoid) dot product is still the ascending fmaf chain), same queue / drain / flush, so accumulators,
-// lists and streams stay bit-identical (tests/test_cluster_gpu.py runs every order mode through it).
-//   D: lane l holds medoid j = l & 31 against A-rows i = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) of a tile, i.e. matrix rows
-//      base + 2 i (tile 0) and base + 2 i + 1 (tile 1)
-// ---------------------------------------------------------------------------------------------
-struct ScanTile2 {
-    float2 xa[16];   // (no live flags: with the matrix compacted at 90 % live rows a block of 64 dead rows does not occur, and a
-                     //  queued pair's liveness is looked up in the drain together with its length)
-};
-
-__device__ __forceinline__ void scan_tile2_load(ScanTile2& t, const float* __restrict__ Mt, int64_t ld, int nk,
-                                                const uint8_t* __restrict__ kept, int64_t base, int j, int h) {
-    const uint32_t off = (uint32_t)((int64_t)h * ld + 2 * j) * 4u;
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-        t.xa[s] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(Mt + (int64_t)(2 * min(s, nk - 1)) * ld + base) + off);
-}
-
-template <bool REF = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void clu_scan_mfma2_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
-                                                                const float* __restrict__ lengths,
-                                                                const uint8_t* __restrict__ kept,
-                                                                const float* __restrict__ q_ext, const MedoidRows medoid,
-                                                                int k_real, unsigned long long* __restrict__ results,
-                                                                int32_t* __restrict__ lists, int dbg, const RefSrc ro) {
-    constexpr int KM = kMaxMedoids;
-    constexpr int NK = 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float4* hq_s = reinterpret_cast<float4*>(smem_raw);                                  // [kBlock/64][kHitCap]
-    unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(hq_s + (kBlock / 64) * kHitCap);   // [KM][kResultWords]
-    float* edges_s = reinterpret_cast<float*>(acc_s + KM * kResultWords);               // [64]
-    unsigned int* lcnt_s = reinterpret_cast<unsigned int*>(edges_s + 64);               // [KM]
-    int32_t* llist_s = reinterpret_cast<int32_t*>(lcnt_s + KM);                         // [KM][kLocalCap]
-    int32_t* med_s = llist_s + KM * kLocalCap;                                          // [KM]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float4* hq = hq_s + wave * kHitCap;
-    for (int i = tid; i < KM; i += kBlock) med_s[i] = (int32_t)medoid.row[i];
-    for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
-    for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
-    for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
-    const int j = lane & 31, h = lane >> 5;
-    const int nk = L4 >> 1;
-    const long long my_med = medoid.row[j];
-    float qb[NK];
-#pragma unroll
-    for (int s = 0; s < NK; ++s) {
-        const int k = 2 * s + h;
-        qb[s] = 0.0f;   // unused medoid slots (j >= k_real, row -1) keep a zero query: dot = 0, never of interest
-        if (s < nk && j < k_real) qb[s] = q_ext ? q_ext[j * L4 + k] : Mt[(int64_t)k * ld + my_med];
-    }
-    __syncthreads();
-    const float edge_hi = edges_s[VH_NBINS];
-    float dot_min = 0.5f - edge_hi;
-    while (0.5f - __uint_as_float(__float_as_uint(dot_min) - 1u) <= edge_hi) dot_min = __uint_as_float(__float_as_uint(dot_min) - 1u);
-    while (!(0.5f - dot_min <= edge_hi)) dot_min = __uint_as_float(__float_as_uint(dot_min) + 1u);
-    if constexpr (REF) dot_min -= 2.0f * ro.slack;
-    if (dbg & 1) dot_min = __builtin_inff();
-    int qn = 0;
-
-    const int64_t ntiles = ld >> 6;   // 64-row blocks (ld is a multiple of 1024)
-    const int64_t stride = (int64_t)gridDim.x * (kBlock / 64);
-    int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + wave;
-    constexpr int DEPTH = 3;
-    ScanTile2 tl[DEPTH];
-#pragma unroll
-    for (int u = 0; u < DEPTH; ++u) {
-#pragma unroll
-        for (int q = 0; q < NK; ++q) tl[u].xa[q] = make_float2(0.0f, 0.0f);
-        if (tile + u * stride < ntiles) scan_tile2_load(tl[u], Mt, ld, nk, kept, (tile + u * stride) << 6, j, h);
-    }
-    auto step = [&](ScanTile2& t) {
-        const int64_t base = tile << 6;
-        scan_f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-        // two independent chains, interleaved: each is the column-ordered fmaf chain of its 32 rows x 32 medoids
-#pragma unroll
-        for (int q = 0; q < NK; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(t.xa[q].x, qb[q], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(t.xa[q].y, qb[q], acc1, 0, 0, 0);
-        }
-        if (tile + DEPTH * stride < ntiles) scan_tile2_load(t, Mt, ld, nk, kept, (tile + DEPTH * stride) << 6, j, h);
-        unsigned long long any = 0ull;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            any |= __builtin_amdgcn_ballot_w64(acc0[r] >= dot_min) | __builtin_amdgcn_ballot_w64(acc1[r] >= dot_min);
-        if (any == 0ull) return;
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const scan_f32x16& acc = tt == 0 ? acc0 : acc1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // matrix row base + o, o = 2 (e + 8 q + 4 h) + tt
-                    const int o0 = 2 * e + 16 * q + tt;          // (h = 0); h = 1 adds 8 rows
-                    const bool hit = acc[4 * q + e] >= dot_min;
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-                    if (m != 0ull) {
-                        if (hit) {
-                            const int64_t row = base + o0 + 8 * h;
-                            const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32),
-                                                                                __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                            hq[pos] = make_float4(0.5f - acc[4 * q + e], 0.0f, __int_as_float((int32_t)row), __int_as_float(j));
-                        }
-                        qn += __popcll(m);
-                        if (qn > kHitCap - 64) {
-                            drain_hits<REF>(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, ro, lengths, kept);
-                            qn = 0;
-                        }
-                    }
-                }
-            }
-        }
-    };
-    while (tile < ntiles) {
-#pragma unroll
-        for (int u = 0; u < DEPTH; ++u) {
-            if (tile < ntiles) {
-                step(tl[u]);
-                tile += stride;
-            }
-        }
-    }
-    drain_hits<REF>(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, ro, lengths, kept);
-    scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists, dbg);
-}
-
 // Query vectors of a many-medoid pass in quad-major order [L4 / 4][km][4] for the scalar loads of the pipelined scan
 // kernel: from the resident rows medoid.row[j], or from explicit vectors q_src[km][L4] (row-sharded execution).
 __global__ __launch_bounds__(kBlock) void clu_gather_quads_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
@@ -1471,7 +1331,6 @@ struct vh_clu {
     bool ref_order = false;       // scan.reference_order = 1: distances and normalisation in the reference build's evaluation order
                                   // (ref_dot / ref_norm; the scan runs on clu_scan_ref_kernel)
     bool use_mfma = true;         // scan.mfma = 0: passes with more than 8 medoids stay on the VALU kernels (A/B)
-    int mfma_tiles = 1;           // scan.mfma_tiles: 2 = the pair-of-tiles kernel (two interleaved chains, float2 loads)
     bool mfma_pass = false;       // set by scan_core for the pass being launched
     int mfma_k = 0;               // its medoid count
     int scan_lc = 1;              // column-loop variant (VAMBHIP_SCAN_LC, A/B measurements): 0 runtime-width loop everywhere,
@@ -1619,22 +1478,6 @@ void launch_scan_mfma(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     else launch_scan_mfma_impl<NK, false>(h, med, q_ext);
 }
 
-template <bool REF>
-void launch_scan_mfma2_impl(vh_clu* h, const MedoidRows& med, const float* q_ext) {
-    const size_t smem = scan_smem_bytes(kMaxMedoids, 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_mfma2_kernel<REF>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScanLdsBudget));
-        attr_set = true;
-    }
-    const int64_t tiles = h->ld >> 6;
-    // two wavefronts per SIMD (registers): two workgroups per CU, every wavefront strides over its 64-row blocks
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(tiles, kBlock / 64), 256 * 2));
-    hipLaunchKernelGGL((clu_scan_mfma2_kernel<REF>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
-                       h->lengths.p, h->kept.p, q_ext, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg, ref_src(h));
-}
-
 // more than 8 medoids and a latent width the B operand registers hold: the matrix-pipe kernel (always 32 medoid slots)
 bool scan_uses_mfma(const vh_clu* h, int k) {
     return h->use_mfma && k > 8 && h->L4 <= 64 && h->max_k >= kMaxMedoids && h->ld < ((int64_t)1 << 28);   // 32-bit byte offsets
@@ -1661,10 +1504,7 @@ void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext)
         return;
     }
     if (h->mfma_pass) {
-        if (h->L4 <= 32 && h->mfma_tiles == 2) {
-            if (h->ref_filter) launch_scan_mfma2_impl<true>(h, med, q_ext);
-            else launch_scan_mfma2_impl<false>(h, med, q_ext);
-        } else if (h->L4 <= 32) launch_scan_mfma<16>(h, med, q_ext);
+        if (h->L4 <= 32) launch_scan_mfma<16>(h, med, q_ext);
         else launch_scan_mfma<32>(h, med, q_ext);
         VH_HIP(hipGetLastError());
         return;
@@ -1768,7 +1608,6 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->min_blocks = option("scan.min_blocks", kMinScanBlocks);
         h->scan_lc = (int)option("scan.column_loop", 1);
         h->use_mfma = option("scan.mfma", 1) != 0;
-        h->mfma_tiles = (int)option("scan.mfma_tiles", 1);
         {
             const int64_t mode = option("scan.reference_order", 2);
             VH_REQUIRE(mode >= 0 && mode <= 2, "scan.reference_order: 0, 1 or 2");
