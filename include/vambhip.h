@@ -63,9 +63,6 @@ const char* vh_version(void);
  *   vae.dw_row_major (1)   bf16 weight gradients contract row-major tensors (transposing LDS reads); 0 = transposed bf16 copies
  *   vae.fork_at_loss (0)   the side stream also forks at the loss kernel (one more fork: measured slower)
  *   vae.opt_split (0)      the optimiser's decoder-side half on the side stream during the encoder's backward (bit-identical, measured slower)
- *   vae.fuse_dz (1)        bf16 step: the dX GEMM applies the BatchNorm / dropout / LeakyReLU backward of the layer below behind an
- *                          in-kernel grid barrier (all its workgroups are resident: one 128 x 128 tile per CU) instead of a
- *                          separate elementwise kernel; bit-identical; 0 = the separate kernel
  *   vae.probe_every (16)   the roofline probe (vh_vae_set_probe) times every n-th launch of the probed GEMM: a timed launch is
  *                          bracketed by a start and a stop event, which costs the step it measures
  *   vae.dz_colsum (1)      bias-gradient column sums in the BatchNorm-backward kernel; 0 = inside the weight-gradient GEMM (measured slower)

@@ -200,7 +200,6 @@ _ENV_OPTIONS = {
     "VAMBHIP_VAE_DZ_COLSUM": ("vae.dz_colsum", int),
     "VAMBHIP_VAE_OPT_SPLIT": ("vae.opt_split", int),
     "VAMBHIP_VAE_PROBE_EVERY": ("vae.probe_every", int),
-    "VAMBHIP_VAE_FUSE_DZ": ("vae.fuse_dz", int),
 }
 _ENV_STRING_OPTIONS = {"VAMBHIP_RCCL": "comm.rccl_library", "ROCM_PATH": "comm.rocm_path"}
 _explicit_options: dict = {}

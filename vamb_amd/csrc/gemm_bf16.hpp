@@ -29,10 +29,6 @@
 //                   sums of h and h^2 taken from the fp32 values before rounding
 //   E16_HIDDEN_EVAL C16 = bf16(leaky_relu(acc + bias) * scale[n] + shift[n])
 //   E16_STORE_BNRED C16 = bf16(acc) (= dA of the layer below) + fp64 batch sums of dA and dA * xhat(Hbelow)
-//   E16_BNRED_DZ    the same sums, then a GRID BARRIER (every workgroup of the launch is resident: one 128 x 128 tile per CU),
-//                   then C16 = dZ of the layer below = the elementwise BatchNorm / dropout / LeakyReLU backward of the dA tile
-//                   still held in LDS -- vae_dz16_kernel's arithmetic on the same bf16 dA, without the 12 us kernel, its launch
-//                   boundary and the 16 MB round trip of dA through HBM
 // bf16 outputs leave through LDS images of the tile (row-major and, for the hidden-train epilogue, transposed) and
 // 16-byte stores (the transposed copy as direct 8-byte stores from the accumulator layout cost 4 us per GEMM more).
 #pragma once
@@ -54,9 +50,7 @@ enum Epi16 : int {
     E16_LATENT_MASK = 2,
     E16_HIDDEN_TRAIN = 3,
     E16_HIDDEN_EVAL = 4,
-    E16_STORE_BNRED = 5,
-    E16_BNRED_DZ = 6       // E16_STORE_BNRED + a grid barrier + the BatchNorm / dropout / LeakyReLU backward of the layer below:
-                           // writes dZ of that layer instead of its dA (see the lean epilogue)
+    E16_STORE_BNRED = 5
 };
 
 struct Gemm16Args {
@@ -90,10 +84,6 @@ struct Gemm16Args {
     int64_t ldh;
     BnSrc bnC;
     double* bstat_out;     // [2][N]
-    // E16_BNRED_DZ: grid barrier (one counter per handle, never reset: a launch waits for `gbar_target`), bias-gradient sums of dZ
-    unsigned int* gbar;
-    unsigned int gbar_target;
-    double* dbias_out;     // [N] (may be nullptr)
     int xcd_remap;
     int dbg;               // timing experiments (vh_debug_gemm16): 1 no fp64 atomics, 2 no transposed copy, 4 no row-major copy
     unsigned long long* tstamps;   // diagnostic (vh_debug_gemm16, variant flag 8): [workgroup][8] s_memtime stamps -- entry, first tile
@@ -105,11 +95,6 @@ __device__ __forceinline__ bf16_t f2bf(float x) {
     return __builtin_bit_cast(unsigned short, b);
 }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((uint32_t)b << 16); }
-// the linear part of the elementwise BatchNorm backward, with its contraction pinned: vae_dz16_kernel and the fused epilogue of
-// the dX GEMM (E16_BNRED_DZ) must produce the same bits
-__device__ __forceinline__ float dz_linear(float ca, float d, float ch, float h, float c0) {
-    return __builtin_fmaf(ca, d, __builtin_fmaf(ch, h, c0));
-}
 
 // slot permutation of the [rows][64 bf16] LDS image (8 slots of 16 B per 128-byte row)
 __device__ __forceinline__ int swz16(int row) { return ((row >> 1) ^ (row >> 4)) & 7; }
@@ -440,12 +425,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
         // by the counter hash (6 full-rate VALU per 32 bits); the image is written TRANSPOSED, [BN][BM + 8], four consecutive
         // rows of the lane's column per ds_write_b64 (8 stores per lane instead of 32), and the row-major 16-byte chunks of
         // the global stores are assembled by the transposing LDS read.
-        constexpr bool BNRED = EPI == E16_STORE_BNRED || EPI == E16_BNRED_DZ;
-        constexpr bool FUSE_DZ = EPI == E16_BNRED_DZ;
         bool lean = m0 + BM <= g.m_real && m0 + BM <= g.M && n0 + BN <= g.N && !(g.dbg & 16);
-        if constexpr (FUSE_DZ) {
-            if (!lean) __builtin_trap();   // the host selects this epilogue only when every tile is interior (vae_step16.hpp)
-        }
         if constexpr (EPI == E16_HIDDEN_TRAIN) lean = lean && g.drop_mask == nullptr && (g.C16T == nullptr || (g.dbg & 2));
         if constexpr (NWAVE % (BN / 32) != 0 || BM % 16 != 0) lean = false;
         if (lean) {
@@ -532,7 +512,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
             const int c0 = cp * 32 + 8 * g4;
             const bf16_t* const isrc = img + (c0 + (r16 >> 2)) * IP + 4 * (r16 & 3);
             float mean8[8], istd8[8], t1[8], t2[8];
-            if constexpr (BNRED) {
+            if constexpr (EPI == E16_STORE_BNRED) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float sc, sh;
@@ -543,8 +523,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
             constexpr int NU = UR / WG;    // row blocks per wave
             static_assert(UR % WG == 0, "row blocks per wave");
             uint4 hv[NU];
-            uint4 ov[FUSE_DZ ? NU : 1];
-            if constexpr (BNRED) {
+            if constexpr (EPI == E16_STORE_BNRED) {
 #pragma unroll
                 for (int k = 0; k < NU; ++k) {
                     const int row = m0 + (wave / UC + WG * k) * 16 + r16;
@@ -562,9 +541,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                 o.z = (uint32_t)(unsigned short)hi[0] | ((uint32_t)(unsigned short)hi[1] << 16);
                 o.w = (uint32_t)(unsigned short)hi[2] | ((uint32_t)(unsigned short)hi[3] << 16);
                 const int row = m0 + rb * 16 + r16;
-                if constexpr (FUSE_DZ) ov[k] = o;
-                else if (!(g.dbg & 4)) *reinterpret_cast<uint4*>(g.C16 + (int64_t)row * g.ldc16 + n0 + c0) = o;
-                if constexpr (BNRED) {
+                if (!(g.dbg & 4)) *reinterpret_cast<uint4*>(g.C16 + (int64_t)row * g.ldc16 + n0 + c0) = o;
+                if constexpr (EPI == E16_STORE_BNRED) {
                     const uint32_t dw[4] = {o.x, o.y, o.z, o.w};
                     const uint32_t hw[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w};
 #pragma unroll
@@ -576,7 +554,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                     }
                 }
             }
-            if constexpr (BNRED) {
+            if constexpr (EPI == E16_STORE_BNRED) {
                 // the 16 row-lanes of a group and the WG waves of a column pass hold partial sums of the same 8 columns
                 float* const bred = reinterpret_cast<float*>(smem16 + IMG_BYTES);   // [2][WG * 16][BN]
 #pragma unroll
@@ -591,70 +569,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
 #pragma unroll
                     for (int w = 0; w < WG * 16; ++w) s += bred[(stat * WG * 16 + w) * BN + cb];
                     atomicAdd(&g.bstat_out[(int64_t)stat * g.N + n0 + cb], (double)s);
-                }
-                if constexpr (FUSE_DZ) {
-                    // ---- grid barrier: every workgroup's sums are in bstat_out.  The sums travel as agent-scope atomics
-                    // (performed at the coherence point of the XCDs, complete once vmcnt drains: the workgroup-scope fence is a
-                    // wait, not a cache write-back), the arrival counter likewise, and the totals are read back with agent-scope
-                    // loads: no L2 write-back anywhere.  The launch is deadlock-free because all its workgroups are resident
-                    // together (<= one per CU, checked on the host); should that ever not hold -- another process filling the
-                    // CUs with a barrier kernel of its own -- the spin gives up after ~0.1 s and traps instead of hanging.
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __syncthreads();
-                    if (tid == 0) {
-                        __hip_atomic_fetch_add(g.gbar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        unsigned int spins = 0;
-                        while ((int)(__hip_atomic_load(g.gbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.gbar_target) < 0) {
-                            __builtin_amdgcn_s_sleep(4);
-                            if (++spins > (1u << 21)) __builtin_trap();
-                        }
-                    }
-                    __syncthreads();
-                    // ---- dZ = keep * slope(h) * (ca dA + ch h + c0) for this thread's 8 columns (vae_dz16_kernel's expression)
-                    const double inv_bs = 1.0 / (double)g.bnC.bs;
-                    float ca[8], ch[8], cz[8], sd[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int col = n0 + c0 + e;
-                        const float c1 = (float)(__hip_atomic_load(&g.bstat_out[col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * inv_bs);
-                        const float c2 = (float)(__hip_atomic_load(&g.bstat_out[(int64_t)g.N + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * inv_bs);
-                        ca[e] = g.drop_scale * istd8[e] * g.bnC.gamma[col];
-                        ch[e] = -ca[e] * istd8[e] * c2;
-                        cz[e] = -ca[e] * c1 - ch[e] * mean8[e];
-                        sd[e] = 0.f;
-                    }
-                    const bool hashed_drop = g.drop_scale != 1.0f;
-#pragma unroll
-                    for (int k = 0; k < NU; ++k) {
-                        const int rb = wave / UC + WG * k;
-                        const uint32_t dw[4] = {ov[k].x, ov[k].y, ov[k].z, ov[k].w};
-                        const uint32_t hw[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w};
-                        uint32_t ow[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float d = __uint_as_float((e & 1) ? (dw[e >> 1] & 0xFFFF0000u) : (dw[e >> 1] << 16));
-                            const float hh = __uint_as_float((e & 1) ? (hw[e >> 1] & 0xFFFF0000u) : (hw[e >> 1] << 16));
-                            const bool keep = hashed_drop ? hh != 0.f : true;
-                            const float l = dz_linear(ca[e], d, ch[e], hh, cz[e]);
-                            const float dz = keep ? l * (hh > 0.f ? 1.0f : kLeakySlopeF) : 0.f;
-                            const bf16_t b = f2bf(dz);
-                            sd[e] += bf2f(b);
-                            ow[e >> 1] |= (uint32_t)b << (16 * (e & 1));
-                        }
-                        const int row = m0 + rb * 16 + r16;
-                        *reinterpret_cast<uint4*>(g.C16 + (int64_t)row * g.ldc16 + n0 + c0) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-                    }
-                    if (g.dbias_out != nullptr) {   // bias gradient = column sums of dZ
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) bred[((wave / UC) * 16 + r16) * BN + c0 + e] = sd[e];
-                        __syncthreads();
-                        for (int t = tid; t < BN; t += NT) {
-                            float s = 0.f;
-#pragma unroll
-                            for (int w = 0; w < WG * 16; ++w) s += bred[w * BN + t];
-                            atomicAdd(&g.dbias_out[n0 + t], (double)s);
-                        }
-                    }
                 }
             }
             if constexpr (EPI == E16_HIDDEN_TRAIN) {
@@ -790,7 +704,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
         static_assert(NT % CPR == 0 && BM % RPP == 0, "row-major pass layout");
         const int cc = tid % CPR, r0 = tid / CPR;
         const int col8 = n0 + 8 * cc;
-        if constexpr (EPI == E16_STORE_BNRED || EPI == E16_BNRED_DZ) {
+        if constexpr (EPI == E16_STORE_BNRED) {
             // per-thread BatchNorm coefficients of its 8 columns (layer below), then the two batch sums
             float mean8[8], istd8[8], t1[8], t2[8];
 #pragma unroll
@@ -879,10 +793,10 @@ constexpr size_t gemm16_smem_bytes() {
     if (EPI == E16_SPLITK || EPI == E16_BIAS || EPI == E16_LATENT_MASK) return ops;
     const size_t img = (size_t)BM * (BN + 8) * 2 + (EPI == E16_HIDDEN_TRAIN ? (size_t)BN * (BM + 8) * 2 : 0);
     const size_t nt = (size_t)WM * WN * 64, rpp = nt / (BN / 8);
-    const size_t red = (EPI == E16_STORE_BNRED || EPI == E16_BNRED_DZ) ? 2 * rpp * BN * 4 : 2 * (size_t)WM * BN * 4;
+    const size_t red = EPI == E16_STORE_BNRED ? 2 * rpp * BN * 4 : 2 * (size_t)WM * BN * 4;
     // lean epilogue: transposed image [BN][BM + 8] + reduction scratch [2][16 * waves per column pass][BN]
     const size_t wg = nt / 64 / (BN / 32 > 0 ? BN / 32 : 1);
-    const size_t lean = (size_t)BN * (BM + 8) * 2 + ((EPI == E16_STORE_BNRED || EPI == E16_BNRED_DZ) ? 2 * (wg > 0 ? wg : 1) * 16 * BN * 4 : 2 * (size_t)WM * BN * 4);
+    const size_t lean = (size_t)BN * (BM + 8) * 2 + (EPI == E16_STORE_BNRED ? 2 * (wg > 0 ? wg : 1) * 16 * BN * 4 : 2 * (size_t)WM * BN * 4);
     size_t need = ops > img + red ? ops : img + red;
     return need > lean ? need : lean;
 }

@@ -173,10 +173,6 @@ struct VaeTuning {
                               // 293 us: stays where it was
     bool dw_row_major = true; // vae.dw_row_major: bf16 weight gradients contract ROW-major tensors (gemm_bf16_tn.hpp); 0 = the
                               // round-2 dataflow with a transposed bf16 copy of every contracted tensor (A/B measurements)
-    bool fuse_dz = true;      // vae.fuse_dz: bf16 step: the dX GEMM that leaves the BatchNorm-backward sums of a hidden layer goes on,
-                              // behind a grid barrier, to write that layer's dZ (epilogue E16_BNRED_DZ): the elementwise kernel
-                              // (4 x 12 us per step at C2), its launch boundary and dA's trip through HBM are gone.  Bit-identical
-                              // (same bf16 dA, same expression); 0 = the separate kernel
 } g_tuning;
 
 void refresh_tuning() {
@@ -188,7 +184,6 @@ void refresh_tuning() {
     g_tuning.dz_colsum = option("vae.dz_colsum", 1) != 0;
     g_tuning.opt_split = option("vae.opt_split", 0) != 0;
     g_tuning.pipeline = option("vae.gemm_pipeline", 2) == 0 ? 0 : 2;
-    g_tuning.fuse_dz = option("vae.fuse_dz", 1) != 0;
 }
 
 int fwd_tile(int M, int N) {
@@ -255,9 +250,6 @@ struct vh_vae {
     int bs = 0, bs_p = 0;
     DevBuf<float> Xb, Wb, MU, Z, EPS, R, dR, dMUk, DA, dMU, loss_part, slabs, out_sm, skinny;
     DevBuf<double> statbuf;          // every hidden layer's fstat | bstat | dbias, zeroed once per step
-    DevBuf<unsigned int> gbar;       // arrival counter of the in-kernel grid barriers (E16_BNRED_DZ); never reset
-    unsigned int gbar_count = 0;     // arrivals enqueued so far = the value the last enqueued barrier waits for
-    int num_cus = 0;                 // compute units of the device (co-residency bound of a barrier launch)
     OptTable opt_tab, opt_tab_flat;  // parameter tensors -> gradient sources (slabs / fp64 accumulators / flat G)
     bool stat_clean = false;         // statbuf is all zero (left so by the optimiser's finalize kernel)
     bool keep_grads = false;         // single-step API: leave the accumulators for vh_vae_get_grad
@@ -1081,14 +1073,6 @@ int create_vae(const vh_vae_config* cfg, const vh_vae_labels_config* lab, vh_vae
         int prio_lo = 0, prio_hi = 0;
         VH_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // lo = least urgent (largest number)
         refresh_tuning();
-        {
-            int dev = 0, cus = 0;
-            VH_HIP(hipGetDevice(&dev));
-            VH_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            h->num_cus = cus;
-            h->gbar.alloc(1);
-            VH_HIP(hipMemset(h->gbar.p, 0, sizeof(unsigned int)));
-        }
         VH_HIP(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
         if (option("vae.single_stream", 0) != 0) h->side = h->stream;   // A/B: weight-gradient GEMMs on the main stream
         else VH_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));

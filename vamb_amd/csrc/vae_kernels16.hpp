@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
                 bool keep = true;
                 if (hashed_drop) keep = h != 0.f;
                 else if (a.drop_mask) keep = a.drop_mask[(int64_t)r * a.ld_mask + col + e] != 0;
-                const float l = dz_linear(ca[e], d, ch[e], h, c0[e]);
+                const float l = ca[e] * d + ch[e] * h + c0[e];
                 const float dz = keep ? l * (h > 0.f ? 1.0f : kLeakySlope) : 0.f;
                 const bf16_t b = f2bf(dz);
                 s[e] += bf2f(b);

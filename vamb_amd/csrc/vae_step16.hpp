@@ -486,46 +486,17 @@ void grad_weight16_rm(vh_vae* h, int tW, const bf16_t* dZ, int out_p, const bf16
     else gemm16_tn<0>(st, g, splits);
 }
 
-// Can the dX GEMM that produces the gradient of hidden layer `below` also apply that layer's elementwise backward (epilogue
-// E16_BNRED_DZ: a grid barrier between the BatchNorm-backward sums and their use)?  Every 128 x 128 tile must be interior, all
-// workgroups of the launch must be resident together (one per CU), the sums must not need an all-reduce over ranks in between
-// (SyncBN under data parallelism), no injected dropout masks (parity tests), row-major weight gradients (no transposed dZ).
-bool can_fuse_dz(const vh_vae* h, const Hidden& below, const DropCfg& dc) {
-    if (!g_tuning.fuse_dz || dc.injected || !g_tuning.dw_row_major || allrank_stats(h)) return false;
-    const int n = below.nout_p;
-    if (h->bs != h->bs_p || h->bs_p % 128 != 0 || n % 128 != 0) return false;
-    const int64_t nwg = (int64_t)(h->bs_p / 128) * (n / 128);
-    return nwg <= (int64_t)h->num_cus;
-}
-
-// dIn16 = dZ16 [bs_p][out] x W16T [in][out]; the epilogue leaves the BatchNorm-backward sums of the layer below and, when
-// `fuse` (can_fuse_dz), goes on to write that layer's dZ16 (+ its bias-gradient sums) instead of its dA16.  `fork`: the side
-// stream's queued work may start when this launch completes (fused launches stand in for the dz kernel as fork points).
-void grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidden& below, bool fuse = false,
-                  const DropCfg* dc = nullptr, double* dbias = nullptr, bool fork = false) {
+// dIn16 = dZ16 [bs_p][out] x W16T [in][out]; the epilogue leaves the BatchNorm-backward sums of the layer below
+void grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidden& below) {
     Gemm16Args g = args16(h);
     g.A = dZ; g.lda = out_p;
     g.B = w16t(h, tW); g.ldb = out_p;
     g.M = h->bs_p; g.N = in_p; g.K = out_p; g.k_per_split = g.K;
     g.m_real = h->bs;
-    g.C16 = fuse ? below.DZ16.p : below.DA16.p; g.ldc16 = in_p;
+    g.C16 = below.DA16.p; g.ldc16 = in_p;
     g.Hbelow = below.H16.p; g.ldh = in_p;
     g.bnC = bn_src(h, below);
     g.bstat_out = below.bstat;
-    if (fuse) {
-        g.drop_scale = dc->scale;
-        g.dbias_out = dbias;
-        g.gbar = h->gbar.p;
-        h->gbar_count += (unsigned int)((h->bs_p / 128) * (in_p / 128));
-        g.gbar_target = h->gbar_count;
-        if (fork && fork_from_kernel(h)) t_fork_stop = h->ev_fork;
-        gemm16<E16_BNRED_DZ>(h->stream, g, 1);
-        if (fork) {
-            if (fork_from_kernel(h)) VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-            else fork_side(h);
-        }
-        return;
-    }
     gemm16<E16_STORE_BNRED>(h->stream, g, 1);
     sync_stats(h, below.bstat, below.nout_p);
 }
@@ -533,33 +504,6 @@ void grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidd
 void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
     const int bs = h->bs, bs_p = h->bs_p, nl = h->nl;
     const DropCfg dc = drop_cfg(h, true, masks_injected);
-    const bool rm = g_tuning.dw_row_major;
-    const bool colsum_in_gemm = rm && !g_tuning.dz_colsum;
-    // layer li's dZ16 was written by the dX GEMM above it (fused epilogue): its dz kernel is not launched
-    bool fused_dz[2 * VH_MAX_HIDDEN_LAYERS] = {false};
-    // Fork points (see below): the top decoder layer and encoder layer 1 (and layer 0 when something is still queued)
-    auto is_fork = [&](int li) { return li == 2 * nl - 1 || li == 1 || (li == 0 && !q.items.empty()); };
-    // weight gradient of hidden layer li: dW = dZ16(li)^T In(li)
-    auto dw_for = [&, h](int li) -> std::function<void(hipStream_t)> {
-        Hidden& hl = h->hidden[li];
-        const bf16_t* InT = rm ? (li == 0 ? h->Xb16.p : (li == nl ? h->Z16.p : h->hidden[li - 1].H16.p))     // row-major input
-                               : (li == 0 ? h->Xb16T.p : (li == nl ? h->Z16T.p : h->hidden[li - 1].H16T.p));
-        const int in_p = li == 0 ? h->D_p : (li == nl ? h->L_p : h->hidden[li - 1].nout_p);
-        return [h, &hl, InT, in_p, rm, colsum_in_gemm](hipStream_t st) {
-            if (rm) grad_weight16_rm(h, hl.tW, hl.DZ16.p, hl.nout_p, InT, in_p, colsum_in_gemm ? hl.dbias : nullptr, st);
-            else grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, st);
-        };
-    };
-    // the dX GEMM whose output is the gradient of hidden layer `target`; returns true if it also produced that layer's dZ16
-    auto produce = [&](int target, const bf16_t* dZ, int out_p, int tW, int in_p) {
-        Hidden& below = h->hidden[target];
-        const bool fuse = can_fuse_dz(h, below, dc);
-        if (fuse && target > 0) q.add(dw_for(target));   // starts when this launch has completed (it is the fork, or a later fork)
-        const bool fork = fuse && is_fork(target);
-        grad_input16(h, dZ, out_p, tW, in_p, below, fuse, &dc, colsum_in_gemm ? nullptr : below.dbias, fork);
-        if (fork) q.flush(h->side);
-        return fuse;
-    };
     {   // output layer: dR16 is ready
         Hidden& last = h->hidden[2 * nl - 1];
         q.add([h, bs_p, bs, &last](hipStream_t st) {
@@ -573,7 +517,7 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         // running statistics, the loss reduction and the output layer's weight gradient depend on nothing later than the
         // loss kernel: hand them to the side stream now (forked on that kernel's completion, loss_and_seed16)
         if (g_tuning.fork_at_loss) q.flush(h->side);
-        fused_dz[2 * nl - 1] = produce(2 * nl - 1, h->dR16.p, h->D_p, h->tWo, last.nout_p);
+        grad_input16(h, h->dR16.p, h->D_p, h->tWo, last.nout_p, last);
     }
     int latent_slabs = 1;
     auto hidden_bwd = [&](int li) {
@@ -585,17 +529,23 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         a.bstat = hl.bstat;
         a.drop_scale = dc.scale;
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
+        const bool rm = g_tuning.dw_row_major;
         // bias gradient = column sums of dZ: with row-major weight gradients the dW GEMM of this layer streams dZ anyway and
         // sums it on the way (COLSUM, a few atomics per column); the elementwise kernel's own sums cost it one fp64 atomic per
         // column from each of its bs_p / 64 row blocks (vae.dz_colsum = 1: keep them there, A/B)
+        const bool colsum_in_gemm = rm && !g_tuning.dz_colsum;
         a.dbias = colsum_in_gemm ? nullptr : hl.dbias;
+        const bf16_t* InT = rm ? (li == 0 ? h->Xb16.p : (li == nl ? h->Z16.p : h->hidden[li - 1].H16.p))     // row-major input
+                               : (li == 0 ? h->Xb16T.p : (li == nl ? h->Z16T.p : h->hidden[li - 1].H16T.p));
         const int in_p = li == 0 ? h->D_p : (li == nl ? h->L_p : h->hidden[li - 1].nout_p);
-        auto dw = dw_for(li);
+        auto dw = [h, &hl, InT, in_p, rm, colsum_in_gemm](hipStream_t st) {
+            if (rm) grad_weight16_rm(h, hl.tW, hl.DZ16.p, hl.nout_p, InT, in_p, colsum_in_gemm ? hl.dbias : nullptr, st);
+            else grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, st);
+        };
         // Fork points: the top decoder layer and encoder layer 1 (and layer 0 when something is still queued): each
         // hands everything queued so far to the side stream.  The first layer's weight gradient is the end of the
         // chain -- nothing is left on the main stream for it to hide behind -- so it runs there.
-        // (a layer whose dZ16 came out of the dX GEMM above had its weight gradient queued there, in front of that fork)
-        if (li > 0 && !fused_dz[li]) q.add(dw);
+        if (li > 0) q.add(dw);
         if (li == nl && !h->comm && nl >= 2 && g_tuning.opt_split) {
             // Every decoder-side gradient is queued now (output layer, decoder layers; their bias / gamma / beta sums are
             // complete on the main stream).  The update of those tensors -- half of the parameters -- does not need this
@@ -627,10 +577,9 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         // costs the main stream ~5 us before its next kernel (the producing kernel's completion signal).  Variants measured at
         // C2 (profiles/r03w_*, r03zb_*, r03zc_*): these two 286 us per step; + the loss kernel 296; loss + LAST decoder layer +
         // encoder layer 1 299 against 297 on the box of that run.
+        const bool fork = li == 2 * nl - 1 || li == 1 || (li == 0 && !q.items.empty());
         const dim3 grid((unsigned)ceil_div(hl.nout_p, kDz16Cols), (unsigned)ceil_div(bs_p, kDz16Rows));
-        if (fused_dz[li]) {
-            // dZ16 of this layer (and its bias-gradient sums) came out of the dX GEMM above, which also was the fork point
-        } else if (is_fork(li)) {
+        if (fork) {
             launch_forking(h, vae_dz16_kernel, grid, dim3(256), 0, a);
             q.flush(h->side);
         } else {
@@ -652,7 +601,7 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
             g.slab_stride = (int64_t)bs_p * in_p;
             gemm16<E16_SPLITK>(h->stream, g, latent_slabs);
         } else {
-            fused_dz[li - 1] = produce(li - 1, hl.DZ16.p, hl.nout_p, hl.tW, in_p);
+            grad_input16(h, hl.DZ16.p, hl.nout_p, hl.tW, in_p, h->hidden[li - 1]);
         }
     };
     for (int li = 2 * nl - 1; li >= nl; --li) hidden_bwd(li);
@@ -671,7 +620,7 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
                 grad_weight16(h, h->tWmu, h->dMU16T.p, h->L_p, enc_last.H16T.p, enc_last.nout_p, st);
             }
         });
-        fused_dz[nl - 1] = produce(nl - 1, h->dMU16.p, h->L_p, h->tWmu, enc_last.nout_p);
+        grad_input16(h, h->dMU16.p, h->L_p, h->tWmu, enc_last.nout_p, enc_last);
     }
     for (int li = nl - 1; li >= 0; --li) hidden_bwd(li);
     join_side(h);   // every weight gradient, the loss reduction and the running statistics are complete
