@@ -167,27 +167,44 @@ __device__ __forceinline__ float ref_g4_tree(float a0, float a1, float a2, float
 }
 __device__ __forceinline__ float ref_distance_g4(const float* __restrict__ x, int64_t xs, const float* __restrict__ q, int64_t qs,
                                                  int L, int p) {
-    float s = x[0] * q[0];
+    // Per 16-lane block the lane's four (x, q) pairs are REQUESTED TOGETHER and then used: one trip to memory per block (written
+    // as load-use-load-use the compiler waits for every pair: nine dependent trips per round at L = 32 instead of three, which
+    // was ~7 us per pass of a C2 sweep, profiles/r04c_*).  Columns of the remainder block beyond the width re-read column L - 1
+    // and are zeroed: 0 * q added to a +0 lane is +0, what the reference's masked lanes hold.
+    const int last = L - 1;
+    const float xc = x[0], qc = q[0];   // (column 0 travels with the first block: its product is formed behind that block's loads)
+    float s;
     const int nfull = (L - 1) >> 4, rem = (L - 1) & 15;
     int k = 1;
     if (nfull > 0) {
-        float a0 = p == 0 ? s : 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
         for (int b = 0; b < nfull; ++b, k += 16) {
             const int64_t c = k + p;
-            a0 = __builtin_fmaf(x[c * xs], q[c * qs], a0);
-            a1 = __builtin_fmaf(x[(c + 4) * xs], q[(c + 4) * qs], a1);
-            a2 = __builtin_fmaf(x[(c + 8) * xs], q[(c + 8) * qs], a2);
-            a3 = __builtin_fmaf(x[(c + 12) * xs], q[(c + 12) * qs], a3);
+            const float x0 = x[c * xs], x1 = x[(c + 4) * xs], x2 = x[(c + 8) * xs], x3 = x[(c + 12) * xs];
+            const float q0 = q[c * qs], q1 = q[(c + 4) * qs], q2 = q[(c + 8) * qs], q3 = q[(c + 12) * qs];
+            if (b == 0 && p == 0) a0 = xc * qc;
+            a0 = __builtin_fmaf(x0, q0, a0);
+            a1 = __builtin_fmaf(x1, q1, a1);
+            a2 = __builtin_fmaf(x2, q2, a2);
+            a3 = __builtin_fmaf(x3, q3, a3);
         }
         s = ref_g4_tree(a0, a1, a2, a3);
+    } else {
+        s = xc * qc;
     }
     if (rem > 0) {
-        float a0 = p == 0 ? s : 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-        const int64_t c = k + p;
-        if (p < rem) a0 = __builtin_fmaf(x[c * xs], q[c * qs], a0);
-        if (p + 4 < rem) a1 = __builtin_fmaf(x[(c + 4) * xs], q[(c + 4) * qs], a1);
-        if (p + 8 < rem) a2 = __builtin_fmaf(x[(c + 8) * xs], q[(c + 8) * qs], a2);
-        if (p + 12 < rem) a3 = __builtin_fmaf(x[(c + 12) * xs], q[(c + 12) * qs], a3);
+        const int c = k + p;
+        const int c0 = c <= last ? c : last, c1 = c + 4 <= last ? c + 4 : last, c2 = c + 8 <= last ? c + 8 : last,
+                  c3 = c + 12 <= last ? c + 12 : last;
+        float x0 = x[(int64_t)c0 * xs], x1 = x[(int64_t)c1 * xs], x2 = x[(int64_t)c2 * xs], x3 = x[(int64_t)c3 * xs];
+        const float q0 = q[(int64_t)c0 * qs], q1 = q[(int64_t)c1 * qs], q2 = q[(int64_t)c2 * qs], q3 = q[(int64_t)c3 * qs];
+        if (c > last) x0 = 0.0f;
+        if (c + 4 > last) x1 = 0.0f;
+        if (c + 8 > last) x2 = 0.0f;
+        if (c + 12 > last) x3 = 0.0f;
+        // (lane p = 0 of the block always holds a real column -- the block exists -- so the running sum is never paired with a zero)
+        const float a0 = __builtin_fmaf(x0, q0, p == 0 ? s : 0.0f);
+        const float a1 = __builtin_fmaf(x1, q1, 0.0f), a2 = __builtin_fmaf(x2, q2, 0.0f), a3 = __builtin_fmaf(x3, q3, 0.0f);
         s = ref_g4_tree(a0, a1, a2, a3);
     }
     return 0.5f - s;
