@@ -557,7 +557,8 @@ def main():
         if roof is not None:
             roof["traffic"] = pmc_traffic(cfg_name.lower())
             roof["traffic_source"] = (f"static: profiles/r03_pmc_roofline_{cfg_name.lower()}.json (rocprofv3 --pmc passes of this kernel "
-                                      "at this shape, FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE); NOT counted in this run")
+                                      "at this shape, FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE; the kernel -- "
+                                      "gemm_bf16.hpp, K loop and hidden-train epilogue -- is unchanged since those passes); NOT counted in this run")
             if roof["traffic"]:
                 # the same launches against the other roofline: at C2 the kernel's arithmetic intensity (flops / PMC bytes)
                 # is below the ridge of 2.5 PFLOP/s : 8 TB/s = 312 flop/B, i.e. it is the HBM side that binds there
