@@ -435,7 +435,7 @@ def main():
     os.environ.pop("VAMBHIP_PRECISION", None)     # --dtype decides
     lib = _lib.load()
     _lib.require_gpu()
-    _lib.check(lib.vh_set_device(local))
+    _lib.check(lib.vh_set_device(local % max(1, _lib.device_count())))   # (several ranks may share a GPU in a functional run)
     comm = None
     dist = None
     if world > 1 or args.force_dist:
@@ -452,7 +452,10 @@ def main():
         dist.init_process_group(backend="gloo")
         from vamb_amd import parallel
 
-        comm = parallel.Communicator.from_torch_distributed(dist)
+        # VAMBHIP_BENCH_HOST_PLANE=1: the library's collectives through this gloo group instead of RCCL -- a FUNCTIONAL run of the
+        # N > 1 path with several ranks on one GPU (RCCL refuses two ranks per device); never a performance number
+        host_plane = bool(os.environ.get("VAMBHIP_BENCH_HOST_PLANE"))
+        comm = parallel.Communicator.from_torch_distributed(dist, rccl="host" if host_plane else True)
 
     strong = args.scaling == "strong" and (world > 1 or args.force_dist)   # (--force-dist: the multi-GPU code path on one rank)
     if strong:
