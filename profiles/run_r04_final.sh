@@ -21,6 +21,6 @@ for line in open(p):
 PY
 timeout 900 python bench.py --steps 1 --warmup 1 > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 1 --warmup 0 --epochs 20 --no-cluster --no-c3 --no-cpu-baseline > $O/bench_profiled.json 2> $O/bench_profiled.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 1 --warmup 0 --epochs 20 --no-cluster --no-c3 --no-cpu-baseline > $O/bench_profiled.json 2> $O/bench_profiled.err
 f=$(find $O/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_bench_train20.csv && head -12 $f | cut -c1-160
 rm -rf $O/prof
