@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Diagnostic (not a test): ONE free-running training step on identical fresh models, repeated; which tensors differ between
-repetitions?   python tools/gpu/gpu_determinism_step.py dtype reps [batch] [nsamples]"""
+repetitions?   python tests/diagnostics/gpu_determinism_step.py dtype reps [batch] [nsamples]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,9 +1,9 @@
-"""Diagnostic: per-tensor gradient error against the fp64 oracle at a large batch (python tools/gpu/gpu_large_batch_errors.py 16384)."""
+"""Diagnostic: per-tensor gradient error against the fp64 oracle at a large batch (python tests/diagnostics/gpu_large_batch_errors.py 16384)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
 import vae_oracle as vo
 from vamb_amd import encode as ve, synth
 batch = int(sys.argv[1]); drop = float(sys.argv[2]) if len(sys.argv) > 2 else 0.2

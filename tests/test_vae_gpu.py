@@ -213,7 +213,7 @@ def test_training_steps_bf16_within_tolerance(name, monkeypatch):
     """BASELINE configs C2+ prescribe bf16 MFMA with fp32 accumulation.  Same fixtures, same injected randomness
     as the fp32 parity test.  Forward quantities meet SURVEY.md section 8(c) (losses 1e-3 relative, latents 2e-2
     of the largest latent; measured 3e-4 and 4e-3).  Gradients are sums over the batch of terms of mixed sign, so
-    rounding their operands to 8 mantissa bits costs 0.5-15 % per tensor (measured, tools/gpu/gpu_bf16_errors.py; the
+    rounding their operands to 8 mantissa bits costs 0.5-15 % per tensor (measured, tests/diagnostics/gpu_bf16_errors.py; the
     layers below a BatchNorm backward are the noisy ones): asserted as direction (cosine > 0.98) and size
     (Frobenius error < 20 %), the level at which the same model trains normally (next test)."""
     monkeypatch.setenv("VAMBHIP_PRECISION", "bf16")
@@ -585,7 +585,7 @@ def test_large_batch_tiles_match_oracle(batch, big, monkeypatch):
     8192 (the largest BASELINE batch).  At 16384 individual output units deviate by up to ~2e-3 of the tensor's
     largest entry: with ~3e7 hidden activations per step some pre-activations land within fp32 rounding of the
     LeakyReLU kink, where float32 and float64 pick different slopes (0.01 vs 1) for that row
-    (tools/gpu/gpu_large_batch_errors.py shows the error concentrated in single units) -- the same happens between
+    (tests/diagnostics/gpu_large_batch_errors.py shows the error concentrated in single units) -- the same happens between
     any two float32 implementations."""
     monkeypatch.setenv("VAMBHIP_BIG_TILES", big)
     S, hid, L = 6, [512, 512], 32
