@@ -238,6 +238,64 @@ def semisup_randomness(name):
 
 
 # ------------------------------------------------------------------------------------------------
+# Joint TaxVamb trainer (SURVEY.md 8f N4 remainder; /root/reference/vamb/taxvamb_encode.py:551-743 on top of
+# semisupervised_encode.py:700-1084).  A taxonomy is a parent table in BFS order (taxvamb_encode.py:29-61); the label of a contig
+# is a NODE index (root, internal node or leaf).  n is a multiple of batch: one epoch of the reference's own trainepoch is
+# exactly `steps` optimiser steps over the rows 0 .. n-1 of the (seeded) permutation make_dataloader_semisupervised_hloss draws.
+# ------------------------------------------------------------------------------------------------
+VAEVAE_CASES = {
+    # 14 nodes / 9 leaves (the shape of the reference's own test taxonomy, test/test_semisupervised_encode.py:22-30)
+    "vaevae_tree_drop": dict(n=96, batch=32, nsamples=6, tree="three_by_three", nhiddens=[48, 40], nlatent=8, dropout=0.2,
+                             alpha=None, beta=200.0, seed=41, steps=3, lrate=1e-3, perm_seed=7),
+    # 131 nodes (> 105: the label block is as wide as the taxonomy), ragged widths, a chain, single-child nodes
+    "vaevae_tree_wide": dict(n=148, batch=37, nsamples=5, tree="random_131", nhiddens=[33, 17], nlatent=5, dropout=0.1,
+                             alpha=0.3, beta=50.0, seed=42, steps=4, lrate=1e-2, perm_seed=3),
+}
+VAEVAE_PASSES = ("joint", "vamb_x", "labels_x", "vamb_u", "vamb_s", "labels_u", "labels_s")   # order of the reference's step
+
+
+def vaevae_tree(name):
+    kind = VAEVAE_CASES[name]["tree"]
+    if kind == "three_by_three":
+        return [-1, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4]
+    rng = np.random.RandomState(1310)
+    parents = [-1, 0, 1, 2, 3]          # a chain of single-child nodes under the root
+    for i in range(5, 131):
+        parents.append(int(rng.randint(max(0, i - 40), i)) if rng.random_sample() < 0.8 else int(rng.randint(0, 5)))
+    return parents
+
+
+def vaevae_inputs(name):
+    """Raw features, the parent table and one node index per contig (every node occurs at least once, the root too)."""
+    c = VAEVAE_CASES[name]
+    ab, tnf, lens, _ = synth.features(c["n"], c["nsamples"], c["seed"], k=4)
+    parents = vaevae_tree(name)
+    nn = len(parents)
+    rng = np.random.RandomState(c["seed"] + 500)
+    assert c["n"] >= nn
+    nodes = np.concatenate([np.arange(nn), rng.randint(0, nn, size=c["n"] - nn)])
+    rng.shuffle(nodes)
+    return ab, tnf, lens, nodes.astype(np.int64), parents
+
+
+def vaevae_randomness(name):
+    """rnd[step][pass] = dict(masks=[bool [batch, width] per dropout call of the pass], eps=float32 [batch, nlatent]); the
+    ``_x`` passes only decode."""
+    c = VAEVAE_CASES[name]
+    rng = np.random.RandomState(c["seed"] + 1000)
+    enc, dec = list(c["nhiddens"]), list(c["nhiddens"][::-1])
+    out = []
+    for _ in range(c["steps"]):
+        step = {}
+        for p in VAEVAE_PASSES:
+            widths = dec if p.endswith("_x") else enc + dec
+            step[p] = dict(masks=[rng.random_sample((c["batch"], w)) >= c["dropout"] for w in widths],
+                           eps=rng.standard_normal((c["batch"], c["nlatent"])).astype(np.float32))
+        out.append(step)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # TNF case (row N2): seeded random sequences over the alphabet of the reference's own k-mer test
 # (test/testtools.py:75-86) plus U / u, lengths 4 .. 6000 and two degenerate ones
 # ------------------------------------------------------------------------------------------------

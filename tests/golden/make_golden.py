@@ -7,7 +7,7 @@ vambcore.overwrite_matrix and dadaptation.DAdaptAdam -- the latter restated, PAR
 The GPU box never runs this; tests read the committed .npz files.
 
     python tests/golden/make_golden.py            # regenerate everything
-    python tests/golden/make_golden.py cluster    # only one family (cluster | cluster_large | prep | vae | semisup | tnf | e2e)
+    python tests/golden/make_golden.py cluster    # only one family (cluster | cluster_large | prep | vae | semisup | vaevae | tnf | e2e)
 
 Environment recorded in golden_manifest.json (torch / numpy versions, thread count).
 """
@@ -248,6 +248,121 @@ def gen_semisup():
     return out
 
 
+def gen_vaevae(en):
+    """VAEVAEHLoss of the real reference (taxvamb_encode.py:551-743 on semisupervised_encode.py:700-1084): its own loaders and its
+    own ``trainmodel`` (one epoch = `steps` optimiser steps), with injected dropout masks / noise per network and pass; the
+    per-step metrics are the return values of the three loss functions, the step-0 gradients are read off the parameters inside
+    the first ``Adam.step``."""
+    import torch
+
+    ss = ref_harness.load_reference_module("semisupervised_encode")
+    tx = ref_harness.load_reference_module("taxvamb_encode")
+    out = {}
+    for name, c in fd.VAEVAE_CASES.items():
+        ab, tnf, lens, nodes, parents = fd.vaevae_inputs(name)
+        B, S, N = c["batch"], c["nsamples"], len(parents)
+        NL = max(N, 105)
+        node_names = [f"n{i}" for i in range(N)]
+        dl_v = en.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=B)
+        dl_j = tx.make_dataloader_concat_hloss(ab.copy(), tnf.copy(), lens, nodes, N, parents, batchsize=B)
+        dl_l = tx.make_dataloader_labels_hloss(ab.copy(), tnf.copy(), lens, nodes, N, parents, batchsize=B)
+        dl = tx.make_dataloader_semisupervised_hloss(dl_j, dl_v, dl_l, N, parents, (S, 103, 1, N), c["perm_seed"], batchsize=B)
+        assert len(dl) == c["steps"], (len(dl), c["steps"])
+        vae = tx.VAEVAEHLoss(S, N, node_names, parents, nhiddens=list(c["nhiddens"]), nlatent=c["nlatent"], alpha=c["alpha"],
+                             beta=c["beta"], dropout=c["dropout"])
+        assert vae.VAELabels.nlabels == vae.VAEJoint.nlabels == int(np.sum(~np.isin(np.arange(N), parents)))
+        widths = dict(VAEVamb=None, VAELabels=NL, VAEJoint=S + 104 + NL)
+        nets = dict(VAEVamb=vae.VAEVamb, VAELabels=vae.VAELabels, VAEJoint=vae.VAEJoint)
+        for i, (k, net) in enumerate(nets.items()):
+            st0 = vae_oracle.init_state(S if k != "VAELabels" else 0, c["nhiddens"], c["nlatent"], c["seed"] + i, width=widths[k])
+            net.load_state_dict({kk: torch.from_numpy(np.array(v)) for kk, v in st0.items()})
+        rnd = fd.vaevae_randomness(name)
+        order = dict(VAEVamb=("vamb_x", "vamb_u", "vamb_s"), VAELabels=("labels_x", "labels_u", "labels_s"), VAEJoint=("joint",))
+        queues = {}
+        for k, net in nets.items():
+            mq = [m for step in rnd for p in order[k] for m in step[p]["masks"]]
+            eq = [step[p]["eps"] for step in rnd for p in order[k]]
+            queues[k] = (mq, eq)
+
+            class InjectedDropout(torch.nn.Module):
+                def __init__(self, q):
+                    super().__init__()
+                    self.q = q
+
+                def forward(self, x):
+                    if not self.training or c["dropout"] == 0:
+                        return x
+                    m = self.q.pop(0)
+                    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(c["dropout"]))
+                    return x * torch.from_numpy(m.astype(np.float32) * scale)
+
+            net.dropoutlayer = InjectedDropout(mq)
+            net.reparameterize = (lambda q: (lambda mu: (mu + torch.from_numpy(q.pop(0))) if q else mu))(eq)
+        rec = {}
+        names10 = ("unsup_depths", "unsup_tnf", "unsup_abundance", "unsup_weights", "unsup_nodes", "sup_depths", "sup_tnf",
+                   "sup_abundance", "sup_weights", "sup_nodes")
+        for k, t in zip(names10, dl.dataset.tensors):
+            rec[k] = t.numpy().copy()
+        rec["parents"] = np.array(parents, np.int64)
+        rec["alpha"] = np.array(vae.VAEVamb.alpha)
+        steps_rec = []
+        cur = {}
+
+        def wrap(fn, key, grab=None):
+            def inner(*a, **kw):
+                r = fn(*a, **kw)
+                cur[key] = [float(x.item()) for x in r]
+                if grab is not None and "step0_mu_sup" not in rec:
+                    grab(a)
+                if key == "joint":
+                    v, lab, j = cur["vamb"], cur["labels"], cur["joint"]
+                    steps_rec.append(v + lab + j + [j[0] + v[0] + lab[0]])
+                return r
+            return inner
+
+        def grab_joint(a):
+            rec["step0_depths_out_x"] = a[1].detach().numpy().copy()
+            rec["step0_tnf_out_x"] = a[3].detach().numpy().copy()
+            rec["step0_labels_out_x"] = a[7].detach().numpy().copy()
+            rec["step0_mu_sup"] = a[8].detach().numpy().copy()
+            rec["step0_mu_vamb_sup"] = a[10].detach().numpy().copy()
+            rec["step0_mu_labels_sup"] = a[12].detach().numpy().copy()
+
+        vae.VAEVamb.calc_loss = wrap(vae.VAEVamb.calc_loss, "vamb")
+        vae.VAELabels.calc_loss = wrap(vae.VAELabels.calc_loss, "labels")
+        vae.calc_loss_joint = wrap(vae.calc_loss_joint, "joint", grab_joint)
+        real_adam = ss._Adam
+
+        class RecordingAdam(real_adam):
+            def step(self, *a, **kw):
+                if "grad0/VAEVamb/mu.weight" not in rec:
+                    for k, net in nets.items():
+                        for pname, p in net.named_parameters():
+                            rec[f"grad0/{k}/{pname}"] = (torch.zeros_like(p) if p.grad is None else p.grad).detach().numpy().copy()
+                return super().step(*a, **kw)
+
+        ss._Adam = RecordingAdam
+        try:
+            vae.trainmodel(dl, nepochs=1, lrate=c["lrate"], batchsteps=None)
+        finally:
+            ss._Adam = real_adam
+        assert len(steps_rec) == c["steps"] and not any(q[0] or q[1] for q in queues.values())
+        rec["losses"] = np.array(steps_rec, np.float64)   # [steps][17] in the order of trainepoch's metrics list (:830-848)
+        for k, net in nets.items():
+            for kk, v in net.state_dict().items():
+                rec[f"final/{k}/{kk}"] = v.numpy().copy()
+        for net in nets.values():
+            net.eval()
+        rec["latent_joint"] = vae.VAEJoint.encode(dl_j)
+        rec["latent_vamb"] = vae.VAEVamb.encode(dl_v)
+        rec["joint_depths"], rec["joint_tnf"], rec["joint_abundance"], rec["joint_weights"], rec["joint_nodes"] = (
+            t.numpy().copy() for t in dl_j.dataset.tensors)
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+        out[name] = dict(loss0=steps_rec[0][-1], loss_last=steps_rec[-1][-1], n_leaves=int(vae.VAELabels.nlabels))
+        print("vaevae", name, out[name])
+    return out
+
+
 def gen_e2e():
     """End-to-end runs of the real reference over several model seeds: loss curves + bin quality.  Free-running
     RNG, 8 threads (the CLI default, vamb/__main__.py:27-28): the stored numbers are a SPREAD to land in, not values to match."""
@@ -311,6 +426,8 @@ def main():
         manifest["vae"] = gen_vae(en)
     if "semisup" in which:
         manifest["semisup"] = gen_semisup()
+    if "vaevae" in which:
+        manifest["vaevae"] = gen_vaevae(en)
     if "e2e" in which:   # minutes of reference CPU time; 8 threads, free-running RNG
         manifest["e2e"] = gen_e2e()
     json.dump(manifest, open(manifest_path, "w"), indent=1, sort_keys=True)
