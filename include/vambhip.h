@@ -344,6 +344,39 @@ int vh_vae_use_dataset(vh_vae* h, vh_dataset* d);
 int vh_dataset_set_labels(vh_dataset* d, const int32_t* labels, int64_t n, int32_t nlabels);
 int vh_dataset_create_labels(const int32_t* labels, int64_t n, int32_t nlabels, vh_dataset** out);
 
+/* ---- hierarchical label loss and the joint TaxVamb trainer (SURVEY.md 8f row N4 remainder) -----------------------------
+ * vh_vae_set_hierarchy replaces Hierarchy(table_parent) + FlatSoftmaxNLL(tree) of VAELabelsHLoss / VAEConcatHLoss
+ * (/root/reference/vamb/taxvamb_encode.py:326-330, 474-478; vamb/hloss_misc.py:20-124, 1102-1133): the labels of the model's
+ * dataset become NODES of the taxonomy (table_parent[0] = -1, 0 <= table_parent[i] < i: the BFS order make_graph emits,
+ * taxvamb_encode.py:29-61), the label loss is -log of the softmax mass -- over the FIRST n_leaves label logits -- on the leaves
+ * at or below the row's node, and "correct predictions" is a constant 0 (taxvamb_encode.py:355).  fp32 step only. */
+int vh_vae_set_hierarchy(vh_vae* h, const int32_t* table_parent, int32_t n_nodes);
+
+/* The joint trainer replaces VAEVAE.trainepoch / trainmodel (/root/reference/vamb/semisupervised_encode.py:829-1084) as
+ * VAEVAEHLoss uses them (taxvamb_encode.py:551-743): per batch seven passes through three networks (VAEVamb = a plain handle,
+ * VAELabels = VH_VAE_LABELS, VAEJoint = VH_VAE_CONCAT; all fp32, all set to VH_OPT_ADAM), the sum of VAEVamb.calc_loss,
+ * VAELabels.calc_loss and calc_loss_joint, one Adam step.  The handles stay usable on their own (encode, state_dict). */
+typedef struct vh_vaevae vh_vaevae;
+int vh_vaevae_create(vh_vae* vamb, vh_vae* labels, vh_vae* joint, vh_vaevae** out);
+int vh_vaevae_destroy(vh_vaevae* t);
+/* The row-aligned tensors of make_dataloader_semisupervised_hloss's TensorDataset (taxvamb_encode.py:192-239): `unsup` =
+ * tensors 0-3 (features + weights), `unsup_labels` = tensor 4 (vh_dataset_create_labels), `sup` = tensors 5-9 (features +
+ * weights + labels: vh_dataset_create + vh_dataset_set_labels).  Same number of rows. */
+int vh_vaevae_set_datasets(vh_vaevae* t, vh_dataset* unsup, vh_dataset* unsup_labels, vh_dataset* sup);
+/* The 17 values of trainepoch's log line, in its order (semisupervised_encode.py:830-848): loss_vamb, ab_vamb, ce_vamb,
+ * sse_vamb, kld_vamb, loss_labels, ce_labels_labels, kld_labels, correct_labels_labels, loss_joint, ce_joint, sse_joint,
+ * ce_labels_joint, kld_vamb_joint, kld_labels_joint, correct_labels_joint, loss.
+ * train_step: one batch on rows[0..batch) (parity interface).  eps: NULL or 7 x [batch][nlatent] in pass order (joint, vamb_x,
+ *   labels_x, vamb_u, vamb_s, labels_u, labels_s: the order in which the reference's step calls reparameterize); masks: NULL or
+ *   the keep-masks of the same passes concatenated, each pass its hidden layers in application order ([batch][width] bytes per
+ *   layer; the two _x passes run decoders only).
+ * train_epoch: batch b takes rows[b*batch .. (b+1)*batch); metrics are the epoch means.  One host synchronisation. */
+int vh_vaevae_train_step(vh_vaevae* t, const int64_t* rows, int64_t batch, const float* eps, const uint8_t* masks,
+                         double metrics[17]);
+int vh_vaevae_train_epoch(vh_vaevae* t, const int64_t* rows, int64_t n_batches, int64_t batch, double metrics[17]);
+/* p.grad of the last vh_vaevae_train_step (after the single loss.backward(), :993): network 0 VAEVamb, 1 VAELabels, 2 VAEJoint */
+int vh_vaevae_get_grad(vh_vaevae* t, int network, const char* name, float* data, int64_t n);
+
 /* ---- make_dataloader on the device -------------------------------------------------
  * The matrix passes of vamb/encode.py:98-119 and vamb/vambtools.py:250-288 (column sums of the abundances, per-row
  * scaling + total + relative abundance, column z-score of the TNF block) run on the RAW matrices after ONE upload and

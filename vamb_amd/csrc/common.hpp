@@ -77,19 +77,28 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool borrowed = false;   // p belongs to another DevBuf (borrow): never freed here
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), borrowed(o.borrowed) { o.p = nullptr; o.n = 0; o.borrowed = false; }
     DevBuf& operator=(DevBuf&& o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; borrowed = o.borrowed; o.p = nullptr; o.n = 0; o.borrowed = false; }
         return *this;
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        borrowed = false;
+    }
+    // alias another buffer's storage (the owner must outlive this view)
+    void borrow(const DevBuf& owner) {
+        release();
+        p = owner.p;
+        n = owner.n;
+        borrowed = true;
     }
     void alloc(size_t count) {
         release();

@@ -18,4 +18,5 @@ struct vh_dataset {
     int64_t n = 0;
     int S = 0, D_p = 0;
     int NL = 0;   // width of the one-hot label block (0: no labels)
+    int32_t max_label = -1;   // largest label present (a hierarchical loss needs every label to be a node of its tree)
 };

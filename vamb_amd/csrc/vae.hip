@@ -223,6 +223,15 @@ struct vh_vae {
     DevBuf<int32_t> Lb;               // labels of the batch rows
     DevBuf<float> lab_part;           // per loss workgroup: label cross-entropy sum, correct predictions
     std::vector<double> label_stats;  // (mean label cross-entropy, correct predictions) per epoch of the last training call
+    // hierarchical label loss (vh_vae_set_hierarchy; taxvamb_encode.py:277-538): labels are nodes of a taxonomy, the loss sees the
+    // first n_leaves logits of the label block
+    int n_nodes = 0, n_leaves = 0;
+    DevBuf<uint8_t> leaf_masks;       // [n_nodes][n_leaves]
+    // joint trainer (vaevae.hpp): a PASS REPLICA shares the parameters, moments, running statistics, streams and counters of the
+    // network it belongs to and owns only its activations, gradient slabs and random-stream seed
+    bool owns_streams = true;
+    const unsigned long long* step_src = nullptr;   // the network's step counter (random streams)
+    const long long* batch_src = nullptr;           // the network's batch cursor (row gather)
     hipStream_t stream = nullptr;
     // weight-gradient GEMMs are off the critical path of backward (only the optimiser needs them): they
     // run on a second stream, forked after each layer's dZ is ready and joined before the update
@@ -301,8 +310,10 @@ struct vh_vae {
         for (auto e : ev_b) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side && side != stream) (void)hipStreamDestroy(side);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (owns_streams) {
+            if (side && side != stream) (void)hipStreamDestroy(side);
+            if (stream) (void)hipStreamDestroy(stream);
+        }
     }
 
     int add_tensor(const std::string& name, int rows, int cols, bool optimised, bool matrix = false) {
@@ -541,11 +552,15 @@ uint64_t layer_key(vh_vae* h, int layer) {
     return (h->cfg.seed * 0xD1342543DE82EF95ull) ^ (uint64_t)layer ^ (rank << 52);
 }
 
-const unsigned long long* step_ptr(vh_vae* h) { return &h->state.p->step; }
+const unsigned long long* step_ptr(vh_vae* h) { return h->step_src ? h->step_src : &h->state.p->step; }
+const long long* batch_ptr(vh_vae* h) { return h->batch_src ? h->batch_src : &h->state.p->batch; }
 
-void upload_masks(vh_vae* h, const uint8_t* masks, int bs) {
+// injected dropout keep-masks of the hidden layers [first, last): per layer [bs][nout] bytes, concatenated in layer order
+void upload_masks(vh_vae* h, const uint8_t* masks, int bs, int first = 0, int last = -1) {
     size_t off = 0;
-    for (auto& hl : h->hidden) {
+    if (last < 0) last = (int)h->hidden.size();
+    for (int li = first; li < last; ++li) {
+        Hidden& hl = h->hidden[li];
         std::vector<uint8_t> buf((size_t)h->bs_p * hl.nout_p, 0);
         for (int r = 0; r < bs; ++r)
             memcpy(buf.data() + (size_t)r * hl.nout_p, masks + off + (size_t)r * hl.nout, hl.nout);
@@ -653,7 +668,13 @@ BnSrc bn_src(vh_vae* h, const Hidden& hl) {
 //   staging its A operand (XF_BN), and its epilogue does bias + LeakyReLU + dropout, stores H and
 //   accumulates the batch sums of H for its own BatchNorm.  The normalised activations are never written.
 // eval: running statistics folded into the epilogue (EPI_HIDDEN_EVAL), activations in hl.A.
-void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, bool add_noise) {
+// Parts of a pass (joint trainer, vaevae.hpp): PASS_DECODER starts at the latent code -- `z_src` [bs_p][L_p] plays mu, the
+// noise is added to it (semisupervised_encode.py:903-908: VAEVamb._decode(VAEVamb.reparameterize(mu_sup))) -- and touches
+// neither the encoder's activations nor its running statistics; PASS_ENCODER (backward only) starts at h->dMUk.
+enum { PASS_FULL = 0, PASS_DECODER = 1, PASS_ENCODER = 2 };
+
+void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, bool add_noise, int part = PASS_FULL,
+             const float* z_src = nullptr, const float* zero_bias = nullptr) {
     const int bs = h->bs, bs_p = h->bs_p;
     hipStream_t s = h->stream;
     const DropCfg dc = drop_cfg(h, training, masks_injected);
@@ -704,9 +725,10 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
         }
         in_w = hl.nout_p;
     };
-    for (int li = 0; li < h->nl; ++li) hidden_layer(li);
+    if (part != PASS_DECODER)
+        for (int li = 0; li < h->nl; ++li) hidden_layer(li);
     int mu_slabs = 1;
-    {   // mu = a * Wmu^T + bmu  (encode.py:268).  The output is only nlatent wide, so the contraction is
+    if (part != PASS_DECODER) {   // mu = a * Wmu^T + bmu  (encode.py:268).  The output is only nlatent wide, so the contraction is
         // split over up to 8 workgroup slices (slabs); bias and the slab sum are folded into the
         // reparameterisation kernel below.
         GemmArgs g = base_args(h->bf16);
@@ -727,10 +749,12 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
     }
     {   // latent = mu + eps  (encode.py:276-286; sigma == 1); eps injected (parity) or generated in place
         const int64_t tot = (int64_t)bs_p * h->L_p;
-        hipLaunchKernelGGL(vae_reparam_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s, h->skinny.p,
-                           mu_slabs, (int64_t)bs_p * h->L_p, h->pptr(h->tbmu), eps_injected ? h->EPS.p : nullptr,
-                           layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z.p, bs, h->L, h->L_p,
-                           bs_p);
+        const bool ext = part == PASS_DECODER;
+        VH_REQUIRE(!ext || (z_src != nullptr && zero_bias != nullptr), "a decoder-only pass needs its latent input");
+        hipLaunchKernelGGL(vae_reparam_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s, ext ? z_src : h->skinny.p,
+                           mu_slabs, (int64_t)bs_p * h->L_p, ext ? zero_bias : h->pptr(h->tbmu),
+                           eps_injected ? h->EPS.p : nullptr, layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p,
+                           h->Z.p, bs, h->L, h->L_p, bs_p);
         VH_HIP(hipGetLastError());
     }
     in = h->Z.p;
@@ -761,7 +785,8 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
         RunningTable rt;
         memset(&rt, 0, sizeof(rt));
         int maxn = 0;
-        for (auto& hl : h->hidden) {
+        for (int li = part == PASS_DECODER ? h->nl : 0; li < 2 * h->nl; ++li) {
+            Hidden& hl = h->hidden[li];
             rt.fstat[rt.n] = hl.fstat; rt.rm[rt.n] = h->pptr(hl.tRM); rt.rv[rt.n] = h->pptr(hl.tRV);
             rt.n_p[rt.n] = hl.nout_p;
             maxn = std::max(maxn, hl.nout_p);
@@ -773,17 +798,19 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
     }
 }
 
-void loss_and_seed(vh_vae* h) {
+// kld_w < 0: the model's own weight; 0: a pass whose Kullback-Leibler term lives elsewhere (calc_loss_joint)
+void loss_and_seed(vh_vae* h, float kld_w = -1.0f) {
     const int bs_global = h->global_bs > 0 ? h->global_bs : h->bs;
     LossArgs a;
     a.R = h->R.p; a.X = h->Xb.p; a.ld = h->D_p;
     a.MU = h->MU.p; a.ldl = h->L_p;
     a.inv_b2 = (float)(1.0 / ((double)bs_global * (double)bs_global));
     a.bs = h->bs; a.bs_p = h->bs_p; a.S = h->S; a.L = h->L;
-    a.ce_w = h->ce_w; a.ab_w = h->ab_w; a.sse_w = h->sse_w; a.kld_w = h->kld_w;
+    a.ce_w = h->ce_w; a.ab_w = h->ab_w; a.sse_w = h->sse_w; a.kld_w = kld_w < 0.f ? h->kld_w : kld_w;
     a.dR = h->dR.p; a.dMUk = h->dMUk.p; a.part = h->loss_part.p;
     a.NL = h->NL; a.lab0 = h->lab0; a.ntnf = h->ntnf; a.nab = h->nab; a.Lb = h->Lb.p;
     a.lab_part = h->NL > 0 ? h->lab_part.p : nullptr;
+    a.leaf_masks = h->leaf_masks.p; a.n_leaves = h->n_leaves;
     // the scalar reduction (loss means, sum of weights) is only needed by the optimiser: side stream; the
     // output layer's weight gradient (backward) forks off the same point
     launch_forking(h, vae_loss_kernel, dim3(h->loss_blocks), dim3(256), 0, a);
@@ -857,11 +884,13 @@ int grad_input(vh_vae* h, const float* dZ, int out_p, int tW, int in_p, float* d
 // Backward of one step.  Critical path (main stream) per hidden layer: one bandwidth-bound dZ kernel and
 // one dIn GEMM whose epilogue leaves dA plus the BatchNorm-backward sums of the layer below (so BatchNorm
 // backward has no reduction / finalize kernels).  Weight gradients run on the side stream.
-void backward(vh_vae* h, bool masks_injected) {
+// part (joint trainer): PASS_DECODER stops at the latent code -- h->dMU then holds d loss / d z and nothing upstream of it is
+// touched; PASS_ENCODER starts there: h->dMUk holds d loss / d mu (put there by the caller), the decoder is skipped.
+void backward(vh_vae* h, bool masks_injected, int part = PASS_FULL) {
     const int bs = h->bs, bs_p = h->bs_p, nrb = bs_p / kRB;
     const DropCfg dc = drop_cfg(h, true, masks_injected);
     const int nl = h->nl;
-    {   // output layer: dR is ready (loss kernel)
+    if (part != PASS_ENCODER) {   // output layer: dR is ready (loss kernel)
         Hidden& last = h->hidden[2 * nl - 1];
         const BnSrc inbn = bn_src(h, last);
         // (the side stream already waits on the loss kernel: loss_and_seed)
@@ -912,7 +941,9 @@ void backward(vh_vae* h, bool masks_injected) {
         } else if (li > 0) grad_input(h, hl.DZ.p, hl.nout_p, hl.tW, in_p, below->DA.p, below, false);
         // li == 0: the input gradient is never needed
     };
-    for (int li = 2 * nl - 1; li >= nl; --li) hidden_bwd(li);
+    if (part != PASS_ENCODER)
+        for (int li = 2 * nl - 1; li >= nl; --li) hidden_bwd(li);
+    else latent_slabs = 0;   // nothing arrives from a decoder: dMU = dMUk
     {   // latent: dMU = dZlat + d(KLD)/dmu; mu layer
         Hidden& enc_last = h->hidden[nl - 1];
         // latent_slabs == 1: the first decoder layer wrote dZlat into DA; otherwise split-K slabs in skinny
@@ -920,6 +951,10 @@ void backward(vh_vae* h, bool masks_injected) {
         launch_forking(h, vae_latent_bwd_kernel, dim3((unsigned)ceil_div(h->L_p, kCT), nrb), dim3(kCT, kRL), 0, src,
                        latent_slabs, (int64_t)bs_p * h->L_p, (const float*)h->dMUk.p, h->dMU.p, h->L_p, bs, bs_p,
                        h->tensors[h->tbmu].slab);
+        if (part == PASS_DECODER) {
+            join_side(h);
+            return;
+        }
         const BnSrc inbn = bn_src(h, enc_last);
         grad_weight(h, h->tWmu, h->dMU.p, h->L_p, enc_last.H.p, enc_last.nout_p, &inbn);
         grad_input(h, h->dMU.p, h->L_p, h->tWmu, enc_last.nout_p, enc_last.DA.p, &enc_last, false);
@@ -928,9 +963,13 @@ void backward(vh_vae* h, bool masks_injected) {
     join_side(h);  // every weight gradient (and the running statistics) is complete before the optimiser
 }
 
-void optimizer_step(vh_vae* h) {
+// combined: the flat buffer h->G already holds the complete, fully scaled gradient (joint trainer: the sum over the passes of a
+// network) -- no slab reduction, no collective, no sum(w) factor
+void optimizer_step(vh_vae* h, bool combined = false) {
     const OptTable* tab = &h->opt_tab;
-    if (h->comm) {
+    if (combined) {
+        tab = &h->opt_tab_flat;
+    } else if (h->comm) {
         // sum this rank's slabs into the flat buffer, all-reduce it over the ranks (RCCL, same stream,
         // no host synchronisation), then every rank applies the identical update
         hipLaunchKernelGGL(vae_reduce_slabs_kernel, dim3(h->opt_blocks), dim3(256), 0, h->stream, h->opt_tab, h->G.p,
@@ -942,7 +981,7 @@ void optimizer_step(vh_vae* h) {
     const int nblk = h->opt_blocks;
     if (nblk > 0) {
         hipLaunchKernelGGL(vae_dadapt_kernel, dim3(nblk), dim3(256), 0, h->stream, *tab, h->P.p, h->M1.p, h->M2.p,
-                           h->Sv.p, h->state.p, h->opt_part.p, 0, h->adam_lr);
+                           h->Sv.p, h->state.p, h->opt_part.p, 0, h->adam_lr, combined ? 1.0f : 0.0f);
         VH_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(vae_dadapt_finalize_kernel, dim3(1), dim3(256), 0, h->stream, h->opt_part.p, h->opt_blocks,
@@ -954,7 +993,7 @@ void optimizer_step(vh_vae* h) {
 void gather_rows(vh_vae* h, const int64_t* dev_idx) {
     auto kern = h->kind == VH_VAE_PLAIN ? vae_gather_kernel<false> : vae_gather_kernel<true>;
     hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, h->stream, h->X.p,
-                       h->ld_src, (int64_t)h->D_p, h->w.p, dev_idx, h->shuffle, &h->state.p->batch, (int64_t)0, h->bs,
+                       h->ld_src, (int64_t)h->D_p, h->w.p, dev_idx, h->shuffle, batch_ptr(h), (int64_t)0, h->bs,
                        h->bs_p, h->Xb.p, h->Wb.p, LabelSrc{h->labels, h->lab0}, h->Lb.p);
     VH_HIP(hipGetLastError());
 }
@@ -1333,6 +1372,8 @@ void upload_labels(vh_dataset* d, const int32_t* labels, int64_t n, int32_t nlab
     d->labels.alloc((size_t)n);
     VH_HIP(hipMemcpy(d->labels.p, labels, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
     d->NL = nlabels;
+    d->max_label = -1;
+    for (int64_t i = 0; i < n; ++i) d->max_label = std::max(d->max_label, labels[i]);
 }
 }  // namespace
 
@@ -1381,6 +1422,8 @@ int vh_vae_use_dataset(vh_vae* h, vh_dataset* d) {
         VH_REQUIRE(d->S == h->S, "dataset has %d samples, the model %d", d->S, h->S);
         if (h->kind == VH_VAE_PLAIN) VH_REQUIRE(d->D_p == h->D_p, "dataset rows are %d wide, the model's %d", d->D_p, h->D_p);
         else VH_REQUIRE(d->labels.p != nullptr && d->NL == h->NL, "the model has %d label columns, the dataset %d", h->NL, d->NL);
+        VH_REQUIRE(h->n_leaves == 0 || d->max_label < h->n_nodes, "label %d is not a node of the model's taxonomy (%d nodes)",
+                   d->max_label, h->n_nodes);
         VH_HIP(hipStreamSynchronize(h->stream));
         h->own.X.release();
         h->own.w.release();
@@ -1890,6 +1933,7 @@ int vh_vae_set_precision(vh_vae* h, int bf16_operands) {
         VH_REQUIRE(h != nullptr, "NULL handle");
         const bool on = bf16_operands != 0;
         if (on == h->bf16) return;
+        VH_REQUIRE(!on || h->n_leaves == 0, "the hierarchical label loss is implemented by the fp32 step");
         // the bf16 step's loss kernel stages 4 x (reconstruction row + target row) in LDS: checked HERE (VH_ERR_INVALID), not at
         // the first training step -- VAEConcat / VAELabels with a few thousand classes reach this width (step16::loss_and_seed16)
         VH_REQUIRE(!on || (size_t)8 * h->D_p * sizeof(float) <= 160 * 1024 - 256,
@@ -1908,6 +1952,39 @@ int vh_vae_set_precision(vh_vae* h, int bf16_operands) {
             step16::refresh_shadows(h, -1);
             VH_HIP(hipStreamSynchronize(h->stream));
         }
+    });
+}
+
+// taxvamb_encode.py:326-330 / 474-478: Hierarchy(table_parent) + FlatSoftmaxNLL(tree).  table_parent[0] = -1 (the root),
+// 0 <= table_parent[i] < i (taxvamb_encode.py:49-61 emits nodes in BFS order); leaves = nodes nobody names as a parent, in
+// node order (hloss_misc.py:51-58); leaf_masks[i][j] = leaf j is node i or below it (hloss_misc.py:98-115, 1110-1113).
+int vh_vae_set_hierarchy(vh_vae* h, const int32_t* table_parent, int32_t n_nodes) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && table_parent != nullptr, "NULL argument");
+        VH_REQUIRE(h->kind != VH_VAE_PLAIN, "the model has no label block");
+        VH_REQUIRE(!h->bf16, "the hierarchical label loss is implemented by the fp32 step");
+        VH_REQUIRE(n_nodes >= 1 && n_nodes <= h->NL, "%d nodes do not fit the model's %d label columns", n_nodes, h->NL);
+        VH_REQUIRE(table_parent[0] == -1, "node 0 must be the root (parent -1), not a child of %d", table_parent[0]);
+        std::vector<int> nchild((size_t)n_nodes, 0);
+        for (int i = 1; i < n_nodes; ++i) {
+            VH_REQUIRE(table_parent[i] >= 0 && table_parent[i] < i, "parent %d of node %d: parents must precede their children",
+                       table_parent[i], i);
+            nchild[table_parent[i]]++;
+        }
+        std::vector<int> leaf_of((size_t)n_nodes, -1);
+        int n_leaves = 0;
+        for (int i = 0; i < n_nodes; ++i)
+            if (nchild[i] == 0) leaf_of[i] = n_leaves++;
+        std::vector<uint8_t> mask((size_t)n_nodes * n_leaves, 0);
+        for (int j = 0; j < n_nodes; ++j) {
+            if (leaf_of[j] < 0) continue;
+            for (int i = j; i >= 0; i = table_parent[i]) mask[(size_t)i * n_leaves + leaf_of[j]] = 1;   // j itself and every ancestor
+        }
+        VH_HIP(hipStreamSynchronize(h->stream));
+        h->leaf_masks.alloc(mask.size());
+        VH_HIP(hipMemcpy(h->leaf_masks.p, mask.data(), mask.size(), hipMemcpyHostToDevice));
+        h->n_nodes = n_nodes;
+        h->n_leaves = n_leaves;
     });
 }
 
@@ -2228,3 +2305,5 @@ int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, 
 }
 
 }  // extern "C"
+
+#include "vaevae.hpp"   // the joint TaxVamb trainer (vh_vaevae_*), built from the step above

@@ -245,6 +245,11 @@ struct LossArgs {
     int NL, lab0, ntnf, nab;
     const int32_t* Lb;
     float* lab_part;     // [gridDim.x][2] : cross-entropy sum, correct predictions
+    // hierarchical label loss (taxvamb_encode.py:277-538 with hloss_misc.FlatSoftmaxNLL, the default 'flat_softmax'): the row's
+    // label is a NODE of the taxonomy, the loss sees only the first n_leaves logits and is -log of the softmax mass on the
+    // leaves at or below the node; leaf_masks[node][leaf] says which.  n_leaves == 0: one-hot cross-entropy over all NL logits.
+    const uint8_t* leaf_masks;
+    int n_leaves;
 };
 
 // Cross-entropy of one row's label logits and its gradient (softmax - onehot) * g; returns (ce, correct) on every lane.
@@ -275,6 +280,44 @@ __device__ __forceinline__ void label_block(const float* __restrict__ r, int NL,
     }
     ce_out = (logf(se) + mx) - r[y];
     correct_out = arg == y ? 1.0f : 0.0f;
+}
+
+// hloss_misc.py:1121-1133 for one row: logp = log_softmax(first n_leaves logits); loss = -logsumexp(logp over the leaves of the
+// row's node); gradient g * (p - [leaf in mask] * p / sum_mask p) on those logits, 0 on the other NL - n_leaves columns (the
+// reference's narrow(1, .., n_leaves) never lets a gradient reach them).  "correct" does not exist here (the HLoss classes
+// return a constant 0, taxvamb_encode.py:355).  Both exponent sums are taken about their own maxima, so a node whose leaves hold
+// a vanishing share of the softmax mass still has a finite loss, as torch.logsumexp has.
+template <class Store>
+__device__ __forceinline__ void label_block_hier(const float* __restrict__ r, int NL, int n_leaves, const uint8_t* __restrict__ mask,
+                                                 float g, Store&& store, float& ce_out) {
+    const int lane = threadIdx.x & 63;
+    float mx = -3.0e38f, mxm = -3.0e38f;
+    for (int c = lane; c < n_leaves; c += 64) {
+        const float v = r[c];
+        mx = fmaxf(mx, v);
+        if (mask[c]) mxm = fmaxf(mxm, v);
+    }
+    mx = wave_max(mx);
+    mxm = wave_max(mxm);
+    float se = 0.f, sm = 0.f;
+    for (int c = lane; c < n_leaves; c += 64) {
+        const float v = r[c];
+        se += expf(v - mx);
+        if (mask[c]) sm += expf(v - mxm);
+    }
+    se = wave_sum(se);
+    sm = wave_sum(sm);
+    const float inv = 1.0f / se, invm = 1.0f / sm;
+    for (int c = lane; c < NL; c += 64) {
+        float d = 0.f;
+        if (c < n_leaves) {
+            const float v = r[c];
+            d = expf(v - mx) * inv;
+            if (mask[c]) d -= expf(v - mxm) * invm;
+        }
+        store(c, g * d);
+    }
+    ce_out = (logf(se) + mx) - (logf(sm) + mxm);
 }
 
 __global__ __launch_bounds__(256) void vae_loss_kernel(const LossArgs a) {
@@ -335,7 +378,10 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const LossArgs a) {
             }
             ab = wave_sum(ab);
             // label logits
-            if (a.NL > 0) label_block(r + a.lab0, a.NL, a.Lb[row], g, [&](int c, float v) { dr[a.lab0 + c] = v; }, cel_t, hit_t);
+            if (a.NL > 0 && a.n_leaves > 0)
+                label_block_hier(r + a.lab0, a.NL, a.n_leaves, a.leaf_masks + (int64_t)a.Lb[row] * a.n_leaves, g,
+                                 [&](int c, float v) { dr[a.lab0 + c] = v; }, cel_t);
+            else if (a.NL > 0) label_block(r + a.lab0, a.NL, a.Lb[row], g, [&](int c, float v) { dr[a.lab0 + c] = v; }, cel_t, hit_t);
             // zero the padding columns
             for (int c = S + a.ntnf + a.nab + a.NL + lane; c < a.ld; c += 64) dr[c] = 0.f;
             // KLD = 0.5 * sum(mu^2)
@@ -734,7 +780,7 @@ __global__ __launch_bounds__(256) void vae_dadapt_kernel(const OptTable tab, flo
                                                          float* __restrict__ M1, float* __restrict__ M2,
                                                          float* __restrict__ Sv, const StepState* __restrict__ st,
                                                          double* __restrict__ partials /*[all blocks][2]*/, int blk0,
-                                                         float adam_lr) {
+                                                         float adam_lr, float gscale_fixed = 0.0f) {
     __shared__ double red[2][4];
     const int blk = blockIdx.x + blk0;   // the launch covers the table's workgroups [blk0, blk0 + gridDim.x)
     const int t = opt_find_tensor(tab, blk);
@@ -743,7 +789,8 @@ __global__ __launch_bounds__(256) void vae_dadapt_kernel(const OptTable tab, flo
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     const double sqrt_b2d = sqrt(0.999);
     const double dlr = st->d;  // lr == 1
-    const float gscale = (float)st->wsum;  // the loss' factor sum(w), see LossArgs::inv_b2
+    // the loss' factor sum(w), see LossArgs::inv_b2 (gscale_fixed > 0: the gradient in the table is already complete)
+    const float gscale = gscale_fixed > 0.0f ? gscale_fixed : (float)st->wsum;
     const float a_m = (float)(dlr * (1.0 - 0.9));
     const float a_s = (float)(dlr * (1.0 - sqrt_b2d));
     const float sqrt_b2 = (float)sqrt_b2d;
