@@ -61,30 +61,42 @@ def test_semisupervised_classes_mirror_the_reference():
         assert sig(getattr(vs, fn)) == sig(getattr(ss, fn)), fn
     # state_dict names / shapes
     ref = ss.VAEConcat(6, 130, nhiddens=[48, 40], nlatent=8).state_dict()
-    me = types.SimpleNamespace(nsamples=6, _native_nsamples=6, nlabels=130, nhiddens=[48, 40], nlatent=8)
+    me = types.SimpleNamespace(nsamples=6, _native_nsamples=6, nlabels=130, _NL=130, nhiddens=[48, 40], nlatent=8)
     me._row_width = lambda: vs.VAEConcat._row_width(me)
     assert vs.VAEConcat._state_names(me) == list(ref.keys())
     for k in ref:
         assert tuple(vs.VAEConcat._shape_of(me, k)) == tuple(ref[k].shape), k
     ref = ss.VAELabels(150, nhiddens=[64, 32], nlatent=6).state_dict()
-    me = types.SimpleNamespace(nsamples=46, nlabels=150, nhiddens=[64, 32], nlatent=6)
+    me = types.SimpleNamespace(nsamples=46, nlabels=150, _NL=150, nhiddens=[64, 32], nlatent=6)
     me._row_width = lambda: vs.VAELabels._row_width(me)
     for k in ref:
         assert tuple(vs.VAELabels._shape_of(me, k)) == tuple(ref[k].shape), k
-    theirs = ss.VAELabels
+    # the joint trainer and the HLoss classes (taxvamb_encode.py:277-743): same constructor / method signatures
+    tx = ref_harness.load_reference_module("taxvamb_encode")
+    from vamb_amd import taxvamb_encode as vt
+
+    for cls, meths in (("VAELabelsHLoss", ("__init__", "calc_loss", "trainmodel")), ("VAEConcatHLoss", ("__init__", "calc_loss")),
+                       ("VAEVAEHLoss", ("__init__", "calc_loss_joint", "trainepoch", "trainmodel", "save", "load"))):
+        for meth in meths:
+            assert sig(getattr(getattr(vt, cls), meth)) == sig(getattr(getattr(tx, cls), meth)), (cls, meth)
+    for fn in ("make_dataloader_labels_hloss", "make_dataloader_concat_hloss", "make_dataloader_semisupervised_hloss",
+               "permute_indices", "make_graph", "kld_gauss", "collate_fn_labels_hloss", "collate_fn_concat_hloss",
+               "collate_fn_semisupervised_hloss"):
+        assert sig(getattr(vt, fn)) == sig(getattr(tx, fn)), fn
+    assert sig(vs.VAEVAE.__init__) == sig(ss.VAEVAE.__init__) and sig(vs.VAEVAE.trainmodel) == sig(ss.VAEVAE.trainmodel)
+    assert vs.VAEVAE_METRICS[0] == "loss_vamb" and len(vs.VAEVAE_METRICS) == 17
+    theirs, their_joint = ss.VAELabels, tx.VAEVAEHLoss
     saved = dropin.install(vamb, semisupervised=True)
     try:
-        assert ss.VAELabels is vs.VAELabels and ss.VAEConcat is vs.VAEConcat
+        assert ss.VAELabels is vs.VAELabels and ss.VAEConcat is vs.VAEConcat and ss.VAEVAE is vs.VAEVAE
         assert ss.make_dataloader_concat is vs.make_dataloader_concat
-        # the reference's joint trainer (semisupervised_encode.py:700-770) still builds -- and gets -- its own torch networks
-        joint = ss.VAEVAE(6, 130, nhiddens=[48, 40], nlatent=8)
-        assert type(joint.VAELabels) is theirs and isinstance(joint.VAEJoint, torch.nn.Module)
-        assert isinstance(joint.VAEVamb, torch.nn.Module) and len(list(joint.VAEVamb.parameters())) > 0
-        assert ss.VAELabels is vs.VAELabels      # ... and the module attributes point at the GPU classes again
+        # what `vamb bin taxvamb` looks up at call time (__main__.py:1988-2047) is the GPU trainer and its loaders
+        assert tx.VAEVAEHLoss is vt.VAEVAEHLoss and tx.VAELabelsHLoss is vt.VAELabelsHLoss
+        assert tx.make_dataloader_semisupervised_hloss is vt.make_dataloader_semisupervised_hloss
+        assert issubclass(tx.VAMB2Label, torch.nn.Module)   # Taxometer's classifier is untouched
     finally:
         dropin.uninstall(saved, vamb)
-    assert ss.VAELabels is theirs
-    assert not getattr(ss.VAEVAE.__init__, "_vamb_amd_wrapped", False)
+    assert ss.VAELabels is theirs and tx.VAEVAEHLoss is their_joint
 
 
 @pytest.mark.skipif(not ref_harness.reference_available(), reason="reference tree not present")

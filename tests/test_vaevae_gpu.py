@@ -1,0 +1,276 @@
+"""GPU parity tests of the joint TaxVamb trainer and the hierarchical label loss (SURVEY.md 8f N4 remainder):
+vamb_amd.taxvamb_encode on libvambhip (vh_vae_set_hierarchy, vh_vaevae_*) against
+(a) golden vectors recorded by running the REAL ``VAEVAEHLoss.trainmodel`` (/root/reference/vamb/taxvamb_encode.py:551-743 on
+    semisupervised_encode.py:829-1084) under torch autograd with injected dropout masks / noise -- all 17 metrics of every step,
+    every parameter's gradient of step 0, every parameter and buffer after the steps, the latents of VAEJoint and VAEVamb -- and
+(b) the fp64 numpy restatement (oracle/vaevae_oracle.py).
+
+Tolerances are those of the single networks (tests/test_vae_gpu.py, test_semisup_gpu.py): fp32 -- metrics 2e-5, gradients 1e-4 of
+the tensor's max, parameters after k Adam steps 3e-2 * lr (elements whose gradient stayed at Adam's eps scale: k * lr, see
+tests/test_oracle_vaevae.py), latents 2^-10."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_defs as fd
+import test_oracle_vaevae as tov
+import vaevae_oracle as vv
+from vamb_amd import encode as ve, semisupervised_encode as vs, synth, taxvamb_encode as vt
+
+pytestmark = pytest.mark.gpu
+rel = tov.rel
+NETS = ("VAEVamb", "VAELabels", "VAEJoint")
+
+
+def build(name, g, dropout=None):
+    c = dict(fd.VAEVAE_CASES[name])
+    if dropout is not None:
+        c["dropout"] = dropout
+    parents = [int(p) for p in g["parents"]]
+    N = len(parents)
+    vae = vt.VAEVAEHLoss(c["nsamples"], N, [f"n{i}" for i in range(N)], parents, nhiddens=list(c["nhiddens"]), nlatent=c["nlatent"],
+                         alpha=c["alpha"], beta=c["beta"], dropout=c["dropout"])
+    assert abs(vae.VAEVamb.alpha - float(g["alpha"])) < 1e-12
+    assert vae.VAELabels.nlabels == vae.VAEJoint.nlabels == int(np.sum(~np.isin(np.arange(N), parents)))
+    for k, st in tov.init_states(name).items():
+        getattr(vae, k).load_state_dict({kk: torch.from_numpy(np.array(v, dtype=np.float32 if v.dtype.kind == "f" else v.dtype))
+                                         for kk, v in st.items()})
+    names10 = ("unsup_depths", "unsup_tnf", "unsup_abundance", "unsup_weights", "unsup_nodes", "sup_depths", "sup_tnf",
+               "sup_abundance", "sup_weights", "sup_nodes")
+    ds = torch.utils.data.TensorDataset(*(torch.from_numpy(g[k]) for k in names10))
+    B = c["batch"]
+    dl = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, drop_last=len(ds) > B,
+                                     collate_fn=partial(vt.collate_fn_semisupervised_hloss, N, parents))
+    assert vae._ensure_dataset(dl) == c["n"]
+    vae._set_adam(c["lrate"], reset=True)
+    return c, vae, dl, parents
+
+
+def randomness_of(c, rnd_step):
+    eps = [rnd_step[p]["eps"] for p in fd.VAEVAE_PASSES]
+    masks = [rnd_step[p]["masks"] for p in fd.VAEVAE_PASSES] if c["dropout"] > 0 else None
+    return eps, masks
+
+
+@pytest.mark.parametrize("name", list(fd.VAEVAE_CASES))
+def test_joint_training_steps_match_reference_and_oracle(name):
+    g = fd.load(name)
+    c, vae, dl, parents = build(name, g)
+    rnd = fd.vaevae_randomness(name)
+    oracle = tov.make_oracle(name, g)
+    B = c["batch"]
+    gmax = {}
+    for step in range(c["steps"]):
+        rows = np.arange(step * B, (step + 1) * B)
+        eps, masks = randomness_of(c, rnd[step])
+        got = vae.train_batch(rows, eps=eps, masks=masks)
+        un, un_nodes = tov.batch_of(g, "unsup", step * B, (step + 1) * B)
+        su, su_nodes = tov.batch_of(g, "sup", step * B, (step + 1) * B)
+        want = oracle.train_step(un, un_nodes, su, su_nodes, rnd[step], lr=c["lrate"])
+        ref = g["losses"][step]
+        for i, key in enumerate(vv.METRICS):
+            assert abs(got[i] - ref[i]) <= 2e-5 * abs(ref[i]) + 1e-8, (step, key, got[i], ref[i])
+            assert abs(got[i] - want[i]) <= 2e-5 * abs(want[i]) + 1e-8, (step, key, got[i], want[i])
+        for k, net in zip(NETS, (oracle.vamb, oracle.labels, oracle.joint)):
+            for n in net.names:
+                gmax[k, n] = np.maximum(gmax.get((k, n), 0.0), np.abs(net.grads[n]))
+                if step == 0:
+                    mine = vae.get_grad(k, n).reshape(net.grads[n].shape)
+                    refg = g[f"grad0/{k}/{n}"]
+                    if k == "VAEJoint" and (n.startswith("decoder") or n.startswith("outputlayer")):
+                        assert not mine.any() and not refg.any(), n    # VAEJoint's decoder output is discarded (:899)
+                        continue
+                    scale = max(np.abs(net.grads[n]).max(), 1e-12)
+                    assert np.abs(mine - net.grads[n]).max() / scale < 1e-4, (k, n)
+                    assert rel(mine, refg) < 1e-4, (k, n)
+    for k, net in zip(NETS, (oracle.vamb, oracle.labels, oracle.joint)):
+        for n, v in getattr(vae, k).state_dict().items():
+            v = v.numpy()
+            ref = g[f"final/{k}/{n}"]
+            if n.endswith("num_batches_tracked"):
+                assert int(v) == int(ref), (k, n)
+            elif (k, n) not in gmax:
+                assert rel(v, ref) < 1e-4, (k, n)      # running statistics
+            else:
+                solid = gmax[k, n] > 1e-6
+                scale = np.abs(ref).max()
+                assert not solid.any() or np.abs(v - ref)[solid].max() < (3e-2 * c["lrate"] + 1e-4) * scale, (k, n)
+                assert np.abs(v - ref).max() <= c["steps"] * c["lrate"], (k, n)
+    N = len(parents)
+    dsj = torch.utils.data.TensorDataset(*(torch.from_numpy(g["joint_" + k]) for k in ("depths", "tnf", "abundance", "weights", "nodes")))
+    dlj = torch.utils.data.DataLoader(dsj, batch_size=B, shuffle=True, drop_last=True, collate_fn=partial(vt.collate_fn_concat_hloss, N, parents))
+    lat = vae.VAEJoint.encode(dlj)
+    assert lat.dtype == np.float32 and lat.shape == (c["n"], c["nlatent"]) and (lat.view(np.uint32) & 0xFFF == 0).all()
+    assert np.abs(lat - g["latent_joint"]).max() <= np.abs(g["latent_joint"]).max() * 2.0 ** -9
+    dsv = torch.utils.data.TensorDataset(*(torch.from_numpy(g["joint_" + k]) for k in ("depths", "tnf", "abundance", "weights")))
+    latv = vae.VAEVamb.encode(torch.utils.data.DataLoader(dsv, batch_size=B, shuffle=True, drop_last=True))
+    assert np.abs(latv - g["latent_vamb"]).max() <= np.abs(g["latent_vamb"]).max() * 2.0 ** -9
+
+
+def test_epoch_call_equals_its_steps():
+    """vh_vaevae_train_epoch (one upload of the epoch's row list, device-side batch cursor, nothing waits for the GPU between
+    steps) against the same batches fed one by one through vh_vaevae_train_step.  No dropout, generated noise: both runs draw
+    the same noise off the same seeds and step counters, so the epoch's metrics are the mean of the steps' and every parameter
+    and running statistic agrees bit for bit."""
+    name = "vaevae_tree_drop"
+    g = fd.load(name)
+    runs = []
+    for mode in ("epoch", "steps"):
+        c, vae, dl, parents = build(name, g, dropout=0.0)
+        B, steps = c["batch"], c["steps"]
+        if mode == "epoch":
+            dl = vae.trainepoch(dl, 0, None, set())
+            metrics = [vae.last_epoch_metrics[k] for k in vs.VAEVAE_METRICS]
+        else:
+            per = [vae.train_batch(np.arange(s * B, (s + 1) * B)) for s in range(steps)]
+            metrics = list(np.mean(np.array(per), axis=0))
+        runs.append((metrics, {k: {n: v.numpy().copy() for n, v in getattr(vae, k).state_dict().items()} for k in NETS}))
+    (ma, sa), (mb, sb) = runs
+    assert rel(ma, mb) < 1e-12
+    for k in NETS:
+        for n in sa[k]:
+            assert np.array_equal(sa[k][n], sb[k][n]), (k, n)
+
+
+def _taxvamb_problem(n, S, seed):
+    """Synthetic features whose genome id decides the taxonomy label: genomes -> leaves of a 3 x 3 tree, with a share of the
+    contigs annotated only to the phylum / the domain / not at all (the shape of test/test_semisupervised_encode.py:17-46)."""
+    ab, tnf, lens, genome = synth.features(n, S, seed=seed, k=9)
+    parents = [-1, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4]
+    rng = np.random.RandomState(seed + 1)
+    leaf = 5 + (genome.astype(np.int64) % 9)
+    u = rng.random_sample(n)
+    nodes = np.where(u < 0.1, 0, np.where(u < 0.2, 1, np.where(u < 0.4, np.array(parents)[leaf], leaf))).astype(np.int64)
+    return ab, tnf, lens, nodes, parents
+
+
+def test_free_running_joint_training(tmp_path, caplog):
+    """The public flow of `vamb bin taxvamb` (__main__.py:1988-2047): loaders -> VAEVAEHLoss.trainmodel (batch size doubling
+    included) -> VAEJoint.encode.  Criteria: every metric finite, the total loss falls, the label loss of the joint pass falls,
+    the counters / save / load behave as the reference's."""
+    import logging
+
+    n, S, B = 4096, 6, 128
+    ab, tnf, lens, nodes, parents = _taxvamb_problem(n, S, seed=5)
+    N = len(parents)
+    names = [f"n{i}" for i in range(N)]
+    dl_v = ve.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=B)
+    dl_j = vt.make_dataloader_concat_hloss(ab.copy(), tnf.copy(), lens, nodes, N, parents, batchsize=B)
+    dl_l = vt.make_dataloader_labels_hloss(ab.copy(), tnf.copy(), lens, nodes, N, parents, batchsize=B)
+    dl = vt.make_dataloader_semisupervised_hloss(dl_j, dl_v, dl_l, N, parents, (S, 103, 1, N), 0, batchsize=B)
+    vae = vt.VAEVAEHLoss(S, N, names, parents, nhiddens=[128, 96], nlatent=16)
+    assert vae.VAELabels.nlabels == 9 and vae.VAELabels._NL == 105
+    first = {}
+    with caplog.at_level(logging.INFO, logger="vamb_amd.encode"):
+        vae.trainmodel(dl, nepochs=1, batchsteps=None)
+        first = dict(vae.last_epoch_metrics)
+        path = tmp_path / "vaevae.pt"
+        vae.trainmodel(dl, nepochs=7, lrate=1e-3, batchsteps=[2, 5], modelfile=str(path))
+    last = vae.last_epoch_metrics
+    assert all(np.isfinite(v) for v in last.values()) and all(np.isfinite(v) for v in first.values())
+    assert last["loss"] < first["loss"] and last["ce_labels_joint"] < first["ce_labels_joint"]
+    assert last["correct_labels_joint"] == 0.0 and last["correct_labels_labels"] == 0.0   # the HLoss classes return 0
+    assert abs(last["loss"] - (last["loss_joint"] + last["loss_vamb"] + last["loss_labels"])) < 1e-9 * abs(last["loss"])
+    lines = [r.getMessage() for r in caplog.records if "Epoch:" in r.getMessage()]
+    assert len(lines) == 8 and "loss_vamb:" in lines[-1] and "kld_labels_joint:" in lines[-1]
+    # steps: 1 epoch of 32, then 2 of 32, 3 of 16, 2 of 8 batches
+    steps = 32 + 2 * 32 + 3 * 16 + 2 * 8
+    sd = vae.VAEVamb.state_dict()
+    assert int(sd["encodernorms.0.num_batches_tracked"]) == 2 * steps and int(sd["decodernorms.0.num_batches_tracked"]) == 3 * steps
+    assert int(vae.VAEJoint.state_dict()["decodernorms.1.num_batches_tracked"]) == steps
+    lat = vae.VAEJoint.encode(dl_j)
+    assert lat.shape == (n, 16) and np.isfinite(lat).all() and (lat.view(np.uint32) & 0xFFF == 0).all()
+    # contigs of one leaf sit closer to each other than to the others' in the joint latent space
+    leaf_rows = [np.flatnonzero(nodes == k) for k in range(5, 14)]
+    cent = np.stack([lat[r].mean(axis=0) for r in leaf_rows])
+    own = np.mean([np.linalg.norm(lat[r] - cent[i], axis=1).mean() for i, r in enumerate(leaf_rows)])
+    other = np.mean([np.linalg.norm(cent[i] - cent[j]) for i in range(9) for j in range(9) if i != j])
+    assert own < other
+    # save / load (taxvamb_encode.py:630-680): the reloaded networks encode identically
+    again = vt.VAEVAEHLoss.load(str(path), names, parents)
+    assert np.array_equal(again.VAEJoint.encode(dl_j), lat)
+    assert not again.VAEVamb.training
+    # the three networks stay usable on their own afterwards (their streams were only borrowed)
+    vae.VAEVamb.trainmodel(dl_v, nepochs=2, batchsteps=None)
+    assert np.isfinite(vae.VAEVamb.encode(dl_v)).all()
+
+
+@pytest.mark.parametrize("kind", ["labels", "concat"])
+def test_hierarchical_loss_of_the_single_networks(kind):
+    """VAELabelsHLoss / VAEConcatHLoss on their own (taxvamb_encode.py:277-538): the loss the device step reports equals the
+    reference's formula -- calc_loss with the host FlatSoftmaxNLL, which tests/test_taxvamb_host.py pins to hloss_misc bit for
+    bit -- evaluated on the step's own forward outputs, and a few epochs of training reduce it."""
+    name = "vaevae_tree_wide"
+    c = fd.VAEVAE_CASES[name]
+    g = fd.load(name)
+    parents = [int(p) for p in g["parents"]]
+    N, B, S = len(parents), c["batch"], c["nsamples"]
+    NL = max(N, 105)
+    names = [f"n{i}" for i in range(N)]
+    rng = np.random.RandomState(9)
+    nl = len(c["nhiddens"])
+    widths = list(c["nhiddens"]) + list(c["nhiddens"][::-1])
+    masks = [rng.random_sample((B, w)) >= c["dropout"] for w in widths]
+    eps = rng.standard_normal((B, c["nlatent"])).astype(np.float32)
+    kw = dict(nhiddens=list(c["nhiddens"]), nlatent=c["nlatent"], alpha=c["alpha"], beta=c["beta"], dropout=c["dropout"])
+    nodes_t = torch.from_numpy(g["joint_nodes"])
+    onehot = torch.nn.functional.one_hot(nodes_t[:B], NL).float()
+    if kind == "labels":
+        m = vt.VAELabelsHLoss(NL, names, parents, **kw)
+        ds = torch.utils.data.TensorDataset(nodes_t)
+        dl = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=True, drop_last=True, collate_fn=partial(vt.collate_fn_labels_hloss, N, parents))
+        m._ensure_dataset(dl)
+        lo, mu, ls = m(onehot, _eps=eps, _masks=masks)
+        assert tuple(lo.shape) == (B, m.nlabels)
+        want = m.calc_loss(onehot, lo, mu, ls)
+        got = m.train_batch(np.arange(B), eps=eps, masks=masks)
+        assert abs(got[0] - float(want[0])) < 2e-5 * abs(float(want[0])) and abs(got[5] - float(want[1])) < 2e-5 * abs(float(want[1]))
+        assert got[6] == 0.0
+        # (D-Adapt-Adam starts from d = 1e-6: a few dozen steps on 148 contigs show that training runs, not that it converges)
+        m.trainmodel(dl, nepochs=6, batchsteps=[3])
+        assert np.isfinite(m.last_epoch_losses["loss"]) and np.isfinite(m.last_epoch_losses["ce_labels"])
+        assert m.last_epoch_losses["batchsize"] == 2 * B
+    else:
+        m = vt.VAEConcatHLoss(S, NL, names, parents, **kw)
+        feats = [torch.from_numpy(g["joint_" + k]) for k in ("depths", "tnf", "abundance", "weights")]
+        ds = torch.utils.data.TensorDataset(*feats, nodes_t)
+        dl = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=True, drop_last=True, collate_fn=partial(vt.collate_fn_concat_hloss, N, parents))
+        m._ensure_dataset(dl)
+        d, t, a, w = (x[:B] for x in feats)
+        do, to, ao, lo, mu, ls = m(d, t, a, onehot, _eps=eps, _masks=masks)
+        assert tuple(lo.shape) == (B, m.nlabels)
+        want = m.calc_loss(d, do, t, to, a, ao, onehot, lo, mu, ls, w)
+        got = m.train_batch(np.arange(B), eps=eps, masks=masks)
+        assert abs(got[0] - float(want[0].mean())) < 2e-5 * abs(float(want[0].mean()))
+        assert abs(got[5] - float(want[3])) < 2e-5 * abs(float(want[3])) and got[6] == 0.0
+        # (D-Adapt-Adam starts from d = 1e-6: a few dozen steps on 148 contigs show that training runs, not that it converges)
+        m.trainmodel(dl, nepochs=6, batchsteps=[3])
+        assert np.isfinite(m.last_epoch_losses["loss"]) and np.isfinite(m.last_epoch_losses["ce_labels"])
+        assert m.last_epoch_losses["batchsize"] == 2 * B
+    assert m.compute_dtype == "fp32"
+
+
+def test_error_behaviour():
+    parents = fd.vaevae_tree("vaevae_tree_drop")
+    names = [f"n{i}" for i in range(len(parents))]
+    with pytest.raises(NotImplementedError):
+        vt.VAELabelsHLoss(105, names, parents, hier_loss="soft_margin")
+    with pytest.raises(AttributeError):
+        vt.VAELabelsHLoss(105, names, parents, hier_loss="nope")
+    with pytest.raises(ValueError):        # parents must precede their children (make_graph's BFS order)
+        vt.VAELabelsHLoss(105, names, [-1, 2, 1])
+    m = vt.VAELabelsHLoss(105, names, parents, nhiddens=[32], nlatent=4)
+    bad = torch.utils.data.TensorDataset(torch.tensor([0, 3, 20, 1]))     # node 20 does not exist (14 nodes)
+    dl = torch.utils.data.DataLoader(bad, batch_size=4, shuffle=True, collate_fn=partial(vt.collate_fn_labels_hloss, 14, parents))
+    with pytest.raises(ValueError):
+        m._ensure_dataset(dl)
+    vae = vt.VAEVAEHLoss(4, len(parents), names, parents, nhiddens=[32], nlatent=4)
+    with pytest.raises(ValueError):
+        vae.trainmodel(None, nepochs=0)
+    with pytest.raises(ValueError):
+        vae.trainmodel(None, nepochs=3, batchsteps=[3])
+    ds = torch.utils.data.TensorDataset(*(torch.zeros(8, 1) for _ in range(4)))
+    with pytest.raises(ValueError):        # not a semisupervised loader
+        vae._ensure_dataset(torch.utils.data.DataLoader(ds, batch_size=4))

@@ -149,6 +149,13 @@ SIGNATURES = {
     "vh_dataset_set_labels": (_int, [_vp, _vp, _i64, ctypes.c_int32]),
     "vh_dataset_create_labels": (_int, [_vp, _i64, ctypes.c_int32, ctypes.POINTER(_vp)]),
     "vh_debug_gemm16_tn": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "vh_vae_set_hierarchy": (_int, [_vp, _vp, ctypes.c_int32]),
+    "vh_vaevae_create": (_int, [_vp, _vp, _vp, _pp]),
+    "vh_vaevae_destroy": (_int, [_vp]),
+    "vh_vaevae_set_datasets": (_int, [_vp, _vp, _vp, _vp]),
+    "vh_vaevae_train_step": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "vh_vaevae_train_epoch": (_int, [_vp, _vp, _i64, _i64, _vp]),
+    "vh_vaevae_get_grad": (_int, [_vp, _int, ctypes.c_char_p, _vp, _i64]),
 }
 
 

@@ -253,7 +253,7 @@ void vv_step(vh_vaevae* t, const int64_t* dev_idx, bool eps_inj, bool masks_inj)
     backward(Lx, masks_inj, PASS_DECODER);
     // ... and the two kld_gauss terms, which tie VAEJoint's mu to the mu of the two *_s passes
     const int bs = J->bs;
-    const float gk = (float)((double)J->kld_w / ((double)J->L * (double)bs * (double)bs));
+    const float gk = (float)((double)V->kld_w / ((double)J->L * (double)bs * (double)bs));   // 1 / (VAEVamb.nlatent * VAEVamb.beta), taxvamb_encode.py:730
     hipLaunchKernelGGL(vv_kld_kernel, dim3((unsigned)t->kld_blocks), dim3(256), 0, s, (const float*)J->MU.p, (const float*)Vs->MU.p,
                        (const float*)Ls->MU.p, (const float*)Vx->dMU.p, (const float*)Lx->dMU.p, gk, bs, J->L, J->L_p, J->bs_p,
                        J->dMUk.p, Vs->dMUk.p, Ls->dMUk.p, t->kld_part.p);
@@ -262,7 +262,7 @@ void vv_step(vh_vaevae* t, const int64_t* dev_idx, bool eps_inj, bool masks_inj)
     backward(Vs, masks_inj, PASS_ENCODER);
     backward(Ls, masks_inj, PASS_ENCODER);
     hipLaunchKernelGGL(vv_joint_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)t->kld_part.p, t->kld_blocks,
-                       (const StepState*)Vx->state.p, (const StepState*)Lx->state.p, V->ce_w, V->sse_w, J->kld_w, bs, J->L,
+                       (const StepState*)Vx->state.p, (const StepState*)Lx->state.p, V->ce_w, V->sse_w, V->kld_w, bs, J->L,
                        t->jstate.p);
     VH_HIP(hipGetLastError());
     // ---- one gradient per network: every pass's slabs -> its flat buffer, the passes summed with their loss scales

@@ -21,13 +21,12 @@ def install(vamb_module=None, semisupervised: bool = False, strict: bool = False
     """Replace the hot-path entry points of ``vamb`` by the ``vamb_amd`` ones.  Returns the dict of
     original objects (pass it to ``uninstall``).
 
-    ``semisupervised=True`` also rebinds ``vamb.semisupervised_encode.{VAELabels, VAEConcat, make_dataloader_labels,
-    make_dataloader_concat}`` (row N4) for callers that train those models on their own.  The reference's joint trainer
-    ``VAEVAE`` / ``VAEVAEHLoss`` (semisupervised_encode.py:700, taxvamb_encode.py:551) is NOT rebuilt here: it drives its three
-    networks as torch modules (``.parameters()``, ``._encode``, cross-decoding) and keeps doing so -- its constructor is wrapped
-    so that it still builds the REFERENCE's classes while the module attributes point at the GPU ones, and
-    ``vamb.taxvamb_encode`` is imported before the rebinding so that its subclasses keep their torch bases.  TaxVamb's
-    clustering is on the GPU either way (``cluster_and_write_files`` below).
+    ``semisupervised=True`` also rebinds the TaxVamb training side (row N4): ``vamb.semisupervised_encode.{VAELabels, VAEConcat,
+    VAEVAE, make_dataloader_labels, make_dataloader_concat}`` and ``vamb.taxvamb_encode.{VAELabelsHLoss, VAEConcatHLoss,
+    VAEVAEHLoss, make_dataloader_labels_hloss, make_dataloader_concat_hloss, make_dataloader_semisupervised_hloss}`` -- the names
+    ``vamb bin taxvamb`` looks up at call time (``vamb/__main__.py:1988-2047``).  ``vamb.taxvamb_encode`` is imported BEFORE the
+    rebinding, while ``vamb.semisupervised_encode``'s classes are still the torch ones: its remaining classes (Taxometer's
+    ``VAMB2Label``) keep their torch bases.  TaxVamb's clustering is on the GPU either way (``cluster_and_write_files`` below).
 
     ``strict=True``: a submodule of ``vamb`` that cannot be imported (``vamb.parsecontigs`` needs ``vambcore``, say) raises
     instead of leaving that hook on the reference's path with a ``RuntimeWarning`` naming the cause."""
@@ -72,45 +71,26 @@ def install(vamb_module=None, semisupervised: bool = False, strict: bool = False
     if semisupervised:
         ss = _submodule(vamb_module, "semisupervised_encode")
         if ss is None:
-            _warn("vamb.semisupervised_encode is not importable: VAELabels / VAEConcat stay the reference's")
+            _warn("vamb.semisupervised_encode is not importable: VAELabels / VAEConcat / VAEVAE stay the reference's")
         else:
             from . import semisupervised_encode as _ss
 
-            names = ("VAELabels", "VAEConcat", "make_dataloader_labels", "make_dataloader_concat")
             # (classes of vamb.taxvamb_encode subclass ss.VAELabels / ss.VAEConcat: import it while those are the torch classes)
-            try:
-                _submodule(vamb_module, "taxvamb_encode")
-            except Exception as exc:   # it needs the whole CLI stack; its absence only means nothing subclasses later
-                _warn(f"vamb.taxvamb_encode could not be imported ({exc!r})")
-            reference = {n: getattr(ss, n) for n in names}
-            original["semisupervised"] = dict(reference)
+            tx = _submodule(vamb_module, "taxvamb_encode")
+            names = ("VAELabels", "VAEConcat", "VAEVAE", "make_dataloader_labels", "make_dataloader_concat")
+            original["semisupervised"] = {n: getattr(ss, n) for n in names}
             for n in names:
                 setattr(ss, n, getattr(_ss, n))
-            # the joint trainer keeps the reference's torch networks
-            joint = getattr(ss, "VAEVAE", None)
-            if joint is not None and not getattr(joint.__init__, "_vamb_amd_wrapped", False):
-                ref_init = joint.__init__
+            if tx is None:
+                _warn("vamb.taxvamb_encode is not importable: nothing to rebind for TaxVamb's trainer")
+            else:
+                from . import taxvamb_encode as _tx
 
-                def _joint_init(self, *args, _ref_init=ref_init, _reference=reference, _ss=ss, **kwargs):
-                    ours = {n: getattr(_ss, n) for n in ("VAELabels", "VAEConcat")}
-                    encode_mod = getattr(_ss, "_encode", None)
-                    our_vae = getattr(encode_mod, "VAE", None) if encode_mod is not None else None
-                    ref_vae = getattr(encode_mod, "VAE_reference", None) if encode_mod is not None else None
-                    for n in ours:
-                        setattr(_ss, n, _reference[n])
-                    if ref_vae is not None:
-                        encode_mod.VAE = ref_vae
-                    try:
-                        _ref_init(self, *args, **kwargs)
-                    finally:
-                        for n, obj in ours.items():
-                            setattr(_ss, n, obj)
-                        if ref_vae is not None:
-                            encode_mod.VAE = our_vae
-
-                _joint_init._vamb_amd_wrapped = True
-                original["joint_init"] = (joint, ref_init)
-                joint.__init__ = _joint_init
+                tnames = ("VAELabelsHLoss", "VAEConcatHLoss", "VAEVAEHLoss", "make_dataloader_labels_hloss",
+                          "make_dataloader_concat_hloss", "make_dataloader_semisupervised_hloss")
+                original["taxvamb"] = {n: getattr(tx, n) for n in tnames}
+                for n in tnames:
+                    setattr(tx, n, getattr(_tx, n))
     return original
 
 
@@ -212,6 +192,5 @@ def uninstall(original, vamb_module=None):
         m.cluster_and_write_files = fn
     for n, obj in original.get("semisupervised", {}).items():
         setattr(vamb_module.semisupervised_encode, n, obj)
-    if "joint_init" in original:
-        cls, init = original["joint_init"]
-        cls.__init__ = init
+    for n, obj in original.get("taxvamb", {}).items():
+        setattr(vamb_module.taxvamb_encode, n, obj)

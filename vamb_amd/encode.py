@@ -814,7 +814,9 @@ class VAE:
         logger.info(f"\t    Batchsteps: {steps}")
         logger.info(f"\t    N sequences: {ncontigs}")
         logger.info(f"\t    N samples: {nsamples}")
-        # a fresh optimiser per call, as the reference's `DAdaptAdam(self.parameters(), decouple=True)` (encode.py:578)
+        # a fresh optimiser per call, as the reference's `DAdaptAdam(self.parameters(), decouple=True)` (encode.py:578) -- also
+        # for a network the joint TaxVamb trainer has driven with Adam before
+        _lib.check(self._lib.vh_vae_set_optimizer(self._h, 0, 0.0))   # VH_OPT_DADAPT_ADAM
         _lib.check(self._lib.vh_vae_reset_optimizer(self._h))
         # the epochs between two batch-size changes are enqueued by ONE library call (a single host
         # synchronisation per segment instead of one per epoch); the log lines are those of trainepoch

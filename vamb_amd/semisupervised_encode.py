@@ -117,7 +117,7 @@ class _LabelledMixin:
     _OPTIMIZER = VH_OPT_DADAPT_ADAM
 
     def _create_handle(self, cfg) -> ctypes.c_void_p:
-        lab = _LabelsConfig(self._KIND, self.nlabels, self._OPTIMIZER, 1e-3)
+        lab = _LabelsConfig(self._KIND, self._NL, self._OPTIMIZER, 1e-3)
         h = ctypes.c_void_p()
         _lib.check(self._lib.vh_vae_create_labelled(ctypes.byref(cfg), ctypes.byref(lab), ctypes.byref(h)))
         return h
@@ -182,20 +182,22 @@ class VAELabels(_LabelledMixin, _encode.VAE):
                  alpha: Optional[float] = None, beta: float = 200, dropout: Optional[float] = 0.2, cuda: bool = False,
                  _seed: int = 0):
         self.nlabels = nlabels
+        self._NL = nlabels   # width of the label block in the network (the HLoss subclasses overwrite `nlabels`)
         super().__init__(nlabels - 104, nhiddens=nhiddens, nlatent=nlatent, alpha=alpha, beta=beta, dropout=dropout,
                          cuda=cuda, seed=_seed)
         self.nlabels = nlabels
 
     def _row_width(self) -> int:
-        return self.nlabels
+        return self._NL
 
     def forward(self, labels, _eps=None, _masks=None):
         x = _encode._as_f32(labels)
-        if x.ndim != 2 or x.shape[1] != self.nlabels:
-            raise ValueError(f"expected one-hot labels [B, {self.nlabels}]")
+        if x.ndim != 2 or x.shape[1] != self._NL:
+            raise ValueError(f"expected one-hot labels [B, {self._NL}]")
         r, mu = self._forward_rows(x, _eps, _masks)
         mu = _torch.from_numpy(mu)
-        return _torch.from_numpy(r), mu, _torch.zeros(mu.size())
+        # `_decode` narrows to self.nlabels columns (:236): all of them here, the leaves in VAELabelsHLoss
+        return _torch.from_numpy(_np.ascontiguousarray(r[:, :self.nlabels])), mu, _torch.zeros(mu.size())
 
     __call__ = forward
 
@@ -215,17 +217,17 @@ class VAELabels(_LabelledMixin, _encode.VAE):
         tensors = holder.tensors
         if len(tensors) != 1:
             raise ValueError("expected a DataLoader made by make_dataloader_labels (1 tensor)")
-        if _label_width(data_loader) != self.nlabels:
-            raise ValueError(f"the loader one-hots to {_label_width(data_loader)} columns, the model has {self.nlabels}")
+        if _label_width(data_loader) != self._NL:
+            raise ValueError(f"the loader one-hots to {_label_width(data_loader)} columns, the model has {self._NL}")
         lab = tensors[0]
         key = (lab.data_ptr(), tuple(lab.shape), lab._version)
         same = self._dataset_ref is not None and self._dataset_ref() is holder
         if not same or key != self._dataset_key:
             cached = getattr(holder, "_vambhip_device_labels", None)
             if cached is None or cached.key != key:
-                arr = _labels_i32(lab, self.nlabels)
+                arr = _labels_i32(lab, self._NL)
                 h = ctypes.c_void_p()
-                _lib.check(self._lib.vh_dataset_create_labels(_lib.ptr(arr), len(arr), self.nlabels, ctypes.byref(h)))
+                _lib.check(self._lib.vh_dataset_create_labels(_lib.ptr(arr), len(arr), self._NL, ctypes.byref(h)))
                 cached = _LabelledDeviceDataset(self._lib, key, h, owned=True)
                 holder._vambhip_device_labels = cached
             _lib.check(self._lib.vh_vae_use_dataset(self._h, cached.handle))
@@ -252,6 +254,9 @@ class VAELabels(_LabelledMixin, _encode.VAE):
     def trainmodel(self, dataloader, nepochs: int = 500, lrate: float = 1e-3, batchsteps: Optional[list[int]] = [25, 75, 150, 300],
                    modelfile=None):
         """semisupervised_encode.py:362-436.  Output: None"""
+        return self._trainmodel(dataloader, nepochs, lrate, batchsteps, modelfile, VH_OPT_ADAM)
+
+    def _trainmodel(self, dataloader, nepochs, lrate, batchsteps, modelfile, optimizer):
         if lrate < 0:
             raise ValueError(f"Learning rate must be positive, not {lrate}")
         if nepochs < 1:
@@ -279,8 +284,8 @@ class VAELabels(_LabelledMixin, _encode.VAE):
         logger.info(f"\t    Batchsteps: {steps}")
         logger.info(f"\t    Learning rate: {lrate}")
         logger.info(f"\t    N labels: {dataloader.dataset.tensors[0].shape}")
-        # `optimizer = Adam(self.parameters(), lr=lrate)` (:405): a fresh state per call
-        _lib.check(self._lib.vh_vae_set_optimizer(self._h, VH_OPT_ADAM, float(lrate)))
+        # `optimizer = Adam(self.parameters(), lr=lrate)` (:405) -- DAdaptAdam(lr=1) in VAELabelsHLoss: a fresh state per call
+        _lib.check(self._lib.vh_vae_set_optimizer(self._h, optimizer, float(lrate)))
         _lib.check(self._lib.vh_vae_reset_optimizer(self._h))
         epoch = 0
         while epoch < nepochs:   # the epochs between two batch-size changes go out as ONE library call
@@ -310,6 +315,7 @@ class VAEConcat(_LabelledMixin, _encode.VAE):
         if nsamples < 1:
             raise ValueError(f"nsamples must be > 0, not {nsamples}")
         self.nlabels = nlabels
+        self._NL = nlabels   # width of the label block in the network (the HLoss subclasses overwrite `nlabels`)
         self._native_nsamples = nsamples
         # as the reference: the defaults of alpha / nhiddens / dropout see nsamples + nlabels (:466-474)
         super().__init__(nsamples + nlabels, nhiddens=nhiddens, nlatent=nlatent, alpha=alpha, beta=beta, dropout=dropout,
@@ -318,19 +324,19 @@ class VAEConcat(_LabelledMixin, _encode.VAE):
         self.nlabels = nlabels
 
     def _row_width(self) -> int:
-        return self._native_nsamples + NTNF + 1 + self.nlabels
+        return self._native_nsamples + NTNF + 1 + self._NL
 
     def forward(self, depths, tnf, abundance, labels, _eps=None, _masks=None):
         d, t, a, l = (_encode._as_f32(x) for x in (depths, tnf, abundance, labels))
         if d.ndim != 2 or d.shape[1] != self.nsamples or t.shape != (len(d), NTNF) or a.shape != (len(d), 1) \
-                or l.shape != (len(d), self.nlabels):
+                or l.shape != (len(d), self._NL):
             raise ValueError("expected depths [B, nsamples], tnf [B, 103], abundance [B, 1], labels [B, nlabels]")
         r, mu = self._forward_rows(_np.ascontiguousarray(_np.concatenate((d, t, a, l), axis=1)), _eps, _masks)
         s = self.nsamples
         f = lambda x: _torch.from_numpy(_np.ascontiguousarray(x))  # noqa: E731
         mu = _torch.from_numpy(mu)
-        return (f(r[:, :s]), f(r[:, s:s + NTNF]), f(r[:, s + NTNF:s + NTNF + 1]), f(r[:, s + NTNF + 1:]), mu,
-                _torch.zeros(mu.size()))
+        return (f(r[:, :s]), f(r[:, s:s + NTNF]), f(r[:, s + NTNF:s + NTNF + 1]),
+                f(r[:, s + NTNF + 1:s + NTNF + 1 + self.nlabels]), mu, _torch.zeros(mu.size()))
 
     __call__ = forward
 
@@ -364,8 +370,8 @@ class VAEConcat(_LabelledMixin, _encode.VAE):
         tensors = holder.tensors
         if len(tensors) != 5:
             raise ValueError("expected a DataLoader made by make_dataloader_concat (5 tensors)")
-        if _label_width(data_loader) != self.nlabels:
-            raise ValueError(f"the loader one-hots to {_label_width(data_loader)} columns, the model has {self.nlabels}")
+        if _label_width(data_loader) != self._NL:
+            raise ValueError(f"the loader one-hots to {_label_width(data_loader)} columns, the model has {self._NL}")
         lab = tensors[4]
         n = len(lab)
         prepared = getattr(holder, "_vambhip_prepared", None)
@@ -378,7 +384,7 @@ class VAEConcat(_LabelledMixin, _encode.VAE):
         if not same or key != self._dataset_key:
             cached = getattr(holder, "_vambhip_device_labels", None)
             if cached is None or cached.key != key:
-                arr = _labels_i32(lab, self.nlabels)
+                arr = _labels_i32(lab, self._NL)
                 if prepared is not None:
                     if prepared.nsamples != self.nsamples:
                         raise ValueError("dataset tensors do not match this VAE (nsamples / 103 TNF / 1 / 1 columns)")
@@ -391,7 +397,7 @@ class VAEConcat(_LabelledMixin, _encode.VAE):
                     _lib.check(self._lib.vh_dataset_create(_lib.ptr(d), _lib.ptr(t), _lib.ptr(a), _lib.ptr(w), n,
                                                            self.nsamples, ctypes.byref(handle)))
                     owned = True
-                _lib.check(self._lib.vh_dataset_set_labels(handle, _lib.ptr(arr), n, self.nlabels))
+                _lib.check(self._lib.vh_dataset_set_labels(handle, _lib.ptr(arr), n, self._NL))
                 cached = _LabelledDeviceDataset(self._lib, key, handle, owned, keepalive=prepared)
                 holder._vambhip_device_labels = cached
             _lib.check(self._lib.vh_vae_use_dataset(self._h, cached.handle))
@@ -423,3 +429,283 @@ class VAEConcat(_LabelledMixin, _encode.VAE):
                                                  stats[e][0], kld / kld_w, stats[e][1] / n_batches, bs))
         self.last_epoch_losses = dict(loss=means[-1][0], ab=means[-1][1], ce=means[-1][2], sse=means[-1][3], kld=means[-1][4],
                                       ce_labels=stats[-1][0], correct_labels=stats[-1][1], batchsize=bs)
+
+
+# ---- the joint trainer (semisupervised_encode.py:50-87, 178-186, 700-1145) ---------------------------------------------
+def collate_fn_semisupervised(num_categories: int, batch):
+    cols = [[i[k] for i in batch] for k in range(10)]
+    hot = lambda v: _F.one_hot(_torch.as_tensor(v), num_classes=max(num_categories, 105)).squeeze(1).float()  # noqa: E731
+    st = _torch.stack
+    return (st(cols[0]), st(cols[1]), st(cols[2]), st(cols[3]), hot(cols[4]), st(cols[5]), st(cols[6]), st(cols[7]), st(cols[8]),
+            hot(cols[9]))
+
+
+def kld_gauss(p_mu, p_logstd, q_mu, q_logstd):
+    """semisupervised_encode.py:79-86 (host tensors)."""
+    loss = q_logstd - p_logstd + (p_logstd.exp().pow(2) + (p_mu - q_mu).pow(2)) / (2 * q_logstd.exp().pow(2)) - 0.5
+    return loss.mean()
+
+
+def permute_indices(n_current: int, n_total: int, seed: int):
+    """semisupervised_encode.py:178-186."""
+    rng = _np.random.default_rng(seed)
+    x = _np.arange(n_current)
+    to_add = int(n_total / n_current)
+    to_concatenate = [rng.permutation(x)]
+    for _ in range(to_add):
+        to_concatenate.append(rng.permutation(x))
+    return _np.concatenate(to_concatenate)[:n_total]
+
+
+VAEVAE_METRICS = ["loss_vamb", "ab_vamb", "ce_vamb", "sse_vamb", "kld_vamb", "loss_labels", "ce_labels_labels", "kld_labels",
+                  "correct_labels_labels", "loss_joint", "ce_joint", "sse_joint", "ce_labels_joint", "kld_vamb_joint",
+                  "kld_labels_joint", "correct_labels_joint", "loss"]   # semisupervised_encode.py:830-848
+
+
+class _JointDeviceDatasets:
+    """The three row-aligned vh_datasets of one semisupervised loader (owned)."""
+
+    def __init__(self, lib, key, unsup, unsup_labels, sup):
+        self._lib, self.key, self.handles = lib, key, [unsup, unsup_labels, sup]
+
+    def __del__(self):
+        try:
+            for h in self.handles:
+                if h is not None:
+                    self._lib.vh_dataset_destroy(h)
+            self.handles = []
+        except Exception:
+            pass
+
+
+class VAEVAE(object):
+    """Bi-modal variational autoencoder that uses TNFs, abundances and one-hot labels: three encoders (VAMB, labels,
+    concatenated VAMB + labels) and two decoders (VAMB and labels) -- semisupervised_encode.py:700-1145.
+
+    The three networks are ``vamb_amd`` models (``VAEVamb``, ``VAELabels``, ``VAEJoint``: usable on their own for encoding and
+    state dicts); a training step -- seven passes through them, the sum of three losses, one Adam update -- runs inside
+    libvambhip (``vh_vaevae_*``, csrc/vaevae.hpp).  (The reference's own base class cannot train: its ``trainepoch`` reads
+    ``self.usecuda`` / ``self.alpha``, which only the subclass ``vamb.taxvamb_encode.VAEVAEHLoss`` defines, :917, :789.  This one
+    runs the computation that code spells out, with the one-hot cross-entropy of its ``calc_loss_joint``.)"""
+
+    def __init__(self, nsamples: int, nlabels: int, nhiddens: Optional[list[int]] = None, nlatent: int = 32,
+                 alpha: Optional[float] = None, beta: float = 200.0, dropout: Optional[float] = 0.2, cuda: bool = False):
+        N_l = max(nlabels, 105)
+        self.usecuda = cuda
+        kw = dict(nhiddens=nhiddens, nlatent=nlatent, alpha=alpha, beta=beta, dropout=dropout, cuda=cuda)
+        # (distinct seeds: the three networks draw independent dropout / noise / initialisation streams)
+        self.VAEVamb = _encode.VAE(nsamples, seed=0, **kw)
+        self.VAELabels = VAELabels(N_l, _seed=1, **kw)
+        self.VAEJoint = VAEConcat(nsamples, N_l, _seed=2, **kw)
+
+    # ---- native trainer -------------------------------------------------------------------------------------------------
+    def _networks(self):
+        return (self.VAEVamb, self.VAELabels, self.VAEJoint)
+
+    def _trainer(self):
+        t = getattr(self, "_vv", None)
+        if t is None:
+            lib = _lib.load()
+            for net in self._networks():   # the joint step is an fp32 step
+                if net.compute_dtype != "fp32":
+                    _lib.check(lib.vh_vae_set_precision(net._h, 0))
+                    net.compute_dtype = "fp32"
+            t = ctypes.c_void_p()
+            _lib.check(lib.vh_vaevae_create(self.VAEVamb._h, self.VAELabels._h, self.VAEJoint._h, ctypes.byref(t)))
+            self._vv, self._vv_lib = t, lib
+            self._vv_key = self._vv_ref = None
+        return t
+
+    def __del__(self):
+        try:
+            t = getattr(self, "_vv", None)
+            if t is not None and t.value:
+                self._vv_lib.vh_vaevae_destroy(t)
+                self._vv = None
+        except Exception:
+            pass
+
+    def _set_adam(self, lrate: float, reset: bool) -> None:
+        lib = _lib.load()
+        for net in self._networks():
+            _lib.check(lib.vh_vae_set_optimizer(net._h, VH_OPT_ADAM, float(lrate)))
+            if reset:
+                _lib.check(lib.vh_vae_reset_optimizer(net._h))
+
+    def _ensure_dataset(self, data_loader) -> int:
+        """Upload the ten tensors of the semisupervised loader (taxvamb_encode.py:213-224) as three resident datasets."""
+        holder = data_loader.dataset
+        tensors = holder.tensors
+        if len(tensors) != 10:
+            raise ValueError("expected a DataLoader made by make_dataloader_semisupervised_hloss (10 tensors)")
+        NL = self.VAELabels._NL
+        if _label_width(data_loader) != NL:
+            raise ValueError(f"the loader one-hots to {_label_width(data_loader)} columns, the model has {NL}")
+        t = self._trainer()
+        lib = self._vv_lib
+        key = tuple((x.data_ptr(), tuple(x.shape), x._version) for x in tensors)
+        same = self._vv_ref is not None and self._vv_ref() is holder
+        if not same or key != self._vv_key:
+            cached = getattr(holder, "_vambhip_joint_datasets", None)
+            if cached is None or cached.key != key:
+                n, S = len(tensors[0]), self.VAEVamb.nsamples
+                handles = []
+                for lo in (0, 5):
+                    d, tn, a, w = (_encode._as_f32(x) for x in tensors[lo:lo + 4])
+                    if d.shape != (n, S) or tn.shape != (n, NTNF) or a.shape != (n, 1) or w.shape != (n, 1):
+                        raise ValueError("dataset tensors do not match this VAE (nsamples / 103 TNF / 1 / 1 columns)")
+                    h = ctypes.c_void_p()
+                    _lib.check(lib.vh_dataset_create(_lib.ptr(d), _lib.ptr(tn), _lib.ptr(a), _lib.ptr(w), n, S, ctypes.byref(h)))
+                    handles.append(h)
+                lab_u, lab_s = _labels_i32(tensors[4], NL), _labels_i32(tensors[9], NL)
+                if len(lab_u) != n or len(lab_s) != n:
+                    raise ValueError("the ten tensors must have the same number of rows")
+                hl = ctypes.c_void_p()
+                _lib.check(lib.vh_dataset_create_labels(_lib.ptr(lab_u), n, NL, ctypes.byref(hl)))
+                _lib.check(lib.vh_dataset_set_labels(handles[1], _lib.ptr(lab_s), n, NL))
+                cached = _JointDeviceDatasets(lib, key, handles[0], hl, handles[1])
+                holder._vambhip_joint_datasets = cached
+            self._vv_datasets, self._vv_key, self._vv_ref = cached, key, weakref.ref(holder)
+            self._vv_rows = len(tensors[0])
+        # (re)attach on every call: the three networks can be used on their own in between (VAEJoint.encode(dataloader_joint)
+        # attaches ITS loader's dataset to the same native handle) -- and forget what they had attached, for the same reason
+        _lib.check(lib.vh_vaevae_set_datasets(t, *self._vv_datasets.handles))
+        for net in self._networks():
+            net._dataset_key = net._dataset_ref = None
+        return self._vv_rows
+
+    def train_batch(self, rows, eps=None, masks=None):
+        """One optimisation step on explicit rows of the attached loader (parity tests).  eps: per pass (joint, vamb_x, labels_x,
+        vamb_u, vamb_s, labels_u, labels_s) a [B, nlatent] array; masks: per pass the list of its dropout keep-masks.  Returns
+        the 17 metrics (VAEVAE_METRICS order)."""
+        rows = _np.ascontiguousarray(rows, dtype=_np.int64)
+        e = None if eps is None else _np.ascontiguousarray(_np.stack([_encode._as_f32(x) for x in eps]))
+        m = None if masks is None else _np.ascontiguousarray(
+            _np.concatenate([_np.asarray(k, dtype=_np.uint8).reshape(-1) for p in masks for k in p]))
+        out = (ctypes.c_double * 17)()
+        _lib.check(self._vv_lib.vh_vaevae_train_step(self._trainer(), _lib.ptr(rows), len(rows), _lib.ptr(e), _lib.ptr(m), out))
+        return list(out)
+
+    def get_grad(self, network: str, name: str) -> _np.ndarray:
+        net = dict(VAEVamb=0, VAELabels=1, VAEJoint=2)[network]
+        n = _lib._i64(0)
+        _lib.check(self._vv_lib.vh_vae_param_size(self._networks()[net]._h, name.encode(), ctypes.byref(n)))
+        out = _np.empty(n.value, _np.float32)
+        _lib.check(self._vv_lib.vh_vaevae_get_grad(self._trainer(), net, name.encode(), _lib.ptr(out), n.value))
+        return out
+
+    # ---- reference interface ----------------------------------------------------------------------------------------------
+    def calc_loss_joint(self, depths_in, depths_out, tnf_in, tnf_out, abundance_in, abundance_out, labels_in, labels_out, mu_sup,
+                        logsigma_sup, mu_vamb_unsup, logsigma_vamb_unsup, mu_labels_unsup, logsigma_labels_unsup, weights):
+        """semisupervised_encode.py:762-827 on host tensors (training computes the same on the device)."""
+        v = self.VAEVamb
+        ab_sse = (abundance_out - abundance_in).pow(2).sum(dim=1)
+        ce = -((depths_out + 1e-9).log() * depths_in).sum(dim=1)
+        sse = (tnf_out - tnf_in).pow(2).sum(dim=1)
+        ce_weight = 0.0 if v.nsamples == 1 else ((1 - v.alpha) * (v.nsamples - 1)) / (v.nsamples * _log(v.nsamples))
+        ab_sse_weight = (1 - v.alpha) * (1 / v.nsamples)
+        sse_weight = v.alpha / v.ntnf
+        ce_labels, correct = self._label_loss(labels_out, labels_in)
+        reconstruction_loss = ce * ce_weight + ab_sse * ab_sse_weight + sse * sse_weight + ce_labels * 1.0
+        kld_vamb = kld_gauss(mu_sup, logsigma_sup, mu_vamb_unsup, logsigma_vamb_unsup)
+        kld_labels = kld_gauss(mu_sup, logsigma_sup, mu_labels_unsup, logsigma_labels_unsup)
+        kld_loss = (kld_vamb + kld_labels) * (1 / (v.nlatent * v.beta))
+        loss = (reconstruction_loss + kld_loss) * weights
+        return loss.mean(), ce.mean(), sse.mean(), ce_labels.mean(), kld_vamb.mean(), kld_labels.mean(), correct
+
+    def _label_loss(self, labels_out, labels_in):
+        _, idx = labels_in.max(dim=1)
+        _, out_idx = labels_out.max(dim=1)
+        return _torch.nn.CrossEntropyLoss()(labels_out, idx), _torch.sum(out_idx == idx)
+
+    def trainepoch(self, data_loader, epoch, optimizer, batchsteps):
+        """One epoch (semisupervised_encode.py:829-1008); `optimizer` is accepted for signature compatibility (the Adam state
+        lives in the three native handles).  Rows are taken in the loader's order: sequential until the first batch-size
+        doubling replaces the loader by a shuffling one (:852-862)."""
+        n = self._ensure_dataset(data_loader)
+        if epoch in batchsteps:
+            new_bs = data_loader.batch_size * 2
+            data_loader = _DataLoader(dataset=data_loader.dataset, batch_size=new_bs, shuffle=True, drop_last=n > new_bs,
+                                      num_workers=0, pin_memory=False, collate_fn=data_loader.collate_fn)
+        bs = data_loader.batch_size
+        order = _np.fromiter(iter(data_loader.sampler), dtype=_np.int64, count=n)
+        if data_loader.drop_last:
+            n_batches, batch = n // bs, bs
+        else:
+            if n > bs:
+                raise ValueError("a loader that keeps a ragged last batch is not supported: use drop_last (the reference's "
+                                 "loaders drop it whenever the dataset is larger than the batch)")
+            n_batches, batch = 1, n
+        if n_batches < 1 or batch < 2:
+            raise ValueError(f"cannot train on {n} sequences with batch size {bs}")
+        rows = _np.ascontiguousarray(order[:n_batches * batch])
+        out = (ctypes.c_double * 17)()
+        _lib.check(self._vv_lib.vh_vaevae_train_epoch(self._trainer(), _lib.ptr(rows), n_batches, batch, out))
+        self.last_epoch_metrics = dict(zip(VAEVAE_METRICS, out))
+        logger.info(f"\t\tEpoch: {epoch}  " + "  ".join(k + f": {v:.5e}" for k, v in self.last_epoch_metrics.items()))
+        return data_loader
+
+    def trainmodel(self, dataloader, nepochs: int = 500, lrate: float = 1e-3, batchsteps: list[int] = [25, 75, 150, 300],
+                   modelfile=None):
+        """Train the three networks jointly (semisupervised_encode.py:1010-1084).  Output: None"""
+        if lrate < 0:
+            raise ValueError("Learning rate must be positive, not {}".format(lrate))
+        if nepochs < 1:
+            raise ValueError("Minimum 1 epoch, not {}".format(nepochs))
+        if batchsteps is None:
+            batchsteps_set = set()
+        else:
+            batchsteps = list(batchsteps)
+            if not all(isinstance(i, int) for i in batchsteps):
+                raise ValueError("All elements of batchsteps must be integers")
+            if max(batchsteps, default=0) >= nepochs:
+                raise ValueError("Max batchsteps must not equal or exceed nepochs")
+            batchsteps_set = set(batchsteps)
+        ncontigs, nsamples = dataloader.dataset.tensors[0].shape
+        v = self.VAEVamb
+        self._trainer()
+        self._set_adam(lrate, reset=True)   # `optimizer = Adam(all parameters, lr=lrate)`: a fresh state per call (:1048)
+        logger.info("\tNetwork properties:")
+        logger.info(f"\t    CUDA: {v.usecuda}")
+        logger.info(f"\t    Alpha: {v.alpha}")
+        logger.info(f"\t    Beta: {v.beta}")
+        logger.info(f"\t    Dropout: {v.dropout}")
+        logger.info(f"\t    N hidden: {', '.join(map(str, v.nhiddens))}")
+        logger.info(f"\t    N latent: {v.nlatent}")
+        logger.info("\tTraining properties:")
+        logger.info(f"\t    N epochs: {nepochs}")
+        logger.info(f"\t    Starting batch size: {dataloader.batch_size}")
+        batchsteps_string = ", ".join(map(str, sorted(batchsteps_set))) if batchsteps_set else "None"
+        logger.info(f"\t    Batchsteps: {batchsteps_string}")
+        logger.info(f"\t    Learning rate: {lrate}")
+        logger.info(f"\t    N sequences: {ncontigs}")
+        logger.info(f"\t    N samples: {nsamples}")
+        for epoch in range(nepochs):
+            dataloader = self.trainepoch(dataloader, epoch, None, batchsteps_set)
+        if modelfile is not None:
+            try:
+                self.save(modelfile)
+            except Exception:
+                pass
+        return None
+
+    def save(self, filehandle):
+        """semisupervised_encode.py:1086-1104."""
+        v = self.VAEVamb
+        state = {"nsamples": v.nsamples, "nlabels": self.VAELabels.nlabels, "alpha": v.alpha, "beta": v.beta, "dropout": v.dropout,
+                 "nhiddens": v.nhiddens, "nlatent": v.nlatent, "state_VAEVamb": self.VAEVamb.state_dict(),
+                 "state_VAELabels": self.VAELabels.state_dict(), "state_VAEJoint": self.VAEJoint.state_dict()}
+        _torch.save(state, filehandle)
+
+    @classmethod
+    def load(cls, path, cuda=False, evaluate=True):
+        """semisupervised_encode.py:1106-1145."""
+        d = _torch.load(path, map_location=lambda storage, loc: storage, weights_only=False)
+        vae = cls(d["nsamples"], d["nlabels"], d["nhiddens"], d["nlatent"], d["alpha"], d["beta"], d["dropout"], cuda)
+        vae.VAEVamb.load_state_dict(d["state_VAEVamb"])
+        vae.VAELabels.load_state_dict(d["state_VAELabels"])
+        vae.VAEJoint.load_state_dict(d["state_VAEJoint"])
+        if evaluate:
+            for net in vae._networks():
+                net.eval()
+        return vae
