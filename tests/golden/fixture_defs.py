@@ -327,6 +327,22 @@ E2E_CASES = {
 }
 
 
+# Joint TaxVamb training, free-running (behavioural comparison): synthetic genomes -> leaves of a 3 x 3 taxonomy, with a share of
+# the contigs annotated only to the phylum / the domain / not at all (the shape of test/test_semisupervised_encode.py:17-46)
+TAXVAMB_E2E = dict(n=4096, nsamples=6, data_seed=5, batch=128, nhiddens=[128, 96], nlatent=16, nepochs=8, batchsteps=[3, 6],
+                   perm_seed=0, model_seeds=[0, 1, 2, 3, 4])
+
+
+def taxvamb_problem(n, S, seed):
+    ab, tnf, lens, genome = synth.features(n, S, seed=seed, k=9)
+    parents = [-1, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4]
+    rng = np.random.RandomState(seed + 1)
+    leaf = 5 + (genome.astype(np.int64) % 9)
+    u = rng.random_sample(n)
+    nodes = np.where(u < 0.1, 0, np.where(u < 0.2, 1, np.where(u < 0.4, np.array(parents)[leaf], leaf))).astype(np.int64)
+    return ab, tnf, lens, nodes, parents
+
+
 def bin_quality(labels, members, kinds=None, big=10):
     """Agreement of a clustering with the synthetic genomes.  ``labels``: int [n] genome of every contig; ``members``: list of
     index arrays (one per cluster, covering every contig exactly once).  Returns plain python numbers:
