@@ -162,15 +162,24 @@ METRICS = ["loss_vamb", "ab_vamb", "ce_vamb", "sse_vamb", "kld_vamb", "loss_labe
 
 
 class OracleVAEVAE:
-    """VAEVAEHLoss(nsamples, nlabels=len(nodes), nodes, table_parent, ...) -- taxvamb_encode.py:579-628."""
+    """VAEVAEHLoss(nsamples, nlabels=len(nodes), nodes, table_parent, ...) -- taxvamb_encode.py:579-628.
+    ``table_parent`` an int: the one-hot base class VAEVAE(nsamples, nlabels) as its code reads (semisupervised_encode.py:721-827;
+    the reference itself cannot run it, see vamb_amd/semisupervised_encode.py:VAEVAE) -- CrossEntropyLoss over all label columns,
+    i.e. the flat-softmax loss with the identity as mask -- plus the ``correct_labels`` counts."""
 
     def __init__(self, nsamples, table_parent, nhiddens, nlatent, alpha, beta, dropout, states, dtype=np.float64):
         if alpha is None:
             alpha = 0.15 if nsamples > 1 else 0.50
         self.nsamples, self.nlatent, self.alpha, self.beta = nsamples, nlatent, alpha, beta
-        self.n_nodes = len(table_parent)
-        self.NL = max(self.n_nodes, 105)                     # width of the label block (taxvamb_encode.py:593)
-        self.masks = leaf_masks_of_nodes(table_parent)
+        self.one_hot = isinstance(table_parent, (int, np.integer))
+        if self.one_hot:
+            self.n_nodes = int(table_parent)
+            self.NL = max(self.n_nodes, 105)
+            self.masks = np.eye(self.NL, dtype=bool)
+        else:
+            self.n_nodes = len(table_parent)
+            self.NL = max(self.n_nodes, 105)                 # width of the label block (taxvamb_encode.py:593)
+            self.masks = leaf_masks_of_nodes(table_parent)
         self.n_leaves = self.masks.shape[1]
         self.dtype = dtype
         S = nsamples
@@ -260,7 +269,8 @@ class OracleVAEVAE:
         # -- VAELabelsHLoss.calc_loss on the unsupervised labels (taxvamb_encode.py:348-355)
         cel, dsc = flat_softmax_nll(rec_lu[:, :self.n_leaves], unsup_nodes, self.masks)
         kld_l = 0.5 * (mu_lu ** 2).sum(axis=1).mean()
-        m.update(ce_labels_labels=cel, kld_labels=kld_l, loss_labels=cel + kld_l * kld_w, correct_labels_labels=0.0)
+        m.update(ce_labels_labels=cel, kld_labels=kld_l, loss_labels=cel + kld_l * kld_w,
+                 correct_labels_labels=float((rec_lu[:, :self.n_leaves].argmax(axis=1) == unsup_nodes).sum()) if self.one_hot else 0.0)
         drec = np.zeros_like(rec_lu)
         drec[:, :self.n_leaves] = dsc
         dz = self.labels.decode_bwd(tape_lu_d, drec)
@@ -275,7 +285,8 @@ class OracleVAEVAE:
         kld_lb = 0.5 * ((mu_sup - mu_ls) ** 2).mean()
         recon_rows = ((ce * ce_w + ab * ab_w) + sse * sse_w) + cel_j
         m.update(loss_joint=((recon_rows + (kld_v + kld_lb) * kld_w) * wm).mean(), ce_joint=ce.mean(), sse_joint=sse.mean(),
-                 ce_labels_joint=cel_j, kld_vamb_joint=kld_v, kld_labels_joint=kld_lb, correct_labels_joint=0.0)
+                 ce_labels_joint=cel_j, kld_vamb_joint=kld_v, kld_labels_joint=kld_lb,
+                 correct_labels_joint=float((rec_lx[:, :self.n_leaves].argmax(axis=1) == sup_nodes).sum()) if self.one_hot else 0.0)
         drec_l = np.zeros_like(rec_lx)
         drec_l[:, :self.n_leaves] = dsc * wm
         dmu = self.vamb.decode_bwd(tape_vx, drec_v) + self.labels.decode_bwd(tape_lx, drec_l)

@@ -109,6 +109,45 @@ def test_joint_training_steps_match_reference_and_oracle(name):
     assert np.abs(latv - g["latent_vamb"]).max() <= np.abs(g["latent_vamb"]).max() * 2.0 ** -9
 
 
+def test_one_hot_joint_trainer_matches_the_oracle():
+    """The base class VAEVAE (semisupervised_encode.py:700-1084: plain CrossEntropyLoss over the one-hot block, `correct_labels`
+    counted) against the oracle's one-hot mode.  No golden: the reference's own base class stops in trainepoch with an
+    AttributeError (`self.usecuda`, :917), so its code is restated, not run."""
+    name = "vaevae_tree_drop"
+    g = fd.load(name)
+    c = fd.VAEVAE_CASES[name]
+    N, B, S = len(g["parents"]), c["batch"], c["nsamples"]
+    vae = vs.VAEVAE(S, N, nhiddens=list(c["nhiddens"]), nlatent=c["nlatent"], alpha=c["alpha"], beta=c["beta"], dropout=c["dropout"])
+    assert type(vae.VAELabels) is vs.VAELabels and vae.VAELabels.nlabels == 105
+    for k, st in tov.init_states(name).items():
+        getattr(vae, k).load_state_dict({kk: torch.from_numpy(np.array(v, dtype=np.float32 if v.dtype.kind == "f" else v.dtype))
+                                         for kk, v in st.items()})
+    names10 = ("unsup_depths", "unsup_tnf", "unsup_abundance", "unsup_weights", "unsup_nodes", "sup_depths", "sup_tnf",
+               "sup_abundance", "sup_weights", "sup_nodes")
+    ds = torch.utils.data.TensorDataset(*(torch.from_numpy(g[k]) for k in names10))
+    dl = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, drop_last=True, collate_fn=partial(vs.collate_fn_semisupervised, N))
+    vae._ensure_dataset(dl)
+    vae._set_adam(c["lrate"], reset=True)
+    oracle = vv.OracleVAEVAE(S, N, c["nhiddens"], c["nlatent"], float(g["alpha"]), c["beta"], c["dropout"], tov.init_states(name))
+    rnd = fd.vaevae_randomness(name)
+    for step in range(c["steps"]):
+        eps, masks = randomness_of(c, rnd[step])
+        got = vae.train_batch(np.arange(step * B, (step + 1) * B), eps=eps, masks=masks)
+        un, un_nodes = tov.batch_of(g, "unsup", step * B, (step + 1) * B)
+        su, su_nodes = tov.batch_of(g, "sup", step * B, (step + 1) * B)
+        want = oracle.train_step(un, un_nodes, su, su_nodes, rnd[step], lr=c["lrate"])
+        for i, key in enumerate(vv.METRICS):
+            if key.startswith("correct"):
+                assert got[i] == want[i], (step, key, got[i], want[i])
+            else:
+                assert abs(got[i] - want[i]) <= 2e-5 * abs(want[i]) + 1e-8, (step, key, got[i], want[i])
+        if step == 0:
+            for k, net in zip(NETS, (oracle.vamb, oracle.labels, oracle.joint)):
+                for n in net.names:
+                    scale = max(np.abs(net.grads[n]).max(), 1e-12)
+                    assert np.abs(vae.get_grad(k, n).reshape(net.grads[n].shape) - net.grads[n]).max() / scale < 1e-4, (k, n)
+
+
 def test_epoch_call_equals_its_steps():
     """vh_vaevae_train_epoch (one upload of the epoch's row list, device-side batch cursor, nothing waits for the GPU between
     steps) against the same batches fed one by one through vh_vaevae_train_step.  No dropout, generated noise: both runs draw
