@@ -79,6 +79,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=24_000, help="contigs of the larger CPU-baseline sample (a second one of a third of it runs beside it)")
     p.add_argument("--no-c3", action="store_true", help="skip the C3-shape leg")
+    p.add_argument("--no-taxvamb", action="store_true", help="skip the joint-TaxVamb-training leg")
     p.add_argument("--no-cluster", action="store_true",
                    help="PROFILING ONLY: leave the cluster sweep out of a step (a rocprofv3 trace of a short training "
                         "run; with few epochs the latents are unstructured and the sweep degenerates).  The line is "
@@ -293,6 +294,40 @@ def config_leg(args, name, ve, vc, lib, _lib, synth, epochs):
             "roofline_encoder_gemm": roof,
             "cluster_scan": scan_summary([timed], [r], "kernel time: a second, event-timed sweep over the same latents; "
                                                           "wall time: the sweep of the timed job")}
+
+
+def taxvamb_leg(ve, synth, n=200_000, S=50, n_nodes=1000, batch=256, epochs=3):
+    """Row N4's trainer in front of the driver: TaxVamb's joint training (VAEVAEHLoss.trainmodel: three networks, seven passes and
+    one Adam step per batch, hierarchical loss over a taxonomy; vamb/__main__.py:1988-2047) at the CLI's starting batch size on
+    a synthetic problem, then VAEJoint.encode.  fp32 step.  Not part of `value`."""
+    from vamb_amd import taxvamb_encode as vt
+
+    rng = np.random.RandomState(0)
+    parents = [-1] + [int(rng.randint(max(0, i - 60), i)) for i in range(1, n_nodes)]
+    ab, tnf, lens, genome = synth.features(n, S, seed=3)
+    nodes = (genome.astype(np.int64) * 7919) % n_nodes
+    names = [f"n{i}" for i in range(n_nodes)]
+    dl_v = ve.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=batch)
+    dl_j = vt.make_dataloader_concat_hloss(ab.copy(), tnf.copy(), lens, nodes, n_nodes, parents, batchsize=batch)
+    dl_l = vt.make_dataloader_labels_hloss(ab, tnf, lens, nodes, n_nodes, parents, batchsize=batch)
+    dl = vt.make_dataloader_semisupervised_hloss(dl_j, dl_v, dl_l, n_nodes, parents, (S, NTNF, 1, n_nodes), 0, batchsize=batch)
+    vae = vt.VAEVAEHLoss(S, n_nodes, names, parents)
+    vae.trainmodel(dl, nepochs=1, batchsteps=None)      # uploads, first launches
+    first = vae.last_epoch_metrics["loss"]
+    t0 = time.perf_counter()
+    vae.trainmodel(dl, nepochs=epochs, batchsteps=None)
+    t_epoch = (time.perf_counter() - t0) / epochs
+    t0 = time.perf_counter()
+    latent = vae.VAEJoint.encode(dl_j)
+    t_enc = time.perf_counter() - t0
+    steps = n // batch
+    return {"workload": f"joint TaxVamb training (VAEVAEHLoss: VAEVamb + VAELabels + VAEJoint, hidden 512-512, latent 32, flat-softmax "
+                        f"loss over a {n_nodes}-node taxonomy): {n} contigs x {S} samples, batch {batch} (the CLI's starting batch), "
+                        f"{epochs} timed epochs after one warm-up epoch; f32",
+            "dtype": "f32", "epoch_s": t_epoch, "ms_per_step": 1e3 * t_epoch / steps, "steps_per_epoch": steps,
+            "passes_per_step": 7, "train_contigs_per_s_per_epoch": steps * batch / t_epoch, "encode_s": t_enc,
+            "loss_first_epoch": first, "loss_last_epoch": vae.last_epoch_metrics["loss"],
+            "latent_finite": bool(np.isfinite(latent).all())}
 
 
 def _cpu_sample(args, n, latent, lens, threads, co, vo, ve, synth, cpu_epochs=3):
@@ -632,6 +667,17 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args, latent_keep, lens_keep)
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None
+        if world == 1 and not args.no_taxvamb:      # ~10 s
+            if args.deadline - (time.perf_counter() - T_START) < 60.0:
+                line["taxvamb"] = {"skipped": "not enough of --deadline left for the extra leg"}
+            else:
+                try:
+                    ve.set_compute_dtype("fp32")
+                    line["taxvamb"] = taxvamb_leg(ve, synth)
+                except Exception as e:   # never lose the headline because of an extra leg
+                    line["taxvamb"] = {"error": repr(e)}
+                finally:
+                    ve.set_compute_dtype(args.dtype)
         if world == 1 and not args.no_c3 and cfg_name != "C3":
             del dl      # free the headline's dataset first (the device copy cached on the loader)
             if cfg_name != "C1":     # configs[1] (200 k x 50, batch 4096, fp32): ~3 s of input + ~6 s job + ~1 s timed sweep

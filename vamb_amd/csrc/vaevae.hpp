@@ -178,14 +178,18 @@ std::unique_ptr<vh_vae> vv_make_replica(vh_vae* m, uint64_t salt) {
 void vv_enter(vh_vaevae* t) {
     VH_REQUIRE(!t->entered, "trainer is busy");
     vh_vae* nets[3] = {t->vamb, t->labels, t->joint};
+    // every check BEFORE the first handle is touched: a refusal must leave the networks as they were
     for (vh_vae* m : nets) {
         VH_REQUIRE(!m->bf16, "the joint trainer runs the fp32 step: vh_vae_set_precision(h, 0) on its three networks");
         VH_REQUIRE(m->comm == nullptr, "the joint trainer is a single-process path");
         VH_REQUIRE(m->adam_lr > 0.f, "the joint trainer optimises with torch.optim.Adam: vh_vae_set_optimizer(h, VH_OPT_ADAM, lr)");
-        VH_HIP(hipStreamSynchronize(m->stream));
     }
+    VH_REQUIRE(t->joint->n_leaves == t->labels->n_leaves && t->joint->n_nodes == t->labels->n_nodes,
+               "VAEJoint and VAELabels must share one taxonomy");
+    for (vh_vae* m : nets) VH_HIP(hipStreamSynchronize(m->stream));
     t->saved[0][0] = t->labels->stream; t->saved[0][1] = t->labels->side;
     t->saved[1][0] = t->joint->stream;  t->saved[1][1] = t->joint->side;
+    t->entered = true;
     for (int p = 0; p < kVvPasses; ++p) {
         vh_vae* h = t->pass(p);
         h->stream = t->vamb->stream;
@@ -199,9 +203,6 @@ void vv_enter(vh_vaevae* t) {
         r->n_leaves = t->labels->n_leaves;
         r->n_nodes = t->labels->n_nodes;
     }
-    VH_REQUIRE(t->joint->n_leaves == t->labels->n_leaves && t->joint->n_nodes == t->labels->n_nodes,
-               "VAEJoint and VAELabels must share one taxonomy");
-    t->entered = true;
 }
 
 void vv_exit(vh_vaevae* t) {
