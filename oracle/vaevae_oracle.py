@@ -183,9 +183,12 @@ class OracleVAEVAE:
         self.n_leaves = self.masks.shape[1]
         self.dtype = dtype
         S = nsamples
-        self.vamb = _Net(S, S + NTNF + 1, nhiddens, nlatent, dropout, states["VAEVamb"], dtype)
-        self.labels = _Net(0, self.NL, nhiddens, nlatent, dropout, states["VAELabels"], dtype)
-        self.joint = _Net(S, S + NTNF + 1 + self.NL, nhiddens, nlatent, dropout, states["VAEJoint"], dtype)
+        # (hidden widths may differ between the networks -- with nhiddens=None the reference's VAELabels over <= 105 label columns
+        # takes the single-sample default [256, 256] beside [512, 512] -- the depth may not: a dict gives them per network)
+        nh = nhiddens if isinstance(nhiddens, dict) else dict(VAEVamb=nhiddens, VAELabels=nhiddens, VAEJoint=nhiddens)
+        self.vamb = _Net(S, S + NTNF + 1, nh["VAEVamb"], nlatent, dropout, states["VAEVamb"], dtype)
+        self.labels = _Net(0, self.NL, nh["VAELabels"], nlatent, dropout, states["VAELabels"], dtype)
+        self.joint = _Net(S, S + NTNF + 1 + self.NL, nh["VAEJoint"], nlatent, dropout, states["VAEJoint"], dtype)
         self.t = 0
 
     def _onehot(self, nodes):
