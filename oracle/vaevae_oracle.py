@@ -195,11 +195,13 @@ class OracleVAEVAE:
         return np.eye(self.NL, dtype=self.dtype)[nodes]
 
     def _vamb_outputs(self, recon):
+        """VAE._decode (encode.py:288-304): softmax over the depth columns -- ALSO for a single sample (the output is then the
+        constant 1 and the cross-entropy -log(1 + 1e-9) * x: zero in float32); only VAEConcat._decode skips it for nsamples == 1
+        (semisupervised_encode.py:497-500), and no loss is ever computed on that decoder here."""
         S = self.nsamples
         out = recon.copy()
-        if S > 1:
-            e = np.exp(recon[:, :S] - recon[:, :S].max(axis=1, keepdims=True))
-            out[:, :S] = e / e.sum(axis=1, keepdims=True)
+        e = np.exp(recon[:, :S] - recon[:, :S].max(axis=1, keepdims=True))
+        out[:, :S] = e / e.sum(axis=1, keepdims=True)
         return out
 
     def _vamb_recon_terms(self, out, x, g):
@@ -214,7 +216,7 @@ class OracleVAEVAE:
         ab = ((a_out - a_in) ** 2).sum(axis=1)
         drecon = np.zeros_like(out)
         dp = g * ce_w * (-d_in / (p + 1e-9))
-        drecon[:, :S] = p * (dp - (p * dp).sum(axis=1, keepdims=True)) if S > 1 else dp
+        drecon[:, :S] = p * (dp - (p * dp).sum(axis=1, keepdims=True))
         drecon[:, S:S + NTNF] = g * sse_w * 2.0 * (t_out - t_in)
         drecon[:, S + NTNF:S + NTNF + 1] = g * ab_w * 2.0 * (a_out - a_in)
         return ce, sse, ab, (ce_w, ab_w, sse_w), drecon

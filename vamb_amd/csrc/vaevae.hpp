@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void vv_joint_finalize_kernel(const float* __r
         const double wmean = vx->wsum / (double)bs;
         const double ab = vx->step_loss[1], ce = vx->step_loss[2], sse = vx->step_loss[3], cel = lx->step_label[0];
         const double loss = ((((ce + ab) + sse) + cel) + (kld_v + kld_l) * (double)kld_w) * wmean;
-        // ce_joint / sse_joint are logged UNWEIGHTED (ce.mean(), sse.mean()); one sample: the abundance cross-entropy has weight 0
-        // and the unweighted value is not kept anywhere -- logged as 0
+        // ce_joint / sse_joint are logged UNWEIGHTED (ce.mean(), sse.mean()).  One sample: the weight is 0, and the value IS 0 in
+        // float32 -- VAE._decode's softmax over a single column is the constant 1, so ce = -log(1 + 1e-9) * x (encode.py:302, 329)
         const double v[6] = {loss, ce_w > 0.f ? ce / (double)ce_w : 0.0, sse / (double)sse_w, cel, kld_v, kld_l};
         for (int t = 0; t < 6; ++t) { js->step[t] = v[t]; js->epoch[t] += v[t]; }
     }
