@@ -224,12 +224,14 @@ def scan_summary(timed, wall, measured_in):
 
 def pmc_traffic(tag):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", f"r03_pmc_roofline_{tag}.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
+    for rnd in ("r04t", "r03"):   # the latest committed passes first
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_roofline_{tag}.json")
+        try:
+            with open(path) as fh:
+                return json.load(fh).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def config_leg(args, name, ve, vc, lib, _lib, synth, epochs):
@@ -594,9 +596,9 @@ def main():
                                        "(bias + leaky-relu + dropout + BatchNorm batch sums in the epilogue)", peak)
         if roof is not None:
             roof["traffic"] = pmc_traffic(cfg_name.lower())
-            roof["traffic_source"] = (f"static: profiles/r03_pmc_roofline_{cfg_name.lower()}.json (rocprofv3 --pmc passes of this kernel "
-                                      "at this shape, FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE; the kernel -- "
-                                      "gemm_bf16.hpp, K loop and hidden-train epilogue -- is unchanged since those passes); NOT counted in this run")
+            roof["traffic_source"] = (f"static: profiles/r04t_pmc_roofline_{cfg_name.lower()}.json (rocprofv3 --pmc passes of this kernel "
+                                      "at this shape on the round-4 build, profiles/run_r04_pmc.sh: FETCH_SIZE doubled as the gfx950 guide "
+                                      "prescribes + WRITE_SIZE, separate passes); NOT counted in this run")
             if roof["traffic"]:
                 # the same launches against the other roofline: at C2 the kernel's arithmetic intensity (flops / PMC bytes)
                 # is below the ridge of 2.5 PFLOP/s : 8 TB/s = 312 flop/B, i.e. it is the HBM side that binds there
