@@ -51,7 +51,7 @@ const char* vh_version(void);
  *   scan.debug (0)         timing experiments only (wrong results): 1 no pair of interest, 2 no histogram, 4 no flush,
  *                          8 no drain, 32 no histogram publication
  *   gen.profile (0)        wall-clock breakdown of the native cluster state machine on stderr
- *   gen.speculate (1), gen.spec_window (8), gen.spec_big_target (0)   medoid statistics scanned ahead of need in the free slots of a pass
+ *   gen.speculate (1), gen.spec_window (16), gen.spec_big_target (0)   medoid statistics scanned ahead of need in the free slots of a pass
  *   gen.spec_neighbours (1)  ... including the within-radius rows of cached upcoming seeds (their first candidate round)
  *   gen.spec_depth (2)       ... and the within-radius rows of those rows (1: first ring only)
  *   gen.max_entry_age (32)   emissions a cached medoid statistic may outlive (validated lazily against the removal log)

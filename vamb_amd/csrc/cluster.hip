@@ -74,7 +74,8 @@ constexpr int kListRing = 64;     // scans whose lists / histograms stay readabl
 // profiles/r02q_scan_ablation.txt).  The list cursor (word 63) lives in copy 0 only.
 constexpr int kResultReplicas = 8;    // (the publish kernel reads and zeroes every copy: more copies cost it more than they save)
 constexpr int kLocalCap = 128;    // per-block, per-medoid staging of list entries in LDS
-constexpr int kSpecWindow = 8;   // upcoming seeds the native state machine looks at when it fills the free medoid slots of a pass
+constexpr int kSpecWindow = 16;  // upcoming seeds the native state machine looks at when it fills the free medoid slots of a pass
+                                 // (8 until the fill's seed-row memo: 283 k -> 258 k passes per C2 sweep, profiles/r04w_*)
 constexpr int kKeepList = 32;    // within-radius lists up to this length are copied out of the ring when a row is scanned ahead
 constexpr int64_t kMaxEntryAgeDefault = 32;   // measured at C2 (profiles/r03r_*): 8 -> 15.9 s, 32 -> 14.9 s, 128 -> 15.3 s, 512 -> 22.4 s   // emissions a cached entry may lag behind before it is dropped unseen (its lazy check walks the log)
 constexpr size_t kMaxCached = 16384; // cached medoid statistics (hard cap; the age rule keeps it far below)
@@ -2295,6 +2296,12 @@ enum ThresholdKind { kLoner = 0, kNoThreshold = 1, kThreshold = 2 };
 
 struct vh_gen {
     vh_clu* clu = nullptr;          // borrowed
+    // gen_speculative_fill asks for the physical row of the same few upcoming seeds pass after pass: a direct-mapped memo of
+    // (original index -> row) saves the binary searches over `indices` (16 MB at C2: ~20 cache misses each); a pack renumbers
+    // the rows and starts a new epoch
+    struct RowMemo { int64_t orig = -1; int64_t row = 0; uint64_t epoch = 0; };
+    RowMemo row_memo[256];
+    uint64_t rows_epoch = 1;
     // Row-sharded execution (vh_gen_create_sharded): `clu` holds this rank's shard and every rank runs this same state machine
     // in lock step on GLOBAL physical rows (rank order = global row order; offsets[r] = first global row of rank r).  All
     // inputs of a decision are identical on every rank -- the pass results are exact integer sums over the shards -- so the
@@ -2576,7 +2583,13 @@ void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& ex
     for (int64_t i = g->order_index; i < n_order && (int)upcoming.size() < g->spec_window && looked < 4096; ++i, ++looked) {
         const int64_t o = g->order[(size_t)i];
         if (o == -1 || !g->alive[(size_t)o]) continue;
-        upcoming.push_back((int64_t)(std::lower_bound(g->indices.begin(), g->indices.end(), o) - g->indices.begin()));
+        vh_gen::RowMemo& m = g->row_memo[(size_t)o & 255u];
+        if (m.orig != o || m.epoch != g->rows_epoch) {
+            m.orig = o;
+            m.epoch = g->rows_epoch;
+            m.row = (int64_t)(std::lower_bound(g->indices.begin(), g->indices.end(), o) - g->indices.begin());
+        }
+        upcoming.push_back(m.row);
     }
     // seeds first (most of them turn out to be loners: their scan is all they need) ...
     for (int64_t row : upcoming) {
@@ -2595,7 +2608,9 @@ void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& ex
         for (int64_t row : upcoming) {
             const GenStats* seed_st = gen_lookup(g, row);
             if (seed_st == nullptr || !seed_st->have_list) continue;
-            const std::vector<int64_t> pool = seed_st->within;   // (copy: gen_lookup may erase entries)
+            // (no copy: gen_lookup below erases or inserts OTHER rows' entries only -- r != row -- and an unordered_map keeps
+            // references to its elements valid across both)
+            const std::vector<int64_t>& pool = seed_st->within;
             for (int64_t r : pool) {
                 if (out.size() >= want) return;
                 if (r == row) continue;
@@ -2606,7 +2621,7 @@ void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& ex
                 if (g->kept[(size_t)r] == 0) continue;
                 const GenStats* nb = gen_lookup(g, r);   // (validated against the removal log: a stale list would name dead rows)
                 if (nb == nullptr || !nb->have_list) continue;
-                const std::vector<int64_t> pool2 = nb->within;   // (copy: gen_lookup may erase entries)
+                const std::vector<int64_t>& pool2 = nb->within;   // (nothing below touches the map)
                 for (int64_t r2 : pool2) {
                     if (out.size() >= want) return;
                     if (r2 != r && r2 != row && absent(r2)) out.push_back(r2);
@@ -3230,6 +3245,7 @@ void gen_next_impl(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t c
                 if (g->kept[r]) g->indices[w++] = g->indices[r];
             VH_REQUIRE((int64_t)w == new_n, "pack bookkeeping mismatch");
             g->indices.resize(w);
+            g->rows_epoch++;   // physical rows renumbered
             g->kept.assign(w, 1);
             gen_bit_build(g);
         }
