@@ -396,10 +396,13 @@ def test_step_scheduling_variants_are_bit_identical(dtype, monkeypatch):
     n, S = 5000, 6
     ab, tnf, lens, _ = synth.features(n, S, seed=11)
     states = []
-    knobs = ("VAMBHIP_FORK_EVENTS", "VAMBHIP_SINGLE_STREAM", "VAMBHIP_VAE_OPT_SPLIT", "VAMBHIP_VAE_FORK_AT_LOSS")
-    # one stream + event-record forks; the defaults; half of the optimiser on the side stream during the backward; one more fork
+    knobs = ("VAMBHIP_FORK_EVENTS", "VAMBHIP_SINGLE_STREAM", "VAMBHIP_VAE_OPT_SPLIT", "VAMBHIP_VAE_FORK_AT_LOSS",
+             "VAMBHIP_VAE_FUSED_SKINNY", "VAMBHIP_VAE_FUSED_FINALIZE")
+    # one stream + event-record forks; the defaults; half of the optimiser on the side stream during the backward; one more fork;
+    # the latent-wide products as split-K launch + slab kernel; the optimiser's scalar tail as its own launch
     for setting in ({"VAMBHIP_FORK_EVENTS": "1", "VAMBHIP_SINGLE_STREAM": "1"}, {}, {"VAMBHIP_VAE_OPT_SPLIT": "1"},
-                    {"VAMBHIP_VAE_FORK_AT_LOSS": "1"}):
+                    {"VAMBHIP_VAE_FORK_AT_LOSS": "1"}, {"VAMBHIP_VAE_FUSED_SKINNY": "0"}, {"VAMBHIP_VAE_FUSED_FINALIZE": "0"},
+                    {"VAMBHIP_VAE_FUSED_SKINNY": "0", "VAMBHIP_VAE_FUSED_FINALIZE": "0", "VAMBHIP_SINGLE_STREAM": "1"}):
         for var in knobs:
             monkeypatch.delenv(var, raising=False)
         for var, val in setting.items():
@@ -417,6 +420,32 @@ def test_step_scheduling_variants_are_bit_identical(dtype, monkeypatch):
         for k in a:
             assert np.array_equal(a[k], b[k]), k
         assert np.array_equal(la, lb)
+
+
+@pytest.mark.parametrize("nhiddens,nlatent", [([512, 512], 32), ([384], 32), ([96, 160], 20), ([1024], 64), ([640, 64], 64),
+                                              ([2048], 32)])
+def test_fused_latent_kernels_are_bit_identical(nhiddens, nlatent, monkeypatch):
+    """gemm_skinny16.hpp (round 5): mu + reparameterisation and the first decoder layer's input gradient + latent backward as ONE
+    launch each.  The waves of a workgroup contract exactly the k ranges of the split-K slabs and add them in the slab kernel's
+    order, so a run with the fused kernels equals a run with the split-K launches bit for bit -- for 1 to 8 slabs, a partial last
+    K-tile (96 columns), both latent paddings, and a layer too wide for one workgroup's LDS (2048 x 32: the fallback)."""
+    monkeypatch.setenv("VAMBHIP_PRECISION", "bf16")
+    n, S = 3000, 7
+    ab, tnf, lens, _ = synth.features(n, S, seed=21)
+    out = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("VAMBHIP_VAE_FUSED_SKINNY", fused)
+        dl = ve.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=640, destroy=True)
+        vae = ve.VAE(S, nhiddens=nhiddens, nlatent=nlatent, seed=5)
+        vae.trainmodel(dl, nepochs=3, batchsteps=None)
+        out.append(({k: v.numpy().copy() for k, v in vae.state_dict().items()}, vae.optimizer_state(), vae.encode(dl)))
+    monkeypatch.delenv("VAMBHIP_VAE_FUSED_SKINNY", raising=False)
+    (a, oa, la), (b, ob, lb) = out
+    assert oa == ob
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(la, lb)
+    assert np.isfinite(la).all() and la.std() > 1e-3
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

@@ -206,6 +206,9 @@ _ENV_OPTIONS = {
     "VAMBHIP_VAE_FORK_AT_LOSS": ("vae.fork_at_loss", int),
     "VAMBHIP_VAE_DZ_COLSUM": ("vae.dz_colsum", int),
     "VAMBHIP_VAE_OPT_SPLIT": ("vae.opt_split", int),
+    "VAMBHIP_VAE_FUSED_SKINNY": ("vae.fused_skinny", int),
+    "VAMBHIP_VAE_FUSED_FINALIZE": ("vae.fused_finalize", int),
+    "VAMBHIP_VAE_DZ_DBG": ("vae.dz_dbg", int),
     "VAMBHIP_VAE_PROBE_EVERY": ("vae.probe_every", int),
 }
 _ENV_STRING_OPTIONS = {"VAMBHIP_RCCL": "comm.rccl_library", "ROCM_PATH": "comm.rocm_path"}

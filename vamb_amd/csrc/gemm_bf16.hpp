@@ -83,6 +83,8 @@ struct Gemm16Args {
     const bf16_t* Hbelow;  // raw activations of the layer below, [M][N] bf16 with leading dimension ldh
     int64_t ldh;
     BnSrc bnC;
+    const float* bn_mean;  // mean / 1/std of the layer below, as the kernel that folded its BatchNorm left them ([N] floats each)
+    const float* bn_istd;
     double* bstat_out;     // [2][N]
     int xcd_remap;
     int dbg;               // timing experiments (vh_debug_gemm16): 1 no fp64 atomics, 2 no transposed copy, 4 no row-major copy
@@ -164,6 +166,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
         by = (t / gx) % gy;
         bz = t / (gx * gy);
     }
+    // (the remap's divisions run on the VALU: without this the compiler treats every tile coordinate -- and with them the K
+    // loop's trip count and the DMA guards -- as divergent and wraps them in exec-mask branches)
+    bx = __builtin_amdgcn_readfirstlane(bx);
+    by = __builtin_amdgcn_readfirstlane(by);
+    bz = __builtin_amdgcn_readfirstlane(bz);
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = bz * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
@@ -223,6 +230,74 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // ---- epilogue operands that do not depend on the product: per-column bias, the dropout stream's seed (a load of the
+    // device-resident step counter + a hash), the BatchNorm coefficients of the layer below (fp64 batch sums) and the tile of its
+    // activations.  Left at the head of the epilogue they formed a chain of dependent round trips -- kernel argument, step
+    // counter, hash; kernel argument, bias -- each behind its own s_waitcnt, ~2 k clk per GEMM with every matrix pipe idle
+    // (found in the ISA, round 5).  Now: epilogue_loads() issues the raw loads in FRONT of the first K-tile's DMAs (older than
+    // them, so the counted vmcnt waits of the K loop are unchanged and the values have landed when tile 0 has) and
+    // pin_epilogue_operands() after the loop keeps them live in registers across it (the compiler does not move loads over the
+    // loop's asm statements by itself).  mean / 1/std of the layer below come as floats from the kernel that folded its
+    // BatchNorm (vae_fold_bn_kernel), so no fp64 arithmetic is left in this kernel.
+    [[maybe_unused]] float bias_pre[TN];
+    [[maybe_unused]] float sc_pre[TN], sh_pre[TN];
+    [[maybe_unused]] unsigned long long step_raw = 0ull;
+    // E16_STORE_BNRED: a wave instruction of the store pass covers 16 rows x 32 columns (lane = 16 g4 + r16: row r16 of the block,
+    // columns 8 g4 .. + 7); this thread's 8 columns and its NU row blocks are fixed by (wave, lane)
+    constexpr int UC_PRE = BN / 32, UR_PRE = BM / 16, WG_PRE = (NWAVE / UC_PRE) > 0 ? NWAVE / UC_PRE : 1;
+    constexpr int NU_PRE = (UR_PRE / WG_PRE) > 0 ? UR_PRE / WG_PRE : 1;
+    [[maybe_unused]] float4 mean_pre[2], istd_pre[2];
+    [[maybe_unused]] uint4 hv_pre[NU_PRE];
+    // Every load below is UNCONDITIONAL with a clamped address (a load inside a branch makes the compiler wait for it at the
+    // join, in front of the DMAs); edge tiles, which take the general epilogue, simply do not use the values.
+    auto epilogue_loads = [&]() {
+        if constexpr (EPI == E16_HIDDEN_TRAIN || EPI == E16_HIDDEN_EVAL || EPI == E16_BIAS || EPI == E16_LATENT_MASK) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = min(n0 + (wn * TN + j) * 32 + (lane & 31), g.N - 1);
+                bias_pre[j] = g.bias[col];
+                sc_pre[j] = 1.f; sh_pre[j] = 0.f;
+                if constexpr (EPI == E16_HIDDEN_EVAL) { sc_pre[j] = g.scale[col]; sh_pre[j] = g.shift[col]; }
+            }
+            if constexpr (EPI == E16_HIDDEN_TRAIN) {
+                const unsigned long long* sp = g.step_ptr ? g.step_ptr : reinterpret_cast<const unsigned long long*>(g.zeros);
+                step_raw = *sp;
+            }
+        }
+        if constexpr (EPI == E16_STORE_BNRED) {
+            const int c0p = min(n0 + (wave % UC_PRE) * 32 + 8 * (lane >> 4), g.N - 8);
+            mean_pre[0] = *reinterpret_cast<const float4*>(g.bn_mean + c0p);
+            mean_pre[1] = *reinterpret_cast<const float4*>(g.bn_mean + c0p + 4);
+            istd_pre[0] = *reinterpret_cast<const float4*>(g.bn_istd + c0p);
+            istd_pre[1] = *reinterpret_cast<const float4*>(g.bn_istd + c0p + 4);
+#pragma unroll
+            for (int k = 0; k < NU_PRE; ++k) {
+                const int row = min(m0 + (wave / UC_PRE + WG_PRE * k) * 16 + (lane & 15), g.M - 1);
+                hv_pre[k] = *reinterpret_cast<const uint4*>(g.Hbelow + (int64_t)row * g.ldh + c0p);
+            }
+        }
+    };
+    // (an empty asm that "reads" the values: the compiler must have them in registers at this point of the program)
+    auto pin_epilogue_operands = [&]() {
+        if constexpr (EPI == E16_BIAS || EPI == E16_LATENT_MASK) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bias_pre[j]));
+        }
+        if constexpr (EPI == E16_HIDDEN_TRAIN || EPI == E16_HIDDEN_EVAL) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bias_pre[j]), "v"(sc_pre[j]), "v"(sh_pre[j]));
+            asm volatile("" ::"v"((uint32_t)step_raw), "v"((uint32_t)(step_raw >> 32)));
+        }
+        if constexpr (EPI == E16_STORE_BNRED) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                asm volatile("" ::"v"(mean_pre[q].x), "v"(mean_pre[q].y), "v"(mean_pre[q].z), "v"(mean_pre[q].w), "v"(istd_pre[q].x),
+                             "v"(istd_pre[q].y), "v"(istd_pre[q].z), "v"(istd_pre[q].w));
+#pragma unroll
+            for (int k = 0; k < NU_PRE; ++k) asm volatile("" ::"v"(hv_pre[k].x), "v"(hv_pre[k].y), "v"(hv_pre[k].z), "v"(hv_pre[k].w));
+        }
+    };
+
     auto compute = [&](const unsigned char* abuf, const unsigned char* bbuf) {
         // Software pipeline inside the K-tile: the fragments of step t + 2 are requested while step t multiplies
         // (hipcc on its own sinks every ds_read_b128 to just in front of its MFMA and waits lgkmcnt(0) four times per
@@ -260,6 +335,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
     // K loop, unrolled by two so that every LDS address is a compile-time offset of the one array.  (A third buffer with
     // the DMA of tile t + 2 in flight across the barrier measured 0-8 % slower: the loop is bound by the per-CU LDS-DMA
     // rate, not by its latency.)
+    epilogue_loads();
     if constexpr (STG == 0) {
         if (nk > 0) stage(As, Bs, kbeg);
         __syncthreads();   // (hipcc drains the DMA queue in front of this barrier)
@@ -319,8 +395,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
         auto bbuf = [&](int b) { return Bs + b * B_BYTES; };
         // prologue: tiles 0 and 1 requested; tile 0 awaited (tile 1's NP pieces may stay in flight)
         if (nk > 0) stage(abuf(0), bbuf(0), kbeg);
+        if (nk > 1) stage(abuf(1), bbuf(1), kbeg + BK);
         if (nk > 1) {
-            stage(abuf(1), bbuf(1), kbeg + BK);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -389,6 +465,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
         }
     }
 
+    pin_epilogue_operands();
     gemm16_stamp(g, 2);
     // ---------------------------------------------------------------------------------------------------
     // epilogue.  acc[i][j][reg] is C[row][col] with
@@ -402,7 +479,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
             const int col = n0 + (wn * TN + j) * 32 + frag_r;
             const bool col_ok = col < g.N;
             float bias = 0.f;
-            if constexpr (EPI != E16_SPLITK) bias = col_ok ? g.bias[col] : 0.f;
+            if constexpr (EPI != E16_SPLITK) bias = col_ok ? bias_pre[j] : 0.f;   // (loaded in the prologue)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -445,14 +522,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                 dsa = g.drop_scale;
                 dsb = g.drop_scale * kLeakySlopeF;
                 thresh16 = g.drop_thresh >> 16;
-                if (hashed) rng = hash_drop(step_key(g.drop_key, g.step_ptr), (uint32_t)(by * (int)gridDim.x + bx) * NT + tid) | 1u;
+                if (hashed) {   // (the step counter was loaded in the prologue)
+                    const uint64_t key = g.step_ptr ? (g.drop_key ^ ((uint64_t)step_raw << 8)) : g.drop_key;
+                    rng = hash_drop(key, (uint32_t)(by * (int)gridDim.x + bx) * NT + tid) | 1u;
+                }
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int cl = (wn * TN + j) * 32 + frag_r;
-                float bias = 0.f, sc = 1.f, sh = 0.f;
-                if constexpr (EPI == E16_HIDDEN_TRAIN || EPI == E16_HIDDEN_EVAL) bias = g.bias[n0 + cl];
-                if constexpr (EPI == E16_HIDDEN_EVAL) { sc = g.scale[n0 + cl]; sh = g.shift[n0 + cl]; }
+                const float bias = bias_pre[j], sc = sc_pre[j], sh = sh_pre[j];   // loaded in the prologue
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -514,21 +592,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
             float mean8[8], istd8[8], t1[8], t2[8];
             if constexpr (EPI == E16_STORE_BNRED) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float sc, sh;
-                    bn_column(g.bnC, n0 + c0 + e, mean8[e], istd8[e], sc, sh);
+                for (int e = 0; e < 8; ++e) {   // (coefficients of the layer below: loaded in the prologue)
+                    mean8[e] = (&mean_pre[e >> 2].x)[e & 3]; istd8[e] = (&istd_pre[e >> 2].x)[e & 3];
                     t1[e] = 0.f; t2[e] = 0.f;
                 }
             }
             constexpr int NU = UR / WG;    // row blocks per wave
             static_assert(UR % WG == 0, "row blocks per wave");
+            static_assert(NU == NU_PRE && UC == UC_PRE && WG == WG_PRE, "prologue prefetch layout");
             uint4 hv[NU];
             if constexpr (EPI == E16_STORE_BNRED) {
 #pragma unroll
-                for (int k = 0; k < NU; ++k) {
-                    const int row = m0 + (wave / UC + WG * k) * 16 + r16;
-                    hv[k] = *reinterpret_cast<const uint4*>(g.Hbelow + (int64_t)row * g.ldh + n0 + c0);
-                }
+                for (int k = 0; k < NU; ++k) hv[k] = hv_pre[k];   // (Hbelow tile: requested in the prologue)
             }
 #pragma unroll
             for (int k = 0; k < NU; ++k) {

@@ -91,6 +91,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(const Gemm16
         by = (t / gx) % gy;
         bz = t / (gx * gy);
     }
+    // (the remap's divisions run on the VALU: without this the compiler treats every tile coordinate -- and with them the K
+    // loop's trip count and the DMA guards -- as divergent and wraps them in exec-mask branches)
+    bx = __builtin_amdgcn_readfirstlane(bx);
+    by = __builtin_amdgcn_readfirstlane(by);
+    bz = __builtin_amdgcn_readfirstlane(bz);
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = bz * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);

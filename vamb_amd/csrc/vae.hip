@@ -18,6 +18,7 @@
 #include "gemm.hpp"
 #include "gemm_bf16.hpp"
 #include "gemm_bf16_tn.hpp"
+#include "gemm_skinny16.hpp"
 #include "vae_kernels.hpp"
 #include "vae_kernels16.hpp"
 
@@ -171,6 +172,12 @@ struct VaeTuning {
                               // (fp64 atomics from every row block); 0 = the weight-gradient GEMM does it on the way.  Measured at C2
                               // (profiles/r03zd_dz_colsum.txt): the dz kernel 12.1 -> 10.2 us, the dW GEMMs 16.9 -> 20.4 us, step 291 ->
                               // 293 us: stays where it was
+    bool fused_skinny = true; // vae.fused_skinny: bf16 step: the two latent-wide products (mu, the first decoder layer's input gradient) and
+                              // their elementwise consumers (reparameterisation, latent backward) as ONE launch each
+                              // (gemm_skinny16.hpp) instead of split-K launch + slab-summing kernel.  Same bits.
+    bool fused_finalize = true; // vae.fused_finalize: bf16 step: d / k / counters / clearing of the fp64 accumulators by the LAST workgroup of the
+                              // update kernel (arrival ticket behind drained write-through stores) instead of a one-workgroup launch
+    int dz_dbg = 0;           // vae.dz_dbg: timing experiments on the elementwise BatchNorm-backward kernel (WRONG results): see Dz16Args
     bool dw_row_major = true; // vae.dw_row_major: bf16 weight gradients contract ROW-major tensors (gemm_bf16_tn.hpp); 0 = the
                               // round-2 dataflow with a transposed bf16 copy of every contracted tensor (A/B measurements)
 } g_tuning;
@@ -184,6 +191,9 @@ void refresh_tuning() {
     g_tuning.dz_colsum = option("vae.dz_colsum", 1) != 0;
     g_tuning.opt_split = option("vae.opt_split", 0) != 0;
     g_tuning.pipeline = option("vae.gemm_pipeline", 2) == 0 ? 0 : 2;
+    g_tuning.fused_skinny = option("vae.fused_skinny", 1) != 0;
+    g_tuning.fused_finalize = option("vae.fused_finalize", 1) != 0;
+    g_tuning.dz_dbg = (int)option("vae.dz_dbg", 0);
 }
 
 int fwd_tile(int M, int N) {
@@ -278,6 +288,8 @@ struct vh_vae {
     double* dbias_mu = nullptr;              // fp64 column sums of dMU / dR (inside statbuf)
     double* dbias_out = nullptr;
     DevBuf<Opt16Tensor> opt16_tab, opt16_tab_flat;
+    DevBuf<uint8_t> opt16_blk2t;             // optimiser workgroup -> entry of the table
+    DevBuf<unsigned int> opt_ticket;         // arrival counter of the update kernel's workgroups (scalar tail by the last one)
     int opt16_n = 0, opt16_blocks = 0;
 
     // data parallelism (one process per GPU; gradients all-reduced over RCCL on `stream`)
@@ -1257,7 +1269,7 @@ int vh_vae_get_grad(vh_vae* h, const char* name, float* data, int64_t n) {
         read_state(h, &st);
         if (h->bf16) {
             // the complete gradient (slab sums + BatchNorm completion) as the optimiser forms it, through the flat buffer
-            hipLaunchKernelGGL(vae_grad16_kernel, dim3(h->opt16_blocks), dim3(256), 0, h->stream, h->opt16_tab.p, h->opt16_n,
+            hipLaunchKernelGGL(vae_grad16_kernel, dim3(h->opt16_blocks), dim3(256), 0, h->stream, h->opt16_tab.p, (const uint8_t*)h->opt16_blk2t.p,
                                stat_bs(h), h->G.p, 0, allrank_stats(h));
             VH_HIP(hipGetLastError());
             std::vector<float> buf((size_t)t.padded());

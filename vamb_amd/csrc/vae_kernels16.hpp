@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void vae_fold_bn_kernel(const float* __restric
                                                           const float* __restrict__ scale_in,
                                                           const float* __restrict__ shift_in,
                                                           bf16_t* __restrict__ W16, float* __restrict__ bias_out,
-                                                          float* __restrict__ scale_out, float* __restrict__ shift_out) {
+                                                          float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                                          float* __restrict__ mean_out, float* __restrict__ istd_out) {
     extern __shared__ __attribute__((aligned(16))) float fold_st[];   // [2][K]
     float* s_s = fold_st;
     float* t_s = fold_st + K;
@@ -173,6 +174,9 @@ __global__ __launch_bounds__(256) void vae_fold_bn_kernel(const float* __restric
         } else {
             float mean, istd;
             bn_column(bn, k, mean, istd, sc, sh);
+            // the backward kernels of this step (input-gradient GEMM epilogue, elementwise BatchNorm backward) read these
+            // instead of re-deriving them from the fp64 sums
+            if (blockIdx.x == 0 && mean_out != nullptr) { mean_out[k] = mean; istd_out[k] = istd; }
         }
         s_s[k] = sc;
         t_s[k] = sh;
@@ -386,11 +390,15 @@ struct Dz16Args {
     int64_t ldt;       // leading dimension of DZT (= bs_p)
     int n_p, bs, bs_p;
     BnSrc bn;
+    const float* mean;    // mean / 1/std of this layer's BatchNorm as the forward fold left them (nullptr: from the fp64 sums)
+    const float* istd;
     const double* bstat;
     float drop_scale;
     const uint8_t* drop_mask;
     int64_t ld_mask;
     double* dbias;
+    int dbg;              // timing experiments only (option vae.dz_dbg; WRONG results): 1 no column-sum atomics, 2 no dZ stores,
+                          // 4 constant coefficients (no statistics loads)
 };
 // (Two register-transposing variants without LDS -- a thread owning an 8 x 8 block, 128 x 128 tiles with 4 waves or
 // 64 x 64 tiles with one wave -- measured 18 and 37 us against 13.7 us for this kernel at 8192 x 512: profiles/README.md.)
@@ -423,9 +431,11 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
     if (tid < kDz16Cols) {
         const int colc = col0 + tid;
         float ca = 0.f, ch = 0.f, c0 = 0.f;
-        if (colc < a.n_p) {
+        if (colc < a.n_p && (a.dbg & 4)) { ca = 1.0f; ch = 0.5f; c0 = 0.25f; }
+        else if (colc < a.n_p) {
             float mean, istd, sc, sh;
-            bn_column(a.bn, colc, mean, istd, sc, sh);
+            if (a.mean != nullptr) { mean = a.mean[colc]; istd = a.istd[colc]; }   // (the same floats bn_column forms)
+            else bn_column(a.bn, colc, mean, istd, sc, sh);
             const double inv_bs = 1.0 / (double)a.bn.bs;   // the statistics' batch (all ranks under SyncBN)
             const float c1 = (float)(a.bstat[colc] * inv_bs);
             const float c2 = (float)(a.bstat[a.n_p + colc] * inv_bs);
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
         }
         const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         if (a.DZT) *reinterpret_cast<uint4*>(&tile[rl][c8]) = o;
-        if (r < a.bs_p && col < a.n_p) *reinterpret_cast<uint4*>(a.DZ + (int64_t)r * a.n_p + col) = o;
+        if (r < a.bs_p && col < a.n_p && !(a.dbg & 2)) *reinterpret_cast<uint4*>(a.DZ + (int64_t)r * a.n_p + col) = o;
     }
     if (a.dbias) {
 #pragma unroll
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += red[i][tid];
-        if (c < a.n_p) atomicAdd(&a.dbias[c], (double)t);
+        if (c < a.n_p && !(a.dbg & 1)) atomicAdd(&a.dbias[c], (double)t);
     }
 }
 
@@ -542,6 +552,16 @@ struct Opt16Tensor {
 };
 constexpr int kMaxOpt16 = 4 * 2 * 8 + 4;
 
+// The scalar tail of the optimiser step inside the update kernel (ticket == nullptr: a separate vae_dadapt_finalize_kernel follows)
+struct Opt16Tail {
+    unsigned int* ticket;   // arrival counter, 0 between steps
+    StepState* st;
+    double* statbuf;        // the step's fp64 accumulators, cleared for the next step
+    int nstat;
+    int nblocks;            // partial-sum pairs of the whole step
+    int adam;
+};
+
 // gradient of 4 consecutive elements (tensor-local index `local` = row * cols_p + col): slab sum or fp64 accumulator,
 // completed for weights that consume BatchNorm-ed activations:  dW = G diag(s) + dbias t^T
 __device__ __forceinline__ float4 opt16_grad(const Opt16Tensor& td, int64_t local, int row, int col, int bs, int allrank = 0) {
@@ -590,29 +610,27 @@ __device__ __forceinline__ bool opt16_locate(const Opt16Tensor& td, int lb, int&
 }
 
 // data-parallel path: G[flat] = this rank's complete gradient (then all-reduced over the ranks)
-__global__ __launch_bounds__(256) void vae_grad16_kernel(const Opt16Tensor* __restrict__ tab, int ntensors, int bs,
-                                                         float* __restrict__ G, int blk0, int allrank) {
+__global__ __launch_bounds__(256) void vae_grad16_kernel(const Opt16Tensor* __restrict__ tab, const uint8_t* __restrict__ blk2t,
+                                                         int bs, float* __restrict__ G, int blk0, int allrank) {
     const int blk = (int)blockIdx.x + blk0;   // the launch covers the table's workgroups [blk0, blk0 + gridDim.x)
-    int t = 0;
-    while (t + 1 < ntensors && blk >= tab[t + 1].blk_start) ++t;
-    const Opt16Tensor td = tab[t];
+    const Opt16Tensor td = tab[blk2t[blk]];
     int row, col;
     int64_t local;
     if (!opt16_locate(td, blk - td.blk_start, row, col, local)) return;
     *reinterpret_cast<float4*>(G + td.p_off + local) = opt16_grad(td, local, row, col, bs, allrank);
 }
 
-__global__ __launch_bounds__(256) void vae_dadapt16_kernel(const Opt16Tensor* __restrict__ tab, int ntensors, int bs,
+// blk2t[workgroup] = its tensor.  (Until round 5 every workgroup walked the table -- `while (blk >= tab[t + 1].blk_start) ++t` --
+// one dependent load per tensor in front of everything else: up to 27 round trips for the workgroups of the last tensors.)
+__global__ __launch_bounds__(256) void vae_dadapt16_kernel(const Opt16Tensor* __restrict__ tab, const uint8_t* __restrict__ blk2t, int bs,
                                                            float* __restrict__ P, float* __restrict__ M1,
                                                            float* __restrict__ M2, float* __restrict__ Sv,
-                                                           const StepState* __restrict__ st,
-                                                           double* __restrict__ partials, float adam_lr, int blk0) {
+                                                           const StepState* st, double* partials, float adam_lr, int blk0,
+                                                           const Opt16Tail tail) {   // (st / partials: also written by the tail)
     __shared__ double red[2][4];
     __shared__ bf16_t wt[32][32 + 2];
     const int blk = (int)blockIdx.x + blk0;   // the launch covers the table's workgroups [blk0, blk0 + gridDim.x)
-    int t = 0;
-    while (t + 1 < ntensors && blk >= tab[t + 1].blk_start) ++t;
-    const Opt16Tensor td = tab[t];
+    const Opt16Tensor td = tab[blk2t[blk]];
     const int lb = blk - td.blk_start;
     const bool matrix = td.rows_p > 1;
     int row, col;
@@ -693,9 +711,65 @@ __global__ __launch_bounds__(256) void vae_dadapt16_kernel(const Opt16Tensor* __
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[0][wave] = wn; red[1][wave] = ws; }
     __syncthreads();
+    const double part0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double part1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    if (tail.ticket == nullptr) {
+        if (threadIdx.x == 0) {
+            partials[(int64_t)blk * 2 + 0] = part0;
+            partials[(int64_t)blk * 2 + 1] = part1;
+        }
+        return;
+    }
+    // ---- the scalar part of the step (vae_dadapt_finalize_kernel) by the workgroup that arrives LAST, instead of one more
+    // dependent launch.  Hand-off as the CDNA4 guide prescribes for data another CU will read: write-through (device-scope)
+    // stores of the partial sums, drained (s_waitcnt vmcnt(0)), THEN the arrival ticket; the last arriver reads every partial
+    // with device-scope loads.  No fence (a release fence writes the whole L2 back).  Every other workgroup has read the step
+    // state and its accumulators before it took its ticket, so the last one may update / clear them.
+    __shared__ int last_s;
     if (threadIdx.x == 0) {
-        partials[(int64_t)blk * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        partials[(int64_t)blk * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        __hip_atomic_store(&partials[(int64_t)blk * 2 + 0], part0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partials[(int64_t)blk * 2 + 1], part1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = (t == (unsigned int)gridDim.x - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    StepState* const stw = tail.st;
+    for (int i = threadIdx.x; i < tail.nstat; i += 256) tail.statbuf[i] = 0.0;
+    __shared__ double fin[2][256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < tail.nblocks; i += 256) {   // (same order as the finalize kernel: same bits)
+        a += __hip_atomic_load(&partials[(int64_t)i * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b += __hip_atomic_load(&partials[(int64_t)i * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    fin[0][threadIdx.x] = a;
+    fin[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            fin[0][threadIdx.x] += fin[0][threadIdx.x + off];
+            fin[1][threadIdx.x] += fin[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double sqrt_b2s = sqrt(0.999);
+        const double d = stw->d;
+        const double numerator_acum = d * fin[0][0];
+        const double sk_l1 = fin[1][0];
+        const double nw = sqrt_b2s * stw->numerator_weighted + (1.0 - sqrt_b2s) * numerator_acum;
+        if (tail.adam) {
+            stw->k += 1;
+        } else if (sk_l1 != 0.0) {
+            const double d_hat = nw / ((1.0 - sqrt_b2s) * sk_l1);
+            stw->d = d_hat > d ? d_hat : d;
+            stw->numerator_weighted = nw;
+            stw->k += 1;
+        }
+        stw->step += 1;
+        stw->batch += 1;
+        __hip_atomic_store(tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // armed for the next step
     }
 }
 

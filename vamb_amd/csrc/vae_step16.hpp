@@ -63,6 +63,27 @@ void launch_gemm16_tn(hipStream_t stream, const Gemm16TnArgs& g, int splits) {
     VH_HIP(hipGetLastError());
 }
 
+// latent-wide product with its elementwise consumer in one launch (gemm_skinny16.hpp); false: the shape does not fit one
+// workgroup's LDS and the caller keeps the split-K launch + slab kernel
+template <int EPI>
+bool launch_skinny16(hipStream_t stream, const Skinny16Args& a, int N) {
+    const size_t smem = skinny16_smem_bytes(N, a.k_per_wave, a.nslab);
+    if (smem == 0 || (a.M & 31) != 0) return false;
+    const int waves = std::max(kSkinnyMinWaves, a.nslab);
+    auto go = [&](auto kern) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a.M / 32)), dim3(64 * waves), smem, stream, a);
+        VH_HIP(hipGetLastError());
+    };
+    if (N == 32) go(gemm_skinny16_kernel<1, EPI>);
+    else go(gemm_skinny16_kernel<2, EPI>);
+    return true;
+}
+
 // weight-gradient tile by output shape (same rule as the K-contiguous kernel; dw_splits16 plans the slabs for it):
 // tile 0 = by shape, 1 = 128x128 / 8 waves, 3 = 64x128 / 4 waves (A/B measurements through vh_debug_gemm16_tn)
 template <int COLSUM, int STG>
@@ -263,6 +284,15 @@ void build_opt16_table(vh_vae* h) {
     h->opt16_blocks = nblk;
     h->opt16_tab.ensure(tab.size());
     VH_HIP(hipMemcpy(h->opt16_tab.p, tab.data(), tab.size() * sizeof(Opt16Tensor), hipMemcpyHostToDevice));
+    {   // workgroup -> tensor (one load instead of a walk over the table)
+        std::vector<uint8_t> map((size_t)nblk);
+        for (size_t t = 0; t < tab.size(); ++t) {
+            const int end = t + 1 < tab.size() ? tab[t + 1].blk_start : nblk;
+            for (int b = tab[t].blk_start; b < end; ++b) map[(size_t)b] = (uint8_t)t;
+        }
+        h->opt16_blk2t.ensure(map.size());
+        VH_HIP(hipMemcpy(h->opt16_blk2t.p, map.data(), map.size(), hipMemcpyHostToDevice));
+    }
     // data-parallel variant: gradients already complete (and all-reduced) in the flat buffer G
     for (auto& d : tab) {
         d.dsrc = nullptr;
@@ -272,6 +302,10 @@ void build_opt16_table(vh_vae* h) {
     h->opt16_tab_flat.ensure(tab.size());
     VH_HIP(hipMemcpy(h->opt16_tab_flat.p, tab.data(), tab.size() * sizeof(Opt16Tensor), hipMemcpyHostToDevice));
     h->opt_part.ensure((size_t)std::max(h->opt_blocks, nblk) * 2);
+    if (h->opt_ticket.n == 0) {
+        h->opt_ticket.alloc(1);
+        VH_HIP(hipMemset(h->opt_ticket.p, 0, sizeof(unsigned int)));
+    }
 }
 
 void fold_bn(vh_vae* h, hipStream_t s, int tW, int tb, int n_rows, int K, const Hidden& prev, bool training,
@@ -280,7 +314,7 @@ void fold_bn(vh_vae* h, hipStream_t s, int tW, int tb, int n_rows, int K, const 
     hipLaunchKernelGGL(vae_fold_bn_kernel, dim3((unsigned)ceil_div(n_rows, 4 * kFoldRowsPerWave)), dim3(256), (size_t)2 * K * sizeof(float), s,
                        h->pptr(tW), (int64_t)K, n_rows, K, h->pptr(tb), bn, training ? nullptr : prev.scale.p,
                        training ? nullptr : prev.shift.p, Wf16, biasf, training ? prev.scale.p : nullptr,
-                       training ? prev.shift.p : nullptr);
+                       training ? prev.shift.p : nullptr, training ? prev.mean.p : nullptr, training ? prev.invstd.p : nullptr);
     VH_HIP(hipGetLastError());
 }
 
@@ -340,32 +374,46 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
     for (int li = 0; li < nl; ++li) hidden_layer(li);
     int mu_slabs = 1;
     const float* mu_bias = h->pptr(h->tbmu);
-    {   // mu (encode.py:268): latent-wide output, contraction split over up to 8 slabs (summed by the reparam kernel).
-        // (One-pass variants with the reparameterisation fused into the epilogue -- 128x32 or 32x32 tiles, 64 / 256
-        // workgroups walking all of K -- measured 13.6-18 us against 5.1 + 4.9 us for slabs + reparam kernel.)
-        Gemm16Args g = args16(h);
-        g.A = in; g.lda = in_w;
-        g.B = w16(h, h->tWmu); g.ldb = in_w;
+    {   // mu (encode.py:268): latent-wide output, contraction split over up to 8 slabs; reparameterisation (encode.py:276-286).
+        // One launch when the operands of 32 output rows fit a workgroup's LDS (gemm_skinny16.hpp: the slabs are the waves of a
+        // workgroup and meet in LDS); else the split-K launch + the slab-summing kernel.  Same bits either way.
+        const bf16_t* Bmu = w16(h, h->tWmu);
         if (training && prev) {
             fold_bn(h, s, h->tWmu, h->tbmu, h->L_p, in_w, *prev, true, h->Wf16_mu.p, h->biasf_mu.p);
-            g.B = h->Wf16_mu.p;
+            Bmu = h->Wf16_mu.p;
             mu_bias = h->biasf_mu.p;
         }
-        g.C32 = h->skinny.p; g.ldc32 = h->L_p;
-        g.M = bs_p; g.N = h->L_p; g.K = in_w;
         const int want = std::max(1, std::min(kSkinnySplits, in_w / 128));
-        g.k_per_split = (int)round_up(ceil_div(in_w, want), 64);
-        mu_slabs = (int)ceil_div(in_w, g.k_per_split);
-        g.slab_stride = (int64_t)bs_p * h->L_p;
-        gemm16<E16_SPLITK>(s, g, mu_slabs);
-    }
-    {
-        const int64_t tot = (int64_t)bs_p * h->L_p;
+        const int k_per_split = (int)round_up(ceil_div(in_w, want), 64);
+        mu_slabs = (int)ceil_div(in_w, k_per_split);
         const float* eps_ptr = eps_injected ? h->EPS.p : nullptr;
-        hipLaunchKernelGGL(vae_reparam16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s,
-                           (const float*)h->skinny.p, mu_slabs, (int64_t)bs_p * h->L_p, mu_bias, eps_ptr,
-                           layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z16.p, bs, h->L, h->L_p, bs_p);
-        VH_HIP(hipGetLastError());
+        bool fused = false;
+        if (g_tuning.fused_skinny) {
+            Skinny16Args a;
+            memset(&a, 0, sizeof(a));
+            a.A = in; a.lda = in_w;
+            a.B = Bmu; a.ldb = in_w;
+            a.M = bs_p; a.K = in_w; a.k_per_wave = k_per_split; a.nslab = mu_slabs;
+            a.zeros = h->zeros16.p; a.bs = bs;
+            a.bias = mu_bias; a.E = eps_ptr; a.key = layer_key(h, 0xEE); a.step_ptr = step_ptr(h); a.noise = add_noise ? 1 : 0;
+            a.L = h->L; a.MU = h->MU.p; a.Z16 = h->Z16.p;
+            fused = launch_skinny16<SK16_REPARAM>(s, a, h->L_p);
+        }
+        if (!fused) {
+            Gemm16Args g = args16(h);
+            g.A = in; g.lda = in_w;
+            g.B = Bmu; g.ldb = in_w;
+            g.C32 = h->skinny.p; g.ldc32 = h->L_p;
+            g.M = bs_p; g.N = h->L_p; g.K = in_w;
+            g.k_per_split = k_per_split;
+            g.slab_stride = (int64_t)bs_p * h->L_p;
+            gemm16<E16_SPLITK>(s, g, mu_slabs);
+            const int64_t tot = (int64_t)bs_p * h->L_p;
+            hipLaunchKernelGGL(vae_reparam16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, s,
+                               (const float*)h->skinny.p, mu_slabs, (int64_t)bs_p * h->L_p, mu_bias, eps_ptr,
+                               layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z16.p, bs, h->L, h->L_p, bs_p);
+            VH_HIP(hipGetLastError());
+        }
         // the transposed latent code feeds the first decoder layer's weight gradient
         if (defer && !g_tuning.dw_row_major)
             defer->add([h, bs_p](hipStream_t st) { transpose16(h, st, h->Z16.p, bs_p, h->L_p, h->Z16T.p, nullptr, 0); });
@@ -496,6 +544,7 @@ void grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidd
     g.C16 = below.DA16.p; g.ldc16 = in_p;
     g.Hbelow = below.H16.p; g.ldh = in_p;
     g.bnC = bn_src(h, below);
+    g.bn_mean = below.mean.p; g.bn_istd = below.invstd.p;   // left by the fold of this layer's BatchNorm in the forward pass
     g.bstat_out = below.bstat;
     gemm16<E16_STORE_BNRED>(h->stream, g, 1);
     sync_stats(h, below.bstat, below.nout_p);
@@ -520,12 +569,15 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         grad_input16(h, h->dR16.p, h->D_p, h->tWo, last.nout_p, last);
     }
     int latent_slabs = 1;
+    bool latent_fused = false;
     auto hidden_bwd = [&](int li) {
         Hidden& hl = h->hidden[li];
         Dz16Args a;
         a.DA = hl.DA16.p; a.H = hl.H16.p; a.DZ = hl.DZ16.p; a.DZT = g_tuning.dw_row_major ? nullptr : hl.DZ16T.p; a.ldt = bs_p;
         a.n_p = hl.nout_p; a.bs = bs; a.bs_p = bs_p;
         a.bn = bn_src(h, hl);
+        a.mean = hl.mean.p; a.istd = hl.invstd.p;
+        a.dbg = g_tuning.dz_dbg;
         a.bstat = hl.bstat;
         a.drop_scale = dc.scale;
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
@@ -554,9 +606,9 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
             // then the main stream has read the decoder's weights for the last time (nl >= 2).
             q.add([h](hipStream_t st) {
                 const int nb = h->opt16_blocks - h->opt16_bucketA_blk0;
-                hipLaunchKernelGGL(vae_dadapt16_kernel, dim3(nb), dim3(256), 0, st, (const Opt16Tensor*)h->opt16_tab.p, h->opt16_n,
-                                   stat_bs(h), h->P.p, h->M1.p, h->M2.p, h->Sv.p, (const StepState*)h->state.p, h->opt_part.p,
-                                   h->adam_lr, h->opt16_bucketA_blk0);
+                hipLaunchKernelGGL(vae_dadapt16_kernel, dim3(nb), dim3(256), 0, st, (const Opt16Tensor*)h->opt16_tab.p,
+                                   (const uint8_t*)h->opt16_blk2t.p, stat_bs(h), h->P.p, h->M1.p, h->M2.p, h->Sv.p, (const StepState*)h->state.p, h->opt_part.p,
+                                   h->adam_lr, h->opt16_bucketA_blk0, Opt16Tail{});
                 VH_HIP(hipGetLastError());
             });
             h->opt16_decoder_done = true;
@@ -566,7 +618,7 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
             // all-reduce it on the side stream while the encoder's backward still runs on the main stream
             q.add([h](hipStream_t st) {
                 const int nb = h->opt16_blocks - h->opt16_bucketA_blk0;
-                hipLaunchKernelGGL(vae_grad16_kernel, dim3(nb), dim3(256), 0, st, h->opt16_tab.p, h->opt16_n, stat_bs(h), h->G.p,
+                hipLaunchKernelGGL(vae_grad16_kernel, dim3(nb), dim3(256), 0, st, h->opt16_tab.p, (const uint8_t*)h->opt16_blk2t.p, stat_bs(h), h->G.p,
                                    h->opt16_bucketA_blk0, allrank_stats(h));
                 VH_HIP(hipGetLastError());
                 rccl_allreduce_sum_f32(h->comm, h->G.p + h->opt16_bucketA_off, h->flat_elems - h->opt16_bucketA_off, st);
@@ -589,17 +641,31 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         if (li == 0) {
             dw(h->stream);
         } else if (li == nl) {
-            // first decoder layer -> latent: latent-wide output, split-K slabs summed by the latent kernel
-            Gemm16Args g = args16(h);
-            g.A = hl.DZ16.p; g.lda = hl.nout_p;
-            g.B = w16t(h, hl.tW); g.ldb = hl.nout_p;
-            g.M = bs_p; g.N = in_p; g.K = hl.nout_p;
+            // first decoder layer -> latent: latent-wide output; dMU = dZlat + d(KLD)/dmu fused into the same launch when the
+            // operands of 32 rows fit a workgroup's LDS (gemm_skinny16.hpp), else split-K slabs summed by the latent kernel
             const int want = std::max(1, std::min(kSkinnySplits, hl.nout_p / 128));
-            g.k_per_split = (int)round_up(ceil_div(hl.nout_p, want), 64);
-            latent_slabs = (int)ceil_div(hl.nout_p, g.k_per_split);
-            g.C32 = h->skinny.p; g.ldc32 = in_p;
-            g.slab_stride = (int64_t)bs_p * in_p;
-            gemm16<E16_SPLITK>(h->stream, g, latent_slabs);
+            const int k_per_split = (int)round_up(ceil_div(hl.nout_p, want), 64);
+            latent_slabs = (int)ceil_div(hl.nout_p, k_per_split);
+            if (g_tuning.fused_skinny) {
+                Skinny16Args sa;
+                memset(&sa, 0, sizeof(sa));
+                sa.A = hl.DZ16.p; sa.lda = hl.nout_p;
+                sa.B = w16t(h, hl.tW); sa.ldb = hl.nout_p;
+                sa.M = bs_p; sa.K = hl.nout_p; sa.k_per_wave = k_per_split; sa.nslab = latent_slabs;
+                sa.zeros = h->zeros16.p; sa.bs = bs;
+                sa.dMUk = h->dMUk.p; sa.dMU16 = h->dMU16.p;
+                latent_fused = launch_skinny16<SK16_LATENT_BWD>(h->stream, sa, in_p);
+            }
+            if (!latent_fused) {
+                Gemm16Args g = args16(h);
+                g.A = hl.DZ16.p; g.lda = hl.nout_p;
+                g.B = w16t(h, hl.tW); g.ldb = hl.nout_p;
+                g.M = bs_p; g.N = in_p; g.K = hl.nout_p;
+                g.k_per_split = k_per_split;
+                g.C32 = h->skinny.p; g.ldc32 = in_p;
+                g.slab_stride = (int64_t)bs_p * in_p;
+                gemm16<E16_SPLITK>(h->stream, g, latent_slabs);
+            }
         } else {
             grad_input16(h, hl.DZ16.p, hl.nout_p, hl.tW, in_p, h->hidden[li - 1]);
         }
@@ -607,11 +673,13 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
     for (int li = 2 * nl - 1; li >= nl; --li) hidden_bwd(li);
     {   // latent: dMU = dZlat + d(KLD)/dmu; mu layer
         Hidden& enc_last = h->hidden[nl - 1];
-        const int64_t tot = (int64_t)bs_p * h->L_p;
-        hipLaunchKernelGGL(vae_latent_bwd16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, h->stream,
-                           (const float*)h->skinny.p, latent_slabs, (int64_t)bs_p * h->L_p, (const float*)h->dMUk.p,
-                           h->dMU16.p, h->L_p, bs, bs_p);
-        VH_HIP(hipGetLastError());
+        if (!latent_fused) {
+            const int64_t tot = (int64_t)bs_p * h->L_p;
+            hipLaunchKernelGGL(vae_latent_bwd16_kernel, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, h->stream,
+                               (const float*)h->skinny.p, latent_slabs, (int64_t)bs_p * h->L_p, (const float*)h->dMUk.p,
+                               h->dMU16.p, h->L_p, bs, bs_p);
+            VH_HIP(hipGetLastError());
+        }
         q.add([h, bs_p, bs, &enc_last](hipStream_t st) {
             if (g_tuning.dw_row_major) {
                 grad_weight16_rm(h, h->tWmu, h->dMU16.p, h->L_p, enc_last.H16.p, enc_last.nout_p, h->dbias_mu, st);
@@ -630,7 +698,7 @@ void optimizer_step16(vh_vae* h) {
     const Opt16Tensor* tab = h->opt16_tab.p;
     if (h->comm) {
         // bucket B (encoder + mu; bucket A went out on the side stream during the encoder's backward, joined by now)
-        hipLaunchKernelGGL(vae_grad16_kernel, dim3(h->opt16_bucketA_blk0), dim3(256), 0, h->stream, h->opt16_tab.p, h->opt16_n,
+        hipLaunchKernelGGL(vae_grad16_kernel, dim3(h->opt16_bucketA_blk0), dim3(256), 0, h->stream, h->opt16_tab.p, (const uint8_t*)h->opt16_blk2t.p,
                            stat_bs(h), h->G.p, 0, allrank_stats(h));
         VH_HIP(hipGetLastError());
         rccl_allreduce_sum_f32(h->comm, h->G.p, h->opt16_bucketA_off, h->stream);
@@ -639,12 +707,22 @@ void optimizer_step16(vh_vae* h) {
     // (the decoder-side half may already have been updated on the side stream: backward16)
     const int nblk = h->opt16_decoder_done ? h->opt16_bucketA_blk0 : h->opt16_blocks;
     h->opt16_decoder_done = false;
-    hipLaunchKernelGGL(vae_dadapt16_kernel, dim3(nblk), dim3(256), 0, h->stream, tab, h->opt16_n, stat_bs(h), h->P.p,
-                       h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p, h->adam_lr, 0);
+    // the scalar tail (d, k, counters, clearing the accumulators) rides on the last workgroup of the update kernel when ONE launch
+    // covers every tensor of the step (vae.fused_finalize; the split / data-parallel schedules keep the separate launch)
+    Opt16Tail tail{};
+    const bool fuse_tail = g_tuning.fused_finalize && nblk == h->opt16_blocks;
+    if (fuse_tail) {
+        tail.ticket = h->opt_ticket.p; tail.st = h->state.p; tail.statbuf = h->statbuf.p;
+        tail.nstat = h->keep_grads ? 0 : (int)h->statbuf.n; tail.nblocks = h->opt16_blocks; tail.adam = h->adam_lr > 0.f ? 1 : 0;
+    }
+    hipLaunchKernelGGL(vae_dadapt16_kernel, dim3(nblk), dim3(256), 0, h->stream, tab, (const uint8_t*)h->opt16_blk2t.p, stat_bs(h), h->P.p,
+                       h->M1.p, h->M2.p, h->Sv.p, h->state.p, h->opt_part.p, h->adam_lr, 0, tail);
     VH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(vae_dadapt_finalize_kernel, dim3(1), dim3(256), 0, h->stream, h->opt_part.p, h->opt16_blocks,
-                       h->state.p, h->statbuf.p, h->keep_grads ? 0 : (int)h->statbuf.n, h->adam_lr > 0.f ? 1 : 0);
-    VH_HIP(hipGetLastError());
+    if (!fuse_tail) {
+        hipLaunchKernelGGL(vae_dadapt_finalize_kernel, dim3(1), dim3(256), 0, h->stream, h->opt_part.p, h->opt16_blocks,
+                           h->state.p, h->statbuf.p, h->keep_grads ? 0 : (int)h->statbuf.n, h->adam_lr > 0.f ? 1 : 0);
+        VH_HIP(hipGetLastError());
+    }
     h->stat_clean = !h->keep_grads;
 }
 
