@@ -15,8 +15,9 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                     GEMM BASELINE's >= 50 % target names) over the timed steps, against the dtype's MFMA peak
   roofline_hidden : the same for a 512x512 hidden layer (the GEMM shape that dominates the step's time), warm-up steps
   cluster_scan    : algorithmic bytes / kernel time of the scan + select passes (HBM bound), warm-up steps
-  c1, c3_shape    : the WHOLE job (300 epochs + encode + sweep, one timed step each) at configs[1] (200 k x 50, fp32) and at the
-                    C3 shape (2 M x 1000, D = 1104) on this GPU
+  c1, c3_shape    : the WHOLE job (300 epochs + encode + sweep) at configs[1] (200 k x 50, fp32) and at the C3 shape (2 M x 1000,
+                    D = 1104, the shape north_star's 1-GPU target is quoted on) on this GPU, each with the headline's protocol:
+                    one full warm-up job, then --leg-steps (3) timed jobs between two device synchronisations
   cluster_order   : which arithmetic the sweeps ran in (library option scan.reference_order; default = the reference's order)
   cpu_baseline    : the CPU oracle ("port") timed on a bounded sample, with its calibration against the real
                     reference measured in the build container (oracle/cpu_calibration.json)
@@ -85,6 +86,7 @@ def parse():
                         "run; with few epochs the latents are unstructured and the sweep degenerates).  The line is "
                         "marked as such and is not a valid headline")
     p.add_argument("--c3-epochs", type=int, default=300, help="training epochs of the C3-shape whole-job leg")
+    p.add_argument("--leg-steps", type=int, default=3, help="timed whole jobs of the c1 / c3_shape legs (after one full warm-up job each)")
     p.add_argument("--deadline", type=float, default=1650.0,
                    help="seconds from process start the whole run should fit in (the driver allows 1800): only the "
                         "UNTIMED parts adapt to it (later warm-up steps run fewer epochs, the C3 leg may be skipped)")
@@ -234,16 +236,19 @@ def pmc_traffic(tag):
     return None
 
 
-def config_leg(args, name, ve, vc, lib, _lib, synth, epochs):
-    """The WHOLE job at another BASELINE configuration on this GPU, as ONE timed step: VAE.trainmodel (`epochs`, default the
-    CLI's 300) -> encode -> full cluster sweep; then the sweep once more on the same latents with HIP-event timing of every
-    pass (its kernel-time roofline).  "C3": 2 M contigs x 1000 samples (8.8 GB of features), the shape BASELINE's 10x target is
-    quoted on, in the headline's dtype.  "C1": configs[1], 200 k x 50, batch 4096, fp32 MFMA."""
+def config_leg(args, name, ve, vc, lib, _lib, synth, epochs, steps=3, warmup=1, est_job_s=None):
+    """The WHOLE job at another BASELINE configuration on this GPU with the headline's protocol: `warmup` untimed full jobs, then
+    EXACTLY `steps` timed jobs (VAE.trainmodel with `epochs`, default the CLI's 300 -> encode -> full cluster sweep) bracketed by
+    a device synchronisation on both sides; then the sweep once more on the last latents with HIP-event timing of every pass
+    (its kernel-time roofline).  "C3": 2 M contigs x 1000 samples (8.8 GB of features), the shape BASELINE's 10x target is
+    quoted on, in the headline's dtype.  "C1": configs[1], 200 k x 50, batch 4096, fp32 MFMA.  When the run's --deadline cannot
+    hold warmup + steps jobs, fewer are run (never fewer than one timed step) and the object says so."""
     n, S, bs, lat_w, cfg_dtype = CONFIGS[name]
     dtype = cfg_dtype if name == "C1" else args.dtype
     a3 = argparse.Namespace(**vars(args))
     a3.contigs, a3.samples, a3.batch, a3.latent, a3.epochs, a3.no_cluster, a3.dtype = n, S, bs, lat_w, epochs, False, dtype
     ve.set_compute_dtype(dtype)
+    planned = (warmup, steps)
     try:
         t0 = time.perf_counter()
         ab, tnf, lens, _ = synth.features(n, S, seed=3)
@@ -253,17 +258,38 @@ def config_leg(args, name, ve, vc, lib, _lib, synth, epochs):
         t_prep = time.perf_counter() - t0
         prep_on_device = getattr(dl.dataset, "_vambhip_prepared", None) is not None
         del ab, tnf
-        # allocations / kernel attributes of this shape, outside the timed step
+        # allocations / kernel attributes of this shape, outside the timed steps
         run_step(ve, vc, lib, _lib, dl, lens, argparse.Namespace(**dict(vars(a3), no_cluster=True)), seed=1003, epochs=1)
+        if est_job_s is not None:   # fit the plan into what is left of --deadline (untimed parts first)
+            left = args.deadline - (time.perf_counter() - T_START) - 60.0
+            while warmup > 0 and (warmup + steps) * est_job_s > left:
+                warmup -= 1
+            while steps > 1 and (warmup + steps) * est_job_s > left:
+                steps -= 1
+        warm_jobs = []
+        for i in range(warmup):
+            tw = time.perf_counter()
+            run_step(ve, vc, lib, _lib, dl, lens, a3, seed=2003 + i, probe_layer=0, time_scans=False).pop("latent")
+            warm_jobs.append(time.perf_counter() - tw)
+        _lib.check(lib.vh_device_synchronize())
         t0 = time.perf_counter()
-        r = run_step(ve, vc, lib, _lib, dl, lens, a3, seed=3, probe_layer=0, time_scans=False)
-        t_job = time.perf_counter() - t0
+        runs = []
+        for i in range(steps):
+            ts = time.perf_counter()
+            r = run_step(ve, vc, lib, _lib, dl, lens, a3, seed=3 + i, probe_layer=0, time_scans=False)
+            r["job_s"] = time.perf_counter() - ts
+            if i + 1 < steps:
+                r.pop("latent")
+            runs.append(r)
+        _lib.check(lib.vh_device_synchronize())
+        t_all = time.perf_counter() - t0
     finally:
         ve.set_compute_dtype(args.dtype)
+    r = runs[-1]
     latent = r.pop("latent")
-    # the same sweep with per-pass kernel timing (a stream synchronisation per pass: not part of the timed job)
+    # the same sweep with per-pass kernel timing (a stream synchronisation per pass: not part of the timed jobs)
     # (the timed job's generator normalised `latent` in place: destroy=True -- normalising twice is not bit-idempotent)
-    gen = vc.ClusterGenerator(latent.copy(), lens, destroy=True, normalized=True, rng_seed=3)
+    gen = vc.ClusterGenerator(latent.copy(), lens, destroy=True, normalized=True, rng_seed=3 + steps - 1)
     gen._backend.set_timing(True)
     tt = time.perf_counter()
     n_clusters2 = sum(1 for _ in gen)
@@ -279,23 +305,27 @@ def config_leg(args, name, ve, vc, lib, _lib, synth, epochs):
     flops_contig = 12 * HIDDEN * (D + HIDDEN + lat_w) - 2 * D * HIDDEN
     bf16 = dtype == "bf16"
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    t_epoch = r["train_s"] / a3.epochs
-    roof = probe_roofline([r], f"first encoder layer, M={bs}, K=D={D} (padded {(D + 31) // 32 * 32}), N=512, "
-                               f"{'bf16 MFMA' if bf16 else 'fp32 MFMA'}", peak)
+    mean = lambda k: float(np.mean([q[k] for q in runs]))   # noqa: E731
+    t_epoch = mean("train_s") / a3.epochs
+    roof = probe_roofline(runs, f"first encoder layer, M={bs}, K=D={D} (padded {(D + 31) // 32 * 32}), N=512, "
+                                f"{'bf16 MFMA' if bf16 else 'fp32 MFMA'}", peak)
     return {"workload": f"{name} on one GPU: {n} contigs x {S} samples (D={D}), batch {bs}, {'bf16' if bf16 else 'f32'}; whole job = "
-                        f"{a3.epochs} train epochs + encode + full cluster sweep, ONE timed step",
+                        f"{a3.epochs} train epochs + encode + full cluster sweep; {len(warm_jobs)} untimed warm-up job(s), then "
+                        f"{steps} timed jobs between two device synchronisations",
             "dtype": "bf16" if bf16 else "f32",
-            "value": n / t_job, "unit": "contigs/s", "job_s": t_job,
-            "train_s": r["train_s"], "encode_s": r["encode_s"], "cluster_s": r["cluster_s"], "setup_s": r["setup_s"],
-            "clusters": r["clusters"], "clusters_second_sweep": n_clusters2, "final_loss": r["loss"],
+            "value": n * steps / t_all, "unit": "contigs/s", "steps": steps, "warmup": len(warm_jobs),
+            "planned_warmup_steps": list(planned), "ms_per_step": t_all / steps * 1e3,
+            "job_s": t_all / steps, "job_s_each": [q["job_s"] for q in runs], "warmup_job_s": warm_jobs,
+            "train_s": mean("train_s"), "encode_s": mean("encode_s"), "cluster_s": mean("cluster_s"), "setup_s": mean("setup_s"),
+            "clusters": [q["clusters"] for q in runs], "clusters_second_sweep": n_clusters2, "final_loss": r["loss"],
             "epoch_ms": t_epoch * 1e3, "us_per_step": t_epoch / (n // bs) * 1e6,
             "train_contigs_per_s_per_epoch": n / t_epoch, "train_tflops_algorithmic": flops_contig * n / t_epoch / 1e12,
             "synthetic_input_s": t_synth, "make_dataloader_s": t_prep,
             "make_dataloader_on": "device (csrc/prep.hip: one upload of the raw matrices + normalisation kernels, "
                                   "PCIe-inclusive)" if prep_on_device else "host (numpy)",
             "roofline_encoder_gemm": roof,
-            "cluster_scan": scan_summary([timed], [r], "kernel time: a second, event-timed sweep over the same latents; "
-                                                          "wall time: the sweep of the timed job")}
+            "cluster_scan": scan_summary([timed], runs, "kernel time: one more, event-timed sweep over the last job's latents; "
+                                                          "wall time: the sweeps of the timed jobs")}
 
 
 def taxvamb_leg(ve, synth, n=200_000, S=50, n_nodes=1000, batch=256, epochs=3):
@@ -332,9 +362,9 @@ def taxvamb_leg(ve, synth, n=200_000, S=50, n_nodes=1000, batch=256, epochs=3):
             "latent_finite": bool(np.isfinite(latent).all())}
 
 
-def _cpu_sample(args, n, latent, lens, threads, co, vo, ve, synth, cpu_epochs=3):
-    """The oracle port on the first n contigs of the workload: seconds per training epoch, for the encode pass and for the
-    full cluster sweep of the first n GPU latents."""
+def _cpu_sample(args, n, latent, lens, threads, co, vo, ve, synth, cpu_epochs=3, with_cluster=True):
+    """The oracle port on the first n contigs of the workload: seconds per training epoch, for the encode pass and (with_cluster)
+    for the full cluster sweep of the first n GPU latents.  The caller has limited the BLAS pool to `threads`."""
     ab, tnf, ln, _ = synth.features(n, args.samples, seed=101)
     ve.set_prep_mode("host")     # the CPU baseline never touches the GPU
     dl = ve.make_dataloader(ab, tnf, ln, batchsize=args.batch, destroy=True)
@@ -360,39 +390,66 @@ def _cpu_sample(args, n, latent, lens, threads, co, vo, ve, synth, cpu_epochs=3)
     t0 = time.perf_counter()
     m.encode(d, t, a)
     t_enc = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    nclu = sum(1 for _ in co.OracleClusterGenerator(np.ascontiguousarray(latent[:n]), lens[:n], rng_seed=1))
-    t_clu = time.perf_counter() - t0
-    return dict(contigs=n, batch=bs, epoch_s=t_epoch, encode_s=t_enc, cluster_s=t_clu, clusters=nclu,
-                job_s=args.epochs * t_epoch + t_enc + t_clu, epochs_timed=cpu_epochs)
+    t_clu, nclu = None, None
+    if with_cluster:
+        t0 = time.perf_counter()
+        nclu = sum(1 for _ in co.OracleClusterGenerator(np.ascontiguousarray(latent[:n]), lens[:n], rng_seed=1))
+        t_clu = time.perf_counter() - t0
+    return dict(contigs=n, batch=bs, threads=int(threads), epoch_s=t_epoch, encode_s=t_enc, cluster_s=t_clu, clusters=nclu,
+                job_s=None if t_clu is None else args.epochs * t_epoch + t_enc + t_clu, epochs_timed=cpu_epochs)
 
 
 def cpu_baseline(args, latent, lens):
-    """The oracle (numpy VAE restatement + C cluster restatement) on TWO bounded samples of the workload, with the
-    reference's default thread count (min(cores, 8), vamb/__main__.py:27-28).  Training and encoding cost is linear in the
+    """The oracle (numpy VAE restatement + C cluster restatement) on THREE bounded samples of the workload (n, n / 3, n / 9
+    contigs) with the reference's default thread count (min(cores, 8), vamb/__main__.py:27-28), and the largest sample's training
+    and encode once more with ALL visible cores (SURVEY.md 8d asks for both; the cluster restatement is scalar code, one
+    thread, as the reference's sweep is one torch thread pool over a [n] vector).  Training and encoding cost is linear in the
     number of contigs; the cluster sweep is not (every cluster costs passes over all remaining contigs), so its exponent is
-    read off the two samples and the extrapolation to the full workload is stated explicitly.  `value` is the measured
-    throughput of the LARGER sample (no extrapolation)."""
+    fitted through the three samples and the extrapolation to the full workload is stated explicitly.  `value` is the measured
+    throughput of the LARGEST sample at the reference's default thread count (no extrapolation)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cluster_oracle as co
     import vae_oracle as vo
     from vamb_amd import encode as ve, synth
 
     cores = os.cpu_count() or 1
-    threads = min(8, cores)
+    try:
+        cores_avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores_avail = cores
+    threads = min(8, cores_avail)
     try:
         from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=threads)
     except Exception:
-        limiter = None
+        threadpool_limits = None
+
+    def limited(nthreads, fn):
+        if threadpool_limits is None:
+            return fn()
+        with threadpool_limits(limits=nthreads):
+            return fn()
+
     n_big = min(args.cpu_sample, args.contigs, len(latent))
-    n_small = max(1000, n_big // 3)
-    small = _cpu_sample(args, n_small, latent, lens, threads, co, vo, ve, synth)
-    big = _cpu_sample(args, n_big, latent, lens, threads, co, vo, ve, synth)
-    if limiter is not None:
-        limiter.restore_original_limits()
-    # cluster sweep: t = c n^p through the two samples; training / encoding: linear through the larger sample
-    p_clu = float(np.log(big["cluster_s"] / small["cluster_s"]) / np.log(n_big / n_small)) if n_big > n_small else 1.0
+    sizes = sorted({max(1000, n_big // 9), max(1000, n_big // 3), n_big})
+    samples = [limited(threads, lambda n=n: _cpu_sample(args, n, latent, lens, threads, co, vo, ve, synth)) for n in sizes]
+    big = samples[-1]
+    # the largest sample's BLAS-bound stages with every visible core (the sweep term is the one measured above)
+    all_cores = None
+    if cores_avail > threads:
+        ac = limited(cores_avail, lambda: _cpu_sample(args, n_big, latent, lens, cores_avail, co, vo, ve, synth, cpu_epochs=2,
+                                                      with_cluster=False))
+        ac["cluster_s"], ac["clusters"] = big["cluster_s"], big["clusters"]
+        ac["job_s"] = args.epochs * ac["epoch_s"] + ac["encode_s"] + ac["cluster_s"]
+        ac["value"] = n_big / ac["job_s"]
+        ac["note"] = (f"training / encode of the {n_big}-contig sample with a BLAS pool of {cores_avail} threads (numpy fp32 GEMMs of "
+                      f"{big['batch']} x 512: more threads than the reference's default do not pay at this size); the sweep term is the "
+                      "single-threaded one of the 8-thread run")
+        all_cores = ac
+    # cluster sweep: t = c n^p, least squares through the samples; training / encoding: linear through the largest sample
+    if len(samples) > 1:
+        p_clu = float(np.polyfit(np.log([q["contigs"] for q in samples]), np.log([q["cluster_s"] for q in samples]), 1)[0])
+    else:
+        p_clu = 1.0
     scale = args.contigs / n_big
     full = dict(contigs=args.contigs, train_s=args.epochs * big["epoch_s"] * scale, encode_s=big["encode_s"] * scale,
                 cluster_s=big["cluster_s"] * scale ** p_clu)
@@ -404,7 +461,9 @@ def cpu_baseline(args, latent, lens):
             c = json.load(fh)
         calib = {"reference_over_port": c["reference_over_port"], "measured_on": f"{c['cpu']}, {c['threads']} threads",
                  "sample": c["sample"],
-                 "note": "the real reference (vamb/{encode,cluster}.py, torch CPU) and this port timed on the same sample "
+                 "points": [{"contigs": q.get("contigs"), "reference_over_port": q["reference_over_port"]} for q in c.get("points", [])],
+                 "cluster_time_exponent_on_that_machine": c.get("cluster_time_exponent"),
+                 "note": "the real reference (vamb/{encode,cluster}.py, torch CPU) and this port timed on the same samples "
                          "in the build container (oracle/calibrate_cpu_baseline.py: a DIFFERENT machine from the one this "
                          "line was measured on); > 1 means the reference is slower"}
     except (OSError, ValueError, KeyError):
@@ -420,13 +479,15 @@ def cpu_baseline(args, latent, lens):
                 sample=(f"{n_big} contigs x {args.samples} samples, batch {big['batch']}: {big['epochs_timed']} oracle epochs timed "
                         f"({big['epoch_s']:.3f} s/epoch, numpy fp32 BLAS, {threads} threads) extrapolated to {args.epochs}, + encode "
                         f"{big['encode_s']:.3f} s + full cluster sweep of the first {n_big} GPU latents {big['cluster_s']:.3f} s "
-                        f"({big['clusters']} clusters, scalar C, 1 thread); second sample of {n_small} contigs beside it"),
+                        f"({big['clusters']} clusters, scalar C, 1 thread); samples of {', '.join(str(q['contigs']) for q in samples[:-1])} "
+                        f"contigs beside it; the BLAS-bound stages again with all {cores_avail} visible cores (all_cores)"),
                 epoch_s=big["epoch_s"], encode_s=big["encode_s"], cluster_s=big["cluster_s"],
-                samples=[small, big], cluster_time_exponent=p_clu,
-                host={"cpu": cpu_model, "cores_visible": int(cores), "threads_used": int(threads)},
+                samples=samples, cluster_time_exponent=p_clu, all_cores=all_cores,
+                host={"cpu": cpu_model, "cores_visible": int(cores_avail), "cores_online": int(cores), "threads_used": int(threads)},
                 extrapolated_to_workload={**full, "how": f"training and encode linear in contigs from the {n_big}-contig sample; cluster "
-                                          f"sweep t = c n^p with p = {p_clu:.2f} from the two samples (a sweep is super-linear: every "
-                                          "cluster costs passes over all remaining contigs); an estimate, not a measurement"},
+                                          f"sweep t = c n^p with p = {p_clu:.2f} fitted through the {len(samples)} samples (a sweep is "
+                                          "super-linear: every cluster costs passes over all remaining contigs); an estimate, not a "
+                                          "measurement"},
                 calibration_vs_reference=calib, reference_estimate_contigs_per_s=ref_est)
 
 
@@ -687,14 +748,18 @@ def main():
                     line["c1"] = {"skipped": "not enough of --deadline left for the extra leg"}
                 else:
                     try:
-                        line["c1"] = config_leg(args, "C1", ve, vc, lib, _lib, synth, args.c3_epochs)
+                        line["c1"] = config_leg(args, "C1", ve, vc, lib, _lib, synth, args.c3_epochs, steps=args.leg_steps, warmup=1,
+                                                est_job_s=8.0)
                     except Exception as e:   # never lose the headline because of an extra leg
                         line["c1"] = {"error": repr(e)}
-            if args.deadline - (time.perf_counter() - T_START) < 330.0:   # synthetic input 35 s + job ~60 s + timed sweep ~30 s + margin
+            # synthetic input ~35 s + upload + (warm-up + timed) jobs of ~1.1 x the headline's step + event-timed sweep ~30 s + margin
+            est_c3 = 1.1 * elapsed / K * (args.c3_epochs / max(1, args.epochs)) if not args.no_cluster else 40.0
+            if args.deadline - (time.perf_counter() - T_START) < 150.0 + est_c3:
                 line["c3_shape"] = {"skipped": "not enough of --deadline left for the extra leg"}
             else:
                 try:
-                    line["c3_shape"] = config_leg(args, "C3", ve, vc, lib, _lib, synth, args.c3_epochs)
+                    line["c3_shape"] = config_leg(args, "C3", ve, vc, lib, _lib, synth, args.c3_epochs, steps=args.leg_steps, warmup=1,
+                                                  est_job_s=est_c3 + 10.0)
                 except Exception as e:
                     line["c3_shape"] = {"error": repr(e)}
         emit_result(line)

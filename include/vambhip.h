@@ -200,13 +200,6 @@ int vh_gen_next(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t cap)
  * infos[i] describes cluster i, its members follow those of cluster i - 1 in `members` (a buffer of the generator's row count
  * always holds whatever is left).  *n_out < max_clusters: exhausted. */
 int vh_gen_next_batch(vh_gen* g, int max_clusters, vh_cluster_info* infos, int64_t* members, int64_t cap, int* n_out);
-/* test hook (host only): find_threshold (cluster.py:452-543) on exact histogram accumulators; kind 0 loner,
- * 1 no threshold, 2 threshold (then *threshold and *observed_pvr are set) */
-int vh_debug_find_threshold(const int64_t* hist_fx, int64_t n_lt, double pvr, int* kind, double* threshold,
-                            double* observed_pvr);
-/* test hook (host only): n_calls consecutive random.Random(seed).sample(range(ns[i]), ks[i]) on one generator,
- * results concatenated into out (sum of ks entries) */
-int vh_debug_pyrandom_sample(uint64_t seed, int n_calls, const int64_t* ns, const int64_t* ks, int64_t* out);
 /* the generator's mutable search state AFTER the last vh_gen_next (ClusterGenerator.peak_valley_ratio / successes /
  * len(attempts) / order_index, cluster.py:282-283, 386-413): what repr() and callers inspecting the attributes see */
 int vh_gen_state(vh_gen* g, double* peak_valley_ratio, int64_t* successes, int64_t* attempts, int64_t* order_index);
@@ -476,38 +469,9 @@ int vh_vae_attach_comm(vh_vae* h, vh_comm* comm);
 int vh_vae_train_epoch_dp(vh_vae* h, const int64_t* perm, int64_t n_batches, int64_t batch, int64_t global_batch,
                           const float* global_wsum, double loss_means[5]);
 
-/* Diagnostic: run one GEMM instantiation on host data.  C[M][N] = sum_k A(m,k) B(n,k) (+bias[n] if
- * bias != NULL).  a_kc / b_kc: operand stored [rows][K] (1) or [K][rows] (0).  tile: 0 = 64x128,
- * 1 = 128x128, 2 = 128x32.  splits > 1 exercises the split-K slabs (summed on the host side of the call). */
-int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, const float* bias, float* C,
-                  int M, int N, int K, int splits, float* ms);
 
-/* Diagnostic: one launch configuration of the bf16-storage GEMM (gemm_bf16.hpp: bf16 operands in memory, LDS-DMA
- * staging, bf16 MFMA with fp32 accumulation) on host data.  A [M][K] and B [N][K] are rounded to bf16 (nearest even) on
- * the host; C[m][n] = sum_k A[m][k] B[n][k].  epi: 0 = split-K fp32 slabs (summed on return), 1 = fp32 + bias,
- * 3 = hidden-layer epilogue without dropout: C = bf16(leaky_relu(acc + bias)) as float, CT (optional) the transposed
- * bf16 copy [N][M] as float, stats (optional) [2][N] the fp64 batch sums of C and C^2.  The tile is chosen from the
- * output shape as in the training step (variant 0) or forced (variant 1..6: the tile / pipeline variants listed in
- * csrc/vae_step16.hpp; + 256 * flags switches parts of the epilogue off for timing experiments, results then wrong).
- * *ms = average duration of `reps` back-to-back launches. */
-int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, float* C, float* CT, double* stats, int M,
-                    int N, int K, int splits, int reps, int variant, float* ms);
 
-/* Diagnostic: the row-major weight-gradient GEMM (gemm_bf16_tn.hpp; reference shape: dW = dZ^T In of a Linear layer's
- * backward, vamb/encode.py:226-249,419) on host data.  A [K][M] and B [K][N] are rounded to bf16 on the host;
- * C[m][n] = sum_k A[k][m] B[k][n] (split-K slabs summed on return); colsum (optional) [M] = sum over k < k_real of the
- * rounded A[k][m] (the fused bias gradient).  tile: 0 = by output shape as in the training step, 1 = 128x128 / 8 waves,
- * 3 = 64x128 / 4 waves; pipeline: 0 = two LDS buffers, 2 = three buffers with interleaved DMA issue.
- * *ms = average duration of `reps` back-to-back launches. */
-int vh_debug_gemm16_tn(const float* A, const float* B, float* C, double* colsum, int M, int N, int K, int k_real, int splits,
-                       int reps, int tile, int pipeline, float* ms);
 
-/* Diagnostic: one launch of the bf16-storage GEMM on device-generated data with in-kernel time stamps (s_memtime ticks,
- * 100 MHz constant clock or shader clock -- compare differences only).  stamps[b][0..4] of workgroup b = kernel entry,
- * first K-tile landed, K loop done, epilogue phase 1 done (image in LDS), stores issued.  epi / variant as vh_debug_gemm16
- * (variant < 256).  Returns the number of workgroups in *n_blocks (<= cap_blocks rows are written). */
-int vh_debug_gemm16_timeline(int epi, int M, int N, int K, int variant, unsigned long long* stamps, int cap_blocks,
-                             int* n_blocks, float* ms);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,11 @@ vamb/{encode,cluster}.py with torch on the CPU, `cuda=False`) and the port on th
 the same thread count and writes the ratio to oracle/cpu_calibration.json.  bench.py reports it as
 `cpu_baseline.calibration_vs_reference` (reference time / port time, per stage and for the whole job).
 
-    python oracle/calibrate_cpu_baseline.py [--contigs 20000] [--samples 200] [--batch 8192] [--threads 8]
+    python oracle/calibrate_cpu_baseline.py [--contigs 20000,7000] [--samples 200] [--batch 8192] [--threads 8]
+
+Several sample sizes (round 5): the top-level fields of the JSON describe the FIRST size; `points` holds every size, and
+`cluster_time_exponent` the exponent p of t = c n^p fitted through the sizes for the reference's sweep and for the port's
+(the sweep is the one stage whose cost is not linear in the number of contigs).
 """
 from __future__ import annotations
 
@@ -28,7 +32,7 @@ sys.path.insert(0, HERE)
 
 def main():
     p = argparse.ArgumentParser()
-    p.add_argument("--contigs", type=int, default=20000)
+    p.add_argument("--contigs", type=str, default="20000,7000", help="comma-separated sample sizes (the first one is the headline)")
     p.add_argument("--samples", type=int, default=200)
     p.add_argument("--batch", type=int, default=8192)
     p.add_argument("--latent", type=int, default=32)
@@ -46,7 +50,22 @@ def main():
     from vamb_amd import synth
 
     vt, rc, re_ = ref_harness.load_reference()
-    n, S, bs = args.contigs, args.samples, min(args.batch, args.contigs)
+    sizes = [int(x) for x in args.contigs.split(",")]
+    points = [calibrate_one(args, n, torch, co, ref_harness, vo, synth, rc, re_) for n in sizes]
+    out = dict(points[0])
+    out["points"] = points
+    if len(points) > 1:
+        ln = np.log([float(q["contigs"]) for q in points])
+        out["cluster_time_exponent"] = {
+            k: float(np.polyfit(ln, np.log([q[k]["cluster_s"] for q in points]), 1)[0]) for k in ("reference", "port")}
+        out["cluster_time_exponent"]["sizes"] = sizes
+    with open(os.path.join(HERE, "cpu_calibration.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+def calibrate_one(args, n, torch, co, ref_harness, vo, synth, rc, re_):
+    S, bs = args.samples, min(args.batch, n)
     ab, tnf, lens, _ = synth.features(n, S, seed=101)
 
     # ---- the reference itself: make_dataloader -> VAE.trainmodel -> encode -> list(ClusterGenerator)
@@ -95,7 +114,8 @@ def main():
     E = 300
     ref_total = E * ref_epoch + ref_encode + ref_cluster
     port_total = E * port_epoch + port_encode + port_cluster
-    out = dict(
+    return dict(
+        contigs=n,
         sample=f"{n} contigs x {S} samples, batch {bs}, latent {args.latent}, {args.epochs} epochs timed, {ref_clusters} clusters "
                f"(blob latents sigma 0.08)",
         threads=args.threads, cpu=open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t"),
@@ -106,9 +126,6 @@ def main():
         reference_over_port=dict(epoch=ref_epoch / port_epoch, encode=ref_encode / port_encode,
                                  cluster=ref_cluster / port_cluster, job_300_epochs=ref_total / port_total),
     )
-    with open(os.path.join(HERE, "cpu_calibration.json"), "w") as fh:
-        json.dump(out, fh, indent=1)
-    print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":

@@ -250,6 +250,14 @@ VAEVAE_CASES = {
     # 131 nodes (> 105: the label block is as wide as the taxonomy), ragged widths, a chain, single-child nodes
     "vaevae_tree_wide": dict(n=148, batch=37, nsamples=5, tree="random_131", nhiddens=[33, 17], nlatent=5, dropout=0.1,
                              alpha=0.3, beta=50.0, seed=42, steps=4, lrate=1e-2, perm_seed=3),
+    # the two halves of the 10-tensor loader DIFFER: dataloader_joint is made from the first 60 contigs only, so its
+    # rows, its normalisation and its order (permute_indices pads it with a second permutation) are not those of dataloader_vamb /
+    # dataloader_labels.  VAEVAE.trainepoch binds the halves BY POSITION (semisupervised_encode.py:864-875): tensors[0:5] -- the
+    # vamb loader's features + the labels loader's labels -- are its `*_sup` batch (VAEJoint, calc_loss_joint, the `_sup_s` passes),
+    # tensors[5:10] -- the joint loader -- its `*_unsup` batch (VAEVamb.calc_loss, VAELabels.calc_loss); only a case like this
+    # one can tell that binding from the opposite one.
+    "vaevae_tree_split": dict(n=96, batch=32, nsamples=6, tree="three_by_three", nhiddens=[48, 40], nlatent=8, dropout=0.2,
+                              alpha=None, beta=200.0, seed=43, steps=3, lrate=1e-3, perm_seed=5, joint_rows=60),
 }
 VAEVAE_PASSES = ("joint", "vamb_x", "labels_x", "vamb_u", "vamb_s", "labels_u", "labels_s")   # order of the reference's step
 

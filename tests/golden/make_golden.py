@@ -264,7 +264,8 @@ def gen_vaevae(en):
         NL = max(N, 105)
         node_names = [f"n{i}" for i in range(N)]
         dl_v = en.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=B)
-        dl_j = tx.make_dataloader_concat_hloss(ab.copy(), tnf.copy(), lens, nodes, N, parents, batchsize=B)
+        jr = c.get("joint_rows", c["n"])   # < n: the joint loader holds other rows than the vamb / labels loaders
+        dl_j = tx.make_dataloader_concat_hloss(ab[:jr].copy(), tnf[:jr].copy(), lens[:jr], nodes[:jr], N, parents, batchsize=B)
         dl_l = tx.make_dataloader_labels_hloss(ab.copy(), tnf.copy(), lens, nodes, N, parents, batchsize=B)
         dl = tx.make_dataloader_semisupervised_hloss(dl_j, dl_v, dl_l, N, parents, (S, 103, 1, N), c["perm_seed"], batchsize=B)
         assert len(dl) == c["steps"], (len(dl), c["steps"])
@@ -357,6 +358,9 @@ def gen_vaevae(en):
         rec["latent_vamb"] = vae.VAEVamb.encode(dl_v)
         rec["joint_depths"], rec["joint_tnf"], rec["joint_abundance"], rec["joint_weights"], rec["joint_nodes"] = (
             t.numpy().copy() for t in dl_j.dataset.tensors)
+        if jr != c["n"]:   # the rows latent_vamb was encoded from (otherwise they are the joint loader's)
+            rec["vamb_depths"], rec["vamb_tnf"], rec["vamb_abundance"], rec["vamb_weights"] = (
+                t.numpy().copy() for t in dl_v.dataset.tensors)
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
         out[name] = dict(loss0=steps_rec[0][-1], loss_last=steps_rec[-1][-1], n_leaves=int(vae.VAELabels.nlabels))
         print("vaevae", name, out[name])

@@ -1,5 +1,6 @@
-"""The C-ABI library loads without a GPU and exports every symbol include/vambhip.h declares;
-the ctypes table in vamb_amd/_lib.py lists exactly the same names.  No compute calls here."""
+"""The C-ABI library loads without a GPU and exports every symbol include/*.h declares (vambhip.h: the drop-in boundary;
+vambhip_debug.h: test hooks and kernel diagnostics, kept out of it); the ctypes table in vamb_amd/_lib.py lists exactly the
+same names.  No compute calls here."""
 import os
 import re
 import subprocess
@@ -21,10 +22,21 @@ def built_lib():
     return _lib.load()
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "vambhip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(vh_[a-z_0-9]+)\s*\(", text)))
+HEADERS = ("vambhip.h", "vambhip_debug.h")
+
+
+def header_symbols(names=HEADERS):
+    found = set()
+    for name in names:
+        text = open(os.path.join(ROOT, "include", name)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        found |= set(re.findall(r"\b(vh_[a-z_0-9]+)\s*\(", text))
+    return sorted(found)
+
+
+def test_debug_hooks_are_not_in_the_public_header():
+    assert not [n for n in header_symbols(("vambhip.h",)) if n.startswith("vh_debug")]
+    assert all(n.startswith("vh_debug") for n in header_symbols(("vambhip_debug.h",)))
 
 
 def test_header_matches_ctypes_table(built_lib):
@@ -87,12 +99,13 @@ def test_header_is_plain_c(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    header = open(os.path.join(root, "include", "vambhip.h")).read()
+    header = "".join(open(os.path.join(root, "include", h)).read() for h in HEADERS)
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     names = sorted(set(re.findall(r"\b(vh_[a-z0-9_]+)\s*\(", header)))
     assert len(names) >= 40
     src = tmp_path / "use_all.c"
     body = "\n".join(f"    p[{i}] = (fn)&{n};" for i, n in enumerate(names))
-    src.write_text('#include "vambhip.h"\ntypedef void (*fn)(void);\nint main(void) {\n    fn p[%d];\n%s\n'
+    src.write_text('#include "vambhip.h"\n#include "vambhip_debug.h"\ntypedef void (*fn)(void);\nint main(void) {\n    fn p[%d];\n%s\n'
                    '    return p[0] == p[1];\n}\n' % (len(names), body))
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
                            "-I", os.path.join(root, "include"), str(src)])

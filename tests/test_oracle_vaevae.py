@@ -36,6 +36,17 @@ def batch_of(g, which, lo, hi):
                  weights=g[which + "_weights"][lo:hi]), g[which + "_nodes"][lo:hi])
 
 
+def step_batches(g, lo, hi):
+    """(unsup, unsup_nodes, sup, sup_nodes) of rows [lo, hi) as VAEVAE.trainepoch binds them: BY POSITION
+    (semisupervised_encode.py:864-875).  The first five tensors of the loader -- dataloader_vamb's features + dataloader_labels'
+    labels, which make_dataloader_semisupervised_hloss (and therefore the fixtures' keys) call "unsup" -- are trainepoch's `*_sup`
+    batch; the last five -- dataloader_joint, "sup" in the fixtures -- its `*_unsup` batch.  The fixture vaevae_tree_split, whose
+    halves differ, is what tells this binding from the opposite one."""
+    su, su_nodes = batch_of(g, "unsup", lo, hi)
+    un, un_nodes = batch_of(g, "sup", lo, hi)
+    return un, un_nodes, su, su_nodes
+
+
 def test_leaf_masks_of_the_reference_test_taxonomy():
     """root -> domain -> 3 phyla -> 3 classes each (test/test_semisupervised_encode.py:22-30): 9 leaves; the root and the domain
     cover all of them, a phylum its three classes, a class itself."""
@@ -67,8 +78,7 @@ def test_oracle_matches_reference(name):
     assert m.n_leaves == int(np.sum(~np.isin(np.arange(len(g["parents"])), g["parents"])))
     gmax = {}   # largest gradient magnitude every element saw over the steps
     for step in range(c["steps"]):
-        un, un_nodes = batch_of(g, "unsup", step * B, (step + 1) * B)
-        su, su_nodes = batch_of(g, "sup", step * B, (step + 1) * B)
+        un, un_nodes, su, su_nodes = step_batches(g, step * B, (step + 1) * B)
         if step == 0:
             # gradients of step 0: run the step on a copy so that the real one below still starts from the initial weights
             probe = make_oracle(name, g)

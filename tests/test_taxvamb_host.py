@@ -130,3 +130,50 @@ def test_loaders_yield_the_reference_tensors_and_batches():
     assert np.array_equal(vt.permute_indices(10, 25, 1), tx.permute_indices(10, 25, 1))
     with pytest.raises(ValueError):
         vt.make_dataloader_labels_hloss(ab, tnf[:-1], lens, nodes, N, parents)
+
+
+def test_labels_loader_validates_and_destroys_like_the_reference():
+    """taxvamb_encode.make_dataloader_labels_hloss builds the FEATURE dataset first (`_make_dataset`) and throws it
+    away, so the labels-only loader inherits make_dataloader's validation (dtypes, shapes, zero rows, batch size against the
+    dataset) and, with destroy=True, normalises the caller's arrays in place.  Same inputs through both."""
+    tx = ref_harness.load_reference_module("taxvamb_encode")
+    name = "vaevae_tree_drop"
+    c = fd.VAEVAE_CASES[name]
+    ab, tnf, lens, nodes, parents = fd.vaevae_inputs(name)
+    N, B = len(parents), c["batch"]
+    bad_inputs = [
+        (ab.astype(np.float64), tnf, lens),                       # abundance not float32
+        (ab, tnf.astype(np.float64), lens),                       # TNF not float32
+        (ab, tnf[:, :50], lens),                                  # TNF of the wrong width
+        (ab[:, :0], tnf, lens),                                   # no samples
+    ]
+    zero = ab.copy()
+    zero[:, 1] = 0.0                                              # a sample nobody has any depth in
+    bad_inputs.append((zero, tnf, lens))
+    verdicts = []
+    for a, t, ln in bad_inputs:
+        outcome = []
+        for fn in (tx.make_dataloader_labels_hloss, vt.make_dataloader_labels_hloss):
+            try:
+                fn(a.copy(), t.copy(), ln, nodes, N, parents, batchsize=B)
+                outcome.append(None)
+            except Exception as e:   # noqa: BLE001 -- the point is that both sides fail (or not) with the same exception type
+                outcome.append(type(e))
+        assert outcome[0] is outcome[1], outcome
+        verdicts.append(outcome[0])
+    assert verdicts[0] is ValueError and verdicts[1] is ValueError and verdicts[-1] is ValueError   # dtypes, the empty sample
+    for fn in (tx.make_dataloader_labels_hloss, vt.make_dataloader_labels_hloss):
+        with pytest.raises(ValueError):
+            fn(ab.copy(), tnf.copy(), lens, nodes, N, parents, batchsize=0)
+    # destroy=True: both normalise the caller's arrays in place, to the same values
+    a_ref, t_ref = ab.copy(), tnf.copy()
+    a_mine, t_mine = ab.copy(), tnf.copy()
+    r = tx.make_dataloader_labels_hloss(a_ref, t_ref, lens, nodes, N, parents, batchsize=B, destroy=True)
+    m = vt.make_dataloader_labels_hloss(a_mine, t_mine, lens, nodes, N, parents, batchsize=B, destroy=True)
+    assert not np.array_equal(a_ref, ab) and not np.array_equal(t_ref, tnf)
+    assert np.array_equal(a_ref, a_mine) and np.array_equal(t_ref, t_mine)
+    assert torch.equal(r.dataset.tensors[0], m.dataset.tensors[0]) and r.batch_size == m.batch_size and r.drop_last == m.drop_last
+    # destroy=False leaves them alone
+    a2, t2 = ab.copy(), tnf.copy()
+    vt.make_dataloader_labels_hloss(a2, t2, lens, nodes, N, parents, batchsize=B)
+    assert np.array_equal(a2, ab) and np.array_equal(t2, tnf)

@@ -66,8 +66,7 @@ def test_joint_training_steps_match_reference_and_oracle(name):
         rows = np.arange(step * B, (step + 1) * B)
         eps, masks = randomness_of(c, rnd[step])
         got = vae.train_batch(rows, eps=eps, masks=masks)
-        un, un_nodes = tov.batch_of(g, "unsup", step * B, (step + 1) * B)
-        su, su_nodes = tov.batch_of(g, "sup", step * B, (step + 1) * B)
+        un, un_nodes, su, su_nodes = tov.step_batches(g, step * B, (step + 1) * B)
         want = oracle.train_step(un, un_nodes, su, su_nodes, rnd[step], lr=c["lrate"])
         ref = g["losses"][step]
         for i, key in enumerate(vv.METRICS):
@@ -102,9 +101,10 @@ def test_joint_training_steps_match_reference_and_oracle(name):
     dsj = torch.utils.data.TensorDataset(*(torch.from_numpy(g["joint_" + k]) for k in ("depths", "tnf", "abundance", "weights", "nodes")))
     dlj = torch.utils.data.DataLoader(dsj, batch_size=B, shuffle=True, drop_last=True, collate_fn=partial(vt.collate_fn_concat_hloss, N, parents))
     lat = vae.VAEJoint.encode(dlj)
-    assert lat.dtype == np.float32 and lat.shape == (c["n"], c["nlatent"]) and (lat.view(np.uint32) & 0xFFF == 0).all()
+    assert lat.dtype == np.float32 and lat.shape == (c.get("joint_rows", c["n"]), c["nlatent"]) and (lat.view(np.uint32) & 0xFFF == 0).all()
     assert np.abs(lat - g["latent_joint"]).max() <= np.abs(g["latent_joint"]).max() * 2.0 ** -9
-    dsv = torch.utils.data.TensorDataset(*(torch.from_numpy(g["joint_" + k]) for k in ("depths", "tnf", "abundance", "weights")))
+    vsrc = "vamb_" if "vamb_depths" in g else "joint_"   # (a fixture whose joint loader holds other rows records the vamb loader's)
+    dsv = torch.utils.data.TensorDataset(*(torch.from_numpy(g[vsrc + k]) for k in ("depths", "tnf", "abundance", "weights")))
     latv = vae.VAEVamb.encode(torch.utils.data.DataLoader(dsv, batch_size=B, shuffle=True, drop_last=True))
     assert np.abs(latv - g["latent_vamb"]).max() <= np.abs(g["latent_vamb"]).max() * 2.0 ** -9
 
@@ -133,8 +133,7 @@ def test_one_hot_joint_trainer_matches_the_oracle():
     for step in range(c["steps"]):
         eps, masks = randomness_of(c, rnd[step])
         got = vae.train_batch(np.arange(step * B, (step + 1) * B), eps=eps, masks=masks)
-        un, un_nodes = tov.batch_of(g, "unsup", step * B, (step + 1) * B)
-        su, su_nodes = tov.batch_of(g, "sup", step * B, (step + 1) * B)
+        un, un_nodes, su, su_nodes = tov.step_batches(g, step * B, (step + 1) * B)
         want = oracle.train_step(un, un_nodes, su, su_nodes, rnd[step], lr=c["lrate"])
         for i, key in enumerate(vv.METRICS):
             if key.startswith("correct"):
@@ -198,9 +197,10 @@ def test_unusual_shapes_match_the_oracle(case):
             w = dec if p.endswith("_x") else enc + dec
             rnd[p] = dict(masks=[rng.random_sample((B, x)) >= 0.1 for x in w], eps=rng.standard_normal((B, L)).astype(np.float32))
         got = vae.train_batch(np.arange(lo, hi), eps=[rnd[p]["eps"] for p in fd.VAEVAE_PASSES], masks=[rnd[p]["masks"] for p in fd.VAEVAE_PASSES])
-        un = dict(depths=t[0][lo:hi], tnf=t[1][lo:hi], abundance=t[2][lo:hi], weights=t[3][lo:hi])
-        su = dict(depths=t[5][lo:hi], tnf=t[6][lo:hi], abundance=t[7][lo:hi], weights=t[8][lo:hi])
-        want = oracle.train_step(un, t[4][lo:hi], su, t[9][lo:hi], rnd, lr=1e-3)
+        # trainepoch binds the ten tensors by position: [0:5] its *_sup batch, [5:10] its *_unsup batch (tov.step_batches)
+        su = dict(depths=t[0][lo:hi], tnf=t[1][lo:hi], abundance=t[2][lo:hi], weights=t[3][lo:hi])
+        un = dict(depths=t[5][lo:hi], tnf=t[6][lo:hi], abundance=t[7][lo:hi], weights=t[8][lo:hi])
+        want = oracle.train_step(un, t[9][lo:hi], su, t[4][lo:hi], rnd, lr=1e-3)
         for i, key in enumerate(vv.METRICS):
             # (ce_joint with one sample: the softmax over one column is 1, the cross-entropy -log(1 + 1e-9) * x -- 0.0 in float32,
             # which is what the device reports; -1e-9 * x in the oracle's float64)
@@ -383,3 +383,59 @@ def test_error_behaviour():
     ds = torch.utils.data.TensorDataset(*(torch.zeros(8, 1) for _ in range(4)))
     with pytest.raises(ValueError):        # not a semisupervised loader
         vae._ensure_dataset(torch.utils.data.DataLoader(ds, batch_size=4))
+
+
+def test_save_load_round_trip_with_more_than_105_nodes(tmp_path):
+    """`save` stores VAELabels.nlabels -- the LEAF count, as the reference does (taxvamb_encode.py:329 overwrites it) --
+    while the label block is max(n_nodes, 105) wide; `load` takes the width from the taxonomy it is given and checks it against
+    the stored weights.  131 nodes / 61 leaves: the reference's own round trip fails here (load_state_dict size mismatch)."""
+    name = "vaevae_tree_wide"
+    c = fd.VAEVAE_CASES[name]
+    parents = fd.vaevae_tree(name)
+    N = len(parents)
+    assert N > 105
+    names = [f"n{i}" for i in range(N)]
+    vae = vt.VAEVAEHLoss(c["nsamples"], N, names, parents, nhiddens=list(c["nhiddens"]), nlatent=c["nlatent"], alpha=c["alpha"],
+                         beta=c["beta"], dropout=c["dropout"])
+    for k, st in tov.init_states(name).items():
+        getattr(vae, k).load_state_dict({kk: torch.from_numpy(np.array(v, dtype=np.float32 if v.dtype.kind == "f" else v.dtype))
+                                         for kk, v in st.items()})
+    path = tmp_path / "taxvamb_model.pt"
+    with open(path, "wb") as fh:
+        vae.save(fh)
+    d = torch.load(path, weights_only=False)
+    assert d["nlabels"] == vae.VAELabels.nlabels == int(np.sum(~np.isin(np.arange(N), parents)))   # the reference's key, the leaf count
+    back = vt.VAEVAEHLoss.load(path, names, parents)
+    for k in NETS:
+        a, b = getattr(vae, k).state_dict(), getattr(back, k).state_dict()
+        assert list(a) == list(b)
+        for kk in a:
+            assert torch.equal(a[kk], b[kk]), (k, kk)
+    g = fd.load(name)
+    dsj = torch.utils.data.TensorDataset(*(torch.from_numpy(g["joint_" + k]) for k in ("depths", "tnf", "abundance", "weights", "nodes")))
+    dlj = torch.utils.data.DataLoader(dsj, batch_size=c["batch"], shuffle=True, drop_last=True, collate_fn=partial(vt.collate_fn_concat_hloss, N, parents))
+    for net in vae._networks():
+        net.eval()
+    assert np.array_equal(vae.VAEJoint.encode(dlj), back.VAEJoint.encode(dlj))
+    with pytest.raises(ValueError):   # a taxonomy of another size than the one the model was trained with
+        vt.VAEVAEHLoss.load(path, names[:110], parents[:110])
+
+
+def test_trainepoch_before_trainmodel_uses_the_optimizers_learning_rate():
+    """the reference's public trainepoch(data_loader, epoch, optimizer, batchsteps) called on its own: the native Adam
+    takes the learning rate of the optimizer that is passed; without one the error says what is missing; train_batch / get_grad
+    create the native trainer themselves."""
+    name = "vaevae_tree_drop"
+    g = fd.load(name)
+    c, vae, dl, parents = build(name, g)
+    vae._adam_lrate = None           # (build() configured Adam: undo)
+    with pytest.raises(ValueError, match="learning rate"):
+        vae.trainepoch(dl, 0, None, set())
+    params = [torch.nn.Parameter(torch.zeros(1))]
+    opt = torch.optim.Adam(params, lr=2e-3)
+    vae.trainepoch(dl, 0, opt, set())
+    assert vae._adam_lrate == 2e-3 and np.isfinite(vae.last_epoch_metrics["loss"])
+    fresh = vt.VAEVAEHLoss(c["nsamples"], len(parents), [f"n{i}" for i in range(len(parents))], parents, nhiddens=list(c["nhiddens"]),
+                           nlatent=c["nlatent"])
+    with pytest.raises(ValueError):   # no datasets / no learning rate yet -- but no AttributeError from a missing trainer
+        fresh.train_batch(np.arange(4))

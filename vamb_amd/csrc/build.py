@@ -56,6 +56,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".hpp", ".h"))]
     headers.append(os.path.join(os.path.dirname(PKG), "include", "vambhip.h"))
+    headers.append(os.path.join(os.path.dirname(PKG), "include", "vambhip_debug.h"))
     jobs = []
     objs = []
     for src, extra in SOURCES.items():

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/vambhip.h"
+#include "../../include/vambhip_debug.h"
 
 namespace vh {
 

@@ -175,8 +175,11 @@ struct VaeTuning {
     bool fused_skinny = true; // vae.fused_skinny: bf16 step: the two latent-wide products (mu, the first decoder layer's input gradient) and
                               // their elementwise consumers (reparameterisation, latent backward) as ONE launch each
                               // (gemm_skinny16.hpp) instead of split-K launch + slab-summing kernel.  Same bits.
-    bool fused_finalize = true; // vae.fused_finalize: bf16 step: d / k / counters / clearing of the fp64 accumulators by the LAST workgroup of the
-                              // update kernel (arrival ticket behind drained write-through stores) instead of a one-workgroup launch
+    bool fused_finalize = false; // vae.fused_finalize: bf16 step: d / k / counters / clearing of the fp64 accumulators by the LAST workgroup of
+                              // the update kernel (arrival ticket behind drained write-through stores) instead of a one-workgroup launch.
+                              // Bit-identical, measured SLOWER (C2: 272.5 vs 267.4 us per step, profiles/r05a_step_ab_c2.txt): ~1000
+                              // arrivals on one ticket word (the guide's dequeue row: one word saturates at ~88 atomics per us) cost more
+                              // than the 4.8 us launch they replace.  Off; kept as the measured negative.
     int dz_dbg = 0;           // vae.dz_dbg: timing experiments on the elementwise BatchNorm-backward kernel (WRONG results): see Dz16Args
     bool dw_row_major = true; // vae.dw_row_major: bf16 weight gradients contract ROW-major tensors (gemm_bf16_tn.hpp); 0 = the
                               // round-2 dataflow with a transposed bf16 copy of every contracted tensor (A/B measurements)
@@ -192,7 +195,7 @@ void refresh_tuning() {
     g_tuning.opt_split = option("vae.opt_split", 0) != 0;
     g_tuning.pipeline = option("vae.gemm_pipeline", 2) == 0 ? 0 : 2;
     g_tuning.fused_skinny = option("vae.fused_skinny", 1) != 0;
-    g_tuning.fused_finalize = option("vae.fused_finalize", 1) != 0;
+    g_tuning.fused_finalize = option("vae.fused_finalize", 0) != 0;
     g_tuning.dz_dbg = (int)option("vae.dz_dbg", 0);
 }
 

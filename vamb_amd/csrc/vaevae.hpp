@@ -363,9 +363,15 @@ int vh_vaevae_destroy(vh_vaevae* t) {
     return guarded([&] { delete t; });
 }
 
-// The three row-aligned datasets of make_dataloader_semisupervised_hloss (taxvamb_encode.py:192-239): row i of `unsup` (features
-// + weights) and of `unsup_labels` (labels only) form the unsupervised sample i, row i of `sup` (features + weights + labels) the
-// supervised one.
+// The three row-aligned datasets behind the 10-tensor loader of make_dataloader_semisupervised[_hloss] (taxvamb_encode.py:192-239),
+// named as THAT function names them: `unsup` = tensors[0:4] (dataloader_vamb: features + weights), `unsup_labels` = tensors[4]
+// (dataloader_labels), `sup` = tensors[5:10] (dataloader_joint: features + weights + labels).  VAEVAE.trainepoch unpacks the ten
+// tensors BY POSITION (semisupervised_encode.py:864-875) and its names are the other way round: tensors[0:5] are its `*_sup`
+// batch -- VAEJoint's input, the targets of the two decoders fed with mu_sup, calc_loss_joint's weights, the two `_sup_s`
+// passes -- and tensors[5:10] its `*_unsup` batch (VAEVamb.calc_loss, VAELabels.calc_loss).  The passes are bound the way
+// trainepoch uses them.  (`vamb bin taxvamb` builds the three loaders from the same contigs with one permutation seed, so both
+// halves hold the same rows there; the fixture vaevae_tree_split pins the binding with halves that differ.  Until round 5 the
+// passes followed the loader's names -- ADVICE r4.)
 int vh_vaevae_set_datasets(vh_vaevae* t, vh_dataset* unsup, vh_dataset* unsup_labels, vh_dataset* sup) {
     return guarded([&] {
         VH_REQUIRE(t != nullptr && unsup != nullptr && unsup_labels != nullptr && sup != nullptr, "NULL argument");
@@ -381,14 +387,18 @@ int vh_vaevae_set_datasets(vh_vaevae* t, vh_dataset* unsup, vh_dataset* unsup_la
         for (int p = 0; p < kVvPasses; ++p) {
             vh_vae* h = t->pass(p);
             if (h->stream) VH_HIP(hipStreamSynchronize(h->stream));
-            vh_dataset* d = h == t->vamb ? unsup : (h == t->labels ? unsup_labels : sup);
+            // the networks' own handles play the `*_unsup` passes (vamb_u, labels_u): tensors[5:10]; VAEJoint and the four
+            // replicas (vamb_x, labels_x, vamb_s, labels_s) see trainepoch's `*_sup` batch: tensors[0:4] + tensors[4]
+            const bool unsup_pass = h == t->vamb || h == t->labels;
+            vh_dataset* feat = unsup_pass ? sup : unsup;           // features + weights
+            vh_dataset* lab = unsup_pass ? sup : unsup_labels;     // labels
             h->own.X.release();
             h->own.w.release();
-            h->n = d->n;
-            h->w.p = d->w.p;
+            h->n = feat->n;
+            h->w.p = feat->w.p;
             if (h->kind == VH_VAE_LABELS) { h->X.p = nullptr; h->ld_src = 0; }
-            else { h->X.p = d->X.p; h->ld_src = d->D_p; }
-            h->labels = h->kind == VH_VAE_PLAIN ? nullptr : d->labels.p;
+            else { h->X.p = feat->X.p; h->ld_src = feat->D_p; }
+            h->labels = h->kind == VH_VAE_PLAIN ? nullptr : lab->labels.p;
         }
         t->n = sup->n;
     });

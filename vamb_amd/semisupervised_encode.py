@@ -531,6 +531,19 @@ class VAEVAE(object):
             _lib.check(lib.vh_vae_set_optimizer(net._h, VH_OPT_ADAM, float(lrate)))
             if reset:
                 _lib.check(lib.vh_vae_reset_optimizer(net._h))
+        self._adam_lrate = float(lrate)
+
+    def _require_adam(self, optimizer=None) -> None:
+        """trainepoch / train_batch called before trainmodel: the reference takes the optimiser as an argument (its learning rate
+        is what counts: the Adam state lives in the native handles), so use it -- or say clearly what is missing."""
+        if getattr(self, "_adam_lrate", None) is not None:
+            return
+        groups = getattr(optimizer, "param_groups", None)
+        if groups:
+            self._set_adam(float(groups[0]["lr"]), reset=True)
+            return
+        raise ValueError("no Adam learning rate set: call trainmodel(...), or pass the torch optimizer whose `lr` should be used "
+                         "to trainepoch (the optimiser state itself lives in the native handles)")
 
     def _ensure_dataset(self, data_loader) -> int:
         """Upload the ten tensors of the semisupervised loader (taxvamb_encode.py:213-224) as three resident datasets."""
@@ -583,15 +596,18 @@ class VAEVAE(object):
         m = None if masks is None else _np.ascontiguousarray(
             _np.concatenate([_np.asarray(k, dtype=_np.uint8).reshape(-1) for p in masks for k in p]))
         out = (ctypes.c_double * 17)()
-        _lib.check(self._vv_lib.vh_vaevae_train_step(self._trainer(), _lib.ptr(rows), len(rows), _lib.ptr(e), _lib.ptr(m), out))
+        t = self._trainer()   # (creates the native trainer -- and self._vv_lib -- on first use)
+        self._require_adam()
+        _lib.check(self._vv_lib.vh_vaevae_train_step(t, _lib.ptr(rows), len(rows), _lib.ptr(e), _lib.ptr(m), out))
         return list(out)
 
     def get_grad(self, network: str, name: str) -> _np.ndarray:
         net = dict(VAEVamb=0, VAELabels=1, VAEJoint=2)[network]
         n = _lib._i64(0)
+        t = self._trainer()
         _lib.check(self._vv_lib.vh_vae_param_size(self._networks()[net]._h, name.encode(), ctypes.byref(n)))
         out = _np.empty(n.value, _np.float32)
-        _lib.check(self._vv_lib.vh_vaevae_get_grad(self._trainer(), net, name.encode(), _lib.ptr(out), n.value))
+        _lib.check(self._vv_lib.vh_vaevae_get_grad(t, net, name.encode(), _lib.ptr(out), n.value))
         return out
 
     # ---- reference interface ----------------------------------------------------------------------------------------------
@@ -623,6 +639,7 @@ class VAEVAE(object):
         lives in the three native handles).  Rows are taken in the loader's order: sequential until the first batch-size
         doubling replaces the loader by a shuffling one (:852-862)."""
         n = self._ensure_dataset(data_loader)
+        self._require_adam(optimizer)
         if epoch in batchsteps:
             new_bs = data_loader.batch_size * 2
             data_loader = _DataLoader(dataset=data_loader.dataset, batch_size=new_bs, shuffle=True, drop_last=n > new_bs,

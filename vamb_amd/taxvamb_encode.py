@@ -158,17 +158,17 @@ def collate_fn_semisupervised_hloss(num_categories: int, table_parent, batch):
     return _semisupervised_encode.collate_fn_semisupervised(num_categories, batch)
 
 
-def _check_features(rpkm, tnf, lengths, batchsize):
-    """The argument checks of ``make_dataloader`` (encode.py:60-96) the labels-only loader inherits through ``_make_dataset``."""
-    if batchsize < 1:
-        raise ValueError(f"Batch size must be minimum 1, not {batchsize}")
-    if len(rpkm) != len(tnf) or len(tnf) != len(lengths):
-        raise ValueError("Lengths of abundance, TNF and lengths arrays must be the same")
-
-
 def make_dataloader_labels_hloss(rpkm, tnf, lengths, labels, N, table_parent, batchsize=256, destroy=False, cuda=False):
-    """taxvamb_encode.py:114-139: one node index per contig (the feature arrays only contribute their checks)."""
-    _check_features(rpkm, tnf, lengths, batchsize)
+    """taxvamb_encode.py:114-139: one node index per contig.  The reference builds the feature dataset first (``_make_dataset``)
+    and throws it away: the feature arrays contribute their validation (dtypes, shapes, batch size against the dataset,
+    zero-depth / zero-TNF rows) and, with ``destroy=True``, are normalised in place -- both kept by routing them through
+    ``make_dataloader`` (host path: nothing of it is used afterwards)."""
+    prep = _encode._PREP_MODE
+    _encode.set_prep_mode("host")
+    try:
+        _encode.make_dataloader(rpkm, tnf, lengths, batchsize, destroy, cuda)
+    finally:
+        _encode.set_prep_mode(prep)
     dataset = _TensorDataset(_torch.Tensor(labels).long())
     return _DataLoader(dataset=dataset, batch_size=batchsize, drop_last=dataset.tensors[0].shape[0] > batchsize, shuffle=True,
                        num_workers=0, pin_memory=False, collate_fn=partial(collate_fn_labels_hloss, N, table_parent))
@@ -318,9 +318,19 @@ class VAEVAEHLoss(_semisupervised_encode.VAEVAE):
 
     @classmethod
     def load(cls, path, nodes, table_parent, cuda=False, evaluate=True):
-        """taxvamb_encode.py:630-680."""
+        """taxvamb_encode.py:630-680.  ``save`` stores ``VAELabels.nlabels`` under "nlabels" as the reference does -- and that is
+        the number of LEAVES (the HLoss classes overwrite it after the layers were built max(n_nodes, 105) wide), so the
+        reference's own round trip breaks for a taxonomy of more than 105 nodes (load_state_dict size mismatch).  The file format
+        stays the reference's; the label block's width is taken from the taxonomy passed in (``table_parent``: one entry per
+        node) and checked against the stored weights."""
         d = _torch.load(path, map_location=lambda storage, loc: storage, weights_only=False)
-        vae = cls(d["nsamples"], d["nlabels"], nodes, table_parent, d["nhiddens"], d["nlatent"], d["alpha"], d["beta"],
+        n_nodes = len(table_parent)
+        width = max(n_nodes, 105)
+        stored = d["state_VAELabels"]["encoderlayers.0.weight"].shape[1]
+        if stored != width:
+            raise ValueError(f"the model was trained with a label block of {stored} columns, the taxonomy passed to load has "
+                             f"{n_nodes} nodes (a block of {width})")
+        vae = cls(d["nsamples"], n_nodes, nodes, table_parent, d["nhiddens"], d["nlatent"], d["alpha"], d["beta"],
                   d["dropout"], cuda=cuda)
         vae.VAEVamb.load_state_dict(d["state_VAEVamb"])
         vae.VAELabels.load_state_dict(d["state_VAELabels"])
