@@ -121,8 +121,22 @@ def gen_vae(en):
         vae.dropoutlayer = InjectedDropout()
         vae.reparameterize = lambda mu: (mu + torch.from_numpy(eps_q.pop(0))) if eps_q else mu
         opt = dadaptation.DAdaptAdam(vae.parameters(), decouple=True)
-        rec = dict(depths=depths.numpy().copy(), tnf=tnfz.numpy().copy(), total_abundance=totab.numpy().copy(),
-                   weights=weights.numpy().copy())
+        keep = c.get("rows_keep")
+
+        def rows_of(x):   # per-row outputs of a big case: the first rows + the norm of everything
+            x = np.asarray(x)
+            return x.copy() if keep is None else x[:keep].copy()
+
+        if c.get("store_inputs", True):
+            rec = dict(depths=depths.numpy().copy(), tnf=tnfz.numpy().copy(), total_abundance=totab.numpy().copy(),
+                       weights=weights.numpy().copy())
+        else:   # checksums of the reference-normalised inputs (exact fp64 sums of the float32 values and of their squares)
+            rec = {}
+            for k, v in (("depths", depths), ("tnf", tnfz), ("total_abundance", totab), ("weights", weights)):
+                v64 = v.numpy().astype(np.float64)
+                rec["input_sum/" + k] = np.array(v64.sum())
+                rec["input_sumsq/" + k] = np.array((v64 * v64).sum())
+                rec["input_head/" + k] = v.numpy()[:8].copy()
         losses, ds = [], []
         vae.train()
         for step in range(c["steps"]):
@@ -134,10 +148,11 @@ def gen_vae(en):
             ls = vae.calc_loss(d_in, do, t_in, to, a_in, ao, mu, w_in)
             ls[0].backward()
             if step == 0:
-                rec["step0_depths_out"] = do.detach().numpy().copy()
-                rec["step0_tnf_out"] = to.detach().numpy().copy()
-                rec["step0_ab_out"] = ao.detach().numpy().copy()
-                rec["step0_mu"] = mu.detach().numpy().copy()
+                for key, val in (("step0_depths_out", do), ("step0_tnf_out", to), ("step0_ab_out", ao), ("step0_mu", mu)):
+                    val = val.detach().numpy()
+                    rec[key] = rows_of(val)
+                    if keep is not None:
+                        rec[key + "_norm"] = np.array(np.sqrt((val.astype(np.float64) ** 2).sum()))
                 for pname, p in vae.named_parameters():
                     g = p.grad.detach().numpy()
                     if c["store"] == "full":
@@ -159,7 +174,10 @@ def gen_vae(en):
                 rec["final_norm/" + k] = np.array(np.sqrt((v.astype(np.float64) ** 2).sum()))
                 rec["final_head/" + k] = v.reshape(-1)[:64].copy()
         vae.eval()
-        rec["latent"] = vae.encode(dl)
+        lat = vae.encode(dl)
+        rec["latent"] = rows_of(lat)
+        if keep is not None:
+            rec["latent_norm"] = np.array(np.sqrt((lat.astype(np.float64) ** 2).sum()))
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
         out[name] = dict(loss0=losses[0][0], loss_last=losses[-1][0], d_last=ds[-1])
         print("vae", name, out[name])

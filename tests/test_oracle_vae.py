@@ -23,39 +23,49 @@ def test_oracle_matches_reference(name):
     st0 = vo.init_state(c["nsamples"], c["nhiddens"], c["nlatent"], c["seed"])
     m = vo.OracleVAE(c["nsamples"], c["nhiddens"], c["nlatent"], c["alpha"], c["beta"], c["dropout"], state=st0)
     d, t, a, w = g["depths"], g["tnf"], g["total_abundance"], g["weights"]
+    # the reference computes in float32: its BatchNorm statistics and loss means over a BASELINE-sized batch (4096 rows) carry a few
+    # more ulps of rounding than over the 16-64 rows of the small cases; the oracle is fp64.  Its GRADIENTS at that size are
+    # noisier still: every BatchNorm backward subtracts batch means (dy - mean(dy) - xhat mean(dy xhat)) and every weight gradient
+    # contracts a zero-mean operand over 4096 rows, so float32 rounding of the common-mode part survives where the exact sums
+    # cancel -- measured against this fp64 oracle: up to 4.4e-4 of a tensor's norm and 4e-3 of its entries on the encoder side
+    # (decoder side: 1e-5).  The bounds for the big case sit at ~2.5 x that noise.
+    big = 4.0 if B >= 1024 else 1.0
+    gnorm_tol, ghead_tol = (1e-3, 1e-2) if B >= 1024 else (2e-5, 2e-4)
     for step in range(c["steps"]):
         do, to, ao, mu = m.forward(d[:B], t[:B], a[:B], eps=eps[step], masks=masks[step], train=True)
         ls = m.calc_loss(d[:B], do, t[:B], to, a[:B], ao, mu, w[:B])
         grads = m.backward()
         if step == 0:
-            assert rel(mu, g["step0_mu"]) < 5e-6
-            assert rel(do, g["step0_depths_out"]) < 5e-6
-            assert rel(to, g["step0_tnf_out"]) < 5e-6
-            assert rel(ao, g["step0_ab_out"]) < 5e-6
+            assert fd.rows_rel(mu, g, "step0_mu") < 5e-6 * big
+            assert fd.rows_rel(do, g, "step0_depths_out") < 5e-6 * big
+            assert fd.rows_rel(to, g, "step0_tnf_out") < 5e-6 * big
+            assert fd.rows_rel(ao, g, "step0_ab_out") < 5e-6 * big
             for n in m.names:
                 if c["store"] == "full":
                     assert rel(grads[n], g["grad0/" + n]) < 2e-5, n
                 else:
                     nrm = np.sqrt((grads[n] ** 2).sum())
-                    assert abs(nrm - g["grad0_norm/" + n]) / g["grad0_norm/" + n] < 2e-5, n
-                    assert rel(grads[n].reshape(-1)[:64], g["grad0_head/" + n]) < 2e-4, n
+                    assert abs(nrm - g["grad0_norm/" + n]) / g["grad0_norm/" + n] < gnorm_tol, n
+                    assert rel(grads[n].reshape(-1)[:64], g["grad0_head/" + n]) < ghead_tol, n
         m.dadapt_step()
-        assert rel(np.array(ls), g["losses"][step]) < 2e-6
-        assert abs(m.d - g["d_after"][step]) / g["d_after"][step] < 2e-5
+        assert rel(np.array(ls), g["losses"][step]) < 2e-6 * big
+        assert abs(m.d - g["d_after"][step]) / g["d_after"][step] < 2e-5 * big
     assert abs(m.numerator_weighted - g["numerator_weighted"]) <= 2e-5 * abs(g["numerator_weighted"]) + 1e-30
     for k, v in m.state.items():
         if v.dtype.kind != "f":
             assert int(v) == int(g["final/" + k])
         elif "final/" + k in g:
-            assert rel(v, g["final/" + k]) < 5e-6, k
+            assert rel(v, g["final/" + k]) < (1e-4 if B >= 1024 else 5e-6), k   # (big case: steps taken with the noisy gradients)
         else:
             nrm = np.sqrt((v ** 2).sum())
-            assert abs(nrm - g["final_norm/" + k]) / g["final_norm/" + k] < 5e-6, k
+            assert abs(nrm - g["final_norm/" + k]) / g["final_norm/" + k] < 5e-6 * big, k
     lat = m.encode(d, t, a)
     assert lat.dtype == np.float32 and lat.shape == (c["n"], c["nlatent"])
     assert (lat.view(np.uint32) & 0xFFF == 0).all()
     # 12 cleared mantissa bits: one unit of the kept mantissa is 2^-11 relative
-    assert np.abs(lat - g["latent"]).max() <= np.abs(g["latent"]).max() * 2.0 ** -10
+    assert np.abs(lat[:len(g["latent"])] - g["latent"]).max() <= np.abs(g["latent"]).max() * 2.0 ** -10
+    if "latent_norm" in g:
+        assert abs(np.sqrt((lat.astype(np.float64) ** 2).sum()) - g["latent_norm"]) <= g["latent_norm"] * 2.0 ** -10
 
 
 def test_loss_weight_broadcast_quirk():

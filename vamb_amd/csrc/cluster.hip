@@ -869,13 +869,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(REF && N
     // as soon as its MFMA chain has been issued, before the chain's result is looked at
     constexpr int DEPTH = NK <= 16 ? 3 : 2;
     ScanTile<NK> tl[DEPTH];
+    // Every prefetch is UNCONDITIONAL: past the end of the matrix the last tile is requested again and never looked at.  With the
+    // request inside `if (tile + DEPTH * stride < ntiles)` the compiler cannot know how many newer loads are in flight when a
+    // tile is consumed -- possibly none -- and waits for ALL of them (s_waitcnt vmcnt(0) in front of every MFMA chain, found in
+    // the ISA in round 5): the three tile buffers then hide nothing and every tile pays a full memory round trip.  With a fixed
+    // number of loads per iteration it waits for this tile's loads only (vmcnt = the loads of the DEPTH - 1 tiles behind it).
+    auto tile_base = [&](int64_t t) { return (t < ntiles ? t : ntiles - 1) << 5; };   // (wave-uniform)
 #pragma unroll
-    for (int u = 0; u < DEPTH; ++u) {
-        tl[u].k0 = tl[u].k1 = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int q = 0; q < NK; ++q) tl[u].xa[q] = 0.0f;
-        if (tile + u * stride < ntiles) scan_tile_load<NK>(tl[u], Mt, ld, nk, kept, (tile + u * stride) << 5, j, h);
-    }
+    for (int u = 0; u < DEPTH; ++u) scan_tile_load<NK>(tl[u], Mt, ld, nk, kept, tile_base(tile + u * stride), j, h);
     auto step = [&](ScanTile<NK>& t) {
         const int64_t base = tile << 5;
         const uint32_t kw[8] = {t.k0.x, t.k0.y, t.k0.z, t.k0.w, t.k1.x, t.k1.y, t.k1.z, t.k1.w};
@@ -890,7 +891,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(REF && N
 #pragma unroll
             for (int q = 0; q < NK; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.xa[q], qb[q], acc, 0, 0, 0);
         }
-        if (tile + DEPTH * stride < ntiles) scan_tile_load<NK>(t, Mt, ld, nk, kept, (tile + DEPTH * stride) << 5, j, h);
+        scan_tile_load<NK>(t, Mt, ld, nk, kept, tile_base(tile + DEPTH * stride), j, h);
         if (!work) return;
         unsigned long long any = 0ull;
 #pragma unroll

@@ -180,6 +180,13 @@ struct VaeTuning {
                               // Bit-identical, measured SLOWER (C2: 272.5 vs 267.4 us per step, profiles/r05a_step_ab_c2.txt): ~1000
                               // arrivals on one ticket word (the guide's dequeue row: one word saturates at ~88 atomics per us) cost more
                               // than the 4.8 us launch they replace.  Off; kept as the measured negative.
+    int fork_plan = 0;        // vae.fork_plan (bf16 step, bit mask; A/B of the two-stream schedule): 1 = one more fork at the first decoder
+                              // layer's BatchNorm-backward kernel (its weight gradient and the mu layer's start there instead of at encoder
+                              // layer 1); 2 = encoder layer 1's weight gradient on the MAIN stream behind layer 0's (the side stream's last
+                              // batch ends before the main stream does); 4 = running statistics + loss reduction at the END of the side
+                              // stream's work instead of in front of the first weight gradient
+    int fork_mode = 0;        // vae.fork_mode: 0 = forks ride on the producing kernel's completion signal (hipExtLaunchKernelGGL stop event);
+                              // 2 = stream memory operations (a value written by the main stream, awaited by the side stream)
     int dz_dbg = 0;           // vae.dz_dbg: timing experiments on the elementwise BatchNorm-backward kernel (WRONG results): see Dz16Args
     bool dw_row_major = true; // vae.dw_row_major: bf16 weight gradients contract ROW-major tensors (gemm_bf16_tn.hpp); 0 = the
                               // round-2 dataflow with a transposed bf16 copy of every contracted tensor (A/B measurements)
@@ -197,6 +204,8 @@ void refresh_tuning() {
     g_tuning.fused_skinny = option("vae.fused_skinny", 1) != 0;
     g_tuning.fused_finalize = option("vae.fused_finalize", 0) != 0;
     g_tuning.dz_dbg = (int)option("vae.dz_dbg", 0);
+    g_tuning.fork_plan = (int)option("vae.fork_plan", 0);
+    g_tuning.fork_mode = (int)option("vae.fork_mode", 0);
 }
 
 int fwd_tile(int M, int N) {
@@ -250,6 +259,8 @@ struct vh_vae {
     // run on a second stream, forked after each layer's dZ is ready and joined before the update
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint32_t* fork_flag = nullptr;    // vae.fork_mode = 2: signal memory the main stream writes and the side stream waits on
+    uint32_t fork_seq = 0;
 
     std::vector<Tensor> tensors;
     std::map<std::string, int> tindex;
@@ -325,6 +336,7 @@ struct vh_vae {
         for (auto e : ev_b) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (fork_flag) (void)hipFree(fork_flag);
         if (owns_streams) {
             if (side && side != stream) (void)hipStreamDestroy(side);
             if (stream) (void)hipStreamDestroy(stream);
@@ -635,9 +647,24 @@ void fork_side(vh_vae* h) {
 // forks per step).  Instead the producing kernel is launched with the fork event as its stop event
 // (hipExtLaunchKernelGGL: the event is the dispatch's own completion signal) and the side stream waits on that.
 bool fork_from_kernel(const vh_vae* h) { return h->side != h->stream && h->fork_ext; }
+// vae.fork_mode = 2: no event at all -- the main stream writes the next value of a counter into signal memory behind the producing
+// kernel (a command-processor packet), the side stream waits until the counter has reached it
+void fork_by_value(vh_vae* h) {
+    if (h->fork_flag == nullptr) {
+        VH_HIP(hipExtMallocWithFlags((void**)&h->fork_flag, 8, hipMallocSignalMemory));
+        VH_HIP(hipMemset(h->fork_flag, 0, 8));
+    }
+    h->fork_seq++;
+    VH_HIP(hipStreamWriteValue32(h->stream, h->fork_flag, h->fork_seq, 0));
+    VH_HIP(hipStreamWaitValue32(h->side, h->fork_flag, h->fork_seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+}
 template <class K, class... Args>
 void launch_forking(vh_vae* h, K kernel, dim3 grid, dim3 block, size_t smem, Args... args) {
-    if (fork_from_kernel(h)) {
+    if (h->side != h->stream && g_tuning.fork_mode == 2) {
+        hipLaunchKernelGGL(kernel, grid, block, smem, h->stream, args...);
+        VH_HIP(hipGetLastError());
+        fork_by_value(h);
+    } else if (fork_from_kernel(h)) {
         hipExtLaunchKernelGGL(kernel, grid, block, smem, h->stream, nullptr, h->ev_fork, 0, args...);
         VH_HIP(hipGetLastError());
         VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));

@@ -185,10 +185,20 @@ void transpose16(vh_vae* h, hipStream_t s, const bf16_t* in, int R, int C, bf16_
 // its last producer on the main stream.
 struct SideQueue {
     std::vector<std::function<void(hipStream_t)>> items;
+    std::vector<std::function<void(hipStream_t)>> tail;   // small items nobody but the optimiser waits for (vae.fork_plan & 4)
     void add(std::function<void(hipStream_t)> f) { items.push_back(std::move(f)); }
+    void add_small(std::function<void(hipStream_t)> f) {
+        if (g_tuning.fork_plan & 4) tail.push_back(std::move(f));
+        else items.push_back(std::move(f));
+    }
     void flush(hipStream_t s) {
         for (auto& f : items) f(s);
         items.clear();
+    }
+    // behind everything else the side stream was given: the producers of these items precede every fork point of the step
+    void flush_tail(hipStream_t s) {
+        for (auto& f : tail) f(s);
+        tail.clear();
     }
 };
 
@@ -452,7 +462,7 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
             VH_HIP(hipGetLastError());
         };
         if (defer) {
-            defer->add(running);
+            defer->add_small(running);
         } else {   // forward-only call: run it now
             fork_side(h);
             running(h->side);
@@ -488,7 +498,7 @@ void loss_and_seed16(vh_vae* h, SideQueue& q) {
     // the scalar reduction (loss means, sum of weights) is only needed by the optimiser
     const float* gw = h->gwsum_src;
     const float* lab_part = a.lab_part;
-    q.add([h, bs_global, gw, lab_part](hipStream_t st) {
+    q.add_small([h, bs_global, gw, lab_part](hipStream_t st) {
         hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(kLossFinThreads), 0, st, h->loss_part.p, h->loss_blocks, h->Wb.p,
                            h->bs, gw, bs_global, h->state.p, lab_part);
         VH_HIP(hipGetLastError());
@@ -570,6 +580,7 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
     }
     int latent_slabs = 1;
     bool latent_fused = false;
+    std::function<void(hipStream_t)> late_dw;
     auto hidden_bwd = [&](int li) {
         Hidden& hl = h->hidden[li];
         Dz16Args a;
@@ -597,7 +608,10 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         // Fork points: the top decoder layer and encoder layer 1 (and layer 0 when something is still queued): each
         // hands everything queued so far to the side stream.  The first layer's weight gradient is the end of the
         // chain -- nothing is left on the main stream for it to hide behind -- so it runs there.
-        if (li > 0) q.add(dw);
+        // (vae.fork_plan & 2: encoder layer 1's weight gradient waits for layer 0's on the main stream)
+        const bool dw_on_main_late = li == 1 && nl >= 2 && (g_tuning.fork_plan & 2) != 0;
+        if (dw_on_main_late) late_dw = dw;
+        else if (li > 0) q.add(dw);
         if (li == nl && !h->comm && nl >= 2 && g_tuning.opt_split) {
             // Every decoder-side gradient is queued now (output layer, decoder layers; their bias / gamma / beta sums are
             // complete on the main stream).  The update of those tensors -- half of the parameters -- does not need this
@@ -629,7 +643,8 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         // costs the main stream ~5 us before its next kernel (the producing kernel's completion signal).  Variants measured at
         // C2 (profiles/r03w_*, r03zb_*, r03zc_*): these two 286 us per step; + the loss kernel 296; loss + LAST decoder layer +
         // encoder layer 1 299 against 297 on the box of that run.
-        const bool fork = li == 2 * nl - 1 || li == 1 || (li == 0 && !q.items.empty());
+        const bool fork = li == 2 * nl - 1 || li == 1 || (li == 0 && !q.items.empty()) ||
+                          (li == nl && nl >= 2 && (g_tuning.fork_plan & 1) != 0);
         const dim3 grid((unsigned)ceil_div(hl.nout_p, kDz16Cols), (unsigned)ceil_div(bs_p, kDz16Rows));
         if (fork) {
             launch_forking(h, vae_dz16_kernel, grid, dim3(256), 0, a);
@@ -640,6 +655,7 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         }
         if (li == 0) {
             dw(h->stream);
+            if (late_dw) late_dw(h->stream);
         } else if (li == nl) {
             // first decoder layer -> latent: latent-wide output; dMU = dZlat + d(KLD)/dmu fused into the same launch when the
             // operands of 32 rows fit a workgroup's LDS (gemm_skinny16.hpp), else split-K slabs summed by the latent kernel
@@ -691,6 +707,8 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         grad_input16(h, h->dMU16.p, h->L_p, h->tWmu, enc_last.nout_p, enc_last);
     }
     for (int li = nl - 1; li >= 0; --li) hidden_bwd(li);
+    if (h->side != h->stream) q.flush_tail(h->side);
+    else q.flush_tail(h->stream);
     join_side(h);   // every weight gradient, the loss reduction and the running statistics are complete
 }
 

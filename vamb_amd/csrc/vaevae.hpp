@@ -395,7 +395,9 @@ int vh_vaevae_set_datasets(vh_vaevae* t, vh_dataset* unsup, vh_dataset* unsup_la
             h->own.X.release();
             h->own.w.release();
             h->n = feat->n;
-            h->w.p = feat->w.p;
+            // (VAELabels.calc_loss has no contig weights: its passes take the unit weights of the labels-only dataset, whichever
+            // half their labels come from)
+            h->w.p = h->kind == VH_VAE_LABELS ? unsup_labels->w.p : feat->w.p;
             if (h->kind == VH_VAE_LABELS) { h->X.p = nullptr; h->ld_src = 0; }
             else { h->X.p = feat->X.p; h->ld_src = feat->D_p; }
             h->labels = h->kind == VH_VAE_PLAIN ? nullptr : lab->labels.p;
