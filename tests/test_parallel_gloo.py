@@ -1,4 +1,4 @@
-"""world_size=2 CPU tests (gloo) of the multi-GPU host path in vamb_amd/parallel.py.
+"""world_size 2 and 8 CPU tests (gloo) of the multi-GPU host path in vamb_amd/parallel.py.
 
 The device passes are replaced by the oracle backend (tests/oracle_backend.py) and the per-rank VAE
 step by the numpy oracle, so these tests exercise exactly the product's sharding / reduction logic:
@@ -70,6 +70,17 @@ def _run(fn_name, world=2):
     return results
 
 
+def uneven_cuts(n, world):
+    """Row boundaries of `world` UNEVEN contiguous shards of n rows (world = 2: the 37 % / 63 % split of rounds 1-4)."""
+    if world == 2:
+        return [0, int(n * 0.37), n]
+    w = np.array([(1 + (3 * r) % 5) for r in range(world)], dtype=np.float64)   # 1, 4, 2, 5, 3, 1, 4, 2: shares between 1/22 and 5/22
+    cuts = [0] + [int(round(x)) for x in np.cumsum(w) / w.sum() * n]
+    cuts[-1] = n
+    assert all(b > a for a, b in zip(cuts, cuts[1:]))
+    return cuts
+
+
 # ---- per-rank bodies (module level so that spawn can pickle them by name) -------------------------
 def _sharded_cluster(comm):
     import fixture_defs as fd
@@ -80,7 +91,7 @@ def _sharded_cluster(comm):
     out = {}
     for name in ("blob_s008_n2000", "blob_s050_window", "blob_zero_dup"):
         mat, lens, kw = fd.cluster_inputs(name)
-        cut = [0, int(len(mat) * 0.37), len(mat)]       # uneven shards
+        cut = uneven_cuts(len(mat), comm.world)
         lo, hi = cut[comm.rank], cut[comm.rank + 1]
         gen = parallel.sharded_cluster_generator(comm, mat[lo:hi].copy(), lens[lo:hi],
                                                  _local_backend_factory=OracleScanBackend, **kw)
@@ -172,8 +183,12 @@ def test_syncbn_data_parallel_equals_serial_global_batch(oracle_lib):
         assert out["err"] < 1e-7 and out["running_err"] < 1e-12, (rank, out)   # E[h^2] - mean^2 vs mean((h - mean)^2) in fp64
 
 
-def test_sharded_cluster_stream_is_identical(oracle_lib):
-    res = _run("_sharded_cluster")
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_cluster_stream_is_identical(oracle_lib, world):
+    """2 and 8 uneven row shards (BASELINE's 8-GPU partition; shard sizes between 1/22 and 5/22 of the rows): every rank emits the
+    reference's golden single-process stream."""
+    res = _run("_sharded_cluster", world=world)
+    assert sorted(res) == list(range(world))
     for rank, out in res.items():
         for name, (ok, msg) in out.items():
             assert ok, f"rank {rank} {name}: {msg}"

@@ -24,7 +24,7 @@ def _sharded_cluster_hip(comm):
     out = {}
     for name in ("blob_s008_n2000", "blob_s050_window", "blob_zero_dup", "blob_s050_n3000"):
         mat, lens, kw = fd.cluster_inputs(name)
-        cut = [0, int(len(mat) * 0.37), len(mat)]       # uneven shards
+        cut = pg.uneven_cuts(len(mat), comm.world)
         lo, hi = cut[comm.rank], cut[comm.rank + 1]
         gen = parallel.sharded_cluster_generator(comm, mat[lo:hi].copy(), lens[lo:hi], **kw)   # default factory: HipScanBackend
         assert type(gen._backend.local).__name__ == "HipScanBackend"
@@ -44,11 +44,18 @@ def _sharded_cluster_native(comm_control):
     _lib.require_gpu()
     vc.ClusterGenerator.PACK_MIN_ROWS = 64   # make the lazy packing happen on small fixtures
     comm = parallel.Communicator(comm_control.dist, rccl="host")
-    assert comm.info() == {"rank": comm.rank, "world": 2, "reported_ranks": 2, "data_plane": "host"}
+    world = comm_control.world
+    assert comm.info() == {"rank": comm.rank, "world": world, "reported_ranks": world, "data_plane": "host"}
     out = {}
     for name in ("blob_s008_n2000", "blob_s050_window", "blob_zero_dup", "blob_s050_n3000", "blob_s008_n10000", "test_cluster_py"):
         mat, lens, kw = fd.cluster_inputs(name)
-        cut = [0, int(len(mat) * 0.37), len(mat)]       # uneven shards
+        # the one-off gather of the normalised matrix goes through a bounded staging buffer: 8 KiB here, i.e. dozens of chunks
+        # with ragged last ones on these fixtures (the default, 64 MiB, would take each of them in one)
+        if name in ("blob_s050_window", "blob_s008_n10000"):
+            os.environ["VAMBHIP_GATHER_STAGE_BYTES"] = "8192"
+        else:
+            os.environ.pop("VAMBHIP_GATHER_STAGE_BYTES", None)
+        cut = pg.uneven_cuts(len(mat), world)
         lo, hi = cut[comm.rank], cut[comm.rank + 1]
         gen = parallel.sharded_cluster_generator(comm, mat[lo:hi].copy(), lens[lo:hi], **kw)
         assert gen._sharded_native and gen._gen is not None
@@ -133,10 +140,12 @@ def test_two_processes_one_gpu_sharded_stream_equals_reference():
             assert ok, (rank, name, msg)
 
 
-def test_two_processes_one_gpu_native_sharded_state_machine_equals_reference():
-    """vh_gen_create_sharded / vh_gen_next on two ranks: both ranks emit the real reference's golden stream."""
-    results = pg._run("test_parallel_gpu:_sharded_cluster_native", world=2)
-    for rank in (0, 1):
+@pytest.mark.parametrize("world", [2, 8])
+def test_processes_on_one_gpu_native_sharded_state_machine_equals_reference(world):
+    """vh_gen_create_sharded / vh_gen_next on 2 and on 8 ranks (BASELINE's 8-GPU partition, uneven shards between 1/22 and 5/22 of
+    the rows, all on one device over the host data plane): every rank emits the real reference's golden stream."""
+    results = pg._run("test_parallel_gpu:_sharded_cluster_native", world=world)
+    for rank in range(world):
         for name, (ok, msg) in results[rank].items():
             assert ok, (rank, name, msg)
 

@@ -195,6 +195,7 @@ _ENV_OPTIONS = {
     "VAMBHIP_SPEC_DEPTH": ("gen.spec_depth", int),
     "VAMBHIP_DEFER_BOOKKEEPING": ("gen.defer_bookkeeping", int),
     "VAMBHIP_SPEC_BIG_TARGET": ("gen.spec_big_target", int),
+    "VAMBHIP_GATHER_STAGE_BYTES": ("gen.gather_stage_bytes", int),
     "VAMBHIP_BIG_TILES": ("vae.big_tiles", int),
     "VAMBHIP_XCD_REMAP": ("vae.xcd_remap", int),
     "VAMBHIP_DW_WGS": ("vae.dw_workgroups", int),

@@ -3033,21 +3033,37 @@ int vh_gen_create_sharded(vh_clu* clu, const int64_t* order, int64_t n_global, i
         std::unique_ptr<vh_gen> g(gen_create_common(clu, comm, order, n_global, maxsteps, windowsize, minsuccesses, rng_seed,
                                                     pack_fraction, pack_min_rows));
         g->offsets = off;
-        // the whole normalised matrix on every rank (validity checks of cached statistics, query vectors of foreign medoids):
-        // equal-sized padded blocks through one all-gather
+        // The whole normalised matrix in HOST memory on every rank: the state machine reads rows of ANY shard all the time -- the query
+        // vector of every medoid it scans (most live in another shard), the row-by-row tests of the lazy validation against the
+        // rows an emission removed -- so fetching them on demand would put a collective on every such read.  Cost: n_global * L * 4
+        // bytes of host memory per rank (C3: 256 MB, C4 10 M x 64: 2.56 GB; an 8-GPU node holds 8 copies).  Device memory is NOT
+        // part of that: the gather goes through a bounded staging buffer, row chunk by row chunk (the one-shot gather
+        // held the whole matrix on every device while the generator was created).
         const size_t max_rows = *std::max_element(sizes.begin(), sizes.end());
-        const size_t block = max_rows * (size_t)L;
+        const size_t kStageBytes = (size_t)std::max<int64_t>(1, option("gen.gather_stage_bytes", (int64_t)64 << 20));   // receive staging per rank
+        const size_t chunk_rows = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(max_rows, 1),
+                                                                        kStageBytes / ((size_t)world * (size_t)L * sizeof(float))));
+        const size_t block = chunk_rows * (size_t)L;
         DevBuf<float> send, recv;
         send.alloc(block);
         recv.alloc(block * (size_t)world);
-        VH_HIP(hipMemsetAsync(send.p, 0, block * sizeof(float), clu->stream));
-        VH_HIP(hipMemcpyAsync(send.p, clu->host_rows.data(), clu->host_rows.size() * sizeof(float), hipMemcpyHostToDevice, clu->stream));
-        rccl_allgather_bytes(comm, send.p, recv.p, block * sizeof(float), clu->stream);
         g->rows_global.resize((size_t)n_global * L);
-        for (int r = 0; r < world; ++r)
-            if (sizes[(size_t)r])
-                VH_HIP(hipMemcpyAsync(g->rows_global.data() + (size_t)off[(size_t)r] * L, recv.p + (size_t)r * block,
-                                      (size_t)sizes[(size_t)r] * L * sizeof(float), hipMemcpyDeviceToHost, clu->stream));
+        for (size_t r0 = 0; r0 < max_rows; r0 += chunk_rows) {
+            const size_t mine_rows = (size_t)clu->n_rows > r0 ? std::min(chunk_rows, (size_t)clu->n_rows - r0) : 0;
+            VH_HIP(hipMemsetAsync(send.p, 0, block * sizeof(float), clu->stream));
+            if (mine_rows)
+                VH_HIP(hipMemcpyAsync(send.p, clu->host_rows.data() + r0 * (size_t)L, mine_rows * (size_t)L * sizeof(float),
+                                      hipMemcpyHostToDevice, clu->stream));
+            rccl_allgather_bytes(comm, send.p, recv.p, block * sizeof(float), clu->stream);
+            for (int r = 0; r < world; ++r) {
+                const size_t have = (size_t)sizes[(size_t)r];
+                if (have <= r0) continue;
+                const size_t take = std::min(chunk_rows, have - r0);
+                VH_HIP(hipMemcpyAsync(g->rows_global.data() + ((size_t)off[(size_t)r] + r0) * L, recv.p + (size_t)r * block,
+                                      take * (size_t)L * sizeof(float), hipMemcpyDeviceToHost, clu->stream));
+            }
+            VH_HIP(hipStreamSynchronize(clu->stream));   // (the staging buffers are reused by the next chunk)
+        }
         VH_HIP(hipStreamSynchronize(clu->stream));
         *out = g.release();
     });

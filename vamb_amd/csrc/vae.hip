@@ -184,7 +184,8 @@ struct VaeTuning {
                               // layer's BatchNorm-backward kernel (its weight gradient and the mu layer's start there instead of at encoder
                               // layer 1); 2 = encoder layer 1's weight gradient on the MAIN stream behind layer 0's (the side stream's last
                               // batch ends before the main stream does); 4 = running statistics + loss reduction at the END of the side
-                              // stream's work instead of in front of the first weight gradient
+                              // stream's work instead of in front of the first weight gradient; 8 = the mu layer's weight gradient on the main
+                              // stream as well
     int fork_mode = 0;        // vae.fork_mode: 0 = forks ride on the producing kernel's completion signal (hipExtLaunchKernelGGL stop event);
                               // 2 = stream memory operations (a value written by the main stream, awaited by the side stream)
     int dz_dbg = 0;           // vae.dz_dbg: timing experiments on the elementwise BatchNorm-backward kernel (WRONG results): see Dz16Args

@@ -580,7 +580,7 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
     }
     int latent_slabs = 1;
     bool latent_fused = false;
-    std::function<void(hipStream_t)> late_dw;
+    std::function<void(hipStream_t)> late_dw, late_dw_mu;
     auto hidden_bwd = [&](int li) {
         Hidden& hl = h->hidden[li];
         Dz16Args a;
@@ -656,6 +656,7 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         if (li == 0) {
             dw(h->stream);
             if (late_dw) late_dw(h->stream);
+            if (late_dw_mu) late_dw_mu(h->stream);
         } else if (li == nl) {
             // first decoder layer -> latent: latent-wide output; dMU = dZlat + d(KLD)/dmu fused into the same launch when the
             // operands of 32 rows fit a workgroup's LDS (gemm_skinny16.hpp), else split-K slabs summed by the latent kernel
@@ -696,14 +697,16 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
                                h->dMU16.p, h->L_p, bs, bs_p);
             VH_HIP(hipGetLastError());
         }
-        q.add([h, bs_p, bs, &enc_last](hipStream_t st) {
+        auto dw_mu = [h, bs_p, bs, &enc_last](hipStream_t st) {
             if (g_tuning.dw_row_major) {
                 grad_weight16_rm(h, h->tWmu, h->dMU16.p, h->L_p, enc_last.H16.p, enc_last.nout_p, h->dbias_mu, st);
             } else {
                 transpose16(h, st, h->dMU16.p, bs_p, h->L_p, h->dMU16T.p, h->dbias_mu, bs);
                 grad_weight16(h, h->tWmu, h->dMU16T.p, h->L_p, enc_last.H16T.p, enc_last.nout_p, st);
             }
-        });
+        };
+        if ((g_tuning.fork_plan & 8) && nl >= 2) late_dw_mu = dw_mu;   // (on the main stream, behind the first layer's)
+        else q.add(dw_mu);
         grad_input16(h, h->dMU16.p, h->L_p, h->tWmu, enc_last.nout_p, enc_last);
     }
     for (int li = nl - 1; li >= 0; --li) hidden_bwd(li);
