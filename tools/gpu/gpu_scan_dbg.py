@@ -24,7 +24,7 @@ g = labels[rng.randint(n)]
 same = np.flatnonzero(labels == g)
 sets = {"random": rng.choice(n, k, replace=False), "neighbours": same[:k] if len(same) >= k else rng.choice(n, k, replace=False)}
 lines = []
-for dbg in (0, 1, 8, 2, 4, 12, 13):
+for dbg in [int(x) for x in os.environ.get('SCAN_DBG_LIST', '0,1,8,2,4,12,13').split(',')]:
     os.environ["VAMBHIP_SCAN_DBG"] = str(dbg)
     b = vc.HipScanBackend(lat, lens, False, None)
     for name, med in sets.items():

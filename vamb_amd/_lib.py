@@ -183,6 +183,7 @@ def load():
 _ENV_OPTIONS = {
     "VAMBHIP_SCAN_LC": ("scan.column_loop", int),
     "VAMBHIP_SCAN_MFMA": ("scan.mfma", int),
+    "VAMBHIP_SCAN_MFMA_ROWMAJOR": ("scan.mfma_rowmajor", int),
     "VAMBHIP_REFERENCE_ORDER": ("scan.reference_order", int),
     "VAMBHIP_SCAN_WIDE": ("scan.wide_rows", lambda v: 1),
     "VAMBHIP_SCAN_MIN_BLOCKS": ("scan.min_blocks", int),

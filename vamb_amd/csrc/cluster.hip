@@ -888,10 +888,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(REF && N
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             // column pairs beyond the latent width hold zeros on both sides: fmaf(0, 0, acc) == acc, bit for bit
+            if (dbg & 16) {   // timing experiment: no matrix pipe (the operands are still consumed: one VALU op each)
 #pragma unroll
-            for (int q = 0; q < NK; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.xa[q], qb[q], acc, 0, 0, 0);
+                for (int q = 0; q < NK; ++q) acc[q & 15] += t.xa[q] * qb[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < NK; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.xa[q], qb[q], acc, 0, 0, 0);
+            }
         }
-        scan_tile_load<NK>(t, Mt, ld, nk, kept, tile_base(tile + DEPTH * stride), j, h);
+        if (!(dbg & 32))   // timing experiment: 32 = no loads behind the first DEPTH tiles (matrix pipe on stale operands)
+            scan_tile_load<NK>(t, Mt, ld, nk, kept, tile_base(tile + DEPTH * stride), j, h);
         if (!work) return;
         unsigned long long any = 0ull;
 #pragma unroll
@@ -933,6 +939,226 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(REF && N
     }
     drain_hits<REF>(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, ro, lengths);
     scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists, dbg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6r: the matrix-pipe pass over a ROW-major copy of the matrix (round 5; scan.reference_order = 2 only).
+// What the counters said about K6m at 32 medoids x 620 k rows (profiles/r05d_pmc_scan_mfma_*, r05e_scan_core.txt): the pass with
+// neither its loads nor its MFMAs still takes 19.5 of 33.9 us -- ~320 issued instructions per 32-row tile beside the 16 MFMAs:
+// sixteen 4-byte loads, each with its own 64-bit address built from a column base that had been spilled to a VGPR lane, the
+// live flags through vector registers, sixteen compares + ballots.  The matrix pipe is busy 22 % of the kernel.
+// The column-major layout forces one load per (column pair) because a lane needs ONE float of each.  But in this mode the kernel
+// is only a FILTER (the drain re-evaluates every pair that can decide differently in the reference's order), so the order in
+// which the products are accumulated is free: step s of the chain multiplies column  h * NK + s  (h = lane >> 5) instead of
+// 2 s + h.  Then a lane needs NK CONSECUTIVE floats of its row -- NK / 4 sixteen-byte loads from a row-major matrix
+// [ld][LR] (LR = 32 or 64 floats per row, zero padded), addressed as one scalar tile base + one per-lane byte offset that
+// never changes.  Live flags are fetched (scalar) only by tiles that have a candidate pair; the candidate test is a max tree +
+// one compare.  Everything downstream (hit queue, drain, flush) is K6m's.
+// ---------------------------------------------------------------------------------------------
+typedef float scan_f32x4 __attribute__((ext_vector_type(4)));
+
+// The tile loads and their waits are written out by hand.  Left to the compiler, every MFMA chain was preceded by
+// s_waitcnt vmcnt(0) -- the hit path between two chains contains loads of its own inside branches, and the waitcnt pass then gives
+// up counting across them -- so the tile buffers hid nothing (same finding as in K6m).  An asm load is invisible to that pass:
+// the wait below is ours alone.  Loads return in order, so "at most (DEPTH - 1) * NK / 4 loads still in flight" means the
+// tile about to be multiplied has landed whatever else was issued in between (waits the compiler adds for its own loads can
+// only wait for more).  The "+v" operands tie the registers to the wait, so nothing reads them before it.
+template <int NK>
+__device__ __forceinline__ void scan_tile_load_rm(scan_f32x4 (&xa)[NK / 4], const float* __restrict__ Mr, int64_t tile, uint32_t lane_off) {
+    const float* base = Mr + tile * (int64_t)(32 * 2 * NK);   // (wave-uniform: a scalar register pair)
+    static_assert(NK == 16 || NK == 32, "row width 32 or 64");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xa[0]) : "v"(lane_off), "s"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(xa[1]) : "v"(lane_off), "s"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(xa[2]) : "v"(lane_off), "s"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:48" : "=v"(xa[3]) : "v"(lane_off), "s"(base) : "memory");
+    if constexpr (NK == 32) {
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(xa[4]) : "v"(lane_off), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:80" : "=v"(xa[5]) : "v"(lane_off), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:96" : "=v"(xa[6]) : "v"(lane_off), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:112" : "=v"(xa[7]) : "v"(lane_off), "s"(base) : "memory");
+    }
+}
+// wait until at most `behind` of OUR tile loads are still in flight, i.e. until the tile in `xa` has landed
+template <int NK, int BEHIND>
+__device__ __forceinline__ void scan_tile_wait_rm(scan_f32x4 (&xa)[NK / 4]) {
+    if constexpr (NK == 16)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]) : "n"(BEHIND) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xa[4]), "+v"(xa[5]), "+v"(xa[6]),
+                     "+v"(xa[7]) : "n"(BEHIND) : "memory");
+}
+
+template <int NK>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NK <= 16 ? 3 : 2, NK <= 16 ? 3 : 8)))
+void clu_scan_mfma_rm_kernel(const float* __restrict__ Mr, int64_t ld, const float* __restrict__ lengths,
+                             const uint8_t* __restrict__ kept, const float* __restrict__ q_ext, int q_ld,
+                             const MedoidRows medoid, int k_real, unsigned long long* __restrict__ results,
+                             int32_t* __restrict__ lists, int dbg, const RefSrc ro) {
+    constexpr int KM = kMaxMedoids;
+    constexpr int LR = 2 * NK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* hq_s = reinterpret_cast<float4*>(smem_raw);                                  // [kBlock/64][kHitCap]
+    unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(hq_s + (kBlock / 64) * kHitCap);   // [KM][kResultWords]
+    float* edges_s = reinterpret_cast<float*>(acc_s + KM * kResultWords);               // [64]
+    unsigned int* lcnt_s = reinterpret_cast<unsigned int*>(edges_s + 64);               // [KM]
+    int32_t* llist_s = reinterpret_cast<int32_t*>(lcnt_s + KM);                         // [KM][kLocalCap]
+    int32_t* med_s = llist_s + KM * kLocalCap;                                          // [KM]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float4* hq = hq_s + wave * kHitCap;
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t lane_off = (uint32_t)(j * LR + h * NK) * 4u;
+    const int64_t ntiles = ld >> 5;
+    const int64_t stride = (int64_t)gridDim.x * (kBlock / 64);
+    int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    auto clamp_tile = [&](int64_t t) { return t < ntiles ? t : ntiles - 1; };   // (wave-uniform; see K6m on unconditional prefetches)
+    // the first tiles are requested before anything else: they travel under the LDS initialisation and the query fetch
+    constexpr int DEPTH = NK <= 16 ? 3 : 2;
+    constexpr int TILE_LOADS = NK / 4;
+    scan_f32x4 xa[DEPTH][NK / 4];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) scan_tile_load_rm<NK>(xa[u], Mr, clamp_tile(tile + u * stride), lane_off);
+    // B operand: lane (medoid j, half h) holds q[j][h NK .. + NK - 1]; unused medoid slots keep zeros (dot = 0, never a candidate)
+    float qb[NK];
+    {
+        const long long my_med = medoid.row[j];
+#pragma unroll
+        for (int s = 0; s < NK; ++s) qb[s] = 0.0f;
+        if (j < k_real) {
+            if (q_ext != nullptr) {
+#pragma unroll
+                for (int s = 0; s < NK; ++s) {
+                    const int k = h * NK + s;
+                    if (k < q_ld) qb[s] = q_ext[j * q_ld + k];
+                }
+            } else {
+                const float4* src = reinterpret_cast<const float4*>(Mr + (int64_t)my_med * LR + h * NK);
+#pragma unroll
+                for (int v = 0; v < NK / 4; ++v) {
+                    const float4 x = src[v];
+                    qb[4 * v + 0] = x.x; qb[4 * v + 1] = x.y; qb[4 * v + 2] = x.z; qb[4 * v + 3] = x.w;
+                }
+            }
+        }
+    }
+    for (int i = tid; i < KM; i += kBlock) med_s[i] = (int32_t)medoid.row[i];
+    for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
+    for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
+    for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
+    __syncthreads();
+    const float edge_hi = edges_s[VH_NBINS];
+    // smallest dot product whose distance 0.5f - dot (float32, round to nearest) is <= the last histogram edge, minus the filter's slack
+    float dot_min = 0.5f - edge_hi;
+    while (0.5f - __uint_as_float(__float_as_uint(dot_min) - 1u) <= edge_hi) dot_min = __uint_as_float(__float_as_uint(dot_min) - 1u);
+    while (!(0.5f - dot_min <= edge_hi)) dot_min = __uint_as_float(__float_as_uint(dot_min) + 1u);
+    dot_min -= 2.0f * ro.slack;
+    if (dbg & 1) dot_min = __builtin_inff();   // timing experiment: no pair of interest
+    int qn = 0;   // hits queued by this wavefront (uniform)
+    // The query registers must be KNOWN complete before the loop: otherwise the compiler keeps them "maybe pending" across the
+    // back edge and puts its own s_waitcnt vmcnt(0) in front of every chain -- which also drains our tile loads.
+#pragma unroll
+    for (int s = 0; s < NK; ++s) asm volatile("" ::"v"(qb[s]));
+
+    // Before any code the compiler is free to allocate registers for (the drain: up to +60 VGPRs) runs, NOTHING of ours is in flight:
+    // an asm load the compiler does not know about must never be pending while it shuffles registers.  (The drain starts with a
+    // load + wait of its own, which happens to drain the queue as well; this makes it deliberate.  Rare path: a drain per ~190 pairs.)
+    auto settle = [&]() {
+        if constexpr (NK == 16)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[0][2]), "+v"(xa[0][3]), "+v"(xa[1][0]), "+v"(xa[1][1]),
+                         "+v"(xa[1][2]), "+v"(xa[1][3]), "+v"(xa[DEPTH - 1][0]), "+v"(xa[DEPTH - 1][1]), "+v"(xa[DEPTH - 1][2]),
+                         "+v"(xa[DEPTH - 1][3]) : : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[0][2]), "+v"(xa[0][3]), "+v"(xa[0][4]), "+v"(xa[0][5]),
+                         "+v"(xa[0][6]), "+v"(xa[0][7]), "+v"(xa[DEPTH - 1][0]), "+v"(xa[DEPTH - 1][1]), "+v"(xa[DEPTH - 1][2]),
+                         "+v"(xa[DEPTH - 1][3]), "+v"(xa[DEPTH - 1][4]), "+v"(xa[DEPTH - 1][5]), "+v"(xa[DEPTH - 1][6]),
+                         "+v"(xa[DEPTH - 1][7]) : : "memory");
+    };
+    auto step = [&](scan_f32x4 (&t)[NK / 4]) {
+        const int64_t base = tile << 5;
+        scan_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        scan_tile_wait_rm<NK, (DEPTH - 1) * TILE_LOADS>(t);   // this tile has landed; the DEPTH - 1 behind it may still be in flight
+#pragma unroll
+        for (int q = 0; q < NK; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t[q >> 2][q & 3], qb[q], acc, 0, 0, 0);
+        scan_tile_load_rm<NK>(t, Mr, clamp_tile(tile + DEPTH * stride), lane_off);
+        // candidate test: the largest of the lane's 16 dot products against the threshold, one ballot
+        float m0 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]), m1 = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
+        float m2 = fmaxf(fmaxf(acc[6], acc[7]), acc[8]), m3 = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
+        float m4 = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
+        m0 = fmaxf(fmaxf(m0, m1), m2);
+        m3 = fmaxf(fmaxf(m3, m4), acc[15]);
+        if (__builtin_amdgcn_ballot_w64(fmaxf(m0, m3) >= dot_min) == 0ull) return;
+        // live flags of the tile's 32 rows: the same 32 bytes for every lane (scalar loads), looked at by candidate tiles only
+        const uint32_t* kp = reinterpret_cast<const uint32_t*>(kept + base);
+        uint32_t kw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kw[i] = __builtin_amdgcn_readfirstlane(kp[i]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // live flags of this half-wave's rows 8 q + 4 h .. + 3 = dword 2 q + h of the 8 flag dwords
+            const uint32_t live4 = h ? kw[2 * q + 1] : kw[2 * q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool hit = acc[4 * q + e] >= dot_min && ((live4 >> (8 * e)) & 0xFFu) != 0u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                if (m != 0ull) {
+                    if (hit) {
+                        const int64_t row = base + 8 * q + 4 * h + e;
+                        const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                        // (the drain fetches the row's length: taking it from a per-tile prefetch instead measured no faster)
+                        hq[pos] = make_float4(0.5f - acc[4 * q + e], 0.0f, __int_as_float((int32_t)row), __int_as_float(j));
+                    }
+                    qn += __popcll(m);
+                    if (qn > kHitCap - 64) {
+                        settle();
+                        drain_hits<true>(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, ro, lengths);
+                        qn = 0;
+                    }
+                }
+            }
+        }
+    };
+    while (tile < ntiles) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            if (tile < ntiles) {
+                step(xa[u]);
+                tile += stride;
+            }
+        }
+    }
+    settle();
+    drain_hits<true>(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, ro, lengths);
+    scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists, dbg);
+}
+
+// Mr[i][0 .. LR) = the normalised row i (L floats) + zero padding, rows >= n all zero
+__global__ __launch_bounds__(kBlock) void clu_rows_pad_kernel(const float* __restrict__ rows, int64_t n, int L,
+                                                              float* __restrict__ Mr, int64_t ld, int LR) {
+    const int64_t total = ld * (int64_t)LR;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = idx / LR;
+        const int c = (int)(idx - i * LR);
+        Mr[idx] = (i < n && c < L) ? rows[i * (int64_t)L + c] : 0.0f;
+    }
+}
+
+// compaction of the row-major copy: out[i][:] = in[src[i]][:] for i < n_new, zero rows behind (16 bytes per thread)
+__global__ __launch_bounds__(kBlock) void clu_gather_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                 const int32_t* __restrict__ src, int64_t n_new,
+                                                                 int64_t ld_out, int LR) {
+    const int q4 = LR / 4;
+    const int64_t total = ld_out * (int64_t)q4;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = idx / q4;
+        const int c = (int)(idx - i * q4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n_new) v = reinterpret_cast<const float4*>(in + (int64_t)src[i] * LR)[c];
+        reinterpret_cast<float4*>(out + i * (int64_t)LR)[c] = v;
+    }
 }
 
 // Query vectors of a many-medoid pass in quad-major order [L4 / 4][km][4] for the scalar loads of the pipelined scan
@@ -1322,6 +1548,8 @@ struct vh_clu {
     int64_t ld = 0;       // leading dimension (>= n_rows, multiple of 1024)
     hipStream_t stream = nullptr;
     DevBuf<float> Mt, Mt_alt, lengths, lengths_alt, q, qp;   // qp: quad-major queries of a many-medoid pass
+    DevBuf<float> Mr, Mr_alt;     // row-major copy [ld][LR] of the matrix for the row-major matrix-pipe pass (K6r), or empty
+    int LR = 0;                   // its row width: 32 or 64 floats (zero padded); 0 = no copy (K6m serves the many-medoid passes)
     DevBuf<uint8_t> kept;
     DevBuf<unsigned long long> results;
     // host-mapped (pinned, coherent) publication buffers written by the scan kernel itself
@@ -1497,6 +1725,22 @@ void launch_scan_mfma(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     else launch_scan_mfma_impl<NK, false>(h, med, q_ext);
 }
 
+// K6r: the same pass over the row-major copy (NK = LR / 2 floats per lane and tile)
+template <int NK>
+void launch_scan_mfma_rm(vh_clu* h, const MedoidRows& med, const float* q_ext) {
+    const size_t smem = scan_smem_bytes(kMaxMedoids, 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clu_scan_mfma_rm_kernel<NK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScanLdsBudget));
+        attr_set = true;
+    }
+    const int64_t tiles = h->ld >> 5;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(tiles, kBlock / 64), 256 * (NK <= 16 ? 3 : 2)));
+    hipLaunchKernelGGL((clu_scan_mfma_rm_kernel<NK>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mr.p, h->ld, h->lengths.p,
+                       h->kept.p, q_ext, h->L4, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg, ref_src(h));
+}
+
 // more than 8 medoids and a latent width the B operand registers hold: the matrix-pipe kernel (always 32 medoid slots)
 bool scan_uses_mfma(const vh_clu* h, int k) {
     return h->use_mfma && k > 8 && h->L4 <= 64 && h->max_k >= kMaxMedoids && h->ld < ((int64_t)1 << 28);   // 32-bit byte offsets
@@ -1523,7 +1767,9 @@ void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext)
         return;
     }
     if (h->mfma_pass) {
-        if (h->L4 <= 32) launch_scan_mfma<16>(h, med, q_ext);
+        if (h->LR == 32 && h->ref_filter) launch_scan_mfma_rm<16>(h, med, q_ext);
+        else if (h->LR == 64 && h->ref_filter) launch_scan_mfma_rm<32>(h, med, q_ext);
+        else if (h->L4 <= 32) launch_scan_mfma<16>(h, med, q_ext);
         else launch_scan_mfma<32>(h, med, q_ext);
         VH_HIP(hipGetLastError());
         return;
@@ -1663,6 +1909,14 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         VH_HIP(hipGetLastError());
         hipLaunchKernelGGL(clu_fill_kept_kernel, dim3(1024), dim3(256), 0, h->stream, h->kept.p, n, h->ld);
         VH_HIP(hipGetLastError());
+        // the row-major copy of K6r: only in the default mode (the tuned kernels as a filter) and for latent widths its operand
+        // registers hold; scan.mfma_rowmajor = 0 keeps K6m (A/B)
+        if (h->use_mfma && h->ref_filter && L <= 64 && h->max_k >= kMaxMedoids && option("scan.mfma_rowmajor", 1) != 0) {
+            h->LR = L <= 32 ? 32 : 64;
+            h->Mr.alloc((size_t)h->ld * h->LR);
+            hipLaunchKernelGGL(clu_rows_pad_kernel, dim3(2048), dim3(kBlock), 0, h->stream, staging.p, n, L, h->Mr.p, h->ld, h->LR);
+            VH_HIP(hipGetLastError());
+        }
         if (normalized_out)
             VH_HIP(hipMemcpyAsync(normalized_out, staging.p, (size_t)n * L * sizeof(float), hipMemcpyDeviceToHost,
                                   h->stream));
@@ -2137,10 +2391,17 @@ int vh_clu_pack(vh_clu* h, int64_t* new_rows) {
         hipLaunchKernelGGL(clu_gather_columns_kernel, dim3(gx, h->L4 + 1), dim3(kBlock), 0, h->stream, h->Mt.p, h->ld,
                            h->Mt_alt.p, ld_new, h->sel_rows.p, n_new, h->lengths.p, h->lengths_alt.p, h->L4);
         VH_HIP(hipGetLastError());
+        if (h->LR) {
+            h->Mr_alt.ensure((size_t)ld_new * h->LR);
+            hipLaunchKernelGGL(clu_gather_rows_kernel, dim3(gx), dim3(kBlock), 0, h->stream, h->Mr.p, h->Mr_alt.p, h->sel_rows.p, n_new,
+                               ld_new, h->LR);
+            VH_HIP(hipGetLastError());
+        }
         hipLaunchKernelGGL(clu_fill_kept_kernel, dim3(1024), dim3(256), 0, h->stream, h->kept.p, n_new, h->ld);
         VH_HIP(hipGetLastError());
         VH_HIP(hipStreamSynchronize(h->stream));
         std::swap(h->Mt, h->Mt_alt);
+        if (h->LR) std::swap(h->Mr, h->Mr_alt);
         std::swap(h->lengths, h->lengths_alt);
         h->ld = ld_new;
         h->n_rows = n_new;
