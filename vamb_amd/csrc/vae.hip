@@ -160,10 +160,12 @@ struct VaeTuning {
     int dw_workgroups = 256;  // vae.dw_workgroups: workgroups wanted per weight-gradient GEMM (split-K target)
     int pipeline = 2;         // vae.gemm_pipeline: K loop of the bf16 GEMMs.  2 = three LDS buffers, DMA pieces of tile t + 2 issued
                               // between the MFMA groups of tile t; 0 = the round-2 loop (two buffers, tile t + 1 requested up front)
-    int fork_at_loss = 0;     // vae.fork_at_loss: the side stream (running statistics, loss reduction, weight gradients) starts when the
-                              // loss kernel ends instead of after the first BatchNorm-backward kernel of the decoder (one more fork =
-                              // ~5 us on the main stream: 296 vs 286 us per step at C2, profiles/r03zc_fork_at_loss.txt; it only paid
-                              // while the loss reduction on the side stream still took 14 us)
+    int fork_at_loss = 1;     // vae.fork_at_loss: the side stream starts when the loss kernel ends instead of after the first
+                              // BatchNorm-backward kernel of the decoder.  One more fork costs the main stream ~5 us (round 3: 296 vs
+                              // 286 us per step, the default then was 0), but since round 5 the SIDE stream is what the optimiser waits for
+                              // at the end of a step (profiles/r05b_step_timeline_C2.txt: its last weight gradient ends ~10 us after the
+                              // main stream's, + the join): starting it 24 us earlier pays together with fork_plan = 6 (263.9 vs 268.8 us
+                              // and 257.5 vs 261.6 us per step on two boxes, profiles/r05c_step_fork_plans_c2.txt, r05d_*)
     bool opt_split = false;   // vae.opt_split: bf16 step, one GPU: the optimiser's decoder-side half runs on the side stream during the
                               // encoder's backward instead of at the end of the step.  Bit-identical, but measured SLOWER at C2 (300 vs
                               // 290 us per step, profiles/r03zj_opt_split.txt): the update streams 30 MB of gradient slabs and moments
@@ -180,7 +182,7 @@ struct VaeTuning {
                               // Bit-identical, measured SLOWER (C2: 272.5 vs 267.4 us per step, profiles/r05a_step_ab_c2.txt): ~1000
                               // arrivals on one ticket word (the guide's dequeue row: one word saturates at ~88 atomics per us) cost more
                               // than the 4.8 us launch they replace.  Off; kept as the measured negative.
-    int fork_plan = 0;        // vae.fork_plan (bf16 step, bit mask; A/B of the two-stream schedule): 1 = one more fork at the first decoder
+    int fork_plan = 6;        // vae.fork_plan (bf16 step, bit mask; the two-stream schedule; default 2 + 4, measured with fork_at_loss): 1 = one more fork at the first decoder
                               // layer's BatchNorm-backward kernel (its weight gradient and the mu layer's start there instead of at encoder
                               // layer 1); 2 = encoder layer 1's weight gradient on the MAIN stream behind layer 0's (the side stream's last
                               // batch ends before the main stream does); 4 = running statistics + loss reduction at the END of the side
@@ -188,6 +190,10 @@ struct VaeTuning {
                               // stream as well
     int fork_mode = 0;        // vae.fork_mode: 0 = forks ride on the producing kernel's completion signal (hipExtLaunchKernelGGL stop event);
                               // 2 = stream memory operations (a value written by the main stream, awaited by the side stream)
+    bool prefetch_batch = true; // vae.prefetch_batch: bf16 step: the gather of step t + 1 (10 MB read, 15 MB written at C2: 8.6 us on the
+                              // critical path) runs on the side stream during step t, FIRST in the batch of work the loss-kernel fork hands
+                              // over; the join in front of the optimiser -- already there -- covers it, so the main stream pays no extra
+                              // event (round 3 tried this with an event of its own and measured it neutral).  Same bits.
     int dz_dbg = 0;           // vae.dz_dbg: timing experiments on the elementwise BatchNorm-backward kernel (WRONG results): see Dz16Args
     bool dw_row_major = true; // vae.dw_row_major: bf16 weight gradients contract ROW-major tensors (gemm_bf16_tn.hpp); 0 = the
                               // round-2 dataflow with a transposed bf16 copy of every contracted tensor (A/B measurements)
@@ -198,14 +204,15 @@ void refresh_tuning() {
     g_tuning.xcd_remap = (int)option("vae.xcd_remap", 1);
     g_tuning.dw_workgroups = (int)option("vae.dw_workgroups", 256);
     g_tuning.dw_row_major = option("vae.dw_row_major", 1) != 0;
-    g_tuning.fork_at_loss = (int)option("vae.fork_at_loss", 0);
+    g_tuning.fork_at_loss = (int)option("vae.fork_at_loss", 1);
     g_tuning.dz_colsum = option("vae.dz_colsum", 1) != 0;
     g_tuning.opt_split = option("vae.opt_split", 0) != 0;
     g_tuning.pipeline = option("vae.gemm_pipeline", 2) == 0 ? 0 : 2;
     g_tuning.fused_skinny = option("vae.fused_skinny", 1) != 0;
     g_tuning.fused_finalize = option("vae.fused_finalize", 0) != 0;
     g_tuning.dz_dbg = (int)option("vae.dz_dbg", 0);
-    g_tuning.fork_plan = (int)option("vae.fork_plan", 0);
+    g_tuning.prefetch_batch = option("vae.prefetch_batch", 1) != 0;
+    g_tuning.fork_plan = (int)option("vae.fork_plan", 6);
     g_tuning.fork_mode = (int)option("vae.fork_mode", 0);
 }
 
@@ -299,6 +306,12 @@ struct vh_vae {
     // bf16-storage step (configs C2-C4; vae_step16.hpp)
     DevBuf<bf16_t> W16, W16T, zeros16;       // bf16 shadows of the flat parameter buffer (plain / transposed matrices)
     DevBuf<bf16_t> Xb16, Xb16T, Z16, Z16T, dR16, dR16T, dMU16, dMU16T, Wf16_mu, Wf16_out;
+    // next-batch prefetch (vae.prefetch_batch): the second set of batch buffers, what the running step was asked to fill, and whether
+    // the set holds the batch the next step needs
+    DevBuf<float> Xb_n, Wb_n;
+    DevBuf<bf16_t> Xb16_n;
+    DevBuf<int32_t> Lb_n;
+    bool prefetch_next = false, batch_prefetched = false;
     DevBuf<float> biasf_mu, biasf_out;
     double* dbias_mu = nullptr;              // fp64 column sums of dMU / dR (inside statbuf)
     double* dbias_out = nullptr;
@@ -1069,7 +1082,14 @@ void run_epoch_steps(vh_vae* h, const int64_t* dev_idx, int64_t n_batches) {
     count_batches(h, n_batches);
     const bool dbg = option("vae.debug_timing", 0) != 0;
     const auto t0 = std::chrono::steady_clock::now();
-    for (int64_t b = 0; b < n_batches; ++b) train_step_device(h, dev_idx, false, false);
+    for (int64_t b = 0; b < n_batches; ++b) {
+        // bf16 step: the NEXT batch of the epoch is assembled on the side stream during this step (vae.prefetch_batch)
+        // (narrow inputs only: at the C3 shape -- 1120 columns, 36 MB read + 55 MB written per batch -- the gather on the side stream
+        // delays the weight gradients the optimiser waits for: 380.5 vs 366.4 us per step, profiles/r05g_step_prefetch_batch.txt)
+        h->prefetch_next = h->bf16 && g_tuning.prefetch_batch && h->D_p <= 512 && b + 1 < n_batches && h->side != h->stream;
+        train_step_device(h, dev_idx, false, false);
+    }
+    h->prefetch_next = false;
     if (dbg) {
         const auto t1 = std::chrono::steady_clock::now();
         VH_HIP(hipStreamSynchronize(h->stream));

@@ -747,13 +747,32 @@ void optimizer_step16(vh_vae* h) {
     h->stat_clean = !h->keep_grads;
 }
 
-void gather_rows16(vh_vae* h, const int64_t* dev_idx, SideQueue& q) {
+// rows [base + batch * bs, ...) of the epoch's order -> (Xb, Xb16, Wb, Lb) on stream st; base = bs: the batch AFTER the cursor's
+void gather_launch16(vh_vae* h, const int64_t* dev_idx, hipStream_t st, int64_t base, float* Xb, bf16_t* Xb16, float* Wb, int32_t* Lb) {
     auto kern = h->kind == VH_VAE_PLAIN ? vae_gather16_kernel<false> : vae_gather16_kernel<true>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, h->stream,
+    hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, st,
                        (const float*)h->X.p, h->ld_src, (int64_t)h->D_p, (const float*)h->w.p, dev_idx, h->shuffle,
-                       (const long long*)&h->state.p->batch, (int64_t)0, h->bs, h->bs_p, h->Xb.p, h->Xb16.p, h->Wb.p,
-                       LabelSrc{h->labels, h->lab0}, h->Lb.p);
+                       (const long long*)&h->state.p->batch, base, h->bs, h->bs_p, Xb, Xb16, Wb,
+                       LabelSrc{h->labels, h->lab0}, Lb);
     VH_HIP(hipGetLastError());
+}
+
+void gather_rows16(vh_vae* h, const int64_t* dev_idx, SideQueue& q) {
+    if (h->batch_prefetched) {
+        // the previous step assembled this batch on the side stream (joined before its optimiser ran): take its buffers
+        std::swap(h->Xb, h->Xb_n); std::swap(h->Xb16, h->Xb16_n); std::swap(h->Wb, h->Wb_n); std::swap(h->Lb, h->Lb_n);
+        h->batch_prefetched = false;
+    } else {
+        gather_launch16(h, dev_idx, h->stream, 0, h->Xb.p, h->Xb16.p, h->Wb.p, h->Lb.p);
+    }
+    if (h->prefetch_next) {
+        // first in the side stream's queue: nothing on it depends on this batch, and it is ready long before the join
+        h->Xb_n.ensure(h->Xb.n); h->Xb16_n.ensure(h->Xb16.n); h->Wb_n.ensure(h->Wb.n); h->Lb_n.ensure(h->Lb.n);
+        q.add([h, dev_idx](hipStream_t st) {
+            gather_launch16(h, dev_idx, st, (int64_t)h->bs, h->Xb_n.p, h->Xb16_n.p, h->Wb_n.p, h->Lb_n.p);
+        });
+        h->batch_prefetched = true;
+    }
     // round-2 dataflow only: transposed copy of the batch for the first layer's weight gradient (needed last)
     if (!g_tuning.dw_row_major) q.add([h](hipStream_t st) { transpose16(h, st, h->Xb16.p, h->bs_p, h->D_p, h->Xb16T.p, nullptr, 0); });
 }
