@@ -194,6 +194,7 @@ struct VaeTuning {
                               // critical path) runs on the side stream during step t, FIRST in the batch of work the loss-kernel fork hands
                               // over; the join in front of the optimiser -- already there -- covers it, so the main stream pays no extra
                               // event (round 3 tried this with an event of its own and measured it neutral).  Same bits.
+    bool loss_dpp = true;     // vae.loss_dpp: bf16 loss kernel: row reductions by DPP instead of ds_bpermute (see vae_loss16_kernel)
     int dz_dbg = 0;           // vae.dz_dbg: timing experiments on the elementwise BatchNorm-backward kernel (WRONG results): see Dz16Args
     bool dw_row_major = true; // vae.dw_row_major: bf16 weight gradients contract ROW-major tensors (gemm_bf16_tn.hpp); 0 = the
                               // round-2 dataflow with a transposed bf16 copy of every contracted tensor (A/B measurements)
@@ -211,6 +212,7 @@ void refresh_tuning() {
     g_tuning.fused_skinny = option("vae.fused_skinny", 1) != 0;
     g_tuning.fused_finalize = option("vae.fused_finalize", 0) != 0;
     g_tuning.dz_dbg = (int)option("vae.dz_dbg", 0);
+    g_tuning.loss_dpp = option("vae.loss_dpp", 1) != 0;
     g_tuning.prefetch_batch = option("vae.prefetch_batch", 1) != 0;
     g_tuning.fork_plan = (int)option("vae.fork_plan", 6);
     g_tuning.fork_mode = (int)option("vae.fork_mode", 0);
@@ -267,6 +269,11 @@ struct vh_vae {
     // run on a second stream, forked after each layer's dZ is ready and joined before the update
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // joint trainer (vaevae.hpp), whose passes run on their own stream pairs: recorded on `stream` when forward() has the latent
+    // code (mu, z) complete, so that the passes fed by it need not wait for the decoder; and the running-statistics update of a
+    // pass left to the trainer, which orders the passes of one network as the reference's step does
+    hipEvent_t ev_latent_hook = nullptr;
+    bool defer_running = false;
     uint32_t* fork_flag = nullptr;    // vae.fork_mode = 2: signal memory the main stream writes and the side stream waits on
     uint32_t fork_seq = 0;
 
@@ -729,6 +736,23 @@ BnSrc bn_src(vh_vae* h, const Hidden& hl) {
 // neither the encoder's activations nor its running statistics; PASS_ENCODER (backward only) starts at h->dMUk.
 enum { PASS_FULL = 0, PASS_DECODER = 1, PASS_ENCODER = 2 };
 
+// BatchNorm1d's running statistics after a training-mode forward of the layers `part` names (momentum 0.1, unbiased variance),
+// from the batch sums the forward GEMMs' epilogues left in statbuf
+void update_running(vh_vae* h, int part, hipStream_t st) {
+    RunningTable rt;
+    memset(&rt, 0, sizeof(rt));
+    int maxn = 0;
+    for (int li = part == PASS_DECODER ? h->nl : 0; li < 2 * h->nl; ++li) {
+        Hidden& hl = h->hidden[li];
+        rt.fstat[rt.n] = hl.fstat; rt.rm[rt.n] = h->pptr(hl.tRM); rt.rv[rt.n] = h->pptr(hl.tRV);
+        rt.n_p[rt.n] = hl.nout_p;
+        maxn = std::max(maxn, hl.nout_p);
+        rt.n++;
+    }
+    hipLaunchKernelGGL(vae_bn_running_kernel, dim3((unsigned)ceil_div(maxn, 256), rt.n), dim3(256), 0, st, rt, stat_bs(h));
+    VH_HIP(hipGetLastError());
+}
+
 void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, bool add_noise, int part = PASS_FULL,
              const float* z_src = nullptr, const float* zero_bias = nullptr) {
     const int bs = h->bs, bs_p = h->bs_p;
@@ -812,6 +836,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
                            eps_injected ? h->EPS.p : nullptr, layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p,
                            h->Z.p, bs, h->L, h->L_p, bs_p);
         VH_HIP(hipGetLastError());
+        if (h->ev_latent_hook) VH_HIP(hipEventRecord(h->ev_latent_hook, s));
     }
     in = h->Z.p;
     in_w = h->L_p;
@@ -838,19 +863,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
     if (training) {
         // running statistics (momentum 0.1, unbiased variance): off the critical path, on the side stream
         if (!fork_from_kernel(h)) fork_side(h);
-        RunningTable rt;
-        memset(&rt, 0, sizeof(rt));
-        int maxn = 0;
-        for (int li = part == PASS_DECODER ? h->nl : 0; li < 2 * h->nl; ++li) {
-            Hidden& hl = h->hidden[li];
-            rt.fstat[rt.n] = hl.fstat; rt.rm[rt.n] = h->pptr(hl.tRM); rt.rv[rt.n] = h->pptr(hl.tRV);
-            rt.n_p[rt.n] = hl.nout_p;
-            maxn = std::max(maxn, hl.nout_p);
-            rt.n++;
-        }
-        hipLaunchKernelGGL(vae_bn_running_kernel, dim3((unsigned)ceil_div(maxn, 256), rt.n), dim3(256), 0, h->side, rt,
-                           stat_bs(h));
-        VH_HIP(hipGetLastError());
+        if (!h->defer_running) update_running(h, part, h->side);
     }
 }
 

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "gemm.hpp"
 
@@ -30,6 +31,30 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
     return v;
 }
+
+// The same reductions on the VALU's data-parallel primitives (DPP) instead of six ds_bpermute round trips through the LDS
+// crossbar: quad swaps, the two row mirrors (every lane of a 16-lane row then holds its row's result), row_bcast:15 / :31 (lane 63
+// holds the wave's) and one v_readlane.  ~8 VALU-rate steps instead of 6 x (LDS issue + lgkmcnt wait) -- in a kernel whose duration
+// IS one wavefront's dependent chain (the bf16 loss kernel: one row per wavefront, ten reductions per row, 60 ds_bpermute in its
+// ISA) that is microseconds.  The order of the additions differs from the butterfly's: same value up to float32 rounding.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float x) {   // rows outside ROW_MASK keep x
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, false));
+}
+template <class Op>
+__device__ __forceinline__ float wave_reduce_dpp(float v, Op op) {
+    v = op(v, dpp_move<0xB1, 0xF>(v));    // quad_perm [1,0,3,2]
+    v = op(v, dpp_move<0x4E, 0xF>(v));    // quad_perm [2,3,0,1]
+    v = op(v, dpp_move<0x141, 0xF>(v));   // row_half_mirror
+    v = op(v, dpp_move<0x140, 0xF>(v));   // row_mirror: every lane of a row now holds the row's result
+    // row_bcast:15 brings lane 15 of rows 0/2 into rows 1/3, row_bcast:31 lane 31 into rows 2/3.  Only lane 63 is read afterwards and
+    // both steps write its row, so what the other rows hold after these two steps does not matter.
+    v = op(v, dpp_move<0x142, 0xA>(v));
+    v = op(v, dpp_move<0x143, 0xC>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) { return wave_reduce_dpp(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float wave_max_dpp(float v) { return wave_reduce_dpp(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 // ---- batch assembly ----------------------------------------------------------------------------
 // Epoch shuffle without a permutation array: a keyed bijection of [0, 2^bits) (odd multiplies and

@@ -274,7 +274,12 @@ struct Loss16Args {
 
 // 8 waves per SIMD: the compiler's own choice was 95 VGPRs (5 waves per SIMD, 1280 of the 2048 workgroups of a batch of 8192
 // resident at once); with 50 VGPRs every row's wavefront is resident from the start: 14.4 -> 12.8 us (profiles/r03zf_*)
+// DPP: the ten per-row reductions on the VALU's data-parallel primitives (wave_reduce_dpp) instead of ds_bpermute butterflies
+// (option vae.loss_dpp; the sums are then formed in another order: same value up to float32 rounding)
+template <bool DPP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void vae_loss16_kernel(const Loss16Args a) {
+    auto rsum = [](float v) { return DPP ? wave_sum_dpp(v) : wave_sum(v); };
+    auto rmax = [](float v) { return DPP ? wave_max_dpp(v) : wave_max(v); };
     // dynamic LDS: per wave the reconstruction row and the target row, read from HBM once with 16-byte loads (the
     // softmax / CE / SSE passes below re-read them four times)
     extern __shared__ __attribute__((aligned(16))) float loss_rows[];   // [4 waves][2][ld]
@@ -306,14 +311,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             // the kernel was bound by libm-accurate transcendentals (3 expf + logf per element: 17 us at C2)
             float mx = -3.0e38f;
             for (int c = lane; c < S; c += 64) mx = fmaxf(mx, r[c]);
-            mx = wave_max(mx);
+            mx = rmax(mx);
             float se = 0.f;
             for (int c = lane; c < S; c += 64) {
                 const float e = __expf(r[c] - mx);
                 r[c] = e;
                 se += e;
             }
-            se = wave_sum(se);
+            se = rsum(se);
             const float inv = S > 0 ? 1.0f / se : 0.0f;
             float ce = 0.f, pdp = 0.f;
             for (int c = lane; c < S; c += 64) {
@@ -326,8 +331,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 r[c] = p;
                 x[c] = t;
             }
-            ce = wave_sum(ce);
-            pdp = wave_sum(pdp);
+            ce = rsum(ce);
+            pdp = rsum(pdp);
             const float gce = g * a.ce_w;
             for (int c = lane; c < S; c += 64) dr[c] = f2bf(gce * r[c] * (-x[c] - pdp));
             float sse = 0.f;
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 sse += diff * diff;
                 dr[c] = f2bf(gsse * diff);
             }
-            sse = wave_sum(sse);
+            sse = rsum(sse);
             float ab = 0.f;
             if (lane == 0 && a.nab) {
                 const int c = S + a.ntnf;
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 ab = diff * diff;
                 dr[c] = f2bf(g * a.ab_w * 2.0f * diff);
             }
-            ab = wave_sum(ab);
+            ab = rsum(ab);
             if (a.NL > 0)
                 label_block(r + a.lab0, a.NL, a.Lb[row], g, [&](int c, float v) { dr[a.lab0 + c] = f2bf(v); }, cel_t, hit_t);
             for (int c = S + a.ntnf + a.nab + a.NL + lane; c < a.ld; c += 64) dr[c] = 0;
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 kld += m * m;
                 dm[c] = gk * m;
             }
-            kld = 0.5f * wave_sum(kld);
+            kld = 0.5f * rsum(kld);
             ab_t = ab * a.ab_w;
             ce_t = ce * a.ce_w;
             sse_t = sse * a.sse_w;

@@ -188,7 +188,9 @@ struct SideQueue {
     std::vector<std::function<void(hipStream_t)>> tail;   // small items nobody but the optimiser waits for (vae.fork_plan & 4)
     void add(std::function<void(hipStream_t)> f) { items.push_back(std::move(f)); }
     void add_small(std::function<void(hipStream_t)> f) {
-        if (g_tuning.fork_plan & 4) tail.push_back(std::move(f));
+        // (vae.opt_split updates half of the parameters on the side stream DURING the backward and needs this step's loss reduction
+        // -- the sum of the batch's weights -- in front of it: round 5's first build ran it behind, on the previous step's sum)
+        if ((g_tuning.fork_plan & 4) && !g_tuning.opt_split) tail.push_back(std::move(f));
         else items.push_back(std::move(f));
     }
     void flush(hipStream_t s) {
@@ -485,14 +487,17 @@ void loss_and_seed16(vh_vae* h, SideQueue& q) {
     VH_REQUIRE(loss_lds <= 160 * 1024 - 256, "%d input columns are too wide for the bf16 step's loss kernel (fp32 mode has no limit)", h->D);
     static bool loss_attr = false;
     if (!loss_attr) {
-        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_loss16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_loss16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024 - 256));
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_loss16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024 - 256));
         loss_attr = true;
     }
+    auto kern = g_tuning.loss_dpp ? vae_loss16_kernel<true> : vae_loss16_kernel<false>;
     if (g_tuning.fork_at_loss) {   // the side stream's first items (see backward16) only need what this kernel leaves
-        launch_forking(h, vae_loss16_kernel, dim3(h->loss_blocks), dim3(256), loss_lds, a);
+        launch_forking(h, kern, dim3(h->loss_blocks), dim3(256), loss_lds, a);
     } else {
-        hipLaunchKernelGGL(vae_loss16_kernel, dim3(h->loss_blocks), dim3(256), loss_lds, h->stream, a);
+        hipLaunchKernelGGL(kern, dim3(h->loss_blocks), dim3(256), loss_lds, h->stream, a);
         VH_HIP(hipGetLastError());
     }
     // the scalar reduction (loss means, sum of weights) is only needed by the optimiser
