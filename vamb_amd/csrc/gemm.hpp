@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 namespace vh {
 
@@ -141,8 +142,28 @@ __device__ __forceinline__ void bn_column(const BnSrc& s, int col, float& mean, 
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
+// a 16-byte global load the compiler does not track (its completion is awaited by a hand-written s_waitcnt), and the empty asm
+// a register passes through so that no use of it is scheduled above that wait
+using f32x4 = __attribute__((ext_vector_type(4))) float;   // (a register tuple for the asm constraints; HIP's float4 is a struct)
+__device__ __forceinline__ void asm_load_x4(f32x4& dst, const float* src) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
+__device__ __forceinline__ void asm_pin_x4(f32x4& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ float4 keep4(float4 v, bool keep) {   // (component selects: a ?: between two structs goes through memory)
+    v.x = keep ? v.x : 0.f; v.y = keep ? v.y : 0.f; v.z = keep ? v.z : 0.f; v.w = keep ? v.w : 0.f;
+    return v;
+}
+__device__ __forceinline__ float4 as_float4(const float4& v) { return v; }
+__device__ __forceinline__ float4 as_float4(const f32x4& v) { return make_float4(v.x, v.y, v.z, v.w); }
+
+// PF (fp32 operands only): K-tiles kept in flight in registers.  1 = the loop as it always was (tile t + 1 requested while tile t
+// is contracted): right when several workgroups share a CU and hide each other's latency.  4 = the small-batch variant (the joint
+// TaxVamb step at batch 256: 32 workgroups on 256 CUs, each alone on its CU with a 16-deep K loop whose every iteration waited a
+// full L2 / HBM round trip, ~1.3 us, for 0.43 us of MFMA work): tile t + 4 is requested while tile t is contracted, every load
+// unconditional (clamped to the matrix; out-of-range rows are zeroed on the way into LDS) so that the compiler's counted vmcnt
+// waits survive.  The host picks it when the K loop is a multiple of PF tiles deep (launch_gemm).
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE,
-          int BK = 32, int DT = 0>
+          int BK = 32, int DT = 0, int PF = 1>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g) {
     // DT = 0: fp32 operands on v_mfma_f32_32x32x2_f32.  DT = 1 (BASELINE configs C2+): the operands are
     // rounded to bf16 (RNE) while they are staged into LDS and contracted on v_mfma_f32_32x32x16_bf16 with
@@ -159,6 +180,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     static_assert(NT % KQ == 0, "every unit of a thread shares its k-quad");
     static_assert(WM * WN == 4 || WM * WN == 1, "4 wavefronts per workgroup, or a single free-running one");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
+    static_assert(PF == 1 || DT == 0, "the deep prefetch is an fp32-operand variant");
 
     // LDS image of an operand tile: [rows][32 floats], i.e. K-contiguous rows of 8 quads (16 B each), the
     // quad of logical index kq stored in slot kq ^ swz(row).  Every fragment read is one ds_read_b128 (256
@@ -252,7 +274,51 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     float4 ra[UA], rb[UB];
+    f32x4 rra[PF][UA], rrb[PF][UB];   // PF > 1 only
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // PF > 1: stage st <- K-tile at k0, unconditionally (rows clamped to the matrix).  The loads and the waits for them are
+    // written out: left to the compiler, a register that rotates through the stages of the unrolled loop is "maybe pending" at
+    // the loop's back edge and every wait becomes vmcnt(0) -- the round trip per iteration the variant exists to remove.
+    // stage_wait(st) returns when stage st's loads have landed, given that exactly PF - 1 younger stages are in flight.
+    auto gload_pf = [&](int st, int k0) {   // (st is a constant after unrolling)
+#pragma unroll
+        for (int r = 0; r < UA; ++r) {
+            const int u = min(tid + NT * r, BM * KQ - 1);
+            const float* src;
+            if constexpr (A_KC) {
+                const int row = u / KQ, kq = u % KQ, gm = min(m0 + row, g.M - 1);
+                src = g.A + (int64_t)gm * g.lda + k0 + 4 * kq;
+            } else {
+                const int k = u / (BM / 4), mq = u % (BM / 4), gm = min(m0 + 4 * mq, g.M - 4);
+                src = g.A + (int64_t)(k0 + k) * g.lda + gm;
+            }
+            asm_load_x4(rra[st][r], src);
+        }
+#pragma unroll
+        for (int r = 0; r < UB; ++r) {
+            const int u = min(tid + NT * r, BN * KQ - 1);
+            const float* src;
+            if constexpr (B_KC) {
+                const int row = u / KQ, kq = u % KQ, gn = min(n0 + row, g.N - 1);
+                src = g.B + (int64_t)gn * g.ldb + k0 + 4 * kq;
+            } else {
+                const int k = u / (BN / 4), nq = u % (BN / 4), gn = min(n0 + 4 * nq, g.N - 4);
+                src = g.B + (int64_t)(k0 + k) * g.ldb + gn;
+            }
+            asm_load_x4(rrb[st][r], src);
+        }
+    };
+    auto stage_wait = [&](int st) {
+        constexpr int behind = (PF - 1) * (UA + UB);
+        static_assert(behind < 64, "vmcnt is a 6-bit counter");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(behind) : "memory");
+        // (the stage's registers pass through an empty asm so that nothing reading them is scheduled above the wait)
+#pragma unroll
+        for (int r = 0; r < UA; ++r) asm_pin_x4(rra[st][r]);
+#pragma unroll
+        for (int r = 0; r < UB; ++r) asm_pin_x4(rrb[st][r]);
+    };
 
     // Global -> registers for the K-tile starting at k0.
     //   K-contiguous operand: unit u = (row u/8, quad u%8): one float4 = 4 consecutive k of one row.
@@ -410,8 +476,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     };
 
     // registers -> LDS (applied when the prefetched data has arrived)
-    auto sstore = [&](int buf, int k0) {
-        if constexpr (BF) { sstore_bf16(buf, k0); return; }
+    auto sstore_from = [&](const auto& xa, const auto& xb, int buf, int k0) {
+        constexpr bool kFullA = (BM * KQ) % NT == 0, kFullB = (BN * KQ) % NT == 0;   // every thread's every unit is inside the tile
         float* as = As + buf * TILE_A;
         float* bs = Bs + buf * TILE_B;
         // every unit of a thread has the same k-quad (NT is a multiple of 8): one coefficient pair per K-tile
@@ -443,39 +509,57 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
 #pragma unroll
         for (int r = 0; r < UA; ++r) {
             const int u = tid + NT * r;
-            float4 v = ra[r];
+            float4 v = as_float4(xa[r]);
             if constexpr (A_KC) {
                 const int row = u / KQ, kq = u % KQ;
+                if constexpr (PF > 1) v = keep4(v, m0 + row < g.M);   // (the deep prefetch loads clamped rows)
                 if constexpr (XFA == XF_BN) v = fma4(v, sA, tA);
-                if (u < BM * KQ) *reinterpret_cast<float4*>(as + row * BK + 4 * (kq ^ swz(row))) = v;
+                if (kFullA || u < BM * KQ) *reinterpret_cast<float4*>(as + row * BK + 4 * (kq ^ swz(row))) = v;
             } else {
                 const int k = u / (BM / 4), mq = u % (BM / 4);
+                if constexpr (PF > 1) v = keep4(v, m0 + 4 * mq < g.M);
                 if constexpr (kRowQuadA) v = fma4(v, sA, tA);
                 else if constexpr (XFA == XF_BN) v = bn4(v, coefA + 4 * mq, coefA + ncolA + 4 * mq);
-                if (u < BM * KQ) *reinterpret_cast<float4*>(as + k * SA + 4 * mq) = v;
+                if (kFullA || u < BM * KQ) *reinterpret_cast<float4*>(as + k * SA + 4 * mq) = v;
             }
         }
 #pragma unroll
         for (int r = 0; r < UB; ++r) {
             const int u = tid + NT * r;
-            float4 v = rb[r];
+            float4 v = as_float4(xb[r]);
             if constexpr (B_KC) {
                 const int row = u / KQ, kq = u % KQ;
+                if constexpr (PF > 1) v = keep4(v, n0 + row < g.N);
                 if constexpr (XFB == XF_BN) v = fma4(v, sB, tB);
-                if (u < BN * KQ) *reinterpret_cast<float4*>(bs + row * BK + 4 * (kq ^ swz(row))) = v;
+                if (kFullB || u < BN * KQ) *reinterpret_cast<float4*>(bs + row * BK + 4 * (kq ^ swz(row))) = v;
             } else {
                 const int k = u / (BN / 4), nq = u % (BN / 4);
+                if constexpr (PF > 1) v = keep4(v, n0 + 4 * nq < g.N);
                 if constexpr (kRowQuadB) v = fma4(v, sB, tB);
                 else if constexpr (XFB == XF_BN) v = bn4(v, coefB + 4 * nq, coefB + ncolB + 4 * nq);
-                if (u < BN * KQ) *reinterpret_cast<float4*>(bs + k * SB + 4 * nq) = v;
+                if (kFullB || u < BN * KQ) *reinterpret_cast<float4*>(bs + k * SB + 4 * nq) = v;
             }
         }
     };
+    auto sstore = [&](int buf, int k0) {
+        if constexpr (BF) sstore_bf16(buf, k0);
+        else sstore_from(ra, rb, buf, k0);
+    };
 
-    if (nchunks > 0) gload(kbeg);
-    __syncthreads();   // coefficient tables are complete
-    if (nchunks > 0) sstore(0, kbeg);
-    __syncthreads();
+    if constexpr (PF > 1) {
+        // the host guarantees nchunks % PF == 0 (launch_gemm): the first PF tiles go out together
+#pragma unroll
+        for (int st = 0; st < PF; ++st) gload_pf(st, kbeg + st * BK);
+        __syncthreads();   // coefficient tables are complete
+        stage_wait(0);
+        sstore_from(rra[0], rrb[0], 0, kbeg);
+        __syncthreads();
+    } else {
+        if (nchunks > 0) gload(kbeg);
+        __syncthreads();   // coefficient tables are complete
+        if (nchunks > 0) sstore(0, kbeg);
+        __syncthreads();
+    }
 
     // MFMA 32x32x2: lanes 0-31 feed k-slot 0, lanes 32-63 k-slot 1 of each step.  Lane (r, h) reads the
     // quads 2q + h of its row, so step 4q + j contracts k = 8q + j (h = 0) with k = 8q + 4 + j (h = 1):
@@ -500,38 +584,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
         for (int q = 0; q < NQ; ++q)
             b_off[j][q] = B_KC ? row * BK + 4 * ((2 * q + frag_h) ^ swz(row)) : (8 * q + 4 * frag_h) * SB + row;
     }
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) gload(kbeg + (c + 1) * BK);
-        if constexpr (BF) {
-            // two 32x32x16 steps per K-tile: lane (r, h) supplies k = 16 t + 8 h .. + 7 of its row (A and B alike)
-            const unsigned short* as16 = reinterpret_cast<const unsigned short*>(As + buf * TILE_A);
-            const unsigned short* bs16 = reinterpret_cast<const unsigned short*>(Bs + buf * TILE_B);
-            bf16x8 a8[TM][2], b8[TN][2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = (wm * TM + i) * 32 + frag_r;
-                    a8[i][t] = *reinterpret_cast<const bf16x8*>(as16 + row * 32 + 8 * ((2 * t + frag_h) ^ swzb(row)));
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int row = (wn * TN + j) * 32 + frag_r;
-                    b8[j][t] = *reinterpret_cast<const bf16x8*>(bs16 + row * 32 + 8 * ((2 * t + frag_h) ^ swzb(row)));
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i][t], b8[j][t], acc[i][j], 0, 0, 0);
-            if (c + 1 < nchunks) sstore(buf ^ 1, kbeg + (c + 1) * BK);
-            __syncthreads();
-            continue;
-        }
+    // contraction of the K-tile in LDS buffer `buf` (fp32 operands)
+    auto contract = [&](int buf) {
         const float* as = As + buf * TILE_A;
         const float* bs = Bs + buf * TILE_B;
         float af[TM][NQ][4], bf[TN][NQ][4];
@@ -567,6 +621,56 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q][e], bf[j][q][e], acc[i][j], 0, 0, 0);
+    };
+    if constexpr (PF > 1) {
+        // stage (c % PF) holds tile c; it was copied into LDS one iteration ago, so tile c + PF may overwrite it now
+        for (int c0 = 0; c0 < nchunks; c0 += PF) {
+#pragma unroll
+            for (int st = 0; st < PF; ++st) {
+                const int c = c0 + st;
+                const int buf = c & 1;
+                gload_pf(st, kbeg + min(c + PF, nchunks - 1) * BK);   // (past the end: a harmless re-read of the last tile)
+                contract(buf);
+                stage_wait((st + 1) % PF);
+                if (c + 1 < nchunks) sstore_from(rra[(st + 1) % PF], rrb[(st + 1) % PF], buf ^ 1, kbeg + (c + 1) * BK);
+                __syncthreads();
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-reads of the last tile: their registers are free after this
+    } else
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) gload(kbeg + (c + 1) * BK);
+        if constexpr (BF) {
+            // two 32x32x16 steps per K-tile: lane (r, h) supplies k = 16 t + 8 h .. + 7 of its row (A and B alike)
+            const unsigned short* as16 = reinterpret_cast<const unsigned short*>(As + buf * TILE_A);
+            const unsigned short* bs16 = reinterpret_cast<const unsigned short*>(Bs + buf * TILE_B);
+            bf16x8 a8[TM][2], b8[TN][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wm * TM + i) * 32 + frag_r;
+                    a8[i][t] = *reinterpret_cast<const bf16x8*>(as16 + row * 32 + 8 * ((2 * t + frag_h) ^ swzb(row)));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = (wn * TN + j) * 32 + frag_r;
+                    b8[j][t] = *reinterpret_cast<const bf16x8*>(bs16 + row * 32 + 8 * ((2 * t + frag_h) ^ swzb(row)));
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i][t], b8[j][t], acc[i][j], 0, 0, 0);
+            if (c + 1 < nchunks) sstore(buf ^ 1, kbeg + (c + 1) * BK);
+            __syncthreads();
+            continue;
+        }
+        contract(buf);
         if (c + 1 < nchunks) sstore(buf ^ 1, kbeg + (c + 1) * BK);
         __syncthreads();
     }

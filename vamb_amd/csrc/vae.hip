@@ -84,12 +84,12 @@ thread_local hipEvent_t t_probe_start = nullptr, t_probe_stop = nullptr;
 thread_local hipEvent_t t_fork_stop = nullptr;
 
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE,
-          int BK = 32, int DT = 0>
+          int BK = 32, int DT = 0, int PF = 1>
 void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
     static bool attr_set = false;
     const size_t smem = gemm_smem_bytes<BM, BN, AKC, BKC, EPI, XFA, XFB, BK, DT>(g.k_per_split);
     VH_REQUIRE(smem <= kMaxDynLds, "layer too wide for the fused GEMM (needs %zu bytes of LDS)", smem);
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AKC, BKC, EPI, XFA, XFB, BK, DT>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AKC, BKC, EPI, XFA, XFB, BK, DT, PF>;
     if (!attr_set) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kMaxDynLds));
@@ -108,6 +108,16 @@ void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
     VH_HIP(hipGetLastError());
 }
 
+// Small launches (at most one workgroup per CU, e.g. every GEMM of the joint TaxVamb step at batch 256) with a K loop that is a
+// multiple of four tiles deep run the deep-prefetch instantiation of the fp32 kernel (gemm.hpp, PF = 4; option vae.gemm_prefetch).
+int g_gemm_prefetch = 4;
+bool deep_prefetch(const GemmArgs& g, int bm, int bn, int splits) {
+    if (g_gemm_prefetch != 4 || g.bf16) return false;
+    const int64_t wgs = ceil_div(g.M, bm) * ceil_div(g.N, bn) * splits;
+    const int kp = g.k_per_split;
+    return wgs <= 256 && kp % 128 == 0 && kp >= 256 && (int64_t)kp * splits == g.K && g.M >= 4 && g.N >= 4;
+}
+
 // (64-wide K-tiles for the forward GEMMs of the step -- tile 4 of vh_debug_gemm -- measured +4-7 % for an isolated GEMM
 // and nothing for the step, 351.5 vs 351.0 us, and slower on the backward GEMMs: not wired into the step.)
 // production tiles: 3 = 64x64 (2x2 waves, 2 workgroups per CU), 2 = 128x32 (4x1) for latent-wide outputs
@@ -121,6 +131,7 @@ void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
     if (tile == 2) launch_gemm<128, 32, 4, 1, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
     else if (tile == 1) launch_gemm<128, 128, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
     else if (tile == 0) launch_gemm<64, 128, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
+    else if (deep_prefetch(g, 64, 64, splits)) launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB, 32, 0, 4>(s, g, splits);
     else launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
 }
 
@@ -143,6 +154,7 @@ void gemm_tile_debug(hipStream_t s, int tile, const GemmArgs& g, int splits) {
         case 1: launch_gemm<128, 128, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
         case 2: launch_gemm<128, 32, 4, 1, AKC, BKC, EPI>(s, g, splits); break;
         case 4: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XF_NONE, XF_NONE, 64>(s, g, splits); break;
+        case 6: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XF_NONE, XF_NONE, 32, 0, 4>(s, g, splits); break;   // deep prefetch
         case 5: launch_gemm<32, 32, 1, 1, AKC, BKC, EPI>(s, g, splits); break;
         default: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
     }
@@ -213,6 +225,7 @@ void refresh_tuning() {
     g_tuning.fused_finalize = option("vae.fused_finalize", 0) != 0;
     g_tuning.dz_dbg = (int)option("vae.dz_dbg", 0);
     g_tuning.loss_dpp = option("vae.loss_dpp", 1) != 0;
+    g_gemm_prefetch = (int)option("vae.gemm_prefetch", 4);
     g_tuning.prefetch_batch = option("vae.prefetch_batch", 1) != 0;
     g_tuning.fork_plan = (int)option("vae.fork_plan", 6);
     g_tuning.fork_mode = (int)option("vae.fork_mode", 0);
@@ -2094,7 +2107,8 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
         VH_REQUIRE(A && B && C, "NULL argument");
         const bool use_bf16 = tile >= 100;   // tile + 100: the bf16-operand instantiation of that tile
         if (use_bf16) tile -= 100;
-        VH_REQUIRE(tile >= 0 && tile <= 5 && !(tile == 4 && use_bf16), "tile in {0..5} (+100 for bf16 operands, not tile 4)");
+        VH_REQUIRE(tile >= 0 && tile <= 6 && !((tile == 4 || tile == 6) && use_bf16), "tile in {0..6} (+100 for bf16 operands, not tiles 4, 6)");
+        VH_REQUIRE(tile != 6 || ((K / std::max(1, splits)) % 128 == 0 && K % std::max(1, splits) == 0), "tile 6 needs K / splits multiple of 128");
         VH_REQUIRE(tile != 4 || (K % 64 == 0 && (K / std::max(1, splits)) % 64 == 0), "tile 4 needs K multiple of 64");
         VH_REQUIRE(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && M % 4 == 0 && N % 4 == 0,
                    "need K multiple of 32 and M, N multiples of 4");
@@ -2131,13 +2145,14 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
             }
         };
         run();  // warm-up (also sets the LDS attribute)
+        const int reps = std::max(1, (int)option("debug.gemm_reps", 1));   // back-to-back launches timed together (ms per launch)
         VH_HIP(hipEventRecord(e0, s));
-        run();
+        for (int r = 0; r < reps; ++r) run();
         VH_HIP(hipEventRecord(e1, s));
         VH_HIP(hipStreamSynchronize(s));
         float t = 0.f;
         VH_HIP(hipEventElapsedTime(&t, e0, e1));
-        if (ms) *ms = t;
+        if (ms) *ms = t / (float)reps;
         std::vector<float> hc((size_t)nsplit * M * N);
         VH_HIP(hipMemcpy(hc.data(), dC.p, sizeof(float) * hc.size(), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < (size_t)M * N; ++i) {
