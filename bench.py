@@ -224,16 +224,17 @@ def scan_summary(timed, wall, measured_in):
     }
 
 
-def pmc_traffic(tag):
+def pmc_traffic(tag, want_source=False):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
-    for rnd in ("r04t", "r03"):   # the latest committed passes first
+    for rnd in ("r05z", "r04t", "r03"):   # the latest committed passes first
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_roofline_{tag}.json")
         try:
             with open(path) as fh:
-                return json.load(fh).get("hbm_bytes_per_launch")
+                v = json.load(fh).get("hbm_bytes_per_launch")
+                return (v, os.path.relpath(path, ROOT)) if want_source else v
         except (OSError, ValueError):
             continue
-    return None
+    return (None, None) if want_source else None
 
 
 def config_leg(args, name, ve, vc, lib, _lib, synth, epochs, steps=3, warmup=1, est_job_s=None):
@@ -656,10 +657,10 @@ def main():
         roof = probe_roofline(results, f"{gemm_kind}: encoder layer 0, M=batch={args.batch}, K=D={D}, N=512 "
                                        "(bias + leaky-relu + dropout + BatchNorm batch sums in the epilogue)", peak)
         if roof is not None:
-            roof["traffic"] = pmc_traffic(cfg_name.lower())
-            roof["traffic_source"] = (f"static: profiles/r04t_pmc_roofline_{cfg_name.lower()}.json (rocprofv3 --pmc passes of this kernel "
-                                      "at this shape on the round-4 build, profiles/run_r04_pmc.sh: FETCH_SIZE doubled as the gfx950 guide "
-                                      "prescribes + WRITE_SIZE, separate passes); NOT counted in this run")
+            roof["traffic"], src = pmc_traffic(cfg_name.lower(), want_source=True)
+            roof["traffic_source"] = (f"static: {src} (rocprofv3 --pmc passes of this kernel at this shape, profiles/run_r05_final.sh "
+                                      "for r05z / run_r04_pmc.sh for r04t: FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE, "
+                                      "separate passes); NOT counted in this run")
             if roof["traffic"]:
                 # the same launches against the other roofline: at C2 the kernel's arithmetic intensity (flops / PMC bytes)
                 # is below the ridge of 2.5 PFLOP/s : 8 TB/s = 312 flop/B, i.e. it is the HBM side that binds there

@@ -86,6 +86,31 @@ def test_gemm_wide_k_tile(layout, shape):
     assert rel(C, want) < 2e-6 * np.sqrt(K)
 
 
+@pytest.mark.parametrize("layout", [(1, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("shape", [(256, 512, 512, 1), (260, 36, 256, 1), (100, 200, 512, 2), (512, 512, 1024, 4), (64, 64, 128, 1)])
+def test_gemm_deep_prefetch_tile(layout, shape):
+    """Tile 6 = the 64x64 workgroup tile with four K-tiles in flight (gemm.hpp, PF = 4: hand-written loads, counted waits, clamped
+    rows): what the fp32 step launches when a GEMM has at most one workgroup per CU (the joint TaxVamb step at batch 256).  Same
+    MFMA order as tile 3, so the two must agree to the bit; ragged M / N exercise the clamping."""
+    M, N, K, splits = shape
+    a_kc, b_kc = layout
+    rng = np.random.RandomState(M + N + K + 11)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = (rng.standard_normal((N, K)) + 0.25 * np.arange(N)[:, None] / N).astype(np.float32)
+    want = A.astype(np.float64) @ B.astype(np.float64).T
+    Ad = np.ascontiguousarray(A if a_kc else A.T)
+    Bd = np.ascontiguousarray(B if b_kc else B.T)
+    out = {}
+    for tile in (6, 3):
+        C = np.zeros((M, N), np.float32)
+        ms = ctypes.c_float()
+        _lib.check(_lib.load().vh_debug_gemm(tile, a_kc, b_kc, _lib.ptr(Ad), _lib.ptr(Bd), None, _lib.ptr(C), M, N, K, splits,
+                                             ctypes.byref(ms)))
+        out[tile] = C
+    assert rel(out[6], want) < 2e-6 * np.sqrt(K)
+    assert np.array_equal(out[6], out[3])
+
+
 def bf16_round(x):
     """float32 -> bf16 (round to nearest even) -> float32, as the staging path of the bf16 GEMMs does."""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)

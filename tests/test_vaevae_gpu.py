@@ -109,6 +109,21 @@ def test_joint_training_steps_match_reference_and_oracle(name):
     assert np.abs(latv - g["latent_vamb"]).max() <= np.abs(g["latent_vamb"]).max() * 2.0 ** -9
 
 
+@pytest.mark.parametrize("setting", [{"VAMBHIP_VAEVAE_LANES": "1"}, {"VAMBHIP_VAE_GEMM_PREFETCH": "1"}])
+def test_joint_trainer_scheduling_options_match_the_goldens(setting, monkeypatch):
+    """The two round-5 knobs of the joint step -- every pass on its own stream pair (measured slower, off by default) and the fp32
+    GEMM without its deep prefetch -- against the same goldens as the defaults."""
+    for k, v in setting.items():
+        monkeypatch.setenv(k, v)
+    try:
+        test_joint_training_steps_match_reference_and_oracle(next(iter(fd.VAEVAE_CASES)))
+    finally:
+        for k in setting:
+            monkeypatch.delenv(k, raising=False)
+        from vamb_amd import _lib
+        _lib.sync_env_options()
+
+
 def test_one_hot_joint_trainer_matches_the_oracle():
     """The base class VAEVAE (semisupervised_encode.py:700-1084: plain CrossEntropyLoss over the one-hot block, `correct_labels`
     counted) against the oracle's one-hot mode.  No golden: the reference's own base class stops in trainepoch with an
