@@ -41,6 +41,8 @@ def test_normalize_bit_exact(oracle_lib, n, L):
 
 @pytest.mark.parametrize("n,L,k", [(1, 8, 1), (700, 32, 1), (5000, 32, 3), (5000, 40, 8), (20000, 32, 12),
                                    (20000, 64, 25), (3000, 3, 32), (2049, 15, 17),
+                                   # the row-major matrix-pipe kernel's padded row widths (32 / 64 floats) with 9-16 and 17-32 medoids
+                                   (5000, 40, 20), (3000, 33, 32), (7000, 64, 16), (2049, 48, 9), (70000, 32, 32),
                                    # latent spaces wider than the matrix-pipe kernel's operand registers (L > 64): more than 8
                                    # medoids take the VALU kernel with scalar-cache queries (quad-major gather)
                                    (5000, 96, 25), (4000, 132, 12), (3000, 72, 9)])
