@@ -37,7 +37,9 @@
 // pair (200 k x 50, 1000-node taxonomy, batch 256; profiles/r05h_taxvamb_lanes.txt) -- 14 HIP streams over the process's four
 // hardware queues: the kernel trace shows no kernel in flight 49 % of the time and two or more only 23 % of it (the runtime
 // pays for every cross-stream dependency with a signal and a barrier packet, and for every change of stream on the host);
-// GPU_MAX_HW_QUEUES=8 made it worse.  The option stays off; it is kept as the measured negative.
+// GPU_MAX_HW_QUEUES=8 made it worse.  A TWO-lane variant (the chain joint / vamb_x / labels_x / vamb_s on one stream pair, the
+// rest on the other: four streams, one hardware queue each) measured 3.69 ms per step and faulted once in three runs
+// (profiles/r05k_taxvamb_two_lanes.txt); it was removed.  The option stays off; it is kept as the measured negative.
 //
 // The Kullback-Leibler terms of calc_loss_joint: every logsigma in the reference is a zero tensor (:241, :507, :916, :922), so
 // kld_gauss(p, 0, q, 0) = 0.5 * mean((p - q)^2) over all batch x nlatent elements (taxvamb_encode.py:541-548).
@@ -150,7 +152,7 @@ struct vh_vaevae {
     int64_t n = 0;         // rows of the attached datasets (0: none)
     int kld_blocks = 0;
     bool entered = false;
-    bool lanes = true;                       // this call: one stream pair per pass (option vaevae.lanes)
+    bool lanes = false;                      // this call: one stream pair per pass (option vaevae.lanes)
     hipStream_t saved[kVvPasses][2] = {};    // the handles' own stream pairs while a call borrows VAEVamb's (lanes off)
     // cross-pass dependencies of one step (see the header); timing disabled
     hipEvent_t ev_start = nullptr, ev_kld = nullptr;
@@ -214,7 +216,7 @@ void vv_enter(vh_vaevae* t) {
         t->saved[p][0] = h->stream;
         t->saved[p][1] = h->side;
     }
-    t->lanes = option("vaevae.lanes", 0) != 0;
+    t->lanes = option("vaevae.lanes", 0) == 1;
     t->entered = true;
     for (int p = 0; p < kVvPasses; ++p) {
         vh_vae* h = t->pass(p);
@@ -319,6 +321,11 @@ void vv_step(vh_vaevae* t, const int64_t* dev_idx, bool eps_inj, bool masks_inj)
     loss_and_seed(Lx, 0.0f);
     backward(Lx, masks_inj, PASS_DECODER);
     mark(Lx, t->ev_dz[P_LX]);
+    // ---- VAEVamb.calc_loss / VAELabels.calc_loss on the unsupervised rows: the ordinary step's loss and backward
+    loss_and_seed(V);
+    backward(V, masks_inj);
+    loss_and_seed(Lb);
+    backward(Lb, masks_inj);
     // ---- ... and the two kld_gauss terms, which tie VAEJoint's mu to the mu of the two *_s passes
     const int bs = J->bs;
     const float gk = (float)((double)V->kld_w / ((double)J->L * (double)bs * (double)bs));   // 1 / (VAEVamb.nlatent * VAEVamb.beta), taxvamb_encode.py:730
@@ -336,11 +343,6 @@ void vv_step(vh_vaevae* t, const int64_t* dev_idx, bool eps_inj, bool masks_inj)
     backward(Vs, masks_inj, PASS_ENCODER);
     after(Ls, t->ev_kld);
     backward(Ls, masks_inj, PASS_ENCODER);
-    // ---- VAEVamb.calc_loss / VAELabels.calc_loss on the unsupervised rows: the ordinary step's loss and backward
-    loss_and_seed(V);
-    backward(V, masks_inj);
-    loss_and_seed(Lb);
-    backward(Lb, masks_inj);
     // (the decoder passes' loss reductions were joined into their streams by backward(): ev_dz covers Vx / Lx's StepState)
     hipLaunchKernelGGL(vv_joint_finalize_kernel, dim3(1), dim3(256), 0, J->stream, (const float*)t->kld_part.p, t->kld_blocks,
                        (const StepState*)Vx->state.p, (const StepState*)Lx->state.p, V->ce_w, V->sse_w, V->kld_w, bs, J->L,
