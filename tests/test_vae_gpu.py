@@ -516,7 +516,7 @@ def test_step_scheduling_variants_are_bit_identical(dtype, monkeypatch):
     states = []
     knobs = ("VAMBHIP_FORK_EVENTS", "VAMBHIP_SINGLE_STREAM", "VAMBHIP_VAE_OPT_SPLIT", "VAMBHIP_VAE_FORK_AT_LOSS",
              "VAMBHIP_VAE_FUSED_SKINNY", "VAMBHIP_VAE_FUSED_FINALIZE", "VAMBHIP_VAE_FORK_PLAN", "VAMBHIP_VAE_FORK_MODE",
-             "VAMBHIP_VAE_PREFETCH_BATCH")
+             "VAMBHIP_VAE_PREFETCH_BATCH", "VAMBHIP_VAE_LOSS_FROM_DATASET")
     # one stream + event-record forks; the defaults; half of the optimiser on the side stream during the backward; one more fork;
     # the latent-wide products as split-K launch + slab kernel; the optimiser's scalar tail on the last workgroup of the update kernel
     for setting in ({"VAMBHIP_FORK_EVENTS": "1", "VAMBHIP_SINGLE_STREAM": "1"}, {}, {"VAMBHIP_VAE_OPT_SPLIT": "1"},
@@ -524,7 +524,9 @@ def test_step_scheduling_variants_are_bit_identical(dtype, monkeypatch):
                     {"VAMBHIP_VAE_FUSED_SKINNY": "0", "VAMBHIP_VAE_FUSED_FINALIZE": "1", "VAMBHIP_SINGLE_STREAM": "1"},
                     {"VAMBHIP_VAE_FORK_PLAN": "0", "VAMBHIP_VAE_FORK_AT_LOSS": "0"}, {"VAMBHIP_VAE_FORK_PLAN": "15"},
                     {"VAMBHIP_VAE_FORK_PLAN": "6", "VAMBHIP_VAE_FORK_AT_LOSS": "1"}, {"VAMBHIP_VAE_FORK_MODE": "2"},
-                    {"VAMBHIP_VAE_PREFETCH_BATCH": "0"}, {"VAMBHIP_VAE_PREFETCH_BATCH": "0", "VAMBHIP_VAE_FORK_AT_LOSS": "0"}):
+                    {"VAMBHIP_VAE_PREFETCH_BATCH": "0"}, {"VAMBHIP_VAE_PREFETCH_BATCH": "0", "VAMBHIP_VAE_FORK_AT_LOSS": "0"},
+                    # the loss kernel's targets from an fp32 copy of the batch instead of from the dataset rows
+                    {"VAMBHIP_VAE_LOSS_FROM_DATASET": "0"}, {"VAMBHIP_VAE_LOSS_FROM_DATASET": "0", "VAMBHIP_VAE_PREFETCH_BATCH": "0"}):
         for var in knobs:
             monkeypatch.delenv(var, raising=False)
         for var, val in setting.items():

@@ -217,6 +217,8 @@ _ENV_OPTIONS = {
     "VAMBHIP_VAE_PROBE_EVERY": ("vae.probe_every", int),
     "VAMBHIP_VAEVAE_LANES": ("vaevae.lanes", int),
     "VAMBHIP_VAE_LOSS_DPP": ("vae.loss_dpp", int),
+    "VAMBHIP_VAE_LOSS_FROM_DATASET": ("vae.loss_from_dataset", int),
+    "VAMBHIP_VAE_PREFETCH_MAX_COLS": ("vae.prefetch_max_cols", int),
     "VAMBHIP_VAE_GEMM_PREFETCH": ("vae.gemm_prefetch", int),
 }
 _ENV_STRING_OPTIONS = {"VAMBHIP_RCCL": "comm.rccl_library", "ROCM_PATH": "comm.rocm_path"}

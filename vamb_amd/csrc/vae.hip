@@ -206,6 +206,9 @@ struct VaeTuning {
                               // critical path) runs on the side stream during step t, FIRST in the batch of work the loss-kernel fork hands
                               // over; the join in front of the optimiser -- already there -- covers it, so the main stream pays no extra
                               // event (round 3 tried this with an event of its own and measured it neutral).  Same bits.
+    int prefetch_max_cols = 512;   // vae.prefetch_max_cols: widest (padded) input the next-batch prefetch is used for
+    bool loss_from_dataset = true; // vae.loss_from_dataset: bf16 step of the plain VAE: the loss kernel reads its targets from the dataset
+                              // rows of the batch; the gather kernel then writes no fp32 copy of the batch (a third of its traffic)
     bool loss_dpp = true;     // vae.loss_dpp: bf16 loss kernel: row reductions by DPP instead of ds_bpermute (see vae_loss16_kernel)
     int dz_dbg = 0;           // vae.dz_dbg: timing experiments on the elementwise BatchNorm-backward kernel (WRONG results): see Dz16Args
     bool dw_row_major = true; // vae.dw_row_major: bf16 weight gradients contract ROW-major tensors (gemm_bf16_tn.hpp); 0 = the
@@ -225,6 +228,8 @@ void refresh_tuning() {
     g_tuning.fused_finalize = option("vae.fused_finalize", 0) != 0;
     g_tuning.dz_dbg = (int)option("vae.dz_dbg", 0);
     g_tuning.loss_dpp = option("vae.loss_dpp", 1) != 0;
+    g_tuning.loss_from_dataset = option("vae.loss_from_dataset", 1) != 0;
+    g_tuning.prefetch_max_cols = (int)option("vae.prefetch_max_cols", 512);
     g_gemm_prefetch = (int)option("vae.gemm_prefetch", 4);
     g_tuning.prefetch_batch = option("vae.prefetch_batch", 1) != 0;
     g_tuning.fork_plan = (int)option("vae.fork_plan", 6);
@@ -331,6 +336,8 @@ struct vh_vae {
     DevBuf<float> Xb_n, Wb_n;
     DevBuf<bf16_t> Xb16_n;
     DevBuf<int32_t> Lb_n;
+    DevBuf<long long> Rb, Rb_n;      // dataset rows of the batch (vae.loss_from_dataset: the loss kernel's targets)
+    bool batch_from_gather = false;  // the batch in Xb16 came from the gather kernel (Rb is valid), not from an uploaded batch
     bool prefetch_next = false, batch_prefetched = false;
     DevBuf<float> biasf_mu, biasf_out;
     double* dbias_mu = nullptr;              // fp64 column sums of dMU / dR (inside statbuf)
@@ -1112,7 +1119,7 @@ void run_epoch_steps(vh_vae* h, const int64_t* dev_idx, int64_t n_batches) {
         // bf16 step: the NEXT batch of the epoch is assembled on the side stream during this step (vae.prefetch_batch)
         // (narrow inputs only: at the C3 shape -- 1120 columns, 36 MB read + 55 MB written per batch -- the gather on the side stream
         // delays the weight gradients the optimiser waits for: 380.5 vs 366.4 us per step, profiles/r05g_step_prefetch_batch.txt)
-        h->prefetch_next = h->bf16 && g_tuning.prefetch_batch && h->D_p <= 512 && b + 1 < n_batches && h->side != h->stream;
+        h->prefetch_next = h->bf16 && g_tuning.prefetch_batch && h->D_p <= g_tuning.prefetch_max_cols && b + 1 < n_batches && h->side != h->stream;
         train_step_device(h, dev_idx, false, false);
     }
     h->prefetch_next = false;
@@ -1764,6 +1771,7 @@ int vh_vae_forward(vh_vae* h, const float* depths, const float* tnf, const float
         VH_HIP(hipStreamSynchronize(h->stream));
         const bool inj_masks = training && masks != nullptr && h->cfg.dropout > 0;
         if (inj_masks) upload_masks(h, masks, (int)batch);
+        h->batch_from_gather = false;   // (an uploaded batch: no dataset rows behind it)
         if (h->bf16) {
             const int64_t n4 = (int64_t)h->bs_p * h->D_p / 4;
             hipLaunchKernelGGL(vae_cast16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n4, 256), 4096)), dim3(256), 0,
@@ -1838,6 +1846,7 @@ int vh_vae_forward_rows(vh_vae* h, const float* X, int64_t batch, int training, 
         VH_HIP(hipStreamSynchronize(h->stream));
         const bool inj_masks = training && masks != nullptr && h->cfg.dropout > 0;
         if (inj_masks) upload_masks(h, masks, (int)batch);
+        h->batch_from_gather = false;   // (an uploaded batch: no dataset rows behind it)
         if (h->bf16) {
             const int64_t n4 = (int64_t)h->bs_p * h->D_p / 4;
             hipLaunchKernelGGL(vae_cast16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n4, 256), 4096)), dim3(256), 0,

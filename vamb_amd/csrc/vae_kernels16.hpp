@@ -33,7 +33,9 @@ __global__ void vae_gather16_kernel(const float* __restrict__ X, int64_t ld_src,
                                     const int64_t* __restrict__ idx, const ShuffleSpec shuffle,
                                     const long long* __restrict__ batch_ptr, int64_t base, int bs, int bs_p,
                                     float* __restrict__ Xb, bf16_t* __restrict__ Xb16, float* __restrict__ Wb,
-                                    const LabelSrc lab, int32_t* __restrict__ Lb) {
+                                    const LabelSrc lab, int32_t* __restrict__ Lb, long long* __restrict__ Rb) {
+    // Rb (plain VAE, vae.loss_from_dataset): the batch's dataset rows, for the loss kernel to read its targets from -- the fp32
+    // copy of the batch (Xb == nullptr then) is a third of this kernel's traffic and has no other reader in the bf16 step
     const int r = blockIdx.x * 4 + threadIdx.y;
     if (r >= bs_p) return;
     const bool real = r < bs;
@@ -48,10 +50,13 @@ __global__ void vae_gather16_kernel(const float* __restrict__ X, int64_t ld_src,
         for (int c = threadIdx.x; c < dq; c += 64) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (real) v = s[c];
-            d[c] = v;
+            if (Xb) d[c] = v;
             d16[c] = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
         }
-        if (threadIdx.x == 0) Wb[r] = real ? w_all[src] : 0.f;
+        if (threadIdx.x == 0) {
+            Wb[r] = real ? w_all[src] : 0.f;
+            if (Rb) Rb[r] = (long long)src;
+        }
     } else {
         const float4* s = reinterpret_cast<const float4*>(X + src * ld_src);
         float4* d = Xb ? reinterpret_cast<float4*>(Xb + (int64_t)r * ldx) : nullptr;   // (encode pass: only the bf16 operand)
@@ -257,7 +262,8 @@ __global__ void vae_reparam16_kernel(const float* __restrict__ slabs, int nslab,
 // consume it), the KLD part of dL/dmu stays fp32.
 struct Loss16Args {
     const float* R;
-    const float* X;
+    const float* X;            // targets: the fp32 batch [bs_p][ld], or (rows != nullptr) the dataset, row rows[r] of it for batch row r
+    const long long* rows;
     int64_t ld;
     const float* MU;
     int64_t ldl;
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             float* x = r + a.ld;
             {
                 const float4* rg = reinterpret_cast<const float4*>(a.R + (int64_t)row * a.ld);
-                const float4* xg = reinterpret_cast<const float4*>(a.X + (int64_t)row * a.ld);
+                const float4* xg = reinterpret_cast<const float4*>(a.X + (a.rows ? (int64_t)a.rows[row] : (int64_t)row) * a.ld);
                 for (int c = lane; c < (int)(a.ld / 4); c += 64) {
                     reinterpret_cast<float4*>(r)[c] = rg[c];
                     reinterpret_cast<float4*>(x)[c] = xg[c];

@@ -472,10 +472,14 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
     }
 }
 
+// plain VAE: the loss kernel takes its targets from the dataset rows the gather recorded instead of from an fp32 copy of the batch
+bool loss_reads_dataset(const vh_vae* h) { return g_tuning.loss_from_dataset && h->kind == VH_VAE_PLAIN && h->batch_from_gather; }
+
 void loss_and_seed16(vh_vae* h, SideQueue& q) {
     const int bs_global = h->global_bs > 0 ? h->global_bs : h->bs;
     Loss16Args a;
-    a.R = h->R.p; a.X = h->Xb.p; a.ld = h->D_p;
+    a.R = h->R.p; a.X = h->Xb.p; a.rows = nullptr; a.ld = h->D_p;
+    if (loss_reads_dataset(h)) { a.X = h->X.p; a.rows = h->Rb.p; }
     a.MU = h->MU.p; a.ldl = h->L_p;
     a.inv_b2 = (float)(1.0 / ((double)bs_global * (double)bs_global));
     a.bs = h->bs; a.bs_p = h->bs_p; a.S = h->S; a.L = h->L;
@@ -753,12 +757,14 @@ void optimizer_step16(vh_vae* h) {
 }
 
 // rows [base + batch * bs, ...) of the epoch's order -> (Xb, Xb16, Wb, Lb) on stream st; base = bs: the batch AFTER the cursor's
-void gather_launch16(vh_vae* h, const int64_t* dev_idx, hipStream_t st, int64_t base, float* Xb, bf16_t* Xb16, float* Wb, int32_t* Lb) {
+void gather_launch16(vh_vae* h, const int64_t* dev_idx, hipStream_t st, int64_t base, float* Xb, bf16_t* Xb16, float* Wb, int32_t* Lb,
+                     long long* Rb) {
     auto kern = h->kind == VH_VAE_PLAIN ? vae_gather16_kernel<false> : vae_gather16_kernel<true>;
+    const bool direct = g_tuning.loss_from_dataset && h->kind == VH_VAE_PLAIN;   // (then nobody reads the fp32 copy of the batch)
     hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(h->bs_p, 4)), dim3(64, 4), 0, st,
                        (const float*)h->X.p, h->ld_src, (int64_t)h->D_p, (const float*)h->w.p, dev_idx, h->shuffle,
-                       (const long long*)&h->state.p->batch, base, h->bs, h->bs_p, Xb, Xb16, Wb,
-                       LabelSrc{h->labels, h->lab0}, Lb);
+                       (const long long*)&h->state.p->batch, base, h->bs, h->bs_p, direct ? (float*)nullptr : Xb, Xb16, Wb,
+                       LabelSrc{h->labels, h->lab0}, Lb, direct ? Rb : (long long*)nullptr);
     VH_HIP(hipGetLastError());
 }
 
@@ -766,15 +772,19 @@ void gather_rows16(vh_vae* h, const int64_t* dev_idx, SideQueue& q) {
     if (h->batch_prefetched) {
         // the previous step assembled this batch on the side stream (joined before its optimiser ran): take its buffers
         std::swap(h->Xb, h->Xb_n); std::swap(h->Xb16, h->Xb16_n); std::swap(h->Wb, h->Wb_n); std::swap(h->Lb, h->Lb_n);
+        std::swap(h->Rb, h->Rb_n);
         h->batch_prefetched = false;
     } else {
-        gather_launch16(h, dev_idx, h->stream, 0, h->Xb.p, h->Xb16.p, h->Wb.p, h->Lb.p);
+        h->Rb.ensure((size_t)h->bs_p);
+        gather_launch16(h, dev_idx, h->stream, 0, h->Xb.p, h->Xb16.p, h->Wb.p, h->Lb.p, h->Rb.p);
     }
+    h->batch_from_gather = true;
     if (h->prefetch_next) {
         // first in the side stream's queue: nothing on it depends on this batch, and it is ready long before the join
         h->Xb_n.ensure(h->Xb.n); h->Xb16_n.ensure(h->Xb16.n); h->Wb_n.ensure(h->Wb.n); h->Lb_n.ensure(h->Lb.n);
+        h->Rb_n.ensure((size_t)h->bs_p);
         q.add([h, dev_idx](hipStream_t st) {
-            gather_launch16(h, dev_idx, st, (int64_t)h->bs, h->Xb_n.p, h->Xb16_n.p, h->Wb_n.p, h->Lb_n.p);
+            gather_launch16(h, dev_idx, st, (int64_t)h->bs, h->Xb_n.p, h->Xb16_n.p, h->Wb_n.p, h->Lb_n.p, h->Rb_n.p);
         });
         h->batch_prefetched = true;
     }
@@ -818,7 +828,7 @@ void encode16(vh_vae* h, float* latent) {
             hipLaunchKernelGGL(vae_gather16_kernel<true>, dim3((unsigned)ceil_div(m, 4)), dim3(64, 4), 0, s, (const float*)h->X.p,
                                h->ld_src, (int64_t)h->D_p, (const float*)h->w.p, (const int64_t*)nullptr, ShuffleSpec{0, 0, 1},
                                (const long long*)nullptr, lo, m, m, (float*)nullptr, a1.p, (float*)nullptr,
-                               LabelSrc{h->labels, h->lab0}, (int32_t*)nullptr);
+                               LabelSrc{h->labels, h->lab0}, (int32_t*)nullptr, (long long*)nullptr);
         }
         VH_HIP(hipGetLastError());
         const bf16_t* in = a1.p;
