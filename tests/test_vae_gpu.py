@@ -111,6 +111,37 @@ def test_gemm_deep_prefetch_tile(layout, shape):
     assert np.array_equal(out[6], out[3])
 
 
+@pytest.mark.parametrize("layout", [(1, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("shape", [(256, 512, 512, 1), (260, 36, 512, 1), (100, 200, 1024, 2), (64, 64, 512, 1), (36, 32, 2048, 1)])
+def test_gemm_k_group_tile(layout, shape):
+    """Tile 7 = 32x32 workgroup tiles with four wavefront groups over the K range (gemm.hpp, KS = 4), each group with its four
+    K-tiles in flight; the slabs meet in LDS in ascending order: what the fp32 step launches for GEMMs of a few dozen 64x64
+    tiles (the joint TaxVamb step at batch 256).  Ragged M / N exercise the clamped loads; two runs must agree to the bit."""
+    M, N, K, splits = shape
+    a_kc, b_kc = layout
+    rng = np.random.RandomState(M + N + K + 13)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = (rng.standard_normal((N, K)) + 0.25 * np.arange(N)[:, None] / N).astype(np.float32)
+    want = A.astype(np.float64) @ B.astype(np.float64).T
+    Ad = np.ascontiguousarray(A if a_kc else A.T)
+    Bd = np.ascontiguousarray(B if b_kc else B.T)
+    out = []
+    for _ in range(2):
+        C = np.zeros((M, N), np.float32)
+        ms = ctypes.c_float()
+        _lib.check(_lib.load().vh_debug_gemm(7, a_kc, b_kc, _lib.ptr(Ad), _lib.ptr(Bd), None, _lib.ptr(C), M, N, K, splits,
+                                             ctypes.byref(ms)))
+        out.append(C)
+    assert rel(out[0], want) < 2e-6 * np.sqrt(K)
+    assert np.array_equal(out[0], out[1])
+    if a_kc and b_kc and splits == 1:
+        bias = rng.standard_normal(N).astype(np.float32)
+        C = np.zeros((M, N), np.float32)
+        ms = ctypes.c_float()
+        _lib.check(_lib.load().vh_debug_gemm(7, 1, 1, _lib.ptr(Ad), _lib.ptr(Bd), _lib.ptr(bias), _lib.ptr(C), M, N, K, 1, ctypes.byref(ms)))
+        assert rel(C, want + bias) < 2e-6 * np.sqrt(K)
+
+
 def bf16_round(x):
     """float32 -> bf16 (round to nearest even) -> float32, as the staging path of the bf16 GEMMs does."""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)

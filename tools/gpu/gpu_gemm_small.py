@@ -1,6 +1,7 @@
 """Diagnostic (GPU box): the fp32 GEMM at the joint TaxVamb step's shapes (batch 256: a few dozen workgroups, each alone on its CU).
 Times vh_debug_gemm (50 back-to-back launches) for the tile variants -- 3 = the production 64 x 64 tile, 4 = 64-wide K-tiles,
-5 = one free-running wavefront per 32 x 32 tile, 6 = 64 x 64 with four K-tiles in flight (gemm.hpp, PF = 4) -- and checks each
+5 = one free-running wavefront per 32 x 32 tile, 6 = 64 x 64 with four K-tiles in flight (gemm.hpp, PF = 4), 7 = 32 x 32 with four
+wavefront groups over K (KS = 4) -- and checks each
 result against float64 numpy.
 
     python tools/gpu/gpu_gemm_small.py [out.txt]
@@ -36,10 +37,12 @@ for a_kc, b_kc, M, N, K, splits in CASES:
     Ad = np.ascontiguousarray(A if a_kc else A.T)
     Bd = np.ascontiguousarray(B if b_kc else B.T)
     row = []
-    for tile in (3, 4, 5, 6, 2):
+    for tile in (3, 4, 5, 6, 7, 2):
         if tile == 4 and (K // splits) % 64:
             continue
         if tile == 6 and ((K // splits) % 128 or K % splits):
+            continue
+        if tile == 7 and ((K // splits) % 512 or K % splits):
             continue
         C = np.zeros((M, N), np.float32)
         ms = ctypes.c_float()

@@ -220,6 +220,7 @@ _ENV_OPTIONS = {
     "VAMBHIP_VAE_LOSS_FROM_DATASET": ("vae.loss_from_dataset", int),
     "VAMBHIP_VAE_PREFETCH_MAX_COLS": ("vae.prefetch_max_cols", int),
     "VAMBHIP_VAE_GEMM_PREFETCH": ("vae.gemm_prefetch", int),
+    "VAMBHIP_VAE_GEMM_KGROUPS": ("vae.gemm_kgroups", int),
 }
 _ENV_STRING_OPTIONS = {"VAMBHIP_RCCL": "comm.rccl_library", "ROCM_PATH": "comm.rocm_path"}
 _explicit_options: dict = {}

@@ -88,6 +88,7 @@ struct GemmArgs {
     int wide_k;           // 1: 64-wide K-tiles (host-side dispatch only; forward GEMMs, which run alone on the GPU)
     int bf16;             // 1: launch the bf16-operand instantiation (host-side dispatch only)
     int xcd_remap;        // 1: give every XCD a contiguous chunk of the tile grid (L2 reuse of operand panels)
+    int group_floats;     // K-group instantiations (KS > 1): LDS floats per group (set by the launcher)
 };
 
 // counter-based uniform 32-bit hash (splitmix64 finaliser); also used by the backward transforms so the
@@ -162,9 +163,15 @@ __device__ __forceinline__ float4 as_float4(const f32x4& v) { return make_float4
 // full L2 / HBM round trip, ~1.3 us, for 0.43 us of MFMA work): tile t + 4 is requested while tile t is contracted, every load
 // unconditional (clamped to the matrix; out-of-range rows are zeroed on the way into LDS) so that the compiler's counted vmcnt
 // waits survive.  The host picks it when the K loop is a multiple of PF tiles deep (launch_gemm).
+// KS (fp32 operands, one wavefront per group: WM = WN = 1): KS wavefront GROUPS per workgroup, group i contracting the i-th
+// slab of the workgroup's K range into its own accumulators over its own LDS tiles; the slabs meet in LDS in ascending order
+// (deterministic) and group 0 runs the epilogue.  For launches that would otherwise be a few dozen workgroups: 256 x 512 x 512
+// is 32 workgroups of 64 x 64 -- 128 of the chip's 1024 matrix pipes, 6.8 us of fp32 MFMA time each -- or 128 workgroups of
+// 32 x 32 x (4 x 128) with four times the pipes busy and a K loop a quarter as deep.  The sum of the slabs is formed in another
+// order than the plain K loop's: same value up to float32 rounding, as with every split-K launch of this file.
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE,
-          int BK = 32, int DT = 0, int PF = 1>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g) {
+          int BK = 32, int DT = 0, int PF = 1, int KS = 1>
+__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_f32_kernel(const GemmArgs g) {
     // DT = 0: fp32 operands on v_mfma_f32_32x32x2_f32.  DT = 1 (BASELINE configs C2+): the operands are
     // rounded to bf16 (RNE) while they are staged into LDS and contracted on v_mfma_f32_32x32x16_bf16 with
     // fp32 accumulation; global tensors, transforms and epilogues stay fp32.
@@ -181,6 +188,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     static_assert(WM * WN == 4 || WM * WN == 1, "4 wavefronts per workgroup, or a single free-running one");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
     static_assert(PF == 1 || DT == 0, "the deep prefetch is an fp32-operand variant");
+    static_assert(KS == 1 || (WM * WN == 1 && DT == 0), "K groups are single wavefronts, fp32 operands");
 
     // LDS image of an operand tile: [rows][32 floats], i.e. K-contiguous rows of 8 quads (16 B each), the
     // quad of logical index kq stored in slot kq ^ swz(row).  Every fragment read is one ds_read_b128 (256
@@ -195,12 +203,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     // in slot q ^ ((row >> 2) & 3)): one ds_read_b128 is the 8-element operand of one 32x32x16 MFMA.
     constexpr int TILE_A = BF ? BM * BK / 2 : (A_KC ? BM * BK : BK * SA);        // floats per buffer
     constexpr int TILE_B = BF ? BN * BK / 2 : (B_KC ? BN * BK : BK * SB);
-    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+    extern __shared__ __attribute__((aligned(16))) float gemm_smem_all[];
+    // K groups: every group owns one copy of the layout below (g.group_floats apart) and the slab [kbeg, kend) of the K range
+    const int grp = KS > 1 ? (int)threadIdx.x / NT : 0;
+    float* gemm_smem = gemm_smem_all + (KS > 1 ? (size_t)grp * g.group_floats : 0);
     float* As = gemm_smem;                 // [2][TILE_A]
     float* Bs = gemm_smem + 2 * TILE_A;    // [2][TILE_B]
     float* coef = Bs + 2 * TILE_B;         // per-column coefficients of the operand transforms (see below)
 
-    const int tid = threadIdx.x;
+    const int tid = KS > 1 ? (int)threadIdx.x % NT : (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -221,8 +232,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
         bz = t / (gx * gy);
     }
     const int m0 = by * BM, n0 = bx * BN;
-    const int kbeg = bz * g.k_per_split;
-    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int kslab = g.k_per_split / KS;                          // (KS > 1: the host guarantees K = splits * KS * kslab)
+    const int kbeg = bz * g.k_per_split + grp * kslab;
+    const int kend = min(g.K, kbeg + kslab);
     const int nchunks = (kend - kbeg) / BK;
 
     // ---- coefficient tables in LDS ---------------------------------------------------------------
@@ -679,6 +691,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmArgs g
     // epilogue.  acc[i][j][reg] is C[row][col] with
     //   row = m0 + (wm*TM + i)*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5),  col = n0 + (wn*TN + j)*32 + (lane&31)
     // ---------------------------------------------------------------------------------------
+    if constexpr (KS > 1) {
+        // every group is past the K loop's last barrier: the operand tiles are free.  part[group - 1][register][lane]
+        float* part = gemm_smem_all;
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[(((grp - 1) * TM * TN + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp > 0) return;   // (a later barrier of the epilogue counts the live wavefronts only)
+#pragma unroll
+        for (int q = 1; q < KS; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += part[(((q - 1) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
+        // (one wavefront: its reads of `part` precede, in program order, the epilogue's writes to the same LDS)
+    }
     float* Cout = g.C;
     if constexpr (EPI == EPI_SPLITK) Cout += (int64_t)bz * g.slab_stride;
 

@@ -84,12 +84,16 @@ thread_local hipEvent_t t_probe_start = nullptr, t_probe_stop = nullptr;
 thread_local hipEvent_t t_fork_stop = nullptr;
 
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, int XFA = XF_NONE, int XFB = XF_NONE,
-          int BK = 32, int DT = 0, int PF = 1>
-void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
+          int BK = 32, int DT = 0, int PF = 1, int KS = 1>
+void launch_gemm(hipStream_t stream, const GemmArgs& g_in, int splits) {
     static bool attr_set = false;
-    const size_t smem = gemm_smem_bytes<BM, BN, AKC, BKC, EPI, XFA, XFB, BK, DT>(g.k_per_split);
+    GemmArgs g = g_in;
+    // K groups: one copy of the LDS layout per group (operand tiles + the coefficient tables of the group's K slab)
+    const size_t group_bytes = round_up(gemm_smem_bytes<BM, BN, AKC, BKC, EPI, XFA, XFB, BK, DT>(g.k_per_split / KS), 16);
+    g.group_floats = (int)(group_bytes / sizeof(float));
+    const size_t smem = group_bytes * KS;
     VH_REQUIRE(smem <= kMaxDynLds, "layer too wide for the fused GEMM (needs %zu bytes of LDS)", smem);
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AKC, BKC, EPI, XFA, XFB, BK, DT, PF>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AKC, BKC, EPI, XFA, XFB, BK, DT, PF, KS>;
     if (!attr_set) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kMaxDynLds));
@@ -97,13 +101,13 @@ void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
     }
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits);
     if (t_probe_start) {
-        hipExtLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, t_probe_start, t_probe_stop, 0, g);
+        hipExtLaunchKernelGGL(kern, grid, dim3(WM * WN * KS * 64), smem, stream, t_probe_start, t_probe_stop, 0, g);
         t_probe_start = t_probe_stop = nullptr;
     } else if (t_fork_stop) {
-        hipExtLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, nullptr, t_fork_stop, 0, g);
+        hipExtLaunchKernelGGL(kern, grid, dim3(WM * WN * KS * 64), smem, stream, nullptr, t_fork_stop, 0, g);
         t_fork_stop = nullptr;
     } else {
-        hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g);
+        hipLaunchKernelGGL(kern, grid, dim3(WM * WN * KS * 64), smem, stream, g);
     }
     VH_HIP(hipGetLastError());
 }
@@ -111,6 +115,15 @@ void launch_gemm(hipStream_t stream, const GemmArgs& g, int splits) {
 // Small launches (at most one workgroup per CU, e.g. every GEMM of the joint TaxVamb step at batch 256) with a K loop that is a
 // multiple of four tiles deep run the deep-prefetch instantiation of the fp32 kernel (gemm.hpp, PF = 4; option vae.gemm_prefetch).
 int g_gemm_prefetch = 4;
+int g_gemm_kgroups = 4;
+// ... and those that would be at most 128 workgroups of 64 x 64 take 32 x 32 tiles with four wavefront groups over the K range
+// (gemm.hpp, KS = 4; option vae.gemm_kgroups), each group with its four K-tiles in flight
+bool k_groups(const GemmArgs& g, int splits) {
+    if (g_gemm_kgroups != 4 || g_gemm_prefetch != 4 || g.bf16) return false;
+    const int64_t wgs64 = ceil_div(g.M, 64) * ceil_div(g.N, 64) * splits;
+    const int kp = g.k_per_split;
+    return wgs64 <= 128 && kp % 512 == 0 && (int64_t)kp * splits == g.K && g.M >= 4 && g.N >= 4;
+}
 bool deep_prefetch(const GemmArgs& g, int bm, int bn, int splits) {
     if (g_gemm_prefetch != 4 || g.bf16) return false;
     const int64_t wgs = ceil_div(g.M, bm) * ceil_div(g.N, bn) * splits;
@@ -131,6 +144,7 @@ void gemm_tile(hipStream_t s, int tile, const GemmArgs& g, int splits) {
     if (tile == 2) launch_gemm<128, 32, 4, 1, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
     else if (tile == 1) launch_gemm<128, 128, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
     else if (tile == 0) launch_gemm<64, 128, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
+    else if (k_groups(g, splits)) launch_gemm<32, 32, 1, 1, AKC, BKC, EPI, XFA, XFB, 32, 0, 4, 4>(s, g, splits);
     else if (deep_prefetch(g, 64, 64, splits)) launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB, 32, 0, 4>(s, g, splits);
     else launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XFA, XFB>(s, g, splits);
 }
@@ -155,6 +169,7 @@ void gemm_tile_debug(hipStream_t s, int tile, const GemmArgs& g, int splits) {
         case 2: launch_gemm<128, 32, 4, 1, AKC, BKC, EPI>(s, g, splits); break;
         case 4: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XF_NONE, XF_NONE, 64>(s, g, splits); break;
         case 6: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI, XF_NONE, XF_NONE, 32, 0, 4>(s, g, splits); break;   // deep prefetch
+        case 7: launch_gemm<32, 32, 1, 1, AKC, BKC, EPI, XF_NONE, XF_NONE, 32, 0, 4, 4>(s, g, splits); break;   // + four K groups
         case 5: launch_gemm<32, 32, 1, 1, AKC, BKC, EPI>(s, g, splits); break;
         default: launch_gemm<64, 64, 2, 2, AKC, BKC, EPI>(s, g, splits); break;
     }
@@ -231,6 +246,7 @@ void refresh_tuning() {
     g_tuning.loss_from_dataset = option("vae.loss_from_dataset", 1) != 0;
     g_tuning.prefetch_max_cols = (int)option("vae.prefetch_max_cols", 512);
     g_gemm_prefetch = (int)option("vae.gemm_prefetch", 4);
+    g_gemm_kgroups = (int)option("vae.gemm_kgroups", 4);
     g_tuning.prefetch_batch = option("vae.prefetch_batch", 1) != 0;
     g_tuning.fork_plan = (int)option("vae.fork_plan", 6);
     g_tuning.fork_mode = (int)option("vae.fork_mode", 0);
@@ -2116,8 +2132,9 @@ int vh_debug_gemm(int tile, int a_kc, int b_kc, const float* A, const float* B, 
         VH_REQUIRE(A && B && C, "NULL argument");
         const bool use_bf16 = tile >= 100;   // tile + 100: the bf16-operand instantiation of that tile
         if (use_bf16) tile -= 100;
-        VH_REQUIRE(tile >= 0 && tile <= 6 && !((tile == 4 || tile == 6) && use_bf16), "tile in {0..6} (+100 for bf16 operands, not tiles 4, 6)");
+        VH_REQUIRE(tile >= 0 && tile <= 7 && !((tile == 4 || tile >= 6) && use_bf16), "tile in {0..7} (+100 for bf16 operands, not tiles 4, 6, 7)");
         VH_REQUIRE(tile != 6 || ((K / std::max(1, splits)) % 128 == 0 && K % std::max(1, splits) == 0), "tile 6 needs K / splits multiple of 128");
+        VH_REQUIRE(tile != 7 || ((K / std::max(1, splits)) % 512 == 0 && K % std::max(1, splits) == 0), "tile 7 needs K / splits multiple of 512");
         VH_REQUIRE(tile != 4 || (K % 64 == 0 && (K / std::max(1, splits)) % 64 == 0), "tile 4 needs K multiple of 64");
         VH_REQUIRE(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && M % 4 == 0 && N % 4 == 0,
                    "need K multiple of 32 and M, N multiples of 4");
