@@ -191,6 +191,8 @@ _ENV_OPTIONS = {
     "VAMBHIP_GEN_PROFILE": ("gen.profile", lambda v: 1),
     "VAMBHIP_NO_SPECULATION": ("gen.speculate", lambda v: 0),
     "VAMBHIP_SPEC_WINDOW": ("gen.spec_window", int),
+    "VAMBHIP_GEN_PREFILL": ("gen.prefill", int),
+    "VAMBHIP_GEN_PREFILL_FRESH_SEEDS": ("gen.prefill_fresh_seeds", int),
     "VAMBHIP_SPEC_NEIGHBOURS": ("gen.spec_neighbours", int),
     "VAMBHIP_MAX_ENTRY_AGE": ("gen.max_entry_age", int),
     "VAMBHIP_SPEC_DEPTH": ("gen.spec_depth", int),

@@ -2622,6 +2622,18 @@ struct vh_gen {
     int64_t max_entry_age = kMaxEntryAgeDefault;   // option gen.max_entry_age
     int spec_depth = 2;             // option gen.spec_depth: 1 = within-radius rows of upcoming seeds, 2 = also THEIR within-radius rows
     double t_validate = 0, t_fill = 0, t_book = 0, t_emit = 0, t_book_hidden = 0;   // profile: lazy validation, speculative fill, post-scan bookkeeping, emission
+    // Speculative fill one pass AHEAD (option gen.prefill): while a pass runs on the GPU the host already collects the rows it
+    // would add to the NEXT pass's free slots; that pass takes the rows of the list that are still unscanned and live and walks
+    // the pools again only when the list comes up short although it had been cut at the slot count.  What is scanned ahead never
+    // changes a result (lazy validation), only the number of passes.
+    bool pass_in_flight = false;    // host code running UNDER a pass: the ring slot that pass writes is not to be read (gen_lookup)
+    int prefill_on = 2;             // 2: a bounded fresh walk (the first prefill_fresh_seeds upcoming seeds, their own pools) in front of the list
+    int prefill_fresh_seeds = 4;
+    std::vector<int64_t> prefill;
+    uint64_t prefill_epoch = 0;
+    bool prefill_ready = false, prefill_exhausted = false;
+    double t_fill_hidden = 0;
+    long long prefill_hits = 0, prefill_topups = 0;
     bool spec_neighbours = true;   // option gen.spec_neighbours: within-radius rows of cached upcoming seeds are scanned ahead too
     int spec_big_target = 0;      // experiment: widening target of passes over matrices above 600 k rows (0 = bucket fill)
     // optional wall-clock breakdown (VAMBHIP_GEN_PROFILE=1): scan calls, select calls, seed walk, logical index
@@ -2790,9 +2802,11 @@ GenStats* gen_lookup(vh_gen* g, int64_t row) {
         return nullptr;
     }
     st.checked = g->n_emitted;
-    // an entry that outlives its emission will be asked for its list sooner or later: take it while its scan is in the ring
-    if (!st.have_list && st.list_count <= (unsigned int)kListCap && g->clu->scan_seq - st.seq <= (uint64_t)kListRing &&
-        st.seq >= g->ring_rows_valid_from) {
+    // an entry that outlives its emission will be asked for its list sooner or later: take it while its scan is in the ring.
+    // (Under a running pass -- the fill one pass ahead -- the ring is one slot shorter: that pass is writing the slot of the
+    // scan kListRing passes back.)
+    if (!st.have_list && st.list_count <= (unsigned int)kListCap &&
+        g->clu->scan_seq + (g->pass_in_flight ? 1u : 0u) - st.seq <= (uint64_t)kListRing && st.seq >= g->ring_rows_valid_from) {
         const int32_t* src = g->clu->lists + ((size_t)(st.seq % kListRing) * kMaxMedoids + st.slot_j) * kListCap;
         st.within.assign(src, src + st.list_count);
         std::sort(st.within.begin(), st.within.end());
@@ -2833,8 +2847,12 @@ void gen_remove_live(vh_gen* g, const int64_t* rows_in, int64_t n_in) {
 // its within-radius list, the rows of that list -- the pool wander_medoid draws its first candidates from
 // (cluster.py:415-450).  A C2 sweep spent 446 k of its 586 k passes on candidate rounds (profiles/r03g_sweep_pass_purposes.txt);
 // a round whose candidates were all scanned ahead needs no pass at all.
-void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& exclude, std::vector<int64_t>& out) {
+// seed_limit / depth_limit (0: the generator's own): a bounded walk over the first few upcoming seeds only
+void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& exclude, std::vector<int64_t>& out, int seed_limit = 0,
+                          int depth_limit = 0) {
     const int64_t n_order = (int64_t)g->order.size();
+    const int window = seed_limit > 0 ? std::min(seed_limit, g->spec_window) : g->spec_window;
+    const int max_depth = depth_limit > 0 ? std::min(depth_limit, g->spec_depth) : g->spec_depth;
     auto taken = [&](int64_t row) {
         return gen_lookup(g, row) != nullptr || std::find(exclude.begin(), exclude.end(), row) != exclude.end() ||
                std::find(out.begin(), out.end(), row) != out.end();
@@ -2842,7 +2860,7 @@ void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& ex
     // the upcoming live seeds, in walk order
     std::vector<int64_t> upcoming;
     int64_t looked = 0;
-    for (int64_t i = g->order_index; i < n_order && (int)upcoming.size() < g->spec_window && looked < 4096; ++i, ++looked) {
+    for (int64_t i = g->order_index; i < n_order && (int)upcoming.size() < window && looked < 4096; ++i, ++looked) {
         const int64_t o = g->order[(size_t)i];
         if (o == -1 || !g->alive[(size_t)o]) continue;
         vh_gen::RowMemo& m = g->row_memo[(size_t)o & 255u];
@@ -2866,7 +2884,7 @@ void gen_speculative_fill(vh_gen* g, size_t want, const std::vector<int64_t>& ex
         return g->kept[(size_t)r] != 0 && g->stats.count(r) == 0 && !gen_is_pending(g, r) &&
                std::find(exclude.begin(), exclude.end(), r) == exclude.end() && std::find(out.begin(), out.end(), r) == out.end();
     };
-    for (int depth = 1; depth <= g->spec_depth; ++depth) {
+    for (int depth = 1; depth <= max_depth; ++depth) {
         for (int64_t row : upcoming) {
             const GenStats* seed_st = gen_lookup(g, row);
             if (seed_st == nullptr || !seed_st->have_list) continue;
@@ -2923,7 +2941,24 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         if (missing.size() < target && missing.size() < (size_t)kMaxMedoids) {
             std::vector<int64_t> extra;
             GenTimer tf(&g->t_fill);
-            gen_speculative_fill(g, target - missing.size(), missing, extra);
+            const size_t want = target - missing.size();
+            bool walk = true;
+            if (g->prefill_ready && g->prefill_epoch == g->rows_epoch) {
+                // what the list cannot know: the pools of the seeds whose statistics the pass it was collected under delivered
+                if (g->prefill_on == 2) gen_speculative_fill(g, want, missing, extra, g->prefill_fresh_seeds, 1);
+                for (int64_t r : g->prefill) {
+                    if (extra.size() >= want) break;
+                    if (g->kept[(size_t)r] != 0 && g->stats.count(r) == 0 && !gen_is_pending(g, r) &&
+                        std::find(missing.begin(), missing.end(), r) == missing.end() &&
+                        std::find(extra.begin(), extra.end(), r) == extra.end())
+                        extra.push_back(r);
+                }
+                // a list that did not fill its own slots had walked every pool: walking them again one pass later finds little
+                walk = extra.size() < want && !g->prefill_exhausted;
+                (walk ? g->prefill_topups : g->prefill_hits)++;
+            }
+            g->prefill_ready = false;
+            if (walk) gen_speculative_fill(g, want, missing, extra);
             missing.insert(missing.end(), extra.begin(), extra.end());
         }
     }
@@ -2935,9 +2970,22 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         {
             GenTimer t(&g->t_scan);
             GenTimer t2(&g->t_km[k]);
-            const std::function<void()> under_the_pass = [g] {
-                GenTimer th(&g->t_book_hidden);
-                gen_flush_pending(g);
+            const bool last_chunk = lo + max_k >= missing.size();
+            const std::function<void()> under_the_pass = [g, &missing, last_chunk] {
+                {
+                    GenTimer th(&g->t_book_hidden);
+                    gen_flush_pending(g);
+                }
+                if (g->prefill_on && g->speculate && last_chunk) {   // the next pass's speculative rows, collected under this one
+                    GenTimer tp(&g->t_fill_hidden);
+                    g->prefill.clear();
+                    g->pass_in_flight = true;
+                    gen_speculative_fill(g, (size_t)kMaxMedoids, missing, g->prefill);
+                    g->pass_in_flight = false;
+                    g->prefill_exhausted = g->prefill.size() < (size_t)kMaxMedoids;
+                    g->prefill_epoch = g->rows_epoch;
+                    g->prefill_ready = true;
+                }
             };
             slot = gen_scan(g, k, missing.data() + lo, &under_the_pass);
         }
@@ -3238,6 +3286,8 @@ vh_gen* gen_create_common(vh_clu* clu, vh_comm* comm, const int64_t* order, int6
     g->profile = option("gen.profile", 0) != 0;
     g->speculate = option("gen.speculate", 1) != 0;
     g->spec_window = (int)option("gen.spec_window", kSpecWindow);
+    g->prefill_on = (int)option("gen.prefill", 2);
+    g->prefill_fresh_seeds = (int)option("gen.prefill_fresh_seeds", 4);
     g->spec_neighbours = option("gen.spec_neighbours", 1) != 0;
     g->max_entry_age = option("gen.max_entry_age", kMaxEntryAgeDefault);
     g->spec_depth = (int)option("gen.spec_depth", 2);
@@ -3339,7 +3389,9 @@ int vh_gen_destroy(vh_gen* g) {
                 (long long)g->scan_medoids, (long long)g->spec_scanned, (long long)g->spec_used, (long long)g->spec_dropped);
     if (g && g->profile) {
         fprintf(stderr, "[vambhip]   host time inside 'rest': lazy validation %.1f ms (part of it inside the fill), speculative fill %.1f ms, "
-                "post-scan bookkeeping %.1f ms (+ %.1f ms under the next pass), removal log + eviction %.1f ms\n", g->t_validate, g->t_fill, g->t_book, g->t_book_hidden, g->t_emit);
+                "post-scan bookkeeping %.1f ms (+ %.1f ms under the next pass), removal log + eviction %.1f ms; fill one pass ahead: %.1f ms "
+                "under the passes, %lld lists used as they were, %lld topped up\n", g->t_validate, g->t_fill, g->t_book, g->t_book_hidden, g->t_emit,
+                g->t_fill_hidden, g->prefill_hits, g->prefill_topups);
         fprintf(stderr, "[vambhip]   passes by purpose: seed scans %lld, candidate rounds %lld, histogram re-scans %lld, selects %lld (+ %lld list selects); "
                 "seeds %lld (cached at arrival %lld), candidate rounds %lld (fully cached %lld, %lld candidates to scan), medoid moves %lld; "
                 "cached entries per emission %.1f; lazy validations %lld (%lld cluster tests, %lld row tests, %lld invalid), histograms reused %lld\n",
