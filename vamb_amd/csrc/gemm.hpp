@@ -27,7 +27,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <type_traits>
 
 namespace vh {
 

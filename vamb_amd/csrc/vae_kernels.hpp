@@ -10,7 +10,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <type_traits>
 
 #include "gemm.hpp"
 
