@@ -1,0 +1,223 @@
+"""TEST INFRASTRUCTURE ONLY -- drives the reference's REAL command line (``vamb bin default``) in the build container.
+
+``run_cli`` calls the unmodified ``vamb.__main__.main()`` (``oracle/ref_main.py``) on ``.npz`` composition / abundance inputs
+(``vamb/__main__.py:2622`` -> ``BinDefaultOptions.from_args`` -> ``run`` -> ``run_bin_default:1451`` -> ``trainvae:1065`` ->
+``cluster_and_write_files:1254``).  Two bindings of the hot-path names the CLI looks up at call time:
+
+* ``binding="reference"``: the reference's own classes behind RECORDING proxies -- every call the CLI makes on
+  ``vamb.encode.{make_dataloader, set_batchsize, VAE}``, ``VAE.{trainmodel, encode}`` and ``vamb.cluster.ClusterGenerator`` is
+  written down (positional / keyword form, scalar values, array shapes and dtypes): the *call trace* a drop-in must accept.
+* ``binding="dropin"``: ``vamb_amd.dropin.install()`` -- the product's classes.  In this container there is no GPU, so the caller
+  passes ``vae="reference"`` (the reference's VAE keeps training on the CPU; what is bound is the cluster side and the output
+  writer) and a ``backend_factory`` for the cluster generator (``tests/oracle_backend.py``); on a machine with a GPU and the
+  reference tree both would be the product's.
+
+Used by ``tests/golden/make_cli_golden.py`` and ``tests/test_cli_dropin.py``.
+"""
+from __future__ import annotations
+
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stderr, redirect_stdout
+from pathlib import Path
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import ref_harness  # noqa: E402
+import ref_main  # noqa: E402
+
+
+def contig_names(n: int, nsamples_in_names: int = 4, seed: int = 3) -> np.ndarray:
+    """``S<sample>C<contig>``: a binsplit separator ("C") with several samples, as a multi-sample assembly has."""
+    rng = np.random.RandomState(seed)
+    return np.array([f"S{rng.randint(1, nsamples_in_names + 1)}C{i}" for i in range(n)], dtype=object)
+
+
+def write_inputs(tmpdir, n: int, nsamples: int, data_seed: int):
+    """composition.npz / abundance.npz of the synthetic features, written by the reference's OWN ``Composition.save`` /
+    ``Abundance.save`` (parsecontigs.py:110, parsebam.py:55).  Returns (comp_path, abundance_path, names, lengths)."""
+    from vamb_amd import synth
+
+    vamb, _ = ref_main.load_reference_main()
+    ab, tnf, lens, _ = synth.features(n, nsamples, seed=data_seed)
+    names = contig_names(n)
+    meta = vamb.parsecontigs.CompositionMetaData(names, lens.astype(np.int32), np.ones(n, dtype=bool), 2000)
+    comp = vamb.parsecontigs.Composition(meta, tnf.copy())
+    abundance = vamb.parsebam.Abundance(ab.copy(), [f"sample{i}" for i in range(nsamples)], 0.0, meta.refhash)
+    cp, ap = Path(tmpdir) / "composition.npz", Path(tmpdir) / "abundance.npz"
+    comp.save(cp)
+    abundance.save(ap)
+    return cp, ap, names, lens
+
+
+def _describe(v):
+    """JSON-able description of one argument: scalars by value, arrays / tensors / loaders by kind, shape and dtype."""
+    import torch
+
+    if v is None or isinstance(v, (bool, int, float, str)):
+        return v
+    if isinstance(v, (np.integer, np.floating, np.bool_)):
+        return v.item()
+    if isinstance(v, Path):
+        return {"kind": "Path", "name": v.name}
+    if isinstance(v, np.ndarray):
+        return {"kind": "ndarray", "shape": list(v.shape), "dtype": str(v.dtype)}
+    if isinstance(v, torch.Tensor):
+        return {"kind": "Tensor", "shape": list(v.shape), "dtype": str(v.dtype)}
+    if isinstance(v, torch.utils.data.DataLoader):
+        return {"kind": "DataLoader", "batch_size": v.batch_size,
+                "tensors": [{"shape": list(t.shape), "dtype": str(t.dtype)} for t in v.dataset.tensors]}
+    if isinstance(v, (list, tuple)):
+        return [_describe(x) for x in v]
+    return {"kind": type(v).__name__}
+
+
+class CallTrace:
+    def __init__(self):
+        self.calls = []
+
+    def record(self, name, args, kwargs, result=None):
+        self.calls.append({"name": name, "args": [_describe(a) for a in args],
+                           "kwargs": {k: _describe(v) for k, v in kwargs.items()}, "result": _describe(result)})
+
+
+def _recording_bindings(vamb, trace: CallTrace):
+    """Proxies around the REFERENCE's hot-path names; returns the originals for the restore."""
+    enc, clu = vamb.encode, vamb.cluster
+    orig = dict(VAE=enc.VAE, make_dataloader=enc.make_dataloader, set_batchsize=enc.set_batchsize,
+                ClusterGenerator=clu.ClusterGenerator)
+
+    def make_dataloader(*a, **k):
+        out = orig["make_dataloader"](*a, **k)
+        trace.record("vamb.encode.make_dataloader", a, k, out)
+        return out
+
+    def set_batchsize(*a, **k):
+        out = orig["set_batchsize"](*a, **k)
+        trace.record("vamb.encode.set_batchsize", a, k, out)
+        return out
+
+    # The classes keep their NAMES and identities (vamb/encode.py:213 says ``super(VAE, self)`` with ``VAE`` looked up in the module
+    # at call time: a subclass or a factory bound to that name sends the reference's constructor into itself); their methods are
+    # wrapped in place and restored afterwards.
+    VAE, CG = orig["VAE"], orig["ClusterGenerator"]
+    orig["methods"] = [(VAE, "__init__", VAE.__init__), (VAE, "trainmodel", VAE.trainmodel), (VAE, "encode", VAE.encode),
+                       (CG, "__init__", CG.__init__)]
+
+    def wrap(cls, meth, label, with_result):
+        inner = getattr(cls, meth)
+
+        def wrapper(self, *a, **k):
+            if not with_result:
+                trace.record(label, a, k)
+                return inner(self, *a, **k)
+            out = inner(self, *a, **k)
+            trace.record(label, a, k, out)
+            return out
+
+        setattr(cls, meth, wrapper)
+
+    wrap(VAE, "__init__", "vamb.encode.VAE", False)
+    wrap(VAE, "trainmodel", "VAE.trainmodel", False)
+    wrap(VAE, "encode", "VAE.encode", True)
+    wrap(CG, "__init__", "vamb.cluster.ClusterGenerator", False)
+    enc.make_dataloader, enc.set_batchsize = make_dataloader, set_batchsize
+    return orig
+
+
+def run_cli(argv, binding: str = "reference", vae: str = "bound", backend_factory=None, threads: int = 4):
+    """Run the reference's real ``main()`` with ``sys.argv = ["vamb"] + argv``.  Returns a dict: ``trace`` (the recorded calls,
+    binding "reference" only), ``log`` (the messages the CLI logged), ``outdir``."""
+    import torch
+
+    vamb, main = ref_main.load_reference_main()
+    outdir = Path(argv[argv.index("--outdir") + 1])
+    log = ref_main.RecordingLogger()
+    loggers_of = [main, vamb.encode]
+    if binding == "dropin":   # the product's writer logs the reference's lines through its own module-level logger
+        from vamb_amd import output as _output
+
+        loggers_of.append(_output)
+    saved_loggers = {m: getattr(m, "logger") for m in loggers_of if hasattr(m, "logger")}
+    for m in saved_loggers:
+        m.logger = log
+    trace = CallTrace()
+    restore = None
+    dropin_saved = None
+    nthreads_before = torch.get_num_threads()
+    argv_before = list(sys.argv)
+    try:
+        if binding == "reference":
+            restore = _recording_bindings(vamb, trace)
+        elif binding == "dropin":
+            from vamb_amd import cluster as vc, dropin
+
+            dropin_saved = dropin.install(vamb, strict=True)
+            if vae == "reference":   # no GPU in the build container: the model side stays the reference's
+                vamb.encode.VAE = dropin_saved["VAE"]
+                vamb.encode.make_dataloader = dropin_saved["make_dataloader"]
+                vamb.encode.set_batchsize = dropin_saved["set_batchsize"]
+            if backend_factory is not None:
+                base = vc.ClusterGenerator
+
+                class _Gen(base):   # the product's generator class and host logic, scans answered by the test backend
+                    def __init__(self, *a, **k):
+                        super().__init__(*a, _backend_factory=backend_factory, **k)
+
+                vamb.cluster.ClusterGenerator = _Gen
+                # (the product's writer constructs the product's generator itself; its private hook takes the test backend's)
+                import functools
+
+                from vamb_amd import output
+
+                main.cluster_and_write_files = functools.partial(output.cluster_and_write_files, _cluster_generator=_Gen)
+        else:
+            raise ValueError(binding)
+        sys.argv = ["vamb"] + [str(a) for a in argv]
+        sink = io.StringIO()
+        with redirect_stdout(sink), redirect_stderr(sink):
+            main.main()
+    finally:
+        sys.argv = argv_before
+        torch.set_num_threads(nthreads_before)
+        for m, lg in saved_loggers.items():
+            m.logger = lg
+        if restore is not None:
+            vamb.encode.make_dataloader, vamb.encode.set_batchsize = restore["make_dataloader"], restore["set_batchsize"]
+            for cls, meth, fn in restore["methods"]:
+                setattr(cls, meth, fn)
+        if dropin_saved is not None:
+            from vamb_amd import dropin
+
+            dropin.uninstall(dropin_saved, vamb)
+    return {"trace": trace.calls, "log": log.messages, "outdir": outdir}
+
+
+def read_outputs(outdir) -> dict:
+    """The files ``vamb bin default`` leaves (``vamb/__main__.py:1096, 1310-1312``)."""
+    outdir = Path(outdir)
+    out = {}
+    for name in ("vae_clusters_metadata.tsv", "vae_clusters_unsplit.tsv", "vae_clusters_split.tsv"):
+        p = outdir / name
+        out[name] = p.read_text() if p.exists() else None
+    vt = ref_harness.load_reference()[0]
+    out["latent"] = vt.read_npz(outdir / "latent.npz") if hasattr(vt, "read_npz") else np.load(outdir / "latent.npz")["arr_0"]
+    out["files"] = sorted(p.name for p in outdir.iterdir())
+    return out
+
+
+if __name__ == "__main__":   # python oracle/cli_reference.py <tmpdir> n S : one recorded run, trace on stdout
+    tmp, n, S = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    cp, ap, _, _ = write_inputs(tmp, n, S, 5)
+    r = run_cli(["bin", "default", "--outdir", os.path.join(tmp, "out"), "--composition", cp, "--abundance", ap, "-e", "3",
+                 "-q", "1", "-t", "64", "--seed", "11", "-o", "C", "-p", "2"])
+    print(json.dumps(r["trace"], indent=1))
+    print("\n".join(m for _, m in r["log"])[:3000])
