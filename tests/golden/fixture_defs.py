@@ -167,6 +167,10 @@ VAE_CASES = {
     # checksums), per-row outputs keep their first `rows_keep` rows + the norm of the whole array, weights are summarised.
     "vae_c1_shape": dict(n=4096, batch=4096, nsamples=50, nhiddens=[512, 512], nlatent=32, dropout=0.2,
                          alpha=None, beta=200.0, seed=26, steps=2, store="summary", rows_keep=96, store_inputs=False),
+    # BASELINE configs[2]'s shape -- the benchmarked one: 200 samples (D = 304), batch 8192, default architecture (round 6, VERDICT r5
+    # item 6: the bf16 step is judged at the benchmarked shape against the REAL reference, not only against the fp64 restatement)
+    "vae_c2_shape": dict(n=8192, batch=8192, nsamples=200, nhiddens=[512, 512], nlatent=32, dropout=0.2,
+                         alpha=None, beta=200.0, seed=27, steps=2, store="summary", rows_keep=96, store_inputs=False),
 }
 
 
@@ -208,12 +212,7 @@ def _regenerated_vae_inputs(name, g):
 
     c = VAE_CASES[name]
     ab, tnf, lens = vae_inputs(name)
-    mode = ve._PREP_MODE
-    ve.set_prep_mode("host")
-    try:
-        dl = ve.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=c["batch"])
-    finally:
-        ve.set_prep_mode(mode)
+    dl = ve.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=c["batch"], _prep="host")
     out = {}
     for k, v in zip(("depths", "tnf", "total_abundance", "weights"), dl.dataset.tensors):
         v = v.numpy()

@@ -212,7 +212,7 @@ _ENV_OPTIONS = {
     "VAMBHIP_VAE_OPT_SPLIT": ("vae.opt_split", int),
     "VAMBHIP_VAE_FUSED_SKINNY": ("vae.fused_skinny", int),
     "VAMBHIP_VAE_FUSED_FINALIZE": ("vae.fused_finalize", int),
-    "VAMBHIP_VAE_DZ_DBG": ("vae.dz_dbg", int),
+    "VAMBHIP_VAE_FUSED_DZ": ("vae.fused_dz", int),
     "VAMBHIP_VAE_PREFETCH_BATCH": ("vae.prefetch_batch", int),
     "VAMBHIP_VAE_FORK_PLAN": ("vae.fork_plan", int),
     "VAMBHIP_VAE_FORK_MODE": ("vae.fork_mode", int),

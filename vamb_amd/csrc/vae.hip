@@ -225,7 +225,9 @@ struct VaeTuning {
     bool loss_from_dataset = true; // vae.loss_from_dataset: bf16 step of the plain VAE: the loss kernel reads its targets from the dataset
                               // rows of the batch; the gather kernel then writes no fp32 copy of the batch (a third of its traffic)
     bool loss_dpp = true;     // vae.loss_dpp: bf16 loss kernel: row reductions by DPP instead of ds_bpermute (see vae_loss16_kernel)
-    int dz_dbg = 0;           // vae.dz_dbg: timing experiments on the elementwise BatchNorm-backward kernel (WRONG results): see Dz16Args
+    bool fused_dz = true;     // vae.fused_dz: bf16 step: the elementwise BatchNorm / dropout / LeakyReLU backward of a hidden layer is applied
+                              // by the input-gradient GEMM that consumes it, while that GEMM stages its A operand (gemm_bf16.hpp STG == 3),
+                              // instead of by a launch of vae_dz16_kernel in front of it.  Same bits (one definition of the element).
     bool dw_row_major = true; // vae.dw_row_major: bf16 weight gradients contract ROW-major tensors (gemm_bf16_tn.hpp); 0 = the
                               // round-2 dataflow with a transposed bf16 copy of every contracted tensor (A/B measurements)
 } g_tuning;
@@ -241,7 +243,7 @@ void refresh_tuning() {
     g_tuning.pipeline = option("vae.gemm_pipeline", 2) == 0 ? 0 : 2;
     g_tuning.fused_skinny = option("vae.fused_skinny", 1) != 0;
     g_tuning.fused_finalize = option("vae.fused_finalize", 0) != 0;
-    g_tuning.dz_dbg = (int)option("vae.dz_dbg", 0);
+    g_tuning.fused_dz = option("vae.fused_dz", 1) != 0;
     g_tuning.loss_dpp = option("vae.loss_dpp", 1) != 0;
     g_tuning.loss_from_dataset = option("vae.loss_from_dataset", 1) != 0;
     g_tuning.prefetch_max_cols = (int)option("vae.prefetch_max_cols", 512);

@@ -401,15 +401,13 @@ struct Dz16Args {
     int64_t ldt;       // leading dimension of DZT (= bs_p)
     int n_p, bs, bs_p;
     BnSrc bn;
-    const float* mean;    // mean / 1/std of this layer's BatchNorm as the forward fold left them (nullptr: from the fp64 sums)
+    const float* mean;    // mean / 1/std of this layer's BatchNorm as the forward fold left them
     const float* istd;
     const double* bstat;
     float drop_scale;
     const uint8_t* drop_mask;
     int64_t ld_mask;
     double* dbias;
-    int dbg;              // timing experiments only (option vae.dz_dbg; WRONG results): 1 no column-sum atomics, 2 no dZ stores,
-                          // 4 constant coefficients (no statistics loads)
 };
 // (Two register-transposing variants without LDS -- a thread owning an 8 x 8 block, 128 x 128 tiles with 4 waves or
 // 64 x 64 tiles with one wave -- measured 18 and 37 us against 13.7 us for this kernel at 8192 x 512: profiles/README.md.)
@@ -442,17 +440,9 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
     if (tid < kDz16Cols) {
         const int colc = col0 + tid;
         float ca = 0.f, ch = 0.f, c0 = 0.f;
-        if (colc < a.n_p && (a.dbg & 4)) { ca = 1.0f; ch = 0.5f; c0 = 0.25f; }
-        else if (colc < a.n_p) {
-            float mean, istd, sc, sh;
-            if (a.mean != nullptr) { mean = a.mean[colc]; istd = a.istd[colc]; }   // (the same floats bn_column forms)
-            else bn_column(a.bn, colc, mean, istd, sc, sh);
-            const double inv_bs = 1.0 / (double)a.bn.bs;   // the statistics' batch (all ranks under SyncBN)
-            const float c1 = (float)(a.bstat[colc] * inv_bs);
-            const float c2 = (float)(a.bstat[a.n_p + colc] * inv_bs);
-            ca = a.drop_scale * istd * a.bn.gamma[colc];
-            ch = -ca * istd * c2;
-            c0 = -ca * c1 - ch * mean;
+        if (colc < a.n_p) {   // (a.mean / a.istd: the floats the forward fold left -- the same bn_column forms)
+            const DzCoefSrc src{a.mean, a.istd, a.bn.gamma, a.bstat, a.n_p, a.bn.bs, a.drop_scale};
+            dz16_coeffs(src, colc, ca, ch, c0);
         }
         cf[0][tid] = ca; cf[1][tid] = ch; cf[2][tid] = c0;
     }
@@ -473,10 +463,8 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
                 const float d = (e & 1) ? bf_hi(dw[e >> 1]) : bf_lo(dw[e >> 1]);
                 const float h = (e & 1) ? bf_hi(hw[e >> 1]) : bf_lo(hw[e >> 1]);
                 bool keep = true;
-                if (hashed_drop) keep = h != 0.f;
-                else if (a.drop_mask) keep = a.drop_mask[(int64_t)r * a.ld_mask + col + e] != 0;
-                const float l = ca[e] * d + ch[e] * h + c0[e];
-                const float dz = keep ? l * (h > 0.f ? 1.0f : kLeakySlope) : 0.f;
+                if (a.drop_mask) keep = a.drop_mask[(int64_t)r * a.ld_mask + col + e] != 0;
+                const float dz = keep ? dz16_elem(d, h, ca[e], ch[e], c0[e], hashed_drop) : 0.f;
                 const bf16_t b = f2bf(dz);
                 s[e] += bf2f(b);
                 ow[e >> 1] |= (uint32_t)b << (16 * (e & 1));
@@ -484,7 +472,7 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
         }
         const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         if (a.DZT) *reinterpret_cast<uint4*>(&tile[rl][c8]) = o;
-        if (r < a.bs_p && col < a.n_p && !(a.dbg & 2)) *reinterpret_cast<uint4*>(a.DZ + (int64_t)r * a.n_p + col) = o;
+        if (r < a.bs_p && col < a.n_p) *reinterpret_cast<uint4*>(a.DZ + (int64_t)r * a.n_p + col) = o;
     }
     if (a.dbias) {
 #pragma unroll
@@ -513,7 +501,7 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += red[i][tid];
-        if (c < a.n_p && !(a.dbg & 1)) atomicAdd(&a.dbias[c], (double)t);
+        if (c < a.n_p) atomicAdd(&a.dbias[c], (double)t);
     }
 }
 

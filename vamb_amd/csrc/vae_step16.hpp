@@ -63,6 +63,34 @@ void launch_gemm16_tn(hipStream_t stream, const Gemm16TnArgs& g, int splits) {
     VH_HIP(hipGetLastError());
 }
 
+// input-gradient GEMM that forms its A operand (dZ of the layer above) while staging it (gemm_bf16.hpp, STG == 3); the LDS
+// holds the operand buffers + the [3][K] coefficient table.  false: the shape does not fit (the caller keeps vae_dz16_kernel)
+constexpr int kFusedDzBM = 128, kFusedDzBN = 128;
+inline size_t fused_dz_smem(int K) {
+    return gemm16_smem_bytes<kFusedDzBM, kFusedDzBN, 2, 4, E16_STORE_BNRED, 3>() + (size_t)12 * round_up(K, 64);
+}
+inline bool fused_dz_fits(const Gemm16Args& g) {
+    return g.k_per_split == g.K && (g.K & 7) == 0 && fused_dz_smem(g.K) <= kMaxDynLds && g.M % kFusedDzBM == 0 && g.N % kFusedDzBN == 0 &&
+           g.m_real == g.M;
+}
+void launch_gemm16_fused_dz(hipStream_t stream, const Gemm16Args& g) {
+    static bool attr_set = false;
+    auto kern = gemm_bf16_kernel<kFusedDzBM, kFusedDzBN, 2, 4, E16_STORE_BNRED, 3>;
+    if (!attr_set) {
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+        attr_set = true;
+    }
+    const size_t smem = fused_dz_smem(g.K);
+    dim3 grid((unsigned)ceil_div(g.N, kFusedDzBN), (unsigned)ceil_div(g.M, kFusedDzBM), 1);
+    if (t_fork_stop) {
+        hipExtLaunchKernelGGL(kern, grid, dim3(512), smem, stream, nullptr, t_fork_stop, 0, g);
+        t_fork_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, g);
+    }
+    VH_HIP(hipGetLastError());
+}
+
 // latent-wide product with its elementwise consumer in one launch (gemm_skinny16.hpp); false: the shape does not fit one
 // workgroup's LDS and the caller keeps the split-K launch + slab kernel
 template <int EPI>
@@ -553,8 +581,12 @@ void grad_weight16_rm(vh_vae* h, int tW, const bf16_t* dZ, int out_p, const bf16
     else gemm16_tn<0>(st, g, splits);
 }
 
-// dIn16 = dZ16 [bs_p][out] x W16T [in][out]; the epilogue leaves the BatchNorm-backward sums of the layer below
-void grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidden& below) {
+// dIn16 = dZ16 [bs_p][out] x W16T [in][out]; the epilogue leaves the BatchNorm-backward sums of the layer below.
+// `above` (with `dz_hashed` >= 0): dZ16 of that layer does not exist yet -- the GEMM forms it from the layer's dA16 / H16 while it
+// stages its A operand and its first tile column stores it (vae.fused_dz); returns false when the shape does not fit that kernel
+// (the caller then runs vae_dz16_kernel first and calls again without `above`).  `fork`: the side stream continues behind this launch.
+bool grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidden& below, Hidden* above = nullptr,
+                  float drop_scale = 1.0f, bool dz_hashed = false, bool fork = false) {
     Gemm16Args g = args16(h);
     g.A = dZ; g.lda = out_p;
     g.B = w16t(h, tW); g.ldb = out_p;
@@ -565,8 +597,25 @@ void grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidd
     g.bnC = bn_src(h, below);
     g.bn_mean = below.mean.p; g.bn_istd = below.invstd.p;   // left by the fold of this layer's BatchNorm in the forward pass
     g.bstat_out = below.bstat;
-    gemm16<E16_STORE_BNRED>(h->stream, g, 1);
+    if (above) {
+        g.A = above->DA16.p;
+        g.dzH = above->H16.p; g.ld_dzh = out_p;
+        g.dzc = DzCoefSrc{above->mean.p, above->invstd.p, h->pptr(above->tG), above->bstat, out_p, stat_bs(h), drop_scale};
+        g.dz_hashed = dz_hashed ? 1 : 0;
+        g.dzOut = above->DZ16.p; g.ld_dzout = out_p;
+        if (!fused_dz_fits(g)) return false;
+    }
+    const bool ext = fork && h->side != h->stream && g_tuning.fork_mode != 2 && fork_from_kernel(h);
+    if (ext) t_fork_stop = h->ev_fork;
+    if (above) launch_gemm16_fused_dz(h->stream, g);
+    else gemm16<E16_STORE_BNRED>(h->stream, g, 1);
+    if (ext) VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    else if (fork && h->side != h->stream) {
+        if (g_tuning.fork_mode == 2) fork_by_value(h);
+        else fork_side(h);
+    }
     sync_stats(h, below.bstat, below.nout_p);
+    return true;
 }
 
 void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
@@ -597,7 +646,6 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         a.n_p = hl.nout_p; a.bs = bs; a.bs_p = bs_p;
         a.bn = bn_src(h, hl);
         a.mean = hl.mean.p; a.istd = hl.invstd.p;
-        a.dbg = g_tuning.dz_dbg;
         a.bstat = hl.bstat;
         a.drop_scale = dc.scale;
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
@@ -654,6 +702,16 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         // encoder layer 1 299 against 297 on the box of that run.
         const bool fork = li == 2 * nl - 1 || li == 1 || (li == 0 && !q.items.empty()) ||
                           (li == nl && nl >= 2 && (g_tuning.fork_plan & 1) != 0);
+        // vae.fused_dz: a layer whose dZ feeds a regular input-gradient GEMM (every hidden layer but the first of each half) is
+        // not given its own elementwise launch: that GEMM forms dZ while it stages its A operand (gemm_bf16.hpp, STG == 3) and
+        // stores it for this layer's weight gradient, which therefore forks behind the GEMM instead of behind the dZ kernel.
+        // Needs row-major weight gradients with their own column sums (the bias gradient) and hash dropout or none.
+        const bool can_fuse = g_tuning.fused_dz && li != 0 && li != nl && rm && colsum_in_gemm && a.drop_mask == nullptr &&
+                              hl.mean.p != nullptr;
+        if (can_fuse && grad_input16(h, nullptr, hl.nout_p, hl.tW, in_p, h->hidden[li - 1], &hl, dc.scale, dc.scale != 1.0f, fork)) {
+            if (fork) q.flush(h->side);
+            return;
+        }
         const dim3 grid((unsigned)ceil_div(hl.nout_p, kDz16Cols), (unsigned)ceil_div(bs_p, kDz16Rows));
         if (fork) {
             launch_forking(h, vae_dz16_kernel, grid, dim3(256), 0, a);

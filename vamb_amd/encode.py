@@ -127,9 +127,10 @@ def set_batchsize(data_loader: _DataLoader, batch_size: int, n_obs: int, encode=
 
 
 def make_dataloader(abundance: _np.ndarray, tnf: _np.ndarray, lengths: _np.ndarray, batchsize: int = 256,
-                    destroy: bool = False, cuda: bool = False) -> _DataLoader:
+                    destroy: bool = False, cuda: bool = False, _prep: Optional[str] = None) -> _DataLoader:
     """Normalise abundance / TNF / lengths and wrap them as the reference's DataLoader
-    (encode.py:53-146): tensors are (depths [N,S], tnf [N,103], total_abundance [N,1], weights [N,1])."""
+    (encode.py:53-146): tensors are (depths [N,S], tnf [N,103], total_abundance [N,1], weights [N,1]).
+    ``_prep`` (private): "host" / "device" for THIS call, whatever the module setting and VAMBHIP_PREP say."""
     if not isinstance(abundance, _np.ndarray) or not isinstance(tnf, _np.ndarray):
         raise ValueError("TNF and abundance must be Numpy arrays")
     if batchsize < 1:
@@ -138,7 +139,9 @@ def make_dataloader(abundance: _np.ndarray, tnf: _np.ndarray, lengths: _np.ndarr
         raise ValueError("Lengths of abundance, TNF and lengths arrays must be the same")
     if not (abundance.dtype == tnf.dtype == _np.float32):
         raise ValueError("TNF and abundance must be Numpy arrays of dtype float32")
-    mode = get_prep_mode()
+    mode = get_prep_mode() if _prep is None else _prep
+    if mode not in ("auto", "host", "device"):
+        raise ValueError(f"prep mode must be 'auto', 'host' or 'device', not {mode!r}")
     if mode != "host" and _device_prep_possible(abundance, tnf, required=(mode == "device")):
         return _make_dataloader_device(abundance, tnf, lengths, batchsize, destroy)
     if not destroy:

@@ -163,12 +163,7 @@ def make_dataloader_labels_hloss(rpkm, tnf, lengths, labels, N, table_parent, ba
     and throws it away: the feature arrays contribute their validation (dtypes, shapes, batch size against the dataset,
     zero-depth / zero-TNF rows) and, with ``destroy=True``, are normalised in place -- both kept by routing them through
     ``make_dataloader`` (host path: nothing of it is used afterwards)."""
-    prep = _encode._PREP_MODE
-    _encode.set_prep_mode("host")
-    try:
-        _encode.make_dataloader(rpkm, tnf, lengths, batchsize, destroy, cuda)
-    finally:
-        _encode.set_prep_mode(prep)
+    _encode.make_dataloader(rpkm, tnf, lengths, batchsize, destroy, cuda, _prep="host")
     dataset = _TensorDataset(_torch.Tensor(labels).long())
     return _DataLoader(dataset=dataset, batch_size=batchsize, drop_last=dataset.tensors[0].shape[0] > batchsize, shuffle=True,
                        num_workers=0, pin_memory=False, collate_fn=partial(collate_fn_labels_hloss, N, table_parent))
