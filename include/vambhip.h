@@ -71,6 +71,12 @@ int vh_set_option(const char* name, int64_t value);
 int vh_unset_option(const char* name);
 int vh_get_option(const char* name, int64_t* value /* in: default, out: the value in force */);
 int vh_set_option_string(const char* name, const char* value);
+/* Start-up self-test of the kernels that rest on hand-counted waits behind inline-asm loads (csrc/selftest.hip): the row-major
+ * many-medoid scan and the deep-prefetch / K-group tiles of the fp32 GEMM are run once beside their compiler-scheduled twins; a
+ * disagreement switches the selecting option off for the process (scan.mfma_rowmajor = 0; vae.gemm_prefetch = vae.gemm_kgroups
+ * = 1) and reports on stderr.  *fallbacks: bit 0 = scan fell back, bit 1 = GEMM tiles fell back.  ~40 ms; call once, before the
+ * first handle is created (vamb_amd/_lib.py does).  No reference counterpart: a property of this build, not of Vamb. */
+int vh_selftest(int* fallbacks);
 /* number of visible HIP devices (0 with an error message when there is no GPU) */
 int vh_device_count(int* n);
 /* bind the calling process to a device (LOCAL_RANK under torch.distributed.run) */

@@ -54,6 +54,7 @@ SIGNATURES = {
     "vh_unset_option": (_int, [ctypes.c_char_p]),
     "vh_get_option": (_int, [ctypes.c_char_p, ctypes.POINTER(_i64)]),
     "vh_set_option_string": (_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "vh_selftest": (_int, [ctypes.POINTER(_int)]),
     "vh_device_count": (_int, [ctypes.POINTER(_int)]),
     "vh_set_device": (_int, [_int]),
     "vh_clu_create": (_int, [_vp, _vp, _i64, _int, _int, _vp, _pp]),
@@ -277,11 +278,30 @@ def device_count() -> int:
     return n.value
 
 
+_selftest_done = False
+selftest_fallbacks = 0   # bit 0: row-major scan kernel switched off, bit 1: deep-prefetch / K-group GEMM tiles switched off
+
+
 def require_gpu():
-    """Fail loudly when no MI355X is visible (never silently fall back)."""
+    """Fail loudly when no MI355X is visible (never silently fall back).  The first call of a process also runs the library's
+    start-up self-test (``vh_selftest``, csrc/selftest.hip: the hand-scheduled kernels beside their compiler-scheduled twins;
+    VAMBHIP_SELFTEST=0 skips it); options it had to switch off stay off for the process."""
+    global _selftest_done, selftest_fallbacks
     n = device_count()
     if n < 1:
         raise VambHipError("no HIP device visible")
+    if not _selftest_done:
+        _selftest_done = True
+        if os.environ.get("VAMBHIP_SELFTEST", "1") != "0":
+            sync_env_options()
+            mask = _int(0)
+            check(load().vh_selftest(ctypes.byref(mask)))
+            selftest_fallbacks = mask.value
+            if mask.value & 1:   # (an entry in _explicit_options: sync_env_options leaves the option as the self-test set it)
+                _explicit_options["scan.mfma_rowmajor"] = 0
+            if mask.value & 2:
+                _explicit_options["vae.gemm_prefetch"] = 1
+                _explicit_options["vae.gemm_kgroups"] = 1
     return n
 
 

@@ -38,6 +38,7 @@ SOURCES = {
     "prep.hip": ["-ffp-contract=off"],
     "tnf.hip": ["-ffp-contract=off"],
     "comm.hip": [],
+    "selftest.hip": [],   # host code on top of the C ABI (start-up self-test of the hand-scheduled kernels)
 }
 
 

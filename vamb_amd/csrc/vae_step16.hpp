@@ -69,6 +69,9 @@ constexpr int kFusedDzBM = 128, kFusedDzBN = 128;
 inline size_t fused_dz_smem(int K) {
     return gemm16_smem_bytes<kFusedDzBM, kFusedDzBN, 2, 4, E16_STORE_BNRED, 3>() + (size_t)12 * round_up(K, 64);
 }
+inline bool fused_dz_shape_ok(int M, int N, int K) {
+    return (K & 7) == 0 && fused_dz_smem(K) <= kMaxDynLds && M % kFusedDzBM == 0 && N % kFusedDzBN == 0;
+}
 inline bool fused_dz_fits(const Gemm16Args& g) {
     return g.k_per_split == g.K && (g.K & 7) == 0 && fused_dz_smem(g.K) <= kMaxDynLds && g.M % kFusedDzBM == 0 && g.N % kFusedDzBN == 0 &&
            g.m_real == g.M;
@@ -650,14 +653,21 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         a.drop_scale = dc.scale;
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
         const bool rm = g_tuning.dw_row_major;
+        const int in_p = li == 0 ? h->D_p : (li == nl ? h->L_p : h->hidden[li - 1].nout_p);
+        // vae.fused_dz: a layer whose dZ feeds a regular input-gradient GEMM (every hidden layer but the first of each half) is
+        // not given its own elementwise launch: that GEMM forms dZ while it stages its A operand (gemm_bf16.hpp, STG == 3) and
+        // stores it for this layer's weight gradient, which therefore forks behind the GEMM instead of behind the dZ kernel and
+        // takes the bias gradient (the column sums of dZ) on its way.  Needs row-major weight gradients, hash dropout or none,
+        // a full batch and tile-aligned widths.
+        const bool fuse = g_tuning.fused_dz && li != 0 && li != nl && rm && a.drop_mask == nullptr && hl.mean.p != nullptr &&
+                          bs == bs_p && fused_dz_shape_ok(bs_p, in_p, hl.nout_p);
         // bias gradient = column sums of dZ: with row-major weight gradients the dW GEMM of this layer streams dZ anyway and
         // sums it on the way (COLSUM, a few atomics per column); the elementwise kernel's own sums cost it one fp64 atomic per
         // column from each of its bs_p / 64 row blocks (vae.dz_colsum = 1: keep them there, A/B)
-        const bool colsum_in_gemm = rm && !g_tuning.dz_colsum;
+        const bool colsum_in_gemm = rm && (fuse || !g_tuning.dz_colsum);
         a.dbias = colsum_in_gemm ? nullptr : hl.dbias;
         const bf16_t* InT = rm ? (li == 0 ? h->Xb16.p : (li == nl ? h->Z16.p : h->hidden[li - 1].H16.p))     // row-major input
                                : (li == 0 ? h->Xb16T.p : (li == nl ? h->Z16T.p : h->hidden[li - 1].H16T.p));
-        const int in_p = li == 0 ? h->D_p : (li == nl ? h->L_p : h->hidden[li - 1].nout_p);
         auto dw = [h, &hl, InT, in_p, rm, colsum_in_gemm](hipStream_t st) {
             if (rm) grad_weight16_rm(h, hl.tW, hl.DZ16.p, hl.nout_p, InT, in_p, colsum_in_gemm ? hl.dbias : nullptr, st);
             else grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, st);
@@ -702,13 +712,9 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         // encoder layer 1 299 against 297 on the box of that run.
         const bool fork = li == 2 * nl - 1 || li == 1 || (li == 0 && !q.items.empty()) ||
                           (li == nl && nl >= 2 && (g_tuning.fork_plan & 1) != 0);
-        // vae.fused_dz: a layer whose dZ feeds a regular input-gradient GEMM (every hidden layer but the first of each half) is
-        // not given its own elementwise launch: that GEMM forms dZ while it stages its A operand (gemm_bf16.hpp, STG == 3) and
-        // stores it for this layer's weight gradient, which therefore forks behind the GEMM instead of behind the dZ kernel.
-        // Needs row-major weight gradients with their own column sums (the bias gradient) and hash dropout or none.
-        const bool can_fuse = g_tuning.fused_dz && li != 0 && li != nl && rm && colsum_in_gemm && a.drop_mask == nullptr &&
-                              hl.mean.p != nullptr;
-        if (can_fuse && grad_input16(h, nullptr, hl.nout_p, hl.tW, in_p, h->hidden[li - 1], &hl, dc.scale, dc.scale != 1.0f, fork)) {
+        if (fuse) {
+            const bool ok = grad_input16(h, nullptr, hl.nout_p, hl.tW, in_p, h->hidden[li - 1], &hl, dc.scale, dc.scale != 1.0f, fork);
+            VH_REQUIRE(ok, "fused dZ: shape predicate and launcher disagree");
             if (fork) q.flush(h->side);
             return;
         }
