@@ -35,10 +35,12 @@ typedef enum {
 const char* vh_last_error(void);
 const char* vh_version(void);
 
-/* Process-wide tuning / diagnostic options, read when a handle is created.  The library itself reads NO environment
- * variables (the Python layer forwards its VAMBHIP_* variables through these calls, vamb_amd/_lib.py).  Integer options:
- *   scan.column_loop (1)   0: runtime-width column loop in every scan kernel; 1: unrolled loads up to 8 medoids
- *   scan.mfma (1)          passes with more than 8 medoids on the matrix-pipe kernel
+/* Process-wide options, read when a handle is created.  The library itself reads NO environment variables (the Python layer
+ * forwards its VAMBHIP_* variables through these calls, vamb_amd/_lib.py).  Round 6 removed the measured-slower variants that
+ * were kept "for the A/B" (stream-memory forks, the split optimiser, per-pass streams of the joint trainer, the transposed-copy
+ * weight-gradient dataflow, the bias sums inside the weight-gradient GEMM, the two-buffer K loop, the non-DPP loss reductions,
+ * the timing switches that produced wrong results): what is left selects between code paths the tests cross-check bit for bit,
+ * or sets a policy.  Integer options:
  *   scan.reference_order (2)  evaluation order of the two float32 reductions behind every cluster decision, `matrix.matmul` and
  *                          `matrix.norm` (cluster.py:668, 674).  2 (default): the order measured on the reference's own torch /
  *                          oneMKL AVX-512 CPU build (oracle/probe_reference_order.py) -- the cluster stream equals the reference's
@@ -46,26 +48,27 @@ const char* vh_version(void);
  *                          re-evaluate in the reference's order only the pairs within the rounding slack of a decision boundary.
  *                          1: the same order on a plain one-pair-per-lane kernel (cross-check, ~3x the time per pass).
  *                          0: the ascending fmaf chain (the default of rounds 1-3; differs from the reference at near-ties)
- *   scan.wide_rows (0)     fixed 4 / 2 rows per lane (no narrow variants for small matrices)
- *   scan.min_blocks (768)  workgroups wanted before lanes take more than one row (measured neutral between 384 and 1536)
- *   scan.debug (0)         timing experiments only (wrong results): 1 no pair of interest, 2 no histogram, 4 no flush,
- *                          8 no drain, 32 no histogram publication
+ *   scan.column_loop (1)   0: runtime-width column loop in every scan kernel; 1: unrolled loads up to 8 medoids
+ *   scan.mfma (1)          passes with more than 8 medoids on the matrix-pipe kernels
+ *   scan.mfma_rowmajor (1) ... on the row-major copy of the matrix (K6r); 0 = the column-major kernel, its compiler-scheduled twin
+ *                          (the start-up self-test's fallback, vh_selftest)
+ *   gen.speculate (1), gen.spec_window (16)   medoid statistics scanned ahead of need in the free slots of a pass
+ *   gen.prefill (2)        the speculative fill of a pass collected one pass ahead, under the running pass
+ *   gen.inline_removals (1)  rows of an emitted cluster are cleared by the NEXT scan's own prologue (kernel arguments) instead of
+ *                          by a launch of their own; same stream
  *   gen.profile (0)        wall-clock breakdown of the native cluster state machine on stderr
- *   gen.speculate (1), gen.spec_window (16), gen.spec_big_target (0)   medoid statistics scanned ahead of need in the free slots of a pass
- *   gen.spec_neighbours (1)  ... including the within-radius rows of cached upcoming seeds (their first candidate round)
- *   gen.spec_depth (2)       ... and the within-radius rows of those rows (1: first ring only)
- *   gen.max_entry_age (32)   emissions a cached medoid statistic may outlive (validated lazily against the removal log)
- *   gen.defer_bookkeeping (1) cache entries of speculative results are built while the next pass runs
- *   vae.single_stream (0)  weight-gradient GEMMs on the main stream
- *   vae.fork_events (0)    forks as event records instead of kernel completion signals
+ *   gen.gather_stage_bytes (64 MiB)  staging buffer of vh_gen_create_sharded's matrix gather
+ *   vae.single_stream (0)  weight-gradient GEMMs on the main stream;  vae.fork_events (0)  forks as event records instead of kernel
+ *                          completion signals (both: scheduling cross-checks, bit-identical)
+ *   vae.fork_plan (-1)     two-stream schedule of the bf16 step, bit mask (csrc/vae.hip VaeTuning); -1 = by input width
+ *   vae.dw_pair (1)        the last two weight gradients of a step as one launch;  vae.fused_skinny (1)  latent-wide products with
+ *                          their elementwise consumer in one launch;  vae.fused_finalize (1)  the optimiser's scalar tail on the last
+ *                          workgroup of the update kernel;  vae.prefetch_batch (1), vae.prefetch_max_cols (512)  the next batch
+ *                          assembled during the running step;  vae.loss_from_dataset (1)  loss targets read from the dataset rows
+ *   vae.gemm_prefetch (4), vae.gemm_kgroups (4)   fp32 GEMM: four K-tiles in flight / four K groups per workgroup for small launches
+ *                          (1 = the plain tile: the self-test's fallback)
  *   vae.big_tiles (0), vae.xcd_remap (1), vae.dw_workgroups (256), vae.debug_timing (0)
- *   vae.gemm_pipeline (2)  K loop of the bf16 GEMMs: 2 = three LDS buffers, DMA issue interleaved with the MFMAs; 0 = two buffers
- *   vae.dw_row_major (1)   bf16 weight gradients contract row-major tensors (transposing LDS reads); 0 = transposed bf16 copies
- *   vae.fork_at_loss (0)   the side stream also forks at the loss kernel (one more fork: measured slower)
- *   vae.opt_split (0)      the optimiser's decoder-side half on the side stream during the encoder's backward (bit-identical, measured slower)
- *   vae.probe_every (16)   the roofline probe (vh_vae_set_probe) times every n-th launch of the probed GEMM: a timed launch is
- *                          bracketed by a start and a stop event, which costs the step it measures
- *   vae.dz_colsum (1)      bias-gradient column sums in the BatchNorm-backward kernel; 0 = inside the weight-gradient GEMM (measured slower)
+ *   vae.probe_every (16)   the roofline probe (vh_vae_set_probe) times every n-th launch of the probed GEMM
  * String options: comm.rccl_library (path of librccl), comm.rocm_path (default /opt/rocm). */
 int vh_set_option(const char* name, int64_t value);
 int vh_unset_option(const char* name);

@@ -42,7 +42,7 @@ def test_sweep_counters_and_stream_are_identical_run_to_run():
         b = gen._backend
         runs.append((len(clusters), int(b.scan_passes), int(b.scan_medoids), _stream_hash(clusters)))
         b.close()
-    assert runs[0][0] > 10_000 and runs[0][1] > runs[0][0]      # a real sweep: more passes than clusters
+    assert runs[0][0] > 10_000 and runs[0][1] > 10_000 and runs[0][2] > runs[0][1]   # a real sweep: tens of thousands of passes
     assert runs[1] == runs[0] and runs[2] == runs[0], runs
 
 

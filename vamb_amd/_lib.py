@@ -186,19 +186,12 @@ _ENV_OPTIONS = {
     "VAMBHIP_SCAN_MFMA": ("scan.mfma", int),
     "VAMBHIP_SCAN_MFMA_ROWMAJOR": ("scan.mfma_rowmajor", int),
     "VAMBHIP_REFERENCE_ORDER": ("scan.reference_order", int),
-    "VAMBHIP_SCAN_WIDE": ("scan.wide_rows", lambda v: 1),
-    "VAMBHIP_SCAN_MIN_BLOCKS": ("scan.min_blocks", int),
     "VAMBHIP_SCAN_DBG": ("scan.debug", int),
     "VAMBHIP_GEN_PROFILE": ("gen.profile", lambda v: 1),
     "VAMBHIP_NO_SPECULATION": ("gen.speculate", lambda v: 0),
     "VAMBHIP_SPEC_WINDOW": ("gen.spec_window", int),
     "VAMBHIP_GEN_PREFILL": ("gen.prefill", int),
-    "VAMBHIP_GEN_PREFILL_FRESH_SEEDS": ("gen.prefill_fresh_seeds", int),
-    "VAMBHIP_SPEC_NEIGHBOURS": ("gen.spec_neighbours", int),
-    "VAMBHIP_MAX_ENTRY_AGE": ("gen.max_entry_age", int),
-    "VAMBHIP_SPEC_DEPTH": ("gen.spec_depth", int),
-    "VAMBHIP_DEFER_BOOKKEEPING": ("gen.defer_bookkeeping", int),
-    "VAMBHIP_SPEC_BIG_TARGET": ("gen.spec_big_target", int),
+    "VAMBHIP_GEN_INLINE_REMOVALS": ("gen.inline_removals", int),
     "VAMBHIP_GATHER_STAGE_BYTES": ("gen.gather_stage_bytes", int),
     "VAMBHIP_BIG_TILES": ("vae.big_tiles", int),
     "VAMBHIP_XCD_REMAP": ("vae.xcd_remap", int),
@@ -206,24 +199,16 @@ _ENV_OPTIONS = {
     "VAMBHIP_SINGLE_STREAM": ("vae.single_stream", lambda v: 1),
     "VAMBHIP_FORK_EVENTS": ("vae.fork_events", lambda v: 1),
     "VAMBHIP_DEBUG_TIMING": ("vae.debug_timing", lambda v: 1),
-    "VAMBHIP_VAE_GEMM_PIPELINE": ("vae.gemm_pipeline", int),
-    "VAMBHIP_VAE_DW_ROW_MAJOR": ("vae.dw_row_major", int),
-    "VAMBHIP_VAE_FORK_AT_LOSS": ("vae.fork_at_loss", int),
-    "VAMBHIP_VAE_DZ_COLSUM": ("vae.dz_colsum", int),
-    "VAMBHIP_VAE_OPT_SPLIT": ("vae.opt_split", int),
     "VAMBHIP_VAE_FUSED_SKINNY": ("vae.fused_skinny", int),
     "VAMBHIP_VAE_FUSED_FINALIZE": ("vae.fused_finalize", int),
-    "VAMBHIP_VAE_FUSED_DZ": ("vae.fused_dz", int),
     "VAMBHIP_VAE_PREFETCH_BATCH": ("vae.prefetch_batch", int),
     "VAMBHIP_VAE_FORK_PLAN": ("vae.fork_plan", int),
-    "VAMBHIP_VAE_FORK_MODE": ("vae.fork_mode", int),
     "VAMBHIP_VAE_PROBE_EVERY": ("vae.probe_every", int),
-    "VAMBHIP_VAEVAE_LANES": ("vaevae.lanes", int),
-    "VAMBHIP_VAE_LOSS_DPP": ("vae.loss_dpp", int),
     "VAMBHIP_VAE_LOSS_FROM_DATASET": ("vae.loss_from_dataset", int),
     "VAMBHIP_VAE_PREFETCH_MAX_COLS": ("vae.prefetch_max_cols", int),
     "VAMBHIP_VAE_GEMM_PREFETCH": ("vae.gemm_prefetch", int),
     "VAMBHIP_VAE_GEMM_KGROUPS": ("vae.gemm_kgroups", int),
+    "VAMBHIP_VAE_DW_PAIR": ("vae.dw_pair", int),
 }
 _ENV_STRING_OPTIONS = {"VAMBHIP_RCCL": "comm.rccl_library", "ROCM_PATH": "comm.rocm_path"}
 _explicit_options: dict = {}

@@ -85,6 +85,22 @@ struct MedoidRows {
     long long row[kMaxMedoids];
 };
 
+// Rows whose live flag the NEXT pass clears before it reads any flag (round 6).  The state machine removes the members of
+// a cluster it emitted from a cached within-radius list -- 174 k of the 218 k emissions of a C2 sweep -- by clearing <= 32
+// flags per one-thread-block launch in front of the next pass: one more dependent launch (~3 us of stream time and ~2.5 us
+// of host time) per emission.  Now the rows wait on the handle and travel in the kernel arguments of the next scan: EVERY
+// workgroup clears all of them (the same zeros to the same bytes) in front of the barrier that ends its prologue, so its own
+// later loads see them whatever the other workgroups have done so far -- a workgroup only reads the flags of rows it scans.
+// Longer lists, and every other reader of the flags (select, compaction, downloads), go through the remove kernel first.
+constexpr int kRmCap = 56;
+struct RmRows {
+    int n;
+    int32_t row[kRmCap];
+};
+__device__ __forceinline__ void apply_removals(uint8_t* kept_w, const RmRows& rm) {
+    if ((int)threadIdx.x < rm.n) kept_w[rm.row[threadIdx.x]] = 0;   // (a __syncthreads() of the caller's prologue follows)
+}
+
 // torch.linspace(0.0, 0.3, 61) float32 bit patterns (== edges torch.histogram writes, cluster.py:288,
 // 475-481).  tests/test_lib_abi.py asserts the table equals torch.linspace.
 __constant__ uint32_t c_edge_bits[VH_NBINS + 1] = {
@@ -518,11 +534,12 @@ __device__ __forceinline__ void scan_flush(int tid, const unsigned long long* __
 template <int KM, int RPT, int LC, int PIPE = 0, bool REF = false>
 __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
                                                           const float* __restrict__ lengths,
-                                                          const uint8_t* __restrict__ kept, int64_t n,
+                                                          const uint8_t* kept, int64_t n,
                                                           const float* __restrict__ q_ext,
                                                           const MedoidRows medoid,
                                                           unsigned long long* __restrict__ results,
-                                                          int32_t* __restrict__ lists, int dbg, const RefSrc ro) {
+                                                          int32_t* __restrict__ lists, int dbg, const RefSrc ro, uint8_t* kept_w,
+                                                          const RmRows rm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* hq_s = reinterpret_cast<float4*>(smem_raw);                                  // [kBlock/64][kHitCap]
     unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(hq_s + (kBlock / 64) * kHitCap);   // [KM][kResultWords]
@@ -539,6 +556,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
     for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
     for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
     for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
+    apply_removals(kept_w, rm);
     // query vectors: explicit (row-sharded execution) or row medoid.row[j] of the resident matrix
     if constexpr (PIPE == 0) {
         for (int i = tid; i < KM * L4; i += kBlock) {
@@ -738,11 +756,12 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void clu_scan_ref_kernel(const float* __restrict__ Mt, int64_t ld, int L, int L4,
                                                               const float* __restrict__ lengths,
-                                                              const uint8_t* __restrict__ kept, int64_t n,
+                                                              const uint8_t* kept, int64_t n,
                                                               const float* __restrict__ q_ext, const MedoidRows medoid,
                                                               int k_real, unsigned long long* __restrict__ results,
-                                                              int32_t* __restrict__ lists, int dbg) {
+                                                              int32_t* __restrict__ lists, int dbg, uint8_t* kept_w, const RmRows rm) {
     constexpr int KM = kMaxMedoids;
+    apply_removals(kept_w, rm);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* hq_s = reinterpret_cast<float4*>(smem_raw);                                  // (unused here; keeps the layout)
     unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(hq_s + (kBlock / 64) * kHitCap);   // [KM][kResultWords]
@@ -822,11 +841,13 @@ __device__ __forceinline__ void scan_tile_load(ScanTile<NK>& t, const float* __r
 template <int NK, bool REF = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(REF && NK <= 16 ? 3 : 1, REF && NK <= 16 ? 3 : 8))) void clu_scan_mfma_kernel(const float* __restrict__ Mt, int64_t ld, int L4,
                                                                const float* __restrict__ lengths,
-                                                               const uint8_t* __restrict__ kept,
+                                                               const uint8_t* kept,
                                                                const float* __restrict__ q_ext, const MedoidRows medoid,
                                                                int k_real, unsigned long long* __restrict__ results,
-                                                               int32_t* __restrict__ lists, int dbg, const RefSrc ro) {
+                                                               int32_t* __restrict__ lists, int dbg, const RefSrc ro, uint8_t* kept_w,
+                                                               const RmRows rm) {
     constexpr int KM = kMaxMedoids;
+    apply_removals(kept_w, rm);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* hq_s = reinterpret_cast<float4*>(smem_raw);                                  // [kBlock/64][kHitCap]
     unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(hq_s + (kBlock / 64) * kHitCap);   // [KM][kResultWords]
@@ -991,11 +1012,12 @@ __device__ __forceinline__ void scan_tile_wait_rm(scan_f32x4 (&xa)[NK / 4]) {
 template <int NK>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NK <= 16 ? 3 : 2, NK <= 16 ? 3 : 8)))
 void clu_scan_mfma_rm_kernel(const float* __restrict__ Mr, int64_t ld, const float* __restrict__ lengths,
-                             const uint8_t* __restrict__ kept, const float* __restrict__ q_ext, int q_ld,
+                             const uint8_t* kept, const float* __restrict__ q_ext, int q_ld,
                              const MedoidRows medoid, int k_real, unsigned long long* __restrict__ results,
-                             int32_t* __restrict__ lists, int dbg, const RefSrc ro) {
+                             int32_t* __restrict__ lists, int dbg, const RefSrc ro, uint8_t* kept_w, const RmRows rm) {
     constexpr int KM = kMaxMedoids;
     constexpr int LR = 2 * NK;
+    apply_removals(kept_w, rm);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* hq_s = reinterpret_cast<float4*>(smem_raw);                                  // [kBlock/64][kHitCap]
     unsigned long long* acc_s = reinterpret_cast<unsigned long long*>(hq_s + (kBlock / 64) * kHitCap);   // [KM][kResultWords]
@@ -1551,6 +1573,8 @@ struct vh_clu {
     DevBuf<float> Mr, Mr_alt;     // row-major copy [ld][LR] of the matrix for the row-major matrix-pipe pass (K6r), or empty
     int LR = 0;                   // its row width: 32 or 64 floats (zero padded); 0 = no copy (K6m serves the many-medoid passes)
     DevBuf<uint8_t> kept;
+    std::vector<int32_t> pend_rm;   // rows removed on the host side whose flags are still set on the device (see RmRows)
+    RmRows rm_pass{};               // ... the part of them the pass being launched applies
     DevBuf<unsigned long long> results;
     // host-mapped (pinned, coherent) publication buffers written by the scan kernel itself
     int32_t* lists = nullptr;     // [kListRing][kMaxMedoids][kListCap] rows within the medoid radius, per scan
@@ -1621,6 +1645,26 @@ namespace {
 // Spin on the sequence flag the scan kernel's last block stores into host-mapped memory (a few hundred ns
 // after the kernel retires, against ~10 us for a copy + event wait).  The stream is polled now and then so
 // that a faulted kernel surfaces as an error instead of a hang.
+// every row waiting in h->pend_rm through the remove kernel (<= 32 rows per launch, in the kernel arguments)
+void flush_pending_rm(vh_clu* h) {
+    const size_t n = h->pend_rm.size();
+    for (size_t lo = 0; lo < n; lo += kMaxMedoids) {
+        const int k = (int)std::min<size_t>(kMaxMedoids, n - lo);
+        MedoidRows mr;
+        for (int j = 0; j < kMaxMedoids; ++j) mr.row[j] = h->pend_rm[lo + (size_t)(j < k ? j : 0)];
+        hipLaunchKernelGGL(clu_remove_args_kernel, dim3(1), dim3(64), 0, h->stream, h->kept.p, mr, k);
+        VH_HIP(hipGetLastError());
+    }
+    h->pend_rm.clear();
+}
+// ... or, up to kRmCap of them, in the arguments of the scan about to be launched (h->rm_pass)
+void take_pending_rm(vh_clu* h) {
+    if (h->pend_rm.size() > (size_t)kRmCap) flush_pending_rm(h);
+    h->rm_pass.n = (int)h->pend_rm.size();
+    for (int i = 0; i < kRmCap; ++i) h->rm_pass.row[i] = i < h->rm_pass.n ? h->pend_rm[(size_t)i] : 0;
+    h->pend_rm.clear();
+}
+
 void wait_for_scan(vh_clu* h, unsigned long long seq) {
     volatile unsigned long long* flag = h->flag();
     for (unsigned long long spins = 1;; ++spins) {
@@ -1659,7 +1703,7 @@ void launch_scan_lc_impl(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     const int64_t blocks = ceil_div(h->ld, (int64_t)kBlock * RPT);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 8));
     hipLaunchKernelGGL((clu_scan_kernel<KM, RPT, LC, PIPE, REF>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
-                       h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_pass, h->scan_dbg, ref_src(h));
+                       h->lengths.p, h->kept.p, h->ld, q_ext, med, h->results.p, h->lists_pass, h->scan_dbg, ref_src(h), h->kept.p, h->rm_pass);
 }
 template <int KM, int RPT, int LC, int PIPE = 0>
 void launch_scan_lc(vh_clu* h, const MedoidRows& med, const float* q_ext) {
@@ -1717,7 +1761,7 @@ void launch_scan_mfma_impl(vh_clu* h, const MedoidRows& med, const float* q_ext)
     // per SIMD): one resident set, every wavefront strides over its tiles
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(tiles, kBlock / 64), 256 * (NK <= 16 ? 3 : 2)));
     hipLaunchKernelGGL((clu_scan_mfma_kernel<NK, REF>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L4,
-                       h->lengths.p, h->kept.p, q_ext, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg, ref_src(h));
+                       h->lengths.p, h->kept.p, q_ext, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg, ref_src(h), h->kept.p, h->rm_pass);
 }
 template <int NK>
 void launch_scan_mfma(vh_clu* h, const MedoidRows& med, const float* q_ext) {
@@ -1738,7 +1782,7 @@ void launch_scan_mfma_rm(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     const int64_t tiles = h->ld >> 5;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(tiles, kBlock / 64), 256 * (NK <= 16 ? 3 : 2)));
     hipLaunchKernelGGL((clu_scan_mfma_rm_kernel<NK>), dim3(grid), dim3(kBlock), smem, h->stream, h->Mr.p, h->ld, h->lengths.p,
-                       h->kept.p, q_ext, h->L4, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg, ref_src(h));
+                       h->kept.p, q_ext, h->L4, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg, ref_src(h), h->kept.p, h->rm_pass);
 }
 
 // more than 8 medoids and a latent width the B operand registers hold: the matrix-pipe kernel (always 32 medoid slots)
@@ -1757,7 +1801,7 @@ void launch_scan_ref(vh_clu* h, const MedoidRows& med, const float* q_ext) {
     VH_REQUIRE(smem <= kScanLdsBudget, "internal: %d latent columns do not fit the LDS", h->L4);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(h->ld, (int64_t)kBlock), 256 * 8));
     hipLaunchKernelGGL(clu_scan_ref_kernel, dim3(grid), dim3(kBlock), smem, h->stream, h->Mt.p, h->ld, h->L, h->L4, h->lengths.p,
-                       h->kept.p, h->ld, q_ext, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg);
+                       h->kept.p, h->ld, q_ext, med, h->mfma_k, h->results.p, h->lists_pass, h->scan_dbg, h->kept.p, h->rm_pass);
 }
 
 void dispatch_scan(vh_clu* h, int km, const MedoidRows& med, const float* q_ext) {
@@ -1869,8 +1913,8 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
                 if (scan_smem_bytes(b, h->L4) <= kScanLdsBudget) { h->max_k = b; break; }
             VH_REQUIRE(h->max_k >= 1, "latent width %d does not fit the scan kernel's LDS", L);
         }
-        h->small_rpt = option("scan.wide_rows", 0) == 0;
-        h->min_blocks = option("scan.min_blocks", kMinScanBlocks);
+        h->small_rpt = true;
+        h->min_blocks = kMinScanBlocks;   // (measured neutral between 384 and 1536)
         h->scan_lc = (int)option("scan.column_loop", 1);
         h->use_mfma = option("scan.mfma", 1) != 0;
         {
@@ -1880,7 +1924,14 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
             h->ref_filter = mode == 2;         // scans: the tuned kernels (filter) instead of the plain kernel
         }
         VH_REQUIRE(!h->ref_order || h->ref_filter || h->max_k >= kMaxMedoids, "scan.reference_order = 1: latent width %d is too wide", L);
+        // scan.debug switches parts of the scan kernels OFF for timing experiments (wrong results): only honoured by a build made for
+        // them (-DVAMBHIP_TIMING_EXPERIMENTS); a stray VAMBHIP_SCAN_DBG cannot corrupt a product build's clustering
+#ifdef VAMBHIP_TIMING_EXPERIMENTS
         h->scan_dbg = (int)option("scan.debug", 0);
+#else
+        h->scan_dbg = 0;
+        VH_REQUIRE(option("scan.debug", 0) == 0, "scan.debug needs a library built with -DVAMBHIP_TIMING_EXPERIMENTS (it produces wrong results)");
+#endif
         h->results.alloc((size_t)kResultReplicas * kMaxMedoids * kResultWords);
         VH_HIP(hipHostMalloc((void**)&h->lists, (size_t)kListRing * kMaxMedoids * kListCap * sizeof(int32_t),
                              hipHostMallocMapped | hipHostMallocCoherent));
@@ -2013,6 +2064,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
         h->lists_pass = h->lists_dev.p;
     }
     h->q_rows_pass = q_ext;   // row-major [km][L4] or nullptr (the quad-major copy some kernels take is made from it)
+    take_pending_rm(h);       // rows the state machine removed since the last pass: cleared by this pass's own prologue
     h->timer.start(h->stream);
     dispatch_scan(h, km, med, q_ext);
     h->timer.stop(h->stream);
@@ -2180,6 +2232,7 @@ int64_t select_sharded_core(vh_clu* h, int64_t local_row, const float* query, fl
         rccl_allreduce_sum_f32(comm, h->q.p, (size_t)h->L4, h->stream);
     }
     // local select (counts[0] is zero on entry)
+    flush_pending_rm(h);
     h->timer.start(h->stream);
     hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
                        h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, h->q.p, local_row, threshold, remove,
@@ -2282,6 +2335,7 @@ int vh_clu_select(vh_clu* h, int64_t medoid_row, const float* query, float thres
             q_ext = h->q.p;
         }
         // counts[0] is zero on entry (creation / re-armed by the publish kernel of the previous select)
+        flush_pending_rm(h);
         h->timer.start(h->stream);
         hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
                            h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, q_ext, medoid_row, threshold, remove,
@@ -2338,6 +2392,7 @@ int vh_clu_remove(vh_clu* h, const int64_t* rows, int64_t n) {
         if (n == 0) return;
         for (int64_t i = 0; i < n; ++i)
             VH_REQUIRE(rows[i] >= 0 && rows[i] < h->n_rows, "row %lld out of range", (long long)rows[i]);
+        flush_pending_rm(h);
         // count rows that are still live so that n_live stays exact
         std::vector<uint8_t> flags;
         h->row_idx.ensure((size_t)n);
@@ -2364,6 +2419,7 @@ int vh_clu_remove(vh_clu* h, const int64_t* rows, int64_t n) {
 int vh_clu_pack(vh_clu* h, int64_t* new_rows) {
     return guarded([&] {
         VH_REQUIRE(h != nullptr, "handle is NULL");
+        flush_pending_rm(h);
         const int nb = (int)(h->ld / kRowsPerBlock);
         unsigned int* block_counts = h->counts.p + 1;
         hipLaunchKernelGGL(clu_count_kept_kernel, dim3(nb), dim3(kBlock), 0, h->stream, h->kept.p, h->ld, block_counts);
@@ -2435,6 +2491,7 @@ int vh_clu_get_rows(vh_clu* h, const int64_t* rows, int64_t k, float* out) {
 int vh_clu_get_kept(vh_clu* h, uint8_t* out) {
     return guarded([&] {
         VH_REQUIRE(h != nullptr && out != nullptr, "NULL argument");
+        flush_pending_rm(h);
         VH_HIP(hipMemcpyAsync(out, h->kept.p, (size_t)h->n_rows, hipMemcpyDeviceToHost, h->stream));
         VH_HIP(hipStreamSynchronize(h->stream));
     });
@@ -2629,6 +2686,7 @@ struct vh_gen {
     bool pass_in_flight = false;    // host code running UNDER a pass: the ring slot that pass writes is not to be read (gen_lookup)
     int prefill_on = 2;             // 2: a bounded fresh walk (the first prefill_fresh_seeds upcoming seeds, their own pools) in front of the list
     int prefill_fresh_seeds = 4;
+    bool inline_rm = true;          // gen.inline_removals: removed rows ride in the next scan's kernel arguments (RmRows); 0 = one launch per emission
     std::vector<int64_t> prefill;
     uint64_t prefill_epoch = 0;
     bool prefill_ready = false, prefill_exhausted = false;
@@ -2829,13 +2887,10 @@ void gen_remove_live(vh_gen* g, const int64_t* rows_in, int64_t n_in) {
         rows = mine.data();
         n = (int64_t)mine.size();
     }
-    for (int64_t lo = 0; lo < n; lo += kMaxMedoids) {
-        const int k = (int)std::min<int64_t>(kMaxMedoids, n - lo);
-        MedoidRows mr;
-        for (int j = 0; j < kMaxMedoids; ++j) mr.row[j] = rows[lo + (j < k ? j : 0)];
-        hipLaunchKernelGGL(clu_remove_args_kernel, dim3(1), dim3(64), 0, h->stream, h->kept.p, mr, k);
-        VH_HIP(hipGetLastError());
-    }
+    // no launch: the rows wait on the handle and are cleared by the next scan's own prologue (RmRows), or by the remove kernel in
+    // front of any other reader of the flags
+    for (int64_t i = 0; i < n; ++i) h->pend_rm.push_back((int32_t)rows[i]);
+    if (!g->inline_rm) flush_pending_rm(h);   // (A/B: one launch per emission, as until round 6)
     h->n_live -= n;
 }
 
@@ -3287,12 +3342,13 @@ vh_gen* gen_create_common(vh_clu* clu, vh_comm* comm, const int64_t* order, int6
     g->speculate = option("gen.speculate", 1) != 0;
     g->spec_window = (int)option("gen.spec_window", kSpecWindow);
     g->prefill_on = (int)option("gen.prefill", 2);
-    g->prefill_fresh_seeds = (int)option("gen.prefill_fresh_seeds", 4);
-    g->spec_neighbours = option("gen.spec_neighbours", 1) != 0;
-    g->max_entry_age = option("gen.max_entry_age", kMaxEntryAgeDefault);
-    g->spec_depth = (int)option("gen.spec_depth", 2);
-    g->defer_book = option("gen.defer_bookkeeping", 1) != 0;
-    g->spec_big_target = (int)option("gen.spec_big_target", 0);
+    g->prefill_fresh_seeds = 4;
+    g->inline_rm = option("gen.inline_removals", 1) != 0;
+    g->spec_neighbours = true;
+    g->max_entry_age = kMaxEntryAgeDefault;
+    g->spec_depth = 2;
+    g->defer_book = true;
+    g->spec_big_target = 0;
     g->order.assign(order, order + n);
     g->indices.resize((size_t)n);
     for (int64_t i = 0; i < n; ++i) g->indices[(size_t)i] = i;

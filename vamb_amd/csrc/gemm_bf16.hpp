@@ -56,7 +56,8 @@ enum Epi16 : int {
 // ---- elementwise backward of one hidden layer (BatchNorm over the batch, dropout, LeakyReLU; vamb/encode.py:259-266 backward)
 //   dZ = keep * slope(h) * (ca dA + ch h + c0),   ca = drop_scale istd gamma,  ch = -ca istd S2/B,  c0 = -ca S1/B - ch mean
 // with S1 = sum dA, S2 = sum dA xhat over the batch.  ONE definition of the coefficients and of the element, with explicit
-// fused multiply-adds, shared by vae_dz16_kernel and by the GEMMs that form dZ while they stage it (STG == 3): same bits.
+// fused multiply-adds (vae_dz16_kernel).  (Round 6 also formed dZ inside the consuming input-gradient GEMM, on its A-operand
+// path through registers -- bit-identical, and slower: profiles/r06c_*, DESIGN.md section 4.3 -- and removed that kernel again.)
 struct DzCoefSrc {
     const float* mean;     // [n_p] mean / 1/std of the layer's BatchNorm as the forward fold left them (vae_fold_bn_kernel)
     const float* istd;
@@ -81,21 +82,6 @@ __device__ __forceinline__ float dz16_elem(float d, float h, float ca, float ch,
     const float dz = l * (h > 0.f ? 1.0f : kLeakySlopeF);
     return (hashed_drop && h == 0.f) ? 0.f : dz;
 }
-// eight consecutive columns: d, h = 8 bf16 each; ca / ch / c0 = the columns' coefficients
-__device__ __forceinline__ uint4 dz16_apply8(uint4 d, uint4 h, const float* ca, const float* ch, const float* c0, bool hashed_drop) {
-    const uint32_t dw[4] = {d.x, d.y, d.z, d.w}, hw[4] = {h.x, h.y, h.z, h.w};
-    uint32_t ow[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float lo = dz16_elem(__uint_as_float(dw[q] << 16), __uint_as_float(hw[q] << 16), ca[2 * q], ch[2 * q], c0[2 * q], hashed_drop);
-        const float hi = dz16_elem(__uint_as_float(dw[q] & 0xFFFF0000u), __uint_as_float(hw[q] & 0xFFFF0000u), ca[2 * q + 1],
-                                   ch[2 * q + 1], c0[2 * q + 1], hashed_drop);
-        const __bf16 bl = (__bf16)lo, bh = (__bf16)hi;
-        ow[q] = (uint32_t)__builtin_bit_cast(unsigned short, bl) | ((uint32_t)__builtin_bit_cast(unsigned short, bh) << 16);
-    }
-    return make_uint4(ow[0], ow[1], ow[2], ow[3]);
-}
-
 struct Gemm16Args {
     const bf16_t* A;
     int64_t lda;
@@ -130,15 +116,6 @@ struct Gemm16Args {
     const float* bn_istd;
     double* bstat_out;     // [2][N]
     int xcd_remap;
-    // STG == 3 (E16_STORE_BNRED only): A is not a tensor in memory but dZ of the layer ABOVE, formed while the tile is staged:
-    // A = dA of that layer (the `A` pointer), dzH = its post-dropout activations, dzc = its per-column coefficients; the workgroups
-    // of the first tile column also store the tiles they formed to dzOut (the weight-gradient GEMM of that layer reads them)
-    const bf16_t* dzH;
-    int64_t ld_dzh;
-    DzCoefSrc dzc;
-    int dz_hashed;         // 1: dropout by the counter hash (an element is dropped iff its stored activation is exactly 0)
-    bf16_t* dzOut;         // [M][ld_dzout] or nullptr
-    int64_t ld_dzout;
     int dbg;               // timing experiments (vh_debug_gemm16): 1 no fp64 atomics, 2 no transposed copy, 4 no row-major copy
     unsigned long long* tstamps;   // diagnostic (vh_debug_gemm16, variant flag 8): [workgroup][8] s_memtime stamps -- entry, first tile
                                    // landed, K loop done, epilogue phase 1 done, stores issued, exit
@@ -184,10 +161,6 @@ __device__ __forceinline__ void gemm16_stamp(const Gemm16Args& g, int slot) {
 //       it (~17-27 clk per 1 KiB piece, 32 pieces per tile and CU), all waves run in lockstep, so "issue 4 pieces, then
 //       12 ds_reads + 8 MFMAs, then drain" is a DMA phase FOLLOWED by a matrix phase.  Spreading the pieces over the MFMA
 //       groups puts the issue stalls under matrix-pipe time, and the third buffer takes the landing latency off the barrier.
-//   3 = B as in 2; A is FORMED on the way: dA and h tiles of the layer above travel through registers, every thread applies the
-//       elementwise BatchNorm / dropout / LeakyReLU backward to its 16-byte slots (dz16_apply8, per-column coefficients in an LDS
-//       table built in the prologue) and writes dZ into the swizzled LDS image; the first tile column also stores it to memory.
-//       Replaces the launch of vae_dz16_kernel in front of this GEMM (12 us of a ~25 us pair at C2).
 template <int BM, int BN, int WM, int WN, int EPI, int STG = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Args g) {
     constexpr int NWAVE = WM * WN;
@@ -198,7 +171,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;   // one buffer of each operand
     constexpr int PA = BM / 8, PB = BN / 8;                 // 1 KiB DMA pieces per K-tile
     constexpr int RA = PA / NWAVE, RB = PB / NWAVE;         // pieces per wave
-    constexpr int NBUF = STG >= 2 ? 3 : 2;
+    constexpr int NBUF = STG == 2 ? 3 : 2;
     static_assert(TM >= 1 && TN >= 1 && PA % NWAVE == 0 && PB % NWAVE == 0, "tile / wave layout");
     // ALL LDS of the kernel is this one array (a second __shared__ object makes hipcc drain the DMA queue
     // in front of every fragment read)
@@ -484,134 +457,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
         if (kt + 1 < nk) iteration(kt + 1, 1, std::false_type{});
         if (kt + 2 < nk) iteration(kt + 2, 2, std::false_type{});
         if (kt + 3 < nk) iteration(kt + 3, 0, std::false_type{});
-    } else if constexpr (STG == 3) {
-        static_assert(EPI == E16_STORE_BNRED, "the dZ-forming A path belongs to the input-gradient GEMM");
-        const int Kt = (g.K + BK - 1) & ~(BK - 1);
-        float* const cf = reinterpret_cast<float*>(smem16 + NBUF * (A_BYTES + B_BYTES));   // [3][Kt]: ca, ch, c0 per column k
-        const bool hashed = g.dz_hashed != 0;
-        const bool store_dz = g.dzOut != nullptr && bx == 0;   // workgroup-uniform
-        // this thread's slots of an A tile: piece r -> (row, k offset); the same addresses in dA, h and the stored dZ
-        const bf16_t* h_src[RA];
-        bf16_t* z_dst[RA];
-        int a_ks[RA];
-        bool row_real[RA];
-#pragma unroll
-        for (int r = 0; r < RA; ++r) {
-            const int row = 8 * (wave + NWAVE * r) + (lane >> 3);
-            a_ks[r] = 8 * ((lane & 7) ^ swz16(row));
-            const bool ok = m0 + row < g.M;
-            row_real[r] = m0 + row < g.m_real;
-            h_src[r] = g.dzH + (int64_t)(ok ? m0 + row : 0) * g.ld_dzh + a_ks[r];
-            z_dst[r] = g.dzOut + (int64_t)(ok ? m0 + row : 0) * g.ld_dzout + a_ks[r];
-        }
-        auto fetchA = [&](uint4* da, uint4* hh, int k0) {
-            const int room = kend - k0;
-#pragma unroll
-            for (int r = 0; r < RA; ++r) {
-                const bool ok = a_k[r] < room;
-                da[r] = *reinterpret_cast<const uint4*>(ok ? a_src[r] + k0 : g.zeros);
-                hh[r] = *reinterpret_cast<const uint4*>(ok ? h_src[r] + k0 : g.zeros);
-            }
-        };
-        auto putA = [&](const uint4* da, const uint4* hh, unsigned char* abuf, int k0) {
-            const int room = kend - k0;
-#pragma unroll
-            for (int r = 0; r < RA; ++r) {
-                const float* const c = cf + (k0 - kbeg) + a_ks[r];
-                const float4 ca0 = *reinterpret_cast<const float4*>(c), ca1 = *reinterpret_cast<const float4*>(c + 4);
-                const float4 ch0 = *reinterpret_cast<const float4*>(c + Kt), ch1 = *reinterpret_cast<const float4*>(c + Kt + 4);
-                const float4 cz0 = *reinterpret_cast<const float4*>(c + 2 * Kt), cz1 = *reinterpret_cast<const float4*>(c + 2 * Kt + 4);
-                const float ca[8] = {ca0.x, ca0.y, ca0.z, ca0.w, ca1.x, ca1.y, ca1.z, ca1.w};
-                const float ch[8] = {ch0.x, ch0.y, ch0.z, ch0.w, ch1.x, ch1.y, ch1.z, ch1.w};
-                const float cz[8] = {cz0.x, cz0.y, cz0.z, cz0.w, cz1.x, cz1.y, cz1.z, cz1.w};
-                uint4 o = dz16_apply8(da[r], hh[r], ca, ch, cz, hashed);
-                if (!row_real[r]) o = make_uint4(0u, 0u, 0u, 0u);   // padding rows of the batch (and rows outside the matrix)
-                *reinterpret_cast<uint4*>(abuf + (wave + NWAVE * r) * 1024 + lane * 16) = o;
-                if (store_dz && a_k[r] < room) *reinterpret_cast<uint4*>(z_dst[r] + k0) = o;
-            }
-        };
-        auto stageB = [&](unsigned char* bbuf, int k0) {
-            const int room = kend - k0;
-#pragma unroll
-            for (int r = 0; r < RB; ++r)
-                glds16(b_k[r] < room ? b_src[r] + k0 : g.zeros, bbuf + (wave + NWAVE * r) * 1024);
-        };
-        auto abuf = [&](int b) { return As + b * A_BYTES; };
-        auto bbuf = [&](int b) { return Bs + b * B_BYTES; };
-        // MFMA groups of tile `cur`; the B pieces of the tile two ahead in between (A travels through registers)
-        auto compute_stage = [&](const unsigned char* ab, const unsigned char* bb, unsigned char* bnext, int knext, bool prefetch) {
-            bf16x8 a8[BK / 16][TM], b8[BK / 16][TN];
-            auto frags = [&](int t) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    a8[t][i] = *reinterpret_cast<const bf16x8*>(ab + a_off[i] + 16 * ((2 * t + frag_h) ^ a_swz[i]));
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    b8[t][j] = *reinterpret_cast<const bf16x8*>(bb + b_off[j] + 16 * ((2 * t + frag_h) ^ b_swz[j]));
-            };
-            frags(0);
-            frags(1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < BK / 16; ++t) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[t][i], b8[t][j], acc[i][j], 0, 0, 0);
-                if (prefetch) {   // workgroup-uniform
-                    const int room = kend - knext;
-#pragma unroll
-                    for (int q = (RB * t) / 4; q < (RB * (t + 1)) / 4; ++q)
-                        glds16(b_k[q] < room ? b_src[q] + knext : g.zeros, bnext + (wave + NWAVE * q) * 1024);
-                }
-                if (t + 2 < BK / 16) frags(t + 2);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        // prologue: the operands of tiles 0 and 1 requested, the coefficient table built underneath them
-        uint4 da0[RA], hh0[RA], da1[RA], hh1[RA];
-        if (nk > 0) { fetchA(da0, hh0, kbeg); stageB(bbuf(0), kbeg); }
-        if (nk > 1) { fetchA(da1, hh1, kbeg + BK); stageB(bbuf(1), kbeg + BK); }
-        for (int k = tid; k < Kt; k += NT) {
-            float ca = 0.f, ch = 0.f, c0 = 0.f;
-            if (kbeg + k < kend) dz16_coeffs(g.dzc, kbeg + k, ca, ch, c0);
-            cf[k] = ca; cf[Kt + k] = ch; cf[2 * Kt + k] = c0;
-        }
-        __syncthreads();   // table complete (hipcc drains vmcnt in front of it: every request above has landed)
-        if (nk > 0) putA(da0, hh0, abuf(0), kbeg);
-        if (nk > 1) putA(da1, hh1, abuf(1), kbeg + BK);
-        __syncthreads();
-        gemm16_stamp(g, 1);
-        // iteration kt: requests the A slots of tile kt + 2, multiplies tile kt with the B pieces of tile kt + 2 issued in between,
-        // then forms tile kt + 2 into buffer (kt + 2) % 3 -- free since the barrier that ended iteration kt - 1.  The loads of the
-        // A slots are older than this iteration's B pieces and younger than those of tile kt + 1: once they have returned (the
-        // compiler's wait in front of putA) tile kt + 1 has landed too (vmcnt retires loads in order).
-        auto iteration = [&](int kt, int cur) {
-            const bool pre = kt + 2 < nk;
-            const int nxt = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
-            const int knext = kbeg + (kt + 2) * BK;
-            if (pre) fetchA(da0, hh0, knext);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_stage(abuf(cur), bbuf(cur), bbuf(nxt), knext, pre);
-            if (pre) {
-                putA(da0, hh0, abuf(nxt), knext);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RB) : "memory");   // (already true: see above)
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        int kt = 0;
-        for (; kt + 2 < nk; kt += 3) {   // kt is a multiple of 3: tile kt sits in buffer 0
-            iteration(kt, 0);
-            iteration(kt + 1, 1);
-            iteration(kt + 2, 2);
-        }
-        if (kt < nk) iteration(kt, 0);
-        if (kt + 1 < nk) iteration(kt + 1, 1);
     } else {
         uint4 ra[RA], rb[RB];
         auto fetch = [&](int k0) {
@@ -1048,7 +893,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
 // dynamic LDS bytes of an instantiation: the operand buffers, or the output image + reduction scratch if larger
 template <int BM, int BN, int WM, int WN, int EPI, int STG = 0>
 constexpr size_t gemm16_smem_bytes() {
-    size_t ops = (STG >= 2 ? 3 : 2) * (size_t)(BM + BN) * 128;   // (STG == 3: + the coefficient table, added by the launcher)
+    size_t ops = (STG == 2 ? 3 : 2) * (size_t)(BM + BN) * 128;
     if (EPI == E16_SPLITK || EPI == E16_BIAS || EPI == E16_LATENT_MASK) return ops;
     const size_t img = (size_t)BM * (BN + 8) * 2 + (EPI == E16_HIDDEN_TRAIN ? (size_t)BN * (BM + 8) * 2 : 0);
     const size_t nt = (size_t)WM * WN * 64, rpp = nt / (BN / 8);

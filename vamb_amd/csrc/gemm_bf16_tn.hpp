@@ -57,8 +57,10 @@ __device__ __forceinline__ int tn_swz(int k) {
 
 // STG: 0 = two LDS buffers, the next tile requested in front of the current tile's MFMAs; 2 = three buffers, the pieces of
 // tile t + 2 issued between the MFMA groups of tile t, counted vmcnt + raw barrier (see gemm_bf16.hpp)
-template <int BM, int BN, int WM, int WN, int COLSUM, int STG = 0>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(const Gemm16TnArgs g) {
+// The workgroup program.  (bid, gx, gy, gz): this workgroup's linear index in ITS problem's (n-tile, m-tile, split) grid and that
+// grid's extents -- the launch's own for gemm_bf16_tn_kernel, a slice of a one-dimensional launch for the grouped kernel below.
+template <int BM, int BN, int WM, int WN, int COLSUM, int STG>
+__device__ __forceinline__ void gemm_bf16_tn_body(const Gemm16TnArgs& g, int bid, int gx, int gy, int gz) {
     constexpr int NWAVE = WM * WN;
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
@@ -80,13 +82,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(const Gemm16
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (g.xcd_remap) {
-        const int gx = gridDim.x, gy = gridDim.y;
-        const int nwg = gx * gy * (int)gridDim.z;
-        const int bid = bx + gx * (by + gy * bz);
-        const int xcd = bid & 7, local = bid >> 3;
-        const int t = xcd * (nwg >> 3) + min(xcd, nwg & 7) + local;
+    int bx, by, bz;
+    {
+        int t = bid;
+        if (g.xcd_remap) {   // XCD x gets the x-th contiguous eighth of the (z, m, n)-ordered tile list (speed only)
+            const int nwg = gx * gy * gz;
+            const int xcd = bid & 7, local = bid >> 3;
+            t = xcd * (nwg >> 3) + min(xcd, nwg & 7) + local;
+        }
         bx = t % gx;
         by = (t / gx) % gy;
         bz = t / (gx * gy);
@@ -301,6 +304,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(const Gemm16
             }
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int COLSUM, int STG = 0>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(const Gemm16TnArgs g) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    gemm_bf16_tn_body<BM, BN, WM, WN, COLSUM, STG>(g, (int)(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z)), gx, gy, (int)gridDim.z);
+}
+
+// Two weight-gradient products in ONE launch (round 6): the last two of a training step -- encoder layer 0's and layer 1's -- wait
+// for the same kernel and end the backward pass one after the other, 14 + 15 us of a ~260 us step at C2, each alone on a chip it
+// fills only once (192 / 256 workgroups of 48 KB of LDS: three fit a CU).  As one launch of nwg0 + nwg1 workgroups they share the
+// CUs and one dispatch ramp / release.  Every workgroup runs the unchanged program on its own problem: same tiles, same slabs,
+// same bits.
+struct Gemm16TnPair {
+    Gemm16TnArgs p[2];
+    int gx[2], gy[2], gz[2];
+    int nwg0;              // workgroups of problem 0 (a multiple of 8 keeps the XCD remap of problem 1 aligned; speed only)
+};
+template <int BM, int BN, int WM, int WN, int STG = 0>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_pair_kernel(const Gemm16TnPair a) {
+    const int b = (int)blockIdx.x;
+    if (b < a.nwg0) gemm_bf16_tn_body<BM, BN, WM, WN, 0, STG>(a.p[0], b, a.gx[0], a.gy[0], a.gz[0]);
+    else gemm_bf16_tn_body<BM, BN, WM, WN, 0, STG>(a.p[1], b - a.nwg0, a.gx[1], a.gy[1], a.gz[1]);
 }
 
 template <int BM, int BN, int STG = 0>

@@ -70,7 +70,7 @@ struct Hidden {
     DevBuf<uint8_t> mask;               // injected dropout keep-mask (parity mode)
     long long batches_tracked = 0;
     // bf16-storage step (vae_step16.hpp): activations / gradients row-major and transposed, BatchNorm-folded weights
-    DevBuf<bf16_t> H16, H16T, DA16, DZ16, DZ16T, Wf16;
+    DevBuf<bf16_t> H16, DA16, DZ16, Wf16;
     DevBuf<float> biasf;
 };
 
@@ -185,38 +185,20 @@ struct VaeTuning {
     bool big_tiles = false;   // vae.big_tiles
     int xcd_remap = 1;        // vae.xcd_remap
     int dw_workgroups = 256;  // vae.dw_workgroups: workgroups wanted per weight-gradient GEMM (split-K target)
-    int pipeline = 2;         // vae.gemm_pipeline: K loop of the bf16 GEMMs.  2 = three LDS buffers, DMA pieces of tile t + 2 issued
-                              // between the MFMA groups of tile t; 0 = the round-2 loop (two buffers, tile t + 1 requested up front)
-    int fork_at_loss = 1;     // vae.fork_at_loss: the side stream starts when the loss kernel ends instead of after the first
-                              // BatchNorm-backward kernel of the decoder.  One more fork costs the main stream ~5 us (round 3: 296 vs
-                              // 286 us per step, the default then was 0), but since round 5 the SIDE stream is what the optimiser waits for
-                              // at the end of a step (profiles/r05b_step_timeline_C2.txt: its last weight gradient ends ~10 us after the
-                              // main stream's, + the join): starting it 24 us earlier pays together with fork_plan = 6 (263.9 vs 268.8 us
-                              // and 257.5 vs 261.6 us per step on two boxes, profiles/r05c_step_fork_plans_c2.txt, r05d_*)
-    bool opt_split = false;   // vae.opt_split: bf16 step, one GPU: the optimiser's decoder-side half runs on the side stream during the
-                              // encoder's backward instead of at the end of the step.  Bit-identical, but measured SLOWER at C2 (300 vs
-                              // 290 us per step, profiles/r03zj_opt_split.txt): the update streams 30 MB of gradient slabs and moments
-                              // against the main stream's GEMMs
-    bool dz_colsum = true;    // vae.dz_colsum: 1 = the elementwise BatchNorm-backward kernel sums its own output for the bias gradient
-                              // (fp64 atomics from every row block); 0 = the weight-gradient GEMM does it on the way.  Measured at C2
-                              // (profiles/r03zd_dz_colsum.txt): the dz kernel 12.1 -> 10.2 us, the dW GEMMs 16.9 -> 20.4 us, step 291 ->
-                              // 293 us: stays where it was
     bool fused_skinny = true; // vae.fused_skinny: bf16 step: the two latent-wide products (mu, the first decoder layer's input gradient) and
                               // their elementwise consumers (reparameterisation, latent backward) as ONE launch each
                               // (gemm_skinny16.hpp) instead of split-K launch + slab-summing kernel.  Same bits.
-    bool fused_finalize = false; // vae.fused_finalize: bf16 step: d / k / counters / clearing of the fp64 accumulators by the LAST workgroup of
+    bool fused_finalize = true;  // (round 6: ON, behind two levels of arrival tickets -- 237.1 vs 238.6 us per step at C2, neutral at the C3 shape, profiles/r06f_*; what follows is round 5's one-level measurement) vae.fused_finalize: bf16 step: d / k / counters / clearing of the fp64 accumulators by the LAST workgroup of
                               // the update kernel (arrival ticket behind drained write-through stores) instead of a one-workgroup launch.
                               // Bit-identical, measured SLOWER (C2: 272.5 vs 267.4 us per step, profiles/r05a_step_ab_c2.txt): ~1000
                               // arrivals on one ticket word (the guide's dequeue row: one word saturates at ~88 atomics per us) cost more
                               // than the 4.8 us launch they replace.  Off; kept as the measured negative.
-    int fork_plan = 6;        // vae.fork_plan (bf16 step, bit mask; the two-stream schedule; default 2 + 4, measured with fork_at_loss): 1 = one more fork at the first decoder
+    int fork_plan = -1;       // (-1 = by input width, round 6: 2 up to 512 padded input columns, 6 above -- see fork_plan_for) vae.fork_plan (bf16 step, bit mask; the two-stream schedule; default 2 + 4, measured with fork_at_loss): 1 = one more fork at the first decoder
                               // layer's BatchNorm-backward kernel (its weight gradient and the mu layer's start there instead of at encoder
                               // layer 1); 2 = encoder layer 1's weight gradient on the MAIN stream behind layer 0's (the side stream's last
                               // batch ends before the main stream does); 4 = running statistics + loss reduction at the END of the side
                               // stream's work instead of in front of the first weight gradient; 8 = the mu layer's weight gradient on the main
                               // stream as well
-    int fork_mode = 0;        // vae.fork_mode: 0 = forks ride on the producing kernel's completion signal (hipExtLaunchKernelGGL stop event);
-                              // 2 = stream memory operations (a value written by the main stream, awaited by the side stream)
     bool prefetch_batch = true; // vae.prefetch_batch: bf16 step: the gather of step t + 1 (10 MB read, 15 MB written at C2: 8.6 us on the
                               // critical path) runs on the side stream during step t, FIRST in the batch of work the loss-kernel fork hands
                               // over; the join in front of the optimiser -- already there -- covers it, so the main stream pays no extra
@@ -224,34 +206,23 @@ struct VaeTuning {
     int prefetch_max_cols = 512;   // vae.prefetch_max_cols: widest (padded) input the next-batch prefetch is used for
     bool loss_from_dataset = true; // vae.loss_from_dataset: bf16 step of the plain VAE: the loss kernel reads its targets from the dataset
                               // rows of the batch; the gather kernel then writes no fp32 copy of the batch (a third of its traffic)
-    bool loss_dpp = true;     // vae.loss_dpp: bf16 loss kernel: row reductions by DPP instead of ds_bpermute (see vae_loss16_kernel)
-    bool fused_dz = true;     // vae.fused_dz: bf16 step: the elementwise BatchNorm / dropout / LeakyReLU backward of a hidden layer is applied
-                              // by the input-gradient GEMM that consumes it, while that GEMM stages its A operand (gemm_bf16.hpp STG == 3),
-                              // instead of by a launch of vae_dz16_kernel in front of it.  Same bits (one definition of the element).
-    bool dw_row_major = true; // vae.dw_row_major: bf16 weight gradients contract ROW-major tensors (gemm_bf16_tn.hpp); 0 = the
-                              // round-2 dataflow with a transposed bf16 copy of every contracted tensor (A/B measurements)
+    bool dw_pair = true;      // vae.dw_pair: bf16 step: the last two weight gradients of the backward pass (encoder layers 0 and 1, both on
+                              // the main stream behind the first layer's BatchNorm backward) as ONE launch (gemm_bf16_tn_pair_kernel).  Same bits.
 } g_tuning;
 
 void refresh_tuning() {
     g_tuning.big_tiles = option("vae.big_tiles", 0) != 0;
     g_tuning.xcd_remap = (int)option("vae.xcd_remap", 1);
     g_tuning.dw_workgroups = (int)option("vae.dw_workgroups", 256);
-    g_tuning.dw_row_major = option("vae.dw_row_major", 1) != 0;
-    g_tuning.fork_at_loss = (int)option("vae.fork_at_loss", 1);
-    g_tuning.dz_colsum = option("vae.dz_colsum", 1) != 0;
-    g_tuning.opt_split = option("vae.opt_split", 0) != 0;
-    g_tuning.pipeline = option("vae.gemm_pipeline", 2) == 0 ? 0 : 2;
+    g_tuning.dw_pair = option("vae.dw_pair", 1) != 0;
     g_tuning.fused_skinny = option("vae.fused_skinny", 1) != 0;
-    g_tuning.fused_finalize = option("vae.fused_finalize", 0) != 0;
-    g_tuning.fused_dz = option("vae.fused_dz", 1) != 0;
-    g_tuning.loss_dpp = option("vae.loss_dpp", 1) != 0;
+    g_tuning.fused_finalize = option("vae.fused_finalize", 1) != 0;
     g_tuning.loss_from_dataset = option("vae.loss_from_dataset", 1) != 0;
     g_tuning.prefetch_max_cols = (int)option("vae.prefetch_max_cols", 512);
     g_gemm_prefetch = (int)option("vae.gemm_prefetch", 4);
     g_gemm_kgroups = (int)option("vae.gemm_kgroups", 4);
     g_tuning.prefetch_batch = option("vae.prefetch_batch", 1) != 0;
-    g_tuning.fork_plan = (int)option("vae.fork_plan", 6);
-    g_tuning.fork_mode = (int)option("vae.fork_mode", 0);
+    g_tuning.fork_plan = (int)option("vae.fork_plan", -1);
 }
 
 int fwd_tile(int M, int N) {
@@ -308,10 +279,6 @@ struct vh_vae {
     // joint trainer (vaevae.hpp), whose passes run on their own stream pairs: recorded on `stream` when forward() has the latent
     // code (mu, z) complete, so that the passes fed by it need not wait for the decoder; and the running-statistics update of a
     // pass left to the trainer, which orders the passes of one network as the reference's step does
-    hipEvent_t ev_latent_hook = nullptr;
-    bool defer_running = false;
-    uint32_t* fork_flag = nullptr;    // vae.fork_mode = 2: signal memory the main stream writes and the side stream waits on
-    uint32_t fork_seq = 0;
 
     std::vector<Tensor> tensors;
     std::map<std::string, int> tindex;
@@ -348,7 +315,7 @@ struct vh_vae {
 
     // bf16-storage step (configs C2-C4; vae_step16.hpp)
     DevBuf<bf16_t> W16, W16T, zeros16;       // bf16 shadows of the flat parameter buffer (plain / transposed matrices)
-    DevBuf<bf16_t> Xb16, Xb16T, Z16, Z16T, dR16, dR16T, dMU16, dMU16T, Wf16_mu, Wf16_out;
+    DevBuf<bf16_t> Xb16, Z16, dR16, dMU16, Wf16_mu, Wf16_out;
     // next-batch prefetch (vae.prefetch_batch): the second set of batch buffers, what the running step was asked to fill, and whether
     // the set holds the batch the next step needs
     DevBuf<float> Xb_n, Wb_n;
@@ -368,7 +335,6 @@ struct vh_vae {
     // data parallelism (one process per GPU; gradients all-reduced over RCCL on `stream`)
     vh_comm* comm = nullptr;
     bool syncbn = true;              // BatchNorm batch statistics over the ALL-RANK batch (reference semantics, encode.py:238,246)
-    bool opt16_decoder_done = false; // bf16 step: the decoder-side tensors were updated on the side stream during this step's backward
     int opt16_bucketA_blk0 = 0;      // bf16 step: first optimiser workgroup / flat offset of the decoder-side tensors
     size_t opt16_bucketA_off = 0;    // (gradient bucket that is all-reduced while the encoder's backward still runs)
     DevBuf<float> G, gwsum;          // flat gradient buffer; per-batch global weight sums
@@ -395,7 +361,6 @@ struct vh_vae {
         for (auto e : ev_b) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
-        if (fork_flag) (void)hipFree(fork_flag);
         if (owns_streams) {
             if (side && side != stream) (void)hipStreamDestroy(side);
             if (stream) (void)hipStreamDestroy(stream);
@@ -706,24 +671,9 @@ void fork_side(vh_vae* h) {
 // forks per step).  Instead the producing kernel is launched with the fork event as its stop event
 // (hipExtLaunchKernelGGL: the event is the dispatch's own completion signal) and the side stream waits on that.
 bool fork_from_kernel(const vh_vae* h) { return h->side != h->stream && h->fork_ext; }
-// vae.fork_mode = 2: no event at all -- the main stream writes the next value of a counter into signal memory behind the producing
-// kernel (a command-processor packet), the side stream waits until the counter has reached it
-void fork_by_value(vh_vae* h) {
-    if (h->fork_flag == nullptr) {
-        VH_HIP(hipExtMallocWithFlags((void**)&h->fork_flag, 8, hipMallocSignalMemory));
-        VH_HIP(hipMemset(h->fork_flag, 0, 8));
-    }
-    h->fork_seq++;
-    VH_HIP(hipStreamWriteValue32(h->stream, h->fork_flag, h->fork_seq, 0));
-    VH_HIP(hipStreamWaitValue32(h->side, h->fork_flag, h->fork_seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
-}
 template <class K, class... Args>
 void launch_forking(vh_vae* h, K kernel, dim3 grid, dim3 block, size_t smem, Args... args) {
-    if (h->side != h->stream && g_tuning.fork_mode == 2) {
-        hipLaunchKernelGGL(kernel, grid, block, smem, h->stream, args...);
-        VH_HIP(hipGetLastError());
-        fork_by_value(h);
-    } else if (fork_from_kernel(h)) {
+    if (fork_from_kernel(h)) {
         hipExtLaunchKernelGGL(kernel, grid, block, smem, h->stream, nullptr, h->ev_fork, 0, args...);
         VH_HIP(hipGetLastError());
         VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -874,7 +824,6 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
                            eps_injected ? h->EPS.p : nullptr, layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p,
                            h->Z.p, bs, h->L, h->L_p, bs_p);
         VH_HIP(hipGetLastError());
-        if (h->ev_latent_hook) VH_HIP(hipEventRecord(h->ev_latent_hook, s));
     }
     in = h->Z.p;
     in_w = h->L_p;
@@ -901,7 +850,7 @@ void forward(vh_vae* h, bool training, bool eps_injected, bool masks_injected, b
     if (training) {
         // running statistics (momentum 0.1, unbiased variance): off the critical path, on the side stream
         if (!fork_from_kernel(h)) fork_side(h);
-        if (!h->defer_running) update_running(h, part, h->side);
+        update_running(h, part, h->side);
     }
 }
 

@@ -89,60 +89,6 @@ __global__ void vae_cast16_kernel(const float* __restrict__ in, bf16_t* __restri
     }
 }
 
-// ---- bf16 transpose: out[c][r] = in[r][c] for r < R, c < C (both multiples of 64 after padding: the caller passes
-// padded extents).  64 x 64 tiles through LDS, 16-byte accesses on both sides.  Optional fp64 column sums of `in`
-// over the rows r < r_real (bias gradients: sum over the batch), one atomic per column and tile.
-constexpr int kTrTile = 64;
-__global__ __launch_bounds__(256) void vae_transpose16_kernel(const bf16_t* __restrict__ in, int64_t ld_in, int R, int C,
-                                                              bf16_t* __restrict__ out, int64_t ld_out,
-                                                              double* __restrict__ colsum, int r_real) {
-    __shared__ __attribute__((aligned(16))) bf16_t tile[kTrTile][kTrTile + 8];
-    __shared__ float csum[4][kTrTile];
-    const int tid = threadIdx.x;
-    const int r0 = blockIdx.y * kTrTile, c0 = blockIdx.x * kTrTile;
-    // load: 8 threads per row (16 B each), 32 rows per pass
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int r = (tid >> 3) + 32 * p, c8 = (tid & 7) * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r0 + r < R && c0 + c8 < C) v = *reinterpret_cast<const uint4*>(in + (int64_t)(r0 + r) * ld_in + c0 + c8);
-        *reinterpret_cast<uint4*>(&tile[r][c8]) = v;
-    }
-    __syncthreads();
-    // store: chunk = (column c, row group rg of 8 rows); lanes of a wave take consecutive columns
-    const int wave = tid >> 6;
-    float s = 0.f;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int id = tid + 256 * p;
-        const int c = id & 63, rg = id >> 6;
-        bf16_t e[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) e[k] = tile[rg * 8 + k][c];
-        if (colsum) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (r0 + rg * 8 + k < r_real) s += bf2f(e[k]);
-        }
-        if (c0 + c < C && r0 + rg * 8 < R) {
-            uint4 v;
-            v.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
-            v.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
-            v.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
-            v.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
-            *reinterpret_cast<uint4*>(out + (int64_t)(c0 + c) * ld_out + r0 + rg * 8) = v;
-        }
-    }
-    if (colsum) {   // thread (wave, lane) summed column `lane` over row groups {wave, wave + 4}: combine the 4 waves
-        csum[wave][tid & 63] = s;
-        __syncthreads();
-        if (tid < kTrTile && c0 + tid < C) {
-            const float t = (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]);
-            atomicAdd(&colsum[c0 + tid], (double)t);
-        }
-    }
-}
-
 // ---- BatchNorm folded into the consumer's weights ------------------------------------------------------------------
 // W [n_rows][ldw] fp32 (master), stats of the producing layer over its K columns -> W16 = bf16(W diag(s)) [n_rows][ldw],
 // bias_out[n] = bias[n] + sum_k W[n][k] t_k.  One wavefront per weight row; s, t are rebuilt per workgroup.
@@ -391,14 +337,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 // ---- elementwise backward of one hidden layer, bf16 in / out ---------------------------------------------------------
 //   dZ = keep * slope(h) * drop_scale * istd*gamma * (dA - S1/B - xhat * S2/B)      (see vae_dz_kernel)
-// reads dA16, H16 [bs_p][n_p]; writes dZ16 [bs_p][n_p] and dZ16T [n_p][bs_p] (the A operand of the weight-gradient
-// GEMM) and accumulates the fp64 column sums of dZ (bias gradient).  A workgroup owns 64 rows x 128 columns.
+// reads dA16, H16 [bs_p][n_p]; writes dZ16 [bs_p][n_p] and accumulates the fp64 column sums of dZ (bias gradient).  A
+// workgroup owns 64 rows x 128 columns.
 struct Dz16Args {
     const bf16_t* DA;
     const bf16_t* H;
     bf16_t* DZ;
-    bf16_t* DZT;
-    int64_t ldt;       // leading dimension of DZT (= bs_p)
     int n_p, bs, bs_p;
     BnSrc bn;
     const float* mean;    // mean / 1/std of this layer's BatchNorm as the forward fold left them
@@ -415,7 +359,6 @@ constexpr int kDz16Cols = 128;
 constexpr int kDz16Rows = 64;   // (32-row tiles, twice the workgroups: the same 12.1 us per launch at C2, profiles/r03zg_*)
 
 __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
-    __shared__ __attribute__((aligned(16))) bf16_t tile[kDz16Rows][kDz16Cols + 8];
     __shared__ float red[16][kDz16Cols];
     __shared__ float cf[3][kDz16Cols];
     const int tid = threadIdx.x;
@@ -471,31 +414,13 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
             }
         }
         const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-        if (a.DZT) *reinterpret_cast<uint4*>(&tile[rl][c8]) = o;
         if (r < a.bs_p && col < a.n_p) *reinterpret_cast<uint4*>(a.DZ + (int64_t)r * a.n_p + col) = o;
     }
     if (a.dbias) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[rt][c8 + e] = s[e];
     }
-    if (a.dbias || a.DZT) __syncthreads();   // (kernel-argument uniform)
-    // transposed copy (round-2 dataflow only): chunk = (column c, 8 consecutive rows); lanes of a wave take consecutive columns
-#pragma unroll
-    for (int p = 0; p < (a.DZT ? (kDz16Cols * (kDz16Rows / 8)) / 256 : 0); ++p) {
-        const int id = tid + 256 * p;
-        const int c = id % kDz16Cols, rg = id / kDz16Cols;
-        bf16_t e[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) e[k] = tile[rg * 8 + k][c];
-        if (col0 + c < a.n_p && row0 + rg * 8 < a.bs_p) {
-            uint4 v;
-            v.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
-            v.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
-            v.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
-            v.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
-            *reinterpret_cast<uint4*>(a.DZT + (int64_t)(col0 + c) * a.ldt + row0 + rg * 8) = v;
-        }
-    }
+    if (a.dbias) __syncthreads();   // (kernel-argument uniform)
     if (a.dbias && tid < kDz16Cols) {
         const int c = col0 + tid;
         float t = 0.f;
@@ -551,6 +476,7 @@ struct Opt16Tensor {
 };
 constexpr int kMaxOpt16 = 4 * 2 * 8 + 4;
 
+constexpr unsigned int kOptTicketGroups = 32, kOptTicketStride = 32;   // arrival words: [0] = top, [32 (1 + g)] = group g (128-byte lines)
 // The scalar tail of the optimiser step inside the update kernel (ticket == nullptr: a separate vae_dadapt_finalize_kernel follows)
 struct Opt16Tail {
     unsigned int* ticket;   // arrival counter, 0 between steps
@@ -724,13 +650,25 @@ __global__ __launch_bounds__(256) void vae_dadapt16_kernel(const Opt16Tensor* __
     // stores of the partial sums, drained (s_waitcnt vmcnt(0)), THEN the arrival ticket; the last arriver reads every partial
     // with device-scope loads.  No fence (a release fence writes the whole L2 back).  Every other workgroup has read the step
     // state and its accumulators before it took its ticket, so the last one may update / clear them.
+    // Two levels of tickets (round 6): one word takes ~88 atomics per microsecond, so the ~900 arrivals of a launch on ONE word cost
+    // ~10 us (round 5 measured the one-level tail 5 us SLOWER than the launch it replaced).  Workgroup b arrives at group word
+    // b % 32 (each word on its own 128-byte line); the last arrival of a group re-arms its word and arrives at the top word; the
+    // last arrival there runs the tail: at most ~28 + 32 arrivals on any word.
     __shared__ int last_s;
     if (threadIdx.x == 0) {
         __hip_atomic_store(&partials[(int64_t)blk * 2 + 0], part0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&partials[(int64_t)blk * 2 + 1], part1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int t = __hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = (t == (unsigned int)gridDim.x - 1u) ? 1 : 0;
+        const unsigned int nb = gridDim.x, grp = (unsigned int)blockIdx.x % kOptTicketGroups;
+        const unsigned int ngroups = nb < kOptTicketGroups ? nb : kOptTicketGroups;
+        const unsigned int gsize = (nb - grp + kOptTicketGroups - 1) / kOptTicketGroups;
+        unsigned int* const gword = tail.ticket + kOptTicketStride * (1 + grp);
+        int last = 0;
+        if (__hip_atomic_fetch_add(gword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
+            __hip_atomic_store(gword, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // armed for the next step
+            last = __hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u;
+        }
+        last_s = last;
     }
     __syncthreads();
     if (!last_s) return;

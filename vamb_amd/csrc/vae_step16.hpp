@@ -3,8 +3,8 @@
 // (drop_cfg, layer_key, step_ptr, bn_src, launch_forking, fork_side, join_side, probe_arm).
 //
 // Tensors (per batch size, see prepare_batch16):
-//   Xb16 / Xb16T, Z16 / Z16T, dR16 / dR16T, dMU16 / dMU16T   bf16, row-major [bs_p][w] and transposed [w][bs_p]
-//   per hidden layer: H16 / H16T (post-dropout activations), DA16 (grad wrt the BatchNorm output), DZ16 / DZ16T
+//   Xb16, Z16, dR16, dMU16   bf16, row-major [bs_p][w]
+//   per hidden layer: H16 (post-dropout activations), DA16 (grad wrt the BatchNorm output), DZ16
 //   W16 / W16T: bf16 shadows of every parameter tensor at the offsets of the flat fp32 buffer (transposed for
 //   matrices); Wf16 / biasf: the BatchNorm-folded weights of the layers that consume normalised activations.
 // Stream plan: the main stream carries gather -> forward -> loss -> dX chain -> optimiser; the side stream carries
@@ -59,37 +59,6 @@ void launch_gemm16_tn(hipStream_t stream, const Gemm16TnArgs& g, int splits) {
         t_fork_stop = nullptr;
     } else {
         hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g);
-    }
-    VH_HIP(hipGetLastError());
-}
-
-// input-gradient GEMM that forms its A operand (dZ of the layer above) while staging it (gemm_bf16.hpp, STG == 3); the LDS
-// holds the operand buffers + the [3][K] coefficient table.  false: the shape does not fit (the caller keeps vae_dz16_kernel)
-constexpr int kFusedDzBM = 128, kFusedDzBN = 128;
-inline size_t fused_dz_smem(int K) {
-    return gemm16_smem_bytes<kFusedDzBM, kFusedDzBN, 2, 4, E16_STORE_BNRED, 3>() + (size_t)12 * round_up(K, 64);
-}
-inline bool fused_dz_shape_ok(int M, int N, int K) {
-    return (K & 7) == 0 && fused_dz_smem(K) <= kMaxDynLds && M % kFusedDzBM == 0 && N % kFusedDzBN == 0;
-}
-inline bool fused_dz_fits(const Gemm16Args& g) {
-    return g.k_per_split == g.K && (g.K & 7) == 0 && fused_dz_smem(g.K) <= kMaxDynLds && g.M % kFusedDzBM == 0 && g.N % kFusedDzBN == 0 &&
-           g.m_real == g.M;
-}
-void launch_gemm16_fused_dz(hipStream_t stream, const Gemm16Args& g) {
-    static bool attr_set = false;
-    auto kern = gemm_bf16_kernel<kFusedDzBM, kFusedDzBN, 2, 4, E16_STORE_BNRED, 3>;
-    if (!attr_set) {
-        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
-        attr_set = true;
-    }
-    const size_t smem = fused_dz_smem(g.K);
-    dim3 grid((unsigned)ceil_div(g.N, kFusedDzBN), (unsigned)ceil_div(g.M, kFusedDzBM), 1);
-    if (t_fork_stop) {
-        hipExtLaunchKernelGGL(kern, grid, dim3(512), smem, stream, nullptr, t_fork_stop, 0, g);
-        t_fork_stop = nullptr;
-    } else {
-        hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, g);
     }
     VH_HIP(hipGetLastError());
 }
@@ -155,8 +124,7 @@ void gemm16(hipStream_t s, const Gemm16Args& g, int splits) {
     if constexpr (EPI == E16_SPLITK || EPI == E16_LATENT_MASK) {
         gemm16_stg<EPI, 0>(s, g, splits);
     } else {
-        if (g_tuning.pipeline == 2) gemm16_stg<EPI, 2>(s, g, splits);
-        else gemm16_stg<EPI, 0>(s, g, splits);
+        gemm16_stg<EPI, 2>(s, g, splits);
     }
 }
 
@@ -203,25 +171,25 @@ int dw_splits16(int M, int N, int K) {
     return std::max(1, want);
 }
 
-void transpose16(vh_vae* h, hipStream_t s, const bf16_t* in, int R, int C, bf16_t* out, double* colsum, int r_real) {
-    hipLaunchKernelGGL(vae_transpose16_kernel, dim3((unsigned)ceil_div(C, kTrTile), (unsigned)ceil_div(R, kTrTile)),
-                       dim3(256), 0, s, in, (int64_t)C, R, C, out, (int64_t)R, colsum, r_real);
-    VH_HIP(hipGetLastError());
-}
-
 // Work that is off the critical path of a step (transposes of the narrow tensors, running statistics, the loss
 // reduction, weight-gradient GEMMs) is queued in program order and handed to the side stream at a few fork points
 // only: every cross-stream fork costs the main stream ~5 us (measured, profiles/r02_c_step_timeline.txt: one fork per
 // producing kernel = 9 forks = 45 us of a 350 us step).  An item may be flushed at any fork that follows the launch of
 // its last producer on the main stream.
+// The two-stream schedule of a step (vae.fork_plan, bit mask: VaeTuning).  Unset, it follows the input width (round 6, with the
+// paired launch of the last two weight gradients; profiles/r06f_step_forkplan2_c{2,3}.txt): up to 512 padded input columns (C2:
+// D_p = 320) the two one-workgroup kernels -- running statistics, loss reduction -- run FIRST on the side stream (plan 2: 238.6
+// against 251.0 us per step with them last), wider inputs (the C3 shape: D_p = 1120, a 3.5 x larger output-layer weight gradient
+// in front of them) keep them LAST (plan 6: 341.5 against 350.8 us).
+int fork_plan_for(const vh_vae* h) { return g_tuning.fork_plan >= 0 ? g_tuning.fork_plan : (h->D_p <= 512 ? 2 : 6); }
+
 struct SideQueue {
+    int plan = 6;
     std::vector<std::function<void(hipStream_t)>> items;
     std::vector<std::function<void(hipStream_t)>> tail;   // small items nobody but the optimiser waits for (vae.fork_plan & 4)
     void add(std::function<void(hipStream_t)> f) { items.push_back(std::move(f)); }
     void add_small(std::function<void(hipStream_t)> f) {
-        // (vae.opt_split updates half of the parameters on the side stream DURING the backward and needs this step's loss reduction
-        // -- the sum of the batch's weights -- in front of it: round 5's first build ran it behind, on the previous step's sum)
-        if ((g_tuning.fork_plan & 4) && !g_tuning.opt_split) tail.push_back(std::move(f));
+        if (plan & 4) tail.push_back(std::move(f));
         else items.push_back(std::move(f));
     }
     void flush(hipStream_t s) {
@@ -250,21 +218,13 @@ void refresh_shadows(vh_vae* h, int only) {
 // everything of the bf16 step that depends on the batch size (called from prepare_batch)
 void prepare_batch16(vh_vae* h) {
     const int bs_p = h->bs_p;
-    const bool tcopies = !g_tuning.dw_row_major;   // transposed bf16 copies: only the round-2 dataflow needs them
     h->Xb16.ensure((size_t)bs_p * h->D_p);
     h->Z16.ensure((size_t)bs_p * h->L_p);
     h->dR16.ensure((size_t)bs_p * h->D_p);
     h->dMU16.ensure((size_t)bs_p * h->L_p);
-    if (tcopies) {
-        h->Xb16T.ensure((size_t)bs_p * h->D_p);
-        h->Z16T.ensure((size_t)bs_p * h->L_p);
-        h->dR16T.ensure((size_t)bs_p * h->D_p);
-        h->dMU16T.ensure((size_t)bs_p * h->L_p);
-    }
     for (auto& hl : h->hidden) {
         const size_t n = (size_t)bs_p * hl.nout_p;
         hl.H16.ensure(n); hl.DA16.ensure(n); hl.DZ16.ensure(n);
-        if (tcopies) { hl.H16T.ensure(n); hl.DZ16T.ensure(n); }
         hl.Wf16.ensure((size_t)hl.nout_p * hl.nin_p);
         hl.biasf.ensure((size_t)hl.nout_p);
     }
@@ -346,8 +306,8 @@ void build_opt16_table(vh_vae* h) {
     VH_HIP(hipMemcpy(h->opt16_tab_flat.p, tab.data(), tab.size() * sizeof(Opt16Tensor), hipMemcpyHostToDevice));
     h->opt_part.ensure((size_t)std::max(h->opt_blocks, nblk) * 2);
     if (h->opt_ticket.n == 0) {
-        h->opt_ticket.alloc(1);
-        VH_HIP(hipMemset(h->opt_ticket.p, 0, sizeof(unsigned int)));
+        h->opt_ticket.alloc((size_t)kOptTicketStride * (1 + kOptTicketGroups));
+        VH_HIP(hipMemset(h->opt_ticket.p, 0, h->opt_ticket.bytes()));
     }
 }
 
@@ -396,7 +356,6 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
                 g.B = w16(h, hl.tW); g.bias = h->pptr(hl.tb);
             }
             g.ldb = hl.nin_p;
-            g.C16T = g_tuning.dw_row_major ? nullptr : hl.H16T.p; g.ldc16t = bs_p;
             g.fstat_out = hl.fstat;
             g.drop_scale = dc.scale; g.drop_thresh = dc.thresh; g.drop_key = layer_key(h, li);
             g.step_ptr = step_ptr(h);
@@ -457,9 +416,6 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
                                layer_key(h, 0xEE), step_ptr(h), add_noise ? 1 : 0, h->MU.p, h->Z16.p, bs, h->L, h->L_p, bs_p);
             VH_HIP(hipGetLastError());
         }
-        // the transposed latent code feeds the first decoder layer's weight gradient
-        if (defer && !g_tuning.dw_row_major)
-            defer->add([h, bs_p](hipStream_t st) { transpose16(h, st, h->Z16.p, bs_p, h->L_p, h->Z16T.p, nullptr, 0); });
     }
     in = h->Z16.p;
     in_w = h->L_p;
@@ -524,17 +480,11 @@ void loss_and_seed16(vh_vae* h, SideQueue& q) {
     if (!loss_attr) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_loss16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024 - 256));
-        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_loss16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024 - 256));
         loss_attr = true;
     }
-    auto kern = g_tuning.loss_dpp ? vae_loss16_kernel<true> : vae_loss16_kernel<false>;
-    if (g_tuning.fork_at_loss) {   // the side stream's first items (see backward16) only need what this kernel leaves
-        launch_forking(h, kern, dim3(h->loss_blocks), dim3(256), loss_lds, a);
-    } else {
-        hipLaunchKernelGGL(kern, dim3(h->loss_blocks), dim3(256), loss_lds, h->stream, a);
-        VH_HIP(hipGetLastError());
-    }
+    auto kern = vae_loss16_kernel<true>;
+    // the side stream starts here: its first items (see backward16) only need what this kernel leaves
+    launch_forking(h, kern, dim3(h->loss_blocks), dim3(256), loss_lds, a);
     // the scalar reduction (loss means, sum of weights) is only needed by the optimiser
     const float* gw = h->gwsum_src;
     const float* lab_part = a.lab_part;
@@ -545,51 +495,72 @@ void loss_and_seed16(vh_vae* h, SideQueue& q) {
     });
 }
 
-// dW slabs = A^T-copy [out][bs_p] x B^T-copy [in][bs_p] (both K-contiguous over the batch)
-void grad_weight16(vh_vae* h, int tW, const bf16_t* dZT, int out_p, const bf16_t* InT, int in_p, hipStream_t st) {
-    Tensor& t = h->tensors[tW];
-    Gemm16Args g = args16(h);
-    g.A = dZT; g.lda = h->bs_p;
-    g.B = InT; g.ldb = h->bs_p;
-    g.C32 = t.slab; g.ldc32 = in_p;
-    g.M = out_p; g.N = in_p; g.K = h->bs_p;
-    g.k_per_split = (int)round_up(ceil_div(h->bs_p, t.nslab), 64);
-    g.slab_stride = t.stride;
-    const int splits = (int)ceil_div(h->bs_p, g.k_per_split);
-    if (splits < t.nslab)
-        VH_HIP(hipMemsetAsync(t.slab + (int64_t)splits * t.stride, 0, sizeof(float) * (t.nslab - splits) * t.stride, st));
-    gemm16<E16_SPLITK>(st, g, splits);
-}
-
 // dW slabs = dZ^T In straight from the ROW-major tensors dZ [bs_p][out_p], In [bs_p][in_p] (gemm_bf16_tn.hpp); dbias: the
 // fp64 column sums of dZ over the real rows, for the layers whose bias gradient no other kernel produces (output, mu)
-void grad_weight16_rm(vh_vae* h, int tW, const bf16_t* dZ, int out_p, const bf16_t* In, int in_p, double* dbias,
-                      hipStream_t st) {
-    Tensor& t = h->tensors[tW];
+struct DwSpec {   // one weight-gradient product of the row-major dataflow
+    int tW = -1;
+    const bf16_t* dZ = nullptr;
+    int out_p = 0;
+    const bf16_t* In = nullptr;
+    int in_p = 0;
+    double* dbias = nullptr;
+};
+Gemm16TnArgs dw_args16_rm(vh_vae* h, const DwSpec& d, int& splits, hipStream_t st) {
+    Tensor& t = h->tensors[d.tW];
     Gemm16TnArgs g;
     memset(&g, 0, sizeof(g));
     g.zeros = h->zeros16.p;
     g.xcd_remap = 1;
-    g.A = dZ; g.lda = out_p;
-    g.B = In; g.ldb = in_p;
-    g.C32 = t.slab; g.ldc = in_p;
-    g.M = out_p; g.N = in_p; g.K = h->bs_p; g.k_real = h->bs;
+    g.A = d.dZ; g.lda = d.out_p;
+    g.B = d.In; g.ldb = d.in_p;
+    g.C32 = t.slab; g.ldc = d.in_p;
+    g.M = d.out_p; g.N = d.in_p; g.K = h->bs_p; g.k_real = h->bs;
     g.k_per_split = (int)round_up(ceil_div(h->bs_p, t.nslab), 64);
     g.slab_stride = t.stride;
-    g.colsum = dbias;
-    const int splits = (int)ceil_div(h->bs_p, g.k_per_split);
+    g.colsum = d.dbias;
+    splits = (int)ceil_div(h->bs_p, g.k_per_split);
     if (splits < t.nslab)
         VH_HIP(hipMemsetAsync(t.slab + (int64_t)splits * t.stride, 0, sizeof(float) * (t.nslab - splits) * t.stride, st));
+    return g;
+}
+void grad_weight16_rm(vh_vae* h, int tW, const bf16_t* dZ, int out_p, const bf16_t* In, int in_p, double* dbias,
+                      hipStream_t st) {
+    int splits = 1;
+    const Gemm16TnArgs g = dw_args16_rm(h, DwSpec{tW, dZ, out_p, In, in_p, dbias}, splits, st);
     if (dbias) gemm16_tn<1>(st, g, splits);
     else gemm16_tn<0>(st, g, splits);
 }
+// The last two weight gradients of the backward pass (encoder layers 0 and 1 on the main stream) as ONE launch
+// (gemm_bf16_tn_pair_kernel): both must take the 64 x 128 tile of gemm16_tn_stg and no column sums.  false: launch them one by one.
+bool grad_weight16_rm_pair(vh_vae* h, const DwSpec& a, const DwSpec& b, hipStream_t st) {
+    auto fits = [](const DwSpec& d) { return d.tW >= 0 && d.dbias == nullptr && d.out_p > 32 && d.in_p > 32; };
+    if (!g_tuning.dw_pair || !fits(a) || !fits(b)) return false;
+    Gemm16TnPair pr;
+    memset(&pr, 0, sizeof(pr));
+    int splits[2];
+    pr.p[0] = dw_args16_rm(h, a, splits[0], st);
+    pr.p[1] = dw_args16_rm(h, b, splits[1], st);
+    for (int i = 0; i < 2; ++i) {
+        pr.gx[i] = (int)ceil_div(pr.p[i].N, 128);
+        pr.gy[i] = (int)ceil_div(pr.p[i].M, 64);
+        pr.gz[i] = splits[i];
+    }
+    pr.nwg0 = pr.gx[0] * pr.gy[0] * pr.gz[0];
+    const int nwg = pr.nwg0 + pr.gx[1] * pr.gy[1] * pr.gz[1];
+    auto kern = gemm_bf16_tn_pair_kernel<64, 128, 2, 2, 0>;
+    constexpr size_t smem = gemm16_tn_smem_bytes<64, 128, 0>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, st, pr);
+    VH_HIP(hipGetLastError());
+    return true;
+}
 
-// dIn16 = dZ16 [bs_p][out] x W16T [in][out]; the epilogue leaves the BatchNorm-backward sums of the layer below.
-// `above` (with `dz_hashed` >= 0): dZ16 of that layer does not exist yet -- the GEMM forms it from the layer's dA16 / H16 while it
-// stages its A operand and its first tile column stores it (vae.fused_dz); returns false when the shape does not fit that kernel
-// (the caller then runs vae_dz16_kernel first and calls again without `above`).  `fork`: the side stream continues behind this launch.
-bool grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidden& below, Hidden* above = nullptr,
-                  float drop_scale = 1.0f, bool dz_hashed = false, bool fork = false) {
+// dIn16 = dZ16 [bs_p][out] x W16T [in][out]; the epilogue leaves the BatchNorm-backward sums of the layer below
+void grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidden& below) {
     Gemm16Args g = args16(h);
     g.A = dZ; g.lda = out_p;
     g.B = w16t(h, tW); g.ldb = out_p;
@@ -600,25 +571,8 @@ bool grad_input16(vh_vae* h, const bf16_t* dZ, int out_p, int tW, int in_p, Hidd
     g.bnC = bn_src(h, below);
     g.bn_mean = below.mean.p; g.bn_istd = below.invstd.p;   // left by the fold of this layer's BatchNorm in the forward pass
     g.bstat_out = below.bstat;
-    if (above) {
-        g.A = above->DA16.p;
-        g.dzH = above->H16.p; g.ld_dzh = out_p;
-        g.dzc = DzCoefSrc{above->mean.p, above->invstd.p, h->pptr(above->tG), above->bstat, out_p, stat_bs(h), drop_scale};
-        g.dz_hashed = dz_hashed ? 1 : 0;
-        g.dzOut = above->DZ16.p; g.ld_dzout = out_p;
-        if (!fused_dz_fits(g)) return false;
-    }
-    const bool ext = fork && h->side != h->stream && g_tuning.fork_mode != 2 && fork_from_kernel(h);
-    if (ext) t_fork_stop = h->ev_fork;
-    if (above) launch_gemm16_fused_dz(h->stream, g);
-    else gemm16<E16_STORE_BNRED>(h->stream, g, 1);
-    if (ext) VH_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    else if (fork && h->side != h->stream) {
-        if (g_tuning.fork_mode == 2) fork_by_value(h);
-        else fork_side(h);
-    }
+    gemm16<E16_STORE_BNRED>(h->stream, g, 1);
     sync_stats(h, below.bstat, below.nout_p);
-    return true;
 }
 
 void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
@@ -626,74 +580,49 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
     const DropCfg dc = drop_cfg(h, true, masks_injected);
     {   // output layer: dR16 is ready
         Hidden& last = h->hidden[2 * nl - 1];
-        q.add([h, bs_p, bs, &last](hipStream_t st) {
-            if (g_tuning.dw_row_major) {
-                grad_weight16_rm(h, h->tWo, h->dR16.p, h->D_p, last.H16.p, last.nout_p, h->dbias_out, st);
-            } else {
-                transpose16(h, st, h->dR16.p, bs_p, h->D_p, h->dR16T.p, h->dbias_out, bs);
-                grad_weight16(h, h->tWo, h->dR16T.p, h->D_p, last.H16T.p, last.nout_p, st);
-            }
+        q.add([h, &last](hipStream_t st) {
+            grad_weight16_rm(h, h->tWo, h->dR16.p, h->D_p, last.H16.p, last.nout_p, h->dbias_out, st);
         });
         // running statistics, the loss reduction and the output layer's weight gradient depend on nothing later than the
         // loss kernel: hand them to the side stream now (forked on that kernel's completion, loss_and_seed16)
-        if (g_tuning.fork_at_loss) q.flush(h->side);
+        q.flush(h->side);
         grad_input16(h, h->dR16.p, h->D_p, h->tWo, last.nout_p, last);
     }
     int latent_slabs = 1;
     bool latent_fused = false;
     std::function<void(hipStream_t)> late_dw, late_dw_mu;
+    DwSpec late_spec;   // what late_dw launches (row-major dataflow), for the paired launch with the first layer's
     auto hidden_bwd = [&](int li) {
         Hidden& hl = h->hidden[li];
         Dz16Args a;
-        a.DA = hl.DA16.p; a.H = hl.H16.p; a.DZ = hl.DZ16.p; a.DZT = g_tuning.dw_row_major ? nullptr : hl.DZ16T.p; a.ldt = bs_p;
+        a.DA = hl.DA16.p; a.H = hl.H16.p; a.DZ = hl.DZ16.p; 
         a.n_p = hl.nout_p; a.bs = bs; a.bs_p = bs_p;
         a.bn = bn_src(h, hl);
         a.mean = hl.mean.p; a.istd = hl.invstd.p;
         a.bstat = hl.bstat;
         a.drop_scale = dc.scale;
         a.drop_mask = dc.injected ? hl.mask.p : nullptr; a.ld_mask = hl.nout_p;
-        const bool rm = g_tuning.dw_row_major;
+        constexpr bool rm = true;   // weight gradients contract the row-major tensors (gemm_bf16_tn.hpp)
         const int in_p = li == 0 ? h->D_p : (li == nl ? h->L_p : h->hidden[li - 1].nout_p);
-        // vae.fused_dz: a layer whose dZ feeds a regular input-gradient GEMM (every hidden layer but the first of each half) is
-        // not given its own elementwise launch: that GEMM forms dZ while it stages its A operand (gemm_bf16.hpp, STG == 3) and
-        // stores it for this layer's weight gradient, which therefore forks behind the GEMM instead of behind the dZ kernel and
-        // takes the bias gradient (the column sums of dZ) on its way.  Needs row-major weight gradients, hash dropout or none,
-        // a full batch and tile-aligned widths.
-        const bool fuse = g_tuning.fused_dz && li != 0 && li != nl && rm && a.drop_mask == nullptr && hl.mean.p != nullptr &&
-                          bs == bs_p && fused_dz_shape_ok(bs_p, in_p, hl.nout_p);
-        // bias gradient = column sums of dZ: with row-major weight gradients the dW GEMM of this layer streams dZ anyway and
-        // sums it on the way (COLSUM, a few atomics per column); the elementwise kernel's own sums cost it one fp64 atomic per
-        // column from each of its bs_p / 64 row blocks (vae.dz_colsum = 1: keep them there, A/B)
-        const bool colsum_in_gemm = rm && (fuse || !g_tuning.dz_colsum);
-        a.dbias = colsum_in_gemm ? nullptr : hl.dbias;
-        const bf16_t* InT = rm ? (li == 0 ? h->Xb16.p : (li == nl ? h->Z16.p : h->hidden[li - 1].H16.p))     // row-major input
-                               : (li == 0 ? h->Xb16T.p : (li == nl ? h->Z16T.p : h->hidden[li - 1].H16T.p));
-        auto dw = [h, &hl, InT, in_p, rm, colsum_in_gemm](hipStream_t st) {
-            if (rm) grad_weight16_rm(h, hl.tW, hl.DZ16.p, hl.nout_p, InT, in_p, colsum_in_gemm ? hl.dbias : nullptr, st);
-            else grad_weight16(h, hl.tW, hl.DZ16T.p, hl.nout_p, InT, in_p, st);
+        // bias gradient = column sums of dZ, taken by this kernel from the values it writes (one fp64 atomic per column from each of
+        // its bs_p / 64 row blocks).  (The weight-gradient GEMM could sum the dZ it streams instead -- COLSUM, as the output and mu
+        // layers do: the dz kernel 12.1 -> 10.2 us, the dW GEMMs 16.9 -> 20.4 us, step 291 -> 293 us, profiles/r03zd_dz_colsum.txt.)
+        constexpr bool colsum_in_gemm = false;
+        a.dbias = hl.dbias;
+        const bf16_t* InT = li == 0 ? h->Xb16.p : (li == nl ? h->Z16.p : h->hidden[li - 1].H16.p);   // row-major input of the layer
+        auto dw = [h, &hl, InT, in_p](hipStream_t st) {
+            grad_weight16_rm(h, hl.tW, hl.DZ16.p, hl.nout_p, InT, in_p, colsum_in_gemm ? hl.dbias : nullptr, st);
         };
         // Fork points: the top decoder layer and encoder layer 1 (and layer 0 when something is still queued): each
         // hands everything queued so far to the side stream.  The first layer's weight gradient is the end of the
         // chain -- nothing is left on the main stream for it to hide behind -- so it runs there.
         // (vae.fork_plan & 2: encoder layer 1's weight gradient waits for layer 0's on the main stream)
-        const bool dw_on_main_late = li == 1 && nl >= 2 && (g_tuning.fork_plan & 2) != 0;
-        if (dw_on_main_late) late_dw = dw;
-        else if (li > 0) q.add(dw);
-        if (li == nl && !h->comm && nl >= 2 && g_tuning.opt_split) {
-            // Every decoder-side gradient is queued now (output layer, decoder layers; their bias / gamma / beta sums are
-            // complete on the main stream).  The update of those tensors -- half of the parameters -- does not need this
-            // step's D-Adapt reductions (it steps with the d of the previous step), so it runs on the side stream under the
-            // encoder's backward instead of at the end of the step.  The batch is handed over at encoder layer 1's fork: by
-            // then the main stream has read the decoder's weights for the last time (nl >= 2).
-            q.add([h](hipStream_t st) {
-                const int nb = h->opt16_blocks - h->opt16_bucketA_blk0;
-                hipLaunchKernelGGL(vae_dadapt16_kernel, dim3(nb), dim3(256), 0, st, (const Opt16Tensor*)h->opt16_tab.p,
-                                   (const uint8_t*)h->opt16_blk2t.p, stat_bs(h), h->P.p, h->M1.p, h->M2.p, h->Sv.p, (const StepState*)h->state.p, h->opt_part.p,
-                                   h->adam_lr, h->opt16_bucketA_blk0, Opt16Tail{});
-                VH_HIP(hipGetLastError());
-            });
-            h->opt16_decoder_done = true;
+        const bool dw_on_main_late = li == 1 && nl >= 2 && (q.plan & 2) != 0;
+        if (dw_on_main_late) {
+            late_dw = dw;
+            if (rm) late_spec = DwSpec{hl.tW, hl.DZ16.p, hl.nout_p, InT, in_p, colsum_in_gemm ? hl.dbias : nullptr};
         }
+        else if (li > 0) q.add(dw);
         if (li == nl && h->comm) {
             // data parallel: every decoder-side gradient is now queued -- materialise that bucket of the flat gradient and
             // all-reduce it on the side stream while the encoder's backward still runs on the main stream
@@ -711,13 +640,7 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         // C2 (profiles/r03w_*, r03zb_*, r03zc_*): these two 286 us per step; + the loss kernel 296; loss + LAST decoder layer +
         // encoder layer 1 299 against 297 on the box of that run.
         const bool fork = li == 2 * nl - 1 || li == 1 || (li == 0 && !q.items.empty()) ||
-                          (li == nl && nl >= 2 && (g_tuning.fork_plan & 1) != 0);
-        if (fuse) {
-            const bool ok = grad_input16(h, nullptr, hl.nout_p, hl.tW, in_p, h->hidden[li - 1], &hl, dc.scale, dc.scale != 1.0f, fork);
-            VH_REQUIRE(ok, "fused dZ: shape predicate and launcher disagree");
-            if (fork) q.flush(h->side);
-            return;
-        }
+                          (li == nl && nl >= 2 && (q.plan & 1) != 0);
         const dim3 grid((unsigned)ceil_div(hl.nout_p, kDz16Cols), (unsigned)ceil_div(bs_p, kDz16Rows));
         if (fork) {
             launch_forking(h, vae_dz16_kernel, grid, dim3(256), 0, a);
@@ -727,8 +650,11 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
             VH_HIP(hipGetLastError());
         }
         if (li == 0) {
-            dw(h->stream);
-            if (late_dw) late_dw(h->stream);
+            const DwSpec first{hl.tW, hl.DZ16.p, hl.nout_p, InT, in_p, colsum_in_gemm ? hl.dbias : nullptr};
+            if (!(rm && late_dw && grad_weight16_rm_pair(h, first, late_spec, h->stream))) {
+                dw(h->stream);
+                if (late_dw) late_dw(h->stream);
+            }
             if (late_dw_mu) late_dw_mu(h->stream);
         } else if (li == nl) {
             // first decoder layer -> latent: latent-wide output; dMU = dZlat + d(KLD)/dmu fused into the same launch when the
@@ -770,15 +696,10 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
                                h->dMU16.p, h->L_p, bs, bs_p);
             VH_HIP(hipGetLastError());
         }
-        auto dw_mu = [h, bs_p, bs, &enc_last](hipStream_t st) {
-            if (g_tuning.dw_row_major) {
-                grad_weight16_rm(h, h->tWmu, h->dMU16.p, h->L_p, enc_last.H16.p, enc_last.nout_p, h->dbias_mu, st);
-            } else {
-                transpose16(h, st, h->dMU16.p, bs_p, h->L_p, h->dMU16T.p, h->dbias_mu, bs);
-                grad_weight16(h, h->tWmu, h->dMU16T.p, h->L_p, enc_last.H16T.p, enc_last.nout_p, st);
-            }
+        auto dw_mu = [h, &enc_last](hipStream_t st) {
+            grad_weight16_rm(h, h->tWmu, h->dMU16.p, h->L_p, enc_last.H16.p, enc_last.nout_p, h->dbias_mu, st);
         };
-        if ((g_tuning.fork_plan & 8) && nl >= 2) late_dw_mu = dw_mu;   // (on the main stream, behind the first layer's)
+        if ((q.plan & 8) && nl >= 2) late_dw_mu = dw_mu;   // (on the main stream, behind the first layer's)
         else q.add(dw_mu);
         grad_input16(h, h->dMU16.p, h->L_p, h->tWmu, enc_last.nout_p, enc_last);
     }
@@ -798,9 +719,7 @@ void optimizer_step16(vh_vae* h) {
         rccl_allreduce_sum_f32(h->comm, h->G.p, h->opt16_bucketA_off, h->stream);
         tab = h->opt16_tab_flat.p;
     }
-    // (the decoder-side half may already have been updated on the side stream: backward16)
-    const int nblk = h->opt16_decoder_done ? h->opt16_bucketA_blk0 : h->opt16_blocks;
-    h->opt16_decoder_done = false;
+    const int nblk = h->opt16_blocks;
     // the scalar tail (d, k, counters, clearing the accumulators) rides on the last workgroup of the update kernel when ONE launch
     // covers every tensor of the step (vae.fused_finalize; the split / data-parallel schedules keep the separate launch)
     Opt16Tail tail{};
@@ -852,12 +771,11 @@ void gather_rows16(vh_vae* h, const int64_t* dev_idx, SideQueue& q) {
         });
         h->batch_prefetched = true;
     }
-    // round-2 dataflow only: transposed copy of the batch for the first layer's weight gradient (needed last)
-    if (!g_tuning.dw_row_major) q.add([h](hipStream_t st) { transpose16(h, st, h->Xb16.p, h->bs_p, h->D_p, h->Xb16T.p, nullptr, 0); });
 }
 
 void train_step16(vh_vae* h, const int64_t* dev_idx, bool eps_injected, bool masks_injected) {
     SideQueue q;
+    q.plan = fork_plan_for(h);
     gather_rows16(h, dev_idx, q);
     forward16(h, true, eps_injected, masks_injected, true, &q);
     loss_and_seed16(h, q);

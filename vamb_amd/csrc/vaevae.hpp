@@ -25,21 +25,10 @@
 // weights, see LossArgs::inv_b2) and the network's Adam kernel runs on the sum.
 //
 // Scheduling.  All seven handles share ONE stream pair (VAEVamb's) for the duration of a call: stream order is program order.
-// At the CLI's batch size (256) every kernel of a pass is a few microseconds on 4-32 workgroups, so the obvious next step was
-// tried in round 5 -- option vaevae.lanes = 1: every pass on its handle's OWN stream pair, the passes meeting only where the
-// step's dataflow says so (events, all recorded and awaited in vv_step):
-//     VAEJoint's latent code   -> the two decoder passes vamb_x / labels_x (ev_latent of the joint pass)
-//     d loss / d z of those two, mu of vamb_s / labels_s -> the KLD kernel on VAEJoint's stream -> the three encoder backwards
-//     every pass of a network  -> that network's running statistics (in the reference's order), gradient sum and Adam update,
-//                                 on the network's own stream; the three updates run side by side
-//     the three updates        -> the next step (ev_start on VAEVamb's stream)
-// Same results (tests/test_vaevae_gpu.py passes either way), but MEASURED SLOWER: 2.55 ms per step against 1.68 ms on the shared
-// pair (200 k x 50, 1000-node taxonomy, batch 256; profiles/r05h_taxvamb_lanes.txt) -- 14 HIP streams over the process's four
-// hardware queues: the kernel trace shows no kernel in flight 49 % of the time and two or more only 23 % of it (the runtime
-// pays for every cross-stream dependency with a signal and a barrier packet, and for every change of stream on the host);
-// GPU_MAX_HW_QUEUES=8 made it worse.  A TWO-lane variant (the chain joint / vamb_x / labels_x / vamb_s on one stream pair, the
-// rest on the other: four streams, one hardware queue each) measured 3.69 ms per step and faulted once in three runs
-// (profiles/r05k_taxvamb_two_lanes.txt); it was removed.  The option stays off; it is kept as the measured negative.
+// (Round 5 measured the obvious alternative -- every pass on its handle's OWN stream pair, the passes meeting through events
+// where the step's dataflow says so: 2.55 ms per step against 1.68 ms on the shared pair, 14 HIP streams over the process's
+// hardware queues; a two-lane variant 3.69 ms and one fault in three runs: profiles/r05h_taxvamb_lanes.txt, r05k_*.  Both were
+// removed in round 6; DESIGN.md section 4.8 keeps the numbers.)
 //
 // The Kullback-Leibler terms of calc_loss_joint: every logsigma in the reference is a zero tensor (:241, :507, :916, :922), so
 // kld_gauss(p, 0, q, 0) = 0.5 * mean((p - q)^2) over all batch x nlatent elements (taxvamb_encode.py:541-548).
@@ -152,17 +141,7 @@ struct vh_vaevae {
     int64_t n = 0;         // rows of the attached datasets (0: none)
     int kld_blocks = 0;
     bool entered = false;
-    bool lanes = false;                      // this call: one stream pair per pass (option vaevae.lanes)
-    hipStream_t saved[kVvPasses][2] = {};    // the handles' own stream pairs while a call borrows VAEVamb's (lanes off)
-    // cross-pass dependencies of one step (see the header); timing disabled
-    hipEvent_t ev_start = nullptr, ev_kld = nullptr;
-    hipEvent_t ev_latent[kVvPasses] = {}, ev_dz[kVvPasses] = {}, ev_done[kVvPasses] = {};
-
-    ~vh_vaevae() {
-        for (hipEvent_t e : {ev_start, ev_kld}) if (e) (void)hipEventDestroy(e);
-        for (int p = 0; p < kVvPasses; ++p)
-            for (hipEvent_t e : {ev_latent[p], ev_dz[p], ev_done[p]}) if (e) (void)hipEventDestroy(e);
-    }
+    hipStream_t saved[kVvPasses][2] = {};    // the handles' own stream pairs while a call borrows VAEVamb's
 
     vh_vae* pass(int p) {
         vh_vae* v[kVvPasses] = {joint, vamb_x.get(), labels_x.get(), vamb, vamb_s.get(), labels, labels_s.get()};
@@ -196,8 +175,8 @@ std::unique_ptr<vh_vae> vv_make_replica(vh_vae* m, uint64_t salt) {
     return r;
 }
 
-// Stream pairs for the duration of a call: every pass on its handle's own pair (lanes), or all seven on VAEVamb's; replicas
-// follow their network's taxonomy.
+// For the duration of a call all seven passes run on VAEVamb's stream pair (stream order is program order); replicas follow their
+// network's taxonomy.
 void vv_enter(vh_vaevae* t) {
     VH_REQUIRE(!t->entered, "trainer is busy");
     vh_vae* nets[3] = {t->vamb, t->labels, t->joint};
@@ -216,21 +195,14 @@ void vv_enter(vh_vaevae* t) {
         t->saved[p][0] = h->stream;
         t->saved[p][1] = h->side;
     }
-    t->lanes = option("vaevae.lanes", 0) == 1;
     t->entered = true;
     for (int p = 0; p < kVvPasses; ++p) {
         vh_vae* h = t->pass(p);
-        if (!t->lanes) {
-            h->stream = t->vamb->stream;
-            h->side = t->vamb->side;
-        }
+        h->stream = t->vamb->stream;
+        h->side = t->vamb->side;
         h->gwsum_src = nullptr;
         h->global_bs = 0;
         h->shuffle.key = 0ull;   // explicit row lists
-        // lanes: the trainer orders the running-statistics updates of a network's passes (vv_step); the mu of the joint, vamb_s
-        // and labels_s passes is awaited by other streams
-        h->defer_running = t->lanes;
-        h->ev_latent_hook = (t->lanes && (p == 0 || p == 4 || p == 6)) ? t->ev_latent[p] : nullptr;
     }
     for (vh_vae* r : {t->labels_x.get(), t->labels_s.get()}) {
         r->leaf_masks.borrow(t->labels->leaf_masks);
@@ -250,8 +222,6 @@ void vv_exit(vh_vaevae* t) {
         vh_vae* h = t->pass(p);
         h->stream = t->saved[p][0];
         h->side = t->saved[p][1];
-        h->defer_running = false;
-        h->ev_latent_hook = nullptr;
     }
     t->entered = false;
 }
@@ -269,41 +239,16 @@ void vv_prepare(vh_vaevae* t, int bs) {
     t->kld_part.ensure((size_t)t->kld_blocks * 2);
 }
 
-// every stream that takes part in a step has passed this point before VAEVamb's stream goes on (setup work -- uploads, counter
-// resets -- is enqueued on the handles' own streams)
-void vv_gather_lanes(vh_vaevae* t) {
-    hipStream_t s = t->vamb->stream;
-    for (int p = 0; p < kVvPasses; ++p) {
-        vh_vae* h = t->pass(p);
-        if (h->stream == s) continue;
-        VH_HIP(hipEventRecord(t->ev_done[p], h->stream));
-        VH_HIP(hipStreamWaitEvent(s, t->ev_done[p], 0));
-    }
-}
-
 // One batch of VAEVAE.trainepoch (semisupervised_encode.py:864-997): rows of the three datasets at the networks' batch cursor.
-// The host enqueues the passes in an order that is valid on one stream pair too (every event is recorded before it is awaited).
+// All passes share one stream pair: the order below is the order on the device.
 void vv_step(vh_vaevae* t, const int64_t* dev_idx, bool eps_inj, bool masks_inj) {
     enum { P_J = 0, P_VX = 1, P_LX = 2, P_V = 3, P_VS = 4, P_LB = 5, P_LS = 6 };
     vh_vae *J = t->joint, *V = t->vamb, *Lb = t->labels, *Vx = t->vamb_x.get(), *Vs = t->vamb_s.get(), *Lx = t->labels_x.get(),
            *Ls = t->labels_s.get();
-    hipStream_t s = V->stream;
-    const bool lanes = t->lanes;   // off: one stream pair, program order is stream order, no event is needed
-    auto after = [&](vh_vae* h, hipEvent_t e) { if (lanes) VH_HIP(hipStreamWaitEvent(h->stream, e, 0)); };
-    auto mark = [&](vh_vae* h, hipEvent_t e) { if (lanes) VH_HIP(hipEventRecord(e, h->stream)); };
-    auto running = [&](vh_vae* h, int part, vh_vae* net) { if (lanes) update_running(h, part, net->stream); };   // (off: forward() did it)
-    // the previous step's three updates are complete on s (end of this function): parameters, counters, cleared accumulators
-    mark(V, t->ev_start);
-    for (int p = 0; p < kVvPasses; ++p) {
-        vh_vae* h = t->pass(p);
-        if (h->stream != s) after(h, t->ev_start);
-        gather_rows(h, dev_idx);
-    }
+    for (int p = 0; p < kVvPasses; ++p) gather_rows(t->pass(p), dev_idx);
     // ---- the seven forward passes (each updates nothing but its own activations and batch sums)
-    forward(J, true, eps_inj, masks_inj, true);            // records ev_latent[P_J] behind its reparameterisation kernel
-    after(Vx, t->ev_latent[P_J]);
+    forward(J, true, eps_inj, masks_inj, true);
     forward(Vx, true, eps_inj, masks_inj, true, PASS_DECODER, J->MU.p, t->zero_bias.p);
-    after(Lx, t->ev_latent[P_J]);
     forward(Lx, true, eps_inj, masks_inj, true, PASS_DECODER, J->MU.p, t->zero_bias.p);
     forward(V, true, eps_inj, masks_inj, true);
     forward(Vs, true, eps_inj, masks_inj, true);
@@ -317,10 +262,8 @@ void vv_step(vh_vaevae* t, const int64_t* dev_idx, bool eps_inj, bool masks_inj)
     // kernel and VAEJoint's backward wait for, enqueued first
     loss_and_seed(Vx, 0.0f);
     backward(Vx, masks_inj, PASS_DECODER);
-    mark(Vx, t->ev_dz[P_VX]);
     loss_and_seed(Lx, 0.0f);
     backward(Lx, masks_inj, PASS_DECODER);
-    mark(Lx, t->ev_dz[P_LX]);
     // ---- VAEVamb.calc_loss / VAELabels.calc_loss on the unsupervised rows: the ordinary step's loss and backward
     loss_and_seed(V);
     backward(V, masks_inj);
@@ -329,31 +272,19 @@ void vv_step(vh_vaevae* t, const int64_t* dev_idx, bool eps_inj, bool masks_inj)
     // ---- ... and the two kld_gauss terms, which tie VAEJoint's mu to the mu of the two *_s passes
     const int bs = J->bs;
     const float gk = (float)((double)V->kld_w / ((double)J->L * (double)bs * (double)bs));   // 1 / (VAEVamb.nlatent * VAEVamb.beta), taxvamb_encode.py:730
-    after(J, t->ev_dz[P_VX]);
-    after(J, t->ev_dz[P_LX]);
-    after(J, t->ev_latent[P_VS]);
-    after(J, t->ev_latent[P_LS]);
     hipLaunchKernelGGL(vv_kld_kernel, dim3((unsigned)t->kld_blocks), dim3(256), 0, J->stream, (const float*)J->MU.p,
                        (const float*)Vs->MU.p, (const float*)Ls->MU.p, (const float*)Vx->dMU.p, (const float*)Lx->dMU.p, gk, bs, J->L,
                        J->L_p, J->bs_p, J->dMUk.p, Vs->dMUk.p, Ls->dMUk.p, t->kld_part.p);
     VH_HIP(hipGetLastError());
-    mark(J, t->ev_kld);
     backward(J, masks_inj, PASS_ENCODER);
-    after(Vs, t->ev_kld);
     backward(Vs, masks_inj, PASS_ENCODER);
-    after(Ls, t->ev_kld);
     backward(Ls, masks_inj, PASS_ENCODER);
-    // (the decoder passes' loss reductions were joined into their streams by backward(): ev_dz covers Vx / Lx's StepState)
     hipLaunchKernelGGL(vv_joint_finalize_kernel, dim3(1), dim3(256), 0, J->stream, (const float*)t->kld_part.p, t->kld_blocks,
                        (const StepState*)Vx->state.p, (const StepState*)Lx->state.p, V->ce_w, V->sse_w, V->kld_w, bs, J->L,
                        t->jstate.p);
     VH_HIP(hipGetLastError());
     // ---- one gradient per network: every pass's slabs -> its flat buffer, the passes summed with their loss scales
-    for (int p : {P_VX, P_LX, P_VS, P_LS}) {
-        vh_vae* h = t->pass(p);
-        reduce(h);
-        mark(h, t->ev_done[p]);
-    }
+    for (int p : {P_VX, P_LX, P_VS, P_LS}) reduce(t->pass(p));
     auto combine = [&](vh_vae* net, VvSource a, VvSource b, VvSource c) {
         const int64_t n = (int64_t)net->flat_elems;
         hipLaunchKernelGGL(vv_combine_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, net->stream, net->G.p, n, a, b, c);
@@ -367,31 +298,16 @@ void vv_step(vh_vaevae* t, const int64_t* dev_idx, bool eps_inj, bool masks_inj)
     // (per-element: three launches are one optimiser).  The update's finalize kernel clears the network handle's batch sums, so
     // the running statistics go first.
     reduce(J);
-    running(J, PASS_FULL, J);
     combine(J, VvSource{J->G.p, w_sup, 0, split_of(J)}, none, none);
     optimizer_step(J, true);
     reduce(V);
-    after(V, t->ev_done[P_VX]);
-    after(V, t->ev_done[P_VS]);
-    running(Vx, PASS_DECODER, V);
-    running(V, PASS_FULL, V);
-    running(Vs, PASS_FULL, V);
     combine(V, VvSource{V->G.p, &V->state.p->wsum, 0, (int64_t)V->flat_elems},
             VvSource{Vx->G.p, w_sup, split_of(V), (int64_t)V->flat_elems}, VvSource{Vs->G.p, w_sup, 0, split_of(V)});
     optimizer_step(V, true);
     reduce(Lb);
-    after(Lb, t->ev_dz[P_VX]);    // w_sup
-    after(Lb, t->ev_done[P_LX]);
-    after(Lb, t->ev_done[P_LS]);
-    running(Lx, PASS_DECODER, Lb);
-    running(Lb, PASS_FULL, Lb);
-    running(Ls, PASS_FULL, Lb);
     combine(Lb, VvSource{Lb->G.p, &Lb->state.p->wsum, 0, (int64_t)Lb->flat_elems},
             VvSource{Lx->G.p, w_sup, split_of(Lb), (int64_t)Lb->flat_elems}, VvSource{Ls->G.p, w_sup, 0, split_of(Lb)});
     optimizer_step(Lb, true);
-    // the step is complete when VAEVamb's stream is: the other two updates join it (the four replica passes already did)
-    if (J->stream != s) { mark(J, t->ev_done[P_J]); after(V, t->ev_done[P_J]); }
-    if (Lb->stream != s) { mark(Lb, t->ev_done[P_LB]); after(V, t->ev_done[P_LB]); }
     // BatchNorm1d.num_batches_tracked: one per training-mode forward of the layer
     for (vh_vae* m : {V, Lb})
         for (int li = 0; li < 2 * m->nl; ++li) m->hidden[li].batches_tracked += li < m->nl ? 2 : 3;
@@ -458,13 +374,6 @@ int vh_vaevae_create(vh_vae* vamb, vh_vae* labels, vh_vae* joint, vh_vaevae** ou
         VH_HIP(hipMemset(t->zero_bias.p, 0, t->zero_bias.bytes()));
         t->jstate.alloc(1);
         VH_HIP(hipMemset(t->jstate.p, 0, sizeof(JointState)));
-        VH_HIP(hipEventCreateWithFlags(&t->ev_start, hipEventDisableTiming));
-        VH_HIP(hipEventCreateWithFlags(&t->ev_kld, hipEventDisableTiming));
-        for (int p = 0; p < kVvPasses; ++p) {
-            VH_HIP(hipEventCreateWithFlags(&t->ev_latent[p], hipEventDisableTiming));
-            VH_HIP(hipEventCreateWithFlags(&t->ev_dz[p], hipEventDisableTiming));
-            VH_HIP(hipEventCreateWithFlags(&t->ev_done[p], hipEventDisableTiming));
-        }
         *out = t.release();
     });
 }
@@ -553,7 +462,6 @@ int vh_vaevae_train_step(vh_vaevae* t, const int64_t* rows, int64_t batch, const
             }
         }
         vv_reset_epoch(t);
-        vv_gather_lanes(t);
         for (int p = 0; p < kVvPasses; ++p) t->pass(p)->keep_grads = true;
         vv_step(t, t->perm.p, eps != nullptr, masks != nullptr && drop);
         for (int p = 0; p < kVvPasses; ++p) t->pass(p)->keep_grads = false;
@@ -587,7 +495,6 @@ int vh_vaevae_train_epoch(vh_vaevae* t, const int64_t* rows, int64_t n_batches, 
         VH_REQUIRE(bad == -1, "row %lld out of range", (long long)bad);
         VH_HIP(hipMemcpyAsync(t->perm.p, t->h_perm.p, sizeof(int64_t) * total, hipMemcpyHostToDevice, s));
         vv_reset_epoch(t);
-        vv_gather_lanes(t);
         for (int64_t b = 0; b < n_batches; ++b) vv_step(t, t->perm.p, false, false);
         VH_HIP(hipStreamSynchronize(s));
         if (metrics) vv_metrics(t, true, n_batches, batch, metrics);
