@@ -13,6 +13,8 @@ def short(n):
 # a step ends with the optimiser's scalar tail; the row after it starts the next step.  (Until round 5 the batch gather marked
 # the start of a step; with vae.prefetch_batch it runs on the side stream in the MIDDLE of the step before the one it feeds.)
 ends = [i for i, n in enumerate(names) if 'vae_dadapt_finalize' in n]
+if len(ends) < 8:   # (round 6: the tail rides on the last workgroup of the update kernel -- vae.fused_finalize -- which then ends a step)
+    ends = [i for i, n in enumerate(names) if 'vae_dadapt16_kernel' in n]
 idx = [i + 1 for i in ends[:-1]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 if any('vae_gather' in n for n in names[idx[k]:idx[k] + 2]) and k + 1 < len(idx) - 1:

@@ -161,7 +161,10 @@ __device__ __forceinline__ void gemm16_stamp(const Gemm16Args& g, int slot) {
 //       it (~17-27 clk per 1 KiB piece, 32 pieces per tile and CU), all waves run in lockstep, so "issue 4 pieces, then
 //       12 ds_reads + 8 MFMAs, then drain" is a DMA phase FOLLOWED by a matrix phase.  Spreading the pieces over the MFMA
 //       groups puts the issue stalls under matrix-pipe time, and the third buffer takes the landing latency off the barrier.
-template <int BM, int BN, int WM, int WN, int EPI, int STG = 0>
+// TAG: no effect on the code -- a launch site that wants its own line in a kernel trace instantiates its own copy (the K = D
+// encoder GEMM of the training step, the roofline kernel of bench.py: TAG 1; until round 6 it shared one name with the three
+// other hidden-layer launches of a step and rocprofv3 --stats could only average over the four).
+template <int BM, int BN, int WM, int WN, int EPI, int STG = 0, int TAG = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Args g) {
     constexpr int NWAVE = WM * WN;
     constexpr int NT = NWAVE * 64;

@@ -188,17 +188,20 @@ struct VaeTuning {
     bool fused_skinny = true; // vae.fused_skinny: bf16 step: the two latent-wide products (mu, the first decoder layer's input gradient) and
                               // their elementwise consumers (reparameterisation, latent backward) as ONE launch each
                               // (gemm_skinny16.hpp) instead of split-K launch + slab-summing kernel.  Same bits.
-    bool fused_finalize = true;  // (round 6: ON, behind two levels of arrival tickets -- 237.1 vs 238.6 us per step at C2, neutral at the C3 shape, profiles/r06f_*; what follows is round 5's one-level measurement) vae.fused_finalize: bf16 step: d / k / counters / clearing of the fp64 accumulators by the LAST workgroup of
-                              // the update kernel (arrival ticket behind drained write-through stores) instead of a one-workgroup launch.
-                              // Bit-identical, measured SLOWER (C2: 272.5 vs 267.4 us per step, profiles/r05a_step_ab_c2.txt): ~1000
-                              // arrivals on one ticket word (the guide's dequeue row: one word saturates at ~88 atomics per us) cost more
-                              // than the 4.8 us launch they replace.  Off; kept as the measured negative.
-    int fork_plan = -1;       // (-1 = by input width, round 6: 2 up to 512 padded input columns, 6 above -- see fork_plan_for) vae.fork_plan (bf16 step, bit mask; the two-stream schedule; default 2 + 4, measured with fork_at_loss): 1 = one more fork at the first decoder
-                              // layer's BatchNorm-backward kernel (its weight gradient and the mu layer's start there instead of at encoder
-                              // layer 1); 2 = encoder layer 1's weight gradient on the MAIN stream behind layer 0's (the side stream's last
-                              // batch ends before the main stream does); 4 = running statistics + loss reduction at the END of the side
-                              // stream's work instead of in front of the first weight gradient; 8 = the mu layer's weight gradient on the main
-                              // stream as well
+    bool fused_finalize = true;  // vae.fused_finalize: bf16 step: d / k / counters / clearing of the fp64 accumulators by the LAST workgroup of the
+                              // update kernel (arrivals behind drained write-through stores, no fence) instead of a one-workgroup launch.
+                              // Bit-identical.  Round 5 measured it SLOWER with ONE arrival word (272.5 vs 267.4 us per step at C2: ~900
+                              // arrivals on a word that takes ~88 atomics per us); with two levels of words (32 groups, round 6) it is
+                              // 237.1 vs 238.6 us at C2 and neutral at the C3 shape (profiles/r06f_*): on.  The data-parallel schedule
+                              // keeps the separate launch.
+    int fork_plan = -1;       // vae.fork_plan: the two-stream schedule of the bf16 step, bit mask; -1 = by input width (fork_plan_for,
+                              // vae_step16.hpp: 2 up to 512 padded input columns, 6 above).  The side stream always starts at the loss
+                              // kernel and forks again at the top decoder layer's and encoder layer 1's BatchNorm backward.
+                              // 1 = one more fork at the first decoder layer (its weight gradient and the mu layer's start there instead
+                              // of at encoder layer 1); 2 = encoder layer 1's weight gradient on the MAIN stream with layer 0's (one paired
+                              // launch, vae.dw_pair); 4 = running statistics + loss reduction at the END of the side stream's work instead
+                              // of in front of its first weight gradient; 8 = the mu layer's weight gradient on the main stream as well;
+                              // 16 = no fork at the top decoder layer
     bool prefetch_batch = true; // vae.prefetch_batch: bf16 step: the gather of step t + 1 (10 MB read, 15 MB written at C2: 8.6 us on the
                               // critical path) runs on the side stream during step t, FIRST in the batch of work the loss-kernel fork hands
                               // over; the join in front of the optimiser -- already there -- covers it, so the main stream pays no extra

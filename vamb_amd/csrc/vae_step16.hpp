@@ -15,11 +15,11 @@ namespace step16 {
 
 constexpr int kDwTargetWgs = 256;   // workgroups wanted per weight-gradient GEMM (they share the chip with the dX chain)
 
-template <int BM, int BN, int WM, int WN, int EPI, int STG = 0>
+template <int BM, int BN, int WM, int WN, int EPI, int STG = 0, int TAG = 0>
 void launch_gemm16(hipStream_t stream, const Gemm16Args& g, int splits) {
     static bool attr_set = false;
     constexpr size_t smem = gemm16_smem_bytes<BM, BN, WM, WN, EPI, STG>();
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STG>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, STG, TAG>;
     if (!attr_set) {
         VH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kMaxDynLds));
@@ -361,7 +361,8 @@ void forward16(vh_vae* h, bool training, bool eps_injected, bool masks_injected,
             g.step_ptr = step_ptr(h);
             g.drop_mask = dc.injected ? hl.mask.p : nullptr; g.ld_mask = hl.nout_p;
             if (h->probe_on && li == h->probe_layer) { probe_arm(h); h->probe_flops = 2.0 * bs * (double)hl.nin * hl.nout; }
-            gemm16<E16_HIDDEN_TRAIN>(s, g, 1);
+            if (li == 0) launch_gemm16<128, 128, 2, 4, E16_HIDDEN_TRAIN, 2, 1>(s, g, 1);   // the K = D launch under its own name (TAG 1)
+            else gemm16<E16_HIDDEN_TRAIN>(s, g, 1);
             sync_stats(h, hl.fstat, hl.nout_p);
             prev = &hl;
         } else {
@@ -639,7 +640,8 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         // costs the main stream ~5 us before its next kernel (the producing kernel's completion signal).  Variants measured at
         // C2 (profiles/r03w_*, r03zb_*, r03zc_*): these two 286 us per step; + the loss kernel 296; loss + LAST decoder layer +
         // encoder layer 1 299 against 297 on the box of that run.
-        const bool fork = li == 2 * nl - 1 || li == 1 || (li == 0 && !q.items.empty()) ||
+        // (plan bit 16: NO fork at the top decoder layer -- its weight gradient waits for the fork at encoder layer 1)
+        const bool fork = (li == 2 * nl - 1 && (q.plan & 16) == 0) || li == 1 || (li == 0 && !q.items.empty()) ||
                           (li == nl && nl >= 2 && (q.plan & 1) != 0);
         const dim3 grid((unsigned)ceil_div(hl.nout_p, kDz16Cols), (unsigned)ceil_div(bs_p, kDz16Rows));
         if (fork) {
