@@ -105,7 +105,9 @@ def streams_equal(a, b, pvr_rtol=0.0):
     """Exact comparison of two packed streams; returns (ok, message).  pvr_rtol > 0 relaxes ONLY the reported
     `observed_pvr` (a ratio of smoothed histogram densities that the reference forms from torch.histogram's
     order-dependent float32 bin sums; with thousands of members per bin its last bit can differ from the correctly
-    rounded exact sum although every decision -- medoid, radius, members -- is identical)."""
+    rounded exact sum although every decision -- medoid, radius, members -- is identical).  Measured on the GPU over all
+    golden streams (profiles/r06n_pvr_deviation.txt): at most 1.5e-7 relative, 7 of 4 104 reported ratios not bit-identical,
+    round(pvr, 2) -- what the CLI writes -- never different; the GPU tests pass 1e-6."""
     for key in ("medoid", "seed", "kind", "successes", "attempts", "sizes", "members"):
         if a[key].shape != b[key].shape or not np.array_equal(a[key], b[key]):
             n = min(len(a[key]), len(b[key]))

@@ -148,7 +148,7 @@ def test_stream_matches_oracle_and_reference(oracle_lib, name):
                     "oracle comparison passed")
     # (reported observed_pvr only: a ratio of smoothed densities the reference forms from torch.histogram's order-dependent
     # float32 bin sums; the library's sums are the exact ones.  Every decision -- medoid, seed, radius, members -- is compared exactly.)
-    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-2)
+    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-6)
     assert ok, "vs reference golden: " + msg
 
 
@@ -267,7 +267,7 @@ def test_100k_stream_matches_reference_golden(name):
     assert _lib.get_option("scan.reference_order", 2) == 2
     got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
     assert len(got["medoid"]) == len(golden["medoid"]) == {"blob_s008_n100000": 500, "blob_s050_n100000": 31583}[name]
-    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-2)
+    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-6)
     assert ok, "vs the reference's golden stream: " + msg
 
 
@@ -295,7 +295,7 @@ def test_100k_stream_python_state_machine(monkeypatch):
     name = "blob_s008_n100000"
     mat, lens, kw = fd.cluster_inputs(name)
     got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
-    ok, msg = fd.streams_equal(got, fd.load("cluster_" + name), pvr_rtol=1e-2)
+    ok, msg = fd.streams_equal(got, fd.load("cluster_" + name), pvr_rtol=1e-6)
     assert ok, msg
 
 
@@ -365,7 +365,7 @@ def test_one_rank_sharded_backend_stream_matches_golden(name):
     order_hash = hashlib.sha256(np.argsort(lens)[::-1].astype(np.int64).tobytes()).hexdigest()
     if str(golden["order_sha256"]) != order_hash:
         pytest.skip("np.argsort tie order differs on this CPU (unstable sort, cluster.py:275)")
-    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-2)
+    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-6)
     assert ok, msg
 
 
@@ -496,7 +496,7 @@ def test_plain_kernel_stream_equals_the_reference(monkeypatch, name):
     if "order_sha256" in golden and str(golden["order_sha256"]) != order_hash:
         pytest.skip("np.argsort tie order differs on this CPU (unstable sort, cluster.py:275)")
     got = fd.pack_stream(list(vc.ClusterGenerator(mat.copy(), lens, **kw)))
-    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-2)
+    ok, msg = fd.streams_equal(got, golden, pvr_rtol=1e-6)
     assert ok, "vs the reference's golden stream: " + msg
 
 

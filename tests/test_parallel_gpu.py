@@ -29,7 +29,7 @@ def _sharded_cluster_hip(comm):
         gen = parallel.sharded_cluster_generator(comm, mat[lo:hi].copy(), lens[lo:hi], **kw)   # default factory: HipScanBackend
         assert type(gen._backend.local).__name__ == "HipScanBackend"
         got = fd.pack_stream(list(gen))
-        out[name] = fd.streams_equal(got, fd.load("cluster_" + name), pvr_rtol=1e-2)
+        out[name] = fd.streams_equal(got, fd.load("cluster_" + name), pvr_rtol=1e-6)
         gen._backend.local.close()
     return out
 
@@ -60,7 +60,7 @@ def _sharded_cluster_native(comm_control):
         gen = parallel.sharded_cluster_generator(comm, mat[lo:hi].copy(), lens[lo:hi], **kw)
         assert gen._sharded_native and gen._gen is not None
         got = fd.pack_stream(list(gen))
-        out[name] = fd.streams_equal(got, fd.load("cluster_" + name), pvr_rtol=1e-2)
+        out[name] = fd.streams_equal(got, fd.load("cluster_" + name), pvr_rtol=1e-6)
         gen._backend.local.close()
     comm.close()
     return out

@@ -118,17 +118,23 @@ int g_gemm_prefetch = 4;
 int g_gemm_kgroups = 4;
 // ... and those that would be at most 128 workgroups of 64 x 64 take 32 x 32 tiles with four wavefront groups over the K range
 // (gemm.hpp, KS = 4; option vae.gemm_kgroups), each group with its four K-tiles in flight
+// the PF / KS tiles fetch row-contiguous operands as clamped 16-byte quads (gemm.hpp asm_load_x4): a row count that is not a
+// multiple of 4 would shift the last quad while the keep mask still takes it, and the loads need 16-byte aligned rows
+bool quad_operands(const GemmArgs& g) {
+    return g.M >= 4 && g.N >= 4 && g.M % 4 == 0 && g.N % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
+}
 bool k_groups(const GemmArgs& g, int splits) {
     if (g_gemm_kgroups != 4 || g_gemm_prefetch != 4 || g.bf16) return false;
     const int64_t wgs64 = ceil_div(g.M, 64) * ceil_div(g.N, 64) * splits;
     const int kp = g.k_per_split;
-    return wgs64 <= 128 && kp % 512 == 0 && (int64_t)kp * splits == g.K && g.M >= 4 && g.N >= 4;
+    return wgs64 <= 128 && kp % 512 == 0 && (int64_t)kp * splits == g.K && quad_operands(g);
 }
 bool deep_prefetch(const GemmArgs& g, int bm, int bn, int splits) {
     if (g_gemm_prefetch != 4 || g.bf16) return false;
     const int64_t wgs = ceil_div(g.M, bm) * ceil_div(g.N, bn) * splits;
     const int kp = g.k_per_split;
-    return wgs <= 256 && kp % 128 == 0 && kp >= 256 && (int64_t)kp * splits == g.K && g.M >= 4 && g.N >= 4;
+    return wgs <= 256 && kp % 128 == 0 && kp >= 256 && (int64_t)kp * splits == g.K && quad_operands(g);
 }
 
 // (64-wide K-tiles for the forward GEMMs of the step -- tile 4 of vh_debug_gemm -- measured +4-7 % for an isolated GEMM
@@ -2328,9 +2334,13 @@ int vh_debug_gemm16(int epi, const float* A, const float* B, const float* bias, 
         g.bias = dbias.p; g.m_real = M; g.fstat_out = dstat.p; g.drop_scale = 1.0f; g.xcd_remap = 1;
         const int tile = variant & 0xFF;
         g.dbg = variant >> 8;
+        if (g.dbg & 32) {   // timing of the training epilogue as the step runs it: hashed dropout, p = 0.2 (values then differ from the host's)
+            g.drop_scale = 1.25f; g.drop_thresh = (uint32_t)(0.2 * 4294967296.0); g.drop_key = 0x1234567ull;
+            g.dbg &= ~32;
+        }
         VH_REQUIRE(tile == 0 || tile == 1 || tile == 3 || tile == 4 || tile == 7 || tile == 11 || tile == 13 || tile == 17 ||
-                       tile == 21 || tile == 23 || tile == 27,
-                   "variant: tile 0, 1, 3, 4, 7; 11, 13, 17 (register-staged); 21, 23, 27 (interleaved DMA) (+ 256 * timing-experiment flags)");
+                       tile == 21 || tile == 23 || tile == 24 || tile == 27 || tile == 28,
+                   "variant: tile 0, 1, 3, 4, 7; 11, 13, 17 (register-staged); 21, 23, 24, 27, 28 (interleaved DMA) (+ 256 * timing-experiment flags)");
         auto run = [&] {
             if (epi == E16_SPLITK) step16::gemm16_variant<E16_SPLITK>(s, tile, g, nsplit);
             else if (epi == E16_BIAS) step16::gemm16_variant<E16_BIAS>(s, tile, g, 1);

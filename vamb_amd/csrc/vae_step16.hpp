@@ -145,6 +145,12 @@ void gemm16_variant(hipStream_t s, int tile, const Gemm16Args& g, int splits) {
         case 17: launch_gemm16<128, 128, 2, 2, EPI, 1>(s, g, splits); break;
         case 21: launch_gemm16<128, 128, 2, 4, EPI, 2>(s, g, splits); break;   // interleaved DMA, three buffers
         case 23: launch_gemm16<64, 128, 2, 2, EPI, 2>(s, g, splits); break;
+        // round 6: tiles of 72 KB (three buffers) -- TWO workgroups per CU, one's prologue / epilogue under the
+        // other's K loop.  8192 x 512 x 320 with the training epilogue: 9.82 us against 10.38 (variant 21), equal at K = 512, 22.2
+        // against 18.6 us at K = 1120 (profiles/r06l_gemm16_twowg.txt); inside the step the K = D launch on tile 24 measured
+        // 242.8 against 241.3 us per step (profiles/r06n_step_fold_narrow_c2.txt): not wired into the step
+        case 24: launch_gemm16<128, 64, 2, 2, EPI, 2>(s, g, splits); break;   // 4 waves of 64 x 32
+        case 28: launch_gemm16<128, 64, 4, 2, EPI, 2>(s, g, splits); break;   // 8 waves of 32 x 32 (16 waves per CU)
         case 27: launch_gemm16<128, 128, 2, 2, EPI, 2>(s, g, splits); break;
         default: gemm16<EPI>(s, g, splits); break;
     }

@@ -536,9 +536,14 @@ class VAEVAE(object):
     def _require_adam(self, optimizer=None) -> None:
         """trainepoch / train_batch called before trainmodel: the reference takes the optimiser as an argument (its learning rate
         is what counts: the Adam state lives in the native handles), so use it -- or say clearly what is missing."""
-        if getattr(self, "_adam_lrate", None) is not None:
-            return
         groups = getattr(optimizer, "param_groups", None)
+        current = getattr(self, "_adam_lrate", None)
+        if current is not None:
+            # an optimiser passed to trainepoch steps with ITS learning rate (semisupervised_encode.py:829-997); the moments
+            # the native handles hold are kept
+            if groups and float(groups[0]["lr"]) != current:
+                self._set_adam(float(groups[0]["lr"]), reset=False)
+            return
         if groups:
             self._set_adam(float(groups[0]["lr"]), reset=True)
             return
