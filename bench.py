@@ -729,7 +729,8 @@ def main():
                 "cluster": ("ONE latent matrix row-sharded over the ranks, the native sharded state machine (vh_gen_create_sharded): "
                             "every rank scans its shard, one all-gather of exact integer accumulators + list parts per pass"
                             if strong else "shard-local sweeps (weak scaling: N independent datasets)"),
-                "n1_reference": ("the c3_shape object of the N = 1 line is this workload on one GPU" if cfg_name == "C3" and strong
+                "n1_reference": ("the c3_shape object of the N = 1 line is this workload on one GPU: compare this line's `value` with that "
+                                 "object's `value`, not with the N = 1 line's `value` (C2, another workload)" if cfg_name == "C3" and strong
                                  else None)},
             "make_dataloader": None if strong else {
                 "seconds": prep_s, "on": "device" if prep_on_device else "host",

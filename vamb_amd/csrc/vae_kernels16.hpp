@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // ---- elementwise backward of one hidden layer, bf16 in / out ---------------------------------------------------------
 //   dZ = keep * slope(h) * drop_scale * istd*gamma * (dA - S1/B - xhat * S2/B)      (see vae_dz_kernel)
 // reads dA16, H16 [bs_p][n_p]; writes dZ16 [bs_p][n_p] and accumulates the fp64 column sums of dZ (bias gradient).  A
-// workgroup owns 64 rows x 128 columns.
+// workgroup owns kDz16Rows rows x kDz16Cols columns.
 struct Dz16Args {
     const bf16_t* DA;
     const bf16_t* H;
@@ -355,23 +355,34 @@ struct Dz16Args {
 };
 // (Two register-transposing variants without LDS -- a thread owning an 8 x 8 block, 128 x 128 tiles with 4 waves or
 // 64 x 64 tiles with one wave -- measured 18 and 37 us against 13.7 us for this kernel at 8192 x 512: profiles/README.md.)
-constexpr int kDz16Cols = 128;
-constexpr int kDz16Rows = 64;   // (32-row tiles, twice the workgroups: the same 12.1 us per launch at C2, profiles/r03zg_*)
+// Tile of a workgroup, measured as step time at C2 / the C3 shape on one box (round 6, profiles/r06o_step_dz_tile_*.txt,
+// r06p_step_dz_tile_*.txt; us per step):   128 x 64 (rounds 3-5) 245.8 / 343.1    64 x 128  241.6 / 339.8    64 x 64  245.6
+//   128 x 32  254.6 / 342.8    256 x 32  256.7 / 346.8    256 x 64  259.6 / 343.0    128 x 128  257.4    512 x 32  271.0 / 354.7
+//   512 x 16  283.9    32 x 128  249.5 / 345.6    32 x 256  249.3 / 346.7    64 x 256  256.8 / 345.2    16 x 256  270.3 / 367.0
+// One 128-byte line of each tensor per row and workgroup, and the taller the tile the fewer fp64 atomics meet on a column of
+// the bias gradient (8192 rows: 64 per column instead of 128) -- until the grid falls under two workgroups per CU.
+constexpr int kDz16Cols = 64;
+constexpr int kDz16Rows = 128;
 
+// COLS x ROWS elements per workgroup of 256 threads: a thread owns 8 consecutive columns, COLS / 8 threads share a row
+template <int COLS, int ROWS>
 __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
-    __shared__ float red[16][kDz16Cols];
-    __shared__ float cf[3][kDz16Cols];
+    constexpr int TPR = COLS / 8;        // threads per row
+    constexpr int RP = 256 / TPR;        // rows per pass of the workgroup
+    constexpr int PASS = ROWS / RP;
+    static_assert(COLS % 8 == 0 && 256 % TPR == 0 && ROWS % RP == 0 && PASS >= 1, "tile layout");
+    __shared__ float red[RP][COLS];
+    __shared__ float cf[3][COLS];
     const int tid = threadIdx.x;
-    const int col0 = blockIdx.x * kDz16Cols, row0 = blockIdx.y * kDz16Rows;
-    const int c8 = (tid & 15) * 8;          // this thread's 8 columns inside the tile
-    const int rt = tid >> 4;                // row lane 0..15
+    const int col0 = blockIdx.x * COLS, row0 = blockIdx.y * ROWS;
+    const int c8 = (tid % TPR) * 8;         // this thread's 8 columns inside the tile
+    const int rt = tid / TPR;               // row lane
     const int col = col0 + c8;
     // the thread's 16-byte loads go out first; the per-column coefficients (fp64 statistics) are formed underneath them
-    constexpr int PASS = kDz16Rows / 16;
     uint4 da[PASS], hh[PASS];
 #pragma unroll
     for (int p = 0; p < PASS; ++p) {
-        const int r = row0 + rt + 16 * p;
+        const int r = row0 + rt + RP * p;
         da[p] = make_uint4(0, 0, 0, 0);
         hh[p] = da[p];
         if (r < a.bs && col < a.n_p) {
@@ -380,14 +391,14 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
             hh[p] = *reinterpret_cast<const uint4*>(a.H + i);
         }
     }
-    if (tid < kDz16Cols) {
-        const int colc = col0 + tid;
+    for (int t = tid; t < COLS; t += 256) {
+        const int colc = col0 + t;
         float ca = 0.f, ch = 0.f, c0 = 0.f;
         if (colc < a.n_p) {   // (a.mean / a.istd: the floats the forward fold left -- the same bn_column forms)
             const DzCoefSrc src{a.mean, a.istd, a.bn.gamma, a.bstat, a.n_p, a.bn.bs, a.drop_scale};
             dz16_coeffs(src, colc, ca, ch, c0);
         }
-        cf[0][tid] = ca; cf[1][tid] = ch; cf[2][tid] = c0;
+        cf[0][t] = ca; cf[1][t] = ch; cf[2][t] = c0;
     }
     __syncthreads();
     const bool hashed_drop = (a.drop_scale != 1.0f) && (a.drop_mask == nullptr);
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
     for (int e = 0; e < 8; ++e) { ca[e] = cf[0][c8 + e]; ch[e] = cf[1][c8 + e]; c0[e] = cf[2][c8 + e]; s[e] = 0.f; }
 #pragma unroll
     for (int p = 0; p < PASS; ++p) {
-        const int rl = rt + 16 * p, r = row0 + rl;
+        const int rl = rt + RP * p, r = row0 + rl;
         const uint32_t dw[4] = {da[p].x, da[p].y, da[p].z, da[p].w};
         const uint32_t hw[4] = {hh[p].x, hh[p].y, hh[p].z, hh[p].w};
         uint32_t ow[4] = {0, 0, 0, 0};
@@ -421,12 +432,14 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
         for (int e = 0; e < 8; ++e) red[rt][c8 + e] = s[e];
     }
     if (a.dbias) __syncthreads();   // (kernel-argument uniform)
-    if (a.dbias && tid < kDz16Cols) {
-        const int c = col0 + tid;
-        float t = 0.f;
+    if (a.dbias) {
+        for (int t = tid; t < COLS; t += 256) {
+            const int c = col0 + t;
+            float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t += red[i][tid];
-        if (c < a.n_p) atomicAdd(&a.dbias[c], (double)t);
+            for (int i = 0; i < RP; ++i) acc += red[i][t];
+            if (c < a.n_p) atomicAdd(&a.dbias[c], (double)acc);
+        }
     }
 }
 

@@ -649,14 +649,17 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
         // (plan bit 16: NO fork at the top decoder layer -- its weight gradient waits for the fork at encoder layer 1)
         const bool fork = (li == 2 * nl - 1 && (q.plan & 16) == 0) || li == 1 || (li == 0 && !q.items.empty()) ||
                           (li == nl && nl >= 2 && (q.plan & 1) != 0);
-        const dim3 grid((unsigned)ceil_div(hl.nout_p, kDz16Cols), (unsigned)ceil_div(bs_p, kDz16Rows));
-        if (fork) {
-            launch_forking(h, vae_dz16_kernel, grid, dim3(256), 0, a);
-            q.flush(h->side);
-        } else {
-            hipLaunchKernelGGL(vae_dz16_kernel, grid, dim3(256), 0, h->stream, a);
-            VH_HIP(hipGetLastError());
-        }
+        auto launch_dz = [&](auto kern, int cols, int rows) {
+            const dim3 grid((unsigned)ceil_div(hl.nout_p, cols), (unsigned)ceil_div(bs_p, rows));
+            if (fork) {
+                launch_forking(h, kern, grid, dim3(256), 0, a);
+                q.flush(h->side);
+            } else {
+                hipLaunchKernelGGL(kern, grid, dim3(256), 0, h->stream, a);
+                VH_HIP(hipGetLastError());
+            }
+        };
+        launch_dz(vae_dz16_kernel<kDz16Cols, kDz16Rows>, kDz16Cols, kDz16Rows);
         if (li == 0) {
             const DwSpec first{hl.tW, hl.DZ16.p, hl.nout_p, InT, in_p, colsum_in_gemm ? hl.dbias : nullptr};
             if (!(rm && late_dw && grad_weight16_rm_pair(h, first, late_spec, h->stream))) {
