@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvambhip.so")
+# (VAMBHIP_LIB_PATH: another build of the same ABI, for same-box A/B runs of two library builds -- tools/gpu)
+LIB_PATH = os.environ.get("VAMBHIP_LIB_PATH") or os.path.join(_HERE, "libvambhip.so")
 NBINS = 60
 DENSITY_SCALE = 65536.0
 HIST_SCALE = 256.0

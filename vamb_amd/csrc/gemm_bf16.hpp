@@ -126,6 +126,16 @@ __device__ __forceinline__ bf16_t f2bf(float x) {
     return __builtin_bit_cast(unsigned short, b);
 }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((uint32_t)b << 16); }
+// two floats -> one dword of two bf16 (lo in bits 0-15), round to nearest even: ONE v_cvt_pk_bf16_f32.  (Written as two scalar
+// conversions + shift + or, the compiler pairs the conversions of elements 0 / 2 and 1 / 3 of a quad and re-pairs the halves with
+// four more instructions per quad: found in the ISA of the training epilogue, round 6.)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    const f32x2_t f = {lo, hi};
+    const bf16x2_t b = __builtin_convertvector(f, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, b);
+}
 
 // slot permutation of the [rows][64 bf16] LDS image (8 slots of 16 B per 128-byte row)
 __device__ __forceinline__ int swz16(int row) { return ((row >> 1) ^ (row >> 4)) & 7; }
@@ -559,10 +569,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                     rng = hash_drop(key, (uint32_t)(by * (int)gridDim.x + bx) * NT + tid) | 1u;
                 }
             }
+            // the dropout stream of a lane: seeded once per launch by the counter hash, then x += x << 13; x ^= x >> 17; x += x << 5
+            // per 32 bits (two odd multiplications around a xor-shift: 4 full-rate instructions; the xorshift32 of rounds 3-5 took 6).
+            // A lane draws 16 words per launch from a hashed seed -- checked on 4 M seeds: rate 0.2 +- 4e-4 at every position,
+            // no correlation above 4 sigma between successive draws, adjacent lanes or distant positions (same as xorshift32).
+            // (the empty asm keeps the compiler from folding the last shift-add of one draw and the first of the next into one
+            // quarter-rate v_mul_lo_u32 by 0x42021)
+            auto draw = [&]() { rng += rng << 13; rng ^= rng >> 17; rng += rng << 5; asm volatile("" : "+v"(rng)); return rng; };
+            // HASHED chosen once per workgroup (tested inside the loops it cost a scalar branch per quad)
+            auto phase_lean = [&](auto hashed_c) {
+                constexpr bool HASHED = decltype(hashed_c)::value;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int cl = (wn * TN + j) * 32 + frag_r;
                 const float bias = bias_pre[j], sc = sc_pre[j], sh = sh_pre[j];   // loaded in the prologue
+                // drop_scale * leaky_relu(acc + bias) = max of two fused multiply-adds on the accumulator (round 6: one instruction
+                // per element fewer than add + two multiplies)
+                [[maybe_unused]] const float ba = bias * dsa, bb = bias * dsb;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -572,15 +595,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
                         if constexpr (EPI == E16_HIDDEN_TRAIN) {
                             uint32_t r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
-                            if (hashed) {   // uniform; two 32-bit draws = four 16-bit uniforms
-                                rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; r0 = rng;
-                                rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; r1 = rng;
+                            if constexpr (HASHED) {   // two 32-bit draws = four 16-bit uniforms
+                                r0 = draw();
+                                r1 = draw();
                             }
                             const uint32_t u[4] = {r0 & 0xFFFFu, r0 >> 16, r1 & 0xFFFFu, r1 >> 16};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float x = v[e] + bias;
-                                float y = fmaxf(x * dsa, x * dsb);       // drop_scale * leaky_relu(x)
+                                float y;
+                                if constexpr (HASHED) {
+                                    y = fmaxf(__builtin_fmaf(v[e], dsa, ba), __builtin_fmaf(v[e], dsb, bb));
+                                } else {   // no dropout (drop_scale 1): the arithmetic of the general epilogue, bit for bit
+                                    const float x = v[e] + bias;
+                                    y = fmaxf(x * dsa, x * dsb);
+                                }
                                 y = u[e] >= thresh16 ? y : 0.f;
                                 s1[j] += y;
                                 s2[j] = fmaf(y, y, s2[j]);
@@ -595,11 +623,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const Gemm16Arg
                         }
                         const int rl4 = (wm * TM + i) * 32 + 8 * q + 4 * frag_h;
                         uint2 w;
-                        w.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                        w.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                        w.x = pack2bf(v[0], v[1]);
+                        w.y = pack2bf(v[2], v[3]);
                         *reinterpret_cast<uint2*>(img + cl * IP + rl4) = w;
                     }
             }
+            };
+            if (hashed) phase_lean(std::true_type{});
+            else phase_lean(std::false_type{});
             if constexpr (EPI == E16_HIDDEN_TRAIN) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
