@@ -64,7 +64,8 @@ const char* vh_version(void);
  *   vae.dw_pair (1)        the last two weight gradients of a step as one launch;  vae.fused_skinny (1)  latent-wide products with
  *                          their elementwise consumer in one launch;  vae.fused_finalize (1)  the optimiser's scalar tail on the last
  *                          workgroup of the update kernel;  vae.prefetch_batch (1), vae.prefetch_max_cols (512)  the next batch
- *                          assembled during the running step;  vae.loss_from_dataset (1)  loss targets read from the dataset rows
+ *                          assembled during the running step;  vae.loss_from_dataset (1)  loss targets read from the dataset rows;
+ *                          vae.loss_registers (1)  the bf16 loss kernel holds its rows in registers (0: staged in LDS; same bits)
  *   vae.gemm_prefetch (4), vae.gemm_kgroups (4)   fp32 GEMM: four K-tiles in flight / four K groups per workgroup for small launches
  *                          (1 = the plain tile: the self-test's fallback)
  *   vae.big_tiles (0), vae.xcd_remap (1), vae.dw_workgroups (256), vae.debug_timing (0)

@@ -626,6 +626,35 @@ def test_fused_latent_kernels_are_bit_identical(nhiddens, nlatent, monkeypatch):
     assert np.isfinite(la).all() and la.std() > 1e-3
 
 
+@pytest.mark.parametrize("S,bs", [(6, 512), (200, 1024), (420, 384), (1000, 256)])
+def test_loss_kernel_in_registers_matches_the_staged_one(S, bs, monkeypatch):
+    """vae_loss16_reg_kernel (round 6; reference: calc_loss, vamb/encode.py:316-357 and its backward): the bf16 step's loss kernel
+    with a wavefront's reconstruction and target rows in registers instead of an LDS staging area.  Same per-lane summation
+    order and the same reductions: every element of dR -- hence every gradient and every parameter after training -- is
+    bit-identical to the staged kernel's; of the reported means only the TNF sum of squares is grouped differently (last float
+    digit).  Input widths that take the 4- / 6- / 8- / 18-value instantiations."""
+    monkeypatch.setenv("VAMBHIP_PRECISION", "bf16")
+    n = 2 * bs + 100
+    ab, tnf, lens, _ = synth.features(n, S, seed=29)
+    out = []
+    for reg in ("1", "0"):
+        monkeypatch.setenv("VAMBHIP_VAE_LOSS_REGISTERS", reg)
+        dl = ve.make_dataloader(ab.copy(), tnf.copy(), lens, batchsize=bs, destroy=True)
+        vae = ve.VAE(S, seed=3)
+        vae._ensure_dataset(dl)
+        first = np.asarray(vae.train_batch(np.arange(bs)), np.float64)
+        vae.trainmodel(dl, nepochs=2, batchsteps=None)
+        out.append((first, {k: v.numpy().copy() for k, v in vae.state_dict().items()}, vae.optimizer_state(), vae.encode(dl)))
+    monkeypatch.delenv("VAMBHIP_VAE_LOSS_REGISTERS", raising=False)
+    (l1, p1, o1, z1), (l0, p0, o0, z0) = out
+    assert l1[1] == l0[1] and l1[2] == l0[2] and l1[4] == l0[4]          # abundance total, cross-entropy, KLD: same bits
+    assert abs(l1[3] - l0[3]) <= 2e-6 * abs(l0[3]) and abs(l1[0] - l0[0]) <= 2e-6 * abs(l0[0])
+    assert o1 == o0
+    for k in p0:
+        assert np.array_equal(p1[k], p0[k]), k
+    assert np.array_equal(z1, z0)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_generated_dropout_statistics(dtype, monkeypatch):
     """The device-generated keep mask (fp32 step: two decisions per 32-bit counter hash; bf16 step: 16-bit fields of a

@@ -210,6 +210,7 @@ _ENV_OPTIONS = {
     "VAMBHIP_VAE_GEMM_PREFETCH": ("vae.gemm_prefetch", int),
     "VAMBHIP_VAE_GEMM_KGROUPS": ("vae.gemm_kgroups", int),
     "VAMBHIP_VAE_DW_PAIR": ("vae.dw_pair", int),
+    "VAMBHIP_VAE_LOSS_REGISTERS": ("vae.loss_registers", int),
 }
 _ENV_STRING_OPTIONS = {"VAMBHIP_RCCL": "comm.rccl_library", "ROCM_PATH": "comm.rocm_path"}
 _explicit_options: dict = {}

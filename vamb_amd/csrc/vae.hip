@@ -217,9 +217,12 @@ struct VaeTuning {
                               // rows of the batch; the gather kernel then writes no fp32 copy of the batch (a third of its traffic)
     bool dw_pair = true;      // vae.dw_pair: bf16 step: the last two weight gradients of the backward pass (encoder layers 0 and 1, both on
                               // the main stream behind the first layer's BatchNorm backward) as ONE launch (gemm_bf16_tn_pair_kernel).  Same bits.
+    bool loss_registers = true; // vae.loss_registers: bf16 step of the plain VAE: the loss kernel holds a wavefront's two rows in registers
+                              // (vae_loss16_reg_kernel) instead of staging them in LDS; same bits but for the last digit of the reported sse
 } g_tuning;
 
 void refresh_tuning() {
+    g_tuning.loss_registers = option("vae.loss_registers", 1) != 0;
     g_tuning.big_tiles = option("vae.big_tiles", 0) != 0;
     g_tuning.xcd_remap = (int)option("vae.xcd_remap", 1);
     g_tuning.dw_workgroups = (int)option("vae.dw_workgroups", 256);

@@ -335,6 +335,121 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
 }
 
+// The same loss with the two rows of a wavefront held in REGISTERS (round 6; plain VAE, no label block): lane l owns the columns
+// l + 64 i, i < NV, of the reconstruction row and of the target row -- NV values each instead of a staging area in LDS that the
+// softmax / cross-entropy / SSE passes re-read through five rolled loops (one ds_read + lgkmcnt(0) + exec-mask bookkeeping per
+// iteration).  Every per-lane sum runs over ascending columns l, l + 64, ... like the loops of vae_loss16_kernel and every
+// reduction is the same DPP tree, so abundance cross-entropy, its gradient, the abundance-total term, KLD and every element of dR
+// carry the same bits; only the TNF sum of squares is grouped by column mod 64 instead of (column - S) mod 64 (the reported
+// `sse` differs in the last float digit, its gradient does not).
+template <int NV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NV <= 8 ? 8 : 4, 8))) void vae_loss16_reg_kernel(const Loss16Args a) {
+    __shared__ float red[4][4];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;   // wave-uniform
+    float ab_t = 0.f, ce_t = 0.f, sse_t = 0.f, kld_t = 0.f;
+    if (row < a.bs_p) {
+        bf16_t* dr = a.dR16 + (int64_t)row * a.ld;
+        float* dm = a.dMUk + (int64_t)row * a.ldl;
+        const int ld = (int)a.ld;
+        if (row >= a.bs) {
+            for (int c = lane; c < ld; c += 64) dr[c] = 0;
+            for (int c = lane; c < a.ldl; c += 64) dm[c] = 0.f;
+        } else {
+            const float* rg = a.R + (int64_t)row * a.ld;
+            const float* xg = a.X + (a.rows ? (int64_t)a.rows[row] : (int64_t)row) * a.ld;
+            float r[NV], x[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + 64 * i;
+                r[i] = 0.f; x[i] = 0.f;
+                if (c < ld) { r[i] = rg[c]; x[i] = xg[c]; }
+            }
+            const float g = a.inv_b2;
+            const int S = a.S, T0 = a.S + a.ntnf;   // [0, S) abundances, [S, T0) TNF, T0 the abundance total (if nab)
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (lane + 64 * i < S) mx = fmaxf(mx, r[i]);
+            mx = wave_max_dpp(mx);
+            float se = 0.f;
+            float e_[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                e_[i] = 0.f;
+                if (lane + 64 * i < S) {
+                    e_[i] = __expf(r[i] - mx);
+                    se += e_[i];
+                }
+            }
+            se = wave_sum_dpp(se);
+            const float inv = S > 0 ? 1.0f / se : 0.0f;
+            float ce = 0.f, pdp = 0.f;
+            float t_[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                t_[i] = 0.f;
+                if (lane + 64 * i < S) {
+                    const float p = e_[i] * inv;
+                    const float q = p + 1e-9f;
+                    const float xv = x[i];
+                    const float t = __fdividef(xv, q);
+                    ce -= __logf(q) * xv;
+                    pdp -= p * t;
+                    e_[i] = p;
+                    t_[i] = t;
+                }
+            }
+            ce = wave_sum_dpp(ce);
+            pdp = wave_sum_dpp(pdp);
+            const float gce = g * a.ce_w;
+            const float gsse = g * a.sse_w * 2.0f;
+            const float gab = g * a.ab_w * 2.0f;
+            float sse = 0.f, ab = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < ld) {
+                    float out = 0.f;
+                    if (c < S) {
+                        out = gce * e_[i] * (-t_[i] - pdp);
+                    } else if (c < T0) {
+                        const float diff = r[i] - x[i];
+                        sse += diff * diff;
+                        out = gsse * diff;
+                    } else if (c == T0 && a.nab) {
+                        const float diff = r[i] - x[i];
+                        ab = diff * diff;
+                        out = gab * diff;
+                    }
+                    dr[c] = f2bf(out);
+                }
+            }
+            sse = wave_sum_dpp(sse);
+            ab = wave_sum_dpp(ab);
+            const float* mu = a.MU + (int64_t)row * a.ldl;
+            float kld = 0.f;
+            const float gk = g * a.kld_w;
+            for (int c = lane; c < a.ldl; c += 64) {
+                const float m = c < a.L ? mu[c] : 0.f;
+                kld += m * m;
+                dm[c] = gk * m;
+            }
+            kld = 0.5f * wave_sum_dpp(kld);
+            ab_t = ab * a.ab_w;
+            ce_t = ce * a.ce_w;
+            sse_t = sse * a.sse_w;
+            kld_t = kld * a.kld_w;
+        }
+    }
+    if (lane == 0) { red[wave][0] = ab_t; red[wave][1] = ce_t; red[wave][2] = sse_t; red[wave][3] = kld_t; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int t = threadIdx.x;
+        a.part[(int64_t)blockIdx.x * 4 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    }
+}
+
 // ---- elementwise backward of one hidden layer, bf16 in / out ---------------------------------------------------------
 //   dZ = keep * slope(h) * drop_scale * istd*gamma * (dA - S1/B - xhat * S2/B)      (see vae_dz_kernel)
 // reads dA16, H16 [bs_p][n_p]; writes dZ16 [bs_p][n_p] and accumulates the fp64 column sums of dZ (bias gradient).  A

@@ -491,7 +491,17 @@ void loss_and_seed16(vh_vae* h, SideQueue& q) {
     }
     auto kern = vae_loss16_kernel<true>;
     // the side stream starts here: its first items (see backward16) only need what this kernel leaves
-    launch_forking(h, kern, dim3(h->loss_blocks), dim3(256), loss_lds, a);
+    // plain VAE, up to 1152 padded input columns: the rows of a wavefront in registers (vae_loss16_reg_kernel; vae.loss_registers)
+    const int nv = (int)ceil_div(h->D_p, 64);
+    if (g_tuning.loss_registers && h->NL == 0 && nv <= 18) {
+        if (nv <= 4) launch_forking(h, vae_loss16_reg_kernel<4>, dim3(h->loss_blocks), dim3(256), 0, a);
+        else if (nv <= 6) launch_forking(h, vae_loss16_reg_kernel<6>, dim3(h->loss_blocks), dim3(256), 0, a);
+        else if (nv <= 8) launch_forking(h, vae_loss16_reg_kernel<8>, dim3(h->loss_blocks), dim3(256), 0, a);
+        else if (nv <= 12) launch_forking(h, vae_loss16_reg_kernel<12>, dim3(h->loss_blocks), dim3(256), 0, a);
+        else launch_forking(h, vae_loss16_reg_kernel<18>, dim3(h->loss_blocks), dim3(256), 0, a);
+    } else {
+        launch_forking(h, kern, dim3(h->loss_blocks), dim3(256), loss_lds, a);
+    }
     // the scalar reduction (loss means, sum of weights) is only needed by the optimiser
     const float* gw = h->gwsum_src;
     const float* lab_part = a.lab_part;
