@@ -480,7 +480,9 @@ constexpr int kDz16Cols = 64;
 constexpr int kDz16Rows = 128;
 
 // COLS x ROWS elements per workgroup of 256 threads: a thread owns 8 consecutive columns, COLS / 8 threads share a row
-template <int COLS, int ROWS>
+// MASKED: injected keep-masks (parity tests); the production instantiation has no per-element control flow (round 6: with the mask
+// test inside, every ELEMENT sat in its own exec-mask region -- s_and_saveexec / s_cbranch_execz / waits -- 32 of them per thread)
+template <int COLS, int ROWS, bool MASKED>
 __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
     constexpr int TPR = COLS / 8;        // threads per row
     constexpr int RP = 256 / TPR;        // rows per pass of the workgroup
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
         cf[0][t] = ca; cf[1][t] = ch; cf[2][t] = c0;
     }
     __syncthreads();
-    const bool hashed_drop = (a.drop_scale != 1.0f) && (a.drop_mask == nullptr);
+    const bool hashed_drop = (a.drop_scale != 1.0f) && !MASKED;
     float ca[8], ch[8], c0[8], s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ca[e] = cf[0][c8 + e]; ch[e] = cf[1][c8 + e]; c0[e] = cf[2][c8 + e]; s[e] = 0.f; }
@@ -526,17 +528,24 @@ __global__ __launch_bounds__(256) void vae_dz16_kernel(const Dz16Args a) {
         const uint32_t dw[4] = {da[p].x, da[p].y, da[p].z, da[p].w};
         const uint32_t hw[4] = {hh[p].x, hh[p].y, hh[p].z, hh[p].w};
         uint32_t ow[4] = {0, 0, 0, 0};
-        if (r < a.bs && col < a.n_p) {
+        if (r < a.bs && col < a.n_p) {   // (rows / columns outside the batch were loaded as zeros and stay zeros)
+            [[maybe_unused]] uint64_t m8 = ~0ull;
+            if constexpr (MASKED) m8 = *reinterpret_cast<const uint64_t*>(a.drop_mask + (int64_t)r * a.ld_mask + col);   // 8 keep bytes
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = (e & 1) ? bf_hi(dw[e >> 1]) : bf_lo(dw[e >> 1]);
-                const float h = (e & 1) ? bf_hi(hw[e >> 1]) : bf_lo(hw[e >> 1]);
-                bool keep = true;
-                if (a.drop_mask) keep = a.drop_mask[(int64_t)r * a.ld_mask + col + e] != 0;
-                const float dz = keep ? dz16_elem(d, h, ca[e], ch[e], c0[e], hashed_drop) : 0.f;
-                const bf16_t b = f2bf(dz);
-                s[e] += bf2f(b);
-                ow[e >> 1] |= (uint32_t)b << (16 * (e & 1));
+            for (int q = 0; q < 4; ++q) {
+                float dz[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = 2 * q + u;
+                    const float d = u ? bf_hi(dw[q]) : bf_lo(dw[q]);
+                    const float h = u ? bf_hi(hw[q]) : bf_lo(hw[q]);
+                    dz[u] = dz16_elem(d, h, ca[e], ch[e], c0[e], hashed_drop);
+                    if constexpr (MASKED) dz[u] = ((m8 >> (8 * e)) & 0xFFull) != 0 ? dz[u] : 0.f;
+                }
+                const uint32_t w = pack2bf(dz[0], dz[1]);   // both roundings in one instruction
+                s[2 * q] += bf_lo(w);
+                s[2 * q + 1] += bf_hi(w);
+                ow[q] = w;
             }
         }
         const uint4 o = make_uint4(ow[0], ow[1], ow[2], ow[3]);

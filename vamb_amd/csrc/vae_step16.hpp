@@ -669,7 +669,8 @@ void backward16(vh_vae* h, bool masks_injected, SideQueue& q) {
                 VH_HIP(hipGetLastError());
             }
         };
-        launch_dz(vae_dz16_kernel<kDz16Cols, kDz16Rows>, kDz16Cols, kDz16Rows);
+        if (a.drop_mask) launch_dz(vae_dz16_kernel<kDz16Cols, kDz16Rows, true>, kDz16Cols, kDz16Rows);   // injected masks (parity tests)
+        else launch_dz(vae_dz16_kernel<kDz16Cols, kDz16Rows, false>, kDz16Cols, kDz16Rows);
         if (li == 0) {
             const DwSpec first{hl.tW, hl.DZ16.p, hl.nout_p, InT, in_p, colsum_in_gemm ? hl.dbias : nullptr};
             if (!(rm && late_dw && grad_weight16_rm_pair(h, first, late_spec, h->stream))) {
