@@ -55,6 +55,20 @@ int vh_debug_gemm16_tn(const float* A, const float* B, float* C, double* colsum,
 int vh_debug_gemm16_timeline(int epi, int M, int N, int K, int variant, unsigned long long* stamps, int cap_blocks,
                              int* n_blocks, float* ms);
 
+/* Diagnostic: guard mode of the device allocator.  With the option debug.guard_bytes = g > 0 (vh_set_option, before the handles
+ * are created) every device allocation is followed by g canary bytes; this call synchronises the device and lists the live
+ * allocations whose canary was overwritten (text, one line each: allocation number, payload size, damaged range, the
+ * allocation's call stack as offsets into the library).  *damaged = their number.  The tool for finding a kernel that stores
+ * past the end of a buffer: GPU AddressSanitizer is not available on the test pool. */
+int vh_debug_check_guards(char* report, int cap, int* damaged);
+
+/* Diagnostic (a library built with -DVAMBHIP_TIMING_EXPERIMENTS only; VH_ERR_INVALID otherwise): constant-clock (100 MHz) stamps
+ * of the LAST scan pass of a handle.  stamps[b][0..6] of workgroup b (b < 4095): kernel entry, prologue done, first row block
+ * evaluated (VALU kernels), row loop done, drain done, flush begun, flush retired; row 4095 = the publish kernel (entry, copies
+ * added up, results in host memory).  host_us[0..3]: scan_core entry, scan launched, publish launched, flag seen (microseconds
+ * on the host clock).  Rows are zero where no workgroup ran.  cap_rows >= 4096. */
+int vh_debug_scan_timeline(vh_clu* h, unsigned long long* stamps, int cap_rows, int* n_rows, double* host_us);
+
 #ifdef __cplusplus
 }
 #endif

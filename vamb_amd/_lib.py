@@ -143,6 +143,8 @@ SIGNATURES = {
     "vh_debug_gemm16": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,
                                ctypes.POINTER(_f32)]),
     "vh_debug_gemm16_timeline": (_int, [_int, _int, _int, _int, _int, _vp, _int, _vp, _vp]),
+    "vh_debug_scan_timeline": (_int, [_vp, _vp, _int, _vp, _vp]),
+    "vh_debug_check_guards": (_int, [ctypes.c_char_p, _int, _vp]),
     "vh_vae_create_labelled": (_int, [_vp, _vp, _pp]),
     "vh_vae_set_optimizer": (_int, [_vp, _int, _f32]),
     "vh_vae_row_width": (_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
@@ -211,6 +213,7 @@ _ENV_OPTIONS = {
     "VAMBHIP_VAE_GEMM_KGROUPS": ("vae.gemm_kgroups", int),
     "VAMBHIP_VAE_DW_PAIR": ("vae.dw_pair", int),
     "VAMBHIP_VAE_LOSS_REGISTERS": ("vae.loss_registers", int),
+    "VAMBHIP_DEBUG_GUARD_BYTES": ("debug.guard_bytes", int),
 }
 _ENV_STRING_OPTIONS = {"VAMBHIP_RCCL": "comm.rccl_library", "ROCM_PATH": "comm.rocm_path"}
 _explicit_options: dict = {}

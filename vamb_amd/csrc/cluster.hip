@@ -18,6 +18,8 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <dlfcn.h>
+#include <execinfo.h>
 #include <map>
 #include <mutex>
 #include <chrono>
@@ -52,6 +54,36 @@ const char* option_string(const char* name) {
     std::lock_guard<std::mutex> lock(g_option_mutex);
     const auto it = option_strings().find(name);
     return it == option_strings().end() ? nullptr : it->second.c_str();
+}
+
+// ---- guard mode of the device allocator (common.hpp) ----
+namespace {
+struct GuardRec {
+    size_t bytes, guard;
+    uint64_t id;
+    void* frames[10];
+    int n_frames;
+};
+std::mutex g_guard_mutex;
+std::map<void*, GuardRec>& guard_table() {
+    static std::map<void*, GuardRec> t;
+    return t;
+}
+uint64_t g_guard_next_id = 0;
+constexpr unsigned char kGuardByte = 0xA5;
+}  // namespace
+size_t guard_bytes() { return (size_t)option("debug.guard_bytes", 0); }
+void guard_track(void* p, size_t bytes, size_t guard) {
+    (void)hipMemset(static_cast<char*>(p) + bytes, kGuardByte, guard);
+    GuardRec r{bytes, guard, 0, {}, 0};
+    r.n_frames = backtrace(r.frames, 10);
+    std::lock_guard<std::mutex> lock(g_guard_mutex);
+    r.id = g_guard_next_id++;
+    guard_table()[p] = r;
+}
+void guard_forget(void* p) {
+    std::lock_guard<std::mutex> lock(g_guard_mutex);
+    guard_table().erase(p);
 }
 }
 
@@ -100,6 +132,25 @@ struct RmRows {
 __device__ __forceinline__ void apply_removals(uint8_t* kept_w, const RmRows& rm) {
     if ((int)threadIdx.x < rm.n) kept_w[rm.row[threadIdx.x]] = 0;   // (a __syncthreads() of the caller's prologue follows)
 }
+
+// Timing build only (-DVAMBHIP_TIMING_EXPERIMENTS): constant-clock (100 MHz) stamps of the phases of a pass, one row of 8 per
+// workgroup (row kStampRows - 1: the publish kernel), read back by vh_debug_scan_timeline.  Absent from the product build.
+#ifdef VAMBHIP_TIMING_EXPERIMENTS
+constexpr int kStampRows = 4096;
+__device__ unsigned long long* g_scan_stamps = nullptr;
+#define SCAN_STAMP(slot)                                                                                                   \
+    do {                                                                                                                   \
+        if (g_scan_stamps != nullptr && threadIdx.x == 0 && blockIdx.x < kStampRows - 1)                                   \
+            g_scan_stamps[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64();                                               \
+    } while (0)
+#define PUBLISH_STAMP(slot)                                                                                                \
+    do {                                                                                                                   \
+        if (g_scan_stamps != nullptr && threadIdx.x == 0) g_scan_stamps[(size_t)(kStampRows - 1) * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define SCAN_STAMP(slot) do { } while (0)
+#define PUBLISH_STAMP(slot) do { } while (0)
+#endif
 
 // torch.linspace(0.0, 0.3, 61) float32 bit patterns (== edges torch.histogram writes, cluster.py:288,
 // 475-481).  tests/test_lib_abi.py asserts the table equals torch.linspace.
@@ -500,6 +551,7 @@ __device__ __forceinline__ void scan_flush(int tid, const unsigned long long* __
                                            unsigned long long* __restrict__ results, int32_t* __restrict__ lists, int dbg = 0) {
     __shared__ unsigned int start_s[kMaxMedoids];
     __syncthreads();
+    SCAN_STAMP(5);
     if (dbg & 4) return;   // timing experiment: no flush
     unsigned long long* copy = results + (size_t)(blockIdx.x % kResultReplicas) * kMaxMedoids * kResultWords;
     for (int i = tid; i < KM * kResultWords; i += kBlock) {
@@ -523,6 +575,10 @@ __device__ __forceinline__ void scan_flush(int tid, const unsigned long long* __
         const unsigned int start = start_s[j];
         if (start + cnt <= (unsigned int)kListCap && tid < (int)cnt) lists[j * kListCap + start + tid] = llist_s[j * kLocalCap + tid];
     }
+#ifdef VAMBHIP_TIMING_EXPERIMENTS
+    __builtin_amdgcn_s_waitcnt(0);   // (every counter at 0: the stamp marks the flush RETIRED, not issued)
+    SCAN_STAMP(6);
+#endif
 }
 
 // (Requesting the first row block before the prologue -- LDS initialisation, query gather, barrier -- to overlap the two
@@ -551,6 +607,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    SCAN_STAMP(0);
     float4* hq = hq_s + (tid >> 6) * kHitCap;
     for (int i = tid; i < KM; i += kBlock) med_s[i] = (int32_t)medoid.row[i];
     for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
@@ -565,6 +622,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
         }
     }
     __syncthreads();
+    SCAN_STAMP(1);
 
     const float edge_hi = edges_s[VH_NBINS];
     int qn = 0;   // hits queued by this wavefront (uniform)
@@ -663,6 +721,7 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
                 }
             }
             evaluate(acc, 0);
+            SCAN_STAMP(2);
         } else if constexpr (PIPE != 0) {
             // Many medoids per pass.  Measured (profiles/r02b_scan_bench_lc*.json): 45 us + 4 us per medoid at 2 M x 32
             // whether the column loads are issued up front or four at a time -- neither HBM nor the loads bound it.  The
@@ -743,7 +802,9 @@ __global__ __launch_bounds__(kBlock) void clu_scan_kernel(const float* __restric
             evaluate(acc, 0);
         }
     }
+    SCAN_STAMP(3);
     drain_hits<REF>(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, ro);
+    SCAN_STAMP(4);
 
     scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists, dbg);
 }
@@ -1017,6 +1078,7 @@ void clu_scan_mfma_rm_kernel(const float* __restrict__ Mr, int64_t ld, const flo
                              int32_t* __restrict__ lists, int dbg, const RefSrc ro, uint8_t* kept_w, const RmRows rm) {
     constexpr int KM = kMaxMedoids;
     constexpr int LR = 2 * NK;
+    SCAN_STAMP(0);
     apply_removals(kept_w, rm);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* hq_s = reinterpret_cast<float4*>(smem_raw);                                  // [kBlock/64][kHitCap]
@@ -1069,6 +1131,7 @@ void clu_scan_mfma_rm_kernel(const float* __restrict__ Mr, int64_t ld, const flo
     for (int i = tid; i <= VH_NBINS; i += kBlock) edges_s[i] = __uint_as_float(c_edge_bits[i]);
     for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
     __syncthreads();
+    SCAN_STAMP(1);
     const float edge_hi = edges_s[VH_NBINS];
     // smallest dot product whose distance 0.5f - dot (float32, round to nearest) is <= the last histogram edge, minus the filter's slack
     float dot_min = 0.5f - edge_hi;
@@ -1153,7 +1216,9 @@ void clu_scan_mfma_rm_kernel(const float* __restrict__ Mr, int64_t ld, const flo
         }
     }
     settle();
+    SCAN_STAMP(3);
     drain_hits<true>(hq, qn, lane, acc_s, lcnt_s, llist_s, edges_s, med_s, dbg, ro, lengths);
+    SCAN_STAMP(4);
     scan_flush<KM>(tid, acc_s, lcnt_s, llist_s, results, lists, dbg);
 }
 
@@ -1306,6 +1371,7 @@ __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, un
                                                                       unsigned long long* __restrict__ host_flag,
                                                                       unsigned long long seq, int dbg) {
     const int tid = threadIdx.x;
+    PUBLISH_STAMP(0);
     // the accumulator copies of the pass are added up first (and zeroed for the next pass)
     __shared__ unsigned long long red_s[kMaxMedoids * kResultWords];
 #pragma unroll 4
@@ -1322,6 +1388,7 @@ __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, un
             if (part[r] != 0ull) results[(size_t)r * kMaxMedoids * kResultWords + i] = 0ull;
     }
     __syncthreads();
+    PUBLISH_STAMP(1);
     // (the candidate lists are already in the host-mapped ring: the scan kernels append them there)
     // the four words every candidate needs (density, n_within, n_lt, list cursor) go to a compact block of
     // their own: the host reads 32 bytes per medoid instead of 512 (host reads of this memory are expensive)
@@ -1336,6 +1403,7 @@ __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, un
         }
     __threadfence_system();
     __syncthreads();
+    PUBLISH_STAMP(2);
     if (tid == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -1628,6 +1696,11 @@ struct vh_clu {
     // host copy of the normalised matrix, row-major, by ORIGINAL row (the generator's validity checks of
     // speculatively scanned seeds; never used for a decision that reaches the output)
     std::vector<float> host_rows;
+#ifdef VAMBHIP_TIMING_EXPERIMENTS
+    DevBuf<unsigned long long> stamps;   // [kStampRows][8] phase stamps of the last pass (vh_debug_scan_timeline)
+    double host_us[4] = {0, 0, 0, 0};    // scan_core of the last pass: entry -> scan launched -> publish launched -> flag seen
+    int last_grid = 0;
+#endif
 
     ~vh_clu() {
         if (ev_done) (void)hipEventDestroy(ev_done);
@@ -1933,6 +2006,14 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         VH_REQUIRE(option("scan.debug", 0) == 0, "scan.debug needs a library built with -DVAMBHIP_TIMING_EXPERIMENTS (it produces wrong results)");
 #endif
         h->results.alloc((size_t)kResultReplicas * kMaxMedoids * kResultWords);
+#ifdef VAMBHIP_TIMING_EXPERIMENTS
+        h->stamps.alloc((size_t)kStampRows * 8);
+        VH_HIP(hipMemset(h->stamps.p, 0, h->stamps.bytes()));
+        {
+            unsigned long long* sp = h->stamps.p;
+            VH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_scan_stamps), &sp, sizeof(sp)));
+        }
+#endif
         VH_HIP(hipHostMalloc((void**)&h->lists, (size_t)kListRing * kMaxMedoids * kListCap * sizeof(int32_t),
                              hipHostMallocMapped | hipHostMallocCoherent));
         const size_t host_words = (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS) + 1;
@@ -2065,9 +2146,17 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
     }
     h->q_rows_pass = q_ext;   // row-major [km][L4] or nullptr (the quad-major copy some kernels take is made from it)
     take_pending_rm(h);       // rows the state machine removed since the last pass: cleared by this pass's own prologue
+#ifdef VAMBHIP_TIMING_EXPERIMENTS
+    const auto ht0 = std::chrono::steady_clock::now();
+    auto host_stamp = [&](int i) { h->host_us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count(); };
+    host_stamp(0);
+#endif
     h->timer.start(h->stream);
     dispatch_scan(h, km, med, q_ext);
     h->timer.stop(h->stream);
+#ifdef VAMBHIP_TIMING_EXPERIMENTS
+    host_stamp(1);
+#endif
     // the exact integer accumulators of all shards: order-free sums, so the result does not depend on the sharding
     if (sharded == 1) {
         hipLaunchKernelGGL(clu_fold_replicas_kernel, dim3(1), dim3(kBlock), 0, h->stream, km, h->results.p);
@@ -2095,8 +2184,14 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
                            h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1), h->scan_dbg);
         VH_HIP(hipGetLastError());
     }
+#ifdef VAMBHIP_TIMING_EXPERIMENTS
+    host_stamp(2);
+#endif
     if (while_waiting) (*while_waiting)();   // host work that does not depend on this pass, under the pass
     wait_for_scan(h, h->scan_seq + 1);
+#ifdef VAMBHIP_TIMING_EXPERIMENTS
+    host_stamp(3);
+#endif
     if (h->timer.enabled) {
         VH_HIP(hipStreamSynchronize(h->stream));
         h->timer.collect();
@@ -3682,6 +3777,68 @@ int vh_debug_find_threshold(const int64_t* hist_fx, int64_t n_lt, double pvr, in
         *threshold = 0.0;
         *observed_pvr = 0.0;
         *kind = (int)gen_find_threshold(&g, st, threshold, observed_pvr);
+    });
+}
+
+// Diagnostic (option debug.guard_bytes > 0): the live device allocations whose trailing canary is no longer intact, one line each
+// (allocation number, payload bytes, first damaged byte past the end, damaged bytes, allocation call stack as offsets into this
+// library: resolve with llvm-symbolizer -e libvambhip.so).  *damaged = how many; the report is cut at cap bytes.
+int vh_debug_check_guards(char* report, int cap, int* damaged) {
+    return guarded([&] {
+        VH_REQUIRE(report != nullptr && cap >= 1 && damaged != nullptr, "bad argument");
+        VH_HIP(hipDeviceSynchronize());
+        std::string out;
+        *damaged = 0;
+        std::lock_guard<std::mutex> lock(::vh::g_guard_mutex);
+        std::vector<unsigned char> host;
+        Dl_info self{};
+        (void)dladdr(reinterpret_cast<void*>(&vh_debug_check_guards), &self);
+        char line[1024];
+        snprintf(line, sizeof(line), "%zu tracked allocations\n", ::vh::guard_table().size());
+        out += line;
+        for (const auto& kv : ::vh::guard_table()) {
+            const ::vh::GuardRec& r = kv.second;
+            host.resize(r.guard);
+            VH_HIP(hipMemcpy(host.data(), static_cast<const char*>(kv.first) + r.bytes, r.guard, hipMemcpyDeviceToHost));
+            size_t first = r.guard, count = 0, last = 0;
+            for (size_t i = 0; i < r.guard; ++i)
+                if (host[i] != ::vh::kGuardByte) { if (first == r.guard) first = i; last = i; ++count; }
+            if (count == 0) continue;
+            ++*damaged;
+            int o = snprintf(line, sizeof(line), "allocation #%llu: %zu bytes; canary damaged at +%zu .. +%zu (%zu bytes); first words:",
+                             (unsigned long long)r.id, r.bytes, first, last, count);
+            for (size_t i = first; i < std::min(first + 16, r.guard) && o < (int)sizeof(line) - 8; i += 4)
+                o += snprintf(line + o, sizeof(line) - o, " %02x%02x%02x%02x", host[i + 3 < r.guard ? i + 3 : i], host[i + 2 < r.guard ? i + 2 : i],
+                              host[i + 1 < r.guard ? i + 1 : i], host[i]);
+            o += snprintf(line + o, sizeof(line) - o, "; stack:");
+            for (int f = 1; f < r.n_frames && o < (int)sizeof(line) - 24; ++f) {
+                Dl_info di{};
+                if (dladdr(r.frames[f], &di) && di.dli_fbase == self.dli_fbase)
+                    o += snprintf(line + o, sizeof(line) - o, " 0x%llx", (unsigned long long)(static_cast<char*>(r.frames[f]) - static_cast<char*>(di.dli_fbase)));
+            }
+            out += line;
+            out += "\n";
+        }
+        snprintf(report, (size_t)cap, "%s", out.c_str());
+    });
+}
+
+// Diagnostic: the phase stamps of the LAST scan pass of a handle (a library built with -DVAMBHIP_TIMING_EXPERIMENTS only)
+int vh_debug_scan_timeline(vh_clu* h, unsigned long long* stamps, int cap_rows, int* n_rows, double* host_us) {
+    return guarded([&] {
+        VH_REQUIRE(h != nullptr && stamps != nullptr && n_rows != nullptr && host_us != nullptr && cap_rows >= 1, "bad argument");
+#ifdef VAMBHIP_TIMING_EXPERIMENTS
+        VH_HIP(hipStreamSynchronize(h->stream));
+        VH_REQUIRE(cap_rows >= kStampRows, "stamps: room for %d rows of 8 words (the last row is the publish kernel's)", kStampRows);
+        VH_HIP(hipMemcpy(stamps, h->stamps.p, (size_t)kStampRows * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        *n_rows = kStampRows;
+        for (int i = 0; i < 4; ++i) host_us[i] = h->host_us[i];
+        VH_HIP(hipMemset(h->stamps.p, 0, h->stamps.bytes()));
+#else
+        (void)h; (void)stamps; (void)cap_rows; (void)host_us;
+        *n_rows = 0;
+        VH_REQUIRE(false, "vh_debug_scan_timeline needs a library built with -DVAMBHIP_TIMING_EXPERIMENTS");
+#endif
     });
 }
 

@@ -74,6 +74,13 @@ int guarded(F&& body) {
     }
 }
 
+// Guard mode (option debug.guard_bytes, off by default; tools/gpu/gpu_guard_check.py): every device allocation is followed by
+// that many canary bytes, vh_debug_check_guards reports the allocations whose canary was overwritten -- the search tool for
+// a kernel that stores past the end of a buffer (no GPU address sanitizer on this pool).  Defined in cluster.hip.
+size_t guard_bytes();
+void guard_track(void* p, size_t bytes, size_t guard);
+void guard_forget(void* p);
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -89,7 +96,10 @@ struct DevBuf {
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p && !borrowed) (void)hipFree(p);
+        if (p && !borrowed) {
+            guard_forget(p);
+            (void)hipFree(p);
+        }
         p = nullptr;
         n = 0;
         borrowed = false;
@@ -104,7 +114,9 @@ struct DevBuf {
     void alloc(size_t count) {
         release();
         if (count == 0) count = 1;
-        VH_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        const size_t guard = guard_bytes();
+        VH_HIP(hipMalloc((void**)&p, count * sizeof(T) + guard));
+        if (guard) guard_track(p, count * sizeof(T), guard);
         n = count;
     }
     void ensure(size_t count) {
