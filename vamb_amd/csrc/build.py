@@ -42,6 +42,35 @@ SOURCES = {
 }
 
 
+# Sources whose kernels wait for inline-asm register loads with hand-written s_waitcnt (the deep-prefetch / K-group fp32 GEMM tiles,
+# the row-major scan): compiled with -save-temps so that the ISA of exactly the object that ships is at hand, and checked by
+# isa_pending_loads.py -- no instruction may touch a register a load is still writing.  A hazard fails the build.
+ISA_CHECKED = ("cluster.hip", "vae.hip")
+ISA_SUFFIX = "-hip-amdgcn-amd-amdhsa-gfx950.s"
+
+
+def isa_path(src: str) -> str:
+    return os.path.join(OBJ_DIR, src.replace(".hip", "") + ISA_SUFFIX)
+
+
+def check_isa(verbose: bool = True) -> None:
+    import isa_pending_loads as ipl
+    for src in ISA_CHECKED:
+        path = isa_path(src)
+        stamp = path + ".checked"
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: rebuild with `python vamb_amd/csrc/build.py --force`")
+        if os.path.exists(stamp) and os.path.getmtime(stamp) >= os.path.getmtime(path):
+            continue
+        report = []
+        n_k, n_asm, hazards = ipl.check_file(path, out=report.append)
+        if verbose:
+            print(f"ISA check {os.path.basename(path)}: {n_k} kernels, {n_asm} with hand-waited register loads, {hazards} hazard(s)", flush=True)
+        if hazards:
+            raise RuntimeError("a register is touched while an inline-asm load into it is in flight:\n" + "\n".join(report))
+        open(stamp, "w").write("ok\n")
+
+
 def hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -67,8 +96,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(obj)
         stale = force or newer(spath, obj) or any(newer(h, obj) for h in headers) or newer(__file__, obj)
-        if stale:
-            jobs.append([hipcc(), *COMMON, *extra, "-c", spath, "-o", obj])
+        temps = ["-save-temps=obj"] if src in ISA_CHECKED else []
+        if stale or (temps and not os.path.exists(isa_path(src))):
+            jobs.append([hipcc(), *COMMON, *extra, *temps, "-c", spath, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -77,6 +107,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    for f in os.listdir(OBJ_DIR):   # the bulky by-products of -save-temps (preprocessed sources, bitcode); the device ISA stays
+        if f.endswith((".hipi", ".bc", ".hipfb", ".out", ".resolution.txt", "-host-x86_64-unknown-linux-gnu.s", "-gfx950.o")):
+            os.remove(os.path.join(OBJ_DIR, f))
+    sys.path.insert(0, HERE)
+    check_isa(verbose)
     if jobs or force or not os.path.exists(OUT):
         run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs, "-ldl"])
     return OUT

@@ -1097,14 +1097,77 @@ void clu_scan_mfma_rm_kernel(const float* __restrict__ Mr, int64_t ld, const flo
     const int64_t stride = (int64_t)gridDim.x * (kBlock / 64);
     int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + wave;
     auto clamp_tile = [&](int64_t t) { return t < ntiles ? t : ntiles - 1; };   // (wave-uniform; see K6m on unconditional prefetches)
-    // the first tiles are requested before anything else: they travel under the LDS initialisation and the query fetch
     constexpr int DEPTH = NK <= 16 ? 3 : 2;
     constexpr int TILE_LOADS = NK / 4;
     scan_f32x4 xa[DEPTH][NK / 4];
-#pragma unroll
-    for (int u = 0; u < DEPTH; ++u) scan_tile_load_rm<NK>(xa[u], Mr, clamp_tile(tile + u * stride), lane_off);
     // B operand: lane (medoid j, half h) holds q[j][h NK .. + NK - 1]; unused medoid slots keep zeros (dot = 0, never a candidate)
     float qb[NK];
+#ifndef VAMBHIP_K6R_OLD_PROLOGUE
+    // Round 6 (profiles/r06v_scan_timeline.txt: the prologue of this kernel ended 5.3 - 7.9 us after its entry, the VALU kernels' after
+    // 1.1 - 1.7 us).  Loads return in order, and everything the prologue needs used to be requested BEHIND the first DEPTH tiles
+    // (37 MB over the chip at 768 workgroups): the medoid rows as a per-lane read of the kernel arguments, then -- a dependent round
+    // trip later -- the query vectors, then the edge table, each awaited by a compiler-made vmcnt(0) that drained the tiles as well;
+    // no matrix-pipe work started before all of that had landed.  Now the medoid rows come through the scalar cache (wave-uniform
+    // reads of the arguments, one select per slot), and the edge table and the query block are requested by asm loads IN FRONT of
+    // the tiles: one counted wait (the DEPTH tiles issued behind them stay in flight) ends the prologue.
+    int med32 = 0;   // lane (j, h): physical row of medoid slot j, -1 = empty slot (rows < 2^31, checked at creation)
+#pragma unroll
+    for (int i = 0; i < KM; ++i) {
+        const int r = (int)medoid.row[i];   // (uniform index: s_load; one compare + select per slot)
+        med32 = j == i ? r : med32;
+    }
+    const bool q_rows = q_ext == nullptr;        // (uniform) the queries are rows of the matrix
+    const bool have_q = j < k_real && (!q_rows || med32 >= 0);
+    uint32_t edge_bits;
+    scan_f32x4 qv[NK / 4];
+    {
+        const uint32_t eoff = (uint32_t)(tid <= VH_NBINS ? tid : VH_NBINS) * 4u;
+        const uint32_t* etab = c_edge_bits;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(edge_bits) : "v"(eoff), "s"(etab) : "memory");
+        // (explicit queries -- row-sharded passes -- are fetched by the compiler's own loads below; the request here then reads row 0)
+        const float* qsrc = Mr + (int64_t)(have_q && q_rows ? med32 : 0) * LR + h * NK;   // (a per-lane 64-bit address)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qv[0]) : "v"(qsrc) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(qv[1]) : "v"(qsrc) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(qv[2]) : "v"(qsrc) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(qv[3]) : "v"(qsrc) : "memory");
+        if constexpr (NK == 32) {
+            asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(qv[4]) : "v"(qsrc) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:80" : "=v"(qv[5]) : "v"(qsrc) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:96" : "=v"(qv[6]) : "v"(qsrc) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:112" : "=v"(qv[7]) : "v"(qsrc) : "memory");
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) scan_tile_load_rm<NK>(xa[u], Mr, clamp_tile(tile + u * stride), lane_off);
+    for (int i = tid; i < KM * kResultWords; i += kBlock) acc_s[i] = 0ull;
+    for (int i = tid; i < KM; i += kBlock) lcnt_s[i] = 0u;
+    // the edge word and the query block have landed once at most the DEPTH tiles requested behind them are in flight
+    if constexpr (NK == 16)
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(edge_bits), "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]) : "n"(DEPTH * TILE_LOADS) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%9)" : "+v"(edge_bits), "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]), "+v"(qv[4]), "+v"(qv[5]),
+                     "+v"(qv[6]), "+v"(qv[7]) : "n"(DEPTH * TILE_LOADS) : "memory");
+    if (tid <= VH_NBINS) edges_s[tid] = __uint_as_float(edge_bits);
+    if (tid < KM) med_s[tid] = med32;
+#pragma unroll
+    for (int v = 0; v < NK / 4; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qb[4 * v + e] = have_q ? qv[v][e] : 0.0f;
+    if (!q_rows) {   // (row-sharded passes; the compiler's wait in front of the first use drains the tiles too, as it always did)
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            const int k = h * NK + s;
+            qb[s] = (j < k_real && k < q_ld) ? q_ext[j * q_ld + k] : 0.0f;
+        }
+    }
+    __syncthreads();
+    SCAN_STAMP(1);
+    const float edge_hi = edges_s[VH_NBINS];
+    // smallest dot product whose distance 0.5f - dot (float32, round to nearest) is <= the last histogram edge, minus the filter's slack
+#else
+    // the first tiles are requested before anything else: they travel under the LDS initialisation and the query fetch
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) scan_tile_load_rm<NK>(xa[u], Mr, clamp_tile(tile + u * stride), lane_off);
     {
         const long long my_med = medoid.row[j];
 #pragma unroll
@@ -1134,6 +1197,7 @@ void clu_scan_mfma_rm_kernel(const float* __restrict__ Mr, int64_t ld, const flo
     SCAN_STAMP(1);
     const float edge_hi = edges_s[VH_NBINS];
     // smallest dot product whose distance 0.5f - dot (float32, round to nearest) is <= the last histogram edge, minus the filter's slack
+#endif
     float dot_min = 0.5f - edge_hi;
     while (0.5f - __uint_as_float(__float_as_uint(dot_min) - 1u) <= edge_hi) dot_min = __uint_as_float(__float_as_uint(dot_min) - 1u);
     while (!(0.5f - dot_min <= edge_hi)) dot_min = __uint_as_float(__float_as_uint(dot_min) + 1u);

@@ -647,7 +647,21 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_f32_kernel(const GemmA
                 __syncthreads();
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-reads of the last tile: their registers are free after this
+        // The clamped re-reads of the last tile are still in flight here, into registers whose VALUES nobody will read: to the
+        // compiler they are free from the loop's exit on.  A bare wait does not say otherwise -- in the split-K instantiations
+        // (EPI_SPLITK) the scheduler moved the epilogue's first address computation above it, into a register a late load then
+        // overwrote: a wild output row, a memory fault in ~2 % of 500-step fp32 runs at the C2 shape, whenever the side stream's
+        // traffic delayed that load (round 6; vamb_amd/csrc/isa_pending_loads.py finds the pattern in the ISA and is part of the build).
+        // Every stage register therefore stays live THROUGH the wait: the empty asm statements below use them after it, and
+        // volatile asm statements keep their order.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int st = 0; st < PF; ++st) {
+#pragma unroll
+            for (int r = 0; r < UA; ++r) asm volatile("" ::"v"(rra[st][r]));
+#pragma unroll
+            for (int r = 0; r < UB; ++r) asm volatile("" ::"v"(rrb[st][r]));
+        }
     } else
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
