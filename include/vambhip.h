@@ -52,6 +52,8 @@ const char* vh_version(void);
  *   scan.mfma (1)          passes with more than 8 medoids on the matrix-pipe kernels
  *   scan.mfma_rowmajor (1) ... on the row-major copy of the matrix (K6r); 0 = the column-major kernel, its compiler-scheduled twin
  *                          (the start-up self-test's fallback, vh_selftest)
+ *   scan.publish_split (1) passes with more than 8 medoids publish the four summary words of every medoid first and their histograms
+ *                          behind a second sequence flag (0: one step, as for the few-medoid passes); same results
  *   gen.speculate (1), gen.spec_window (16)   medoid statistics scanned ahead of need in the free slots of a pass
  *   gen.prefill (2)        the speculative fill of a pass collected one pass ahead, under the running pass
  *   gen.inline_removals (1)  rows of an emitted cluster are cleared by the NEXT scan's own prologue (kernel arguments) instead of
@@ -70,6 +72,7 @@ const char* vh_version(void);
  *                          (1 = the plain tile: the self-test's fallback)
  *   vae.big_tiles (0), vae.xcd_remap (1), vae.dw_workgroups (256), vae.debug_timing (0)
  *   vae.probe_every (16)   the roofline probe (vh_vae_set_probe) times every n-th launch of the probed GEMM
+ *   debug.guard_bytes (0)  diagnostic: canary bytes behind every device allocation (vh_debug_check_guards, vambhip_debug.h)
  * String options: comm.rccl_library (path of librccl), comm.rocm_path (default /opt/rocm). */
 int vh_set_option(const char* name, int64_t value);
 int vh_unset_option(const char* name);

@@ -47,7 +47,9 @@ for r in range(reps + 3):
     pub = s[ROWS - 1]
     ph["publish entry"] = ((pub[0] - t0) / 100.0,) * 3
     ph["publish copies added"] = ((pub[1] - t0) / 100.0,) * 3
-    ph["publish done"] = ((pub[2] - t0) / 100.0,) * 3
+    ph["publish done"] = ((pub[2] - t0) / 100.0,) * 3      # (two-step publish: the pass flag; the histograms follow)
+    if pub[3] > 0:
+        ph["publish histograms done"] = ((pub[3] - t0) / 100.0,) * 3
     acc.append((int(ran.sum()), ph))
     hosts.append(host.copy())
 b.set_timing(False)

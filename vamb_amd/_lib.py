@@ -190,6 +190,7 @@ _ENV_OPTIONS = {
     "VAMBHIP_SCAN_MFMA_ROWMAJOR": ("scan.mfma_rowmajor", int),
     "VAMBHIP_REFERENCE_ORDER": ("scan.reference_order", int),
     "VAMBHIP_SCAN_DBG": ("scan.debug", int),
+    "VAMBHIP_SCAN_PUBLISH_SPLIT": ("scan.publish_split", int),
     "VAMBHIP_GEN_PROFILE": ("gen.profile", lambda v: 1),
     "VAMBHIP_NO_SPECULATION": ("gen.speculate", lambda v: 0),
     "VAMBHIP_SPEC_WINDOW": ("gen.spec_window", int),

@@ -1349,7 +1349,10 @@ __global__ __launch_bounds__(kBlock) void clu_gather_owned_kernel(const float* _
 
 constexpr int kPublishThreads = 256;    // ONE workgroup (the flag must follow every write).  Measured, C1 sweep under rocprofv3:
                                         // 256 threads + list copy 8.4 us average / 2.9 us minimum per pass; 1024 threads 9.1 /
-                                        // 5.4 us (a 16-wavefront workgroup starts later and 1024 threads sit in the system fence)
+                                        // 5.4 us (a 16-wavefront workgroup starts later and 1024 threads sit in the system fence).
+                                        // Round 6, behind passes with 32 medoids (in-kernel stamps, profiles/r06y3_publish_width.txt):
+                                        // 256 / 512 / 1024 threads form the sums in 5.6 / 4.4 / 4.2 us and then need 2.9 / 3.8 / 8.0 us
+                                        // to get them into host memory behind the system fence; a C2 sweep 12.0 / 12.3 / 12.6 s.
 // ---- row-sharded pass of the NATIVE state machine: ONE collective per pass --------------------------------------------------
 // Every rank scans its shard with explicit query vectors (each rank holds a host copy of the whole normalised matrix for
 // the generator's validity checks, so no query exchange is needed) and then contributes ONE block to an all-gather:
@@ -1421,7 +1424,10 @@ __global__ __launch_bounds__(kPublishThreads) void clu_publish_sharded_kernel(in
     }
     __threadfence_system();
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) {   // (host_flag + 1: the histogram flag of vh_clu::hist_flag(), raised with the pass flag here)
+        __hip_atomic_store(host_flag + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // K6b: publication without a copy-engine round trip.  One block moves the accumulators and the candidate
@@ -1433,6 +1439,7 @@ __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, un
                                                                       unsigned long long* __restrict__ host_summary,
                                                                       unsigned long long* __restrict__ host_hist,
                                                                       unsigned long long* __restrict__ host_flag,
+                                                                      unsigned long long* __restrict__ host_hist_flag,
                                                                       unsigned long long seq, int dbg) {
     const int tid = threadIdx.x;
     PUBLISH_STAMP(0);
@@ -1468,7 +1475,58 @@ __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, un
     __threadfence_system();
     __syncthreads();
     PUBLISH_STAMP(2);
+    if (tid == 0) {   // (the histogram flag first: whoever has seen the pass flag may read the histograms)
+        __hip_atomic_store(host_hist_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// The same for passes with more than 8 medoids, in TWO steps (round 6).  In-kernel stamps (profiles/r06v_scan_timeline.txt) put the
+// publish kernel of a 32-medoid pass at 9.2 us: 5.6 us until the eight copies of 32 x 64 words are added up, 2.9 us until they are
+// in host memory.  What the state machine needs at once are the FOUR summary words of a medoid (density, two counts, list cursor);
+// the 60 histogram words are read for the one medoid a cluster is built around, later, if at all.  So: the summary words first
+// (128 threads, one round of eight loads each), fence, sequence flag -- then the histograms and the re-arming of the copies,
+// fence, a second flag (hist_flag) that the readers of the histogram ring wait for (wait_for_hist).  The next scan is ordered
+// behind this kernel by the stream, whatever the host does in between.
+__global__ __launch_bounds__(kPublishThreads) void clu_publish2_kernel(int km, unsigned long long* __restrict__ results,
+                                                                       unsigned long long* __restrict__ host_summary,
+                                                                       unsigned long long* __restrict__ host_hist,
+                                                                       unsigned long long* __restrict__ host_flag,
+                                                                       unsigned long long* __restrict__ host_hist_flag,
+                                                                       unsigned long long seq, int dbg) {
+    const int tid = threadIdx.x;
+    PUBLISH_STAMP(0);
+    auto fold = [&](int word) {   // sum of the copies of one accumulator word, the copies re-armed
+        unsigned long long part[kResultReplicas];
+#pragma unroll
+        for (int r = 0; r < kResultReplicas; ++r) part[r] = results[(size_t)r * kMaxMedoids * kResultWords + word];
+        unsigned long long v = 0ull;
+#pragma unroll
+        for (int r = 0; r < kResultReplicas; ++r) v += part[r];
+#pragma unroll
+        for (int r = 0; r < kResultReplicas; ++r)
+            if (part[r] != 0ull) results[(size_t)r * kMaxMedoids * kResultWords + word] = 0ull;
+        return v;
+    };
+    for (int i = tid; i < km * 4; i += kPublishThreads) {
+        const int j = i >> 2, w = i & 3;
+        host_summary[i] = fold(j * kResultWords + (w == 0 ? 0 : VH_NBINS + w));
+    }
+    PUBLISH_STAMP(1);
+    __threadfence_system();
+    __syncthreads();
+    PUBLISH_STAMP(2);
     if (tid == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll 4
+    for (int i = tid; i < km * VH_NBINS; i += kPublishThreads) {
+        const int j = i / VH_NBINS, b = i - j * VH_NBINS;
+        const unsigned long long v = fold(j * kResultWords + 1 + b);
+        if (!(dbg & 32)) host_hist[i] = v;
+    }
+    __threadfence_system();
+    __syncthreads();
+    PUBLISH_STAMP(3);
+    if (tid == 0) __hip_atomic_store(host_hist_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1720,7 +1778,9 @@ struct vh_clu {
         return host_results + (size_t)kListRing * kMaxMedoids * 4 + (size_t)slot * kMaxMedoids * VH_NBINS;
     }
     unsigned long long* flag() { return host_results + (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS); }
+    unsigned long long* hist_flag() { return flag() + 1; }   // sequence number of the last pass whose HISTOGRAMS are in the ring (clu_publish2_kernel)
     int scan_dbg = 0;             // VAMBHIP_SCAN_DBG: timing experiments only (wrong results)
+    bool publish_split = true;    // option scan.publish_split: passes with more than 8 medoids publish their summaries first (clu_publish2_kernel)
     int max_k = kMaxMedoids;      // medoids per pass the LDS can hold for this latent width (query vectors are staged there)
     vh_comm* comm = nullptr;      // row-sharded execution (vh_clu_attach_comm): the ranks holding the other shards
     int64_t max_shard_ld = 0;     // largest padded shard over the ranks (size of the select exchange buffers)
@@ -1811,6 +1871,22 @@ void wait_for_scan(vh_clu* h, unsigned long long seq) {
             if (q == hipSuccess) {
                 if (*flag == seq) break;
                 throw ::vh::HipError{hipErrorUnknown, "scan kernel retired without publishing its results", __FILE__, __LINE__};
+            }
+            if (q != hipErrorNotReady) VH_HIP(q);
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+}
+
+// the histograms of scan number `seq` (1-based, = the flag value its publish kernel stores) are in the host-mapped ring
+void wait_for_hist(vh_clu* h, unsigned long long seq) {
+    volatile unsigned long long* flag = h->hist_flag();
+    for (unsigned long long spins = 1; *flag < seq; ++spins) {
+        if ((spins & 0xFFFFull) == 0) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) {
+                if (*flag >= seq) break;
+                throw ::vh::HipError{hipErrorUnknown, "publish kernel retired without its histograms", __FILE__, __LINE__};
             }
             if (q != hipErrorNotReady) VH_HIP(q);
         }
@@ -2054,6 +2130,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->min_blocks = kMinScanBlocks;   // (measured neutral between 384 and 1536)
         h->scan_lc = (int)option("scan.column_loop", 1);
         h->use_mfma = option("scan.mfma", 1) != 0;
+        h->publish_split = option("scan.publish_split", 1) != 0;
         {
             const int64_t mode = option("scan.reference_order", 2);
             VH_REQUIRE(mode >= 0 && mode <= 2, "scan.reference_order: 0, 1 or 2");
@@ -2080,7 +2157,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
 #endif
         VH_HIP(hipHostMalloc((void**)&h->lists, (size_t)kListRing * kMaxMedoids * kListCap * sizeof(int32_t),
                              hipHostMallocMapped | hipHostMallocCoherent));
-        const size_t host_words = (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS) + 1;
+        const size_t host_words = (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS) + 2;
         VH_HIP(hipHostMalloc((void**)&h->host_results, host_words * 8, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(h->host_results, 0, host_words * 8);
         VH_HIP(hipHostMalloc((void**)&h->sel_host, (size_t)kSelHostCap * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
@@ -2244,8 +2321,13 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
                            (unsigned long long)(h->scan_seq + 1));
         VH_HIP(hipGetLastError());
     } else {
-        hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, h->mfma_pass ? k : km, h->results.p,
-                           h->summary(slot), h->hist(slot), h->flag(), (unsigned long long)(h->scan_seq + 1), h->scan_dbg);
+        const int pk = h->mfma_pass ? k : km;
+        if (pk > 8 && h->publish_split)
+            hipLaunchKernelGGL(clu_publish2_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, pk, h->results.p, h->summary(slot),
+                               h->hist(slot), h->flag(), h->hist_flag(), (unsigned long long)(h->scan_seq + 1), h->scan_dbg);
+        else
+            hipLaunchKernelGGL(clu_publish_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, pk, h->results.p, h->summary(slot),
+                               h->hist(slot), h->flag(), h->hist_flag(), (unsigned long long)(h->scan_seq + 1), h->scan_dbg);
         VH_HIP(hipGetLastError());
     }
 #ifdef VAMBHIP_TIMING_EXPERIMENTS
@@ -2308,6 +2390,7 @@ int vh_clu_scan(vh_clu* h, int k, const int64_t* medoid_rows, const float* queri
         const int slot = scan_core(h, k, medoid_rows, queries);
         const std::vector<unsigned long long>& sm = h->last_summary[slot];
         std::vector<unsigned long long> hist((size_t)k * VH_NBINS);
+        wait_for_hist(h, h->scan_seq);   // (scan_core has counted the pass: its flag value is scan_seq)
         memcpy(hist.data(), h->hist(slot), hist.size() * 8);
         for (int j = 0; j < k; ++j) {
             out[j].density_fx = (int64_t)sm[4 * j + 0];
@@ -2342,6 +2425,7 @@ int vh_clu_scan_sharded(vh_clu* h, int k, const int64_t* local_rows, vh_scan_res
         const int slot = scan_core(h, k, local_rows, nullptr, 1);
         const std::vector<unsigned long long>& sm = h->last_summary[slot];
         std::vector<unsigned long long> hist((size_t)k * VH_NBINS);
+        wait_for_hist(h, h->scan_seq);   // (scan_core has counted the pass: its flag value is scan_seq)
         memcpy(hist.data(), h->hist(slot), hist.size() * 8);
         for (int j = 0; j < k; ++j) {
             out[j].density_fx = (int64_t)sm[4 * j + 0];
@@ -3329,8 +3413,14 @@ int64_t gen_wander(vh_gen* g, int64_t seed) {
             g->cand_needed += (int64_t)miss;
             g->cand_rounds_cached += miss == 0 ? 1 : 0;
         }
-        g->pass_purpose = 1;
-        gen_ensure_stats(g, candidates.data() + i, candidates.size() - i);
+        // ONE call per round: it leaves every candidate of the round with valid statistics (all the missing ones are scanned, in
+        // chunks if need be), and nothing inside a walk can change that -- entries are validated against emissions, and none
+        // happens here.  (Until round 6 it was repeated in front of every candidate; the lookups it repeated are cached and
+        // cheap -- the sweep measured the same, profiles/r06y4_sweep_ab.txt -- so this is tidiness, not speed.)
+        if (i == 0) {
+            g->pass_purpose = 1;
+            gen_ensure_stats(g, candidates.data(), candidates.size());
+        }
         const int64_t sampled = candidates[i];
         tried.push_back(sampled);
         const double d = g->stats.at(sampled).density;
@@ -3380,6 +3470,7 @@ void gen_fetch_hist(vh_gen* g, int64_t medoid, GenStats& st) {
             st.list_count = g->clu->last_counts[(int)(seq % kListRing)][0];
         }
         unsigned long long tmp0[VH_NBINS];
+        wait_for_hist(g->clu, seq + 1);
         memcpy(tmp0, g->clu->hist((int)(seq % kListRing)), sizeof(tmp0));
         for (int b = 0; b < VH_NBINS; ++b) st.hist_fx[b] = (int64_t)tmp0[b];
         st.have_hist = true;
@@ -3388,6 +3479,7 @@ void gen_fetch_hist(vh_gen* g, int64_t medoid, GenStats& st) {
     }
     if (st.born != g->n_emitted) g->hist_kept++;
     unsigned long long tmp[VH_NBINS];
+    wait_for_hist(g->clu, st.seq + 1);   // (the scan's pass flag has been seen; its histograms may still be on their way)
     memcpy(tmp, g->clu->hist((int)(st.seq % kListRing)) + (size_t)st.slot_j * VH_NBINS, sizeof(tmp));
     for (int b = 0; b < VH_NBINS; ++b) st.hist_fx[b] = (int64_t)tmp[b];
     st.have_hist = true;
