@@ -1780,7 +1780,8 @@ struct vh_clu {
     unsigned long long* flag() { return host_results + (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS); }
     unsigned long long* hist_flag() { return flag() + 1; }   // sequence number of the last pass whose HISTOGRAMS are in the ring (clu_publish2_kernel)
     int scan_dbg = 0;             // VAMBHIP_SCAN_DBG: timing experiments only (wrong results)
-    bool publish_split = true;    // option scan.publish_split: passes with more than 8 medoids publish their summaries first (clu_publish2_kernel)
+    int publish_split = 1;        // option scan.publish_split: 1 = passes with more than 8 medoids publish their summaries first
+                                  // (clu_publish2_kernel), 2 = every pass, 0 = none
     int max_k = kMaxMedoids;      // medoids per pass the LDS can hold for this latent width (query vectors are staged there)
     vh_comm* comm = nullptr;      // row-sharded execution (vh_clu_attach_comm): the ranks holding the other shards
     int64_t max_shard_ld = 0;     // largest padded shard over the ranks (size of the select exchange buffers)
@@ -2130,7 +2131,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->min_blocks = kMinScanBlocks;   // (measured neutral between 384 and 1536)
         h->scan_lc = (int)option("scan.column_loop", 1);
         h->use_mfma = option("scan.mfma", 1) != 0;
-        h->publish_split = option("scan.publish_split", 1) != 0;
+        h->publish_split = (int)option("scan.publish_split", 1);
         {
             const int64_t mode = option("scan.reference_order", 2);
             VH_REQUIRE(mode >= 0 && mode <= 2, "scan.reference_order: 0, 1 or 2");
@@ -2322,7 +2323,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
         VH_HIP(hipGetLastError());
     } else {
         const int pk = h->mfma_pass ? k : km;
-        if (pk > 8 && h->publish_split)
+        if ((pk > 8 && h->publish_split >= 1) || h->publish_split == 2)
             hipLaunchKernelGGL(clu_publish2_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, pk, h->results.p, h->summary(slot),
                                h->hist(slot), h->flag(), h->hist_flag(), (unsigned long long)(h->scan_seq + 1), h->scan_dbg);
         else
