@@ -52,8 +52,8 @@ const char* vh_version(void);
  *   scan.mfma (1)          passes with more than 8 medoids on the matrix-pipe kernels
  *   scan.mfma_rowmajor (1) ... on the row-major copy of the matrix (K6r); 0 = the column-major kernel, its compiler-scheduled twin
  *                          (the start-up self-test's fallback, vh_selftest)
- *   scan.publish_split (1) passes with more than 8 medoids publish the four summary words of every medoid first and their histograms
- *                          behind a second sequence flag (0: one step, as for the few-medoid passes); same results
+ *   scan.publish_split (1) a pass publishes the four summary words of every medoid first and the histograms behind a second sequence
+ *                          flag (0: everything in one step); same results
  *   gen.speculate (1), gen.spec_window (16)   medoid statistics scanned ahead of need in the free slots of a pass
  *   gen.prefill (2)        the speculative fill of a pass collected one pass ahead, under the running pass
  *   gen.inline_removals (1)  rows of an emitted cluster are cleared by the NEXT scan's own prologue (kernel arguments) instead of

@@ -1481,13 +1481,14 @@ __global__ __launch_bounds__(kPublishThreads) void clu_publish_kernel(int km, un
     }
 }
 
-// The same for passes with more than 8 medoids, in TWO steps (round 6).  In-kernel stamps (profiles/r06v_scan_timeline.txt) put the
-// publish kernel of a 32-medoid pass at 9.2 us: 5.6 us until the eight copies of 32 x 64 words are added up, 2.9 us until they are
-// in host memory.  What the state machine needs at once are the FOUR summary words of a medoid (density, two counts, list cursor);
-// the 60 histogram words are read for the one medoid a cluster is built around, later, if at all.  So: the summary words first
-// (128 threads, one round of eight loads each), fence, sequence flag -- then the histograms and the re-arming of the copies,
-// fence, a second flag (hist_flag) that the readers of the histogram ring wait for (wait_for_hist).  The next scan is ordered
-// behind this kernel by the stream, whatever the host does in between.
+// The same in TWO steps (round 6; the default).  In-kernel stamps (profiles/r06v_scan_timeline.txt) put the publish kernel of a
+// 32-medoid pass at 9.2 us: 5.6 us until the eight copies of 32 x 64 words are added up, 2.9 us until they are in host memory.  What
+// the state machine needs at once are the FOUR summary words of a medoid (density, two counts, list cursor); the 60 histogram words
+// are read for the one medoid a cluster is built around, later, if at all.  So: the summary words first (up to 128 threads, one round
+// of eight loads each), fence, sequence flag -- then the histograms and the re-arming of the copies, fence, a second flag (hist_flag)
+// that the readers of the histogram ring wait for (wait_for_hist).  The next scan is ordered behind this kernel by the stream, whatever
+// the host does in between.  Measured per C2 sweep on one box: -0.75 s behind the passes with more than 8 medoids, another -0.24 s
+// behind the others (profiles/r06y4_sweep_publish_split.txt, r06y5_sweep_publish_split_all.txt).
 __global__ __launch_bounds__(kPublishThreads) void clu_publish2_kernel(int km, unsigned long long* __restrict__ results,
                                                                        unsigned long long* __restrict__ host_summary,
                                                                        unsigned long long* __restrict__ host_hist,
@@ -1539,11 +1540,12 @@ __global__ __launch_bounds__(kBlock) void clu_select_kernel(const float* __restr
                                                             float threshold, int remove,
                                                             int32_t* __restrict__ out_rows,
                                                             unsigned int* __restrict__ out_count, int ref_L, float ref_slack,
-                                                            int ref_all) {
+                                                            int ref_all, const RmRows rm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* q_s = reinterpret_cast<float*>(smem_raw);
     __shared__ int32_t med_one[1];   // (the reference-order re-evaluation takes medoid rows from an array)
     const int tid = threadIdx.x;
+    apply_removals(kept, rm);   // rows the state machine removed since the last pass (as in the scans: in front of the prologue's barrier)
     for (int i = tid; i < L4; i += kBlock) q_s[i] = q_ext ? q_ext[i] : Mt[(int64_t)i * ld + medoid];
     if (tid == 0) med_one[0] = (int32_t)medoid;
     __syncthreads();
@@ -1780,8 +1782,8 @@ struct vh_clu {
     unsigned long long* flag() { return host_results + (size_t)kListRing * kMaxMedoids * (4 + VH_NBINS); }
     unsigned long long* hist_flag() { return flag() + 1; }   // sequence number of the last pass whose HISTOGRAMS are in the ring (clu_publish2_kernel)
     int scan_dbg = 0;             // VAMBHIP_SCAN_DBG: timing experiments only (wrong results)
-    int publish_split = 1;        // option scan.publish_split: 1 = passes with more than 8 medoids publish their summaries first
-                                  // (clu_publish2_kernel), 2 = every pass, 0 = none
+    bool publish_split = true;    // option scan.publish_split: a pass publishes its summary words first, its histograms behind a second flag
+                                  // (clu_publish2_kernel); 0 = everything in one step (clu_publish_kernel)
     int max_k = kMaxMedoids;      // medoids per pass the LDS can hold for this latent width (query vectors are staged there)
     vh_comm* comm = nullptr;      // row-sharded execution (vh_clu_attach_comm): the ranks holding the other shards
     int64_t max_shard_ld = 0;     // largest padded shard over the ranks (size of the select exchange buffers)
@@ -2131,7 +2133,7 @@ int vh_clu_create(const float* matrix, const float* lengths, int64_t n, int L, i
         h->min_blocks = kMinScanBlocks;   // (measured neutral between 384 and 1536)
         h->scan_lc = (int)option("scan.column_loop", 1);
         h->use_mfma = option("scan.mfma", 1) != 0;
-        h->publish_split = (int)option("scan.publish_split", 1);
+        h->publish_split = option("scan.publish_split", 1) != 0;
         {
             const int64_t mode = option("scan.reference_order", 2);
             VH_REQUIRE(mode >= 0 && mode <= 2, "scan.reference_order: 0, 1 or 2");
@@ -2323,7 +2325,7 @@ int scan_core(vh_clu* h, int k, const int64_t* medoid_rows, const float* queries
         VH_HIP(hipGetLastError());
     } else {
         const int pk = h->mfma_pass ? k : km;
-        if ((pk > 8 && h->publish_split >= 1) || h->publish_split == 2)
+        if (h->publish_split)
             hipLaunchKernelGGL(clu_publish2_kernel, dim3(1), dim3(kPublishThreads), 0, h->stream, pk, h->results.p, h->summary(slot),
                                h->hist(slot), h->flag(), h->hist_flag(), (unsigned long long)(h->scan_seq + 1), h->scan_dbg);
         else
@@ -2480,7 +2482,7 @@ int64_t select_sharded_core(vh_clu* h, int64_t local_row, const float* query, fl
     h->timer.start(h->stream);
     hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
                        h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, h->q.p, local_row, threshold, remove,
-                       h->sel_rows.p, h->counts.p, h->ref_order ? h->L : 0, ref_slack(h->L), h->ref_filter ? 0 : 1);
+                       h->sel_rows.p, h->counts.p, h->ref_order ? h->L : 0, ref_slack(h->L), h->ref_filter ? 0 : 1, RmRows{});
     VH_HIP(hipGetLastError());
     h->timer.stop(h->stream);
     const size_t bw = 1 + (size_t)kSelXCap;
@@ -2579,11 +2581,11 @@ int vh_clu_select(vh_clu* h, int64_t medoid_row, const float* query, float thres
             q_ext = h->q.p;
         }
         // counts[0] is zero on entry (creation / re-armed by the publish kernel of the previous select)
-        flush_pending_rm(h);
+        take_pending_rm(h);   // (up to kRmCap removed rows ride in the kernel's arguments, as in the scans; longer lists keep their launch)
         h->timer.start(h->stream);
         hipLaunchKernelGGL(clu_select_kernel, dim3(scan_grid(h->n_rows)), dim3(kBlock), (size_t)h->L4 * 4, h->stream,
                            h->Mt.p, h->ld, h->L4, h->kept.p, h->ld, q_ext, medoid_row, threshold, remove,
-                           h->sel_rows.p, h->counts.p, h->ref_order ? h->L : 0, ref_slack(h->L), h->ref_filter ? 0 : 1);
+                           h->sel_rows.p, h->counts.p, h->ref_order ? h->L : 0, ref_slack(h->L), h->ref_filter ? 0 : 1, h->rm_pass);
         VH_HIP(hipGetLastError());
         h->timer.stop(h->stream);
         // count and (short) row list travel through host-mapped memory; the host spins on the sequence flag
