@@ -2897,6 +2897,7 @@ struct vh_gen {
     struct Pending { int64_t row; int slot; int j; uint64_t seq; int64_t born; };
     std::vector<Pending> pending;
     std::vector<uint8_t> pending_mark;   // [current rows]: 1 while the row is in `pending`
+    std::vector<uint8_t> tried_mark;     // [current rows]: 1 while the row is in the running walk's `tried` list (gen_wander)
     bool defer_book = true;         // option gen.defer_bookkeeping
     // Removal log: one record per emitted cluster (index = emission count at the time), the rows it removed by ORIGINAL index.
     // Cached statistics are validated against it lazily, when they are looked at (gen_lookup), instead of eagerly at every
@@ -2925,6 +2926,8 @@ struct vh_gen {
     int64_t max_entry_age = kMaxEntryAgeDefault;   // option gen.max_entry_age
     int spec_depth = 2;             // option gen.spec_depth: 1 = within-radius rows of upcoming seeds, 2 = also THEIR within-radius rows
     double t_validate = 0, t_fill = 0, t_book = 0, t_emit = 0, t_book_hidden = 0;   // profile: lazy validation, speculative fill, post-scan bookkeeping, emission
+    // profile, INCLUSIVE times of the top-level pieces of one emission (scans and selects inside them included):
+    double t_wander_incl = 0, t_hist_incl = 0, t_threshold = 0, t_members = 0, t_live = 0, t_pack_incl = 0, t_sample = 0, t_within = 0;
     // Speculative fill one pass AHEAD (option gen.prefill): while a pass runs on the GPU the host already collects the rows it
     // would add to the NEXT pass's free slots; that pass takes the rows of the list that are still unscanned and live and walks
     // the pools again only when the list comes up short although it had been cut at the slot count.  What is scanned ahead never
@@ -3392,7 +3395,15 @@ void gen_update_successes(vh_gen* g, bool success) {
 // cluster.py:415-450
 int64_t gen_wander(vh_gen* g, int64_t seed) {
     int64_t medoid = seed;
+    // rows this walk has sampled so far (cluster.py:425 `tried`): a list to undo the marks with, a byte per row to test membership --
+    // a pool of a large cluster is up to kListCap rows, and each round used to compare every one of them with the whole list
     std::vector<int64_t> tried{medoid};
+    if (g->tried_mark.size() < g->kept.size()) g->tried_mark.assign(g->kept.size(), 0);
+    g->tried_mark[(size_t)medoid] = 1;
+    struct Unmark {
+        vh_gen* g; std::vector<int64_t>& t;
+        ~Unmark() { for (int64_t r : t) g->tried_mark[(size_t)r] = 0; }
+    } unmark{g, tried};
     g->seeds_total++;
     if (gen_lookup(g, seed) != nullptr) g->seeds_cached++;
     g->pass_purpose = 0;
@@ -3400,12 +3411,23 @@ int64_t gen_wander(vh_gen* g, int64_t seed) {
     double local_density = g->stats.at(seed).density;
     auto untried = [&](const std::vector<int64_t>& rows) {
         std::vector<int64_t> c;
+        c.reserve(rows.size());
         for (int64_t r : rows)
-            if (std::find(tried.begin(), tried.end(), r) == tried.end()) c.push_back(r);
+            if (g->tried_mark[(size_t)r] == 0) c.push_back(r);
         return c;
     };
-    std::vector<int64_t> pool = untried(gen_within(g, seed)), candidates;
-    g->rng.sample(pool, (int)std::min<size_t>(pool.size(), (size_t)g->maxsteps), candidates);
+    std::vector<int64_t> pool, candidates;
+    auto draw = [&](int64_t from) {
+        const std::vector<int64_t>* w;
+        {
+            GenTimer tw(&g->t_within);
+            w = &gen_within(g, from);
+        }
+        GenTimer ts(&g->t_sample);
+        pool = untried(*w);
+        g->rng.sample(pool, (int)std::min<size_t>(pool.size(), (size_t)g->maxsteps), candidates);
+    };
+    draw(seed);
     size_t i = 0;
     while (i < candidates.size()) {
         // look ahead: every not-yet-scanned candidate of this round shares one matrix pass
@@ -3426,13 +3448,13 @@ int64_t gen_wander(vh_gen* g, int64_t seed) {
         }
         const int64_t sampled = candidates[i];
         tried.push_back(sampled);
+        g->tried_mark[(size_t)sampled] = 1;
         const double d = g->stats.at(sampled).density;
         if (d > local_density) {
             medoid = sampled;
             local_density = d;
             g->wander_moves++;
-            pool = untried(gen_within(g, sampled));
-            g->rng.sample(pool, (int)std::min<size_t>(pool.size(), (size_t)g->maxsteps), candidates);
+            draw(sampled);
             i = 0;
         } else {
             ++i;
@@ -3702,6 +3724,9 @@ int vh_gen_destroy(vh_gen* g) {
                 "post-scan bookkeeping %.1f ms (+ %.1f ms under the next pass), removal log + eviction %.1f ms; fill one pass ahead: %.1f ms "
                 "under the passes, %lld lists used as they were, %lld topped up\n", g->t_validate, g->t_fill, g->t_book, g->t_book_hidden, g->t_emit,
                 g->t_fill_hidden, g->prefill_hits, g->prefill_topups);
+        fprintf(stderr, "[vambhip]   inclusive times of an emission's pieces: walk %.1f ms (of it: within-radius lists %.1f, untried + sample %.1f), "
+                "histogram %.1f, threshold %.1f, member copy %.1f, live flags + rank tree %.1f, rest of the emission incl. compaction %.1f\n",
+                g->t_wander_incl, g->t_within, g->t_sample, g->t_hist_incl, g->t_threshold, g->t_members, g->t_live, g->t_pack_incl);
         fprintf(stderr, "[vambhip]   passes by purpose: seed scans %lld, candidate rounds %lld, histogram re-scans %lld, selects %lld (+ %lld list selects); "
                 "seeds %lld (cached at arrival %lld), candidate rounds %lld (fully cached %lld, %lld candidates to scan), medoid moves %lld; "
                 "cached entries per emission %.1f; lazy validations %lld (%lld cluster tests, %lld row tests, %lld invalid), histograms reused %lld\n",
@@ -3737,11 +3762,22 @@ void gen_next_impl(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t c
         double emitted_radius = 0.0;
         while (true) {
             const int64_t seed = gen_next_seed(g);
-            const int64_t medoid = gen_wander(g, seed);
+            int64_t medoid;
+            {
+                GenTimer tw(&g->t_wander_incl);
+                medoid = gen_wander(g, seed);
+            }
             GenStats& st = g->stats.at(medoid);
             double threshold = 0.0, observed = 0.0;
-            if (st.n_lt != 1) gen_fetch_hist(g, medoid, st);
-            const ThresholdKind kind = gen_find_threshold(g, st, &threshold, &observed);
+            if (st.n_lt != 1) {
+                GenTimer th(&g->t_hist_incl);
+                gen_fetch_hist(g, medoid, st);
+            }
+            ThresholdKind kind;
+            {
+                GenTimer tt(&g->t_threshold);
+                kind = gen_find_threshold(g, st, &threshold, &observed);
+            }
             const int64_t original = g->indices[(size_t)medoid];
             info->medoid = original;
             info->maximal_pvr = g->pvr;
@@ -3786,7 +3822,10 @@ void gen_next_impl(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t c
             break;
         }
         VH_REQUIRE((int64_t)points.size() <= cap, "members buffer too small");
-        for (size_t i = 0; i < points.size(); ++i) members[i] = g->indices[(size_t)points[i]];
+        {
+            GenTimer tm(&g->t_members);
+            for (size_t i = 0; i < points.size(); ++i) members[i] = g->indices[(size_t)points[i]];
+        }
         info->n_members = (int64_t)points.size();
         // __next__ bookkeeping.  The reference clears its sample_medoid cache here because a removal may change any cached
         // result (cluster.py:298-316).  Here the removal goes into a log and cached entries are validated against it when they
@@ -3833,11 +3872,15 @@ void gen_next_impl(vh_gen* g, vh_cluster_info* info, int64_t* members, int64_t c
         }
         g->n_emitted++;
         g->n_remaining -= (int64_t)points.size();
-        for (int64_t r : points) {
-            g->kept[(size_t)r] = 0;
-            g->alive[(size_t)g->indices[(size_t)r]] = 0;
-            gen_bit_remove(g, r);
+        {
+            GenTimer tl(&g->t_live);
+            for (int64_t r : points) {
+                g->kept[(size_t)r] = 0;
+                g->alive[(size_t)g->indices[(size_t)r]] = 0;
+                gen_bit_remove(g, r);
+            }
         }
+        GenTimer tpk(&g->t_pack_incl);   // (to the end of the emission: the compaction, when one is due)
         const int64_t n_rows = (int64_t)g->kept.size();
         if (g->n_remaining > 0 && n_rows >= g->pack_min_rows && (double)g->n_remaining < g->pack_fraction * (double)n_rows) {
             int64_t new_n = 0;
