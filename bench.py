@@ -226,7 +226,7 @@ def scan_summary(timed, wall, measured_in):
 
 def pmc_traffic(tag, want_source=False):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
-    for rnd in ("r06f5", "r06f4", "r06zzz", "r06zz", "r06y", "r05z", "r04t", "r03"):   # the latest committed passes first
+    for rnd in ("r06f6", "r06f5", "r06f4", "r06zzz", "r06zz", "r06y", "r05z", "r04t", "r03"):   # the latest committed passes first
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_roofline_{tag}.json")
         try:
             with open(path) as fh:
@@ -673,8 +673,8 @@ def main():
                                        "(bias + leaky-relu + dropout + BatchNorm batch sums in the epilogue)", peak)
         if roof is not None:
             roof["traffic"], src = pmc_traffic(cfg_name.lower(), want_source=True)
-            roof["traffic_source"] = (f"static: {src} (rocprofv3 --pmc passes of this kernel at this shape, profiles/run_r06_final5.sh "
-                                      "for r06f5 / run_r06_final4.sh for r06f4: FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE, "
+            roof["traffic_source"] = (f"static: {src} (rocprofv3 --pmc passes of this kernel at this shape, profiles/run_r06_final6.sh "
+                                      "for r06f6 / run_r06_final5.sh for r06f5: FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE, "
                                       "separate passes); NOT counted in this run")
             if roof["traffic"]:
                 # the same launches against the other roofline: at C2 the kernel's arithmetic intensity (flops / PMC bytes)

@@ -3239,7 +3239,9 @@ void gen_ensure_stats(vh_gen* g, const int64_t* medoids, size_t n) {
         size_t target = (size_t)pick_km((int)std::min<size_t>(missing.size(), kMaxMedoids));
         if (g->clu->max_k < kMaxMedoids) target = std::min(missing.size(), (size_t)g->clu->max_k);   // wide latents: no widening
         else if (scan_uses_mfma(g->clu, (int)std::min<size_t>(missing.size(), kMaxMedoids))) target = kMaxMedoids;   // matrix-pipe pass: 32 medoids cost what 9 cost
-        else if (g->clu->n_rows <= 600000) target = kMaxMedoids;  // latency-bound pass: extra medoids are free
+        else if (g->clu->n_rows <= 600000) target = kMaxMedoids;  // latency-bound pass: extra medoids are free (the limit re-measured
+                                                                   // in round 6 with the cheaper 32-slot pass: 400 k / 600 k / 900 k / 1.3 M /
+                                                                   // 2.1 M rows give 11.55 / 10.7-11.4 / 10.9 / 11.1-11.2 / 11.3 s per C2 sweep)
         else if (g->spec_big_target > 0 && missing.size() <= 8) target = std::max(target, (size_t)g->spec_big_target);
         else if (missing.size() == 1) target = 8;
         if (missing.size() < target && missing.size() < (size_t)kMaxMedoids) {
