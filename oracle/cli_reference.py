@@ -12,6 +12,11 @@
   writer) and a ``backend_factory`` for the cluster generator (``tests/oracle_backend.py``); on a machine with a GPU and the
   reference tree both would be the product's.
 
+``family="taxvamb"`` does the same for ``vamb bin taxvamb --no_predictor`` (``run_vaevae``, ``vamb/__main__.py:1940-2068``): the
+names recorded are ``vamb.encode.make_dataloader``, ``vamb.taxvamb_encode.{make_dataloader_concat_hloss,
+make_dataloader_labels_hloss, make_dataloader_semisupervised_hloss, VAEVAEHLoss}``, ``VAEVAEHLoss.trainmodel``, the joint
+network's ``encode`` and ``vamb.cluster.ClusterGenerator``; the drop-in is installed with ``semisupervised=True``.
+
 Used by ``tests/golden/make_cli_golden.py`` and ``tests/test_cli_dropin.py``.
 """
 from __future__ import annotations
@@ -73,9 +78,12 @@ def _describe(v):
     if isinstance(v, torch.Tensor):
         return {"kind": "Tensor", "shape": list(v.shape), "dtype": str(v.dtype)}
     if isinstance(v, torch.utils.data.DataLoader):
+        tensors = getattr(v.dataset, "tensors", None)
         return {"kind": "DataLoader", "batch_size": v.batch_size,
-                "tensors": [{"shape": list(t.shape), "dtype": str(t.dtype)} for t in v.dataset.tensors]}
+                "tensors": None if tensors is None else [{"shape": list(t.shape), "dtype": str(t.dtype)} for t in tensors]}
     if isinstance(v, (list, tuple)):
+        if len(v) > 16:   # (the node list / parent table of a taxonomy: by length and element type)
+            return {"kind": "list", "len": len(v), "of": type(v[0]).__name__}
         return [_describe(x) for x in v]
     return {"kind": type(v).__name__}
 
@@ -133,7 +141,82 @@ def _recording_bindings(vamb, trace: CallTrace):
     return orig
 
 
-def run_cli(argv, binding: str = "reference", vae: str = "bound", backend_factory=None, threads: int = 4):
+def taxonomy_lines(names, labels):
+    """A synthetic seven-rank taxonomy of the synthetic genomes (label g): genus / family / ... shared by genomes with equal
+    g mod 48 / 24 / ...; some genomes annotated to order only, some not at all -- as a real classifier's output is."""
+    out = []
+    for nm, g in zip(names, labels):
+        g = int(g)
+        ranks = ["d_Bacteria", f"p_{g % 3}", f"c_{g % 6}", f"o_{g % 12}", f"f_{g % 24}", f"g_{g % 48}", f"s_{g}"]
+        k = 0 if g % 11 == 0 else (4 if g % 5 == 0 else 7)
+        out.append(f"{nm}\t{';'.join(ranks[:k])}")
+    return out
+
+
+def write_taxonomy(tmpdir, names, labels):
+    """The unrefined taxonomy file ``vamb bin taxvamb --taxonomy`` reads (vamb/taxonomy.py:8, 61-120)."""
+    path = Path(tmpdir) / "taxonomy.tsv"
+    path.write_text("contigs\tpredictions\n" + "\n".join(taxonomy_lines(names, labels)) + "\n")
+    return path
+
+
+TAXVAMB_FUNCTIONS = ("make_dataloader_concat_hloss", "make_dataloader_labels_hloss", "make_dataloader_semisupervised_hloss")
+
+
+def _recording_bindings_taxvamb(vamb, trace: CallTrace):
+    """Proxies around the names ``run_vaevae`` (vamb/__main__.py:1940-2068) looks up; returns what the restore needs."""
+    enc, clu, tx = vamb.encode, vamb.cluster, vamb.taxvamb_encode
+    orig = {"functions": [(enc, "make_dataloader", enc.make_dataloader)] + [(tx, n, getattr(tx, n)) for n in TAXVAMB_FUNCTIONS]}
+
+    def proxy(mod, name, inner, label):
+        def wrapper(*a, **k):
+            out = inner(*a, **k)
+            trace.record(label, a, k, out)
+            return out
+
+        setattr(mod, name, wrapper)
+
+    proxy(enc, "make_dataloader", enc.make_dataloader, "vamb.encode.make_dataloader")
+    for n in TAXVAMB_FUNCTIONS:
+        proxy(tx, n, getattr(tx, n), "vamb.taxvamb_encode." + n)
+    VV, CG = tx.VAEVAEHLoss, clu.ClusterGenerator
+    joint = tx.VAEConcatHLoss            # the class of VAEVAEHLoss.VAEJoint; `encode` is inherited from VAEConcat
+    orig["methods"] = [(VV, "__init__", VV.__init__), (VV, "trainmodel", VV.trainmodel), (CG, "__init__", CG.__init__)]
+    orig["joint_encode_added"] = "encode" not in joint.__dict__
+    if not orig["joint_encode_added"]:
+        orig["methods"].append((joint, "encode", joint.__dict__["encode"]))
+    orig["joint"] = joint
+
+    def wrap(cls, meth, label, with_result):
+        inner = getattr(cls, meth)
+
+        def wrapper(self, *a, **k):
+            if not with_result:
+                trace.record(label, a, k)
+                return inner(self, *a, **k)
+            out = inner(self, *a, **k)
+            trace.record(label, a, k, out)
+            return out
+
+        setattr(cls, meth, wrapper)
+
+    wrap(VV, "__init__", "vamb.taxvamb_encode.VAEVAEHLoss", False)
+    wrap(VV, "trainmodel", "VAEVAEHLoss.trainmodel", False)
+    wrap(joint, "encode", "VAEJoint.encode", True)
+    wrap(CG, "__init__", "vamb.cluster.ClusterGenerator", False)
+    return orig
+
+
+def _restore_taxvamb(orig):
+    for mod, name, fn in orig["functions"]:
+        setattr(mod, name, fn)
+    for cls, meth, fn in orig["methods"]:
+        setattr(cls, meth, fn)
+    if orig["joint_encode_added"]:
+        delattr(orig["joint"], "encode")
+
+
+def run_cli(argv, binding: str = "reference", vae: str = "bound", backend_factory=None, threads: int = 4, family: str = "default"):
     """Run the reference's real ``main()`` with ``sys.argv = ["vamb"] + argv``.  Returns a dict: ``trace`` (the recorded calls,
     binding "reference" only), ``log`` (the messages the CLI logged), ``outdir``."""
     import torch
@@ -141,7 +224,7 @@ def run_cli(argv, binding: str = "reference", vae: str = "bound", backend_factor
     vamb, main = ref_main.load_reference_main()
     outdir = Path(argv[argv.index("--outdir") + 1])
     log = ref_main.RecordingLogger()
-    loggers_of = [main, vamb.encode]
+    loggers_of = [main, vamb.encode] + ([vamb.taxvamb_encode, vamb.semisupervised_encode] if family == "taxvamb" else [])
     if binding == "dropin":   # the product's writer logs the reference's lines through its own module-level logger
         from vamb_amd import output as _output
 
@@ -156,15 +239,20 @@ def run_cli(argv, binding: str = "reference", vae: str = "bound", backend_factor
     argv_before = list(sys.argv)
     try:
         if binding == "reference":
-            restore = _recording_bindings(vamb, trace)
+            restore = _recording_bindings_taxvamb(vamb, trace) if family == "taxvamb" else _recording_bindings(vamb, trace)
         elif binding == "dropin":
             from vamb_amd import cluster as vc, dropin
 
-            dropin_saved = dropin.install(vamb, strict=True)
+            dropin_saved = dropin.install(vamb, semisupervised=family == "taxvamb", strict=True)
             if vae == "reference":   # no GPU in the build container: the model side stays the reference's
                 vamb.encode.VAE = dropin_saved["VAE"]
                 vamb.encode.make_dataloader = dropin_saved["make_dataloader"]
                 vamb.encode.set_batchsize = dropin_saved["set_batchsize"]
+                if family == "taxvamb":
+                    for n, obj in dropin_saved["semisupervised"].items():
+                        setattr(vamb.semisupervised_encode, n, obj)
+                    for n, obj in dropin_saved["taxvamb"].items():
+                        setattr(vamb.taxvamb_encode, n, obj)
             if backend_factory is not None:
                 base = vc.ClusterGenerator
 
@@ -190,7 +278,9 @@ def run_cli(argv, binding: str = "reference", vae: str = "bound", backend_factor
         torch.set_num_threads(nthreads_before)
         for m, lg in saved_loggers.items():
             m.logger = lg
-        if restore is not None:
+        if restore is not None and family == "taxvamb":
+            _restore_taxvamb(restore)
+        elif restore is not None:
             vamb.encode.make_dataloader, vamb.encode.set_batchsize = restore["make_dataloader"], restore["set_batchsize"]
             for cls, meth, fn in restore["methods"]:
                 setattr(cls, meth, fn)
@@ -201,15 +291,16 @@ def run_cli(argv, binding: str = "reference", vae: str = "bound", backend_factor
     return {"trace": trace.calls, "log": log.messages, "outdir": outdir}
 
 
-def read_outputs(outdir) -> dict:
-    """The files ``vamb bin default`` leaves (``vamb/__main__.py:1096, 1310-1312``)."""
+def read_outputs(outdir, prefix: str = "vae", latent_name: str = "latent.npz") -> dict:
+    """The files ``vamb bin default`` leaves (``vamb/__main__.py:1096, 1310-1312``); ``prefix="vaevae"``,
+    ``latent_name="vaevae_latent.npz"`` for ``vamb bin taxvamb`` (``:2048-2066``)."""
     outdir = Path(outdir)
     out = {}
-    for name in ("vae_clusters_metadata.tsv", "vae_clusters_unsplit.tsv", "vae_clusters_split.tsv"):
+    for name in (f"{prefix}_clusters_metadata.tsv", f"{prefix}_clusters_unsplit.tsv", f"{prefix}_clusters_split.tsv"):
         p = outdir / name
         out[name] = p.read_text() if p.exists() else None
     vt = ref_harness.load_reference()[0]
-    out["latent"] = vt.read_npz(outdir / "latent.npz") if hasattr(vt, "read_npz") else np.load(outdir / "latent.npz")["arr_0"]
+    out["latent"] = vt.read_npz(outdir / latent_name) if hasattr(vt, "read_npz") else np.load(outdir / latent_name)["arr_0"]
     out["files"] = sorted(p.name for p in outdir.iterdir())
     return out
 

@@ -115,3 +115,74 @@ def test_real_cli_with_the_drop_in_bound_writes_the_reference_files(tmp_path):
         return [m for m in lines if "seconds" not in m and "Invoked with" not in m and ".npz" not in m and "Epoch:" not in m]
 
     assert visible(m for _, m in r["log"]) == visible(TRACE["log"])
+
+
+# ---- `vamb bin taxvamb --no_predictor`: run_vaevae (vamb/__main__.py:1940-2068) with install(semisupervised=True) ----------------
+TRACE_TAX = json.load(open(os.path.join(HERE, "golden", "cli_bin_taxvamb_trace.json")))
+
+
+def _targets_taxvamb():
+    from vamb_amd import cluster as vc, encode as ve, semisupervised_encode as vs, taxvamb_encode as vt
+
+    return {"vamb.encode.make_dataloader": (ve.make_dataloader, False),
+            "vamb.taxvamb_encode.make_dataloader_concat_hloss": (vt.make_dataloader_concat_hloss, False),
+            "vamb.taxvamb_encode.make_dataloader_labels_hloss": (vt.make_dataloader_labels_hloss, False),
+            "vamb.taxvamb_encode.make_dataloader_semisupervised_hloss": (vt.make_dataloader_semisupervised_hloss, False),
+            "vamb.taxvamb_encode.VAEVAEHLoss": (vt.VAEVAEHLoss.__init__, True), "VAEVAEHLoss.trainmodel": (vt.VAEVAEHLoss.trainmodel, True),
+            "VAEJoint.encode": (vt.VAEConcatHLoss.encode, True), "vamb.cluster.ClusterGenerator": (vc.ClusterGenerator.__init__, True)}
+
+
+def test_every_recorded_taxvamb_cli_call_binds_to_the_products_signatures():
+    """Runs anywhere.  Every call the reference's run_vaevae makes on the names install(semisupervised=True) rebinds -- and the calls
+    the reference's own loaders make on vamb.encode.make_dataloader from inside -- is a valid call of the product's function."""
+    targets = _targets_taxvamb()
+    seen = []
+    for call in TRACE_TAX["trace"]:
+        fn, is_method = targets[call["name"]]
+        args = ([object()] if is_method else []) + list(call["args"])
+        bound = inspect.signature(fn).bind(*args, **call["kwargs"])
+        assert not any(k.startswith("_") for k in bound.arguments), "the CLI never passes a private parameter"
+        seen.append(call["name"])
+    assert set(seen) == set(targets), "the recorded run exercised every rebound name"
+    # the CLI's own call order (vamb/__main__.py:1986, 1999, 2006, 2017, 2029, 2043, 2051, 2058); the two bare make_dataloader calls
+    # come from inside the reference's concat / labels loaders
+    outer = [c["name"] for c in TRACE_TAX["trace"] if not (c["name"] == "vamb.encode.make_dataloader" and not c["kwargs"])]
+    assert outer == ["vamb.taxvamb_encode.VAEVAEHLoss", "vamb.encode.make_dataloader", "vamb.taxvamb_encode.make_dataloader_concat_hloss",
+                     "vamb.taxvamb_encode.make_dataloader_labels_hloss", "vamb.taxvamb_encode.make_dataloader_semisupervised_hloss",
+                     "VAEVAEHLoss.trainmodel", "VAEJoint.encode", "vamb.cluster.ClusterGenerator"]
+
+
+@needs_reference
+def test_real_taxvamb_cli_with_the_drop_in_bound_writes_the_reference_files(tmp_path):
+    """``vamb bin taxvamb --no_predictor`` -- the reference's main(), option classes, run_vaevae -- with
+    dropin.install(semisupervised=True) active.  No GPU here: the three networks stay the reference's (same seed, same threads: the
+    golden run's latent, checked), the product's ClusterGenerator runs on the oracle backend inside the product's writer."""
+    import cli_reference as cr
+    import make_cli_golden as mk
+    from oracle_backend import OracleScanBackend
+    from vamb_amd import synth
+
+    g = np.load(os.path.join(HERE, "golden", "cli_bin_taxvamb.npz"))
+    c = TRACE_TAX["case"]
+    comp, abundance, names, _ = cr.write_inputs(str(tmp_path), c["n"], c["nsamples"], c["data_seed"])
+    assert list(names) == list(g["names"])
+    _, _, _, labels = synth.features(c["n"], c["nsamples"], seed=c["data_seed"])
+    assert cr.taxonomy_lines(names, labels) == [str(x) for x in g["taxonomy_lines"]]
+    taxonomy = cr.write_taxonomy(str(tmp_path), names, labels)
+    out = tmp_path / "out"
+    r = cr.run_cli(mk.argv_for_taxvamb(c, out, comp, abundance, taxonomy, c["seed"]), binding="dropin", vae="reference",
+                   backend_factory=OracleScanBackend, family="taxvamb")
+    files = cr.read_outputs(out, prefix="vaevae", latent_name="vaevae_latent.npz")
+    assert files["files"] == TRACE_TAX["files"]
+    if not np.array_equal(files["latent"], g["latent"]):
+        pytest.skip("the reference's CPU training did not reproduce the golden latent bit for bit on this host")
+    assert files["vaevae_clusters_metadata.tsv"] == str(g["metadata_tsv"])
+    assert files["vaevae_clusters_unsplit.tsv"] == str(g["unsplit_tsv"])
+    a, b = files["vaevae_clusters_split.tsv"].splitlines(), str(g["split_tsv"]).splitlines()
+    assert a[0] == b[0] and sorted(a) == sorted(b)
+
+    def visible(lines):
+        return [m for m in lines if "seconds" not in m and "Invoked with" not in m and ".npz" not in m and ".tsv" not in m
+                and "Epoch:" not in m]
+
+    assert visible(m for _, m in r["log"]) == visible(TRACE_TAX["log"])

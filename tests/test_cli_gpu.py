@@ -135,3 +135,122 @@ def test_replay_of_the_real_clis_calls(tmp_path):
     assert q["purity_big"] >= g["spread_purity_big"].min() - 0.01
     assert 0.7 * g["spread_n_clusters"].min() <= q["n_clusters"] <= 1.3 * g["spread_n_clusters"].max(), q["n_clusters"]
     assert q["genomes_recovered"] >= g["spread_genomes_recovered"].min() - 3
+
+
+# ---- `vamb bin taxvamb --no_predictor` (run_vaevae, vamb/__main__.py:1940-2068) replayed with install(semisupervised=True)'s classes ----
+TRACE_TAX = json.load(open(os.path.join(HERE, "golden", "cli_bin_taxvamb_trace.json")))
+
+
+def test_replay_of_the_real_taxvamb_clis_calls(tmp_path):
+    """The recorded calls of the reference's run_vaevae, in their positional / keyword form, on the product's TaxVamb classes:
+    (a) every call is accepted and returns what the CLI's next statement uses (loader tensors, the joint latent's shape);
+    (b) on the latent the REFERENCE wrote the product's generator + writer give the reference's files byte for byte;
+    (c) the free-running joint trainer's last loss and the bins of its latent land in the spread of three reference CLI runs."""
+    from vamb_amd import encode as ve, output, synth, taxvamb_encode as vt
+
+    c = TRACE_TAX["case"]
+    g = np.load(os.path.join(HERE, "golden", "cli_bin_taxvamb.npz"))
+    ab, tnf, lens, labels = synth.features(c["n"], c["nsamples"], seed=c["data_seed"])
+    lens32 = lens.astype(np.int32)
+    assert np.array_equal(lens, g["lengths"])
+    names = [str(x) for x in g["names"]]
+    # Taxonomy.from_file (vamb/taxonomy.py:61-120, 30-35): one ContigTaxonomy per contig, ranks split at ';', [] for an empty field
+    taxes = []
+    for nm, line in zip(names, (str(x) for x in g["taxonomy_lines"])):
+        contig, pred = line.split("\t")
+        assert contig == nm
+        taxes.append(types.SimpleNamespace(ranks=pred.split(";") if pred else []))
+    nodes, ind_nodes, table_parent = vt.make_graph(taxes)                      # __main__.py:1981-1983
+    targets = np.array([ind_nodes["root" if len(t.ranks) == 0 else t.ranks[-1]] for t in taxes])   # :1984-1990
+
+    calls = TRACE_TAX["trace"]
+    # (the two bare make_dataloader calls come from INSIDE the reference's concat / labels loaders: the product's business)
+    cli_calls = [x for x in calls if not (x["name"] == "vamb.encode.make_dataloader" and not x["kwargs"])]
+    state = {}
+
+    def live(desc, arrays, lists, loaders):
+        if isinstance(desc, dict):
+            kind = desc["kind"]
+            if kind == "ndarray":
+                return next(arrays)
+            if kind == "list":
+                return lists[desc["of"]]
+            if kind == "DataLoader":
+                return next(loaders)
+            if kind == "BufferedWriter":
+                return state["modelfile"]
+            raise AssertionError(kind)
+        return desc
+
+    def tensors_of(loader):
+        return [(list(t.shape), str(t.dtype)) for t in loader.dataset.tensors]
+
+    latent = None
+    gen_kwargs = None
+    for call in cli_calls:
+        name = call["name"]
+        arrays = iter([ab, tnf, lens32, targets])
+        lists = {"str": nodes, "int": table_parent}
+        loaders = iter([state.get("joint"), state.get("vamb"), state.get("labels")])
+        if name == "vamb.cluster.ClusterGenerator":
+            assert [a["kind"] for a in call["args"]] == ["ndarray", "ndarray"]
+            gen_kwargs = dict(call["kwargs"])
+            continue
+        if name == "VAEVAEHLoss.trainmodel":
+            loaders = iter([state["semi"]])
+            state["modelfile"] = open(Path(tmp_path) / "vaevae_model.pt", "wb")
+        if name == "VAEJoint.encode":
+            loaders = iter([state["joint"]])
+        args = [live(a, arrays, lists, loaders) for a in call["args"]]
+        kwargs = {k: live(v, arrays, lists, loaders) for k, v in call["kwargs"].items()}
+        if name == "vamb.taxvamb_encode.VAEVAEHLoss":
+            assert args[1] == len(nodes) and call["args"][2]["len"] == len(nodes) and call["args"][3]["len"] == len(table_parent)
+            state["vae"] = vt.VAEVAEHLoss(*args, **kwargs)
+        elif name == "vamb.encode.make_dataloader":
+            state["vamb"] = ve.make_dataloader(*args, **kwargs)
+            assert tensors_of(state["vamb"]) == [(t["shape"], t["dtype"]) for t in call["result"]["tensors"]]
+        elif name == "vamb.taxvamb_encode.make_dataloader_concat_hloss":
+            state["joint"] = vt.make_dataloader_concat_hloss(*args, **kwargs)
+            assert tensors_of(state["joint"]) == [(t["shape"], t["dtype"]) for t in call["result"]["tensors"]]
+        elif name == "vamb.taxvamb_encode.make_dataloader_labels_hloss":
+            state["labels"] = vt.make_dataloader_labels_hloss(*args, **kwargs)
+            assert tensors_of(state["labels"]) == [(t["shape"], t["dtype"]) for t in call["result"]["tensors"]]
+        elif name == "vamb.taxvamb_encode.make_dataloader_semisupervised_hloss":
+            assert args[0] is state["joint"] and args[1] is state["vamb"] and args[2] is state["labels"]
+            state["semi"] = vt.make_dataloader_semisupervised_hloss(*args, **kwargs)
+            assert state["semi"].batch_size == call["result"]["batch_size"]
+        elif name == "VAEVAEHLoss.trainmodel":
+            state["vae"].trainmodel(*args, **kwargs)
+            state["modelfile"].close()
+            assert (Path(tmp_path) / "vaevae_model.pt").stat().st_size > 0
+        elif name == "VAEJoint.encode":
+            latent = state["vae"].VAEJoint.encode(*args, **kwargs)
+            assert isinstance(latent, np.ndarray) and list(latent.shape) == call["result"]["shape"]
+            assert str(latent.dtype) == call["result"]["dtype"] and np.isfinite(latent).all()
+        else:
+            raise AssertionError(name)
+    assert latent is not None and gen_kwargs is not None
+
+    # (b) cluster_and_write_files (vamb/__main__.py:2055-2066 -> 1254-1404) on the latent the REFERENCE wrote
+    opts = types.SimpleNamespace(window_size=gen_kwargs["windowsize"], min_successes=gen_kwargs["minsuccesses"], max_clusters=None)
+    base = str(Path(tmp_path) / "vaevae_clusters")
+    output.cluster_and_write_files(opts, _BinSplitter(c["binsplit"]), g["latent"].copy(), names, lens32, gen_kwargs["rng_seed"],
+                                   gen_kwargs["cuda"], base, None, None)
+    assert open(base + "_metadata.tsv").read() == str(g["metadata_tsv"])
+    assert open(base + "_unsplit.tsv").read() == str(g["unsplit_tsv"])
+    a, b = open(base + "_split.tsv").read().splitlines(), str(g["split_tsv"]).splitlines()
+    assert a[0] == b[0] and sorted(a) == sorted(b)
+
+    # (c) free-running
+    base2 = str(Path(tmp_path) / "free")
+    output.cluster_and_write_files(opts, _BinSplitter(c["binsplit"]), latent.copy(), names, lens32, gen_kwargs["rng_seed"], False,
+                                   base2, None, None)
+    meta = open(base2 + "_metadata.tsv").read().splitlines()[1:]
+    q = fd.bin_quality(labels, _clusters_of(open(base2 + "_unsplit.tsv").read(), names), [l.split("\t")[3] for l in meta])
+    last = state["vae"].last_epoch_metrics["loss"]
+    ref_last = g["spread_loss_last"]
+    assert abs(last - ref_last.mean()) < max(3 * (ref_last.max() - ref_last.min()), 2e-2), (last, ref_last)
+    assert q["ari"] >= g["spread_ari"].min() - 0.05, (q["ari"], g["spread_ari"])
+    assert q["purity_big"] >= g["spread_purity_big"].min() - 0.02
+    assert 0.6 * g["spread_n_clusters"].min() <= q["n_clusters"] <= 1.5 * g["spread_n_clusters"].max(), q["n_clusters"]
+    assert q["genomes_recovered"] >= g["spread_genomes_recovered"].min() - 3
