@@ -173,6 +173,10 @@ VAE_CASES = {
     # item 6: the bf16 step is judged at the benchmarked shape against the REAL reference, not only against the fp64 restatement)
     "vae_c2_shape": dict(n=8192, batch=8192, nsamples=200, nhiddens=[512, 512], nlatent=32, dropout=0.2,
                          alpha=None, beta=200.0, seed=27, steps=2, store="summary", rows_keep=96, store_inputs=False),
+    # BASELINE configs[3]'s shape: 1000 samples (D = 1104), batch 8192 -- the wide-input schedule of the bf16 step (fork plan by
+    # input width, no next-batch prefetch, K = 1120 GEMMs) against the REAL reference as well
+    "vae_c3_shape": dict(n=8192, batch=8192, nsamples=1000, nhiddens=[512, 512], nlatent=32, dropout=0.2,
+                         alpha=None, beta=200.0, seed=28, steps=2, store="summary", rows_keep=96, store_inputs=False),
 }
 
 

@@ -469,7 +469,7 @@ def test_free_running_training_learns():
     assert np.isfinite(lat).all() and lat.std() > 1e-3
 
 
-@pytest.mark.parametrize("name", ["vae_c1_shape", "vae_c2_shape"])
+@pytest.mark.parametrize("name", ["vae_c1_shape", "vae_c2_shape", "vae_c3_shape"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_c1_shape_steps_match_the_reference_golden(dtype, name, monkeypatch):
     """BASELINE configs[1] as the REAL reference computes it (tests/golden/vae_c1_shape.npz: batch 4096, 50 samples, D = 154, default
