@@ -8,8 +8,13 @@ twice (state carried over the back edge).  Forward branches are ignored (both si
 
     python vamb_amd/csrc/isa_pending_loads.py vae.s [<mangled-name-substring>] [--all-loads]
 
-By default only loads whose destination is NOT read before the next s_waitcnt are tracked as "hand-waited"; --all-loads tracks
-every load (the compiler's own loads then never trigger, because it waits before their first use).
+Only loads between the ;;#ASMSTART / ;;#ASMEND markers of inline asm are tracked with their registers (the compiler waits for its
+own loads before it touches their registers, by construction); every vector-memory operation takes its place in the in-order
+queue that s_waitcnt vmcnt(n) retires.  --all-loads tracks the compiler's loads as well (noisy: the linear walk does not follow
+its branches).  Because the queue is retired by COUNT, the check covers the hand-counted waits themselves: a wait that waits for
+too little leaves the consuming instruction (an MFMA reading a tile register) flagged.  Limitation: control flow is not analysed --
+a wait inside a conditionally executed region is assumed to have run; the kernels checked here wait unconditionally in front of
+every consumer.
 """
 import re
 import sys
